@@ -1,0 +1,195 @@
+/* tendon_hip.h -- C ABI of libtendon_hip.so: the MI355X (gfx950) batched tendon-robot
+ * forward-kinematics + voxel-collision engine.
+ *
+ * This is the drop-in boundary for the reference's hot path (paths relative to the reference's
+ * cpp/src/).  Plain pointers and sizes only.  Every entry point cites the reference interface it
+ * stands in for; INTEGRATION.md shows the C++ shim (tendon::TendonRobot, collision::VoxelOctree,
+ * motion_planning::VoxelBackboneValidityChecker / VoxelBackboneMotionValidator) a maintainer
+ * adds on the reference side.
+ *
+ * Conventions
+ *   - every function returns a tr_status (0 = ok); tr_last_error(ctx) gives the message.  The
+ *     statuses map 1:1 to the C++ exception types the reference throws at the same conditions.
+ *   - "states" are the reference's robot states: n x S row-major doubles,
+ *     [tau_1..tau_N, (theta if enable_rotation), (s_start if enable_retraction)]
+ *     (tendon/TendonRobot.h:105-115, motion-planning/AbstractValidityChecker.cpp:50-78).
+ *   - *_dev entry points take DEVICE pointers and a hipStream_t (as void*); they enqueue work and
+ *     return without synchronising.  The host-pointer forms copy in/out and synchronise.
+ *   - validity bitmasks: bit (i & 63) of word (i >> 6) is configuration i; padding bits are 0.
+ *   - non-convergence / NaN in a lane is not an error: that configuration is simply invalid.
+ */
+#ifndef TENDON_HIP_H
+#define TENDON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TR_MAX_TENDONS 8
+#define TR_MAX_COEF    8
+
+typedef enum {
+  TR_OK                = 0,
+  TR_ERR_INVALID_ARG   = 1,  /* std::invalid_argument: state size, dims, dL vs voxel size ...   */
+  TR_ERR_OUT_OF_RANGE  = 2,  /* std::out_of_range: tendon / tau count mismatch                  */
+  TR_ERR_DOMAIN        = 3,  /* std::domain_error: point outside the voxel domain (find_cell)   */
+  TR_ERR_LENGTH        = 4,  /* std::length_error: non-positive voxel limits                    */
+  TR_ERR_RUNTIME       = 5,  /* std::runtime_error                                              */
+  TR_ERR_HIP           = 6,  /* HIP runtime failure (message carries hipGetErrorString)          */
+  TR_ERR_UNSUPPORTED   = 7   /* feature of the reference not offered by this build              */
+} tr_status;
+
+/* tendon::TendonRobot + BackboneSpecs + TendonSpecs (tendon/TendonRobot.h:52-58,
+ * tendon/BackboneSpecs.h:14-20, tendon/TendonSpecs.h:25-30).  All tendons share n_a = C.size()
+ * and n_m = D.size(), as get_r_info assumes (tendon/get_r_info.cpp:112-115). */
+typedef struct {
+  double  r;                       /* robot radius (m)                                         */
+  double  L, dL, ro, ri, E, nu;    /* backbone                                                  */
+  int32_t n_tendons, n_a, n_m;
+  const double *C;                 /* n_tendons x n_a row-major: theta_i(t) = sum C[i][k] t^k   */
+  const double *D;                 /* n_tendons x n_m row-major: rho_i(t)   = sum D[i][k] t^k   */
+  const double *max_tension;       /* [n_tendons]                                               */
+  const double *min_length;        /* [n_tendons]                                               */
+  const double *max_length;        /* [n_tendons]                                               */
+  int32_t enable_rotation, enable_retraction;
+  double  residual_threshold;
+} tr_robot_desc;
+
+typedef struct tr_ctx tr_ctx;
+
+/* flag bits written per configuration by the validate calls (optional output) */
+#define TR_FLAG_CONVERGED   1u   /* fk.converged && home.converged                               */
+#define TR_FLAG_LENGTH_OK   2u   /* is_within_length_limits                                      */
+#define TR_FLAG_NO_SELFCOL  4u   /* !collides_self                                               */
+#define TR_FLAG_NO_VOXCOL   8u   /* !collides(voxelize(fk))                                      */
+#define TR_FLAG_DOMAIN     16u   /* a backbone point was non-finite or absurdly far outside the
+                                    voxel domain (reference: undefined behaviour); forced invalid */
+
+/* ---- life cycle ------------------------------------------------------------------------- */
+
+/* Replaces constructing a tendon::TendonRobot (TendonRobot::from_toml, tendon/TendonRobot.cpp:1033-1089)
+ * plus the per-call constants of tension_shape (get_stiffness_matrices, t_range,
+ * tendon/TendonRobot.cpp:69-84,105-148).  device = HIP device ordinal. */
+int tr_create(const tr_robot_desc *robot, int device, tr_ctx **out);
+void tr_destroy(tr_ctx *ctx);
+const char *tr_last_error(const tr_ctx *ctx);   /* ctx may be NULL: last create error */
+
+int tr_state_size(const tr_ctx *ctx);           /* TendonRobot::state_size, TendonRobot.h:60-64 */
+int tr_num_points(const tr_ctx *ctx);           /* |t_range(0, L, dL)| = max backbone points    */
+int tr_device(const tr_ctx *ctx);
+
+/* Home shape tendon lengths at s_start = 0 (TendonRobot::home_shape, tendon/TendonRobot.cpp:249-314) */
+int tr_home_lengths(const tr_ctx *ctx, double *L_i /*[n_tendons]*/);
+
+/* Replaces the VoxelOctree obstacle member + VoxelEnvironment rotation held by the voxel
+ * validity checkers (motion-planning/AbstractVoxelValidityChecker.h:63-64,
+ * VoxelEnvironment.cpp:129-131).  blocks: HOST pointer, Nb^3 uint64 (Nb = N/4), index
+ * ((bx*Nb)+by)*Nb+bz, bit x*16+y*4+z inside a block (collision/VoxelOctree.cpp:1501-1503).
+ * lim = {xmin,xmax,ymin,ymax,zmin,zmax}.  inv_rot: row-major 3x3 (NULL = identity).
+ * Fails with TR_ERR_INVALID_ARG when dL > max voxel edge, as VoxelBackboneValidityChecker's
+ * constructor does (motion-planning/VoxelBackboneValidityChecker.h:37-45). */
+int tr_set_grid(tr_ctx *ctx, uint32_t N, const double lim[6], const uint64_t *blocks,
+                const double inv_rot[9]);
+
+/* Pre-size the device workspace for batches of up to n configurations (optional; the batch
+ * calls grow it on demand, which allocates and therefore synchronises). */
+int tr_reserve(tr_ctx *ctx, int64_t n);
+
+/* ---- forward kinematics: TendonRobot::shape / forward_kinematics ------------------------ */
+
+/* Batched TendonRobot::shape(state) (tendon/TendonRobot.h:105-131 -> tension_shape,
+ * tendon/TendonRobot.cpp:325-500), replacing the omp-parallel loops at
+ * apps/estimate_length_discretization.cpp:62-71 and apps/roadmap2samples.cpp:65-78.
+ * Host buffers; any output pointer may be NULL.
+ *   p         n x P x 3   backbone points (rows past n_points[i] are NaN), P = tr_num_points
+ *   R         n x P x 9   rotation matrices, column-major per matrix (Eigen layout)
+ *   L, L_i    n, n x N    backbone / tendon lengths
+ *   converged n           TendonResult::converged
+ *   n_points  n           points of configuration i (P unless retraction shortens it)      */
+int tr_fk_batch(tr_ctx *ctx, const double *states, int64_t n,
+                double *p, double *R, double *L, double *L_i, uint8_t *converged, int32_t *n_points);
+
+/* Device form.  Points are written structure-of-arrays, lane-contiguous:
+ * d_px[j*ld + i] is x of point j of configuration i (ld >= n, multiple of 64).  d_R (optional)
+ * is [9][P][ld].  d_Li is [N][ld]. */
+int tr_fk_batch_dev(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld,
+                    double *d_px, double *d_py, double *d_pz, double *d_R,
+                    double *d_L, double *d_Li, uint8_t *d_converged, int32_t *d_n_points,
+                    void *stream);
+
+/* ---- state validity: StateValidityChecker::isValid -------------------------------------- */
+
+/* Batched AbstractValidityChecker::isValid (motion-planning/AbstractValidityChecker.cpp:124-133)
+ * with VoxelBackboneValidityChecker::voxelize_impl + collides
+ * (VoxelBackboneValidityChecker.h:49-57, AbstractVoxelValidityChecker.h:55-57): FK, converged,
+ * tendon-length limits, self-collision, backbone voxelisation vs the obstacle grid.  Replaces the
+ * loops at motion-planning/VoxelCachedLazyPRM.cpp:1448-1455 and :1584-1591.
+ *   valid_bits  ceil(n/64) words
+ *   tips        n x 3 (optional)  fk_shape.p.back() (VoxelCachedLazyPRM.cpp:1438)
+ *   flags       n (optional)      TR_FLAG_* bits                                            */
+int tr_validate_batch(tr_ctx *ctx, const double *states, int64_t n,
+                      uint64_t *valid_bits, double *tips, uint8_t *flags);
+int tr_validate_batch_dev(tr_ctx *ctx, const double *d_states, int64_t n,
+                          uint64_t *d_valid_bits, double *d_tips, uint8_t *d_flags, void *stream);
+
+/* The second stage alone, on caller-supplied backbone shapes (is_valid_shape + voxelize +
+ * collides on given TendonResults: AbstractValidityChecker.cpp:99-122).  Device pointers, SoA as
+ * produced by tr_fk_batch_dev.  d_n_points may be NULL (all P).  check_voxels = 0 skips the
+ * obstacle test (the "is_valid_shape only" predicate used while voxelising edges,
+ * VoxelBackboneMotionValidator.cpp:29-36). */
+int tr_validate_shapes_dev(tr_ctx *ctx, int64_t n, int64_t ld,
+                           const double *d_px, const double *d_py, const double *d_pz,
+                           const int32_t *d_n_points, const double *d_Li, const uint8_t *d_converged,
+                           int check_voxels, uint64_t *d_valid_bits, uint8_t *d_flags, void *stream);
+
+/* ---- motion validity: MotionValidator::checkMotion -------------------------------------- */
+
+typedef struct {
+  double min_tension_change;     /* motion-planning/Problem.h:59 (0.02)   */
+  double min_rotation_change;    /* :61 (0.01)                            */
+  double min_retraction_change;  /* :62 (0.0001)                          */
+} tr_space_params;
+
+/* Batched AbstractVoxelMotionValidator::checkMotion(s1, s2)
+ * (motion-planning/AbstractVoxelMotionValidator.h:143-151 -> VoxelBackboneMotionValidator.cpp:41-81
+ * -> VoxelEnvironment::voxelize_valid_backbone_motion, VoxelEnvironment.cpp:207-444), replacing
+ * the loops at VoxelCachedLazyPRM.cpp:1520-1542 and :1621-1641.  a, b: n_edges x S host states.
+ * n_fk (optional) receives the number of FK samples taken per edge.
+ * An edge whose samples leave the voxel domain (std::domain_error in the reference) is reported
+ * invalid and counted in *n_domain_errors (optional). */
+int tr_validate_edges(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
+                      int64_t n_edges, uint64_t *valid_bits, int32_t *n_fk, int64_t *n_domain_errors);
+
+/* ---- cached voxel sets vs obstacles: VoxelOctree::collides on roadmap caches ------------ */
+
+/* Batched `obstacles.collides(*cached_voxels)` for roadmap vertices / edges
+ * (motion-planning/VoxelCachedLazyPRM.cpp:2397-2411, :2497-2509, :2607-2631).  Items are sparse
+ * block lists in CSR form: item i owns entries offsets[i]..offsets[i+1]-1 of (block_ids, masks);
+ * block id = ((bx*Nb)+by)*Nb+bz.  hit_bits: ceil(n_items/64) words, bit set = collides. */
+int tr_check_cached(tr_ctx *ctx, const uint32_t *block_ids, const uint64_t *masks,
+                    const int64_t *offsets, int64_t n_items, uint64_t *hit_bits);
+int tr_check_cached_dev(tr_ctx *ctx, const uint32_t *d_block_ids, const uint64_t *d_masks,
+                        const int64_t *d_offsets, int64_t n_items, uint64_t *d_hit_bits, void *stream);
+
+/* ---- instrumentation ---------------------------------------------------------------------- */
+
+/* Time the last `which` kernel launches with HIP events on the stream they ran on.
+ * tr_profile_begin enables event recording around every kernel launched by this context;
+ * tr_profile_read returns, per kernel slot, launches and total milliseconds since begin.
+ * slots: 0 = fk_rk4_batch, 1 = backbone_voxel_sweep, 2 = cached_blocks_vs_grid, 3 = edge helpers */
+#define TR_PROFILE_SLOTS 4
+int tr_profile_begin(tr_ctx *ctx);
+int tr_profile_read(tr_ctx *ctx, int64_t launches[TR_PROFILE_SLOTS], double total_ms[TR_PROFILE_SLOTS]);
+int tr_profile_end(tr_ctx *ctx);
+
+/* debug / A-B switches (tests): bit0 = brute-force O(P^2) self-collision instead of the
+ * conservative-skip sweep (verdicts must be identical) */
+int tr_set_debug(tr_ctx *ctx, uint32_t bits);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TENDON_HIP_H */

@@ -1,0 +1,161 @@
+"""ctypes binding of libtendon_hip.so (the C ABI declared in include/tendon_hip.h).
+
+There is no CPU fallback: if the shared library is missing or no HIP device is present the
+functions that need it raise, loudly.  `build()` compiles the library in-tree with hipcc for
+gfx950 (cross-compiles without a GPU).
+"""
+import ctypes as C
+import os
+import subprocess
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_ROOT = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libtendon_hip.so")
+SRC_DIR = os.path.join(_PKG, "csrc")
+HEADER = os.path.join(_ROOT, "include", "tendon_hip.h")
+
+TR_OK, TR_ERR_INVALID_ARG, TR_ERR_OUT_OF_RANGE, TR_ERR_DOMAIN, TR_ERR_LENGTH, TR_ERR_RUNTIME, \
+    TR_ERR_HIP, TR_ERR_UNSUPPORTED = range(8)
+
+TR_FLAG_CONVERGED, TR_FLAG_LENGTH_OK, TR_FLAG_NO_SELFCOL, TR_FLAG_NO_VOXCOL, TR_FLAG_DOMAIN = 1, 2, 4, 8, 16
+TR_PROFILE_SLOTS = 4
+PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_grid", "edge_helpers")
+
+# every symbol include/tendon_hip.h declares (tests check the .so exports exactly these)
+ABI_SYMBOLS = (
+    "tr_create", "tr_destroy", "tr_last_error", "tr_state_size", "tr_num_points", "tr_device",
+    "tr_home_lengths", "tr_set_grid", "tr_reserve", "tr_fk_batch", "tr_fk_batch_dev",
+    "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges",
+    "tr_check_cached", "tr_check_cached_dev", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
+    "tr_set_debug",
+)
+
+
+class TrRobotDesc(C.Structure):
+    _fields_ = [
+        ("r", C.c_double),
+        ("L", C.c_double), ("dL", C.c_double), ("ro", C.c_double), ("ri", C.c_double),
+        ("E", C.c_double), ("nu", C.c_double),
+        ("n_tendons", C.c_int32), ("n_a", C.c_int32), ("n_m", C.c_int32),
+        ("C", C.POINTER(C.c_double)), ("D", C.POINTER(C.c_double)),
+        ("max_tension", C.POINTER(C.c_double)), ("min_length", C.POINTER(C.c_double)),
+        ("max_length", C.POINTER(C.c_double)),
+        ("enable_rotation", C.c_int32), ("enable_retraction", C.c_int32),
+        ("residual_threshold", C.c_double),
+    ]
+
+
+class TrSpaceParams(C.Structure):
+    _fields_ = [("min_tension_change", C.c_double), ("min_rotation_change", C.c_double),
+                ("min_retraction_change", C.c_double)]
+
+
+class TendonHipError(RuntimeError):
+    """Base for errors reported by libtendon_hip (status + tr_last_error text)."""
+    status = TR_ERR_RUNTIME
+
+
+# status -> Python exception mirroring the C++ exception type the reference throws
+class InvalidArgument(TendonHipError, ValueError):      # std::invalid_argument
+    status = TR_ERR_INVALID_ARG
+
+
+class OutOfRange(TendonHipError, IndexError):           # std::out_of_range
+    status = TR_ERR_OUT_OF_RANGE
+
+
+class DomainError(TendonHipError, ArithmeticError):     # std::domain_error
+    status = TR_ERR_DOMAIN
+
+
+class LengthError(TendonHipError, ValueError):          # std::length_error
+    status = TR_ERR_LENGTH
+
+
+class HipError(TendonHipError):
+    status = TR_ERR_HIP
+
+
+class Unsupported(TendonHipError, NotImplementedError):
+    status = TR_ERR_UNSUPPORTED
+
+
+_EXC = {TR_ERR_INVALID_ARG: InvalidArgument, TR_ERR_OUT_OF_RANGE: OutOfRange, TR_ERR_DOMAIN: DomainError,
+        TR_ERR_LENGTH: LengthError, TR_ERR_RUNTIME: TendonHipError, TR_ERR_HIP: HipError,
+        TR_ERR_UNSUPPORTED: Unsupported}
+
+
+def hipcc_command(out=LIB_PATH):
+    return ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+            "-o", out, os.path.join(SRC_DIR, "tendon_hip.hip")]
+
+
+def _sources():
+    return [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))] + [HEADER]
+
+
+def build(force=False, verbose=False):
+    """Compile libtendon_hip.so in-tree for gfx950 if it is missing or older than its sources."""
+    if not force and os.path.exists(LIB_PATH):
+        t = os.path.getmtime(LIB_PATH)
+        if all(os.path.getmtime(s) <= t for s in _sources()):
+            return LIB_PATH
+    cmd = hipcc_command()
+    if verbose:
+        print(" ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    """Load libtendon_hip.so (after torch, so both share one HIP runtime). Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libtendon_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`. "
+            "There is no CPU fallback for this engine." % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (loads the HIP runtime this process will share)
+    except Exception:
+        pass
+    L = C.CDLL(LIB_PATH)
+    P = C.POINTER
+    vp, i64, dp = C.c_void_p, C.c_int64, C.POINTER(C.c_double)
+    L.tr_create.argtypes = [P(TrRobotDesc), C.c_int, P(vp)]
+    L.tr_destroy.argtypes = [vp]
+    L.tr_destroy.restype = None
+    L.tr_last_error.argtypes = [vp]
+    L.tr_last_error.restype = C.c_char_p
+    for f in ("tr_state_size", "tr_num_points", "tr_device"):
+        getattr(L, f).argtypes = [vp]
+    L.tr_home_lengths.argtypes = [vp, dp]
+    L.tr_set_grid.argtypes = [vp, C.c_uint32, dp, P(C.c_uint64), dp]
+    L.tr_reserve.argtypes = [vp, i64]
+    L.tr_fk_batch.argtypes = [vp, dp, i64, dp, dp, dp, dp, P(C.c_uint8), P(C.c_int32)]
+    L.tr_fk_batch_dev.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tr_validate_batch.argtypes = [vp, dp, i64, P(C.c_uint64), dp, P(C.c_uint8)]
+    L.tr_validate_batch_dev.argtypes = [vp, vp, i64, vp, vp, vp, vp]
+    L.tr_validate_shapes_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.tr_validate_edges.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(C.c_uint64), P(C.c_int32), P(i64)]
+    L.tr_check_cached.argtypes = [vp, P(C.c_uint32), P(C.c_uint64), P(i64), i64, P(C.c_uint64)]
+    L.tr_check_cached_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.tr_profile_begin.argtypes = [vp]
+    L.tr_profile_read.argtypes = [vp, P(i64), dp]
+    L.tr_profile_end.argtypes = [vp]
+    L.tr_set_debug.argtypes = [vp, C.c_uint32]
+    _lib = L
+    return L
+
+
+def check(ctx, status):
+    """Raise the Python exception matching a non-zero tr_status."""
+    if status == TR_OK:
+        return
+    msg = lib().tr_last_error(ctx)
+    msg = msg.decode() if msg else "status %d" % status
+    raise _EXC.get(status, TendonHipError)(msg)

@@ -1,0 +1,177 @@
+"""Host-side mirror of collision::VoxelOctree (cpp/src/collision/VoxelOctree.h:68-330) as the
+engine consumes it: a DENSE array of 64-bit blocks (4x4x4 voxels each, bit x*16+y*4+z,
+VoxelOctree.cpp:1501-1503), block index ((bx*Nb)+by)*Nb+bz.  Only what the hot path needs on
+the host: limits, cell/block access, rasterising an obstacle environment (points, spheres), the
+sparse (block id, mask) export used for roadmap voxel caches.  Robot voxelisation and the
+octree-vs-octree test run on the GPU (sweep_kernel.hpp).
+"""
+import numpy as np
+
+from . import _lib as L
+
+_SUPPORTED = (4, 8, 16, 32, 64, 128, 256, 512)
+
+
+class VoxelOctree:
+    def __init__(self, Ndim=4):
+        if Ndim not in _SUPPORTED:                         # VoxelOctree.cpp:98-116
+            raise L.InvalidArgument("unsupported voxel dimension: %d" % Ndim)
+        self._N = int(Ndim)
+        nb = self._N // 4
+        self.blocks = np.zeros((nb, nb, nb), dtype=np.uint64)
+        self.set_xlim(0.0, 1.0)
+        self.set_ylim(0.0, 1.0)
+        self.set_zlim(0.0, 1.0)
+
+    @staticmethod
+    def to_supported_size(Ndim):                           # VoxelOctree.cpp:82-96
+        for s in _SUPPORTED:
+            if Ndim <= s:
+                return s
+        raise L.InvalidArgument("too large for supported voxel octree: %d" % Ndim)
+
+    # sizes ------------------------------------------------------------------------------------
+    def Nx(self): return self._N
+    def Ny(self): return self._N
+    def Nz(self): return self._N
+    def N(self): return self._N ** 3
+    def Nbx(self): return self._N // 4
+    def Nb(self): return self._N ** 3 // 64
+
+    # limits (VoxelOctree.cpp:152-177) ------------------------------------------------------------
+    def _set(self, axis, lo, hi):
+        if lo >= hi:
+            raise L.LengthError("%slimits must be positive in size" % axis)
+        setattr(self, "_%smin" % axis, float(lo))
+        setattr(self, "_%smax" % axis, float(hi))
+        setattr(self, "_d%s" % axis, (float(hi) - float(lo)) / self._N)
+
+    def set_xlim(self, lo, hi=None):
+        self._set("x", *(lo if hi is None else (lo, hi)))
+
+    def set_ylim(self, lo, hi=None):
+        self._set("y", *(lo if hi is None else (lo, hi)))
+
+    def set_zlim(self, lo, hi=None):
+        self._set("z", *(lo if hi is None else (lo, hi)))
+
+    def xlim(self): return (self._xmin, self._xmax)
+    def ylim(self): return (self._ymin, self._ymax)
+    def zlim(self): return (self._zmin, self._zmax)
+    def limits(self): return (self._xmin, self._xmax, self._ymin, self._ymax, self._zmin, self._zmax)
+    def dx(self): return self._dx
+    def dy(self): return self._dy
+    def dz(self): return self._dz
+
+    def copy_limits(self, other):
+        for a in ("_xmin", "_xmax", "_ymin", "_ymax", "_zmin", "_zmax", "_dx", "_dy", "_dz"):
+            setattr(self, a, getattr(other, a))
+
+    def empty_copy(self):                                  # VoxelOctree.cpp:146-150
+        c = VoxelOctree(self._N)
+        c.copy_limits(self)
+        return c
+
+    def __eq__(self, other):
+        return (isinstance(other, VoxelOctree) and self._N == other._N and self.limits() == other.limits()
+                and np.array_equal(self.blocks, other.blocks))
+
+    # cells / blocks ---------------------------------------------------------------------------------
+    @staticmethod
+    def bitmask(x, y, z):                                  # VoxelOctree.cpp:1501-1503
+        return np.uint64(1) << np.uint64(x * 16 + y * 4 + z)
+
+    def block(self, bx, by, bz):
+        return int(self.blocks[bx, by, bz])
+
+    def set_block(self, bx, by, bz, value):
+        self.blocks[bx, by, bz] = np.uint64(value)
+
+    def cell(self, ix, iy, iz):
+        return bool(self.blocks[ix // 4, iy // 4, iz // 4] & self.bitmask(ix % 4, iy % 4, iz % 4))
+
+    def set_cell(self, ix, iy, iz, value=True):            # VoxelOctree.cpp:256-265
+        m = self.bitmask(ix % 4, iy % 4, iz % 4)
+        old = self.blocks[ix // 4, iy // 4, iz // 4]
+        self.blocks[ix // 4, iy // 4, iz // 4] = (old | m) if value else (old & ~m)
+        return bool(old & m) if value else bool(old & ~m)
+
+    def is_empty(self): return not self.blocks.any()
+    def nblocks(self): return int(np.count_nonzero(self.blocks))
+
+    def ncells(self):
+        return int(np.unpackbits(self.blocks.view(np.uint8)).sum())
+
+    def is_in_domain(self, x, y, z):                       # VoxelOctree.cpp:1505-1509 (closed)
+        return (self._xmin <= x <= self._xmax) and (self._ymin <= y <= self._ymax) and (self._zmin <= z <= self._zmax)
+
+    def nearest_cell(self, x, y, z):                       # VoxelOctree.cpp:295-307 (truncate, clamp)
+        m = self._N - 1
+        f = lambda v, lo, d: min(m, max(0, int((v - lo) / d)))
+        return f(x, self._xmin, self._dx), f(y, self._ymin, self._dy), f(z, self._zmin, self._dz)
+
+    def find_cell(self, x, y, z):                          # VoxelOctree.cpp:309-317, 1511-1521
+        for v, lo, hi, name in ((x, self._xmin, self._xmax, "x"), (y, self._ymin, self._ymax, "y"),
+                                (z, self._zmin, self._zmax, "z")):
+            if v < lo or hi < v:
+                raise L.DomainError("%s is out of the voxel dimensions" % name)
+        return (int((x - self._xmin) / self._dx), int((y - self._ymin) / self._dy), int((z - self._zmin) / self._dz))
+
+    def _nearest_block_idx(self, x, y, z):                 # VoxelOctree.cpp:281-293
+        m = self._N // 4 - 1
+        f = lambda v, lo, d: min(m, max(0, int(int((v - lo) / d) / 4)))
+        return f(x, self._xmin, self._dx), f(y, self._ymin, self._dy), f(z, self._zmin, self._dz)
+
+    # rasterisation of the obstacle environment -----------------------------------------------------
+    def add_point(self, p):                                # VoxelOctree.cpp:319-323
+        x, y, z = map(float, p)
+        if self.is_in_domain(x, y, z):
+            self.set_cell(*self.nearest_cell(x, y, z))
+
+    def add_sphere(self, c, r):
+        """Voxel centres inside the sphere (VoxelOctree.cpp:434-469; |c - p|^2 <= r^2, collision.hxx:65-68)."""
+        c = np.asarray(c, dtype=np.float64)
+        r = float(r)
+        self.add_point(c)
+        lo = self._nearest_block_idx(*(c - r))
+        hi = self._nearest_block_idx(*(c + r))
+        ix = np.arange(lo[0] * 4, hi[0] * 4 + 4)
+        iy = np.arange(lo[1] * 4, hi[1] * 4 + 4)
+        iz = np.arange(lo[2] * 4, hi[2] * 4 + 4)
+        x = self._xmin + self._dx * (ix + 0.5)
+        y = self._ymin + self._dy * (iy + 0.5)
+        z = self._zmin + self._dz * (iz + 0.5)
+        ddx, ddy, ddz = c[0] - x, c[1] - y, c[2] - z
+        d2 = ((ddx * ddx)[:, None, None] + (ddy * ddy)[None, :, None]) + (ddz * ddz)[None, None, :]
+        inside = d2 <= r * r
+        nbx, nby, nbz = len(ix) // 4, len(iy) // 4, len(iz) // 4
+        cells = inside.reshape(nbx, 4, nby, 4, nbz, 4).transpose(0, 2, 4, 1, 3, 5).reshape(nbx, nby, nbz, 64)
+        w = (np.uint64(1) << np.arange(64, dtype=np.uint64))
+        masks = (cells.astype(np.uint64) * w).sum(axis=-1, dtype=np.uint64)
+        self.blocks[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] |= masks
+
+    def add_voxels(self, other):
+        if other._N != self._N:
+            raise L.InvalidArgument("voxel dimension mismatch (%d != %d)" % (self._N, other._N))
+        self.blocks |= other.blocks
+
+    def collides(self, other):
+        """Host form of VoxelOctree::collides (VoxelOctree.cpp:967-978) for small checks in tests."""
+        if isinstance(other, VoxelOctree):
+            if other._N != self._N:
+                raise L.InvalidArgument("voxel dimension mismatch (%d != %d)" % (self._N, other._N))
+            return bool((self.blocks & other.blocks).any())
+        x, y, z = map(float, other)
+        return self.is_in_domain(x, y, z) and self.cell(*self.nearest_cell(x, y, z))
+
+    # sparse export: what a roadmap voxel cache stores (VoxelCachedLazyPRM.cpp:986-1114 .rmp blocks) ---
+    def to_sparse(self):
+        ids = np.flatnonzero(self.blocks.reshape(-1)).astype(np.uint32)
+        return ids, self.blocks.reshape(-1)[ids].copy()
+
+    @classmethod
+    def from_sparse(cls, N, limits, ids, masks):
+        v = cls(N)
+        v.set_xlim(limits[0], limits[1]); v.set_ylim(limits[2], limits[3]); v.set_zlim(limits[4], limits[5])
+        v.blocks.reshape(-1)[np.asarray(ids, dtype=np.int64)] = np.asarray(masks, dtype=np.uint64)
+        return v

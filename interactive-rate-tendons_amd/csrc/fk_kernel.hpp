@@ -1,0 +1,353 @@
+// fk_kernel.hpp -- K1 `fk_rk4_batch`: one wavefront lane integrates one configuration's
+// Cosserat-rod ODE with classical RK4 along arc length.
+//
+// What it computes is TendonRobot::tension_shape (tendon/TendonRobot.cpp:325-500) for a batch:
+// solve_initial_bending (tendon/solve_initial_bending.cpp:14-73), then RK4 over the arc-length
+// grid with tendon_deriv (tendon/tendon_deriv.cpp:95-178) as right-hand side, then the base
+// residual test (TendonRobot.cpp:470-474), then rotate_z (tendon/TendonResult.cpp:13-18).
+//
+// How it computes it is specific to this engine:
+//  * the state lives in VGPRs for the whole integration (no per-step memory traffic); only the
+//    observed backbone points are stored, structure-of-arrays so a wavefront writes 512 contiguous
+//    bytes per coordinate;
+//  * with retraction disabled every configuration of the batch shares the arc-length grid, so the
+//    tendon routing r(s), r'(s), r''(s) (polynomial + sin/cos, get_r_info.cpp:105-144) is
+//    tabulated once on the host for the 3 distinct stage abscissae of every step and read through
+//    wave-uniform scalar loads (SGPR operands) -- no per-lane transcendental in the hot loop;
+//  * the right-hand side exploits structure the reference leaves to Eigen: r has no z component,
+//    A_i is symmetric, G = B^T, H is symmetric, K_se/K_bt are diagonal, and the 6x6 solve is a
+//    symmetric block (Schur) elimination with adjugate 3x3 inverses: [v';u'] = M^-1 [d;c] with
+//    M = [[K_se+A, B^T],[B, K_bt+H]];
+//  * (p, L, L_i) are pure quadratures (nothing depends on them), so they keep no stage copy.
+// fp64 throughout.  Contraction to FMA is enabled here (parity with the oracle is by tolerance:
+// tip position <= 1e-9 m, see tests/); the bit-exact integer/predicate stage lives in
+// sweep_kernel.hpp and is compiled without contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+
+namespace trk {
+
+// 1/x and 1/sqrt(x) from the hardware seed + two Newton steps (|rel err| ~ 1e-16).
+__device__ __forceinline__ double fast_rcp(double x) {
+  double y = __builtin_amdgcn_rcp(x);
+  double e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(e, y, y);
+  e = __builtin_fma(-x, y, 1.0);
+  y = __builtin_fma(e, y, y);
+  return y;
+}
+__device__ __forceinline__ double fast_rsqrt(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  // y <- y * (1.5 - 0.5 x y^2), twice
+  double hx = 0.5 * x;
+  double t = __builtin_fma(-hx * y, y, 0.5);
+  y = __builtin_fma(y, t, y);
+  t = __builtin_fma(-hx * y, y, 0.5);
+  y = __builtin_fma(y, t, y);
+  return y;
+}
+
+// Right-hand side for the strain part of the state: (v', u') and the length rates.
+// ri: wave-uniform pointer to N x 6 doubles {rx, ry, rdx, rdy, rddx, rddy} per tendon.
+template <int N>
+__device__ __forceinline__ void strain_rates(const double v[3], const double u[3], const double (&tau)[N],
+                                             const double *__restrict__ ri, const RobotK &K,
+                                             double dv[3], double du[3], double (&sdot)[N]) {
+#pragma clang fp contract(fast)
+  double Axx = 0, Axy = 0, Axz = 0, Ayy = 0, Ayz = 0, Azz = 0;
+  double B00 = 0, B01 = 0, B02 = 0, B10 = 0, B11 = 0, B12 = 0, B20 = 0, B21 = 0, B22 = 0;
+  double Hxx = 0, Hxy = 0, Hxz = 0, Hyy = 0, Hyz = 0, Hzz = 0;
+  double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    const double rx = ri[6 * j + 0], ry = ri[6 * j + 1];
+    const double rdx = ri[6 * j + 2], rdy = ri[6 * j + 3];
+    const double rddx = ri[6 * j + 4], rddy = ri[6 * j + 5];
+    // pd = u x r + r' + v
+    const double pdx = (v[0] + rdx) - u[2] * ry;
+    const double pdy = (v[1] + rdy) + u[2] * rx;
+    const double pdz = v[2] + (u[0] * ry - u[1] * rx);
+    const double xx = pdx * pdx, yy = pdy * pdy, zz = pdz * pdz;
+    const double s2 = xx + yy + zz;
+    const double rs = fast_rsqrt(s2);
+    sdot[j] = s2 * rs;
+    const double c = -tau[j] * (rs * rs * rs);
+    // A_i = c * hat(pd)^2
+    const double aixx = -c * (yy + zz), aiyy = -c * (xx + zz), aizz = -c * (xx + yy);
+    const double aixy = c * (pdx * pdy), aixz = c * (pdx * pdz), aiyz = c * (pdy * pdz);
+    // w = u x pd + u x r' + r''
+    const double qx = pdx + rdx, qy = pdy + rdy, qz = pdz;
+    const double wx = (u[1] * qz - u[2] * qy) + rddx;
+    const double wy = (u[2] * qx - u[0] * qz) + rddy;
+    const double wz = u[0] * qy - u[1] * qx;
+    const double aix = aixx * wx + aixy * wy + aixz * wz;
+    const double aiy = aixy * wx + aiyy * wy + aiyz * wz;
+    const double aiz = aixz * wx + aiyz * wy + aizz * wz;
+    // b_i = r x a_i (r_z = 0)
+    bx += ry * aiz; by -= rx * aiz; bz += rx * aiy - ry * aix;
+    ax += aix; ay += aiy; az += aiz;
+    // B_i = rhat A_i : rows (ry*A2, -rx*A2, rx*A1 - ry*A0)
+    const double b00 = ry * aixz, b01 = ry * aiyz, b02 = ry * aizz;
+    const double b10 = -rx * aixz, b11 = -rx * aiyz, b12 = -rx * aizz;
+    const double b20 = rx * aixy - ry * aixx, b21 = rx * aiyy - ry * aixy, b22 = rx * aiyz - ry * aixz;
+    // H_i = -B_i rhat (symmetric)
+    Hxx += ry * b02; Hxy -= rx * b02; Hyy -= rx * b12;
+    Hxz += rx * b01 - ry * b00; Hyz += rx * b11 - ry * b10; Hzz += rx * b21 - ry * b20;
+    Axx += aixx; Axy += aixy; Axz += aixz; Ayy += aiyy; Ayz += aiyz; Azz += aizz;
+    B00 += b00; B01 += b01; B02 += b02; B10 += b10; B11 += b11; B12 += b12; B20 += b20; B21 += b21; B22 += b22;
+  }
+  // c = -u x (K_bt u) - v x (K_se (v - e3)) - b ;  d = -u x (K_se (v - e3)) - a
+  const double kux = K.kb0 * u[0], kuy = K.kb0 * u[1], kuz = K.kb2 * u[2];
+  const double svx = K.ks0 * v[0], svy = K.ks0 * v[1], svz = K.ks2 * (v[2] - 1.0);
+  const double cx = -(u[1] * kuz - u[2] * kuy) - (v[1] * svz - v[2] * svy) - bx;
+  const double cy = -(u[2] * kux - u[0] * kuz) - (v[2] * svx - v[0] * svz) - by;
+  const double cz = -(u[0] * kuy - u[1] * kux) - (v[0] * svy - v[1] * svx) - bz;
+  const double dx = -(u[1] * svz - u[2] * svy) - ax;
+  const double dy = -(u[2] * svx - u[0] * svz) - ay;
+  const double dz = -(u[0] * svy - u[1] * svx) - az;
+  // M11 = K_se + A (symmetric); inverse by adjugate
+  const double m00 = K.ks0 + Axx, m01 = Axy, m02 = Axz, m11 = K.ks0 + Ayy, m12 = Ayz, m22 = K.ks2 + Azz;
+  const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
+  const double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
+  const double idet = fast_rcp(m00 * c00 + m01 * c01 + m02 * c02);
+  const double i00 = c00 * idet, i01 = c01 * idet, i02 = c02 * idet, i11 = c11 * idet, i12 = c12 * idet, i22 = c22 * idet;
+  // y = M11^-1 d
+  const double yx = i00 * dx + i01 * dy + i02 * dz;
+  const double yy_ = i01 * dx + i11 * dy + i12 * dz;
+  const double yz = i02 * dx + i12 * dy + i22 * dz;
+  // T = B M11^-1
+  const double T00 = B00 * i00 + B01 * i01 + B02 * i02, T01 = B00 * i01 + B01 * i11 + B02 * i12, T02 = B00 * i02 + B01 * i12 + B02 * i22;
+  const double T10 = B10 * i00 + B11 * i01 + B12 * i02, T11 = B10 * i01 + B11 * i11 + B12 * i12, T12 = B10 * i02 + B11 * i12 + B12 * i22;
+  const double T20 = B20 * i00 + B21 * i01 + B22 * i02, T21 = B20 * i01 + B21 * i11 + B22 * i12, T22 = B20 * i02 + B21 * i12 + B22 * i22;
+  // Schur complement S = (K_bt + H) - T B^T (symmetric)
+  const double s00 = (K.kb0 + Hxx) - (T00 * B00 + T01 * B01 + T02 * B02);
+  const double s01 = Hxy - (T00 * B10 + T01 * B11 + T02 * B12);
+  const double s02 = Hxz - (T00 * B20 + T01 * B21 + T02 * B22);
+  const double s11 = (K.kb0 + Hyy) - (T10 * B10 + T11 * B11 + T12 * B12);
+  const double s12 = Hyz - (T10 * B20 + T11 * B21 + T12 * B22);
+  const double s22 = (K.kb2 + Hzz) - (T20 * B20 + T21 * B21 + T22 * B22);
+  // rhs = c - B y
+  const double ex = cx - (B00 * yx + B01 * yy_ + B02 * yz);
+  const double ey = cy - (B10 * yx + B11 * yy_ + B12 * yz);
+  const double ez = cz - (B20 * yx + B21 * yy_ + B22 * yz);
+  // u' = S^-1 rhs (adjugate)
+  const double g00 = s11 * s22 - s12 * s12, g01 = s02 * s12 - s01 * s22, g02 = s01 * s12 - s02 * s11;
+  const double g11 = s00 * s22 - s02 * s02, g12 = s01 * s02 - s00 * s12, g22 = s00 * s11 - s01 * s01;
+  const double isd = fast_rcp(s00 * g00 + s01 * g01 + s02 * g02);
+  du[0] = (g00 * ex + g01 * ey + g02 * ez) * isd;
+  du[1] = (g01 * ex + g11 * ey + g12 * ez) * isd;
+  du[2] = (g02 * ex + g12 * ey + g22 * ez) * isd;
+  // v' = y - T^T u'
+  dv[0] = yx - (T00 * du[0] + T10 * du[1] + T20 * du[2]);
+  dv[1] = yy_ - (T01 * du[0] + T11 * du[1] + T21 * du[2]);
+  dv[2] = yz - (T02 * du[0] + T12 * du[1] + T22 * du[2]);
+}
+
+// solve_initial_bending + base residual.  Written without contraction and with IEEE div/sqrt so
+// the data-dependent iteration count follows the same decisions as a plain fp64 evaluation.
+// rb: wave-uniform pointer to N x 6 routing values at s_start (only the first 4 of each are used).
+template <int N>
+__device__ __forceinline__ void initial_bending(const double (&tau)[N], const double *__restrict__ rb,
+                                                const RobotK &K, double v[3], double u[3], bool &converged) {
+#pragma clang fp contract(off)
+  v[0] = 0; v[1] = 0; v[2] = 1;
+  u[0] = 0; u[1] = 0; u[2] = 0;
+  bool done = false;
+  for (int it = 0; it < 1000; ++it) {
+    if (!__any(!done)) break;
+    double Fx = 0, Fy = 0, Fz = 0, Lx = 0, Ly = 0, Lz = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const double rx = rb[6 * k + 0], ry = rb[6 * k + 1], rdx = rb[6 * k + 2], rdy = rb[6 * k + 3];
+      double px = (-u[2] * ry) + rdx + v[0];
+      double py = (u[2] * rx) + rdy + v[1];
+      double pz = (u[0] * ry - u[1] * rx) + v[2];
+      const double z = px * px + py * py + pz * pz;
+      if (z > 0.0) { const double s = sqrt(z); px = px / s; py = py / s; pz = pz / s; }
+      Fx -= tau[k] * px; Fy -= tau[k] * py; Fz -= tau[k] * pz;
+      // (tau * rhat) * unit, rhat = [[0,0,ry],[0,0,-rx],[-ry,rx,0]]
+      const double trx = tau[k] * rx, try_ = tau[k] * ry;
+      Lx -= try_ * pz; Ly -= (-trx) * pz; Lz -= ((-try_) * px + trx * py);
+    }
+    const double nx = K.ks0 * v[0], ny = K.ks0 * v[1], nz = K.ks2 * (v[2] - 1);
+    const double mx = K.kb0 * u[0], my = K.kb0 * u[1], mz = K.kb2 * u[2];
+    const double e1 = (nx - Fx) * (nx - Fx) + (ny - Fy) * (ny - Fy) + (nz - Fz) * (nz - Fz);
+    const double e2 = (mx - Lx) * (mx - Lx) + (my - Ly) * (my - Ly) + (mz - Lz) * (mz - Lz);
+    const double residual = sqrt(e1 + e2);
+    if (!done && residual < K.residual_threshold) done = true;
+    const double vnx = K.iks0 * Fx, vny = K.iks0 * Fy, vnz = K.iks2 * Fz + 1;
+    const double unx = K.ikb0 * Lx, uny = K.ikb0 * Ly, unz = K.ikb2 * Lz;
+    if (!done) {
+      const double dvn = sqrt((vnx - v[0]) * (vnx - v[0]) + (vny - v[1]) * (vny - v[1]) + (vnz - v[2]) * (vnz - v[2]));
+      const double dun = sqrt((unx - u[0]) * (unx - u[0]) + (uny - u[1]) * (uny - u[1]) + (unz - u[2]) * (unz - u[2]));
+      const double vn = sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+      const double un = sqrt(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+      if (dvn < 1e-9 * vn && dun < 1e-9 * un) done = true;
+    }
+    if (!done) { v[0] = vnx; v[1] = vny; v[2] = vnz; u[0] = unx; u[1] = uny; u[2] = unz; }
+  }
+  // base residual: PointForces::calc_point_forces with R = I (TendonRobot.cpp:188-217,470-474)
+  {
+    double Fx = 0, Fy = 0, Fz = 0, Lx = 0, Ly = 0, Lz = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+      const double rx = rb[6 * k + 0], ry = rb[6 * k + 1], rdx = rb[6 * k + 2], rdy = rb[6 * k + 3];
+      double px = (u[1] * 0.0 - u[2] * ry) + rdx + v[0];
+      double py = (u[2] * rx - u[0] * 0.0) + rdy + v[1];
+      double pz = (u[0] * ry - u[1] * rx) + 0.0 + v[2];
+      const double z = px * px + py * py + pz * pz;
+      if (z > 0.0) { const double s = sqrt(z); px = px / s; py = py / s; pz = pz / s; }
+      const double fx = -tau[k] * px, fy = -tau[k] * py, fz = -tau[k] * pz;
+      Fx += fx; Fy += fy; Fz += fz;
+      Lx += ry * fz - 0.0 * fy; Ly += 0.0 * fx - rx * fz; Lz += rx * fy - ry * fx;
+    }
+    const double nx = K.ks0 * v[0], ny = K.ks0 * v[1], nz = K.ks2 * (v[2] - 1);
+    const double mx = K.kb0 * u[0], my = K.kb0 * u[1], mz = K.kb2 * u[2];
+    const double e1 = (nx - Fx) * (nx - Fx) + (ny - Fy) * (ny - Fy) + (nz - Fz) * (nz - Fz);
+    const double e2 = (mx - Lx) * (mx - Lx) + (my - Ly) * (my - Ly) + (mz - Lz) * (mz - Lz);
+    converged = sqrt(e1 + e2) <= K.residual_threshold;
+  }
+}
+
+struct FkOut {
+  double *__restrict__ px, *__restrict__ py, *__restrict__ pz;   // [P][ld]
+  double *__restrict__ R;                                        // [9][P][ld] or null
+  double *__restrict__ L;                                        // [n] or null
+  double *__restrict__ Li;                                       // [N][ld] or null
+  double *__restrict__ tips;                                     // [n][3] or null
+  uint8_t *__restrict__ converged;                               // [n] or null
+  int32_t *__restrict__ n_points;                                // [n] or null
+};
+
+// K1 for the shared arc-length grid (retraction disabled).
+//   tab:   [(nsteps*3 + 1)][N][6] routing table; entry 0 = base (s_start), then 3 per step
+//   steps: [nsteps]
+template <int N, bool ROT, bool WRITE_R>
+__global__ __launch_bounds__(64) void fk_rk4_batch_uniform(
+    const double *__restrict__ states, int64_t n, int64_t ld, RobotK K,
+    const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, FkOut out) {
+#pragma clang fp contract(fast)
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = i < n;
+  const int64_t ic = live ? i : (n - 1);       // tail lanes recompute the last configuration, stores masked
+  const int S = K.state_size;
+  double tau[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) tau[j] = states[ic * S + j];
+  double rc = 1.0, rs = 0.0, r22 = 1.0;
+  if (ROT) {
+    const double th = states[ic * S + N];
+    rs = sin(th); rc = cos(th);
+    r22 = (1.0 - rc) + rc;                     // Eigen AngleAxis::toRotationMatrix diagonal term
+  }
+
+  double v[3], u[3];
+  bool conv;
+  initial_bending<N>(tau, tab, K, v, u, conv);
+
+  // state
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // column-major: R[c*3+r]
+  double p[3] = {0, 0, 0};
+  double Lb = 0;
+  double Li[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) Li[j] = 0;
+
+  auto store_point = [&](int j) {
+    if (!live) return;
+    const int64_t o = (int64_t)j * ld + i;
+    double x = p[0], y = p[1], z = p[2];
+    if (ROT) { const double x2 = rc * x - rs * y, y2 = rs * x + rc * y; x = x2; y = y2; z = r22 * z; }
+    out.px[o] = x; out.py[o] = y; out.pz[o] = z;
+    if (WRITE_R) {
+      const int64_t PS = (int64_t)K.n_points * ld;
+#pragma unroll
+      for (int c = 0; c < 3; c++) {
+        double a = R[c * 3 + 0], b = R[c * 3 + 1], cc = R[c * 3 + 2];
+        if (ROT) { const double a2 = rc * a - rs * b, b2 = rs * a + rc * b; a = a2; b = b2; cc = r22 * cc; }
+        out.R[(c * 3 + 0) * PS + o] = a; out.R[(c * 3 + 1) * PS + o] = b; out.R[(c * 3 + 2) * PS + o] = cc;
+      }
+    }
+  };
+  store_point(0);
+
+  for (int k = 0; k < nsteps; k++) {
+    const double h = steps[k].h;
+    const int obs = steps[k].obs;
+    const double *__restrict__ rt = tab + (size_t)(1 + 3 * k) * (N * 6);
+    const double hh = h * 0.5;
+    const double b1 = h * (1.0 / 6.0), b2 = h * (1.0 / 3.0);
+    // accumulators start at the current state
+    double aR[9], av[3], au[3];
+#pragma unroll
+    for (int q = 0; q < 9; q++) aR[q] = R[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { av[q] = v[q]; au[q] = u[q]; }
+    double sR[9], sv[3], su[3];                // stage state
+#pragma unroll
+    for (int q = 0; q < 9; q++) sR[q] = R[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { sv[q] = v[q]; su[q] = u[q]; }
+
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+      const double *__restrict__ ri = rt + (st == 0 ? 0 : (st == 3 ? 2 : 1)) * (N * 6);
+      const double bw = (st == 0 || st == 3) ? b1 : b2;      // weight of this stage in the update
+      const double aw = (st == 2) ? h : hh;                  // coefficient towards the next stage
+      double dv[3], du[3], sd[N];
+      strain_rates<N>(sv, su, tau, ri, K, dv, du, sd);
+      // quadratures: p' = R v, L' = |v|, L_i' = |pd_i|
+      p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
+      p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
+      p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);
+      {
+        const double v2 = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2];
+        Lb += bw * (v2 * fast_rsqrt(v2));
+      }
+#pragma unroll
+      for (int j = 0; j < N; j++) Li[j] += bw * sd[j];
+      // R' = R uhat : col0 = R1*uz - R2*uy ; col1 = R2*ux - R0*uz ; col2 = R0*uy - R1*ux
+      double dR[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const double r0 = sR[0 + r], r1 = sR[3 + r], r2 = sR[6 + r];
+        dR[0 + r] = r1 * su[2] - r2 * su[1];
+        dR[3 + r] = r2 * su[0] - r0 * su[2];
+        dR[6 + r] = r0 * su[1] - r1 * su[0];
+      }
+#pragma unroll
+      for (int q = 0; q < 9; q++) aR[q] += bw * dR[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { av[q] += bw * dv[q]; au[q] += bw * du[q]; }
+      if (st < 3) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) sR[q] = R[q] + aw * dR[q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { sv[q] = v[q] + aw * dv[q]; su[q] = u[q] + aw * du[q]; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) R[q] = aR[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { v[q] = av[q]; u[q] = au[q]; }
+    if (obs >= 0) store_point(obs);
+  }
+
+  if (live) {
+    if (out.L) out.L[i] = Lb;
+    if (out.Li) {
+#pragma unroll
+      for (int j = 0; j < N; j++) out.Li[(int64_t)j * ld + i] = Li[j];
+    }
+    if (out.converged) out.converged[i] = conv ? 1 : 0;
+    if (out.n_points) out.n_points[i] = K.n_points;
+    if (out.tips) {
+      double x = p[0], y = p[1], z = p[2];
+      if (ROT) { const double x2 = rc * x - rs * y, y2 = rs * x + rc * y; x = x2; y = y2; z = r22 * z; }
+      out.tips[3 * i + 0] = x; out.tips[3 * i + 1] = y; out.tips[3 * i + 2] = z;
+    }
+  }
+}
+
+}  // namespace trk

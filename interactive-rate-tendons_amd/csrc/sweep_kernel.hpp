@@ -1,0 +1,373 @@
+// sweep_kernel.hpp -- K2 `backbone_voxel_sweep`: the validity predicate on computed backbone
+// shapes, one wavefront lane per configuration, one verdict bit per lane gathered with a
+// wavefront ballot.
+//
+// Predicate (motion-planning/AbstractValidityChecker.cpp:99-133, short-circuit order kept):
+//   converged  &&  min_length <= L_home_i - L_i <= max_length  (tendon/TendonRobot.h:247-278)
+//   && !collides_self (collision/collision.cpp:6-46)
+//   && !obstacles.collides(voxelize(backbone))
+//      (VoxelBackboneValidityChecker.h:49-57 -> VoxelEnvironment.cpp:129-131 rotate_points ->
+//       VoxelOctree::add_piecewise_line/add_line, collision/VoxelOctree.cpp:325-432 ->
+//       VoxelOctree::collides :973-978)
+//
+// Everything in this file must give the SAME verdict as a plain IEEE fp64 evaluation of the
+// reference's statements on the same points: no FMA contraction (pragma below), IEEE division and
+// square root, the reference's evaluation order.  The robot's own voxel set is never materialised:
+// "obstacles.collides(robot_voxels)" is true iff any cell add_line would set is occupied, so each
+// visited cell is tested against the bit-packed obstacle grid as the DDA produces it (64-bit
+// blocks, 4x4x4 voxels, bit x*16+y*4+z -- VoxelOctree.cpp:1501-1503; 2 MiB for 256^3, resident in
+// every XCD's L2).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+
+namespace trk {
+
+struct V3 { double x, y, z; };
+
+__device__ __forceinline__ double dot3(const V3 &a, const V3 &b) {
+#pragma clang fp contract(off)
+  return a.x * b.x + a.y * b.y + a.z * b.z;
+}
+
+// collision/collision_primitives.h:62-85 (segment_aabox_intersect), C = lower-left, D = upper-right
+__device__ __forceinline__ bool segment_aabox_intersect(const V3 &A, const V3 &B, const GridK &g) {
+#pragma clang fp contract(off)
+  const V3 AB = {B.x - A.x, B.y - A.y, B.z - A.z};
+  const double len = sqrt(dot3(AB, AB)) / 2;
+  const V3 U = {AB.x / (2 * len), AB.y / (2 * len), AB.z / (2 * len)};
+  const V3 Ua = {fabs(U.x), fabs(U.y), fabs(U.z)};
+  const V3 P = {(A.x + B.x) / 2 - (g.xmax + g.xmin) / 2, (A.y + B.y) / 2 - (g.ymax + g.ymin) / 2,
+                (A.z + B.z) / 2 - (g.zmax + g.zmin) / 2};
+  const V3 ext = {fabs(g.xmax - g.xmin) / 2, fabs(g.ymax - g.ymin) / 2, fabs(g.zmax - g.zmin) / 2};
+  const V3 UxP = {fabs(U.y * P.z - U.z * P.y), fabs(U.z * P.x - U.x * P.z), fabs(U.x * P.y - U.y * P.x)};
+  const V3 Pa = {fabs(P.x), fabs(P.y), fabs(P.z)};
+  const bool separated = Pa.x > ext.x + len * Ua.x || Pa.y > ext.y + len * Ua.y || Pa.z > ext.z + len * Ua.z ||
+                         UxP.x > ext.y * Ua.z + ext.z * Ua.y || UxP.y > ext.z * Ua.x + ext.x * Ua.z ||
+                         UxP.z > ext.x * Ua.y + ext.y * Ua.x;
+  return !separated;
+}
+
+// Per-lane cursor into the obstacle grid with a one-block register cache.
+struct GridCursor {
+  const uint64_t *__restrict__ blocks;
+  int Nb;
+  int cached_id;
+  uint64_t cached;
+  __device__ __forceinline__ bool occupied(int x, int y, int z) {
+    const int id = ((x >> 2) * Nb + (y >> 2)) * Nb + (z >> 2);
+    if (id != cached_id) { cached = blocks[id]; cached_id = id; }
+    return (cached >> (((x & 3) << 4) | ((y & 3) << 2) | (z & 3))) & 1ull;
+  }
+};
+
+// VoxelOctree::add_line (collision/VoxelOctree.cpp:325-426) with set_cell replaced by an
+// occupancy test.  Returns true as soon as a visited cell is occupied.  `bad` is raised when an
+// endpoint is non-finite or farther than 4N voxels outside the domain (reference: undefined
+// behaviour / unbounded walk); the caller then forces the configuration invalid.
+__device__ __forceinline__ bool line_hits(const V3 &a, const V3 &b, const GridK &g, GridCursor &gc, bool &bad) {
+#pragma clang fp contract(off)
+  // Fast accept of the AABB pre-test: both endpoints at least 1e-6 of the box size inside the
+  // domain => the exact test above is true by a margin far larger than its rounding error.
+  const double mx = 1e-6 * (g.xmax - g.xmin), my = 1e-6 * (g.ymax - g.ymin), mz = 1e-6 * (g.zmax - g.zmin);
+  const bool inside = a.x > g.xmin + mx && a.x < g.xmax - mx && b.x > g.xmin + mx && b.x < g.xmax - mx &&
+                      a.y > g.ymin + my && a.y < g.ymax - my && b.y > g.ymin + my && b.y < g.ymax - my &&
+                      a.z > g.zmin + mz && a.z < g.zmax - mz && b.z > g.zmin + mz && b.z < g.zmax - mz;
+  if (!inside) {
+    if (!segment_aabox_intersect(a, b, g)) return false;
+  }
+  const V3 A = {(a.x - g.xmin) * g.inv_dx, (a.y - g.ymin) * g.inv_dy, (a.z - g.zmin) * g.inv_dz};
+  const V3 B = {(b.x - g.xmin) * g.inv_dx, (b.y - g.ymin) * g.inv_dy, (b.z - g.zmin) * g.inv_dz};
+  const int N = g.N;
+  const double lim = 4.0 * N;
+  if (!(fabs(A.x) < lim + N && fabs(A.y) < lim + N && fabs(A.z) < lim + N &&
+        fabs(B.x) < lim + N && fabs(B.y) < lim + N && fabs(B.z) < lim + N)) {
+    bad = true;
+    return false;
+  }
+  const int Axi = (int)A.x - (A.x < 0), Ayi = (int)A.y - (A.y < 0), Azi = (int)A.z - (A.z < 0);
+  const int Bxi = (int)B.x - (B.x < 0), Byi = (int)B.y - (B.y < 0), Bzi = (int)B.z - (B.z < 0);
+  auto idx_in = [N](int q) { return 0 <= q && q < N; };
+  auto vox_in = [&](int x, int y, int z) { return idx_in(x) && idx_in(y) && idx_in(z); };
+  bool entered = vox_in(Axi, Ayi, Azi);
+  if (entered && gc.occupied(Axi, Ayi, Azi)) return true;
+  if (vox_in(Bxi, Byi, Bzi) && gc.occupied(Bxi, Byi, Bzi)) return true;
+
+  V3 U = {B.x - A.x, B.y - A.y, B.z - A.z};
+  {
+    const double z = dot3(U, U);                   // Eigen normalized(): n / sqrt(z) if z > 0
+    if (z > 0.0) { const double s = sqrt(z); U.x = U.x / s; U.y = U.y / s; U.z = U.z / s; }
+  }
+  const int step_x = 1 - 2 * (U.x < 0), step_y = 1 - 2 * (U.y < 0), step_z = 1 - 2 * (U.z < 0);
+  const double ex = fabs(A.x - (Axi + step_x) * g.dx);
+  const double ey = fabs(A.y - (Ayi + step_y) * g.dy);
+  const double ez = fabs(A.z - (Azi + step_z) * g.dz);
+  const double uax = fabs(U.x), uay = fabs(U.y), uaz = fabs(U.z);
+  const double threshold = 1e-10;
+  const double tx_delta = (uax > threshold) ? 1 / uax : 1 / threshold;
+  const double ty_delta = (uay > threshold) ? 1 / uay : 1 / threshold;
+  const double tz_delta = (uaz > threshold) ? 1 / uaz : 1 / threshold;
+  double tx = fabs(ex * tx_delta), ty = fabs(ey * ty_delta), tz = fabs(ez * tz_delta);
+  int xi = Axi, yi = Ayi, zi = Azi;
+  // the walk visits at most |dBx|+|dBy|+|dBz|+1 cells; the cap only guards against corrupt input
+  for (int guard = 0; guard < 32 * N + 64; ++guard) {
+    if (!(step_x * (Bxi - xi) >= 0 && step_y * (Byi - yi) >= 0 && step_z * (Bzi - zi) >= 0)) break;
+    const bool tx_is_min = (tx < ty) && (tx < tz);
+    const bool ty_is_min = !(tx < ty) && (ty < tz);
+    if (tx_is_min) {
+      xi += step_x;
+      if (entered && !idx_in(xi)) break;
+      tx += tx_delta;
+    } else if (ty_is_min) {
+      yi += step_y;
+      if (entered && !idx_in(yi)) break;
+      ty += ty_delta;
+    } else {
+      zi += step_z;
+      if (entered && !idx_in(zi)) break;
+      tz += tz_delta;
+    }
+    if (!entered && vox_in(xi, yi, zi)) entered = true;
+    if (entered && gc.occupied(xi, yi, zi)) return true;
+  }
+  return false;
+}
+
+// collision/collision_primitives.cpp:10-102 (closest_st_segment) + collision.hxx:102-108
+// capsule-capsule with radius sum rsum: distance^2 between closest points <= rsum^2.
+__device__ __forceinline__ bool capsules_collide(const V3 &A, const V3 &B, const V3 &C, const V3 &D, double rsum) {
+#pragma clang fp contract(off)
+  const double eps = 2.220446049250313e-16, eps2 = eps * eps;
+  double s = 0.0, t = 0.0;
+  const V3 AB = {B.x - A.x, B.y - A.y, B.z - A.z};
+  const V3 CD = {D.x - C.x, D.y - C.y, D.z - C.z};
+  const double a = dot3(AB, AB), c = dot3(CD, CD);
+  auto bound = [](double q) { return fmax(0.0, fmin(1.0, q)); };
+  auto closest_AB_s = [&](const V3 &P) {
+    if (a <= eps2) return 0.0;
+    const V3 d = {P.x - A.x, P.y - A.y, P.z - A.z};
+    return dot3(AB, d) / a;
+  };
+  auto closest_CD_t = [&](const V3 &P) {
+    if (c <= eps2) return 0.0;
+    const V3 d = {P.x - C.x, P.y - C.y, P.z - C.z};
+    return dot3(CD, d) / c;
+  };
+  if (a <= eps2) { s = 0.0; t = bound(closest_CD_t(A)); }
+  else if (c <= eps2) { s = bound(closest_AB_s(C)); t = 0.0; }
+  else {
+    const V3 AC = {C.x - A.x, C.y - A.y, C.z - A.z};
+    const double b = dot3(AB, CD), d = dot3(AC, AB), e = dot3(AC, CD);
+    const double denom = fmax(0.0, a * c - b * b);
+    if (denom <= eps2) {
+      bool found = false;
+      t = closest_CD_t(A);
+      if (0.0 <= t && t <= 1.0) { s = 0.0; found = true; }
+      if (!found) { t = closest_CD_t(B); if (0.0 <= t && t <= 1.0) { s = 1.0; found = true; } }
+      if (!found) { s = closest_AB_s(C); if (0.0 <= s && s <= 1.0) { t = 0.0; found = true; } }
+      if (!found) {
+        const V3 AD = {D.x - A.x, D.y - A.y, D.z - A.z};
+        const V3 BC = {C.x - B.x, C.y - B.y, C.z - B.z};
+        const V3 BD = {D.x - B.x, D.y - B.y, D.z - B.z};
+        const double ac2 = dot3(AC, AC), ad2 = dot3(AD, AD), bc2 = dot3(BC, BC), bd2 = dot3(BD, BD);
+        if (ac2 <= ad2 && ac2 <= bc2 && ac2 <= bd2) { s = 0.0; t = 0.0; }
+        else if (ad2 <= bc2 && ad2 <= bd2) { s = 0.0; t = 1.0; }
+        else if (bc2 <= bd2) { s = 1.0; t = 0.0; }
+        else { s = 1.0; t = 1.0; }
+      }
+    } else {
+      s = (c * d - b * e) / denom;
+      t = (b * d - a * e) / denom;
+      if (0.0 <= t && t <= 1.0) { s = bound(s); }
+      else if (t < 0.0) { s = bound(-c / a); t = 0.0; }
+      else { s = bound((b - c) / a); t = 1.0; }
+    }
+  }
+  const V3 c1 = {A.x + (B.x - A.x) * s, A.y + (B.y - A.y) * s, A.z + (B.z - A.z) * s};
+  const V3 c2 = {C.x + (D.x - C.x) * t, C.y + (D.y - C.y) * t, C.z + (D.z - C.z) * t};
+  const V3 df = {c1.x - c2.x, c1.y - c2.y, c1.z - c2.z};
+  return dot3(df, df) <= (rsum * rsum);
+}
+
+__device__ __forceinline__ int wave_min_i32(int v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const int o = __shfl_xor(v, off, 64);
+    v = o < v ? o : v;
+  }
+  return v;
+}
+
+struct SweepIn {
+  const double *__restrict__ px, *__restrict__ py, *__restrict__ pz;   // [P][ld]
+  const int32_t *__restrict__ n_points;                                // [n] or null (= P)
+  const double *__restrict__ Li;                                       // [N][ld]
+  const uint8_t *__restrict__ converged;                               // [n]
+  const double *__restrict__ home_Li;                                  // [N][ld] per-config home lengths or null (use K.home_Li)
+  double *__restrict__ acc;                                            // [P][ld] scratch: accumulated chord lengths
+};
+
+// K2.  block = 256 threads (4 independent waves); valid_bits word = global wave index.
+//   debug bit0: brute-force self-collision (every pair), for A/B verification of the skip sweep.
+__global__ __launch_bounds__(256) void backbone_voxel_sweep(
+    SweepIn in, int64_t n, int64_t ld, int P, RobotK K, GridK g, const uint64_t *__restrict__ grid,
+    int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits, uint8_t *__restrict__ flags) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < n;
+  const int64_t ic = live ? i : (n - 1);
+  const int NT = K.n_tendons;
+  uint32_t fl = 0;
+  bool alive = live;
+
+  // 1. converged (the home shape always converges: TendonRobot.cpp:249-314 never clears the flag)
+  if (alive) { if (in.converged[ic]) fl |= 1u; else alive = false; }
+  // 2. tendon length limits: dl = L_home - L_fk in [min_length, max_length]
+  if (alive) {
+    bool ok = true;
+    for (int j = 0; j < NT; j++) {
+      const double home = in.home_Li ? in.home_Li[(int64_t)j * ld + ic] : K.home_Li[j];
+      const double dl = home - in.Li[(int64_t)j * ld + ic];
+      if (dl < K.min_len[j] || K.max_len[j] < dl) ok = false;
+    }
+    if (ok) fl |= 2u; else alive = false;
+  }
+  const int np = in.n_points ? in.n_points[ic] : P;
+
+  // 3. self collision.  Pass 1: accumulated chord lengths (collision.cpp:21-30) + longest chord.
+  double hmax = 0.0, dist = 0.0;
+  if (__any(alive)) {
+    V3 prev = {in.px[ic], in.py[ic], in.pz[ic]};
+    for (int j = 0; j < P; j++) {
+      if (alive && j < np) {
+        const int64_t o = (int64_t)j * ld + ic;
+        const V3 q = {in.px[o], in.py[o], in.pz[o]};
+        const V3 d = {q.x - prev.x, q.y - prev.y, q.z - prev.z};
+        const double h = sqrt(dot3(d, d));
+        dist += h;
+        hmax = fmax(hmax, h);
+        in.acc[o] = dist;
+        prev = q;
+      }
+    }
+  }
+  if (alive && !(dist < 1e300)) { alive = false; fl |= 16u; }    // NaN / inf points
+
+  bool selfhit = false;
+  {
+    const double r = K.radius;
+    const double consider = 3.0 * r;
+    const double rsum = r + r;
+    // conservative bounds for the skip sweep (all slack is >= 1e-9 relative, far above rounding)
+    const double h_eff = hmax * (1.0 + 1e-9) + 1e-300;
+    const double inv_h = 1.0 / h_eff;
+    bool act = alive && np > 2;
+    const bool brute = debug & 1u;
+    for (int a = 0; a < P - 3; ++a) {
+      if (!__any(act && a < np - 3)) break;
+      const bool act_a = act && a < np - 3;
+      const int64_t oa = (int64_t)a * ld + ic;
+      V3 pa = {0, 0, 0}, pa1 = {0, 0, 0};
+      double acc_a1 = 0;
+      if (act_a) {
+        pa = V3{in.px[oa], in.py[oa], in.pz[oa]};
+        pa1 = V3{in.px[oa + ld], in.py[oa + ld], in.pz[oa + ld]};
+        acc_a1 = in.acc[oa + ld];
+      }
+      int b = a + 2;
+      while (b < P - 1) {
+        const bool act_b = act_a && !selfhit && b < np - 1;
+        if (!__any(act_b)) break;
+        int skip = 0x7fffffff;
+        if (act_b) {
+          const int64_t ob = (int64_t)b * ld + ic;
+          const V3 pb = {in.px[ob], in.py[ob], in.pz[ob]};
+          skip = 1;
+          bool need_exact = true;
+          if (!brute) {
+            // any pair (a, b+k) has segment distance >= |pa - pb| - (k + 2) * hmax
+            const V3 d = {pa.x - pb.x, pa.y - pb.y, pa.z - pb.z};
+            const double D = sqrt(dot3(d, d));
+            const double slack = D - rsum - 2.0 * h_eff - 1e-9 * (1.0 + D);
+            if (slack > 0.0) {
+              need_exact = false;
+              const double m = slack * inv_h * (1.0 - 1e-9);
+              skip = m > 1.0 ? (m < 1e6 ? (int)m : 1000000) : 1;
+            }
+          }
+          if (need_exact) {
+            const double gd = in.acc[ob] - acc_a1;
+            if (gd < consider) {
+              // gated out (collision.cpp:38-40); (a, b+k) stays gated while gd + k*hmax < 3r
+              if (!brute) {
+                const double m = (consider - gd) * inv_h * (1.0 - 1e-9) - 1e-9;
+                skip = m > 1.0 ? (m < 1e6 ? (int)m : 1000000) : 1;
+              }
+            } else {
+              const V3 pb1 = {in.px[ob + ld], in.py[ob + ld], in.pz[ob + ld]};
+              if (capsules_collide(pa, pa1, pb, pb1, rsum)) selfhit = true;
+            }
+          }
+        }
+        b += wave_min_i32(skip);
+      }
+      if (selfhit) act = false;
+    }
+  }
+  if (alive) { if (!selfhit) fl |= 4u; else alive = false; }
+
+  // 4. backbone voxelisation against the obstacle grid
+  if (check_voxels) {
+    bool hit = false, bad = false;
+    if (__any(alive)) {
+      GridCursor gc{grid, g.Nb, -1, 0ull};
+      V3 prev = {0, 0, 0};
+      for (int j = 0; j < P; j++) {
+        const bool on = alive && !hit && !bad && j < np;
+        if (!__any(on)) break;
+        if (on) {
+          const int64_t o = (int64_t)j * ld + ic;
+          const double x = in.px[o], y = in.py[o], z = in.pz[o];
+          V3 q;
+          if (g.rot_is_identity) { q = V3{x, y, z}; }
+          else {
+            q.x = g.inv_rot[0] * x + g.inv_rot[1] * y + g.inv_rot[2] * z;
+            q.y = g.inv_rot[3] * x + g.inv_rot[4] * y + g.inv_rot[5] * z;
+            q.z = g.inv_rot[6] * x + g.inv_rot[7] * y + g.inv_rot[8] * z;
+          }
+          if (j > 0) hit = line_hits(prev, q, g, gc, bad);
+          prev = q;
+        }
+      }
+    }
+    if (alive) {
+      if (bad) { fl |= 16u; alive = false; }
+      else if (!hit) fl |= 8u;
+      else alive = false;
+    }
+  }
+
+  const uint64_t bits = __ballot(alive);
+  if ((threadIdx.x & 63) == 0 && i < n) valid_bits[i >> 6] = bits;
+  if (flags && live) flags[i] = (uint8_t)fl;
+}
+
+// K4 `cached_blocks_vs_grid`: sparse cached voxel sets (CSR of (block id, mask)) vs the dense grid.
+// One lane per item; items are short (tens of blocks).
+__global__ __launch_bounds__(256) void cached_blocks_vs_grid(
+    const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int64_t *__restrict__ offsets,
+    int64_t n_items, const uint64_t *__restrict__ grid, uint32_t n_blocks, uint64_t *__restrict__ hit_bits) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool hit = false;
+  if (i < n_items) {
+    const int64_t e = offsets[i + 1];
+    for (int64_t k = offsets[i]; k < e; k++) {
+      const uint32_t id = ids[k];
+      if (id < n_blocks && (grid[id] & masks[k])) { hit = true; break; }
+    }
+  }
+  const uint64_t bits = __ballot(hit);
+  if ((threadIdx.x & 63) == 0 && i < n_items) hit_bits[i >> 6] = bits;
+}
+
+}  // namespace trk

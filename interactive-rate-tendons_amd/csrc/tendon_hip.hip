@@ -1,0 +1,648 @@
+// tendon_hip.hip -- libtendon_hip.so: C ABI (include/tendon_hip.h) over the HIP kernels in
+// fk_kernel.hpp (K1 fk_rk4_batch) and sweep_kernel.hpp (K2 backbone_voxel_sweep,
+// K4 cached_blocks_vs_grid).  gfx950 only.
+//
+// Host-side responsibilities (all per context, none per configuration):
+//   * robot constants (get_stiffness_matrices, tendon/TendonRobot.cpp:105-148),
+//   * the shared arc-length grid and its RK4 step list (t_range, TendonRobot.cpp:69-84;
+//     Boost.odeint integrate_times stepping, call site :458-462),
+//   * the tendon-routing table r, r', r'' at every stage abscissa (get_r_info2,
+//     tendon/get_r_info.cpp:105-144),
+//   * home-shape tendon lengths (home_shape, TendonRobot.cpp:249-314),
+//   * device workspace, launches, optional HIP-event timing per kernel.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <string>
+#include <vector>
+
+#include "../../include/tendon_hip.h"
+#include "tr_types.hpp"
+#include "fk_kernel.hpp"
+#include "sweep_kernel.hpp"
+#include "edge_kernel.hpp"
+
+namespace {
+
+std::string g_create_error;
+
+struct Workspace {
+  int64_t ld = 0;                 // capacity in configurations (multiple of 64)
+  double *px = nullptr, *py = nullptr, *pz = nullptr, *acc = nullptr;   // [P][ld]
+  double *Li = nullptr;           // [N][ld]
+  uint8_t *conv = nullptr;        // [ld]
+  // staging for the host-pointer entry points
+  int64_t st_cap = 0;
+  double *states = nullptr;       // [st_cap][S]
+  uint64_t *bits = nullptr;       // [st_cap/64]
+  double *tips = nullptr;         // [st_cap][3]
+  uint8_t *flags = nullptr;       // [st_cap]
+  double *L = nullptr;            // [st_cap]
+  int32_t *npts = nullptr;        // [st_cap]
+};
+
+struct EventPair { hipEvent_t a, b; };
+
+}  // namespace
+
+struct tr_ctx {
+  int device = 0;
+  std::string err;
+  RobotK K{};
+  std::vector<double> C, D, max_tension;
+  // shared arc-length grid
+  std::vector<double> t;          // backbone abscissae (s_start = 0)
+  std::vector<StepK> steps;
+  double *d_tab = nullptr;
+  StepK *d_steps = nullptr;
+  // obstacle grid
+  bool has_grid = false;
+  GridK G{};
+  uint64_t *d_grid = nullptr;
+  uint32_t n_blocks = 0;
+  Workspace ws;
+  int64_t max_chunk = 1 << 20;
+  // instrumentation
+  bool profiling = false;
+  std::vector<EventPair> events[TR_PROFILE_SLOTS];
+  uint32_t debug = 0;
+};
+
+namespace {
+
+int fail(tr_ctx *ctx, int code, const std::string &msg) {
+  if (ctx) ctx->err = msg; else g_create_error = msg;
+  return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                   \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess)                                                                    \
+      return fail(ctx, TR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));       \
+  } while (0)
+
+// util/vector_ops.h:67-75 (range) + tendon/TendonRobot.cpp:69-84 (t_range)
+std::vector<double> t_range(double start, double end, double dt) {
+  std::vector<double> vals;
+  for (double p = start; p <= end - (dt / 2); p += dt) vals.push_back(p);
+  vals.push_back(end);
+  for (auto &v : vals) v = end - (v - start);
+  std::reverse(vals.begin(), vals.end());
+  return vals;
+}
+
+// tendon/get_r_info.cpp:17-40,105-144: routing r, r', r'' of every tendon at arc length t.
+// out: N x 6 {rx, ry, rdx, rdy, rddx, rddy} (z components are identically zero).
+void routing_at(const tr_ctx *c, double t, double *out) {
+  const int N_a = c->K.n_a, N_m = c->K.n_m, N_s = std::max(N_a, N_m);
+  double S[TRK_MAX_COEF], Sd[TRK_MAX_COEF], Sdd[TRK_MAX_COEF];
+  S[0] = 1; Sd[0] = 0; Sdd[0] = 0;
+  if (N_s >= 2) { S[1] = t; Sd[1] = 1; Sdd[1] = 0; }
+  for (int i = 2; i < N_s; i++) { S[i] = t * S[i - 1]; Sd[i] = i * S[i - 1]; Sdd[i] = i * (i - 1) * S[i - 2]; }
+  for (int j = 0; j < c->K.n_tendons; j++) {
+    const double *Cj = &c->C[(size_t)j * N_a], *Dj = &c->D[(size_t)j * N_m];
+    double C_a = 0, C_ad = 0, C_add = 0, D_m = 0, D_md = 0, D_mdd = 0;
+    for (int i = 0; i < N_a; i++) { C_a += Cj[i] * S[i]; C_ad += Cj[i] * Sd[i]; C_add += Cj[i] * Sdd[i]; }
+    for (int i = 0; i < N_m; i++) { D_m += Dj[i] * S[i]; D_md += Dj[i] * Sd[i]; D_mdd += Dj[i] * Sdd[i]; }
+    const double sa = std::sin(C_a), ca = std::cos(C_a);
+    double *o = out + 6 * j;
+    o[0] = D_m * sa;
+    o[1] = D_m * ca;
+    o[2] = D_md * sa + D_m * (ca * C_ad);
+    o[3] = D_md * ca + D_m * (-sa * C_ad);
+    o[4] = D_mdd * sa + 2 * D_md * (ca * C_ad) - D_m * (sa * C_ad * C_ad) + D_m * (ca * C_add);
+    o[5] = D_mdd * ca + 2 * D_md * (-sa * C_ad) - D_m * (ca * C_ad * C_ad) + D_m * (-sa * C_add);
+  }
+}
+
+int poly_degree(const double *c, int n) {
+  for (int i = n - 1; i > 0; i--) if (std::fabs(c[i]) > 0.0) return i;
+  return 0;
+}
+double poly_at(const double *c, int n, double t) {     // util/poly.h:9-17
+  double val = 0.0, tpow = 1;
+  for (int i = 0; i < n; i++) { val += c[i] * tpow; tpow *= t; }
+  return val;
+}
+
+// Home-shape tendon lengths (tendon/TendonRobot.cpp:281-311).  The reference's simpsons()
+// (:160-178) reads one element past the end of its input; this uses the rule its comment
+// describes (composite Simpson, trapezoid for a trailing odd interval) -- see DESIGN.md.
+void home_lengths(const tr_ctx *c, const std::vector<double> &t, double s_start, double *Li) {
+  const double Lh = c->K.L - s_start;
+  const int N_a = c->K.n_a, N_m = c->K.n_m;
+  for (int j = 0; j < c->K.n_tendons; j++) {
+    const double *Cj = &c->C[(size_t)j * N_a], *Dj = &c->D[(size_t)j * N_m];
+    const int rdeg = poly_degree(Dj, N_m), tdeg = poly_degree(Cj, N_a);
+    if (rdeg == 0 && tdeg == 0) {
+      Li[j] = Lh;
+    } else if (rdeg == 0 && tdeg == 1) {
+      const double d0 = Dj[0], c1 = Cj[1];
+      Li[j] = Lh * std::sqrt(1 + d0 * d0 * c1 * c1);
+    } else {
+      double Cdot[TRK_MAX_COEF] = {0}, Ddot[TRK_MAX_COEF] = {0};
+      for (int k = 1; k < N_a; k++) Cdot[k - 1] = k * Cj[k];
+      for (int k = 1; k < N_m; k++) Ddot[k - 1] = k * Dj[k];
+      const int n = (int)t.size();
+      std::vector<double> vals(n);
+      for (int q = 0; q < n; q++) {
+        const double dd = poly_at(Ddot, N_m, t[q]), d = poly_at(Dj, N_m, t[q]), cd = poly_at(Cdot, N_a, t[q]);
+        vals[q] = std::sqrt(dd * dd + (d * d) * (cd * cd) + 1);
+      }
+      const double dx = c->K.dL;
+      double res = 0.0;
+      if (n >= 2) {
+        int nint = n - 1;
+        double odd = 0.0;
+        if (nint % 2 != 0) { odd = 0.5 * dx * (vals[n - 2] + vals[n - 1]); nint--; }
+        if (nint == 0) res = odd;
+        else {
+          double integral = vals[0] + vals[nint];
+          for (int i = 1; i < nint; i++) integral += ((i % 2) ? 4 : 2) * vals[i];
+          res = odd + (integral * dx / 3.0);
+        }
+      }
+      Li[j] = res;
+    }
+  }
+}
+
+int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+template <typename T>
+int dev_alloc(tr_ctx *ctx, T **p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  if (count == 0) count = 1;
+  HIP_TRY(ctx, hipMalloc((void **)p, count * sizeof(T)));
+  return TR_OK;
+}
+
+int ensure_workspace(tr_ctx *ctx, int64_t n) {
+  Workspace &w = ctx->ws;
+  const int64_t want = round_up(std::min<int64_t>(std::max<int64_t>(n, 64), ctx->max_chunk), 64);
+  if (w.ld >= want) return TR_OK;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  const size_t P = (size_t)ctx->K.n_points, N = (size_t)ctx->K.n_tendons;
+  int rc;
+  if ((rc = dev_alloc(ctx, &w.px, P * want))) return rc;
+  if ((rc = dev_alloc(ctx, &w.py, P * want))) return rc;
+  if ((rc = dev_alloc(ctx, &w.pz, P * want))) return rc;
+  if ((rc = dev_alloc(ctx, &w.acc, P * want))) return rc;
+  if ((rc = dev_alloc(ctx, &w.Li, N * want))) return rc;
+  if ((rc = dev_alloc(ctx, &w.conv, (size_t)want))) return rc;
+  w.ld = want;
+  return TR_OK;
+}
+
+int ensure_staging(tr_ctx *ctx, int64_t n) {
+  Workspace &w = ctx->ws;
+  const int64_t want = round_up(std::max<int64_t>(n, 64), 64);
+  if (w.st_cap >= want) return TR_OK;
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  int rc;
+  if ((rc = dev_alloc(ctx, &w.states, (size_t)want * ctx->K.state_size))) return rc;
+  if ((rc = dev_alloc(ctx, &w.bits, (size_t)want / 64))) return rc;
+  if ((rc = dev_alloc(ctx, &w.tips, (size_t)want * 3))) return rc;
+  if ((rc = dev_alloc(ctx, &w.flags, (size_t)want))) return rc;
+  if ((rc = dev_alloc(ctx, &w.L, (size_t)want))) return rc;
+  if ((rc = dev_alloc(ctx, &w.npts, (size_t)want))) return rc;
+  w.st_cap = want;
+  return TR_OK;
+}
+
+struct ProfScope {
+  tr_ctx *ctx; int slot; hipStream_t s; EventPair ev{};
+  bool on;
+  ProfScope(tr_ctx *c, int slot_, hipStream_t s_) : ctx(c), slot(slot_), s(s_), on(c->profiling) {
+    if (on) {
+      (void)hipEventCreate(&ev.a); (void)hipEventCreate(&ev.b);
+      (void)hipEventRecord(ev.a, s);
+    }
+  }
+  ~ProfScope() {
+    if (on) { (void)hipEventRecord(ev.b, s); ctx->events[slot].push_back(ev); }
+  }
+};
+
+// ---- K1 launch -----------------------------------------------------------------------------
+template <int N, bool ROT, bool WR>
+void launch_fk_t(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL((trk::fk_rk4_batch_uniform<N, ROT, WR>), dim3(grid), dim3(64), 0, s, d_states, n, ld, ctx->K,
+                     ctx->d_tab, ctx->d_steps, (int)ctx->steps.size(), out);
+}
+template <int N>
+void launch_fk_n(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
+  const bool rot = ctx->K.enable_rotation, wr = out.R != nullptr;
+  if (rot) { if (wr) launch_fk_t<N, true, true>(ctx, d_states, n, ld, out, s); else launch_fk_t<N, true, false>(ctx, d_states, n, ld, out, s); }
+  else     { if (wr) launch_fk_t<N, false, true>(ctx, d_states, n, ld, out, s); else launch_fk_t<N, false, false>(ctx, d_states, n, ld, out, s); }
+}
+int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
+  if (n <= 0) return TR_OK;
+  if (ctx->K.enable_retraction)
+    return fail(ctx, TR_ERR_UNSUPPORTED, "retraction-enabled robots are not supported by this build of fk_rk4_batch");
+  ProfScope ps(ctx, 0, s);
+  switch (ctx->K.n_tendons) {
+    case 1: launch_fk_n<1>(ctx, d_states, n, ld, out, s); break;
+    case 2: launch_fk_n<2>(ctx, d_states, n, ld, out, s); break;
+    case 3: launch_fk_n<3>(ctx, d_states, n, ld, out, s); break;
+    case 4: launch_fk_n<4>(ctx, d_states, n, ld, out, s); break;
+    case 5: launch_fk_n<5>(ctx, d_states, n, ld, out, s); break;
+    case 6: launch_fk_n<6>(ctx, d_states, n, ld, out, s); break;
+    case 7: launch_fk_n<7>(ctx, d_states, n, ld, out, s); break;
+    case 8: launch_fk_n<8>(ctx, d_states, n, ld, out, s); break;
+    default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
+  }
+  HIP_TRY(ctx, hipGetLastError());
+  return TR_OK;
+}
+
+int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int check_voxels,
+                 uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
+  if (n <= 0) return TR_OK;
+  if (check_voxels && !ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  ProfScope ps(ctx, 1, s);
+  const unsigned grid = (unsigned)((n + 255) / 256);
+  hipLaunchKernelGGL(trk::backbone_voxel_sweep, dim3(grid), dim3(256), 0, s, in, n, ld, (int)ctx->K.n_points, ctx->K,
+                     ctx->G, ctx->d_grid, check_voxels, ctx->debug, d_bits, d_flags);
+  HIP_TRY(ctx, hipGetLastError());
+  return TR_OK;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+const char *tr_last_error(const tr_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
+  if (!rb || !out) return fail(nullptr, TR_ERR_INVALID_ARG, "null argument");
+  *out = nullptr;
+  if (rb->n_tendons < 1 || rb->n_tendons > TR_MAX_TENDONS)
+    return fail(nullptr, TR_ERR_OUT_OF_RANGE, "n_tendons must be in 1..8");
+  if (rb->n_a < 1 || rb->n_a > TR_MAX_COEF || rb->n_m < 1 || rb->n_m > TR_MAX_COEF)
+    return fail(nullptr, TR_ERR_OUT_OF_RANGE, "polynomial sizes must be in 1..8");
+  if (!rb->C || !rb->D || !rb->max_tension || !rb->min_length || !rb->max_length)
+    return fail(nullptr, TR_ERR_INVALID_ARG, "null tendon arrays");
+  if (!(rb->L > 0) || !(rb->dL > 0) || !(rb->ro > rb->ri) || !(rb->E > 0))
+    return fail(nullptr, TR_ERR_INVALID_ARG, "backbone specs must be positive (L, dL, E) with ro > ri");
+  if (rb->L / rb->dL > 65536)
+    return fail(nullptr, TR_ERR_INVALID_ARG, "more than 65536 backbone points");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(nullptr, TR_ERR_HIP, "no HIP device available (libtendon_hip has no CPU fallback)");
+  if (device < 0 || device >= ndev) return fail(nullptr, TR_ERR_INVALID_ARG, "bad device ordinal");
+  tr_ctx *c = new tr_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, TR_ERR_HIP, "hipSetDevice failed"); }
+
+  RobotK &K = c->K;
+  const int N = rb->n_tendons;
+  K.n_tendons = N; K.n_a = rb->n_a; K.n_m = rb->n_m;
+  K.enable_rotation = rb->enable_rotation ? 1 : 0;
+  K.enable_retraction = rb->enable_retraction ? 1 : 0;
+  K.state_size = N + K.enable_rotation + K.enable_retraction;
+  K.residual_threshold = rb->residual_threshold;
+  K.radius = rb->r; K.L = rb->L; K.dL = rb->dL;
+  c->C.assign(rb->C, rb->C + (size_t)N * rb->n_a);
+  c->D.assign(rb->D, rb->D + (size_t)N * rb->n_m);
+  c->max_tension.assign(rb->max_tension, rb->max_tension + N);
+  for (int j = 0; j < N; j++) { K.min_len[j] = rb->min_length[j]; K.max_len[j] = rb->max_length[j]; }
+  {  // get_stiffness_matrices, tendon/TendonRobot.cpp:105-148
+    const double ro2 = rb->ro * rb->ro, ri2 = rb->ri * rb->ri;
+    const double I = (1.0 / 4.0) * M_PI * (ro2 * ro2 - ri2 * ri2);
+    const double Ar = M_PI * (ro2 - ri2);
+    const double J = 2 * I;
+    const double Gmod = rb->E / (2 * (1 + rb->nu));
+    K.kb0 = rb->E * I; K.kb2 = J * Gmod;
+    K.ikb0 = 1 / (rb->E * I); K.ikb2 = 1 / (J * Gmod);
+    K.ks0 = Gmod * Ar; K.ks2 = rb->E * Ar;
+    K.iks0 = 1 / (Gmod * Ar); K.iks2 = 1 / (rb->E * Ar);
+  }
+  // shared arc-length grid, RK4 step list (integrate_times: steps of min(dL, t[j+1]-cur) while
+  // t[j+1]-cur > eps; every interval restarts at exactly t[j]) and the routing table
+  c->t = t_range(0.0, rb->L, rb->dL);
+  K.n_points = (int)c->t.size();
+  std::vector<double> step_t;
+  for (size_t j = 0; j + 1 < c->t.size(); j++) {
+    double cur = c->t[j];
+    const double tn = c->t[j + 1];
+    bool any = false;
+    while (tn - cur > DBL_EPSILON) {
+      const double h = std::min(rb->dL, tn - cur);
+      c->steps.push_back(StepK{h, -1, 0});
+      step_t.push_back(cur);
+      cur += h;
+      any = true;
+    }
+    if (!any) { c->steps.push_back(StepK{0.0, -1, 0}); step_t.push_back(cur); }
+    c->steps.back().obs = (int)j + 1;
+  }
+  const size_t ent = (size_t)N * 6;
+  std::vector<double> tab((1 + 3 * c->steps.size()) * ent);
+  routing_at(c, 0.0, tab.data());
+  for (size_t k = 0; k < c->steps.size(); k++) {
+    const double tk = step_t[k], h = c->steps[k].h;
+    routing_at(c, tk, &tab[(1 + 3 * k + 0) * ent]);
+    routing_at(c, tk + h * 0.5, &tab[(1 + 3 * k + 1) * ent]);
+    routing_at(c, tk + h, &tab[(1 + 3 * k + 2) * ent]);
+  }
+  home_lengths(c, c->t, 0.0, K.home_Li);
+
+  auto bail = [&](const char *what) { std::string m = what; tr_destroy(c); return fail(nullptr, TR_ERR_HIP, m); };
+  if (hipMalloc((void **)&c->d_tab, tab.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc(tab)");
+  if (hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy(tab)");
+  if (hipMalloc((void **)&c->d_steps, std::max<size_t>(1, c->steps.size()) * sizeof(StepK)) != hipSuccess) return bail("hipMalloc(steps)");
+  if (!c->steps.empty() &&
+      hipMemcpy(c->d_steps, c->steps.data(), c->steps.size() * sizeof(StepK), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy(steps)");
+  *out = c;
+  return TR_OK;
+}
+
+void tr_destroy(tr_ctx *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  (void)hipDeviceSynchronize();
+  for (auto &v : c->events) for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  Workspace &w = c->ws;
+  void *ptrs[] = {c->d_tab, c->d_steps, c->d_grid, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
+                  w.states, w.bits, w.tips, w.flags, w.L, w.npts};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  delete c;
+}
+
+int tr_state_size(const tr_ctx *c) { return c ? c->K.state_size : -1; }
+int tr_num_points(const tr_ctx *c) { return c ? c->K.n_points : -1; }
+int tr_device(const tr_ctx *c) { return c ? c->device : -1; }
+
+int tr_home_lengths(const tr_ctx *c, double *L_i) {
+  if (!c || !L_i) return TR_ERR_INVALID_ARG;
+  for (int j = 0; j < c->K.n_tendons; j++) L_i[j] = c->K.home_Li[j];
+  return TR_OK;
+}
+
+int tr_set_debug(tr_ctx *c, uint32_t bits) { if (!c) return TR_ERR_INVALID_ARG; c->debug = bits; return TR_OK; }
+
+int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *blocks, const double inv_rot[9]) {
+  if (!c || !lim || !blocks) return fail(c, TR_ERR_INVALID_ARG, "null argument");
+  if (N < 4 || N > 512 || (N & (N - 1)))       // collision/VoxelOctree.cpp:98-116
+    return fail(c, TR_ERR_INVALID_ARG, "unsupported voxel dimension: " + std::to_string(N));
+  if (!(lim[0] < lim[1]) || !(lim[2] < lim[3]) || !(lim[4] < lim[5]))   // VoxelOctree.cpp:152-177
+    return fail(c, TR_ERR_LENGTH, "limits must be positive in size");
+  GridK g{};
+  g.N = (int)N; g.Nb = (int)N / 4;
+  g.xmin = lim[0]; g.xmax = lim[1]; g.ymin = lim[2]; g.ymax = lim[3]; g.zmin = lim[4]; g.zmax = lim[5];
+  g.dx = (g.xmax - g.xmin) / N; g.dy = (g.ymax - g.ymin) / N; g.dz = (g.zmax - g.zmin) / N;
+  g.inv_dx = 1 / g.dx; g.inv_dy = 1 / g.dy; g.inv_dz = 1 / g.dz;
+  // VoxelBackboneValidityChecker.h:37-45
+  const double max_dim = std::max({g.dx, g.dy, g.dz});
+  if (c->K.dL > max_dim) {
+    char buf[160];
+    snprintf(buf, sizeof buf, "robot.specs.dL is larger than expected by VoxelBackboneValidityChecker (%g > %g)", c->K.dL, max_dim);
+    return fail(c, TR_ERR_INVALID_ARG, buf);
+  }
+  static const double I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  const double *r = inv_rot ? inv_rot : I9;
+  g.rot_is_identity = 1;
+  for (int i = 0; i < 9; i++) { g.inv_rot[i] = r[i]; if (r[i] != I9[i]) g.rot_is_identity = 0; }
+  HIP_TRY(c, hipSetDevice(c->device));
+  const size_t nb = (size_t)g.Nb * g.Nb * g.Nb;
+  if (c->n_blocks != nb) {
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->d_grid) { (void)hipFree(c->d_grid); c->d_grid = nullptr; }
+    HIP_TRY(c, hipMalloc((void **)&c->d_grid, nb * sizeof(uint64_t)));
+    c->n_blocks = (uint32_t)nb;
+  }
+  HIP_TRY(c, hipMemcpy(c->d_grid, blocks, nb * sizeof(uint64_t), hipMemcpyHostToDevice));
+  c->G = g;
+  c->has_grid = true;
+  return TR_OK;
+}
+
+int tr_reserve(tr_ctx *c, int64_t n) {
+  if (!c || n < 0) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc = ensure_workspace(c, n);
+  if (rc) return rc;
+  return ensure_staging(c, n);
+}
+
+// ---- FK ------------------------------------------------------------------------------------
+int tr_fk_batch_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t ld, double *d_px, double *d_py,
+                    double *d_pz, double *d_R, double *d_L, double *d_Li, uint8_t *d_converged,
+                    int32_t *d_n_points, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
+  if (n == 0) return TR_OK;
+  if (!d_states || !d_px || !d_py || !d_pz) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  trk::FkOut out{d_px, d_py, d_pz, d_R, d_L, d_Li, nullptr, d_converged, d_n_points};
+  return launch_fk(c, d_states, n, ld, out, (hipStream_t)stream);
+}
+
+int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R, double *L, double *L_i,
+                uint8_t *converged, int32_t *n_points) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && !states)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  if (n == 0) return TR_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int S = c->K.state_size, P = c->K.n_points, N = c->K.n_tendons;
+  const int64_t chunk_max = std::min<int64_t>(c->max_chunk, 1 << 16);
+  int rc;
+  if ((rc = ensure_workspace(c, std::min(n, chunk_max)))) return rc;
+  if ((rc = ensure_staging(c, std::min(n, chunk_max)))) return rc;
+  Workspace &w = c->ws;
+  double *d_R = nullptr;
+  std::vector<double> hx, hy, hz, hR, hLi;
+  for (int64_t off = 0; off < n; off += chunk_max) {
+    const int64_t m = std::min(chunk_max, n - off), ld = w.ld;
+    HIP_TRY(c, hipMemcpy(w.states, states + off * S, (size_t)m * S * sizeof(double), hipMemcpyHostToDevice));
+    if (R && !d_R) HIP_TRY(c, hipMalloc((void **)&d_R, (size_t)9 * P * ld * sizeof(double)));
+    trk::FkOut out{w.px, w.py, w.pz, d_R, w.L, w.Li, nullptr, w.conv, w.npts};
+    if ((rc = launch_fk(c, w.states, m, ld, out, nullptr))) { if (d_R) (void)hipFree(d_R); return rc; }
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (p) {
+      hx.resize((size_t)P * ld); hy.resize((size_t)P * ld); hz.resize((size_t)P * ld);
+      HIP_TRY(c, hipMemcpy(hx.data(), w.px, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(hy.data(), w.py, hy.size() * sizeof(double), hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy(hz.data(), w.pz, hz.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; i++)
+        for (int j = 0; j < P; j++) {
+          double *o = p + ((size_t)(off + i) * P + j) * 3;
+          o[0] = hx[(size_t)j * ld + i]; o[1] = hy[(size_t)j * ld + i]; o[2] = hz[(size_t)j * ld + i];
+        }
+    }
+    if (R) {
+      hR.resize((size_t)9 * P * ld);
+      HIP_TRY(c, hipMemcpy(hR.data(), d_R, hR.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; i++)
+        for (int j = 0; j < P; j++)
+          for (int q = 0; q < 9; q++)
+            R[((size_t)(off + i) * P + j) * 9 + q] = hR[((size_t)q * P + j) * ld + i];
+    }
+    if (L) HIP_TRY(c, hipMemcpy(L + off, w.L, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
+    if (L_i) {
+      hLi.resize((size_t)N * ld);
+      HIP_TRY(c, hipMemcpy(hLi.data(), w.Li, hLi.size() * sizeof(double), hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; i++) for (int j = 0; j < N; j++) L_i[(size_t)(off + i) * N + j] = hLi[(size_t)j * ld + i];
+    }
+    if (converged) HIP_TRY(c, hipMemcpy(converged + off, w.conv, (size_t)m, hipMemcpyDeviceToHost));
+    if (n_points) HIP_TRY(c, hipMemcpy(n_points + off, w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+  }
+  if (d_R) (void)hipFree(d_R);
+  return TR_OK;
+}
+
+// ---- state validity ------------------------------------------------------------------------
+int tr_validate_shapes_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px, const double *d_py,
+                           const double *d_pz, const int32_t *d_n_points, const double *d_Li,
+                           const uint8_t *d_converged, int check_voxels, uint64_t *d_valid_bits,
+                           uint8_t *d_flags, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
+  if (n == 0) return TR_OK;
+  if (!d_px || !d_py || !d_pz || !d_Li || !d_converged || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  int rc;
+  // the accumulated-chord scratch has the caller's leading dimension
+  if (c->ws.ld < ld) {
+    if (ld > c->max_chunk) return fail(c, TR_ERR_INVALID_ARG, "ld exceeds the workspace chunk size; call in smaller batches");
+    if ((rc = ensure_workspace(c, ld))) return rc;
+  }
+  trk::SweepIn in{d_px, d_py, d_pz, d_n_points, d_Li, d_converged, nullptr, c->ws.acc};
+  // acc scratch is laid out [P][ws.ld]; the kernel indexes it with ld, which is <= ws.ld: fine as
+  // long as P*ld <= P*ws.ld (it only needs P*ld doubles).
+  return launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream);
+}
+
+int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
+                          double *d_tips, uint8_t *d_flags, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n < 0) return fail(c, TR_ERR_INVALID_ARG, "negative batch size");
+  if (n == 0) return TR_OK;
+  if (!d_states || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  int rc;
+  if ((rc = ensure_workspace(c, n))) return rc;
+  Workspace &w = c->ws;
+  hipStream_t s = (hipStream_t)stream;
+  const int S = c->K.state_size;
+  for (int64_t off = 0; off < n; off += w.ld) {
+    const int64_t m = std::min<int64_t>(w.ld, n - off);
+    trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, d_tips ? d_tips + 3 * off : nullptr, w.conv, nullptr};
+    if ((rc = launch_fk(c, d_states + off * S, m, w.ld, out, s))) return rc;
+    trk::SweepIn in{w.px, w.py, w.pz, nullptr, w.Li, w.conv, nullptr, w.acc};
+    if ((rc = launch_sweep(c, in, m, w.ld, 1, d_valid_bits + off / 64, d_flags ? d_flags + off : nullptr, s))) return rc;
+  }
+  return TR_OK;
+}
+
+int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *valid_bits, double *tips, uint8_t *flags) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!states || !valid_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  if (n == 0) return TR_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  int rc;
+  if ((rc = ensure_staging(c, n))) return rc;
+  Workspace &w = c->ws;
+  const int S = c->K.state_size;
+  HIP_TRY(c, hipMemcpy(w.states, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice));
+  if ((rc = tr_validate_batch_dev(c, w.states, n, w.bits, tips ? w.tips : nullptr, flags ? w.flags : nullptr, nullptr))) return rc;
+  HIP_TRY(c, hipDeviceSynchronize());
+  HIP_TRY(c, hipMemcpy(valid_bits, w.bits, (size_t)((n + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  if (tips) HIP_TRY(c, hipMemcpy(tips, w.tips, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
+  if (flags) HIP_TRY(c, hipMemcpy(flags, w.flags, (size_t)n, hipMemcpyDeviceToHost));
+  return TR_OK;
+}
+
+// ---- cached voxel sets ---------------------------------------------------------------------
+int tr_check_cached_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_masks, const int64_t *d_offsets,
+                        int64_t n_items, uint64_t *d_hit_bits, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n_items < 0) return fail(c, TR_ERR_INVALID_ARG, "negative item count");
+  if (n_items == 0) return TR_OK;
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  if (!d_ids || !d_masks || !d_offsets || !d_hit_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(c, 2, s);
+  const unsigned grid = (unsigned)((n_items + 255) / 256);
+  hipLaunchKernelGGL(trk::cached_blocks_vs_grid, dim3(grid), dim3(256), 0, s, d_ids, d_masks, d_offsets, n_items,
+                     c->d_grid, c->n_blocks, d_hit_bits);
+  HIP_TRY(c, hipGetLastError());
+  return TR_OK;
+}
+
+int tr_check_cached(tr_ctx *c, const uint32_t *ids, const uint64_t *masks, const int64_t *offsets,
+                    int64_t n_items, uint64_t *hit_bits) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n_items < 0 || (n_items > 0 && (!offsets || !hit_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  if (n_items == 0) return TR_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t nnz = offsets[n_items];
+  if (nnz < 0 || (nnz > 0 && (!ids || !masks))) return fail(c, TR_ERR_INVALID_ARG, "bad CSR arrays");
+  for (int64_t i = 0; i < n_items; i++)
+    if (offsets[i] > offsets[i + 1]) return fail(c, TR_ERR_INVALID_ARG, "offsets must be non-decreasing");
+  for (int64_t k = 0; k < nnz; k++)
+    if (ids[k] >= c->n_blocks) return fail(c, TR_ERR_INVALID_ARG, "voxel dimension mismatch (block id out of range)");
+  uint32_t *d_ids = nullptr; uint64_t *d_masks = nullptr, *d_bits = nullptr; int64_t *d_off = nullptr;
+  const size_t words = (size_t)((n_items + 63) / 64);
+  int rc = TR_OK;
+  do {
+    if (hipMalloc((void **)&d_ids, std::max<size_t>(1, nnz) * sizeof(uint32_t)) != hipSuccess ||
+        hipMalloc((void **)&d_masks, std::max<size_t>(1, nnz) * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void **)&d_off, (size_t)(n_items + 1) * sizeof(int64_t)) != hipSuccess ||
+        hipMalloc((void **)&d_bits, words * sizeof(uint64_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    if ((nnz && (hipMemcpy(d_ids, ids, nnz * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess ||
+                 hipMemcpy(d_masks, masks, nnz * sizeof(uint64_t), hipMemcpyHostToDevice) != hipSuccess)) ||
+        hipMemcpy(d_off, offsets, (size_t)(n_items + 1) * sizeof(int64_t), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
+    if ((rc = tr_check_cached_dev(c, d_ids, d_masks, d_off, n_items, d_bits, nullptr))) break;
+    if (hipDeviceSynchronize() != hipSuccess ||
+        hipMemcpy(hit_bits, d_bits, words * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+  } while (0);
+  if (d_ids) (void)hipFree(d_ids);
+  if (d_masks) (void)hipFree(d_masks);
+  if (d_off) (void)hipFree(d_off);
+  if (d_bits) (void)hipFree(d_bits);
+  return rc;
+}
+
+// ---- instrumentation -----------------------------------------------------------------------
+int tr_profile_begin(tr_ctx *c) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  for (auto &v : c->events) { for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } v.clear(); }
+  c->profiling = true;
+  return TR_OK;
+}
+int tr_profile_read(tr_ctx *c, int64_t launches[TR_PROFILE_SLOTS], double total_ms[TR_PROFILE_SLOTS]) {
+  if (!c || !launches || !total_ms) return TR_ERR_INVALID_ARG;
+  HIP_TRY(c, hipSetDevice(c->device));
+  for (int s = 0; s < TR_PROFILE_SLOTS; s++) {
+    launches[s] = (int64_t)c->events[s].size();
+    double tot = 0;
+    for (auto &e : c->events[s]) {
+      HIP_TRY(c, hipEventSynchronize(e.b));
+      float ms = 0;
+      HIP_TRY(c, hipEventElapsedTime(&ms, e.a, e.b));
+      tot += ms;
+    }
+    total_ms[s] = tot;
+  }
+  return TR_OK;
+}
+int tr_profile_end(tr_ctx *c) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  c->profiling = false;
+  for (auto &v : c->events) { for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } v.clear(); }
+  return TR_OK;
+}
+
+}  // extern "C"
+
+#include "edge_host.inc"

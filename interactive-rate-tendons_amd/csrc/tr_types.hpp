@@ -1,0 +1,46 @@
+// tr_types.hpp -- plain structs shared by host and device code of libtendon_hip.so.
+#pragma once
+#include <stdint.h>
+
+#define TRK_MAX_TENDONS 8
+#define TRK_MAX_COEF    8
+
+// Robot constants handed to kernels by value (lands in SGPRs via the kernarg segment).
+// Reference: tendon/TendonRobot.h:52-58, get_stiffness_matrices tendon/TendonRobot.cpp:105-148.
+struct RobotK {
+  double ks0, ks2;            // K_se = diag(G*Ar, G*Ar, E*Ar)
+  double kb0, kb2;            // K_bt = diag(E*I, E*I, J*G)
+  double iks0, iks2;          // K_se_inv diagonal (computed as 1/x on the host, as the reference does)
+  double ikb0, ikb2;          // K_bt_inv diagonal
+  double residual_threshold;
+  double radius;              // robot radius r
+  double L, dL;
+  double min_len[TRK_MAX_TENDONS];
+  double max_len[TRK_MAX_TENDONS];
+  double home_Li[TRK_MAX_TENDONS];   // home_shape(0).L_i  (used when retraction is disabled)
+  int32_t n_tendons, n_a, n_m;
+  int32_t enable_rotation, enable_retraction;
+  int32_t state_size;
+  int32_t n_points;           // P = |t_range(0, L, dL)|
+  int32_t pad_;
+};
+
+// One RK4 step of the shared arc-length grid (retraction disabled): produced on the host by the
+// integrate_times stepping rule (Boost.odeint, call site tendon/TendonRobot.cpp:458-462).
+struct StepK {
+  double h;                   // step size
+  int32_t obs;                // backbone-point index observed after this step, or -1
+  int32_t pad_;
+};
+
+// Obstacle grid + environment rotation (collision/VoxelOctree.h:68-330 dense form,
+// motion-planning/VoxelEnvironment.h:46-49).
+struct GridK {
+  double xmin, xmax, ymin, ymax, zmin, zmax;
+  double dx, dy, dz;
+  double inv_dx, inv_dy, inv_dz;     // 1/dx() etc. exactly as VoxelOctree::add_line forms them (:338)
+  double inv_rot[9];                 // row-major
+  int32_t N, Nb;
+  int32_t rot_is_identity;
+  int32_t pad_;
+};

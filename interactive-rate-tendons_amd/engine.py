@@ -1,0 +1,238 @@
+"""Thin object wrapper over one tr_ctx (robot constants + obstacle grid resident on one GPU).
+
+Device buffers are torch tensors (torch is the memory / stream plumbing, nothing more); every
+compute call goes through the C ABI in include/tendon_hip.h.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a):
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float64))
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def unpack_bits(words, n):
+    """uint64 validity words -> bool[n] (bit i&63 of word i>>6)."""
+    w = np.ascontiguousarray(words, dtype=np.uint64)
+    return np.unpackbits(w.view(np.uint8), bitorder="little")[:n].astype(bool)
+
+
+class Engine:
+    """One context of libtendon_hip.so: tr_create ... tr_destroy."""
+
+    def __init__(self, robot, device=0):
+        self._ctx = None
+        lib = L.lib()
+        n = len(robot.tendons)
+        if n == 0:
+            raise L.OutOfRange("robot has no tendons")
+        n_a, n_m = len(robot.tendons[0].C), len(robot.tendons[0].D)
+        for t in robot.tendons:
+            if len(t.C) != n_a or len(t.D) != n_m:
+                raise L.InvalidArgument("all tendons must share C.size() and D.size() (get_r_info.cpp:112-115)")
+        self._C = _f64([t.C for t in robot.tendons]).reshape(n, n_a)
+        self._D = _f64([t.D for t in robot.tendons]).reshape(n, n_m)
+        self._maxt = _f64([t.max_tension for t in robot.tendons])
+        self._minl = _f64([t.min_length for t in robot.tendons])
+        self._maxl = _f64([t.max_length for t in robot.tendons])
+        d = L.TrRobotDesc()
+        s = robot.specs
+        d.r, d.L, d.dL, d.ro, d.ri, d.E, d.nu = robot.r, s.L, s.dL, s.ro, s.ri, s.E, s.nu
+        d.n_tendons, d.n_a, d.n_m = n, n_a, n_m
+        d.C, d.D = _dp(self._C), _dp(self._D)
+        d.max_tension, d.min_length, d.max_length = _dp(self._maxt), _dp(self._minl), _dp(self._maxl)
+        d.enable_rotation, d.enable_retraction = int(robot.enable_rotation), int(robot.enable_retraction)
+        d.residual_threshold = robot.residual_threshold
+        ctx = C.c_void_p()
+        st = lib.tr_create(C.byref(d), int(device), C.byref(ctx))
+        if st != L.TR_OK:
+            L.check(None, st)
+        self._ctx = ctx
+        self.lib = lib
+        self.device = int(device)
+        self.n_tendons = n
+        self.state_size = lib.tr_state_size(ctx)
+        self.num_points = lib.tr_num_points(ctx)
+        self.has_grid = False
+
+    def close(self):
+        if self._ctx is not None:
+            self.lib.tr_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- setup -------------------------------------------------------------------------------
+    def home_lengths(self):
+        out = np.zeros(self.n_tendons)
+        L.check(self._ctx, self.lib.tr_home_lengths(self._ctx, _dp(out)))
+        return out
+
+    def set_grid(self, N, limits, blocks, inv_rot=None):
+        lim = _f64(limits).reshape(6)
+        blk = np.ascontiguousarray(blocks, dtype=np.uint64).reshape(-1)
+        if blk.size != (N // 4) ** 3:
+            raise L.InvalidArgument("voxel dimension mismatch (%d blocks for N=%d)" % (blk.size, N))
+        rot = None if inv_rot is None else _f64(inv_rot).reshape(9)
+        L.check(self._ctx, self.lib.tr_set_grid(self._ctx, int(N), _dp(lim),
+                                                blk.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                _dp(rot) if rot is not None else None))
+        self.has_grid = True
+
+    def reserve(self, n):
+        L.check(self._ctx, self.lib.tr_reserve(self._ctx, int(n)))
+
+    def set_debug(self, bits):
+        L.check(self._ctx, self.lib.tr_set_debug(self._ctx, int(bits)))
+
+    # ---- host-buffer calls ---------------------------------------------------------------------
+    def _states(self, states):
+        st = _f64(states)
+        if st.ndim == 1:
+            st = st.reshape(1, -1)
+        if st.ndim != 2 or st.shape[1] != self.state_size:
+            raise L.InvalidArgument("State is not the right size")       # TendonRobot.h:107-109
+        return st
+
+    def fk_batch(self, states, want_R=False):
+        st = self._states(states)
+        n, P, N = st.shape[0], self.num_points, self.n_tendons
+        p = np.empty((n, P, 3))
+        R = np.empty((n, P, 9)) if want_R else None
+        Lb, Li = np.empty(n), np.empty((n, N))
+        conv = np.empty(n, dtype=np.uint8)
+        npts = np.empty(n, dtype=np.int32)
+        L.check(self._ctx, self.lib.tr_fk_batch(self._ctx, _dp(st), n, _dp(p), _dp(R) if want_R else None,
+                                                _dp(Lb), _dp(Li), conv.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                npts.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(p=p, R=R, L=Lb, L_i=Li, converged=conv.astype(bool), n_points=npts)
+
+    def validate_batch(self, states, want_tips=True, want_flags=True):
+        st = self._states(states)
+        n = st.shape[0]
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        tips = np.empty((n, 3)) if want_tips else None
+        flags = np.empty(n, dtype=np.uint8) if want_flags else None
+        L.check(self._ctx, self.lib.tr_validate_batch(
+            self._ctx, _dp(st), n, bits.ctypes.data_as(C.POINTER(C.c_uint64)),
+            _dp(tips) if want_tips else None,
+            flags.ctypes.data_as(C.POINTER(C.c_uint8)) if want_flags else None))
+        return dict(valid=unpack_bits(bits, n), bits=bits, tips=tips, flags=flags)
+
+    def validate_edges(self, a, b, min_tension_change=0.02, min_rotation_change=0.01,
+                       min_retraction_change=0.0001):
+        a, b = self._states(a), self._states(b)
+        if a.shape != b.shape:
+            raise L.InvalidArgument("start and end are different sizes")   # VoxelEnvironment.cpp:227-229
+        n = a.shape[0]
+        sp = L.TrSpaceParams(min_tension_change, min_rotation_change, min_retraction_change)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        nfk = np.zeros(n, dtype=np.int32)
+        nde = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_validate_edges(
+            self._ctx, C.byref(sp), _dp(a), _dp(b), n, bits.ctypes.data_as(C.POINTER(C.c_uint64)),
+            nfk.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nde)))
+        return dict(valid=unpack_bits(bits, n), bits=bits, n_fk=nfk, n_domain_errors=nde.value)
+
+    def check_cached(self, block_ids, masks, offsets):
+        ids = np.ascontiguousarray(block_ids, dtype=np.uint32)
+        mk = np.ascontiguousarray(masks, dtype=np.uint64)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        n = off.size - 1
+        bits = np.zeros((max(n, 0) + 63) // 64, dtype=np.uint64)
+        L.check(self._ctx, self.lib.tr_check_cached(
+            self._ctx, ids.ctypes.data_as(C.POINTER(C.c_uint32)), mk.ctypes.data_as(C.POINTER(C.c_uint64)),
+            off.ctypes.data_as(C.POINTER(C.c_int64)), n, bits.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return unpack_bits(bits, n)
+
+    # ---- device-buffer calls (torch tensors on this engine's GPU) -------------------------------
+    @staticmethod
+    def _stream_ptr(stream):
+        if stream is None:
+            stream = _torch().cuda.current_stream()
+        return C.c_void_p(stream.cuda_stream)
+
+    def _check_dev(self, t, dtype, min_numel, name):
+        torch = _torch()
+        if not (isinstance(t, torch.Tensor) and t.is_cuda and t.dtype == dtype and t.is_contiguous()
+                and t.device.index == self.device and t.numel() >= min_numel):
+            raise L.InvalidArgument("%s must be a contiguous %s tensor on cuda:%d with >= %d elements"
+                                    % (name, dtype, self.device, min_numel))
+        return C.c_void_p(t.data_ptr())
+
+    def validate_batch_dev(self, d_states, n, d_bits, d_tips=None, d_flags=None, stream=None):
+        torch = _torch()
+        ps = self._check_dev(d_states, torch.float64, n * self.state_size, "d_states")
+        pb = self._check_dev(d_bits, torch.int64, (n + 63) // 64, "d_bits")
+        pt = self._check_dev(d_tips, torch.float64, 3 * n, "d_tips") if d_tips is not None else None
+        pf = self._check_dev(d_flags, torch.uint8, n, "d_flags") if d_flags is not None else None
+        L.check(self._ctx, self.lib.tr_validate_batch_dev(self._ctx, ps, int(n), pb, pt, pf, self._stream_ptr(stream)))
+
+    def fk_batch_dev(self, d_states, n, ld, d_px, d_py, d_pz, d_L=None, d_Li=None, d_conv=None, d_R=None,
+                     d_npts=None, stream=None):
+        torch = _torch()
+        P = self.num_points
+        ps = self._check_dev(d_states, torch.float64, n * self.state_size, "d_states")
+        px = self._check_dev(d_px, torch.float64, P * ld, "d_px")
+        py = self._check_dev(d_py, torch.float64, P * ld, "d_py")
+        pz = self._check_dev(d_pz, torch.float64, P * ld, "d_pz")
+        pR = self._check_dev(d_R, torch.float64, 9 * P * ld, "d_R") if d_R is not None else None
+        pL = self._check_dev(d_L, torch.float64, n, "d_L") if d_L is not None else None
+        pLi = self._check_dev(d_Li, torch.float64, self.n_tendons * ld, "d_Li") if d_Li is not None else None
+        pc = self._check_dev(d_conv, torch.uint8, n, "d_conv") if d_conv is not None else None
+        pn = self._check_dev(d_npts, torch.int32, n, "d_npts") if d_npts is not None else None
+        L.check(self._ctx, self.lib.tr_fk_batch_dev(self._ctx, ps, int(n), int(ld), px, py, pz, pR, pL, pLi, pc, pn,
+                                                    self._stream_ptr(stream)))
+
+    def validate_shapes_dev(self, n, ld, d_px, d_py, d_pz, d_Li, d_conv, d_bits, d_flags=None, d_npts=None,
+                            check_voxels=True, stream=None):
+        torch = _torch()
+        P = self.num_points
+        px = self._check_dev(d_px, torch.float64, P * ld, "d_px")
+        py = self._check_dev(d_py, torch.float64, P * ld, "d_py")
+        pz = self._check_dev(d_pz, torch.float64, P * ld, "d_pz")
+        pLi = self._check_dev(d_Li, torch.float64, self.n_tendons * ld, "d_Li")
+        pc = self._check_dev(d_conv, torch.uint8, n, "d_conv")
+        pb = self._check_dev(d_bits, torch.int64, (n + 63) // 64, "d_bits")
+        pf = self._check_dev(d_flags, torch.uint8, n, "d_flags") if d_flags is not None else None
+        pn = self._check_dev(d_npts, torch.int32, n, "d_npts") if d_npts is not None else None
+        L.check(self._ctx, self.lib.tr_validate_shapes_dev(self._ctx, int(n), int(ld), px, py, pz, pn, pLi, pc,
+                                                           int(bool(check_voxels)), pb, pf, self._stream_ptr(stream)))
+
+    def check_cached_dev(self, d_ids, d_masks, d_offsets, n_items, d_bits, stream=None):
+        torch = _torch()
+        pi = self._check_dev(d_ids, torch.int32, 0, "d_ids")
+        pm = self._check_dev(d_masks, torch.int64, 0, "d_masks")
+        po = self._check_dev(d_offsets, torch.int64, n_items + 1, "d_offsets")
+        pb = self._check_dev(d_bits, torch.int64, (n_items + 63) // 64, "d_bits")
+        L.check(self._ctx, self.lib.tr_check_cached_dev(self._ctx, pi, pm, po, int(n_items), pb,
+                                                        self._stream_ptr(stream)))
+
+    # ---- instrumentation -----------------------------------------------------------------------
+    def profile_begin(self):
+        L.check(self._ctx, self.lib.tr_profile_begin(self._ctx))
+
+    def profile_read(self):
+        n = (C.c_int64 * L.TR_PROFILE_SLOTS)()
+        ms = (C.c_double * L.TR_PROFILE_SLOTS)()
+        L.check(self._ctx, self.lib.tr_profile_read(self._ctx, n, ms))
+        return {name: dict(launches=int(n[i]), total_ms=float(ms[i])) for i, name in enumerate(L.PROFILE_SLOT_NAMES)}
+
+    def profile_end(self):
+        L.check(self._ctx, self.lib.tr_profile_end(self._ctx))

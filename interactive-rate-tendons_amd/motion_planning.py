@@ -1,0 +1,128 @@
+"""Host-side mirror of the reference's validity plug-ins for the hot path
+(cpp/src/motion-planning/{VoxelEnvironment, AbstractValidityChecker, AbstractVoxelValidityChecker,
+VoxelBackboneValidityChecker, AbstractVoxelMotionValidator, VoxelBackboneMotionValidator}):
+same names and semantics, operating on robot states (`std::vector<double>` in the reference,
+AbstractValidityChecker.cpp:50-78) -- one or a batch.  OMPL itself is not a dependency here; the
+OMPL-facing virtuals (isValid(const State*), checkMotion(s1, s2)) are the C++ shim shown in
+INTEGRATION.md.
+"""
+import time
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _lib as L
+from .collision import VoxelOctree
+from .tendon import TendonRobot
+
+
+class FunctionTimer:
+    """util::FunctionTimer (util/FunctionTimer.h:14-91): one wall-time sample per timed call.
+    Here a call is a whole batch."""
+
+    def __init__(self):
+        self.times = []
+
+    def time(self, f, *a, **k):
+        t0 = time.perf_counter()
+        try:
+            return f(*a, **k)
+        finally:
+            self.times.append(time.perf_counter() - t0)
+
+    def get_times(self): return self.times
+    def clear(self): self.times = []
+
+
+@dataclass
+class VoxelEnvironment:                    # motion-planning/VoxelEnvironment.h:31-49
+    filename: str = ""
+    scaling: float = 1.0
+    translation: np.ndarray = field(default_factory=lambda: np.zeros(3))
+    inv_rotation: np.ndarray = field(default_factory=lambda: np.eye(3))
+    interior_fname: str = ""
+    _obstacle_cache: VoxelOctree = None
+
+    def set_obstacle_cache(self, obstacles):
+        self._obstacle_cache = obstacles
+
+    def get_obstacles(self):
+        if self._obstacle_cache is None:
+            raise L.Unsupported("loading voxel files (nrrd/json/toml) is outside the hot path")
+        return self._obstacle_cache
+
+    def rotate_point(self, p):             # VoxelEnvironment.cpp:125-127
+        return np.asarray(self.inv_rotation, float) @ np.asarray(p, float)
+
+    def rotate_points(self, pts):          # VoxelEnvironment.cpp:129-131
+        return (np.asarray(self.inv_rotation, float) @ np.asarray(pts, float).T).T
+
+
+class VoxelBackboneValidityChecker:
+    """motion-planning/VoxelBackboneValidityChecker.h:28-58 over AbstractVoxelValidityChecker /
+    AbstractValidityChecker.  `is_valid(states)` is AbstractValidityChecker::isValid
+    (AbstractValidityChecker.cpp:124-133) for a batch: one K1 + one K2 launch."""
+
+    def __init__(self, robot: TendonRobot, venv: VoxelEnvironment, voxels: VoxelOctree, device=0):
+        self._robot, self._venv, self._voxels = robot, venv, voxels
+        self._timers = {k: FunctionTimer() for k in
+                        ("fk", "collision", "self_collision", "voxelize", "collision-without-voxelizing", "is_valid")}
+        self.engine = robot.engine(device)
+        # constructor check of VoxelBackboneValidityChecker.h:37-45 is enforced by tr_set_grid
+        self.engine.set_grid(voxels.Nx(), voxels.limits(), voxels.blocks, venv.inv_rotation)
+
+    def robot(self): return self._robot
+    def timers(self): return self._timers
+    def timer(self, name): return self._timers[name]
+    def calls(self, name): return len(self._timers[name].get_times())
+
+    def clear_timing(self):
+        for t in self._timers.values():
+            t.clear()
+
+    def fk(self, robot_states):
+        """AbstractValidityChecker::fk (AbstractValidityChecker.cpp:80-97) for a batch."""
+        return self._timers["fk"].time(self.engine.fk_batch, robot_states)
+
+    def is_valid(self, robot_states):
+        """bool[n]: full state validity (FK, converged, lengths, self collision, voxel collision)."""
+        return self._timers["is_valid"].time(self.engine.validate_batch, robot_states, False, False)["valid"]
+
+    def is_valid_detail(self, robot_states):
+        """valid, tips (fk_shape.p.back(), VoxelCachedLazyPRM.cpp:1438) and TR_FLAG_* bits."""
+        return self._timers["is_valid"].time(self.engine.validate_batch, robot_states, True, True)
+
+    def isValid(self, robot_state):
+        """Single state, reference spelling."""
+        return bool(self.is_valid(np.asarray(robot_state, float).reshape(1, -1))[0])
+
+
+class VoxelBackboneMotionValidator:
+    """motion-planning/VoxelBackboneMotionValidator.{h,cpp} over AbstractVoxelMotionValidator:
+    `check_motion(a, b)` is checkMotion(s1, s2) (AbstractVoxelMotionValidator.h:143-151) for a
+    batch of edges."""
+
+    def __init__(self, checker: VoxelBackboneValidityChecker, min_tension_change=0.02,
+                 min_rotation_change=0.01, min_retraction_change=0.0001):
+        self._vc = checker
+        self.engine = checker.engine
+        self.min_tension_change = min_tension_change          # Problem.h:59
+        self.min_rotation_change = min_rotation_change        # Problem.h:61
+        self.min_retraction_change = min_retraction_change    # Problem.h:62
+        self._timers = {"voxelize-swept-volume": FunctionTimer(), "collision-swept-volume": FunctionTimer()}
+        self._num_voxelize_errors = 0
+
+    def validity_checker(self): return self._vc
+    def timers(self): return self._timers
+    def num_voxelize_errors(self): return self._num_voxelize_errors
+
+    def check_motion_detail(self, a, b):
+        return self._timers["voxelize-swept-volume"].time(
+            self.engine.validate_edges, a, b, self.min_tension_change, self.min_rotation_change,
+            self.min_retraction_change)
+
+    def check_motion(self, a, b):
+        return self.check_motion_detail(a, b)["valid"]
+
+    def checkMotion(self, s1, s2):
+        return bool(self.check_motion(np.asarray(s1, float).reshape(1, -1), np.asarray(s2, float).reshape(1, -1))[0])

@@ -1,0 +1,138 @@
+"""Host-side mirror of the reference's `tendon` namespace for the hot path
+(cpp/src/tendon/{BackboneSpecs,TendonSpecs,TendonResult,TendonRobot}.h): same names, argument
+meaning and error behaviour; all arithmetic runs in libtendon_hip.so on the GPU.
+"""
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Engine
+
+
+@dataclass
+class BackboneSpecs:                       # tendon/BackboneSpecs.h:14-20
+    L: float = 0.2
+    dL: float = 0.005
+    ro: float = 0.01
+    ri: float = 0.0
+    E: float = 2.1e6
+    nu: float = 0.3
+
+
+@dataclass
+class TendonSpecs:                         # tendon/TendonSpecs.h:25-30
+    C: List[float] = field(default_factory=lambda: [0.0])
+    D: List[float] = field(default_factory=lambda: [0.01])
+    max_tension: float = 20.0
+    min_length: float = -0.015
+    max_length: float = 0.035
+
+    @staticmethod
+    def _degree(c, eps):
+        for i in range(len(c) - 1, 0, -1):
+            if abs(c[i]) > eps:
+                return i
+        return 0
+
+    def r_degree(self, eps=0.0):
+        return self._degree(self.D, eps)
+
+    def theta_degree(self, eps=0.0):
+        return self._degree(self.C, eps)
+
+    def is_straight(self, eps=0.0):        # TendonSpecs.h:36-38
+        return self.r_degree(eps) == 0 and self.theta_degree(eps) == 0
+
+    def is_helix(self, eps=0.0):           # TendonSpecs.h:40-42
+        return self.r_degree(eps) == 0 and self.theta_degree(eps) == 1
+
+
+@dataclass
+class TendonResult:                        # tendon/TendonResult.h:17-40
+    t: np.ndarray
+    p: np.ndarray                          # (P, 3)
+    R: np.ndarray                          # (P, 3, 3) or None
+    L: float
+    L_i: np.ndarray
+    converged: bool = True
+
+
+class TendonRobot:
+    """tendon::TendonRobot (tendon/TendonRobot.h:52-355), batched on the GPU."""
+
+    def __init__(self, tendons=None, specs=None, r=0.015, enable_rotation=False, enable_retraction=False,
+                 residual_threshold=5e-6):
+        self.r = r
+        self.specs = specs or BackboneSpecs()
+        self.tendons = list(tendons or [])
+        self.enable_rotation = enable_rotation
+        self.enable_retraction = enable_retraction
+        self.residual_threshold = residual_threshold
+        self._engines = {}
+
+    def state_size(self):                  # TendonRobot.h:60-64
+        return len(self.tendons) + int(self.enable_rotation) + int(self.enable_retraction)
+
+    def engine(self, device=0) -> Engine:
+        """The GPU context holding this robot's constants (created on first use)."""
+        if device not in self._engines:
+            self._engines[device] = Engine(self, device)
+        return self._engines[device]
+
+    def _t(self, device=0):
+        # the shared arc-length grid is re-derived on the host only for TendonResult.t
+        s = self.specs
+        vals, p = [], 0.0
+        while p <= s.L - s.dL / 2:
+            vals.append(p)
+            p += s.dL
+        vals.append(s.L)
+        return np.array([s.L - (v - 0.0) for v in vals])[::-1].copy()
+
+    # ---- single-configuration API (reference signatures) -----------------------------------------
+    def shape(self, state, device=0) -> TendonResult:          # TendonRobot.h:105-115
+        state = np.asarray(state, dtype=np.float64).reshape(-1)
+        if state.size != self.state_size():
+            raise L.InvalidArgument("State is not the right size")
+        out = self.engine(device).fk_batch(state.reshape(1, -1), want_R=True)
+        n = int(out["n_points"][0])
+        R = out["R"][0, :n].reshape(n, 3, 3).transpose(0, 2, 1)    # column-major storage -> R[j][r][c]
+        return TendonResult(t=self._t()[:n], p=out["p"][0, :n], R=R, L=float(out["L"][0]),
+                            L_i=out["L_i"][0], converged=bool(out["converged"][0]))
+
+    def forward_kinematics(self, state, device=0):              # TendonRobot.h:68-72
+        return self.shape(state, device).p
+
+    def home_shape(self, s_start=0.0, device=0) -> TendonResult:  # TendonRobot.cpp:249-314 (s_start = 0)
+        if s_start != 0.0:
+            raise L.Unsupported("home_shape(s_start != 0) needs retraction support")
+        t = self._t()
+        p = np.zeros((t.size, 3))
+        p[:, 2] = t
+        R = np.tile(np.eye(3), (t.size, 1, 1))
+        return TendonResult(t=t, p=p, R=R, L=self.specs.L, L_i=self.engine(device).home_lengths(), converged=True)
+
+    def calc_dl(self, home_l, other_l):                        # TendonRobot.h:247-259
+        home_l, other_l = np.asarray(home_l, float), np.asarray(other_l, float)
+        if home_l.shape != other_l.shape:
+            raise L.OutOfRange("vector size mismatch")
+        return home_l - other_l
+
+    def is_within_length_limits(self, dl):                     # TendonRobot.h:268-278
+        dl = np.asarray(dl, float)
+        if dl.shape[-1] != len(self.tendons):
+            raise L.OutOfRange("length mismatch")
+        lo = np.array([t.min_length for t in self.tendons])
+        hi = np.array([t.max_length for t in self.tendons])
+        return bool(np.all(~((dl < lo) | (hi < dl))))
+
+    # ---- batched API ---------------------------------------------------------------------------
+    def shape_batch(self, states, want_R=False, device=0):
+        """Batched shape(): dict(p (n,P,3), R, L, L_i, converged, n_points)."""
+        return self.engine(device).fk_batch(states, want_R=want_R)
+
+    def forward_kinematics_batch(self, states, device=0):
+        """The omp loop of apps/estimate_length_discretization.cpp:62-71 as one launch."""
+        return self.engine(device).fk_batch(states)["p"]

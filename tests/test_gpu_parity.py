@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded
+inputs.  Tolerances: FK (floating point) tip / point position <= 1e-9 m absolute (north_star's
+"stated fp64 tip-position tolerance"); everything downstream of the points (validity predicate,
+voxel sweep) bit-exact when fed identical points, and verdict-identical end to end on these sets.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TIP_TOL = 1e-9      # metres
+LEN_TOL = 1e-10
+
+
+def _soa(p, ld):
+    """(n, P, 3) -> three (P, ld) arrays."""
+    n, P, _ = p.shape
+    out = []
+    for k in range(3):
+        a = np.zeros((P, ld))
+        a[:, :n] = p[:, :, k].T
+        out.append(a)
+    return out
+
+
+def _fk_check(irt, orc, helpers, robot, states):
+    orb = helpers.oracle_robot(orc, robot)
+    want = orb.fk_batch(states)
+    got = robot.shape_batch(states)
+    assert got["p"].shape == want["p"].shape
+    assert np.array_equal(got["converged"], want["converged"])
+    err = np.abs(got["p"] - want["p"]).max()
+    tip = np.abs(got["p"][:, -1] - want["p"][:, -1]).max()
+    assert tip <= TIP_TOL and err <= TIP_TOL, (tip, err)
+    assert np.abs(got["L"] - want["L"]).max() <= LEN_TOL
+    assert np.abs(got["L_i"] - want["L_i"]).max() <= LEN_TOL
+    assert (got["n_points"] == got["p"].shape[1]).all()
+    return err
+
+
+def test_fk_config1_linear_routed(irt, orc, helpers):
+    """BASELINE config 1: 3-tendon linear-routed robot, 1000 random configs, FK only."""
+    robot = irt.workloads.robot_config1()
+    states = irt.workloads.random_states(robot, 1000, seed=42)
+    err = _fk_check(irt, orc, helpers, robot, states)
+    print("config1 max point error %.3g m" % err)
+
+
+def test_fk_config2_helical(irt, orc, helpers):
+    robot = irt.workloads.robot_config2()
+    states = irt.workloads.random_states(robot, 1500, seed=43, tau_max=20.0)
+    _fk_check(irt, orc, helpers, robot, states)
+
+
+def test_fk_config3_quadratic_4_tendons(irt, orc, helpers):
+    robot = irt.workloads.robot_config3()
+    states = irt.workloads.random_states(robot, 1000, seed=44)
+    _fk_check(irt, orc, helpers, robot, states)
+
+
+def test_fk_rotation_and_R(irt, orc, helpers):
+    robot = irt.workloads.robot_config1()
+    robot.enable_rotation = True
+    states = irt.workloads.random_states(robot, 300, seed=45)
+    _fk_check(irt, orc, helpers, robot, states)
+    orb = helpers.oracle_robot(orc, robot)
+    for s in states[:5]:
+        want = orb.shape(s)
+        got = robot.shape(s)
+        assert np.abs(got.p - want["p"]).max() <= TIP_TOL
+        Rw = want["R"].reshape(-1, 3, 3).transpose(0, 2, 1)     # oracle stores column-major
+        assert np.abs(got.R - Rw).max() <= 1e-8
+        assert np.allclose(got.t, want["t"], rtol=0, atol=0)
+
+
+def test_fk_zero_tension_is_home_shape(irt):
+    """Known answer: shape(0) is the straight home shape (TendonRobot.cpp:272-292)."""
+    robot = irt.workloads.robot_config2()
+    res = robot.shape([0.0, 0.0, 0.0])
+    assert res.converged
+    assert np.abs(res.p[:, :2]).max() == 0.0
+    assert np.abs(res.p[:, 2] - res.t).max() <= 1e-13
+    home = robot.home_shape()
+    assert np.abs(res.L_i - home.L_i).max() <= 1e-12
+    assert abs(res.L - 0.2) <= 1e-13
+
+
+def test_fk_odd_batch_sizes(irt, orc, helpers):
+    robot = irt.workloads.robot_config1()
+    orb = helpers.oracle_robot(orc, robot)
+    for n in (1, 63, 64, 65, 130):
+        states = irt.workloads.random_states(robot, n, seed=100 + n)
+        got = robot.shape_batch(states)
+        want = orb.fk_batch(states)
+        assert np.abs(got["p"] - want["p"]).max() <= TIP_TOL
+
+
+def _checker(irt, robot, vox, inv_rot=None):
+    env = irt.VoxelEnvironment()
+    if inv_rot is not None:
+        env.inv_rotation = inv_rot
+    return irt.VoxelBackboneValidityChecker(robot, env, vox)
+
+
+def _sweep_case(irt, orc, helpers, robot, n, seed, tau_max):
+    import torch
+    W = irt.workloads
+    vox, _ = W.reach_environment(seed=3, n_spheres=48)
+    chk = _checker(irt, robot, vox)
+    orb = helpers.oracle_robot(orc, robot)
+    og = helpers.oracle_grid(orc, vox)
+    states = W.random_states(robot, n, seed=seed, tau_max=tau_max)
+    fk = orb.fk_batch(states)
+    want_valid = np.zeros(n, bool)
+    want_flags = np.zeros(n, np.uint8)
+    for i in range(n):
+        v, _, fl = orc.is_valid_state(orb, og, states[i])
+        want_valid[i], want_flags[i] = v, fl
+    ld = (n + 63) // 64 * 64
+    N = len(robot.tendons)
+    px, py, pz = (torch.from_numpy(a).cuda() for a in _soa(fk["p"], ld))
+    Li = np.zeros((N, ld)); Li[:, :n] = fk["L_i"].T
+    d_Li = torch.from_numpy(Li).cuda()
+    d_conv = torch.from_numpy(fk["converged"].astype(np.uint8)).cuda()
+    d_bits = torch.zeros(ld // 64, dtype=torch.int64, device="cuda")
+    d_flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    for debug in (0, 1):              # skip sweep and brute-force self-collision must agree
+        chk.engine.set_debug(debug)
+        chk.engine.validate_shapes_dev(n, ld, px, py, pz, d_Li, d_conv, d_bits, d_flags)
+        torch.cuda.synchronize()
+        got_valid = irt.unpack_bits(d_bits.cpu().numpy().view(np.uint64), n)
+        got_flags = d_flags.cpu().numpy()
+        assert np.array_equal(got_flags, want_flags), np.flatnonzero(got_flags != want_flags)[:10]
+        assert np.array_equal(got_valid, want_valid)
+    chk.engine.set_debug(0)
+    return np.bincount(want_flags, minlength=16)
+
+
+def test_sweep_bit_exact_on_oracle_points(irt, orc, helpers):
+    """K2 alone on the ORACLE's fp64 points: flags and verdicts must match bit for bit, with the
+    conservative-skip self-collision sweep and with the brute-force one."""
+    W = irt.workloads
+    # (A) straight tendons, thin robot, high tension: length limits, self collision, obstacles
+    ra = W.robot_config1()
+    ra.specs.dL = 0.2 / 128
+    ra.r = 0.01
+    for t in ra.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 0.08
+    ha = _sweep_case(irt, orc, helpers, ra, 2500, 5, 100.0)
+    # (B) helical tendons at high tension: non-converged base solves
+    rb = W.robot_config2()
+    for t in rb.tendons:
+        t.max_tension, t.max_length = 60.0, 0.02
+    hb = _sweep_case(irt, orc, helpers, rb, 1500, 6, 45.0)
+    hist = ha + hb
+    print("flag histogram", hist)
+    # together the sets exercise every branch of the predicate
+    assert hist[15] > 0 and hist[7] > 0 and hist[3] > 0 and hist[1] > 0 and hist[0] > 0
+
+
+def test_validate_batch_matches_oracle(irt, orc, helpers):
+    """End to end (GPU FK -> GPU sweep) against oracle verdicts and tips."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = _checker(irt, robot, vox)
+    orb = helpers.oracle_robot(orc, robot)
+    og = helpers.oracle_grid(orc, vox)
+    states = W.random_states(robot, 20000, seed=11, tau_max=20.0)
+    got = chk.is_valid_detail(states)
+    want, tips, _ = orc.validate_batch(orb, og, states, nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(got["valid"], want), int((got["valid"] != want).sum())
+    assert np.abs(got["tips"] - tips).max() <= TIP_TOL
+    assert 0.2 < want.mean() < 0.95
+    # padding bits of the last word are zero
+    assert got["bits"][-1] >> np.uint64(20000 % 64) == 0 if 20000 % 64 else True
+
+
+def test_validate_batch_rotated_environment(irt, orc, helpers):
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=9, n_spheres=64)
+    a = 0.3
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    chk = _checker(irt, robot, vox, rot)
+    orb = helpers.oracle_robot(orc, robot)
+    og = helpers.oracle_grid(orc, vox)
+    states = W.random_states(robot, 4000, seed=12, tau_max=20.0)
+    want, _, _ = orc.validate_batch(orb, og, states, inv_rot=rot, nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(chk.is_valid(states), want)
+
+
+def test_self_collision_cases(irt, orc, helpers):
+    """Tight curls: self-collision verdicts bit-exact against the oracle on the GPU's own points."""
+    W = irt.workloads
+    robot = W.robot_config1()
+    robot.specs.dL = 0.2 / 128
+    robot.r = 0.012
+    for t in robot.tendons:
+        t.max_tension = 80.0
+        t.min_length, t.max_length = -1.0, 1.0
+    vox = irt.VoxelOctree(256)
+    vox.set_xlim(-0.25, 0.25); vox.set_ylim(-0.25, 0.25); vox.set_zlim(-0.25, 0.25)
+    chk = _checker(irt, robot, vox)
+    orb = helpers.oracle_robot(orc, robot)
+    states = W.random_states(robot, 2000, seed=21, tau_max=80.0)
+    got = chk.is_valid_detail(states)
+    fk = robot.shape_batch(states)
+    want_self = np.array([orb.collides_self(fk["p"][i]) for i in range(len(states))])
+    got_self = (got["flags"] & 4) == 0
+    conv_len = (got["flags"] & 3) == 3
+    assert np.array_equal(got_self[conv_len], want_self[conv_len])
+    assert want_self[conv_len].sum() > 20 and (~want_self[conv_len]).sum() > 20
+
+
+def test_empty_and_error_paths(irt):
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=7, n_spheres=4)
+    chk = _checker(irt, robot, vox)
+    assert chk.is_valid(np.zeros((0, 3))).size == 0
+    with pytest.raises(irt.InvalidArgument):          # "State is not the right size"
+        chk.is_valid(np.zeros((4, 5)))
+    coarse = irt.VoxelOctree(64)                      # voxel 7.8 mm > dL is fine; dL > voxel is not
+    coarse.set_xlim(-0.25, 0.25); coarse.set_ylim(-0.25, 0.25); coarse.set_zlim(-0.25, 0.25)
+    _checker(irt, robot, coarse)
+    fine = irt.VoxelOctree(512)
+    fine.set_xlim(-0.25, 0.25); fine.set_ylim(-0.25, 0.25); fine.set_zlim(-0.25, 0.25)
+    with pytest.raises(irt.InvalidArgument):          # VoxelBackboneValidityChecker.h:37-45
+        _checker(irt, robot, fine)
+    with pytest.raises(irt.LengthError):
+        v = irt.VoxelOctree(8)
+        v.set_xlim(1.0, 1.0)
