@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- FK+collision checks/sec (3-tendon helical robot, 256^3 voxel environment).
+
+One "step" = one pass of the hot path (K1 fk_rk4_batch -> K2 backbone_voxel_sweep, plus for N>1
+the all-gather of the validity bitmask) over one batch of 2^20 synthetic configurations PER GPU
+(weak scaling), inputs resident in HBM before the timed region.  Workload = BASELINE.json
+configs[1] as specified in BASELINE.md section 2 (seeded, synthetic).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+Rank 0 prints ONE JSON line; see README / DESIGN.md for the `roofline` and `cpu_baseline` objects.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_VALU_PEAK_TF = 78.6       # 256 CU x 4 SIMD x 16 fp64 FMA lanes/clk x 2 flop x 2.4 GHz
+BATCH_LOG2 = 20
+
+
+def algorithmic_bytes_per_check(S, P, N):
+    """SURVEY.md section 8(d), unfused pair: K1 reads 8S, writes 24P + 8(N+1) + 1; K2 reads 24P (+L_i,
+    converged), writes 1 bit."""
+    k1 = 8 * S + 24 * P + 8 * (N + 1) + 1
+    k2 = 24 * P + 8 * N + 1 + 0.125
+    return k1, k2
+
+
+def cpu_baseline(irt, robot, vox, states, budget_s=12.0):
+    """The oracle's OpenMP port (oracle/_build/liboracle_omp.so) on this box's host cores, on a
+    bounded sample of the same configurations.  kind = "port": the reference itself cannot be
+    built."""
+    from oracle import oracle as orc
+    s = robot.specs
+    orb = orc.Robot([t.C for t in robot.tendons], [t.D for t in robot.tendons], r=robot.r, L=s.L, dL=s.dL,
+                    ro=s.ro, ri=s.ri, E=s.E, nu=s.nu, max_tension=[t.max_tension for t in robot.tendons],
+                    min_length=[t.min_length for t in robot.tendons], max_length=[t.max_length for t in robot.tendons],
+                    residual_threshold=robot.residual_threshold, lib="omp")
+    og = orc.Grid(vox.Nx(), vox.limits(), lib="omp")
+    og.blocks()[...] = vox.blocks
+    threads = orc.max_threads()
+    # calibrate on a small slice, then size the sample for ~budget_s of CPU work
+    t0 = time.perf_counter()
+    orc.validate_batch(orb, og, states[:2048], nthreads=threads, lib=orc.omp_lib())
+    orc.validate_batch(orb, og, states[:2048], nthreads=threads, lib=orc.omp_lib())
+    rate = 2 * 2048 / (time.perf_counter() - t0)
+    m = int(min(len(states), max(4096, rate * budget_s)))
+    t0 = time.perf_counter()
+    valid, _, used = orc.validate_batch(orb, og, states[:m], nthreads=threads, lib=orc.omp_lib())
+    dt = time.perf_counter() - t0
+    return dict(value=m / dt, unit="checks/s", cores=int(used), kind="port",
+                sample="first %d of the %d configurations of rank 0's batch, %.1f s wall, OpenMP schedule(dynamic,1)"
+                       % (m, len(states), dt)), valid, m
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-log2", type=int, default=BATCH_LOG2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    irt = importlib.import_module("interactive-rate-tendons_amd")
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    checker = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox, device=local_rank)
+    eng = checker.engine
+    n = 1 << args.batch_log2
+    S, P, N = eng.state_size, eng.num_points, eng.n_tendons
+    # every rank validates its own shard of the global candidate sequence (weak scaling)
+    states = irt.distributed.candidate_states(robot, seed=2024, start=rank * n, count=n, tau_max=10.0)
+    d_states = torch.from_numpy(states).cuda()
+    d_bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
+    d_tips = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    d_all = torch.zeros(world * (n // 64), dtype=torch.int64, device="cuda") if world > 1 else None
+    eng.reserve(n)
+
+    def step():
+        eng.validate_batch_dev(d_states, n, d_bits, d_tips)
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_bits)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_end()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    valid_bits = d_bits.cpu().numpy().view(np.uint64)
+    valid = irt.unpack_bits(valid_bits, n)
+    checks = world * n * args.steps
+
+    if rank == 0:
+        k1b, k2b = algorithmic_bytes_per_check(S, P, N)
+        k1 = prof["fk_rk4_batch"]
+        k2 = prof["backbone_voxel_sweep"]
+        k1_ms = k1["total_ms"] / max(1, k1["launches"])
+        k2_ms = k2["total_ms"] / max(1, k2["launches"])
+        units_per_launch = n * args.steps / max(1, k1["launches"])
+        dom_name, dom_ms, dom_bytes = ("fk_rk4_batch", k1_ms, k1b) if k1_ms >= k2_ms else ("backbone_voxel_sweep", k2_ms, k2b)
+        achieved = dom_bytes * units_per_launch / (dom_ms * 1e-3) / 1e9
+        traffic = None
+        if os.path.exists(args.traffic_json):
+            try:
+                tj = json.load(open(args.traffic_json))
+                traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        flops_per_check = 1.1e6                                  # N=3, P=129 (+-20 %)
+        out = {
+            "metric": "FK+collision checks/sec (3-tendon, 256^3 voxel env)",
+            "value": checks / elapsed,
+            "unit": "checks/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "configs[1]: 3-tendon helical-routed robot (C=[2*pi*k/3, 5], D=[0.01], L=0.2, dL=L/128, "
+                                   "129 backbone points), 2^%d seeded configs per GPU per step (tau~U[0,10)^3), batched FK + "
+                                   "256^3 voxel collision (64 seeded spheres r=0.02 in reach)" % args.batch_log2,
+                       "batch_per_gpu": n, "parallelism": "shard%d+allgather(bitmask)" % world if world > 1 else "single",
+                       "valid_fraction_rank0": float(valid.mean())},
+            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "algorithmic_bytes_per_check": dom_bytes, "avg_launch_ms": dom_ms},
+            "kernels": {"fk_rk4_batch": {"avg_ms": k1_ms, "launches": k1["launches"], "bytes_per_check": k1b},
+                        "backbone_voxel_sweep": {"avg_ms": k2_ms, "launches": k2["launches"], "bytes_per_check": k2b}},
+            "valu_fp64": {"achieved_tflops": flops_per_check * units_per_launch / (k1_ms * 1e-3) / 1e12,
+                          "peak_tflops": FP64_VALU_PEAK_TF,
+                          "frac": flops_per_check * units_per_launch / (k1_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
+                          "note": "K1 is fp64-VALU-bound (SURVEY 8d); flops/check is the op-counted estimate"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, cpu_valid, m = cpu_baseline(irt, robot, vox, states)
+            out["cpu_baseline"] = cb
+            out["config"]["verdicts_match_cpu_sample"] = bool(np.array_equal(valid[:m], cpu_valid))
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

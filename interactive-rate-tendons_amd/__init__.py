@@ -16,11 +16,11 @@ from .tendon import BackboneSpecs, TendonSpecs, TendonResult, TendonRobot
 from .collision import VoxelOctree
 from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelBackboneMotionValidator,
                               FunctionTimer)
-from . import workloads
+from . import workloads, distributed
 
 __all__ = [
     "TendonHipError", "InvalidArgument", "OutOfRange", "DomainError", "LengthError", "HipError", "Unsupported",
     "build", "LIB_PATH", "Engine", "unpack_bits", "BackboneSpecs", "TendonSpecs", "TendonResult", "TendonRobot",
     "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelBackboneMotionValidator",
-    "FunctionTimer", "workloads",
+    "FunctionTimer", "workloads", "distributed",
 ]

@@ -1,0 +1,97 @@
+"""Multi-GPU sharding of roadmap vertex validation (BASELINE config 4): one process per GPU,
+contiguous vertex shards, no data-path collective inside the FK/collision kernels, and ONE
+all-gather of the packed validity bitmask (RCCL over xGMI; `gloo` in CPU tests) before the
+host connects edges -- the exchange step the reference's single-process createRoadmap gets for
+free from shared memory (motion-planning/VoxelCachedLazyPRM.cpp:1446-1483: parallel vertex
+validation, then serial addMilestone over ALL vertices).
+
+Candidate vertices come from a counter-keyed generator (chunk index -> stream), so the candidate
+set and therefore the gathered mask are identical for every world size.
+"""
+import numpy as np
+
+WORD = 64
+RNG_CHUNK = 1 << 16
+
+
+def shard_bounds(M, world_size, rank):
+    """Contiguous equal shards of M items padded so every shard is a whole number of 64-bit mask
+    words (all-gather needs equal counts).  Returns (start, stop, shard_len); stop may exceed M
+    for the padding tail, whose verdict bits are forced to 0."""
+    words = (M + WORD - 1) // WORD
+    words_per_rank = (words + world_size - 1) // world_size
+    shard = words_per_rank * WORD
+    start = rank * shard
+    return start, start + shard, shard
+
+
+def candidate_states(robot, seed, start, count, tau_max=None):
+    """States [start, start+count) of the global candidate sequence keyed by (seed, chunk)."""
+    S = robot.state_size()
+    out = np.empty((count, S))
+    pos = start
+    while pos < start + count:
+        chunk = pos // RNG_CHUNK
+        lo = chunk * RNG_CHUNK
+        rng = np.random.default_rng([int(seed), int(chunk)])
+        block = np.empty((RNG_CHUNK, S))
+        k = 0
+        for t in robot.tendons:
+            block[:, k] = rng.uniform(0.0, t.max_tension if tau_max is None else tau_max, RNG_CHUNK)
+            k += 1
+        if robot.enable_rotation:
+            block[:, k] = rng.uniform(-np.pi, np.pi, RNG_CHUNK)
+            k += 1
+        if robot.enable_retraction:
+            block[:, k] = rng.uniform(0.0, robot.specs.L, RNG_CHUNK)
+        a = pos - lo
+        b = min(RNG_CHUNK, start + count - lo)
+        out[pos - start: pos - start + (b - a)] = block[a:b]
+        pos += b - a
+    return out
+
+
+def allgather_mask(local_words, group=None):
+    """All-gather equal-length int64 mask shards into the global mask (rank-major)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local_words.clone()
+    world = dist.get_world_size(group)
+    out = torch.empty(world * local_words.numel(), dtype=local_words.dtype, device=local_words.device)
+    dist.all_gather_into_tensor(out, local_words.contiguous(), group=group)
+    return out
+
+
+class ShardedVertexValidator:
+    """Validate M candidate vertices across the ranks of the default process group.
+
+    validate_local(states) -> uint64/int64 mask words for that shard (bit i&63 of word i>>6).
+    In production this is Engine.validate_batch_dev on the rank's GPU; the CPU tests plug in the
+    oracle to exercise the sharding and the collective with the `gloo` backend.
+    """
+
+    def __init__(self, robot, validate_local, seed=0, tau_max=None, device="cpu"):
+        self.robot, self.validate_local = robot, validate_local
+        self.seed, self.tau_max, self.device = seed, tau_max, device
+
+    def run(self, M, rank=None, world_size=None):
+        import torch
+        import torch.distributed as dist
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_initialized() else 1
+        start, stop, shard = shard_bounds(M, world_size, rank)
+        n_real = max(0, min(stop, M) - start)
+        words = np.zeros(shard // WORD, dtype=np.uint64)
+        if n_real > 0:
+            states = candidate_states(self.robot, self.seed, start, n_real, self.tau_max)
+            w = np.asarray(self.validate_local(states)).view(np.uint64)
+            words[: w.size] = w
+            if n_real % WORD:                              # padding bits stay zero
+                words[n_real // WORD] &= np.uint64((1 << (n_real % WORD)) - 1)
+        local = torch.from_numpy(words.view(np.int64)).to(self.device)
+        full = allgather_mask(local)
+        # world_size * shard/64 words; bits of items >= M are zero.  unpack_bits(words, M) is the mask.
+        return full.cpu().numpy().view(np.uint64)
