@@ -207,21 +207,109 @@ struct SweepIn {
   double *__restrict__ acc;                                            // [P][ld] scratch: accumulated chord lengths
 };
 
-// K2.  block = 256 threads (4 independent waves); valid_bits word = global wave index.
-//   debug bit0: brute-force self-collision (every pair), for A/B verification of the skip sweep.
-__global__ __launch_bounds__(256) void backbone_voxel_sweep(
-    SweepIn in, int64_t n, int64_t ld, int P, RobotK K, GridK g, const uint64_t *__restrict__ grid,
+// Exact self-collision sweep for one lane set (collision/collision.cpp:6-46), reading the lane's
+// points and accumulated chord lengths from global memory.  The (a, b) loops are wave-uniform; a lane
+// skips ahead over pairs that provably cannot collide (distance bound) or are provably gated out
+// (arc-length bound); the wave advances by the minimum skip.  `brute` disables skipping.
+__device__ __forceinline__ bool exact_self_collision(const SweepIn &in, int64_t ic, int64_t ld, int P, int np,
+                                                     bool act, double hmax, double r, bool brute) {
+#pragma clang fp contract(off)
+  const double consider = 3.0 * r;
+  const double rsum = r + r;
+  // conservative bounds for the skip sweep (all slack is >= 1e-9 relative, far above rounding)
+  const double h_eff = hmax * (1.0 + 1e-9) + 1e-300;
+  const double inv_h = 1.0 / h_eff;
+  bool selfhit = false;
+  act = act && np > 2;
+  for (int a = 0; a < P - 3; ++a) {
+    if (!__any(act && a < np - 3)) break;
+    const bool act_a = act && a < np - 3;
+    const int64_t oa = (int64_t)a * ld + ic;
+    V3 pa = {0, 0, 0}, pa1 = {0, 0, 0};
+    double acc_a1 = 0;
+    if (act_a) {
+      pa = V3{in.px[oa], in.py[oa], in.pz[oa]};
+      pa1 = V3{in.px[oa + ld], in.py[oa + ld], in.pz[oa + ld]};
+      acc_a1 = in.acc[oa + ld];
+    }
+    int b = a + 2;
+    while (b < P - 1) {
+      const bool act_b = act_a && !selfhit && b < np - 1;
+      if (!__any(act_b)) break;
+      int skip = 0x7fffffff;
+      if (act_b) {
+        const int64_t ob = (int64_t)b * ld + ic;
+        const V3 pb = {in.px[ob], in.py[ob], in.pz[ob]};
+        skip = 1;
+        bool need_exact = true;
+        if (!brute) {
+          // any pair (a, b+k) has segment distance >= |pa - pb| - (k + 2) * hmax
+          const V3 d = {pa.x - pb.x, pa.y - pb.y, pa.z - pb.z};
+          const double D = sqrt(dot3(d, d));
+          const double slack = D - rsum - 2.0 * h_eff - 1e-9 * (1.0 + D);
+          if (slack > 0.0) {
+            need_exact = false;
+            const double m = slack * inv_h * (1.0 - 1e-9);
+            skip = m > 1.0 ? (m < 1e6 ? (int)m : 1000000) : 1;
+          }
+        }
+        if (need_exact) {
+          const double gd = in.acc[ob] - acc_a1;
+          if (gd < consider) {
+            // gated out (collision.cpp:38-40); (a, b+k) stays gated while gd + k*hmax < 3r
+            if (!brute) {
+              const double m = (consider - gd) * inv_h * (1.0 - 1e-9) - 1e-9;
+              skip = m > 1.0 ? (m < 1e6 ? (int)m : 1000000) : 1;
+            }
+          } else {
+            const V3 pb1 = {in.px[ob + ld], in.py[ob + ld], in.pz[ob + ld]};
+            if (capsules_collide(pa, pa1, pb, pb1, rsum)) selfhit = true;
+          }
+        }
+      }
+      b += wave_min_i32(skip);
+    }
+    if (selfhit) act = false;
+  }
+  return selfhit;
+}
+
+// K2.  One wave per block; dynamic LDS = 4 * NM * 64 floats (milestone x, y, z, arc per lane).
+//
+// Pass 1 streams every backbone point ONCE (coalesced, lane-contiguous): accumulated chord length,
+// DDA of the segment against the obstacle grid, and a float copy of every CH-th point ("milestone")
+// with its arc position into LDS.
+// Pass 2 proves the absence of self collision from the milestones alone whenever it can.  For
+// milestones i < j (span = the polyline between them) with arc length s and chord c:
+//   (C) s < 3r               -> every capsule pair inside the span is gated out (collision.cpp:38-40);
+//   (A) s - c < r            -> any gate-passing pair (a, b) inside the span has segment distance
+//                               >= c - s + (arc(b) - arc(a+1)) >= 3r - (s - c) > 2r;
+//   (B) |M_i - M_j'| - rho_i - rho_j' > 2r for the first / last chunk of the span (chunk midpoint M,
+//       half arc length rho) -> those two chunks cannot touch.
+// Each test keeps >= 1e-6 m of slack over the float rounding (~1e-7 m), so a cleared configuration
+// gets exactly the reference's verdict ("no self collision").  A lane some span of which is not
+// cleared falls back to pass 3, the exact pairwise sweep -- rare (tight curls only).
+//   debug bit0: brute-force pairs in pass 3;  bit1: skip pass 2 (every lane takes pass 3).
+__global__ __launch_bounds__(64) void backbone_voxel_sweep(
+    SweepIn in, int64_t n, int64_t ld, int P, int CH, int NM, RobotK K, GridK g, const uint64_t *__restrict__ grid,
     int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits, uint8_t *__restrict__ flags) {
 #pragma clang fp contract(off)
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x;
+  float *__restrict__ mx = lds + lane;                   // [k][64] layout: conflict-free
+  float *__restrict__ my = mx + (size_t)NM * 64;
+  float *__restrict__ mz = my + (size_t)NM * 64;
+  float *__restrict__ ma = mz + (size_t)NM * 64;
+
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const bool live = i < n;
   const int64_t ic = live ? i : (n - 1);
   const int NT = K.n_tendons;
-  uint32_t fl = 0;
   bool alive = live;
+  bool conv_ok = false, len_ok = false;
 
   // 1. converged (the home shape always converges: TendonRobot.cpp:249-314 never clears the flag)
-  if (alive) { if (in.converged[ic]) fl |= 1u; else alive = false; }
+  if (alive) { conv_ok = in.converged[ic] != 0; alive = conv_ok; }
   // 2. tendon length limits: dl = L_home - L_fk in [min_length, max_length]
   if (alive) {
     bool ok = true;
@@ -230,125 +318,117 @@ __global__ __launch_bounds__(256) void backbone_voxel_sweep(
       const double dl = home - in.Li[(int64_t)j * ld + ic];
       if (dl < K.min_len[j] || K.max_len[j] < dl) ok = false;
     }
-    if (ok) fl |= 2u; else alive = false;
+    len_ok = ok; alive = ok;
   }
   const int np = in.n_points ? in.n_points[ic] : P;
+  const int Kl = (np - 1 + CH - 1) / CH;                 // this lane's last milestone index
 
-  // 3. self collision.  Pass 1: accumulated chord lengths (collision.cpp:21-30) + longest chord.
+  // Pass 1: one streaming read of the points.
   double hmax = 0.0, dist = 0.0;
+  bool hit = false, bad = false;
   if (__any(alive)) {
-    V3 prev = {in.px[ic], in.py[ic], in.pz[ic]};
+    GridCursor gc{grid, g.Nb, -1, 0ull};
+    V3 prev = {0, 0, 0}, prevr = {0, 0, 0};
     for (int j = 0; j < P; j++) {
-      if (alive && j < np) {
+      const bool on = alive && j < np;
+      if (!__any(on)) break;
+      if (on) {
         const int64_t o = (int64_t)j * ld + ic;
         const V3 q = {in.px[o], in.py[o], in.pz[o]};
+        if (j == 0) prev = q;
         const V3 d = {q.x - prev.x, q.y - prev.y, q.z - prev.z};
         const double h = sqrt(dot3(d, d));
         dist += h;
         hmax = fmax(hmax, h);
-        in.acc[o] = dist;
+        prev = q;
+        const bool last = (j == np - 1);
+        if (last || (j % CH) == 0) {
+          const int k = last ? Kl : j / CH;
+          mx[k * 64] = (float)q.x; my[k * 64] = (float)q.y; mz[k * 64] = (float)q.z; ma[k * 64] = (float)dist;
+        }
+        if (check_voxels && !hit && !bad) {
+          V3 qr;
+          if (g.rot_is_identity) { qr = q; }
+          else {
+            qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
+            qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
+            qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
+          }
+          if (j > 0) hit = line_hits(prevr, qr, g, gc, bad);
+          prevr = qr;
+        }
+      }
+    }
+  }
+  if (alive && !(dist < 1e300)) { alive = false; bad = true; }   // NaN / inf points
+
+  // Pass 2: milestone proof of "no self collision".
+  bool need_exact = alive && np > 2;
+  if (!(debug & 2u) && __any(need_exact)) {
+    const float r = (float)K.radius;
+    const float mrg = 1e-6f;
+    const float gate = 3.0f * r - mrg, aslack = r - mrg, bclear = 2.0f * r + mrg;
+    bool unresolved = false;
+    for (int a = 0; a < NM - 1; ++a) {
+      const bool on_a = need_exact && !unresolved && a < Kl;
+      if (!__any(on_a)) break;
+      if (on_a) {
+        const float ax = mx[a * 64], ay = my[a * 64], az = mz[a * 64], aa = ma[a * 64];
+        // whole remaining span first: s - c is monotone in the span, so this clears the row
+        {
+          const float ex = mx[Kl * 64] - ax, ey = my[Kl * 64] - ay, ez = mz[Kl * 64] - az;
+          const float s = ma[Kl * 64] - aa;
+          if (s < gate || s - sqrtf(ex * ex + ey * ey + ez * ez) < aslack) continue;
+        }
+        const float a1x = mx[(a + 1) * 64], a1y = my[(a + 1) * 64], a1z = mz[(a + 1) * 64], a1a = ma[(a + 1) * 64];
+        const float Max = 0.5f * (ax + a1x), May = 0.5f * (ay + a1y), Maz = 0.5f * (az + a1z);
+        const float rho_a = 0.5f * (a1a - aa);
+        for (int b = a + 1; b <= Kl; ++b) {
+          const float bx = mx[b * 64], by = my[b * 64], bz = mz[b * 64], ba = ma[b * 64];
+          const float s = ba - aa;
+          if (s < gate) continue;
+          const float ex = bx - ax, ey = by - ay, ez = bz - az;
+          if (s - sqrtf(ex * ex + ey * ey + ez * ez) < aslack) continue;
+          // (B) first chunk [a, a+1] vs last chunk [b-1, b] of the span
+          const float cx = mx[(b - 1) * 64], cy = my[(b - 1) * 64], cz = mz[(b - 1) * 64], ca = ma[(b - 1) * 64];
+          const float fx = 0.5f * (bx + cx) - Max, fy = 0.5f * (by + cy) - May, fz = 0.5f * (bz + cz) - Maz;
+          if (sqrtf(fx * fx + fy * fy + fz * fz) - rho_a - 0.5f * (ba - ca) > bclear) continue;
+          unresolved = true;
+          break;
+        }
+      }
+    }
+    need_exact = unresolved;
+  }
+
+  // Pass 3 (rare): exact pairwise sweep for the lanes pass 2 could not clear.
+  bool selfhit = false;
+  if (__any(need_exact)) {
+    if (need_exact) {
+      double dd = 0.0;
+      V3 prev = {in.px[ic], in.py[ic], in.pz[ic]};
+      for (int j = 0; j < np; j++) {
+        const int64_t o = (int64_t)j * ld + ic;
+        const V3 q = {in.px[o], in.py[o], in.pz[o]};
+        const V3 d = {q.x - prev.x, q.y - prev.y, q.z - prev.z};
+        dd += sqrt(dot3(d, d));
+        in.acc[o] = dd;
         prev = q;
       }
     }
-  }
-  if (alive && !(dist < 1e300)) { alive = false; fl |= 16u; }    // NaN / inf points
-
-  bool selfhit = false;
-  {
-    const double r = K.radius;
-    const double consider = 3.0 * r;
-    const double rsum = r + r;
-    // conservative bounds for the skip sweep (all slack is >= 1e-9 relative, far above rounding)
-    const double h_eff = hmax * (1.0 + 1e-9) + 1e-300;
-    const double inv_h = 1.0 / h_eff;
-    bool act = alive && np > 2;
-    const bool brute = debug & 1u;
-    for (int a = 0; a < P - 3; ++a) {
-      if (!__any(act && a < np - 3)) break;
-      const bool act_a = act && a < np - 3;
-      const int64_t oa = (int64_t)a * ld + ic;
-      V3 pa = {0, 0, 0}, pa1 = {0, 0, 0};
-      double acc_a1 = 0;
-      if (act_a) {
-        pa = V3{in.px[oa], in.py[oa], in.pz[oa]};
-        pa1 = V3{in.px[oa + ld], in.py[oa + ld], in.pz[oa + ld]};
-        acc_a1 = in.acc[oa + ld];
-      }
-      int b = a + 2;
-      while (b < P - 1) {
-        const bool act_b = act_a && !selfhit && b < np - 1;
-        if (!__any(act_b)) break;
-        int skip = 0x7fffffff;
-        if (act_b) {
-          const int64_t ob = (int64_t)b * ld + ic;
-          const V3 pb = {in.px[ob], in.py[ob], in.pz[ob]};
-          skip = 1;
-          bool need_exact = true;
-          if (!brute) {
-            // any pair (a, b+k) has segment distance >= |pa - pb| - (k + 2) * hmax
-            const V3 d = {pa.x - pb.x, pa.y - pb.y, pa.z - pb.z};
-            const double D = sqrt(dot3(d, d));
-            const double slack = D - rsum - 2.0 * h_eff - 1e-9 * (1.0 + D);
-            if (slack > 0.0) {
-              need_exact = false;
-              const double m = slack * inv_h * (1.0 - 1e-9);
-              skip = m > 1.0 ? (m < 1e6 ? (int)m : 1000000) : 1;
-            }
-          }
-          if (need_exact) {
-            const double gd = in.acc[ob] - acc_a1;
-            if (gd < consider) {
-              // gated out (collision.cpp:38-40); (a, b+k) stays gated while gd + k*hmax < 3r
-              if (!brute) {
-                const double m = (consider - gd) * inv_h * (1.0 - 1e-9) - 1e-9;
-                skip = m > 1.0 ? (m < 1e6 ? (int)m : 1000000) : 1;
-              }
-            } else {
-              const V3 pb1 = {in.px[ob + ld], in.py[ob + ld], in.pz[ob + ld]};
-              if (capsules_collide(pa, pa1, pb, pb1, rsum)) selfhit = true;
-            }
-          }
-        }
-        b += wave_min_i32(skip);
-      }
-      if (selfhit) act = false;
-    }
-  }
-  if (alive) { if (!selfhit) fl |= 4u; else alive = false; }
-
-  // 4. backbone voxelisation against the obstacle grid
-  if (check_voxels) {
-    bool hit = false, bad = false;
-    if (__any(alive)) {
-      GridCursor gc{grid, g.Nb, -1, 0ull};
-      V3 prev = {0, 0, 0};
-      for (int j = 0; j < P; j++) {
-        const bool on = alive && !hit && !bad && j < np;
-        if (!__any(on)) break;
-        if (on) {
-          const int64_t o = (int64_t)j * ld + ic;
-          const double x = in.px[o], y = in.py[o], z = in.pz[o];
-          V3 q;
-          if (g.rot_is_identity) { q = V3{x, y, z}; }
-          else {
-            q.x = g.inv_rot[0] * x + g.inv_rot[1] * y + g.inv_rot[2] * z;
-            q.y = g.inv_rot[3] * x + g.inv_rot[4] * y + g.inv_rot[5] * z;
-            q.z = g.inv_rot[6] * x + g.inv_rot[7] * y + g.inv_rot[8] * z;
-          }
-          if (j > 0) hit = line_hits(prev, q, g, gc, bad);
-          prev = q;
-        }
-      }
-    }
-    if (alive) {
-      if (bad) { fl |= 16u; alive = false; }
-      else if (!hit) fl |= 8u;
-      else alive = false;
-    }
+    selfhit = exact_self_collision(in, ic, ld, P, np, need_exact, hmax, K.radius, (debug & 1u) != 0);
   }
 
-  const uint64_t bits = __ballot(alive);
-  if ((threadIdx.x & 63) == 0 && i < n) valid_bits[i >> 6] = bits;
+  uint32_t fl = 0;
+  if (conv_ok) fl |= 1u;
+  if (conv_ok && len_ok) fl |= 2u;
+  bool valid = conv_ok && len_ok;
+  if (valid && bad) { fl |= 16u; valid = false; }
+  if (valid) { if (!selfhit) fl |= 4u; else valid = false; }
+  if (valid && check_voxels) { if (!hit) fl |= 8u; else valid = false; }
+
+  const uint64_t bits = __ballot(valid && live);
+  if (lane == 0 && i < n) valid_bits[i >> 6] = bits;
   if (flags && live) flags[i] = (uint8_t)fl;
 }
 

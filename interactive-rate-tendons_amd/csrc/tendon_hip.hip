@@ -268,8 +268,16 @@ int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int
   if (n <= 0) return TR_OK;
   if (check_voxels && !ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   ProfScope ps(ctx, 1, s);
-  const unsigned grid = (unsigned)((n + 255) / 256);
-  hipLaunchKernelGGL(trk::backbone_voxel_sweep, dim3(grid), dim3(256), 0, s, in, n, ld, (int)ctx->K.n_points, ctx->K,
+  // milestone spacing for the LDS self-collision proof: about one robot radius of arc per chunk,
+  // coarser if needed to keep the per-wave LDS image (4 * NM * 64 floats) within 48 KiB
+  const int P = ctx->K.n_points;
+  int CH = (int)std::lround(ctx->K.radius / ctx->K.dL);
+  if (CH < 1) CH = 1;
+  while ((P - 1 + CH - 1) / CH + 1 > 48) CH++;
+  const int NM = (P - 1 + CH - 1) / CH + 1;
+  const size_t lds = (size_t)4 * NM * 64 * sizeof(float);
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL(trk::backbone_voxel_sweep, dim3(grid), dim3(64), lds, s, in, n, ld, P, CH, NM, ctx->K,
                      ctx->G, ctx->d_grid, check_voxels, ctx->debug, d_bits, d_flags);
   HIP_TRY(ctx, hipGetLastError());
   return TR_OK;
