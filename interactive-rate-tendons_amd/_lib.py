@@ -10,7 +10,7 @@ import subprocess
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
-LIB_PATH = os.path.join(_PKG, "libtendon_hip.so")
+LIB_PATH = os.environ.get("TENDON_HIP_LIB") or os.path.join(_PKG, "libtendon_hip.so")   # env override: A/B builds
 SRC_DIR = os.path.join(_PKG, "csrc")
 HEADER = os.path.join(_ROOT, "include", "tendon_hip.h")
 

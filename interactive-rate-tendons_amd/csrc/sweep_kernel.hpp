@@ -65,7 +65,14 @@ struct GridCursor {
 // occupancy test.  Returns true as soon as a visited cell is occupied.  `bad` is raised when an
 // endpoint is non-finite or farther than 4N voxels outside the domain (reference: undefined
 // behaviour / unbounded walk); the caller then forces the configuration invalid.
-__device__ __forceinline__ bool line_hits(const V3 &a, const V3 &b, const GridK &g, GridCursor &gc, bool &bad) {
+//
+// Fast path: `near` is the obstacle grid dilated by 2 cells (Chebyshev).  Every cell add_line can
+// visit lies in [min(A,B)-1, max(A,B)+1] per axis (the walker moves from A's cell towards B's and
+// stops once any axis has passed B's index by one), i.e. within Chebyshev distance |B-A|_inf + 1 of
+// A's cell.  So when the end cells differ by at most one per axis and A's cell is free in `near`,
+// no visited cell can be occupied and the whole fp64 set-up of the walk is skipped.
+__device__ __forceinline__ bool line_hits(const V3 &a, const V3 &b, const GridK &g, GridCursor &gc, GridCursor &near,
+                                          bool &bad) {
 #pragma clang fp contract(off)
   // Fast accept of the AABB pre-test: both endpoints at least 1e-6 of the box size inside the
   // domain => the exact test above is true by a margin far larger than its rounding error.
@@ -87,6 +94,10 @@ __device__ __forceinline__ bool line_hits(const V3 &a, const V3 &b, const GridK 
   }
   const int Axi = (int)A.x - (A.x < 0), Ayi = (int)A.y - (A.y < 0), Azi = (int)A.z - (A.z < 0);
   const int Bxi = (int)B.x - (B.x < 0), Byi = (int)B.y - (B.y < 0), Bzi = (int)B.z - (B.z < 0);
+  if (inside && near.blocks) {
+    const int ddx = Bxi - Axi, ddy = Byi - Ayi, ddz = Bzi - Azi;
+    if (ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1 && !near.occupied(Axi, Ayi, Azi)) return false;
+  }
   auto idx_in = [N](int q) { return 0 <= q && q < N; };
   auto vox_in = [&](int x, int y, int z) { return idx_in(x) && idx_in(y) && idx_in(z); };
   bool entered = vox_in(Axi, Ayi, Azi);
@@ -289,10 +300,12 @@ __device__ __forceinline__ bool exact_self_collision(const SweepIn &in, int64_t 
 // Each test keeps >= 1e-6 m of slack over the float rounding (~1e-7 m), so a cleared configuration
 // gets exactly the reference's verdict ("no self collision").  A lane some span of which is not
 // cleared falls back to pass 3, the exact pairwise sweep -- rare (tight curls only).
-//   debug bit0: brute-force pairs in pass 3;  bit1: skip pass 2 (every lane takes pass 3).
+//   debug bit0: brute-force pairs in pass 3;  bit1: skip pass 2 (every lane takes pass 3);
+//         bit2: disable the dilated-grid fast path of the voxel walk.
 __global__ __launch_bounds__(64) void backbone_voxel_sweep(
     SweepIn in, int64_t n, int64_t ld, int P, int CH, int NM, RobotK K, GridK g, const uint64_t *__restrict__ grid,
-    int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits, uint8_t *__restrict__ flags) {
+    const uint64_t *__restrict__ near_grid, int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits,
+    uint8_t *__restrict__ flags) {
 #pragma clang fp contract(off)
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
@@ -323,11 +336,13 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
   const int np = in.n_points ? in.n_points[ic] : P;
   const int Kl = (np - 1 + CH - 1) / CH;                 // this lane's last milestone index
 
-  // Pass 1: one streaming read of the points.
-  double hmax = 0.0, dist = 0.0;
+  // Pass 1: one streaming read of the points.  Arc positions of the milestones are accumulated in
+  // float: they only feed the conservative tests of pass 2 (error ~2e-8 m against 1e-6 m of slack).
+  float dist = 0.0f;
   bool hit = false, bad = false;
   if (__any(alive)) {
     GridCursor gc{grid, g.Nb, -1, 0ull};
+    GridCursor near{(debug & 4u) ? nullptr : near_grid, g.Nb, -1, 0ull};
     V3 prev = {0, 0, 0}, prevr = {0, 0, 0};
     for (int j = 0; j < P; j++) {
       const bool on = alive && j < np;
@@ -336,15 +351,13 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
         const int64_t o = (int64_t)j * ld + ic;
         const V3 q = {in.px[o], in.py[o], in.pz[o]};
         if (j == 0) prev = q;
-        const V3 d = {q.x - prev.x, q.y - prev.y, q.z - prev.z};
-        const double h = sqrt(dot3(d, d));
-        dist += h;
-        hmax = fmax(hmax, h);
+        const float dx = (float)(q.x - prev.x), dy = (float)(q.y - prev.y), dz = (float)(q.z - prev.z);
+        dist += sqrtf(dx * dx + dy * dy + dz * dz);
         prev = q;
         const bool last = (j == np - 1);
         if (last || (j % CH) == 0) {
           const int k = last ? Kl : j / CH;
-          mx[k * 64] = (float)q.x; my[k * 64] = (float)q.y; mz[k * 64] = (float)q.z; ma[k * 64] = (float)dist;
+          mx[k * 64] = (float)q.x; my[k * 64] = (float)q.y; mz[k * 64] = (float)q.z; ma[k * 64] = dist;
         }
         if (check_voxels && !hit && !bad) {
           V3 qr;
@@ -354,13 +367,13 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
             qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
             qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
           }
-          if (j > 0) hit = line_hits(prevr, qr, g, gc, bad);
+          if (j > 0) hit = line_hits(prevr, qr, g, gc, near, bad);
           prevr = qr;
         }
       }
     }
   }
-  if (alive && !(dist < 1e300)) { alive = false; bad = true; }   // NaN / inf points
+  if (alive && !(dist < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
 
   // Pass 2: milestone proof of "no self collision".
   bool need_exact = alive && np > 2;
@@ -401,9 +414,11 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
     need_exact = unresolved;
   }
 
-  // Pass 3 (rare): exact pairwise sweep for the lanes pass 2 could not clear.
+  // Pass 3 (rare): exact pairwise sweep for the lanes pass 2 could not clear: accumulated chord
+  // lengths in fp64 exactly as collision.cpp:21-30 forms them, then the pair loops.
   bool selfhit = false;
   if (__any(need_exact)) {
+    double hmax = 0.0;
     if (need_exact) {
       double dd = 0.0;
       V3 prev = {in.px[ic], in.py[ic], in.pz[ic]};
@@ -411,7 +426,9 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
         const int64_t o = (int64_t)j * ld + ic;
         const V3 q = {in.px[o], in.py[o], in.pz[o]};
         const V3 d = {q.x - prev.x, q.y - prev.y, q.z - prev.z};
-        dd += sqrt(dot3(d, d));
+        const double h = sqrt(dot3(d, d));
+        dd += h;
+        hmax = fmax(hmax, h);
         in.acc[o] = dd;
         prev = q;
       }

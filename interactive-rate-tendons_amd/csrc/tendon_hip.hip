@@ -64,6 +64,7 @@ struct tr_ctx {
   bool has_grid = false;
   GridK G{};
   uint64_t *d_grid = nullptr;
+  uint64_t *d_near = nullptr;     // obstacle grid dilated by 2 cells (Chebyshev), same layout
   uint32_t n_blocks = 0;
   Workspace ws;
   int64_t max_chunk = 1 << 20;
@@ -175,6 +176,43 @@ void home_lengths(const tr_ctx *c, const std::vector<double> &t, double s_start,
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
+// Obstacle grid dilated by 2 cells in the Chebyshev metric (a cell is set iff some occupied cell
+// lies within +-2 along every axis), same block / bit layout.  Used only to skip voxel walks that
+// provably cannot touch an obstacle (sweep_kernel.hpp, line_hits); computed once per tr_set_grid.
+std::vector<uint64_t> dilate2(const uint64_t *blocks, int N) {
+  const int Nb = N / 4;
+  const size_t NN = (size_t)N * N * N;
+  std::vector<uint8_t> a(NN, 0), b(NN, 0);
+  for (int bx = 0; bx < Nb; bx++) for (int by = 0; by < Nb; by++) for (int bz = 0; bz < Nb; bz++) {
+    const uint64_t v = blocks[((size_t)bx * Nb + by) * Nb + bz];
+    if (!v) continue;
+    for (int bit = 0; bit < 64; bit++) if (v >> bit & 1) {
+      const int x = 4 * bx + (bit >> 4), y = 4 * by + ((bit >> 2) & 3), z = 4 * bz + (bit & 3);
+      a[((size_t)x * N + y) * N + z] = 1;
+    }
+  }
+  auto pass = [N](const std::vector<uint8_t> &src, std::vector<uint8_t> &dst, size_t stride, size_t so1, size_t so2) {
+    // dilate along the axis with the given stride; so1, so2 are the strides of the other two axes
+    for (int u = 0; u < N; u++) for (int v = 0; v < N; v++) {
+      const size_t base = u * so1 + v * so2;
+      for (int w = 0; w < N; w++) {
+        uint8_t m = 0;
+        for (int d = -2; d <= 2; d++) { const int q = w + d; if (q >= 0 && q < N) m |= src[base + q * stride]; }
+        dst[base + w * stride] = m;
+      }
+    }
+  };
+  const size_t sx = (size_t)N * N, sy = (size_t)N, sz = 1;
+  pass(a, b, sz, sx, sy);
+  pass(b, a, sy, sx, sz);
+  pass(a, b, sx, sy, sz);
+  std::vector<uint64_t> out((size_t)Nb * Nb * Nb, 0);
+  for (int x = 0; x < N; x++) for (int y = 0; y < N; y++) for (int z = 0; z < N; z++)
+    if (b[((size_t)x * N + y) * N + z])
+      out[((size_t)(x >> 2) * Nb + (y >> 2)) * Nb + (z >> 2)] |= (uint64_t)1 << (((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
+  return out;
+}
+
 template <typename T>
 int dev_alloc(tr_ctx *ctx, T **p, size_t count) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -278,7 +316,7 @@ int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int
   const size_t lds = (size_t)4 * NM * 64 * sizeof(float);
   const unsigned grid = (unsigned)((n + 63) / 64);
   hipLaunchKernelGGL(trk::backbone_voxel_sweep, dim3(grid), dim3(64), lds, s, in, n, ld, P, CH, NM, ctx->K,
-                     ctx->G, ctx->d_grid, check_voxels, ctx->debug, d_bits, d_flags);
+                     ctx->G, ctx->d_grid, ctx->d_near, check_voxels, ctx->debug, d_bits, d_flags);
   HIP_TRY(ctx, hipGetLastError());
   return TR_OK;
 }
@@ -382,7 +420,7 @@ void tr_destroy(tr_ctx *c) {
   (void)hipDeviceSynchronize();
   for (auto &v : c->events) for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   Workspace &w = c->ws;
-  void *ptrs[] = {c->d_tab, c->d_steps, c->d_grid, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
+  void *ptrs[] = {c->d_tab, c->d_steps, c->d_grid, c->d_near, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
@@ -427,10 +465,16 @@ int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *bloc
   if (c->n_blocks != nb) {
     HIP_TRY(c, hipDeviceSynchronize());
     if (c->d_grid) { (void)hipFree(c->d_grid); c->d_grid = nullptr; }
+    if (c->d_near) { (void)hipFree(c->d_near); c->d_near = nullptr; }
     HIP_TRY(c, hipMalloc((void **)&c->d_grid, nb * sizeof(uint64_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_near, nb * sizeof(uint64_t)));
     c->n_blocks = (uint32_t)nb;
   }
   HIP_TRY(c, hipMemcpy(c->d_grid, blocks, nb * sizeof(uint64_t), hipMemcpyHostToDevice));
+  {
+    std::vector<uint64_t> near = dilate2(blocks, (int)N);
+    HIP_TRY(c, hipMemcpy(c->d_near, near.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
   c->G = g;
   c->has_grid = true;
   return TR_OK;

@@ -124,7 +124,7 @@ def _sweep_case(irt, orc, helpers, robot, n, seed, tau_max):
     d_conv = torch.from_numpy(fk["converged"].astype(np.uint8)).cuda()
     d_bits = torch.zeros(ld // 64, dtype=torch.int64, device="cuda")
     d_flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
-    for debug in (0, 2, 3):           # milestone proof + fallback | exact skip sweep for all | brute-force pairs for all
+    for debug in (0, 2, 3, 4):        # default | exact skip sweep for all | brute-force pairs for all | no dilated-grid fast path
         chk.engine.set_debug(debug)
         chk.engine.validate_shapes_dev(n, ld, px, py, pz, d_Li, d_conv, d_bits, d_flags)
         torch.cuda.synchronize()
