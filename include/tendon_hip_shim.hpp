@@ -1,0 +1,284 @@
+// tendon_hip_shim.hpp -- header-only C++17 host shim over the C ABI (tendon_hip.h) that keeps the
+// reference's class and method names for the hot path, so reference-side code can switch with a
+// namespace alias.  STL only (the reference's Eigen / OMPL types are adapted in INTEGRATION.md).
+//
+//   tendon::TendonRobot / BackboneSpecs / TendonSpecs / TendonResult   tendon/*.h
+//   collision::VoxelOctree (dense view)                                 collision/VoxelOctree.h:68-330
+//   motion_planning::VoxelEnvironment                                   motion-planning/VoxelEnvironment.h:31-49
+//   motion_planning::VoxelBackboneValidityChecker                       motion-planning/VoxelBackboneValidityChecker.h:28-58
+//   motion_planning::VoxelBackboneMotionValidator                       motion-planning/VoxelBackboneMotionValidator.h
+//
+// Error behaviour: every tr_status is rethrown as the C++ exception type the reference throws at
+// the same condition (std::invalid_argument, std::out_of_range, std::domain_error,
+// std::length_error, std::runtime_error).
+#pragma once
+#include <array>
+#include <cmath>
+#include <cstdint>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tendon_hip.h"
+
+namespace tendon_hip {
+
+inline void check(const tr_ctx *ctx, int status) {
+  if (status == TR_OK) return;
+  const std::string msg = tr_last_error(ctx);
+  switch (status) {
+    case TR_ERR_INVALID_ARG: throw std::invalid_argument(msg);
+    case TR_ERR_OUT_OF_RANGE: throw std::out_of_range(msg);
+    case TR_ERR_DOMAIN: throw std::domain_error(msg);
+    case TR_ERR_LENGTH: throw std::length_error(msg);
+    default: throw std::runtime_error(msg);
+  }
+}
+
+namespace tendon {
+
+struct BackboneSpecs {              // tendon/BackboneSpecs.h:14-20
+  double L = 0.2, dL = 0.005, ro = 0.01, ri = 0.0, E = 2.1e6, nu = 0.3;
+};
+
+struct TendonSpecs {                // tendon/TendonSpecs.h:25-30
+  std::vector<double> C{0.0}, D{0.01};
+  double max_tension = 20.0, min_length = -0.015, max_length = 0.035;
+};
+
+struct TendonResult {               // tendon/TendonResult.h:17-40
+  std::vector<double> t;
+  std::vector<std::array<double, 3>> p;
+  std::vector<std::array<double, 9>> R;   // column-major, as Eigen::Matrix3d stores it
+  double L = 0.0;
+  std::vector<double> L_i;
+  bool converged = true;
+};
+
+class TendonRobot {                 // tendon/TendonRobot.h:52-355
+ public:
+  double r = 0.015;
+  BackboneSpecs specs{};
+  std::vector<TendonSpecs> tendons;
+  bool enable_rotation = false, enable_retraction = false;
+  double residual_threshold = 5e-6;
+
+  size_t state_size() const { return tendons.size() + (enable_rotation ? 1 : 0) + (enable_retraction ? 1 : 0); }
+
+  /// The GPU context holding this robot's constants; (re)created on first use on `device`.
+  tr_ctx *context(int device = 0) const {
+    if (!ctx_) {
+      const size_t n = tendons.size();
+      if (n == 0) throw std::out_of_range("tendons and tau are not the same length");
+      const size_t na = tendons[0].C.size(), nm = tendons[0].D.size();
+      std::vector<double> C, D, mt, mn, mx;
+      for (auto &t : tendons) {
+        if (t.C.size() != na || t.D.size() != nm) throw std::invalid_argument("tendons must share C.size() and D.size()");
+        C.insert(C.end(), t.C.begin(), t.C.end());
+        D.insert(D.end(), t.D.begin(), t.D.end());
+        mt.push_back(t.max_tension); mn.push_back(t.min_length); mx.push_back(t.max_length);
+      }
+      tr_robot_desc d{};
+      d.r = r; d.L = specs.L; d.dL = specs.dL; d.ro = specs.ro; d.ri = specs.ri; d.E = specs.E; d.nu = specs.nu;
+      d.n_tendons = (int32_t)n; d.n_a = (int32_t)na; d.n_m = (int32_t)nm;
+      d.C = C.data(); d.D = D.data(); d.max_tension = mt.data(); d.min_length = mn.data(); d.max_length = mx.data();
+      d.enable_rotation = enable_rotation; d.enable_retraction = enable_retraction;
+      d.residual_threshold = residual_threshold;
+      tr_ctx *c = nullptr;
+      check(nullptr, tr_create(&d, device, &c));
+      ctx_ = std::shared_ptr<tr_ctx>(c, tr_destroy);
+    }
+    return ctx_.get();
+  }
+
+  /// TendonRobot::shape(state), TendonRobot.h:105-115
+  TendonResult shape(const std::vector<double> &state) const {
+    if (state.size() != state_size()) throw std::invalid_argument("State is not the right size");
+    return std::move(shape_batch(state, 1)[0]);
+  }
+
+  /// forward_kinematics(state), TendonRobot.h:68-72
+  std::vector<std::array<double, 3>> forward_kinematics(const std::vector<double> &state) const { return shape(state).p; }
+
+  /// n shapes in one launch (the omp loop of apps/estimate_length_discretization.cpp:62-71)
+  std::vector<TendonResult> shape_batch(const std::vector<double> &states, size_t n) const {
+    tr_ctx *c = context();
+    const size_t S = state_size(), P = (size_t)tr_num_points(c), N = tendons.size();
+    if (states.size() != n * S) throw std::invalid_argument("State is not the right size");
+    std::vector<double> p(n * P * 3), R(n * P * 9), L(n), Li(n * N);
+    std::vector<uint8_t> conv(n);
+    std::vector<int32_t> np(n);
+    check(c, tr_fk_batch(c, states.data(), (int64_t)n, p.data(), R.data(), L.data(), Li.data(), conv.data(), np.data()));
+    const std::vector<double> tg = t_grid();
+    std::vector<TendonResult> out(n);
+    for (size_t i = 0; i < n; i++) {
+      TendonResult &res = out[i];
+      const size_t m = (size_t)np[i];
+      res.t.assign(tg.begin(), tg.begin() + m);
+      res.p.resize(m); res.R.resize(m);
+      for (size_t j = 0; j < m; j++) {
+        for (int k = 0; k < 3; k++) res.p[j][k] = p[(i * P + j) * 3 + k];
+        for (int k = 0; k < 9; k++) res.R[j][k] = R[(i * P + j) * 9 + k];
+      }
+      res.L = L[i];
+      res.L_i.assign(Li.begin() + i * N, Li.begin() + (i + 1) * N);
+      res.converged = conv[i] != 0;
+    }
+    return out;
+  }
+
+  /// home_shape(0).L_i, TendonRobot.cpp:249-314
+  std::vector<double> home_lengths() const {
+    std::vector<double> Li(tendons.size());
+    check(context(), tr_home_lengths(context(), Li.data()));
+    return Li;
+  }
+
+  std::vector<double> calc_dl(const std::vector<double> &home_l, const std::vector<double> &other_l) const {   // :247-259
+    if (home_l.size() != other_l.size()) throw std::out_of_range("vector size mismatch");
+    std::vector<double> dl(home_l.size());
+    for (size_t i = 0; i < dl.size(); i++) dl[i] = home_l[i] - other_l[i];
+    return dl;
+  }
+  bool is_within_length_limits(const std::vector<double> &dl) const {                                          // :268-278
+    if (dl.size() != tendons.size()) throw std::out_of_range("length mismatch");
+    for (size_t i = 0; i < dl.size(); i++)
+      if (dl[i] < tendons[i].min_length || tendons[i].max_length < dl[i]) return false;
+    return true;
+  }
+
+  /// util::range + t_range (TendonRobot.cpp:69-84) for s_start = 0: only to fill TendonResult::t
+  std::vector<double> t_grid() const {
+    std::vector<double> v;
+    for (double q = 0.0; q <= specs.L - specs.dL / 2; q += specs.dL) v.push_back(q);
+    v.push_back(specs.L);
+    std::vector<double> t(v.size());
+    for (size_t i = 0; i < v.size(); i++) t[v.size() - 1 - i] = specs.L - (v[i] - 0.0);
+    return t;
+  }
+
+ private:
+  mutable std::shared_ptr<tr_ctx> ctx_;
+};
+
+}  // namespace tendon
+
+namespace collision {
+
+/// Dense view of collision::VoxelOctree: what the engine consumes as the obstacle set.
+class VoxelOctree {
+ public:
+  explicit VoxelOctree(size_t Ndim = 4) : N_(Ndim) {
+    if (Ndim < 4 || Ndim > 512 || (Ndim & (Ndim - 1)))
+      throw std::invalid_argument("unsupported voxel dimension: " + std::to_string(Ndim));     // VoxelOctree.cpp:113-115
+    blocks_.assign((Ndim / 4) * (Ndim / 4) * (Ndim / 4), 0);
+  }
+  size_t Nx() const { return N_; }
+  size_t Nbx() const { return N_ / 4; }
+  void set_xlim(double lo, double hi) { set(0, lo, hi, "x"); }
+  void set_ylim(double lo, double hi) { set(1, lo, hi, "y"); }
+  void set_zlim(double lo, double hi) { set(2, lo, hi, "z"); }
+  double dx() const { return (lim_[1] - lim_[0]) / N_; }
+  double dy() const { return (lim_[3] - lim_[2]) / N_; }
+  double dz() const { return (lim_[5] - lim_[4]) / N_; }
+  const double *limits() const { return lim_; }
+  static uint64_t bitmask(unsigned x, unsigned y, unsigned z) { return uint64_t(1) << (x * 16 + y * 4 + z); }   // :1501-1503
+  uint64_t block(size_t bx, size_t by, size_t bz) const { return blocks_[(bx * Nbx() + by) * Nbx() + bz]; }
+  void set_block(size_t bx, size_t by, size_t bz, uint64_t v) { blocks_[(bx * Nbx() + by) * Nbx() + bz] = v; }
+  bool cell(size_t ix, size_t iy, size_t iz) const { return block(ix / 4, iy / 4, iz / 4) & bitmask(ix % 4, iy % 4, iz % 4); }
+  bool set_cell(size_t ix, size_t iy, size_t iz) {                                                               // :256-265
+    uint64_t &b = blocks_[((ix / 4) * Nbx() + iy / 4) * Nbx() + iz / 4];
+    const uint64_t m = bitmask(ix % 4, iy % 4, iz % 4), old = b;
+    b |= m;
+    return old & m;
+  }
+  const std::vector<uint64_t> &blocks() const { return blocks_; }
+  std::vector<uint64_t> &blocks() { return blocks_; }
+
+ private:
+  void set(int a, double lo, double hi, const char *name) {
+    if (lo >= hi) throw std::length_error(std::string(name) + "limits must be positive in size");              // :152-177
+    lim_[2 * a] = lo; lim_[2 * a + 1] = hi;
+  }
+  size_t N_;
+  double lim_[6] = {0, 1, 0, 1, 0, 1};
+  std::vector<uint64_t> blocks_;
+};
+
+}  // namespace collision
+
+namespace motion_planning {
+
+struct VoxelEnvironment {           // motion-planning/VoxelEnvironment.h:46-49 (fields the hot path reads)
+  double inv_rotation[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // row-major
+};
+
+/// VoxelBackboneValidityChecker: isValid(state) and its batched form.
+class VoxelBackboneValidityChecker {
+ public:
+  VoxelBackboneValidityChecker(const tendon::TendonRobot &robot, const VoxelEnvironment &venv,
+                               const collision::VoxelOctree &voxels, int device = 0)
+      : robot_(robot), ctx_(robot.context(device)) {
+    // throws std::invalid_argument when robot.specs.dL exceeds the largest voxel edge (VoxelBackboneValidityChecker.h:37-45)
+    check(ctx_, tr_set_grid(ctx_, (uint32_t)voxels.Nx(), voxels.limits(), voxels.blocks().data(), venv.inv_rotation));
+  }
+  const tendon::TendonRobot &robot() const { return robot_; }
+
+  /// AbstractValidityChecker::isValid on a robot state (AbstractValidityChecker.cpp:124-133)
+  bool isValid(const std::vector<double> &robot_state) const {
+    if (robot_state.size() != robot_.state_size()) throw std::invalid_argument("State is not the right size");
+    uint64_t bits = 0;
+    check(ctx_, tr_validate_batch(ctx_, robot_state.data(), 1, &bits, nullptr, nullptr));
+    return bits & 1u;
+  }
+
+  /// n states in one K1 + K2 pass; tips (optional) receive fk_shape.p.back()
+  std::vector<bool> isValidBatch(const std::vector<double> &states, size_t n, std::vector<double> *tips = nullptr,
+                                 std::vector<uint8_t> *flags = nullptr) const {
+    if (states.size() != n * robot_.state_size()) throw std::invalid_argument("State is not the right size");
+    std::vector<uint64_t> bits((n + 63) / 64);
+    if (tips) tips->resize(3 * n);
+    if (flags) flags->resize(n);
+    check(ctx_, tr_validate_batch(ctx_, states.data(), (int64_t)n, bits.data(), tips ? tips->data() : nullptr,
+                                  flags ? flags->data() : nullptr));
+    std::vector<bool> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = (bits[i >> 6] >> (i & 63)) & 1u;
+    return out;
+  }
+  tr_ctx *context() const { return ctx_; }
+
+ private:
+  const tendon::TendonRobot &robot_;
+  tr_ctx *ctx_;
+};
+
+/// VoxelBackboneMotionValidator: checkMotion(s1, s2) and its batched form.
+class VoxelBackboneMotionValidator {
+ public:
+  explicit VoxelBackboneMotionValidator(const VoxelBackboneValidityChecker &vc) : vc_(vc) {}
+  tr_space_params space{0.02, 0.01, 0.0001};      // Problem.h:59-62
+
+  bool checkMotion(const std::vector<double> &a, const std::vector<double> &b) const {   // AbstractVoxelMotionValidator.h:143-151
+    return checkMotionBatch(a, b, 1)[0];
+  }
+  std::vector<bool> checkMotionBatch(const std::vector<double> &a, const std::vector<double> &b, size_t n,
+                                     std::vector<int32_t> *n_fk = nullptr) const {
+    const size_t S = vc_.robot().state_size();
+    if (a.size() != n * S || b.size() != n * S) throw std::invalid_argument("start and end are different sizes");
+    std::vector<uint64_t> bits((n + 63) / 64);
+    if (n_fk) n_fk->resize(n);
+    check(vc_.context(), tr_validate_edges(vc_.context(), &space, a.data(), b.data(), (int64_t)n, bits.data(),
+                                           n_fk ? n_fk->data() : nullptr, nullptr));
+    std::vector<bool> out(n);
+    for (size_t i = 0; i < n; i++) out[i] = (bits[i >> 6] >> (i & 63)) & 1u;
+    return out;
+  }
+
+ private:
+  const VoxelBackboneValidityChecker &vc_;
+};
+
+}  // namespace motion_planning
+}  // namespace tendon_hip

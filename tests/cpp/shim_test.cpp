@@ -1,0 +1,54 @@
+// Exercises include/tendon_hip_shim.hpp the way reference-side C++ would: TendonRobot::shape,
+// VoxelBackboneValidityChecker::isValid / isValidBatch, and the exception mapping.  Prints
+// results for tests/test_gpu_cpp_shim.py to compare with the oracle.
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "tendon_hip_shim.hpp"
+
+using namespace tendon_hip;
+
+int main(int argc, char **argv) {
+  const bool compile_only = argc > 1 && std::string(argv[1]) == "--no-gpu";
+  tendon::TendonRobot robot;
+  robot.specs.dL = 0.2 / 128;
+  for (int k = 0; k < 3; k++) {
+    tendon::TendonSpecs t;
+    t.C = {2 * M_PI * k / 3, 5.0};
+    t.D = {0.01};
+    robot.tendons.push_back(t);
+  }
+  // error mapping that needs no GPU
+  int caught = 0;
+  try { collision::VoxelOctree bad(100); } catch (const std::invalid_argument &) { caught++; }
+  try { collision::VoxelOctree v(8); v.set_xlim(1, 1); } catch (const std::length_error &) { caught++; }
+  try { robot.calc_dl({1.0}, {1.0, 2.0}); } catch (const std::out_of_range &) { caught++; }
+  std::printf("caught %d\n", caught);
+  if (compile_only) return caught == 3 ? 0 : 1;
+
+  try { robot.shape({1.0, 2.0}); } catch (const std::invalid_argument &e) { std::printf("invalid_argument: %s\n", e.what()); }
+  const std::vector<std::vector<double>> states = {{0, 0, 0}, {8, 3, 1}, {2.5, 9.0, 4.0}, {19.0, 0.5, 17.0}};
+  for (auto &s : states) {
+    auto res = robot.shape(s);
+    std::printf("shape %zu %.17g %.17g %.17g %.17g %d\n", res.p.size(), res.p.back()[0], res.p.back()[1], res.p.back()[2],
+                res.L_i[0], (int)res.converged);
+  }
+  collision::VoxelOctree vox(256);
+  vox.set_xlim(-0.25, 0.25); vox.set_ylim(-0.25, 0.25); vox.set_zlim(-0.25, 0.25);
+  // a slab of obstacles at x in [0.03, 0.05], z >= 0.1
+  for (size_t ix = 143; ix < 154; ix++) for (size_t iy = 64; iy < 192; iy++) for (size_t iz = 179; iz < 240; iz++) vox.set_cell(ix, iy, iz);
+  motion_planning::VoxelEnvironment env;
+  motion_planning::VoxelBackboneValidityChecker vc(robot, env, vox);
+  std::vector<double> flat;
+  for (auto &s : states) { std::printf("isValid %d\n", (int)vc.isValid(s)); flat.insert(flat.end(), s.begin(), s.end()); }
+  std::vector<double> tips; std::vector<uint8_t> flags;
+  auto v = vc.isValidBatch(flat, states.size(), &tips, &flags);
+  for (size_t i = 0; i < v.size(); i++) std::printf("batch %d %u %.17g\n", (int)v[i], flags[i], tips[3 * i]);
+  try {
+    collision::VoxelOctree fine(512);
+    fine.set_xlim(-0.25, 0.25); fine.set_ylim(-0.25, 0.25); fine.set_zlim(-0.25, 0.25);
+    motion_planning::VoxelBackboneValidityChecker bad(robot, env, fine);
+  } catch (const std::invalid_argument &e) { std::printf("invalid_argument: %s\n", e.what()); }
+  return 0;
+}
