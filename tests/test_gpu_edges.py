@@ -1,0 +1,84 @@
+"""GPU parity of batched edge (motion) validation, tr_validate_edges, against the oracle's
+depth-first restatement of VoxelEnvironment::voxelize_valid_backbone_motion + checkMotion."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _edges(robot, irt, n, seed, step):
+    rng = np.random.default_rng(seed)
+    a = irt.workloads.random_states(robot, n, seed=seed)
+    d = rng.normal(size=a.shape)
+    d *= (rng.uniform(0.05, step, n) / np.linalg.norm(d[:, :len(robot.tendons)], axis=1))[:, None]
+    b = a + d
+    nt = len(robot.tendons)
+    b[:, :nt] = np.clip(b[:, :nt], 0.0, [t.max_tension for t in robot.tendons])
+    if robot.enable_rotation:
+        b[:, nt] = (b[:, nt] + np.pi) % (2 * np.pi) - np.pi
+    return a, b
+
+
+def _compare(irt, orc, helpers, robot, vox, a, b):
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    got = mv.check_motion_detail(a, b)
+    orb = helpers.oracle_robot(orc, robot, lib="omp")
+    og = helpers.oracle_grid(orc, vox)
+    want, want_nfk, _ = orc.check_motion_batch(orb, og, a, b, nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(got["valid"], want), np.flatnonzero(got["valid"] != want)[:10]
+    # for valid edges nothing is pruned, so the sample sets (and counts) coincide
+    assert np.array_equal(got["n_fk"][want], want_nfk[want])
+    assert (got["n_fk"] >= 2).all() and got["n_domain_errors"] == 0
+    return got, want, want_nfk
+
+
+def test_edges_config3_match_oracle(irt, orc, helpers):
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    a, b = _edges(robot, irt, 1500, seed=31, step=3.0)
+    got, want, nfk = _compare(irt, orc, helpers, robot, vox, a, b)
+    print("edges valid %.2f, FK samples/edge mean %.1f max %d" % (want.mean(), nfk.mean(), nfk.max()))
+    assert 0.1 < want.mean() < 0.95 and nfk.max() > 8
+
+
+def test_edges_with_rotation_wraparound(irt, orc, helpers):
+    W = irt.workloads
+    robot = W.robot_config2()
+    robot.enable_rotation = True
+    vox, _ = W.reach_environment(seed=8, n_spheres=48)
+    a, b = _edges(robot, irt, 600, seed=32, step=2.0)
+    # force a share of the edges across the +-pi seam
+    a[:100, 3] = np.pi - 0.05
+    b[:100, 3] = -np.pi + 0.07
+    _compare(irt, orc, helpers, robot, vox, a, b)
+
+
+def test_edge_degenerate_and_single(irt, orc, helpers):
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    s = np.array([[3.0, 1.0, 2.0]])
+    d = mv.check_motion_detail(s, s)                       # a == b: two samples, verdict = isValid(a)
+    assert d["n_fk"][0] == 2 and d["valid"][0] == chk.isValid(s[0])
+    assert mv.checkMotion([3.0, 1.0, 2.0], [3.5, 1.2, 2.1]) in (True, False)
+    assert mv.check_motion(np.zeros((0, 3)), np.zeros((0, 3))).size == 0
+    with pytest.raises(irt.InvalidArgument):
+        mv.check_motion(np.zeros((2, 3)), np.zeros((3, 3)))
+
+
+def test_edges_leaving_the_voxel_domain_are_reported(irt):
+    """find_cell throws std::domain_error in the reference; here the edge is invalid and counted."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    small = irt.VoxelOctree(64)                            # domain smaller than the robot's reach
+    small.set_xlim(-0.06, 0.06); small.set_ylim(-0.06, 0.06); small.set_zlim(-0.01, 0.11)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), small)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    a = np.array([[0.0, 0.0, 0.0], [0.1, 0.0, 0.0]])
+    b = np.array([[6.0, 0.0, 0.0], [0.2, 0.1, 0.0]])
+    d = mv.check_motion_detail(a, b)
+    assert d["n_domain_errors"] >= 1 and not d["valid"][0]
