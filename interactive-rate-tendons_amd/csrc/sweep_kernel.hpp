@@ -344,32 +344,50 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
     GridCursor gc{grid, g.Nb, -1, 0ull};
     GridCursor near{(debug & 4u) ? nullptr : near_grid, g.Nb, -1, 0ull};
     V3 prev = {0, 0, 0}, prevr = {0, 0, 0};
-    for (int j = 0; j < P; j++) {
-      const bool on = alive && j < np;
-      if (!__any(on)) break;
-      if (on) {
-        const int64_t o = (int64_t)j * ld + ic;
-        const V3 q = {in.px[o], in.py[o], in.pz[o]};
-        if (j == 0) prev = q;
-        const float dx = (float)(q.x - prev.x), dy = (float)(q.y - prev.y), dz = (float)(q.z - prev.z);
-        dist += sqrtf(dx * dx + dy * dy + dz * dz);
-        prev = q;
-        const bool last = (j == np - 1);
-        if (last || (j % CH) == 0) {
-          const int k = last ? Kl : j / CH;
-          mx[k * 64] = (float)q.x; my[k * 64] = (float)q.y; mz[k * 64] = (float)q.z; ma[k * 64] = dist;
+    // The loads of point j+PF are issued before point j is processed (register ring, statically
+    // indexed by unrolling): the walk below is a long dependent chain, and without the prefetch each
+    // iteration exposes a full HBM round trip (r01: 49 % of K2's wave cycles were s_waitcnt).
+    constexpr int PF = 4;
+    V3 ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) {
+      const int64_t o = (int64_t)(u < P ? u : P - 1) * ld + ic;
+      ring[u] = V3{in.px[o], in.py[o], in.pz[o]};
+    }
+    auto visit = [&](int j, const V3 &q) {
+      if (j == 0) prev = q;
+      const float dx = (float)(q.x - prev.x), dy = (float)(q.y - prev.y), dz = (float)(q.z - prev.z);
+      dist += sqrtf(dx * dx + dy * dy + dz * dz);
+      prev = q;
+      const bool last = (j == np - 1);
+      if (last || (j % CH) == 0) {
+        const int k = last ? Kl : j / CH;
+        mx[k * 64] = (float)q.x; my[k * 64] = (float)q.y; mz[k * 64] = (float)q.z; ma[k * 64] = dist;
+      }
+      if (check_voxels && !hit && !bad) {
+        V3 qr;
+        if (g.rot_is_identity) { qr = q; }
+        else {
+          qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
+          qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
+          qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
         }
-        if (check_voxels && !hit && !bad) {
-          V3 qr;
-          if (g.rot_is_identity) { qr = q; }
-          else {
-            qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
-            qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
-            qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
-          }
-          if (j > 0) hit = line_hits(prevr, qr, g, gc, near, bad);
-          prevr = qr;
+        if (j > 0) hit = line_hits(prevr, qr, g, gc, near, bad);
+        prevr = qr;
+      }
+    };
+    for (int j0 = 0; j0 < P; j0 += PF) {
+      if (!__any(alive && j0 < np)) break;
+#pragma unroll
+      for (int u = 0; u < PF; u++) {
+        const int j = j0 + u;
+        const V3 q = ring[u];
+        {
+          const int jn = j + PF;
+          const int64_t o = (int64_t)(jn < P ? jn : P - 1) * ld + ic;
+          ring[u] = V3{in.px[o], in.py[o], in.pz[o]};
         }
+        if (alive && j < np) visit(j, q);
       }
     }
   }
