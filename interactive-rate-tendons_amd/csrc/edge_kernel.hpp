@@ -19,13 +19,21 @@ struct PairK { int32_t a, b; };
 // does, so an early "subdivide" wins over a later out-of-domain point exactly as it does there.
 __global__ __launch_bounds__(256) void pair_cells_differ(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, int64_t ld, int P,
-    const PairK *__restrict__ pairs, int64_t n_pairs, GridK g, uint8_t *__restrict__ out) {
+    const int32_t *__restrict__ n_points /* per sample, or null = P */, const PairK *__restrict__ pairs, int64_t n_pairs, GridK g, uint8_t *__restrict__ out) {
 #pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= n_pairs) return;
   const int64_t sa = pairs[i].a, sb = pairs[i].b;
   uint8_t res = 0;
-  for (int j = P - 1; j >= 0; j--) {
+  int Pm = P;
+  if (n_points) {
+    // retraction: backbones of different lengths (VoxelEnvironment.cpp:317-326): more than one link
+    // apart -> subdivide; otherwise compare the common prefix of points
+    const int na = n_points[sa], nb = n_points[sb];
+    if (na + 1 < nb || na > nb + 1) { out[i] = 1; return; }
+    Pm = na < nb ? na : nb;
+  }
+  for (int j = Pm - 1; j >= 0; j--) {
     const int64_t oa = (int64_t)j * ld + sa, ob = (int64_t)j * ld + sb;
     V3 A = {px[oa], py[oa], pz[oa]}, B = {px[ob], py[ob], pz[ob]};
     if (!g.rot_is_identity) {

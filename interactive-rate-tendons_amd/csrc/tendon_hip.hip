@@ -24,6 +24,7 @@
 #include "../../include/tendon_hip.h"
 #include "tr_types.hpp"
 #include "fk_kernel.hpp"
+#include "fk_retract_kernel.hpp"
 #include "sweep_kernel.hpp"
 #include "edge_kernel.hpp"
 
@@ -35,6 +36,8 @@ struct Workspace {
   int64_t ld = 0;                 // capacity in configurations (multiple of 64)
   double *px = nullptr, *py = nullptr, *pz = nullptr, *acc = nullptr;   // [P][ld]
   double *Li = nullptr;           // [N][ld]
+  double *homeLi = nullptr;       // [N][ld]  per-configuration home lengths (retraction only)
+  int32_t *np = nullptr;          // [ld]     per-configuration point counts (retraction only)
   uint8_t *conv = nullptr;        // [ld]
   // staging for the host-pointer entry points
   int64_t st_cap = 0;
@@ -60,6 +63,7 @@ struct tr_ctx {
   std::vector<StepK> steps;
   double *d_tab = nullptr;
   StepK *d_steps = nullptr;
+  PolyK *d_poly = nullptr;        // routing polynomials (retraction kernel)
   // obstacle grid
   bool has_grid = false;
   GridK G{};
@@ -234,6 +238,10 @@ int ensure_workspace(tr_ctx *ctx, int64_t n) {
   if ((rc = dev_alloc(ctx, &w.acc, P * want))) return rc;
   if ((rc = dev_alloc(ctx, &w.Li, N * want))) return rc;
   if ((rc = dev_alloc(ctx, &w.conv, (size_t)want))) return rc;
+  if (ctx->K.enable_retraction) {
+    if ((rc = dev_alloc(ctx, &w.homeLi, N * want))) return rc;
+    if ((rc = dev_alloc(ctx, &w.np, (size_t)want))) return rc;
+  }
   w.ld = want;
   return TR_OK;
 }
@@ -281,11 +289,40 @@ void launch_fk_n(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
   if (rot) { if (wr) launch_fk_t<N, true, true>(ctx, d_states, n, ld, out, s); else launch_fk_t<N, true, false>(ctx, d_states, n, ld, out, s); }
   else     { if (wr) launch_fk_t<N, false, true>(ctx, d_states, n, ld, out, s); else launch_fk_t<N, false, false>(ctx, d_states, n, ld, out, s); }
 }
+template <int N, bool ROT, bool WR>
+void launch_fkr_t(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
+  const unsigned grid = (unsigned)((n + 63) / 64);
+  hipLaunchKernelGGL((trk::fk_rk4_batch_retract<N, ROT, WR>), dim3(grid), dim3(64), 0, s, d_states, n, ld, ctx->K,
+                     ctx->d_poly, ctx->ws.acc, out);
+}
+template <int N>
+void launch_fkr_n(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
+  const bool rot = ctx->K.enable_rotation, wr = out.R != nullptr;
+  if (rot) { if (wr) launch_fkr_t<N, true, true>(ctx, d_states, n, ld, out, s); else launch_fkr_t<N, true, false>(ctx, d_states, n, ld, out, s); }
+  else     { if (wr) launch_fkr_t<N, false, true>(ctx, d_states, n, ld, out, s); else launch_fkr_t<N, false, false>(ctx, d_states, n, ld, out, s); }
+}
+
+// With retraction the kernel uses ws.acc (leading dimension ws.ld) as scratch for the range()
+// abscissae, so ld must equal ws.ld there.
 int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
   if (n <= 0) return TR_OK;
-  if (ctx->K.enable_retraction)
-    return fail(ctx, TR_ERR_UNSUPPORTED, "retraction-enabled robots are not supported by this build of fk_rk4_batch");
   ProfScope ps(ctx, 0, s);
+  if (ctx->K.enable_retraction) {
+    if (ld != ctx->ws.ld) return fail(ctx, TR_ERR_INVALID_ARG, "retraction: ld must equal the workspace leading dimension (tr_reserve)");
+    switch (ctx->K.n_tendons) {
+      case 1: launch_fkr_n<1>(ctx, d_states, n, ld, out, s); break;
+      case 2: launch_fkr_n<2>(ctx, d_states, n, ld, out, s); break;
+      case 3: launch_fkr_n<3>(ctx, d_states, n, ld, out, s); break;
+      case 4: launch_fkr_n<4>(ctx, d_states, n, ld, out, s); break;
+      case 5: launch_fkr_n<5>(ctx, d_states, n, ld, out, s); break;
+      case 6: launch_fkr_n<6>(ctx, d_states, n, ld, out, s); break;
+      case 7: launch_fkr_n<7>(ctx, d_states, n, ld, out, s); break;
+      case 8: launch_fkr_n<8>(ctx, d_states, n, ld, out, s); break;
+      default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
+    }
+    HIP_TRY(ctx, hipGetLastError());
+    return TR_OK;
+  }
   switch (ctx->K.n_tendons) {
     case 1: launch_fk_n<1>(ctx, d_states, n, ld, out, s); break;
     case 2: launch_fk_n<2>(ctx, d_states, n, ld, out, s); break;
@@ -403,8 +440,19 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
     routing_at(c, tk + h, &tab[(1 + 3 * k + 2) * ent]);
   }
   home_lengths(c, c->t, 0.0, K.home_Li);
+  PolyK poly{};
+  for (int j = 0; j < N; j++) {
+    for (int i = 0; i < rb->n_a; i++) poly.C[j][i] = c->C[(size_t)j * rb->n_a + i];
+    for (int i = 0; i < rb->n_m; i++) poly.D[j][i] = c->D[(size_t)j * rb->n_m + i];
+    const int rdeg = poly_degree(&c->D[(size_t)j * rb->n_m], rb->n_m), tdeg = poly_degree(&c->C[(size_t)j * rb->n_a], rb->n_a);
+    poly.home_kind[j] = (rdeg == 0 && tdeg == 0) ? 0 : ((rdeg == 0 && tdeg == 1) ? 1 : 2);
+    const double d0 = poly.D[j][0], c1 = rb->n_a > 1 ? poly.C[j][1] : 0.0;
+    poly.helix_scale[j] = std::sqrt(1 + d0 * d0 * c1 * c1);
+  }
 
   auto bail = [&](const char *what) { std::string m = what; tr_destroy(c); return fail(nullptr, TR_ERR_HIP, m); };
+  if (hipMalloc((void **)&c->d_poly, sizeof(PolyK)) != hipSuccess) return bail("hipMalloc(poly)");
+  if (hipMemcpy(c->d_poly, &poly, sizeof(PolyK), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy(poly)");
   if (hipMalloc((void **)&c->d_tab, tab.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc(tab)");
   if (hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy(tab)");
   if (hipMalloc((void **)&c->d_steps, std::max<size_t>(1, c->steps.size()) * sizeof(StepK)) != hipSuccess) return bail("hipMalloc(steps)");
@@ -420,7 +468,7 @@ void tr_destroy(tr_ctx *c) {
   (void)hipDeviceSynchronize();
   for (auto &v : c->events) for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   Workspace &w = c->ws;
-  void *ptrs[] = {c->d_tab, c->d_steps, c->d_grid, c->d_near, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
+  void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_grid, c->d_near, w.homeLi, w.np, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
@@ -496,7 +544,12 @@ int tr_fk_batch_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t ld, do
   if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
   if (n == 0) return TR_OK;
   if (!d_states || !d_px || !d_py || !d_pz) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
-  trk::FkOut out{d_px, d_py, d_pz, d_R, d_L, d_Li, nullptr, d_converged, d_n_points};
+  if (c->K.enable_retraction) {
+    // the retraction kernel keeps its range() scratch in the workspace, whose leading dimension it shares
+    if (c->ws.ld == 0) { int rc = ensure_workspace(c, ld); if (rc) return rc; }
+    if (ld != c->ws.ld) return fail(c, TR_ERR_INVALID_ARG, "retraction: ld must equal the reserved workspace size (tr_reserve(ld))");
+  }
+  trk::FkOut out{d_px, d_py, d_pz, d_R, d_L, d_Li, nullptr, d_converged, d_n_points, nullptr};
   return launch_fk(c, d_states, n, ld, out, (hipStream_t)stream);
 }
 
@@ -514,11 +567,12 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
   Workspace &w = c->ws;
   double *d_R = nullptr;
   std::vector<double> hx, hy, hz, hR, hLi;
+  std::vector<int32_t> hn;
   for (int64_t off = 0; off < n; off += chunk_max) {
     const int64_t m = std::min(chunk_max, n - off), ld = w.ld;
     HIP_TRY(c, hipMemcpy(w.states, states + off * S, (size_t)m * S * sizeof(double), hipMemcpyHostToDevice));
     if (R && !d_R) HIP_TRY(c, hipMalloc((void **)&d_R, (size_t)9 * P * ld * sizeof(double)));
-    trk::FkOut out{w.px, w.py, w.pz, d_R, w.L, w.Li, nullptr, w.conv, w.npts};
+    trk::FkOut out{w.px, w.py, w.pz, d_R, w.L, w.Li, nullptr, w.conv, w.npts, nullptr};
     if ((rc = launch_fk(c, w.states, m, ld, out, nullptr))) { if (d_R) (void)hipFree(d_R); return rc; }
     HIP_TRY(c, hipDeviceSynchronize());
     if (p) {
@@ -526,10 +580,13 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
       HIP_TRY(c, hipMemcpy(hx.data(), w.px, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
       HIP_TRY(c, hipMemcpy(hy.data(), w.py, hy.size() * sizeof(double), hipMemcpyDeviceToHost));
       HIP_TRY(c, hipMemcpy(hz.data(), w.pz, hz.size() * sizeof(double), hipMemcpyDeviceToHost));
+      hn.resize((size_t)m);
+      HIP_TRY(c, hipMemcpy(hn.data(), w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < m; i++)
         for (int j = 0; j < P; j++) {
           double *o = p + ((size_t)(off + i) * P + j) * 3;
-          o[0] = hx[(size_t)j * ld + i]; o[1] = hy[(size_t)j * ld + i]; o[2] = hz[(size_t)j * ld + i];
+          if (j < hn[(size_t)i]) { o[0] = hx[(size_t)j * ld + i]; o[1] = hy[(size_t)j * ld + i]; o[2] = hz[(size_t)j * ld + i]; }
+          else o[0] = o[1] = o[2] = std::numeric_limits<double>::quiet_NaN();
         }
     }
     if (R) {
@@ -562,6 +619,8 @@ int tr_validate_shapes_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px,
   if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
   if (n == 0) return TR_OK;
   if (!d_px || !d_py || !d_pz || !d_Li || !d_converged || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  if (c->K.enable_retraction)
+    return fail(c, TR_ERR_UNSUPPORTED, "tr_validate_shapes_dev needs per-configuration home lengths with retraction; use tr_validate_batch");
   int rc;
   // the accumulated-chord scratch has the caller's leading dimension
   if (c->ws.ld < ld) {
@@ -588,9 +647,11 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
   const int S = c->K.state_size;
   for (int64_t off = 0; off < n; off += w.ld) {
     const int64_t m = std::min<int64_t>(w.ld, n - off);
-    trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, d_tips ? d_tips + 3 * off : nullptr, w.conv, nullptr};
+    const bool ret = c->K.enable_retraction;
+    trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, d_tips ? d_tips + 3 * off : nullptr, w.conv,
+                   ret ? w.np : nullptr, ret ? w.homeLi : nullptr};
     if ((rc = launch_fk(c, d_states + off * S, m, w.ld, out, s))) return rc;
-    trk::SweepIn in{w.px, w.py, w.pz, nullptr, w.Li, w.conv, nullptr, w.acc};
+    trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
     if ((rc = launch_sweep(c, in, m, w.ld, 1, d_valid_bits + off / 64, d_flags ? d_flags + off : nullptr, s))) return rc;
   }
   return TR_OK;

@@ -25,6 +25,15 @@ struct RobotK {
   int32_t pad_;
 };
 
+// Tendon routing polynomials and home-length classification, read by the retraction kernel
+// (per-lane arc-length grid) through wave-uniform scalar loads.
+struct PolyK {
+  double C[TRK_MAX_TENDONS][TRK_MAX_COEF];   // theta_i(t) coefficients (tendon/TendonSpecs.h:26)
+  double D[TRK_MAX_TENDONS][TRK_MAX_COEF];   // rho_i(t) coefficients   (tendon/TendonSpecs.h:27)
+  double helix_scale[TRK_MAX_TENDONS];       // sqrt(1 + d0^2 c1^2)      (tendon/TendonRobot.cpp:289-292)
+  int32_t home_kind[TRK_MAX_TENDONS];        // 0 straight, 1 helix, 2 general (numerical integration)
+};
+
 // One RK4 step of the shared arc-length grid (retraction disabled): produced on the host by the
 // integrate_times stepping rule (Boost.odeint, call site tendon/TendonRobot.cpp:458-462).
 struct StepK {

@@ -81,15 +81,16 @@ class TendonRobot:
             self._engines[device] = Engine(self, device)
         return self._engines[device]
 
-    def _t(self, device=0):
-        # the shared arc-length grid is re-derived on the host only for TendonResult.t
+    def _t(self, s_start=0.0):
+        """t_range(s_start, L, dL) (TendonRobot.cpp:69-84): only to fill TendonResult.t on the host."""
         s = self.specs
-        vals, p = [], 0.0
+        start = min(float(s_start), s.L)
+        vals, p = [], start
         while p <= s.L - s.dL / 2:
             vals.append(p)
             p += s.dL
         vals.append(s.L)
-        return np.array([s.L - (v - 0.0) for v in vals])[::-1].copy()
+        return np.array([s.L - (v - start) for v in vals])[::-1].copy()
 
     # ---- single-configuration API (reference signatures) -----------------------------------------
     def shape(self, state, device=0) -> TendonResult:          # TendonRobot.h:105-115
@@ -99,20 +100,50 @@ class TendonRobot:
         out = self.engine(device).fk_batch(state.reshape(1, -1), want_R=True)
         n = int(out["n_points"][0])
         R = out["R"][0, :n].reshape(n, 3, 3).transpose(0, 2, 1)    # column-major storage -> R[j][r][c]
-        return TendonResult(t=self._t()[:n], p=out["p"][0, :n], R=R, L=float(out["L"][0]),
+        s_start = float(state[-1]) if self.enable_retraction else 0.0
+        t = self._t(s_start) if n > 1 else np.array([min(s_start, self.specs.L)])
+        return TendonResult(t=t[:n], p=out["p"][0, :n], R=R, L=float(out["L"][0]),
                             L_i=out["L_i"][0], converged=bool(out["converged"][0]))
 
     def forward_kinematics(self, state, device=0):              # TendonRobot.h:68-72
         return self.shape(state, device).p
 
-    def home_shape(self, s_start=0.0, device=0) -> TendonResult:  # TendonRobot.cpp:249-314 (s_start = 0)
-        if s_start != 0.0:
-            raise L.Unsupported("home_shape(s_start != 0) needs retraction support")
-        t = self._t()
+    def home_shape(self, s_start=0.0, device=0) -> TendonResult:  # TendonRobot.cpp:249-314
+        """Zero-tension shape.  Pure host arithmetic (closed forms; the defined Simpson rule of DESIGN.md
+        for general routing); s_start = 0 lengths come from the engine so both agree bit for bit."""
+        L = self.specs.L
+        s_start = min(max(float(s_start), 0.0), L)
+        n_t = len(self.tendons)
+        if s_start == L:
+            return TendonResult(t=np.array([L]), p=np.zeros((1, 3)), R=np.eye(3)[None], L=0.0, L_i=np.zeros(n_t))
+        t = self._t(s_start)
         p = np.zeros((t.size, 3))
-        p[:, 2] = t
+        p[:, 2] = t - s_start
         R = np.tile(np.eye(3), (t.size, 1, 1))
-        return TendonResult(t=t, p=p, R=R, L=self.specs.L, L_i=self.engine(device).home_lengths(), converged=True)
+        if s_start == 0.0:
+            L_i = self.engine(device).home_lengths()
+        else:
+            L_i = np.empty(n_t)
+            for i, td in enumerate(self.tendons):
+                if td.is_straight():
+                    L_i[i] = L - s_start
+                elif td.is_helix():
+                    L_i[i] = (L - s_start) * np.sqrt(1 + td.D[0] * td.D[0] * td.C[1] * td.C[1])
+                else:
+                    Cd = np.polynomial.Polynomial(td.C).deriv()
+                    D, Dd = np.polynomial.Polynomial(td.D), np.polynomial.Polynomial(td.D).deriv()
+                    vals = np.sqrt(Dd(t) ** 2 + D(t) ** 2 * Cd(t) ** 2 + 1)
+                    n, dx = t.size, self.specs.dL
+                    nint, odd = n - 1, 0.0
+                    if nint % 2:
+                        odd = 0.5 * dx * (vals[n - 2] + vals[n - 1])
+                        nint -= 1
+                    if nint == 0:
+                        L_i[i] = odd
+                    else:
+                        w = np.where(np.arange(1, nint) % 2 == 1, 4.0, 2.0)
+                        L_i[i] = odd + (vals[0] + vals[nint] + (w * vals[1:nint]).sum()) * dx / 3.0
+        return TendonResult(t=t, p=p, R=R, L=L - s_start, L_i=L_i, converged=True)
 
     def calc_dl(self, home_l, other_l):                        # TendonRobot.h:247-259
         home_l, other_l = np.asarray(home_l, float), np.asarray(other_l, float)

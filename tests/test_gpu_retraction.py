@@ -1,0 +1,90 @@
+"""GPU parity for retraction-enabled robots (per-configuration arc-length grid, variable point
+count, two-step first interval, per-configuration home lengths) against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+TIP_TOL = 1e-9
+
+
+def _robot(irt, kind):
+    W = irt.workloads
+    r = {"straight": W.robot_config1, "helix": W.robot_config2, "quad": W.robot_config3}[kind]()
+    r.specs.dL = 0.2 / 128
+    r.enable_retraction = True
+    return r
+
+
+def _states(irt, robot, n, seed):
+    st = irt.workloads.random_states(robot, n, seed=seed, tau_max=15.0)
+    L, dL = robot.specs.L, robot.specs.dL
+    special = [0.0, L, L + 0.01, L - dL / 4, L - dL / 2, L - 0.75 * dL, L - 1.25 * dL, L - 1.5 * dL, 0.0975, 0.1, dL / 3,
+               L - 2.49 * dL, 17 * dL, 17.5 * dL]
+    st[:len(special), -1] = special
+    return st
+
+
+@pytest.mark.parametrize("kind", ["straight", "helix", "quad"])
+def test_fk_with_retraction(irt, orc, helpers, kind):
+    robot = _robot(irt, kind)
+    orb = helpers.oracle_robot(orc, robot)
+    st = _states(irt, robot, 700, seed=61)
+    got = robot.shape_batch(st)
+    want = orb.fk_batch(st)
+    P = got["p"].shape[1]
+    wp = want["p"][:, :P]
+    want_n = (~np.isnan(wp[:, :, 0])).sum(1)
+    assert np.array_equal(got["n_points"], want_n)
+    assert np.array_equal(np.isnan(got["p"]), np.isnan(wp))
+    assert np.nanmax(np.abs(got["p"] - wp)) <= TIP_TOL
+    assert np.abs(got["L"] - want["L"]).max() <= 1e-10 and np.abs(got["L_i"] - want["L_i"]).max() <= 1e-10
+    assert np.array_equal(got["converged"], want["converged"])
+    assert got["n_points"].min() == 1 and got["n_points"].max() == P
+    # single-state API: t grid and home shape
+    for s in st[8:12]:
+        res, w = robot.shape(s), orb.shape(s)
+        assert np.array_equal(res.t, w["t"]) and np.abs(res.p - w["p"]).max() <= TIP_TOL
+        assert np.abs(robot.home_shape(s[-1]).L_i - orb.home_shape(s[-1])["L_i"]).max() <= 1e-14
+
+
+def test_negative_retraction_is_reported_unconverged(irt):
+    robot = _robot(irt, "helix")
+    out = robot.shape_batch(np.array([[1.0, 2.0, 3.0, -0.01]]))
+    assert not out["converged"][0] and out["n_points"][0] == 1
+
+
+@pytest.mark.parametrize("kind", ["helix", "quad"])
+def test_validity_with_retraction(irt, orc, helpers, kind):
+    W = irt.workloads
+    robot = _robot(irt, kind)
+    for t in robot.tendons:
+        t.max_length = 0.02
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    st = _states(irt, robot, 6000, seed=62)
+    got = chk.is_valid_detail(st)
+    want, tips, _ = orc.validate_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), st,
+                                       nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(got["valid"], want), np.flatnonzero(got["valid"] != want)[:10]
+    assert np.abs(got["tips"] - tips).max() <= TIP_TOL
+    hist = np.bincount(got["flags"], minlength=16)
+    assert hist[15] > 0 and hist[7] > 0 and hist[1] > 0          # valid, voxel hit, length-limit failures
+
+
+def test_edges_with_retraction(irt, orc, helpers):
+    W = irt.workloads
+    robot = _robot(irt, "helix")
+    vox, _ = W.reach_environment(seed=7, n_spheres=48)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    rng = np.random.default_rng(63)
+    a = W.random_states(robot, 500, seed=63, tau_max=15.0)
+    b = a + rng.normal(size=a.shape) * np.array([1.0, 1.0, 1.0, 0.01])
+    b[:, :3] = np.clip(b[:, :3], 0, 20)
+    b[:, 3] = np.clip(b[:, 3], 0, 0.2)
+    got = mv.check_motion_detail(a, b)
+    want, nfk, _ = orc.check_motion_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), a, b,
+                                          nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(got["valid"], want)
+    assert np.array_equal(got["n_fk"][want], nfk[want])
+    assert 0.05 < want.mean() < 0.98
