@@ -213,37 +213,37 @@ __device__ __forceinline__ void initial_bending(const double (&tau)[N], const do
 }
 
 // One classical RK4 step of size h (Boost.odeint runge_kutta4 tableau: a = {1/2},{0,1/2},{0,0,1};
-// b = {1/6,1/3,1/3,1/6}; c = {0,1/2,1/2,1}) of the state (R, v, u | p, L, L_i).
-// ri0 / ri1 / ri2: routing values at t, t + h/2, t + h (N x 6 each; wave-uniform table rows or
-// per-lane arrays).
-template <int N>
-__device__ __forceinline__ void rk4_step(double (&R)[9], double (&v)[3], double (&u)[3], double (&p)[3], double &Lb,
-                                         double (&Li)[N], const double (&tau)[N], const RobotK &K, double h,
-                                         const double *__restrict__ ri0, const double *__restrict__ ri1,
-                                         const double *__restrict__ ri2) {
+// b = {1/6,1/3,1/3,1/6}; c = {0,1/2,1/2,1}) of the state (R, v, u | p, L, L_i), with the routing
+// produced on demand by `route(t, ri)` at t, t + h/2 (shared by stages 2 and 3) and t + h.
+// Used by the retraction kernel; the shared-grid kernel below carries the same statements inline
+// (as a function taking three table rows it made hipcc hoist all scalar loads and spill ~100 VGPRs).
+template <int N, class Route>
+__device__ __forceinline__ void rk4_step_routed(double (&R)[9], double (&v)[3], double (&u)[3], double (&p)[3], double &Lb,
+                                                double (&Li)[N], const double (&tau)[N], const RobotK &K, double t, double h,
+                                                Route &&route) {
 #pragma clang fp contract(fast)
   const double hh = h * 0.5;
   const double b1 = h * (1.0 / 6.0), b2 = h * (1.0 / 3.0);
-  // accumulators start at the current state
   double aR[9], av[3], au[3];
 #pragma unroll
   for (int q = 0; q < 9; q++) aR[q] = R[q];
 #pragma unroll
   for (int q = 0; q < 3; q++) { av[q] = v[q]; au[q] = u[q]; }
-  double sR[9], sv[3], su[3];                // stage state
+  double sR[9], sv[3], su[3];
 #pragma unroll
   for (int q = 0; q < 9; q++) sR[q] = R[q];
 #pragma unroll
   for (int q = 0; q < 3; q++) { sv[q] = v[q]; su[q] = u[q]; }
-
+  double ri[N * 6];
 #pragma unroll
   for (int st = 0; st < 4; st++) {
-    const double *__restrict__ ri = (st == 0) ? ri0 : (st == 3 ? ri2 : ri1);
-    const double bw = (st == 0 || st == 3) ? b1 : b2;      // weight of this stage in the update
-    const double aw = (st == 2) ? h : hh;                  // coefficient towards the next stage
+    if (st == 0) route(t, ri);
+    if (st == 1) route(t + h * 0.5, ri);
+    if (st == 3) route(t + h, ri);
+    const double bw = (st == 0 || st == 3) ? b1 : b2;
+    const double aw = (st == 2) ? h : hh;
     double dv[3], du[3], sd[N];
     strain_rates<N>(sv, su, tau, ri, K, dv, du, sd);
-    // quadratures: p' = R v, L' = |v|, L_i' = |pd_i|
     p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
     p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
     p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);
@@ -253,7 +253,6 @@ __device__ __forceinline__ void rk4_step(double (&R)[9], double (&v)[3], double 
     }
 #pragma unroll
     for (int j = 0; j < N; j++) Li[j] += bw * sd[j];
-    // R' = R uhat : col0 = R1*uz - R2*uy ; col1 = R2*ux - R0*uz ; col2 = R0*uy - R1*ux
     double dR[9];
 #pragma unroll
     for (int r = 0; r < 3; r++) {
@@ -346,7 +345,61 @@ __global__ __launch_bounds__(64, 2) void fk_rk4_batch_uniform(
     const double h = steps[k].h;
     const int obs = steps[k].obs;
     const double *__restrict__ rt = tab + (size_t)(1 + 3 * k) * (N * 6);
-    rk4_step<N>(R, v, u, p, Lb, Li, tau, K, h, rt, rt + N * 6, rt + 2 * N * 6);
+    const double hh = h * 0.5;
+    const double b1 = h * (1.0 / 6.0), b2 = h * (1.0 / 3.0);
+    // accumulators start at the current state
+    double aR[9], av[3], au[3];
+#pragma unroll
+    for (int q = 0; q < 9; q++) aR[q] = R[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { av[q] = v[q]; au[q] = u[q]; }
+    double sR[9], sv[3], su[3];                // stage state
+#pragma unroll
+    for (int q = 0; q < 9; q++) sR[q] = R[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { sv[q] = v[q]; su[q] = u[q]; }
+
+#pragma unroll
+    for (int st = 0; st < 4; st++) {
+      const double *__restrict__ ri = rt + (st == 0 ? 0 : (st == 3 ? 2 : 1)) * (N * 6);
+      const double bw = (st == 0 || st == 3) ? b1 : b2;      // weight of this stage in the update
+      const double aw = (st == 2) ? h : hh;                  // coefficient towards the next stage
+      double dv[3], du[3], sd[N];
+      strain_rates<N>(sv, su, tau, ri, K, dv, du, sd);
+      // quadratures: p' = R v, L' = |v|, L_i' = |pd_i|
+      p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
+      p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
+      p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);
+      {
+        const double v2 = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2];
+        Lb += bw * (v2 * fast_rsqrt(v2));
+      }
+#pragma unroll
+      for (int j = 0; j < N; j++) Li[j] += bw * sd[j];
+      // R' = R uhat : col0 = R1*uz - R2*uy ; col1 = R2*ux - R0*uz ; col2 = R0*uy - R1*ux
+      double dR[9];
+#pragma unroll
+      for (int r = 0; r < 3; r++) {
+        const double r0 = sR[0 + r], r1 = sR[3 + r], r2 = sR[6 + r];
+        dR[0 + r] = r1 * su[2] - r2 * su[1];
+        dR[3 + r] = r2 * su[0] - r0 * su[2];
+        dR[6 + r] = r0 * su[1] - r1 * su[0];
+      }
+#pragma unroll
+      for (int q = 0; q < 9; q++) aR[q] += bw * dR[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { av[q] += bw * dv[q]; au[q] += bw * du[q]; }
+      if (st < 3) {
+#pragma unroll
+        for (int q = 0; q < 9; q++) sR[q] = R[q] + aw * dR[q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { sv[q] = v[q] + aw * dv[q]; su[q] = u[q] + aw * du[q]; }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 9; q++) R[q] = aR[q];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { v[q] = av[q]; u[q] = au[q]; }
     if (obs >= 0) store_point(obs);
   }
 

@@ -3,7 +3,7 @@
 // backbone points, a first interval in [dL/2, 1.5 dL) that may need two RK4 steps
 // (integrate_times, call site TendonRobot.cpp:458-462), and its own home-shape tendon lengths
 // (home_shape(s_start), TendonRobot.cpp:249-314).  The routing r(t), r'(t), r''(t) is evaluated per
-// lane (polynomials with scalar coefficients + sincos), everything else is the shared rk4_step.
+// lane (polynomials with scalar coefficients + sincos) on demand per RK4 stage (rk4_step_routed).
 //
 // Lanes run their intervals aligned at the base (interval j of every lane in iteration j); lanes
 // with a retracted, shorter backbone idle at the end of the wave's loop.
@@ -56,7 +56,7 @@ __device__ __forceinline__ double home_ldot(const PolyK *__restrict__ pk, int j,
 }
 
 template <int N, bool ROT, bool WRITE_R>
-__global__ __launch_bounds__(64, 2) void fk_rk4_batch_retract(
+__global__ __launch_bounds__(64) void fk_rk4_batch_retract(
     const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const PolyK *__restrict__ pk,
     double *__restrict__ pscr /* [P][ld] scratch for the range() abscissae */, FkOut out) {
 #pragma clang fp contract(fast)
@@ -158,11 +158,8 @@ __global__ __launch_bounds__(64, 2) void fk_rk4_batch_retract(
       if (!__any(go)) break;
       if (go) {
         const double h = (dL < tn - cur) ? dL : (tn - cur);
-        double r0[N * 6], r1[N * 6], r2[N * 6];
-        routing_lane<N>(pk, K.n_a, K.n_m, cur, r0);
-        routing_lane<N>(pk, K.n_a, K.n_m, cur + h * 0.5, r1);
-        routing_lane<N>(pk, K.n_a, K.n_m, cur + h, r2);
-        rk4_step<N>(R, v, u, p, Lb, Li, tau, K, h, r0, r1, r2);
+        rk4_step_routed<N>(R, v, u, p, Lb, Li, tau, K, cur, h,
+                           [&](double tt, double (&ri)[N * 6]) { routing_lane<N>(pk, K.n_a, K.n_m, tt, ri); });
         cur += h;
       }
     }
