@@ -57,9 +57,14 @@ __device__ __forceinline__ void strain_rates(const double v[3], const double u[3
                                              const double *__restrict__ ri, const RobotK &K,
                                              double dv[3], double du[3], double (&sdot)[N]) {
 #pragma clang fp contract(fast)
-  double Axx = 0, Axy = 0, Axz = 0, Ayy = 0, Ayz = 0, Azz = 0;
-  double B00 = 0, B01 = 0, B02 = 0, B10 = 0, B11 = 0, B12 = 0, B20 = 0, B21 = 0, B22 = 0;
-  double Hxx = 0, Hxy = 0, Hxz = 0, Hyy = 0, Hyz = 0, Hzz = 0;
+  // Sums over tendons, using A_i = c (pd pd^T - |pd|^2 I), c = -tau/|pd|^3, q = c pd, e = r x pd, g = c e:
+  //   A = sum q pd^T - (sum c|pd|^2) I
+  //   B = sum rhat A_i   = sum g pd^T - sum c|pd|^2 rhat
+  //   H = -sum B_i rhat  = sum g e^T  + sum c|pd|^2 rhat^2
+  //   a = sum q (pd.w) - c|pd|^2 w,   b = sum r x a_i,   w = u x (pd + r') + r''
+  double Axx = 0, Axy = 0, Axz = 0, Ayy = 0, Ayz = 0, Azz = 0, Z = 0;
+  double B00 = 0, B01 = 0, B02 = 0, B10 = 0, B11 = 0, B12 = 0, B20 = 0, B21 = 0, B22 = 0, Q1 = 0, Q2 = 0;
+  double Hxx = 0, Hxy = 0, Hxz = 0, Hyy = 0, Hyz = 0, Hzz = 0, P1 = 0, P2 = 0, P3 = 0;
   double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
 #pragma unroll
   for (int j = 0; j < N; j++) {
@@ -70,35 +75,38 @@ __device__ __forceinline__ void strain_rates(const double v[3], const double u[3
     const double pdx = (v[0] + rdx) - u[2] * ry;
     const double pdy = (v[1] + rdy) + u[2] * rx;
     const double pdz = v[2] + (u[0] * ry - u[1] * rx);
-    const double xx = pdx * pdx, yy = pdy * pdy, zz = pdz * pdz;
-    const double s2 = xx + yy + zz;
+    const double s2 = pdx * pdx + pdy * pdy + pdz * pdz;
     const double rs = fast_rsqrt(s2);
     sdot[j] = s2 * rs;
     const double c = -tau[j] * (rs * rs * rs);
-    // A_i = c * hat(pd)^2
-    const double aixx = -c * (yy + zz), aiyy = -c * (xx + zz), aizz = -c * (xx + yy);
-    const double aixy = c * (pdx * pdy), aixz = c * (pdx * pdz), aiyz = c * (pdy * pdz);
-    // w = u x pd + u x r' + r''
-    const double qx = pdx + rdx, qy = pdy + rdy, qz = pdz;
-    const double wx = (u[1] * qz - u[2] * qy) + rddx;
-    const double wy = (u[2] * qx - u[0] * qz) + rddy;
-    const double wz = u[0] * qy - u[1] * qx;
-    const double aix = aixx * wx + aixy * wy + aixz * wz;
-    const double aiy = aixy * wx + aiyy * wy + aiyz * wz;
-    const double aiz = aixz * wx + aiyz * wy + aizz * wz;
-    // b_i = r x a_i (r_z = 0)
-    bx += ry * aiz; by -= rx * aiz; bz += rx * aiy - ry * aix;
+    const double qx = c * pdx, qy = c * pdy, qz = c * pdz, cs2 = c * s2;
+    Axx += qx * pdx; Axy += qx * pdy; Axz += qx * pdz; Ayy += qy * pdy; Ayz += qy * pdz; Azz += qz * pdz;
+    Z += cs2;
+    // e = r x pd, g = c e  (r_z = 0)
+    const double ex = ry * pdz, ey = -rx * pdz, ez = rx * pdy - ry * pdx;
+    const double gx = c * ex, gy = c * ey, gz = c * ez;
+    B00 += gx * pdx; B01 += gx * pdy; B02 += gx * pdz;
+    B10 += gy * pdx; B11 += gy * pdy; B12 += gy * pdz;
+    B20 += gz * pdx; B21 += gz * pdy; B22 += gz * pdz;
+    Hxx += gx * ex; Hxy += gx * ey; Hxz += gx * ez; Hyy += gy * ey; Hyz += gy * ez; Hzz += gz * ez;
+    const double t1 = cs2 * rx, t2 = cs2 * ry;
+    Q1 += t1; Q2 += t2;
+    P1 += t1 * rx; P2 += t1 * ry; P3 += t2 * ry;
+    // w = u x (pd + r') + r''
+    const double hx = pdx + rdx, hy = pdy + rdy, hz = pdz;
+    const double wx = (u[1] * hz - u[2] * hy) + rddx;
+    const double wy = (u[2] * hx - u[0] * hz) + rddy;
+    const double wz = u[0] * hy - u[1] * hx;
+    const double pw = pdx * wx + pdy * wy + pdz * wz;
+    const double aix = qx * pw - cs2 * wx, aiy = qy * pw - cs2 * wy, aiz = qz * pw - cs2 * wz;
     ax += aix; ay += aiy; az += aiz;
-    // B_i = rhat A_i : rows (ry*A2, -rx*A2, rx*A1 - ry*A0)
-    const double b00 = ry * aixz, b01 = ry * aiyz, b02 = ry * aizz;
-    const double b10 = -rx * aixz, b11 = -rx * aiyz, b12 = -rx * aizz;
-    const double b20 = rx * aixy - ry * aixx, b21 = rx * aiyy - ry * aixy, b22 = rx * aiyz - ry * aixz;
-    // H_i = -B_i rhat (symmetric)
-    Hxx += ry * b02; Hxy -= rx * b02; Hyy -= rx * b12;
-    Hxz += rx * b01 - ry * b00; Hyz += rx * b11 - ry * b10; Hzz += rx * b21 - ry * b20;
-    Axx += aixx; Axy += aixy; Axz += aixz; Ayy += aiyy; Ayz += aiyz; Azz += aizz;
-    B00 += b00; B01 += b01; B02 += b02; B10 += b10; B11 += b11; B12 += b12; B20 += b20; B21 += b21; B22 += b22;
+    bx += ry * aiz; by -= rx * aiz; bz += rx * aiy - ry * aix;
   }
+  Axx -= Z; Ayy -= Z; Azz -= Z;
+  // - sum c|pd|^2 rhat, rhat = [[0,0,ry],[0,0,-rx],[-ry,rx,0]]
+  B02 -= Q2; B12 += Q1; B20 += Q2; B21 -= Q1;
+  // + sum c|pd|^2 rhat^2, rhat^2 = [[-ry^2, rx ry, 0],[rx ry, -rx^2, 0],[0,0,-(rx^2+ry^2)]]
+  Hxx -= P3; Hxy += P2; Hyy -= P1; Hzz -= (P1 + P3);
   // c = -u x (K_bt u) - v x (K_se (v - e3)) - b ;  d = -u x (K_se (v - e3)) - a
   const double kux = K.kb0 * u[0], kuy = K.kb0 * u[1], kuz = K.kb2 * u[2];
   const double svx = K.ks0 * v[0], svy = K.ks0 * v[1], svz = K.ks2 * (v[2] - 1.0);
