@@ -174,6 +174,28 @@ int tr_check_cached(tr_ctx *ctx, const uint32_t *block_ids, const uint64_t *mask
 int tr_check_cached_dev(tr_ctx *ctx, const uint32_t *d_block_ids, const uint64_t *d_masks,
                         const int64_t *d_offsets, int64_t n_items, uint64_t *d_hit_bits, void *stream);
 
+/* ---- robot voxel sets for roadmap caches: voxelizeVertex / voxelizeEdge -------------------------- */
+
+/* Batched VoxelCachedLazyPRM::voxelizeVertex (motion-planning/VoxelCachedLazyPRM.cpp:2803-2837),
+ * replacing the loop at :1704-1713: FK, is_valid_shape (no obstacle test), and for every valid shape
+ * the voxel set voxelize_impl would return (VoxelBackboneValidityChecker.h:49-57) as a sparse list
+ * of (block id, mask).  Results are CSR: offsets[n+1] is written here (item i owns
+ * offsets[i]..offsets[i+1]-1, nothing for an invalid shape); the lists stay inside the context
+ * until tr_voxelize_fetch copies them.  shape_valid_bits: ceil(n/64) words; tips optional n x 3.
+ * Block order inside an item is unspecified. */
+int tr_voxelize_batch(tr_ctx *ctx, const double *states, int64_t n, int64_t *offsets,
+                      uint64_t *shape_valid_bits, double *tips);
+
+/* Batched VoxelCachedLazyPRM::voxelizeEdge (:2879-2902 -> AbstractVoxelMotionValidator::voxelize,
+ * AbstractVoxelMotionValidator.h:98-107), replacing the loop at :1751-1775: the swept-volume
+ * voxelisation of every edge whose samples are all shape-valid (is_fully_valid); other edges get an
+ * empty item and a 0 bit.  Same CSR + fetch protocol. */
+int tr_voxelize_edges(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
+                      int64_t n_edges, int64_t *offsets, uint64_t *fully_valid_bits, int32_t *n_fk);
+
+/* Copy the block lists of the last tr_voxelize_* call; capacity must be >= its offsets[n]. */
+int tr_voxelize_fetch(tr_ctx *ctx, uint32_t *block_ids, uint64_t *masks, int64_t capacity);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 
 /* Time the last `which` kernel launches with HIP events on the stream they ran on.

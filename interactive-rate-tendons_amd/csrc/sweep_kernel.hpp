@@ -61,48 +61,23 @@ struct GridCursor {
   }
 };
 
-// VoxelOctree::add_line (collision/VoxelOctree.cpp:325-426) with set_cell replaced by an
-// occupancy test.  Returns true as soon as a visited cell is occupied.  `bad` is raised when an
-// endpoint is non-finite or farther than 4N voxels outside the domain (reference: undefined
-// behaviour / unbounded walk); the caller then forces the configuration invalid.
-//
-// Fast path: `near` is the obstacle grid dilated by 2 cells (Chebyshev).  Every cell add_line can
-// visit lies in [min(A,B)-1, max(A,B)+1] per axis (the walker moves from A's cell towards B's and
-// stops once any axis has passed B's index by one), i.e. within Chebyshev distance |B-A|_inf + 1 of
-// A's cell.  So when the end cells differ by at most one per axis and A's cell is free in `near`,
-// no visited cell can be occupied and the whole fp64 set-up of the walk is skipped.
-__device__ __forceinline__ bool line_hits(const V3 &a, const V3 &b, const GridK &g, GridCursor &gc, GridCursor &near,
-                                          bool &bad) {
+// VoxelOctree::add_line (collision/VoxelOctree.cpp:325-426) with set_cell replaced by a callback
+// `on_cell(x, y, z) -> bool` (true = stop early).  Visits, like the reference, A's cell and B's cell
+// (when inside the grid) and then the cells of the walk.  Returns true iff a callback asked to stop.
+// `bad` is raised when an endpoint is non-finite or farther than 4N voxels outside the domain
+// (reference: undefined behaviour / unbounded walk); the caller then forces the configuration invalid.
+// `A`, `B` are the endpoints already in voxel coordinates ((a - ll) * (1/d), VoxelOctree.cpp:338-340).
+template <class OnCell>
+__device__ __forceinline__ bool walk_cells(const V3 &A, const V3 &B, const GridK &g, OnCell &&on_cell) {
 #pragma clang fp contract(off)
-  // Fast accept of the AABB pre-test: both endpoints at least 1e-6 of the box size inside the
-  // domain => the exact test above is true by a margin far larger than its rounding error.
-  const double mx = 1e-6 * (g.xmax - g.xmin), my = 1e-6 * (g.ymax - g.ymin), mz = 1e-6 * (g.zmax - g.zmin);
-  const bool inside = a.x > g.xmin + mx && a.x < g.xmax - mx && b.x > g.xmin + mx && b.x < g.xmax - mx &&
-                      a.y > g.ymin + my && a.y < g.ymax - my && b.y > g.ymin + my && b.y < g.ymax - my &&
-                      a.z > g.zmin + mz && a.z < g.zmax - mz && b.z > g.zmin + mz && b.z < g.zmax - mz;
-  if (!inside) {
-    if (!segment_aabox_intersect(a, b, g)) return false;
-  }
-  const V3 A = {(a.x - g.xmin) * g.inv_dx, (a.y - g.ymin) * g.inv_dy, (a.z - g.zmin) * g.inv_dz};
-  const V3 B = {(b.x - g.xmin) * g.inv_dx, (b.y - g.ymin) * g.inv_dy, (b.z - g.zmin) * g.inv_dz};
   const int N = g.N;
-  const double lim = 4.0 * N;
-  if (!(fabs(A.x) < lim + N && fabs(A.y) < lim + N && fabs(A.z) < lim + N &&
-        fabs(B.x) < lim + N && fabs(B.y) < lim + N && fabs(B.z) < lim + N)) {
-    bad = true;
-    return false;
-  }
   const int Axi = (int)A.x - (A.x < 0), Ayi = (int)A.y - (A.y < 0), Azi = (int)A.z - (A.z < 0);
   const int Bxi = (int)B.x - (B.x < 0), Byi = (int)B.y - (B.y < 0), Bzi = (int)B.z - (B.z < 0);
-  if (inside && near.blocks) {
-    const int ddx = Bxi - Axi, ddy = Byi - Ayi, ddz = Bzi - Azi;
-    if (ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1 && !near.occupied(Axi, Ayi, Azi)) return false;
-  }
   auto idx_in = [N](int q) { return 0 <= q && q < N; };
   auto vox_in = [&](int x, int y, int z) { return idx_in(x) && idx_in(y) && idx_in(z); };
   bool entered = vox_in(Axi, Ayi, Azi);
-  if (entered && gc.occupied(Axi, Ayi, Azi)) return true;
-  if (vox_in(Bxi, Byi, Bzi) && gc.occupied(Bxi, Byi, Bzi)) return true;
+  if (entered && on_cell(Axi, Ayi, Azi)) return true;
+  if (vox_in(Bxi, Byi, Bzi) && on_cell(Bxi, Byi, Bzi)) return true;
 
   V3 U = {B.x - A.x, B.y - A.y, B.z - A.z};
   {
@@ -139,9 +114,54 @@ __device__ __forceinline__ bool line_hits(const V3 &a, const V3 &b, const GridK 
       tz += tz_delta;
     }
     if (!entered && vox_in(xi, yi, zi)) entered = true;
-    if (entered && gc.occupied(xi, yi, zi)) return true;
+    if (entered && on_cell(xi, yi, zi)) return true;
   }
   return false;
+}
+
+// Pre-test + voxel coordinates shared by every use of the walk.  Returns false when the segment
+// misses the domain (add_line's early return).  `inside`: both endpoints at least 1e-6 of the box
+// size inside the domain, in which case segment_aabox_intersect is true by a margin far larger than
+// its rounding error and is not evaluated.
+__device__ __forceinline__ bool line_setup(const V3 &a, const V3 &b, const GridK &g, V3 &A, V3 &B, bool &inside, bool &bad) {
+#pragma clang fp contract(off)
+  const double mx = 1e-6 * (g.xmax - g.xmin), my = 1e-6 * (g.ymax - g.ymin), mz = 1e-6 * (g.zmax - g.zmin);
+  inside = a.x > g.xmin + mx && a.x < g.xmax - mx && b.x > g.xmin + mx && b.x < g.xmax - mx &&
+           a.y > g.ymin + my && a.y < g.ymax - my && b.y > g.ymin + my && b.y < g.ymax - my &&
+           a.z > g.zmin + mz && a.z < g.zmax - mz && b.z > g.zmin + mz && b.z < g.zmax - mz;
+  if (!inside) {
+    if (!segment_aabox_intersect(a, b, g)) return false;
+  }
+  A = V3{(a.x - g.xmin) * g.inv_dx, (a.y - g.ymin) * g.inv_dy, (a.z - g.zmin) * g.inv_dz};
+  B = V3{(b.x - g.xmin) * g.inv_dx, (b.y - g.ymin) * g.inv_dy, (b.z - g.zmin) * g.inv_dz};
+  const double lim = 5.0 * g.N;
+  if (!(fabs(A.x) < lim && fabs(A.y) < lim && fabs(A.z) < lim && fabs(B.x) < lim && fabs(B.y) < lim && fabs(B.z) < lim)) {
+    bad = true;
+    return false;
+  }
+  return true;
+}
+
+// Does add_line(a, b) set a cell that is occupied in the obstacle grid?
+//
+// Fast path: `near` is the obstacle grid dilated by 2 cells (Chebyshev).  Every cell add_line can
+// visit lies in [min(A,B)-1, max(A,B)+1] per axis (the walker moves from A's cell towards B's and
+// stops once any axis has passed B's index by one), i.e. within Chebyshev distance |B-A|_inf + 1 of
+// A's cell.  So when the end cells differ by at most one per axis and A's cell is free in `near`,
+// no visited cell can be occupied and the whole fp64 set-up of the walk is skipped.
+__device__ __forceinline__ bool line_hits(const V3 &a, const V3 &b, const GridK &g, GridCursor &gc, GridCursor &near,
+                                          bool &bad) {
+#pragma clang fp contract(off)
+  V3 A, B;
+  bool inside;
+  if (!line_setup(a, b, g, A, B, inside, bad)) return false;
+  if (inside && near.blocks) {
+    const int Axi = (int)A.x - (A.x < 0), Ayi = (int)A.y - (A.y < 0), Azi = (int)A.z - (A.z < 0);
+    const int Bxi = (int)B.x - (B.x < 0), Byi = (int)B.y - (B.y < 0), Bzi = (int)B.z - (B.z < 0);
+    const int ddx = Bxi - Axi, ddy = Byi - Ayi, ddz = Bzi - Azi;
+    if (ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1 && !near.occupied(Axi, Ayi, Azi)) return false;
+  }
+  return walk_cells(A, B, g, [&](int x, int y, int z) { return gc.occupied(x, y, z); });
 }
 
 // collision/collision_primitives.cpp:10-102 (closest_st_segment) + collision.hxx:102-108
@@ -465,6 +485,77 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
   const uint64_t bits = __ballot(valid && live);
   if (lane == 0 && i < n) valid_bits[i >> 6] = bits;
   if (flags && live) flags[i] = (uint8_t)fl;
+}
+
+// K5 `backbone_voxelize`: the robot's own voxel set (what voxelize_impl returns,
+// VoxelBackboneValidityChecker.h:49-57) as a sparse list of (block id, 64-bit mask) per configuration --
+// the form roadmap voxel caches are stored in (VoxelCachedLazyPRM.cpp:2816-2823).  One lane per
+// configuration; cells arrive mostly block by block, so the lane keeps the current block in registers
+// and merges it into its list (a column of ids/masks, [maxB][ld]) when the walk leaves the block.
+// counts[i] = number of distinct blocks, or -1 when the list overflowed maxB.
+__global__ __launch_bounds__(64) void backbone_voxelize(
+    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+    const int32_t *__restrict__ n_points, const uint64_t *__restrict__ shape_valid_bits, int64_t n, int64_t ld, int P,
+    GridK g, int maxB, uint32_t *__restrict__ ids, uint64_t *__restrict__ masks, int32_t *__restrict__ counts) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  if (!((shape_valid_bits[i >> 6] >> (i & 63)) & 1ull)) { counts[i] = 0; return; }
+  const int np = n_points ? n_points[i] : P;
+  int cnt = 0;
+  bool overflow = false, bad = false;
+  int cur_id = -1;
+  uint64_t cur_mask = 0;
+  auto flush = [&]() {
+    if (cur_id < 0) return;
+    for (int k = 0; k < cnt; k++)
+      if (ids[(int64_t)k * ld + i] == (uint32_t)cur_id) { masks[(int64_t)k * ld + i] |= cur_mask; return; }
+    if (cnt >= maxB) { overflow = true; return; }
+    ids[(int64_t)cnt * ld + i] = (uint32_t)cur_id;
+    masks[(int64_t)cnt * ld + i] = cur_mask;
+    cnt++;
+  };
+  auto set_cell = [&](int x, int y, int z) {
+    const int id = ((x >> 2) * g.Nb + (y >> 2)) * g.Nb + (z >> 2);
+    const uint64_t bit = 1ull << (((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
+    if (id != cur_id) { flush(); cur_id = id; cur_mask = 0; }
+    cur_mask |= bit;
+    return false;
+  };
+  V3 prev = {0, 0, 0};
+  for (int j = 0; j < np; j++) {
+    const int64_t o = (int64_t)j * ld + i;
+    const double x = px[o], y = py[o], z = pz[o];
+    V3 q;
+    if (g.rot_is_identity) { q = V3{x, y, z}; }
+    else {
+      q.x = g.inv_rot[0] * x + g.inv_rot[1] * y + g.inv_rot[2] * z;
+      q.y = g.inv_rot[3] * x + g.inv_rot[4] * y + g.inv_rot[5] * z;
+      q.z = g.inv_rot[6] * x + g.inv_rot[7] * y + g.inv_rot[8] * z;
+    }
+    if (j > 0) {
+      V3 A, B;
+      bool inside;
+      if (line_setup(prev, q, g, A, B, inside, bad)) walk_cells(A, B, g, set_cell);
+    }
+    prev = q;
+  }
+  flush();
+  counts[i] = (overflow || bad) ? -1 : cnt;
+}
+
+// CSR compaction of the per-lane lists: item i's entries go to [offsets[i], offsets[i] + counts[i]).
+__global__ __launch_bounds__(256) void compact_block_lists(
+    const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int32_t *__restrict__ counts,
+    const int64_t *__restrict__ offsets, int64_t n, int64_t ld, uint32_t *__restrict__ out_ids, uint64_t *__restrict__ out_masks) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int c = counts[i];
+  const int64_t o = offsets[i];
+  for (int k = 0; k < c; k++) {
+    out_ids[o + k] = ids[(int64_t)k * ld + i];
+    out_masks[o + k] = masks[(int64_t)k * ld + i];
+  }
 }
 
 // K4 `cached_blocks_vs_grid`: sparse cached voxel sets (CSR of (block id, mask)) vs the dense grid.

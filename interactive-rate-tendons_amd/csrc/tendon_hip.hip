@@ -72,6 +72,12 @@ struct tr_ctx {
   uint32_t n_blocks = 0;
   Workspace ws;
   int64_t max_chunk = 1 << 20;
+  // result of the last tr_voxelize_* call (host side) and its device scratch
+  std::vector<uint32_t> vox_ids;
+  std::vector<uint64_t> vox_masks;
+  uint32_t *d_vids = nullptr; uint64_t *d_vmasks = nullptr; int32_t *d_vcounts = nullptr; int64_t *d_voffsets = nullptr;
+  uint32_t *d_cids = nullptr; uint64_t *d_cmasks = nullptr; uint64_t *d_vbits = nullptr;
+  int64_t vox_cap = 0, vox_cnnz = 0;
   // instrumentation
   bool profiling = false;
   std::vector<EventPair> events[TR_PROFILE_SLOTS];
@@ -468,7 +474,8 @@ void tr_destroy(tr_ctx *c) {
   (void)hipDeviceSynchronize();
   for (auto &v : c->events) for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   Workspace &w = c->ws;
-  void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_grid, c->d_near, w.homeLi, w.np, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
+  void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_grid, c->d_near, w.homeLi, w.np, c->d_vids, c->d_vmasks, c->d_vcounts,
+                  c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
@@ -724,6 +731,117 @@ int tr_check_cached(tr_ctx *c, const uint32_t *ids, const uint64_t *masks, const
   if (d_off) (void)hipFree(d_off);
   if (d_bits) (void)hipFree(d_bits);
   return rc;
+}
+
+// ---- robot voxel sets -----------------------------------------------------------------------
+namespace {
+
+int vox_max_blocks(const tr_ctx *c) { return 2 * c->K.n_points + 16; }
+
+int ensure_vox_scratch(tr_ctx *c, int64_t cap) {
+  if (c->vox_cap >= cap) return TR_OK;
+  HIP_TRY(c, hipDeviceSynchronize());
+  const size_t mb = (size_t)vox_max_blocks(c);
+  int rc;
+  if ((rc = dev_alloc(c, &c->d_vids, mb * cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_vmasks, mb * cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_vcounts, (size_t)cap))) return rc;
+  if ((rc = dev_alloc(c, &c->d_voffsets, (size_t)cap + 1))) return rc;
+  if ((rc = dev_alloc(c, &c->d_vbits, (size_t)cap / 64 + 1))) return rc;
+  c->vox_cap = cap;
+  return TR_OK;
+}
+
+// Voxelise samples [0, m) of the workspace (points already there, leading dimension ld) whose bit
+// in d_bits is set; appends per-sample lists to (ids, masks) and writes counts (host).
+int voxelize_samples(tr_ctx *c, int64_t m, int64_t ld, const int32_t *d_np, const uint64_t *d_bits,
+                     std::vector<int32_t> &counts, std::vector<int64_t> &offs, std::vector<uint32_t> &ids,
+                     std::vector<uint64_t> &masks) {
+  Workspace &w = c->ws;
+  int rc;
+  if ((rc = ensure_vox_scratch(c, ld))) return rc;
+  const int mb = vox_max_blocks(c);
+  {
+    ProfScope ps(c, 3, nullptr);
+    hipLaunchKernelGGL(trk::backbone_voxelize, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, nullptr, w.px, w.py, w.pz, d_np,
+                       d_bits, m, ld, (int)c->K.n_points, c->G, mb, c->d_vids, c->d_vmasks, c->d_vcounts);
+    HIP_TRY(c, hipGetLastError());
+  }
+  counts.resize((size_t)m);
+  HIP_TRY(c, hipMemcpy(counts.data(), c->d_vcounts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+  offs.assign((size_t)m + 1, 0);
+  for (int64_t i = 0; i < m; i++) {
+    if (counts[(size_t)i] < 0) return fail(c, TR_ERR_RUNTIME, "voxel set of a configuration exceeds the block-list capacity or leaves the domain");
+    offs[(size_t)i + 1] = offs[(size_t)i] + counts[(size_t)i];
+  }
+  const int64_t nnz = offs[(size_t)m];
+  if (nnz > c->vox_cnnz) {
+    if (c->d_cids) (void)hipFree(c->d_cids);
+    if (c->d_cmasks) (void)hipFree(c->d_cmasks);
+    c->d_cids = nullptr; c->d_cmasks = nullptr;
+    c->vox_cnnz = nnz + nnz / 4 + 1024;
+    HIP_TRY(c, hipMalloc((void **)&c->d_cids, (size_t)c->vox_cnnz * sizeof(uint32_t)));
+    HIP_TRY(c, hipMalloc((void **)&c->d_cmasks, (size_t)c->vox_cnnz * sizeof(uint64_t)));
+  }
+  ids.resize((size_t)nnz); masks.resize((size_t)nnz);
+  if (nnz > 0) {
+    HIP_TRY(c, hipMemcpy(c->d_voffsets, offs.data(), (size_t)(m + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(trk::compact_block_lists, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nullptr, c->d_vids, c->d_vmasks,
+                       c->d_vcounts, c->d_voffsets, m, ld, c->d_cids, c->d_cmasks);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpy(ids.data(), c->d_cids, (size_t)nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(masks.data(), c->d_cmasks, (size_t)nnz * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  }
+  return TR_OK;
+}
+
+}  // namespace
+
+int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offsets, uint64_t *shape_valid_bits, double *tips) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n < 0 || (n > 0 && (!states || !offsets || !shape_valid_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  c->vox_ids.clear(); c->vox_masks.clear();
+  if (offsets) offsets[0] = 0;
+  if (n == 0) return TR_OK;
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int64_t chunk = std::min<int64_t>(c->max_chunk, 1 << 15);
+  int rc;
+  if ((rc = ensure_workspace(c, std::min(n, chunk)))) return rc;
+  if ((rc = ensure_staging(c, std::min(n, chunk)))) return rc;
+  Workspace &w = c->ws;
+  const int S = c->K.state_size;
+  const bool ret = c->K.enable_retraction;
+  std::vector<int32_t> counts; std::vector<int64_t> offs; std::vector<uint32_t> ids; std::vector<uint64_t> masks;
+  for (int64_t off = 0; off < n; off += chunk) {
+    const int64_t m = std::min(chunk, n - off);
+    HIP_TRY(c, hipMemcpy(w.states, states + off * S, (size_t)m * S * sizeof(double), hipMemcpyHostToDevice));
+    trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, tips ? w.tips : nullptr, w.conv, ret ? w.np : nullptr,
+                   ret ? w.homeLi : nullptr};
+    if ((rc = launch_fk(c, w.states, m, w.ld, out, nullptr))) return rc;
+    trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
+    if ((rc = launch_sweep(c, in, m, w.ld, 0, w.bits, nullptr, nullptr))) return rc;     // is_valid_shape only
+    if ((rc = voxelize_samples(c, m, w.ld, ret ? w.np : nullptr, w.bits, counts, offs, ids, masks))) return rc;
+    HIP_TRY(c, hipMemcpy(shape_valid_bits + off / 64, w.bits, (size_t)((m + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (tips) HIP_TRY(c, hipMemcpy(tips + 3 * off, w.tips, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost));
+    const int64_t base = (int64_t)c->vox_ids.size();
+    for (int64_t i = 0; i < m; i++) offsets[off + i + 1] = base + offs[(size_t)i + 1];
+    c->vox_ids.insert(c->vox_ids.end(), ids.begin(), ids.end());
+    c->vox_masks.insert(c->vox_masks.end(), masks.begin(), masks.end());
+  }
+  return TR_OK;
+}
+
+int tr_voxelize_fetch(tr_ctx *c, uint32_t *block_ids, uint64_t *masks, int64_t capacity) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  const int64_t nnz = (int64_t)c->vox_ids.size();
+  if (capacity < nnz) return fail(c, TR_ERR_INVALID_ARG, "capacity smaller than the stored block lists");
+  if (nnz > 0) {
+    if (!block_ids || !masks) return fail(c, TR_ERR_INVALID_ARG, "null output");
+    std::memcpy(block_ids, c->vox_ids.data(), (size_t)nnz * sizeof(uint32_t));
+    std::memcpy(masks, c->vox_masks.data(), (size_t)nnz * sizeof(uint64_t));
+  }
+  return TR_OK;
 }
 
 // ---- instrumentation -----------------------------------------------------------------------

@@ -161,6 +161,42 @@ class Engine:
             off.ctypes.data_as(C.POINTER(C.c_int64)), n, bits.ctypes.data_as(C.POINTER(C.c_uint64))))
         return unpack_bits(bits, n)
 
+    def _fetch_lists(self, nnz):
+        ids = np.empty(nnz, dtype=np.uint32)
+        masks = np.empty(nnz, dtype=np.uint64)
+        L.check(self._ctx, self.lib.tr_voxelize_fetch(self._ctx, ids.ctypes.data_as(C.POINTER(C.c_uint32)),
+                                                      masks.ctypes.data_as(C.POINTER(C.c_uint64)), nnz))
+        return ids, masks
+
+    def voxelize_batch(self, states):
+        """voxelizeVertex for a batch: CSR (offsets, block_ids, masks), shape validity, tips."""
+        st = self._states(states)
+        n = st.shape[0]
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        tips = np.empty((n, 3))
+        L.check(self._ctx, self.lib.tr_voxelize_batch(self._ctx, _dp(st), n, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                      bits.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(tips)))
+        ids, masks = self._fetch_lists(int(offsets[-1]))
+        return dict(offsets=offsets, block_ids=ids, masks=masks, shape_valid=unpack_bits(bits, n), tips=tips)
+
+    def voxelize_edges(self, a, b, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001):
+        """voxelizeEdge for a batch: swept-volume block lists of the fully valid edges."""
+        a, b = self._states(a), self._states(b)
+        if a.shape != b.shape:
+            raise L.InvalidArgument("start and end are different sizes")
+        n = a.shape[0]
+        sp = L.TrSpaceParams(min_tension_change, min_rotation_change, min_retraction_change)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        nfk = np.zeros(n, dtype=np.int32)
+        L.check(self._ctx, self.lib.tr_voxelize_edges(self._ctx, C.byref(sp), _dp(a), _dp(b), n,
+                                                      offsets.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                      bits.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                                      nfk.ctypes.data_as(C.POINTER(C.c_int32))))
+        ids, masks = self._fetch_lists(int(offsets[-1]))
+        return dict(offsets=offsets, block_ids=ids, masks=masks, fully_valid=unpack_bits(bits, n), n_fk=nfk)
+
     # ---- device-buffer calls (torch tensors on this engine's GPU) -------------------------------
     @staticmethod
     def _stream_ptr(stream):

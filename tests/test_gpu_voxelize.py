@@ -1,0 +1,91 @@
+"""GPU parity of the robot voxel sets used for roadmap caches (tr_voxelize_batch / tr_voxelize_edges):
+voxelizeVertex / voxelizeEdge of VoxelCachedLazyPRM.cpp:2803-2837,2879-2902."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _item(out, i):
+    a, b = out["offsets"][i], out["offsets"][i + 1]
+    o = np.argsort(out["block_ids"][a:b])
+    return out["block_ids"][a:b][o], out["masks"][a:b][o]
+
+
+def test_vertex_voxel_sets_bit_exact(irt, orc, helpers):
+    """Block lists == oracle add_piecewise_line of the SAME (GPU-computed) backbone points."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    for t in robot.tendons:
+        t.max_tension, t.max_length = 60.0, 0.02
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    rot = np.array([[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]])
+    env = irt.VoxelEnvironment()
+    env.inv_rotation = rot
+    chk = irt.VoxelBackboneValidityChecker(robot, env, vox)
+    st = W.random_states(robot, 1200, seed=71, tau_max=40.0)
+    out = chk.engine.voxelize_batch(st)
+    det = chk.is_valid_detail(st)
+    want_shape = (det["flags"] & 7) == 7
+    assert np.array_equal(out["shape_valid"], want_shape)
+    assert np.array_equal(out["tips"], det["tips"])
+    assert 0 < want_shape.sum() < len(st)
+    pts = robot.shape_batch(st)["p"]
+    ref = orc.Grid(256, vox.limits())
+    for i in range(len(st)):
+        ids, masks = _item(out, i)
+        if not want_shape[i]:
+            assert ids.size == 0
+            continue
+        g = ref.empty_copy()
+        g.add_piecewise_line(pts[i] @ rot.T)
+        wi, wm = g.export_blocks()
+        assert np.array_equal(ids, wi) and np.array_equal(masks, wm), i
+    # a cached set collides with the obstacles exactly when the state's voxel flag says so
+    hit = chk.engine.check_cached(out["block_ids"], out["masks"], out["offsets"])
+    assert np.array_equal(hit[want_shape], ((det["flags"] & 8) == 0)[want_shape])
+    assert not hit[~want_shape].any()
+
+
+def test_edge_swept_volumes_match_oracle(irt, orc, helpers):
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rng = np.random.default_rng(72)
+    a = W.random_states(robot, 300, seed=72, tau_max=15.0)
+    b = np.clip(a + rng.normal(size=a.shape) * 0.8, 0, 20)
+    out = chk.engine.voxelize_edges(a, b)
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    n_same = n_full = 0
+    for i in range(len(a)):
+        w = orc.check_motion(orb, og, a[i], b[i], want_swept=True)
+        assert out["fully_valid"][i] == w["is_fully_valid"]
+        ids, masks = _item(out, i)
+        if not w["is_fully_valid"]:
+            assert ids.size == 0
+            continue
+        n_full += 1
+        assert out["n_fk"][i] == w["n_fk"]
+        wi, wm = w["swept"].export_blocks()
+        if np.array_equal(ids, wi) and np.array_equal(masks, wm):
+            n_same += 1
+        else:   # GPU FK vs oracle FK points differ by ~1e-15 m: a point on a voxel face may flip one cell
+            d = {int(k): int(v) for k, v in zip(ids, masks)}
+            e = {int(k): int(v) for k, v in zip(wi, wm)}
+            diff = sum(bin(d.get(k, 0) ^ e.get(k, 0)).count("1") for k in set(d) | set(e))
+            assert diff <= 2
+    assert n_full > 50 and n_same >= n_full - 1
+    # cached edge sets vs obstacles == checkMotion verdict for the fully valid edges
+    hit = chk.engine.check_cached(out["block_ids"], out["masks"], out["offsets"])
+    verdict = irt.VoxelBackboneMotionValidator(chk).check_motion(a, b)
+    assert np.array_equal(verdict, out["fully_valid"] & ~hit)
+
+
+def test_voxelize_empty(irt):
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=7, n_spheres=4)
+    e = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+    out = e.voxelize_batch(np.zeros((0, 3)))
+    assert out["offsets"].tolist() == [0] and out["block_ids"].size == 0
