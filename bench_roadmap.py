@@ -1,0 +1,81 @@
+#!/usr/bin/env python3
+"""Secondary measurements for BASELINE configs 3 and 5 (not the driver's headline bench.py):
+PRM roadmap of N vertices + k-NN edges on one MI355X, voxel caches, cached re-validation.
+Prints one JSON object.  Host-buffer API (PCIe and host bookkeeping included).
+
+    python bench_roadmap.py --vertices 100000 --k 10
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--vertices", type=int, default=100000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--cache-items", type=int, default=200000)
+    args = ap.parse_args()
+    irt = importlib.import_module("interactive-rate-tendons_amd")
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
+    chk.engine.reserve(1 << 20)
+    rb.sample_valid_vertices(2048, batch=4096)                       # warm-up
+    states, tips = rb.sample_valid_vertices(args.vertices, batch=1 << 17)
+    edges = rb.knn_edges(states, args.k)
+    valid, nfk = rb.validate_edges(states, edges)
+    t = rb.timing
+    out = {
+        "config3": {
+            "robot": "4-tendon quadratic-routed (workloads.robot_config3), 256^3 grid, 64 spheres",
+            "vertices": args.vertices, "k": args.k, "edges": int(len(edges)),
+            "vertex_candidates": t["vertices"]["candidates"],
+            "valid_vertices_per_s": args.vertices / t["vertices"]["seconds"],
+            "vertex_checks_per_s": t["vertices"]["candidates"] / t["vertices"]["seconds"],
+            "knn_host_seconds": t["knn"]["seconds"],
+            "edges_per_s": len(edges) / t["edges"]["seconds"],
+            "edge_fk_samples_per_s": t["edges"]["fk_samples"] / t["edges"]["seconds"],
+            "edge_valid_fraction": float(valid.mean()),
+            "fk_samples_per_edge": {"mean": float(nfk.mean()), "p50": float(np.median(nfk)), "max": int(nfk.max())},
+        }
+    }
+    # config 5: caches for a slice of the roadmap, then re-validation against a perturbed environment
+    nv = min(args.cache_items, len(states))
+    ne = min(args.cache_items, len(edges))
+    vc = rb.vertex_caches(states[:nv])
+    ec = rb.edge_caches(states, edges[:ne])
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=72)
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        vh = rb.revalidate(vc, new_vox)
+    tv = (time.perf_counter() - t0) / reps
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        eh = rb.revalidate(ec, new_vox)
+    te = (time.perf_counter() - t0) / reps
+    out["config5"] = {
+        "vertex_cache_items": nv, "vertex_cache_blocks": int(vc["offsets"][-1]),
+        "vertex_caches_built_per_s": nv / rb.timing["vertex_caches"]["seconds"],
+        "edge_cache_items": ne, "edge_cache_blocks": int(ec["offsets"][-1]),
+        "edge_caches_built_per_s": ne / rb.timing["edge_caches"]["seconds"],
+        "revalidate_vertex_items_per_s_host_api": nv / tv, "revalidate_edge_items_per_s_host_api": ne / te,
+        "vertex_hit_fraction": float(vh.mean()), "edge_hit_fraction": float(eh.mean()),
+        "note": "host API: includes set_grid (2 MiB upload + dilation) and CSR upload every call",
+    }
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

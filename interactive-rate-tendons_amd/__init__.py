@@ -16,11 +16,12 @@ from .tendon import BackboneSpecs, TendonSpecs, TendonResult, TendonRobot
 from .collision import VoxelOctree
 from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelBackboneMotionValidator,
                               FunctionTimer)
-from . import workloads, distributed
+from . import workloads, distributed, roadmap
+from .roadmap import RoadmapBuilder
 
 __all__ = [
     "TendonHipError", "InvalidArgument", "OutOfRange", "DomainError", "LengthError", "HipError", "Unsupported",
     "build", "LIB_PATH", "Engine", "unpack_bits", "BackboneSpecs", "TendonSpecs", "TendonResult", "TendonRobot",
     "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelBackboneMotionValidator",
-    "FunctionTimer", "workloads", "distributed",
+    "FunctionTimer", "workloads", "distributed", "roadmap", "RoadmapBuilder",
 ]

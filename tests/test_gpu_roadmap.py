@@ -1,0 +1,82 @@
+"""Roadmap-level flows of BASELINE configs 3-5 at test scale: rejection-sampled vertices, k-NN edges,
+edge validation, voxel caches, re-validation after the environment changes, and the sharded vertex
+mask (single rank on the GPU; world_size 2 is covered with gloo in test_host.py)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _builder(irt, robot, vox, **kw):
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    return irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), **kw), chk
+
+
+def test_config3_roadmap_build_matches_oracle(irt, orc, helpers):
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    rb, chk = _builder(irt, robot, vox, seed=5)
+    N, k = 1500, 6
+    states, tips = rb.sample_valid_vertices(N, batch=4096)
+    assert states.shape == (N, 4) and chk.is_valid(states).all()
+    # the accepted set is the valid prefix of the candidate sequence, whatever the batch size
+    s2, _ = _builder(irt, robot, vox, seed=5)[0].sample_valid_vertices(N, batch=1000)
+    assert np.array_equal(states, s2)
+    orb, og = helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox)
+    cand = irt.distributed.candidate_states(robot, 5, 0, rb.timing["vertices"]["candidates"])
+    want_valid, want_tips, _ = orc.validate_batch(orb, og, cand, nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(cand[want_valid][:N], states) and np.abs(want_tips[want_valid][:N] - tips).max() <= 1e-9
+    edges = rb.knn_edges(states, k)
+    assert edges.shape[1] == 2 and (edges[:, 0] < edges[:, 1]).all() and len(edges) >= N * k // 2
+    valid, nfk = rb.validate_edges(states, edges)
+    sub = np.random.default_rng(0).choice(len(edges), 400, replace=False)
+    want, wn, _ = orc.check_motion_batch(orb, og, states[edges[sub, 0]], states[edges[sub, 1]], nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(valid[sub], want) and np.array_equal(nfk[sub][want], wn[want])
+    assert 0.3 < valid.mean() <= 1.0
+    print("config3 test scale:", rb.timing)
+
+
+def test_config5_cached_revalidation(irt, orc, helpers):
+    """Caches built in one environment, re-validated in a perturbed one: identical to validating from scratch."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    rb, chk = _builder(irt, robot, vox, seed=6)
+    states, _ = rb.sample_valid_vertices(800, batch=4096)
+    edges = rb.knn_edges(states, 4)
+    vc = rb.vertex_caches(states)
+    ec = rb.edge_caches(states, edges)
+    assert vc["shape_valid"].all()
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=72)        # 8 extra spheres
+    assert new_vox != vox
+    v_hit = rb.revalidate(vc, new_vox)
+    e_hit = rb.revalidate(ec, new_vox)
+    # from scratch in the new environment
+    chk2 = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), new_vox)
+    assert np.array_equal(~v_hit, chk2.is_valid(states))
+    e_valid = irt.VoxelBackboneMotionValidator(chk2).check_motion(states[edges[:, 0]], states[edges[:, 1]])
+    assert np.array_equal(ec["fully_valid"] & ~e_hit, e_valid)
+    assert v_hit.any() and e_hit.any() and not v_hit.all()
+
+
+def test_config4_sharded_mask_single_rank(irt, orc, helpers):
+    import torch
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+
+    def validate_local(states):
+        d = torch.from_numpy(states).cuda()
+        bits = torch.zeros((len(states) + 63) // 64, dtype=torch.int64, device="cuda")
+        chk.engine.validate_batch_dev(d, len(states), bits)
+        torch.cuda.synchronize()
+        return bits.cpu().numpy()
+
+    M = 5000
+    mask = irt.roadmap.gathered_vertex_mask(robot, validate_local, M, seed=3, tau_max=None, device="cuda")
+    cand = irt.distributed.candidate_states(robot, 3, 0, M)
+    want, _, _ = orc.validate_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), cand,
+                                    nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(mask, want)
