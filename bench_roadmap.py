@@ -65,7 +65,26 @@ def main():
     for _ in range(reps):
         eh = rb.revalidate(ec, new_vox)
     te = (time.perf_counter() - t0) / reps
+    import torch
+    dv, de = irt.roadmap.DeviceCaches(chk.engine, vc), irt.roadmap.DeviceCaches(chk.engine, ec)
+    assert np.array_equal(dv.revalidate(new_vox), vh) and np.array_equal(de.revalidate(), eh)
+    chk.engine.profile_begin()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        dv.revalidate(sync=False); de.revalidate(sync=False)
+    torch.cuda.synchronize()
+    t_dev = (time.perf_counter() - t0) / 20
+    k4 = chk.engine.profile_read()["cached_blocks_vs_grid"]
+    chk.engine.profile_end()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        chk.engine.set_grid(new_vox.Nx(), new_vox.limits(), new_vox.blocks)
+    t_grid = (time.perf_counter() - t0) / 5
     out["config5"] = {
+        "device_resident": {"items_per_s": (nv + ne) / t_dev, "k4_kernel_ms_avg": k4["total_ms"] / max(1, k4["launches"]),
+                            "k4_algorithmic_GBps": 12.0 * (int(vc["offsets"][-1]) + int(ec["offsets"][-1])) / 2
+                                                   / (k4["total_ms"] / max(1, k4["launches"]) * 1e-3) / 1e9,
+                            "set_grid_ms": 1e3 * t_grid},
         "vertex_cache_items": nv, "vertex_cache_blocks": int(vc["offsets"][-1]),
         "vertex_caches_built_per_s": nv / rb.timing["vertex_caches"]["seconds"],
         "edge_cache_items": ne, "edge_cache_blocks": int(ec["offsets"][-1]),

@@ -558,22 +558,70 @@ __global__ __launch_bounds__(256) void compact_block_lists(
   }
 }
 
-// K4 `cached_blocks_vs_grid`: sparse cached voxel sets (CSR of (block id, mask)) vs the dense grid.
-// One lane per item; items are short (tens of blocks).
-__global__ __launch_bounds__(256) void cached_blocks_vs_grid(
-    const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int64_t *__restrict__ offsets,
-    int64_t n_items, const uint64_t *__restrict__ grid, uint32_t n_blocks, uint64_t *__restrict__ hit_bits) {
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+// Obstacle grid dilated by 2 cells in the Chebyshev metric (a cell is set iff some occupied cell
+// lies within +-2 along every axis), same block / bit layout; feeds the fast path of line_hits.
+// One wave per block, lane = bit index (x*16 + y*4 + z); the 64 verdicts are packed with a ballot.
+__global__ __launch_bounds__(64) void dilate2_blocks(const uint64_t *__restrict__ grid, uint64_t *__restrict__ out, int Nb) {
+  const int b = blockIdx.x;
+  const int bz = b % Nb, by = (b / Nb) % Nb, bx = b / (Nb * Nb);
+  const int lane = threadIdx.x;
+  // quick reject: all 27 neighbouring blocks empty
+  bool nz = false;
+  if (lane < 27) {
+    const int qx = bx + lane / 9 - 1, qy = by + (lane / 3) % 3 - 1, qz = bz + lane % 3 - 1;
+    if (qx >= 0 && qx < Nb && qy >= 0 && qy < Nb && qz >= 0 && qz < Nb) nz = grid[((size_t)qx * Nb + qy) * Nb + qz] != 0;
+  }
+  if (!__any(nz)) { if (lane == 0) out[b] = 0; return; }
+  const int N = 4 * Nb;
+  const int X = 4 * bx + (lane >> 4), Y = 4 * by + ((lane >> 2) & 3), Z = 4 * bz + (lane & 3);
   bool hit = false;
-  if (i < n_items) {
-    const int64_t e = offsets[i + 1];
-    for (int64_t k = offsets[i]; k < e; k++) {
-      const uint32_t id = ids[k];
-      if (id < n_blocks && (grid[id] & masks[k])) { hit = true; break; }
+  for (int dx = -2; dx <= 2 && !hit; dx++) {
+    const int x = X + dx;
+    if (x < 0 || x >= N) continue;
+    for (int dy = -2; dy <= 2 && !hit; dy++) {
+      const int y = Y + dy;
+      if (y < 0 || y >= N) continue;
+      for (int dz = -2; dz <= 2; dz++) {
+        const int z = Z + dz;
+        if (z < 0 || z >= N) continue;
+        const uint64_t v = grid[((size_t)(x >> 2) * Nb + (y >> 2)) * Nb + (z >> 2)];
+        if ((v >> (((x & 3) << 4) | ((y & 3) << 2) | (z & 3))) & 1ull) { hit = true; break; }
+      }
     }
   }
-  const uint64_t bits = __ballot(hit);
-  if ((threadIdx.x & 63) == 0 && i < n_items) hit_bits[i >> 6] = bits;
+  const uint64_t m = __ballot(hit);
+  if (lane == 0) out[b] = m;
+}
+
+// K4 `cached_blocks_vs_grid`: sparse cached voxel sets (CSR of (block id, mask)) vs the dense grid:
+// `obstacles.collides(*cached_voxels)` of VoxelCachedLazyPRM.cpp:2397-2411 for every roadmap item.
+// HBM-streaming kernel: one WAVE per item, lanes read consecutive entries of the item (coalesced
+// 4 B + 8 B per lane), gather the obstacle block (2 MiB grid, L2 resident) and vote; a workgroup of
+// 16 waves covers the 64 items of one output word.
+__global__ __launch_bounds__(1024) void cached_blocks_vs_grid(
+    const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int64_t *__restrict__ offsets,
+    int64_t n_items, const uint64_t *__restrict__ grid, uint32_t n_blocks, uint64_t *__restrict__ hit_bits) {
+  __shared__ unsigned long long word;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) word = 0ull;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * 64;
+#pragma unroll
+  for (int it = 0; it < 4; it++) {
+    const int slot = it * 16 + wave;
+    const int64_t item = base + slot;
+    if (item < n_items) {
+      const int64_t b = offsets[item], e = offsets[item + 1];
+      bool hit = false;
+      for (int64_t k = b + lane; k < e && !hit; k += 64) {
+        const uint32_t id = ids[k];
+        hit = id < n_blocks && (grid[id] & masks[k]) != 0;
+      }
+      if (__any(hit) && lane == 0) atomicOr(&word, 1ull << slot);
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) hit_bits[blockIdx.x] = word;
 }
 
 }  // namespace trk

@@ -186,43 +186,6 @@ void home_lengths(const tr_ctx *c, const std::vector<double> &t, double s_start,
 
 int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
-// Obstacle grid dilated by 2 cells in the Chebyshev metric (a cell is set iff some occupied cell
-// lies within +-2 along every axis), same block / bit layout.  Used only to skip voxel walks that
-// provably cannot touch an obstacle (sweep_kernel.hpp, line_hits); computed once per tr_set_grid.
-std::vector<uint64_t> dilate2(const uint64_t *blocks, int N) {
-  const int Nb = N / 4;
-  const size_t NN = (size_t)N * N * N;
-  std::vector<uint8_t> a(NN, 0), b(NN, 0);
-  for (int bx = 0; bx < Nb; bx++) for (int by = 0; by < Nb; by++) for (int bz = 0; bz < Nb; bz++) {
-    const uint64_t v = blocks[((size_t)bx * Nb + by) * Nb + bz];
-    if (!v) continue;
-    for (int bit = 0; bit < 64; bit++) if (v >> bit & 1) {
-      const int x = 4 * bx + (bit >> 4), y = 4 * by + ((bit >> 2) & 3), z = 4 * bz + (bit & 3);
-      a[((size_t)x * N + y) * N + z] = 1;
-    }
-  }
-  auto pass = [N](const std::vector<uint8_t> &src, std::vector<uint8_t> &dst, size_t stride, size_t so1, size_t so2) {
-    // dilate along the axis with the given stride; so1, so2 are the strides of the other two axes
-    for (int u = 0; u < N; u++) for (int v = 0; v < N; v++) {
-      const size_t base = u * so1 + v * so2;
-      for (int w = 0; w < N; w++) {
-        uint8_t m = 0;
-        for (int d = -2; d <= 2; d++) { const int q = w + d; if (q >= 0 && q < N) m |= src[base + q * stride]; }
-        dst[base + w * stride] = m;
-      }
-    }
-  };
-  const size_t sx = (size_t)N * N, sy = (size_t)N, sz = 1;
-  pass(a, b, sz, sx, sy);
-  pass(b, a, sy, sx, sz);
-  pass(a, b, sx, sy, sz);
-  std::vector<uint64_t> out((size_t)Nb * Nb * Nb, 0);
-  for (int x = 0; x < N; x++) for (int y = 0; y < N; y++) for (int z = 0; z < N; z++)
-    if (b[((size_t)x * N + y) * N + z])
-      out[((size_t)(x >> 2) * Nb + (y >> 2)) * Nb + (z >> 2)] |= (uint64_t)1 << (((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
-  return out;
-}
-
 template <typename T>
 int dev_alloc(tr_ctx *ctx, T **p, size_t count) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -526,10 +489,9 @@ int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *bloc
     c->n_blocks = (uint32_t)nb;
   }
   HIP_TRY(c, hipMemcpy(c->d_grid, blocks, nb * sizeof(uint64_t), hipMemcpyHostToDevice));
-  {
-    std::vector<uint64_t> near = dilate2(blocks, (int)N);
-    HIP_TRY(c, hipMemcpy(c->d_near, near.data(), nb * sizeof(uint64_t), hipMemcpyHostToDevice));
-  }
+  hipLaunchKernelGGL(trk::dilate2_blocks, dim3((unsigned)nb), dim3(64), 0, nullptr, c->d_grid, c->d_near, g.Nb);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipDeviceSynchronize());
   c->G = g;
   c->has_grid = true;
   return TR_OK;
@@ -692,8 +654,8 @@ int tr_check_cached_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_mask
   if (!d_ids || !d_masks || !d_offsets || !d_hit_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(c, 2, s);
-  const unsigned grid = (unsigned)((n_items + 255) / 256);
-  hipLaunchKernelGGL(trk::cached_blocks_vs_grid, dim3(grid), dim3(256), 0, s, d_ids, d_masks, d_offsets, n_items,
+  const unsigned grid = (unsigned)((n_items + 63) / 64);
+  hipLaunchKernelGGL(trk::cached_blocks_vs_grid, dim3(grid), dim3(1024), 0, s, d_ids, d_masks, d_offsets, n_items,
                      c->d_grid, c->n_blocks, d_hit_bits);
   HIP_TRY(c, hipGetLastError());
   return TR_OK;

@@ -102,6 +102,33 @@ class RoadmapBuilder:
         return hit
 
 
+class DeviceCaches:
+    """Roadmap voxel caches resident in HBM (CSR of block ids / masks): uploaded once, re-validated
+    with one K4 launch each time the obstacle grid changes -- the interactive loop of BASELINE config 5."""
+
+    def __init__(self, engine, caches):
+        import torch
+        self.engine = engine
+        dev = "cuda:%d" % engine.device
+        self.n = len(caches["offsets"]) - 1
+        self.ids = torch.from_numpy(caches["block_ids"].view(np.int32)).to(dev)
+        self.masks = torch.from_numpy(caches["masks"].view(np.int64)).to(dev)
+        self.offsets = torch.from_numpy(np.ascontiguousarray(caches["offsets"], dtype=np.int64)).to(dev)
+        self.bits = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=dev)
+
+    def revalidate(self, new_obstacles=None, env=None, sync=True):
+        """hit mask (bool[n]) of every cached set against the current (or a new) obstacle grid."""
+        import torch
+        if new_obstacles is not None:
+            self.engine.set_grid(new_obstacles.Nx(), new_obstacles.limits(), new_obstacles.blocks,
+                                 None if env is None else env.inv_rotation)
+        self.engine.check_cached_dev(self.ids, self.masks, self.offsets, self.n, self.bits)
+        if not sync:
+            return None
+        torch.cuda.synchronize()
+        return unpack_bits(self.bits.cpu().numpy().view(np.uint64), self.n)
+
+
 def gathered_vertex_mask(robot, validate_bits_dev, M, seed, tau_max, device):
     """BASELINE config 4: validate M candidate vertices sharded over the ranks of the default process
     group and all-gather the validity bitmask (distributed.ShardedVertexValidator with the GPU engine
