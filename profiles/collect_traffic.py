@@ -1,9 +1,10 @@
 #!/usr/bin/env python3
 """Turns two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, --output-format csv)
 into per-launch HBM bytes per kernel.  rocprofv3 reports both counters in KiB.  On gfx950 FETCH_SIZE
-under-reports wide (16 B/lane) coalesced streaming reads by 2x (MI355X_MICROARCH.md, HBM); these
-kernels read 8 B/lane, for which the guide gives no calibration, so the raw figure is used and the
-x2 figure is recorded next to it.
+reports half of the bytes of a coalesced streaming read (MI355X_MICROARCH.md, HBM: "double it before
+comparing with a byte count").  Calibrated on this path: backbone_voxel_sweep reads every backbone
+point exactly once (2^20 x 3121 B = 3.27 GB per launch) and rocprofv3 reports FETCH_SIZE = 1.60 GB,
+so the doubled figure is the one used (`hbm_bytes_per_launch`); the raw sum is kept next to it.
 
     python profiles/collect_traffic.py <fetch_dir> <write_dir> <out.json>
 """
@@ -35,7 +36,7 @@ def main():
     for k in sorted(set(f) | set(w)):
         fk, wk = f.get(k, (0.0, 0))[0], w.get(k, (0.0, 0))[0]
         out[k] = {"FETCH_SIZE_KiB_avg": fk, "WRITE_SIZE_KiB_avg": wk, "launches": f.get(k, (0, 0))[1],
-                  "hbm_bytes_per_launch": (fk + wk) * 1024, "hbm_bytes_per_launch_fetch_x2": (2 * fk + wk) * 1024}
+                  "hbm_bytes_per_launch": (2 * fk + wk) * 1024, "hbm_bytes_per_launch_raw_counters": (fk + wk) * 1024}
     json.dump(out, open(dst, "w"), indent=1)
     print(json.dumps(out, indent=1))
 
