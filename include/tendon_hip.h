@@ -196,6 +196,18 @@ int tr_voxelize_edges(tr_ctx *ctx, const tr_space_params *sp, const double *a, c
 /* Copy the block lists of the last tr_voxelize_* call; capacity must be >= its offsets[n]. */
 int tr_voxelize_fetch(tr_ctx *ctx, uint32_t *block_ids, uint64_t *masks, int64_t capacity);
 
+/* ---- nearest neighbours in state space ---------------------------- */
+
+/* For every state its k nearest among the same n states in the reference's state-space metric
+ * (CompoundStateSpace::distance with the subspace weights of motion-planning/Problem.cpp:112-152):
+ * the neighbour lists connectionStrategy_(v) produces in createRoadmap phase 3
+ * (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502; KBoundedStrategy :1339 / KStarStrategy :1352).
+ * Like nearestK on a structure that already contains v, row i starts with i itself at distance 0.
+ * Entries farther than max_distance (KBoundedStrategy's bound; pass INFINITY for none) are -1 / inf.
+ * idx, dist: n x k row-major, ascending distance.  Exact (brute force). */
+int tr_knn(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_distance,
+           int32_t *idx, double *dist);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 
 /* Time the last `which` kernel launches with HIP events on the stream they ran on.

@@ -26,7 +26,7 @@ ABI_SYMBOLS = (
     "tr_create", "tr_destroy", "tr_last_error", "tr_state_size", "tr_num_points", "tr_device",
     "tr_home_lengths", "tr_set_grid", "tr_reserve", "tr_fk_batch", "tr_fk_batch_dev",
     "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges",
-    "tr_check_cached", "tr_check_cached_dev", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
+    "tr_check_cached", "tr_check_cached_dev", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_knn", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug",
 )
 
@@ -147,6 +147,7 @@ def lib():
     L.tr_voxelize_batch.argtypes = [vp, dp, i64, P(i64), P(C.c_uint64), dp]
     L.tr_voxelize_edges.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(i64), P(C.c_uint64), P(C.c_int32)]
     L.tr_voxelize_fetch.argtypes = [vp, P(C.c_uint32), P(C.c_uint64), i64]
+    L.tr_knn.argtypes = [vp, dp, i64, C.c_int32, C.c_double, P(C.c_int32), dp]
     L.tr_profile_begin.argtypes = [vp]
     L.tr_profile_read.argtypes = [vp, P(i64), dp]
     L.tr_profile_end.argtypes = [vp]

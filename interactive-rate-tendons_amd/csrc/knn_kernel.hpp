@@ -1,0 +1,82 @@
+// knn_kernel.hpp -- K6 `knn_bruteforce`: exact k nearest neighbours of every roadmap vertex among all
+// vertices, in the reference's state-space metric -- what connectionStrategy_(v) (KBoundedStrategy /
+// KStarStrategy over the GNAT nn_, motion-planning/VoxelCachedLazyPRM.cpp:1339,1352,1491-1502) returns
+// for each v.  Metric = OMPL CompoundStateSpace::distance as wired by Problem.cpp:101-163:
+//   |d tau|_2  +  (extent / 4 pi) * arc(d theta)  +  (2 extent / L) * |d s_start|.
+// One lane per query vertex; the candidate index is wave-uniform, so candidates arrive through scalar
+// loads and feed the fp64 FMAs as SGPR operands; each lane keeps its k best in an LDS column (sorted
+// insertion; insertions become rare once the list has warmed up).  O(n^2) by design: at roadmap sizes
+// (1e5 - 1e6 vertices, <= 10 dimensions) the exact brute force is milliseconds to a second on this
+// chip and needs no tree build.  Like nearestK on a structure that already holds v, the result
+// includes v itself (distance 0), which connectVertices then skips (:2848).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+
+namespace trk {
+
+struct KnnMetric {
+  int32_t n_tension, has_rot, has_ret, S;
+  double w_rot, w_ret;
+};
+
+constexpr int KNN_SMAX = TRK_MAX_TENDONS + 2;
+
+__global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ states, int64_t n, KnnMetric m, int k,
+                                                     double max_dist, int32_t *__restrict__ out_idx,
+                                                     double *__restrict__ out_dist) {
+#pragma clang fp contract(off)
+  extern __shared__ unsigned char knn_lds[];
+  double *bd = reinterpret_cast<double *>(knn_lds) + threadIdx.x;               // [k][64]
+  int32_t *bi = reinterpret_cast<int32_t *>(knn_lds + (size_t)k * 64 * 8) + threadIdx.x;
+  const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const bool live = q < n;
+  const int64_t qc = live ? q : n - 1;
+  const int S = m.S, NT = m.n_tension;
+  double x[KNN_SMAX];
+#pragma unroll
+  for (int d = 0; d < KNN_SMAX; d++) x[d] = d < S ? states[qc * S + d] : 0.0;
+  for (int p = 0; p < k; p++) { bd[p * 64] = 1.0 / 0.0; bi[p * 64] = -1; }
+  double worst = 1.0 / 0.0;
+  const bool plain = !m.has_rot && !m.has_ret;      // tension only: order by squared distance, sqrt at the end
+  for (int64_t j = 0; j < n; j++) {
+    const double *__restrict__ c = states + j * S;  // wave-uniform
+    double s2 = 0.0;
+#pragma unroll
+    for (int d = 0; d < TRK_MAX_TENDONS; d++)
+      if (d < NT) { const double t = x[d] - c[d]; s2 += t * t; }
+    double dist = s2;
+    if (!plain) {
+      dist = sqrt(s2);
+      int col = NT;
+      if (m.has_rot) {                              // SO2StateSpace::distance
+        double a = fabs(x[NT] - c[NT]);
+        a = (a > 3.14159265358979323846) ? 2.0 * 3.14159265358979323846 - a : a;
+        dist += m.w_rot * a;
+        col++;
+      }
+      if (m.has_ret) {
+        const double xs = m.has_rot ? x[NT + 1] : x[NT];
+        const double t = xs - c[col];
+        dist += m.w_ret * sqrt(t * t);
+      }
+    }
+    if (dist < worst) {                             // strict: on exact ties the lower index stays
+      int p = k - 1;
+      while (p > 0 && bd[(p - 1) * 64] > dist) { bd[p * 64] = bd[(p - 1) * 64]; bi[p * 64] = bi[(p - 1) * 64]; p--; }
+      bd[p * 64] = dist; bi[p * 64] = (int32_t)j;
+      worst = bd[(k - 1) * 64];
+    }
+  }
+  if (live) {
+    for (int p = 0; p < k; p++) {
+      double d = bd[p * 64];
+      if (plain) d = sqrt(d);
+      const bool ok = bi[p * 64] >= 0 && !(d > max_dist);
+      out_idx[q * k + p] = ok ? bi[p * 64] : -1;
+      out_dist[q * k + p] = ok ? d : 1.0 / 0.0;
+    }
+  }
+}
+
+}  // namespace trk

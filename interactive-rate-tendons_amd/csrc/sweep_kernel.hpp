@@ -21,6 +21,10 @@
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
 
+#ifndef TRK_K2_PF
+#define TRK_K2_PF 4      // points prefetched ahead per lane in backbone_voxel_sweep (A/B-tunable)
+#endif
+
 namespace trk {
 
 struct V3 { double x, y, z; };
@@ -367,7 +371,7 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
     // The loads of point j+PF are issued before point j is processed (register ring, statically
     // indexed by unrolling): the walk below is a long dependent chain, and without the prefetch each
     // iteration exposes a full HBM round trip (r01: 49 % of K2's wave cycles were s_waitcnt).
-    constexpr int PF = 4;
+    constexpr int PF = TRK_K2_PF;
     V3 ring[PF];
 #pragma unroll
     for (int u = 0; u < PF; u++) {

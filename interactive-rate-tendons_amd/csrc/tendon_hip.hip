@@ -16,6 +16,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -27,6 +28,7 @@
 #include "fk_retract_kernel.hpp"
 #include "sweep_kernel.hpp"
 #include "edge_kernel.hpp"
+#include "knn_kernel.hpp"
 
 namespace {
 
@@ -72,6 +74,7 @@ struct tr_ctx {
   uint32_t n_blocks = 0;
   Workspace ws;
   int64_t max_chunk = 1 << 20;
+  double ch_scale = 2.0;          // milestone spacing of K2 in robot radii (env TENDON_HIP_CH_SCALE, tuning only)
   // result of the last tr_voxelize_* call (host side) and its device scratch
   std::vector<uint32_t> vox_ids;
   std::vector<uint64_t> vox_masks;
@@ -315,7 +318,7 @@ int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int
   // milestone spacing for the LDS self-collision proof: about one robot radius of arc per chunk,
   // coarser if needed to keep the per-wave LDS image (4 * NM * 64 floats) within 48 KiB
   const int P = ctx->K.n_points;
-  int CH = (int)std::lround(ctx->K.radius / ctx->K.dL);
+  int CH = (int)std::lround(ctx->ch_scale * ctx->K.radius / ctx->K.dL);
   if (CH < 1) CH = 1;
   while ((P - 1 + CH - 1) / CH + 1 > 48) CH++;
   const int NM = (P - 1 + CH - 1) / CH + 1;
@@ -355,6 +358,7 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (device < 0 || device >= ndev) return fail(nullptr, TR_ERR_INVALID_ARG, "bad device ordinal");
   tr_ctx *c = new tr_ctx();
   c->device = device;
+  if (const char *e = std::getenv("TENDON_HIP_CH_SCALE")) { const double v = std::atof(e); if (v > 0.05 && v < 50) c->ch_scale = v; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, TR_ERR_HIP, "hipSetDevice failed"); }
 
   RobotK &K = c->K;
@@ -804,6 +808,41 @@ int tr_voxelize_fetch(tr_ctx *c, uint32_t *block_ids, uint64_t *masks, int64_t c
     std::memcpy(masks, c->vox_masks.data(), (size_t)nnz * sizeof(uint64_t));
   }
   return TR_OK;
+}
+
+// ---- nearest neighbours ---------------------------------------------------------------------
+int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n < 0 || k < 1 || (n > 0 && (!states || !idx || !dist))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  if (n == 0) return TR_OK;
+  if ((size_t)k * 64 * 12 > 60 * 1024) return fail(c, TR_ERR_INVALID_ARG, "k too large (at most 80)");
+  if (n > (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const int S = c->K.state_size, N = c->K.n_tendons;
+  double ext2 = 0;
+  for (int i = 0; i < N; i++) ext2 += c->max_tension[i] * c->max_tension[i];
+  const double ext = std::sqrt(ext2);                         // RealVectorStateSpace::getMaximumExtent
+  trk::KnnMetric m{N, c->K.enable_rotation, c->K.enable_retraction, S, ext / (4.0 * M_PI), 2.0 * ext / c->K.L};
+  double *d_s = nullptr, *d_d = nullptr; int32_t *d_i = nullptr;
+  int rc = TR_OK;
+  do {
+    if (hipMalloc((void **)&d_s, (size_t)n * S * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_d, (size_t)n * k * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_i, (size_t)n * k * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
+    {
+      ProfScope ps(c, 3, nullptr);
+      hipLaunchKernelGGL(trk::knn_bruteforce, dim3((unsigned)((n + 63) / 64)), dim3(64), (size_t)k * 64 * 12, nullptr, d_s, n, m, (int)k,
+                         max_distance, d_i, d_d);
+    }
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, TR_ERR_HIP, "knn launch failed"); break; }
+    if (hipMemcpy(idx, d_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(dist, d_d, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+  } while (0);
+  if (d_s) (void)hipFree(d_s);
+  if (d_d) (void)hipFree(d_d);
+  if (d_i) (void)hipFree(d_i);
+  return rc;
 }
 
 // ---- instrumentation -----------------------------------------------------------------------

@@ -161,6 +161,16 @@ class Engine:
             off.ctypes.data_as(C.POINTER(C.c_int64)), n, bits.ctypes.data_as(C.POINTER(C.c_uint64))))
         return unpack_bits(bits, n)
 
+    def knn(self, states, k, max_distance=np.inf):
+        """k nearest (self included, as OMPL's nearestK on a populated structure) in the state-space metric."""
+        st = self._states(states)
+        n = st.shape[0]
+        idx = np.empty((n, k), dtype=np.int32)
+        dist = np.empty((n, k))
+        L.check(self._ctx, self.lib.tr_knn(self._ctx, _dp(st), n, int(k), float(max_distance),
+                                           idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dist)))
+        return idx, dist
+
     def _fetch_lists(self, nnz):
         ids = np.empty(nnz, dtype=np.uint32)
         masks = np.empty(nnz, dtype=np.uint64)

@@ -55,6 +55,21 @@ class RoadmapBuilder:
             w.append(2 * ext / self.robot.specs.L)
         return np.array(w)
 
+    def knn_edges_gpu(self, states, k, max_distance=np.inf):
+        """connectionStrategy_(v) for every vertex on the GPU (tr_knn; the reference's metric incl.
+        rotation / retraction weights), then the undirected edge set the reference's
+        `if (!getEdge(v, n)) connectVertices(v, n)` loop builds (:1491-1502): k counts v itself."""
+        t0 = time.perf_counter()
+        idx, dist = self.engine.knn(states, k, max_distance)
+        src = np.repeat(np.arange(len(states), dtype=np.int64), k)
+        dst = idx.reshape(-1).astype(np.int64)
+        keep = (dst >= 0) & (dst != src)
+        lo, hi = np.minimum(src[keep], dst[keep]), np.maximum(src[keep], dst[keep])
+        key = np.unique(lo * len(states) + hi)
+        e = np.stack([key // len(states), key % len(states)], 1)
+        self.timing["knn_gpu"] = dict(seconds=time.perf_counter() - t0, edges=len(e))
+        return e
+
     def knn_edges(self, states, k):
         """Undirected k-NN edge list (i < j).  Distances are the compound-space sums of per-subspace
         norms; for tension-only robots that is the Euclidean norm, which cKDTree handles exactly."""

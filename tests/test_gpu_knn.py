@@ -1,0 +1,63 @@
+"""GPU k-nearest-neighbours in the reference's state-space metric (tr_knn) against brute-force numpy
+with the oracle's compound distance, and the edge set against the host cKDTree path."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle_dist_matrix(orc, orb, st):
+    n = len(st)
+    D = np.empty((n, n))
+    f = orb.lib.orc_state_distance
+    for i in range(n):
+        for j in range(n):
+            D[i, j] = f(C.byref(orb.c), orc._dp(st[i]), orc._dp(st[j]))
+    return D
+
+
+@pytest.mark.parametrize("rot,ret", [(False, False), (True, False), (True, True)])
+def test_knn_matches_oracle_metric(irt, orc, helpers, rot, ret):
+    W = irt.workloads
+    robot = W.robot_config2()
+    robot.enable_rotation, robot.enable_retraction = rot, ret
+    st = W.random_states(robot, 300, seed=81)
+    idx, dist = robot.engine().knn(st, 9)
+    D = _oracle_dist_matrix(orc, helpers.oracle_robot(orc, robot), st)
+    want = np.argsort(D, axis=1, kind="stable")[:, :9]
+    assert np.array_equal(idx[:, 0], np.arange(300)) and (dist[:, 0] == 0).all()     # self first
+    assert np.array_equal(idx, want)
+    assert np.abs(dist - np.take_along_axis(D, want, 1)).max() <= 1e-12
+    assert (np.diff(dist, axis=1) >= 0).all()
+    # bounded strategy: entries beyond max_distance are dropped
+    md = float(np.median(dist[:, 4]))
+    idx2, dist2 = robot.engine().knn(st, 9, max_distance=md)
+    assert np.array_equal(idx2 >= 0, dist <= md) and np.array_equal(idx2[idx2 >= 0], idx[dist <= md])
+
+
+def test_knn_edges_equal_host_kdtree(irt):
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=16)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=2)
+    st = W.random_states(robot, 20000, seed=82)
+    t0 = time.perf_counter(); e_gpu = rb.knn_edges_gpu(st, 11); t1 = time.perf_counter()
+    e_cpu = rb.knn_edges(st, 10)                       # k counts the vertex itself on the GPU path
+    assert np.array_equal(e_gpu, e_cpu)
+    print("knn 20k x 4: gpu %.3f s (incl. PCIe + edge dedup), host cKDTree %.3f s" % (t1 - t0, rb.timing["knn"]["seconds"]))
+
+
+def test_knn_errors(irt):
+    e = irt.workloads.robot_config2().engine()
+    with pytest.raises(irt.InvalidArgument):
+        e.knn(np.zeros((10, 3)), 0)
+    with pytest.raises(irt.InvalidArgument):
+        e.knn(np.zeros((10, 3)), 500)
+    idx, dist = e.knn(np.zeros((0, 3)), 4)
+    assert idx.shape == (0, 4)
+    idx, dist = e.knn(np.array([[1.0, 2.0, 3.0], [1.0, 2.0, 4.0]]), 4)     # fewer states than k
+    assert idx.tolist() == [[0, 1, -1, -1], [1, 0, -1, -1]] and np.isinf(dist[:, 2:]).all()
