@@ -74,6 +74,7 @@ struct tr_ctx {
   uint32_t n_blocks = 0;
   Workspace ws;
   int64_t max_chunk = 1 << 20;
+  int64_t edge_pool_max = 1 << 22; // samples held at once by tr_validate_edges / tr_voxelize_edges
   double ch_scale = 2.0;          // milestone spacing of K2 in robot radii (env TENDON_HIP_CH_SCALE, tuning only)
   // result of the last tr_voxelize_* call (host side) and its device scratch
   std::vector<uint32_t> vox_ids;
@@ -548,33 +549,34 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
     trk::FkOut out{w.px, w.py, w.pz, d_R, w.L, w.Li, nullptr, w.conv, w.npts, nullptr};
     if ((rc = launch_fk(c, w.states, m, ld, out, nullptr))) { if (d_R) (void)hipFree(d_R); return rc; }
     HIP_TRY(c, hipDeviceSynchronize());
+    // device planes are [P][ld]; only the first m columns are copied (2-D copies, host pitch m)
     if (p) {
-      hx.resize((size_t)P * ld); hy.resize((size_t)P * ld); hz.resize((size_t)P * ld);
-      HIP_TRY(c, hipMemcpy(hx.data(), w.px, hx.size() * sizeof(double), hipMemcpyDeviceToHost));
-      HIP_TRY(c, hipMemcpy(hy.data(), w.py, hy.size() * sizeof(double), hipMemcpyDeviceToHost));
-      HIP_TRY(c, hipMemcpy(hz.data(), w.pz, hz.size() * sizeof(double), hipMemcpyDeviceToHost));
+      hx.resize((size_t)P * m); hy.resize((size_t)P * m); hz.resize((size_t)P * m);
+      HIP_TRY(c, hipMemcpy2D(hx.data(), (size_t)m * 8, w.px, (size_t)ld * 8, (size_t)m * 8, (size_t)P, hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy2D(hy.data(), (size_t)m * 8, w.py, (size_t)ld * 8, (size_t)m * 8, (size_t)P, hipMemcpyDeviceToHost));
+      HIP_TRY(c, hipMemcpy2D(hz.data(), (size_t)m * 8, w.pz, (size_t)ld * 8, (size_t)m * 8, (size_t)P, hipMemcpyDeviceToHost));
       hn.resize((size_t)m);
       HIP_TRY(c, hipMemcpy(hn.data(), w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < m; i++)
         for (int j = 0; j < P; j++) {
           double *o = p + ((size_t)(off + i) * P + j) * 3;
-          if (j < hn[(size_t)i]) { o[0] = hx[(size_t)j * ld + i]; o[1] = hy[(size_t)j * ld + i]; o[2] = hz[(size_t)j * ld + i]; }
+          if (j < hn[(size_t)i]) { o[0] = hx[(size_t)j * m + i]; o[1] = hy[(size_t)j * m + i]; o[2] = hz[(size_t)j * m + i]; }
           else o[0] = o[1] = o[2] = std::numeric_limits<double>::quiet_NaN();
         }
     }
     if (R) {
-      hR.resize((size_t)9 * P * ld);
-      HIP_TRY(c, hipMemcpy(hR.data(), d_R, hR.size() * sizeof(double), hipMemcpyDeviceToHost));
+      hR.resize((size_t)9 * P * m);
+      HIP_TRY(c, hipMemcpy2D(hR.data(), (size_t)m * 8, d_R, (size_t)ld * 8, (size_t)m * 8, (size_t)9 * P, hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < m; i++)
         for (int j = 0; j < P; j++)
           for (int q = 0; q < 9; q++)
-            R[((size_t)(off + i) * P + j) * 9 + q] = hR[((size_t)q * P + j) * ld + i];
+            R[((size_t)(off + i) * P + j) * 9 + q] = hR[((size_t)q * P + j) * m + i];
     }
     if (L) HIP_TRY(c, hipMemcpy(L + off, w.L, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
     if (L_i) {
-      hLi.resize((size_t)N * ld);
-      HIP_TRY(c, hipMemcpy(hLi.data(), w.Li, hLi.size() * sizeof(double), hipMemcpyDeviceToHost));
-      for (int64_t i = 0; i < m; i++) for (int j = 0; j < N; j++) L_i[(size_t)(off + i) * N + j] = hLi[(size_t)j * ld + i];
+      hLi.resize((size_t)N * m);
+      HIP_TRY(c, hipMemcpy2D(hLi.data(), (size_t)m * 8, w.Li, (size_t)ld * 8, (size_t)m * 8, (size_t)N, hipMemcpyDeviceToHost));
+      for (int64_t i = 0; i < m; i++) for (int j = 0; j < N; j++) L_i[(size_t)(off + i) * N + j] = hLi[(size_t)j * m + i];
     }
     if (converged) HIP_TRY(c, hipMemcpy(converged + off, w.conv, (size_t)m, hipMemcpyDeviceToHost));
     if (n_points) HIP_TRY(c, hipMemcpy(n_points + off, w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
