@@ -1,0 +1,120 @@
+"""Properties at BASELINE's full size (2^20 configurations, config 2) that do not need the oracle to
+run for minutes: determinism, chunking invariance, permutation equivariance, rotation equivariance of
+FK, zero-tension known answer, agreement of the three routes to a voxel verdict, plus an oracle check
+on a random sample of the big batch."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+N = 1 << 20
+
+
+@pytest.fixture(scope="module")
+def setup(irt):
+    import torch
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    states = irt.distributed.candidate_states(robot, seed=2024, start=0, count=N, tau_max=10.0)
+    d_states = torch.from_numpy(states).cuda()
+    return dict(robot=robot, vox=vox, chk=chk, states=states, d_states=d_states, torch=torch)
+
+
+def _bits(setup, d_states, n):
+    torch = setup["torch"]
+    bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+    tips = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+    setup["chk"].engine.validate_batch_dev(d_states, n, bits, tips, flags)
+    torch.cuda.synchronize()
+    return bits.cpu().numpy().view(np.uint64), tips.cpu().numpy(), flags.cpu().numpy()
+
+
+def test_full_batch_deterministic_and_chunk_invariant(irt, setup):
+    b1, t1, f1 = _bits(setup, setup["d_states"], N)
+    b2, t2, f2 = _bits(setup, setup["d_states"], N)
+    assert np.array_equal(b1, b2) and np.array_equal(t1, t2) and np.array_equal(f1, f2)
+    valid = irt.unpack_bits(b1, N)
+    assert 0.8 < valid.mean() < 0.9 and np.array_equal(valid, f1 == 15)
+    # the same configurations in ragged pieces (sizes not multiples of 64) give the same verdicts
+    torch = setup["torch"]
+    cuts = [0, 1, 64, 1000, 65537, 300001, N]
+    pieces = []
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        d = torch.from_numpy(setup["states"][a:b]).cuda()
+        pieces.append(irt.unpack_bits(_bits(setup, d, b - a)[0], b - a))
+    assert np.array_equal(np.concatenate(pieces), valid)
+    setup["valid"], setup["tips"], setup["flags"] = valid, t1, f1
+
+
+def test_permutation_equivariance(irt, setup):
+    torch = setup["torch"]
+    perm = np.random.default_rng(0).permutation(N)
+    d = torch.from_numpy(setup["states"][perm]).cuda()
+    b, t, _ = _bits(setup, d, N)
+    assert np.array_equal(irt.unpack_bits(b, N), setup["valid"][perm])
+    assert np.array_equal(t, setup["tips"][perm])              # lanes do not influence each other: bit-identical
+
+
+def test_sample_of_full_batch_matches_oracle(irt, orc, helpers, setup):
+    idx = np.random.default_rng(1).choice(N, 6000, replace=False)
+    want, tips, _ = orc.validate_batch(helpers.oracle_robot(orc, setup["robot"], lib="omp"),
+                                       helpers.oracle_grid(orc, setup["vox"]), setup["states"][idx],
+                                       nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(setup["valid"][idx], want)
+    assert np.abs(setup["tips"][idx] - tips).max() <= 1e-9
+
+
+def test_three_routes_to_the_voxel_verdict_agree(irt, setup):
+    """validate (K1+K2) == voxelize (K5) + check_cached (K4), on 2^17 configurations."""
+    n = 1 << 17
+    eng = setup["chk"].engine
+    out = eng.voxelize_batch(setup["states"][:n])
+    hit = eng.check_cached(out["block_ids"], out["masks"], out["offsets"])
+    fl = setup["flags"][:n]
+    shape_ok = (fl & 7) == 7
+    assert np.array_equal(out["shape_valid"], shape_ok)
+    assert np.array_equal(~hit[shape_ok], (fl[shape_ok] & 8) != 0)
+    assert np.array_equal(out["tips"], setup["tips"][:n])
+
+
+def test_fk_rotation_equivariance_full_size(irt):
+    """shape([tau, theta]) = Rz(theta) * shape([tau, 0]) for 2^18 configurations (TendonResult::rotate_z)."""
+    import torch
+    W = irt.workloads
+    robot = W.robot_config2()
+    robot.enable_rotation = True
+    n = 1 << 18
+    st = W.random_states(robot, n, seed=91, tau_max=12.0)
+    st0 = st.copy(); st0[:, 3] = 0.0
+    eng = robot.engine()
+    P = eng.num_points
+    eng.reserve(n)
+
+    def run(s):
+        d = torch.from_numpy(s).cuda()
+        px, py, pz = (torch.empty(P * n, dtype=torch.float64, device="cuda") for _ in range(3))
+        Li = torch.empty(3 * n, dtype=torch.float64, device="cuda")
+        conv = torch.empty(n, dtype=torch.uint8, device="cuda")
+        eng.fk_batch_dev(d, n, n, px, py, pz, d_Li=Li, d_conv=conv)
+        torch.cuda.synchronize()
+        return px.view(P, n), py.view(P, n), pz.view(P, n), Li, conv
+    x, y, z, Li, conv = run(st)
+    x0, y0, z0, Li0, conv0 = run(st0)
+    th = torch.from_numpy(st[:, 3]).cuda()
+    c, s = torch.cos(th), torch.sin(th)
+    assert float((x - (c * x0 - s * y0)).abs().max()) < 1e-14
+    assert float((y - (s * x0 + c * y0)).abs().max()) < 1e-14
+    assert float((z - z0).abs().max()) < 1e-15
+    assert torch.equal(Li, Li0) and torch.equal(conv, conv0)
+
+
+def test_zero_tension_known_answer_full_size(irt, setup):
+    """tau = 0 for 2^16 configurations: the home shape (straight, in free space by construction) is valid."""
+    torch = setup["torch"]
+    n = 1 << 16
+    d = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+    b, t, f = _bits(setup, d, n)
+    assert irt.unpack_bits(b, n).all() and (f == 15).all()
+    assert np.abs(t - np.array([0.0, 0.0, 0.2])).max() < 1e-13
