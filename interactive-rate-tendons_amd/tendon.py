@@ -167,3 +167,34 @@ class TendonRobot:
     def forward_kinematics_batch(self, states, device=0):
         """The omp loop of apps/estimate_length_discretization.cpp:62-71 as one launch."""
         return self.engine(device).fk_batch(states)["p"]
+
+    def tip_jacobian_batch(self, states, delta=1e-6, device=0):
+        """Central-difference tip Jacobians d tip / d state for a batch of states: (n, 3, S).
+
+        This is the Jacobian levmar forms inside tip_control::inverse_kinematics
+        (tip-control/tip_control.cpp:35-140 passes opts[4] = -finite_difference_delta, i.e. central
+        differences; 3rdparty/levmar-2.6/misc_core.c:175-211): per column j, d = max(1e-4 |p_j|, delta),
+        J[:, j] = (tip(p + d e_j) - tip(p - d e_j)) * (0.5 / d) -- but all 2*S*n perturbed states go
+        through ONE K1 launch instead of 2*S sequential FK calls per state."""
+        st = np.ascontiguousarray(np.asarray(states, dtype=np.float64))
+        if st.ndim == 1:
+            st = st.reshape(1, -1)
+        n, S = st.shape
+        if S != self.state_size():
+            raise L.InvalidArgument("State is not the right size")
+        d = np.maximum(np.abs(1e-4 * st), delta)                         # (n, S)
+        pert = np.repeat(st[:, None, None, :], S, axis=1).repeat(2, axis=2)   # (n, S, 2, S)
+        j = np.arange(S)
+        pert[:, j, 0, j] = st[:, j] - d[:, j]
+        pert[:, j, 1, j] = st[:, j] + d[:, j]
+        out = self.engine(device).fk_batch(pert.reshape(-1, S))
+        npts = out["n_points"]
+        tips = out["p"][np.arange(len(npts)), npts - 1].reshape(n, S, 2, 3)
+        if self.enable_retraction:
+            # tip_control's FK wrapper: s_start beyond L returns (0, 0, L - s_start)  (tip_control.cpp:96-104)
+            s = pert[..., -1]
+            over = s > self.specs.L
+            tips[over] = 0.0
+            tips[over, 2] = (self.specs.L - s)[over]
+        J = (tips[:, :, 1, :] - tips[:, :, 0, :]) * (0.5 / d)[:, :, None]   # (n, S, 3)
+        return np.transpose(J, (0, 2, 1))

@@ -231,3 +231,25 @@ def test_empty_and_error_paths(irt):
     with pytest.raises(irt.LengthError):
         v = irt.VoxelOctree(8)
         v.set_xlim(1.0, 1.0)
+
+
+def test_tip_jacobian_batch(irt, orc, helpers):
+    """Batched central-difference tip Jacobian (what levmar builds inside the reference's IK) vs the same
+    differences of oracle FK calls."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    robot.enable_rotation = True
+    orb = helpers.oracle_robot(orc, robot)
+    st = W.random_states(robot, 40, seed=95)
+    J = robot.tip_jacobian_batch(st, delta=1e-6)
+    assert J.shape == (40, 3, 5)
+    for i in range(0, 40, 7):
+        for j in range(5):
+            d = max(abs(1e-4 * st[i, j]), 1e-6)
+            a, b = st[i].copy(), st[i].copy()
+            a[j] -= d; b[j] += d
+            want = (orb.shape(b)["p"][-1] - orb.shape(a)["p"][-1]) * (0.5 / d)
+            assert np.abs(J[i, :, j] - want).max() <= 1e-6          # tip error 1e-13 m / 2e-6
+    # rotation column: d tip / d theta = e_z x tip
+    tips = robot.shape_batch(st)["p"][:, -1]
+    assert np.abs(J[:, 0, 4] + tips[:, 1]).max() < 1e-6 and np.abs(J[:, 1, 4] - tips[:, 0]).max() < 1e-6
