@@ -16,7 +16,7 @@ from .tendon import BackboneSpecs, TendonSpecs, TendonResult, TendonRobot
 from .collision import VoxelOctree
 from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelBackboneMotionValidator,
                               FunctionTimer)
-from . import workloads, distributed, roadmap
+from . import workloads, distributed, roadmap, rmp
 from .roadmap import RoadmapBuilder
 
 __all__ = [

@@ -37,7 +37,7 @@ def test_config3_roadmap_build_matches_oracle(irt, orc, helpers):
     print("config3 test scale:", rb.timing)
 
 
-def test_config5_cached_revalidation(irt, orc, helpers):
+def test_config5_cached_revalidation(irt, orc, helpers, tmp_path):
     """Caches built in one environment, re-validated in a perturbed one: identical to validating from scratch."""
     W = irt.workloads
     robot = W.robot_config3()
@@ -58,6 +58,15 @@ def test_config5_cached_revalidation(irt, orc, helpers):
     e_valid = irt.VoxelBackboneMotionValidator(chk2).check_motion(states[edges[:, 0]], states[edges[:, 1]])
     assert np.array_equal(ec["fully_valid"] & ~e_hit, e_valid)
     assert v_hit.any() and e_hit.any() and not v_hit.all()
+    # through the reference's .rmp roadmap file and back: file -> CSR -> K4, no octrees built
+    path = str(tmp_path / "roadmap.rmp")
+    w = np.linalg.norm(states[edges[:, 0]] - states[edges[:, 1]], axis=1)
+    ec_file = dict(ec, present=ec["fully_valid"])
+    irt.rmp.write_rmp(path, states, vc["tips"], edges, w, vc, ec_file, N=256, limits=vox.limits())
+    r = irt.rmp.read_rmp(path)
+    assert np.array_equal(r["states"], states) and np.array_equal(r["edges"], edges) and np.array_equal(r["tips"], vc["tips"])
+    assert np.array_equal(rb.revalidate(r["vertex_caches"], new_vox), v_hit)
+    assert np.array_equal(rb.revalidate(r["edge_caches"], new_vox), e_hit)
 
 
 def test_config4_sharded_mask_single_rank(irt, orc, helpers):

@@ -212,3 +212,41 @@ def test_sharded_validation_gloo_world2_matches_world1(irt, tmp_path):
     a, b = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
     assert a.shape == (M,) and np.array_equal(a, b)
     assert 0 < a.sum() < M
+
+
+# ---- .rmp roadmap files <-> CSR voxel caches ------------------------------------------------------------------
+def test_rmp_byte_layout_and_roundtrip(irt, tmp_path):
+    import struct
+    rmp = irt.rmp
+    # a file assembled by hand from the layout of RmpStreamer (VoxelCachedLazyPRM.cpp:986-1114)
+    blob = struct.pack("<IIB", 2, 1, 1) + struct.pack("<B6d", 64, -0.25, 0.25, -0.25, 0.25, -0.25, 0.25)
+    blob += struct.pack("<II3d", 0, 3, 1.0, 2.0, 3.0) + b"\x01" + struct.pack("<3d", 0.1, 0.2, 0.3)
+    blob += b"\x01" + struct.pack("<I", 2) + struct.pack("<BBBQ", 1, 2, 3, 0xFF) + struct.pack("<BBBQ", 63, 0, 5, 1 << 63)
+    blob += struct.pack("<II3d", 1, 3, 4.0, 5.0, 6.0) + b"\x00" + b"\x00"
+    blob += struct.pack("<IId", 0, 1, 5.196) + b"\x01" + struct.pack("<I", 1) + struct.pack("<BBBQ", 0, 0, 0, 7)
+    f = tmp_path / "hand.rmp"
+    f.write_bytes(blob)
+    r = rmp.read_rmp(str(f))
+    assert r["N"] == 256 and r["limits"] == (-0.25, 0.25) * 3
+    assert np.array_equal(r["states"], [[1, 2, 3], [4, 5, 6]]) and np.array_equal(r["tips"][0], [0.1, 0.2, 0.3])
+    assert np.isnan(r["tips"][1]).all() and r["edges"].tolist() == [[0, 1]] and r["weights"][0] == 5.196
+    vc = r["vertex_caches"]
+    assert vc["offsets"].tolist() == [0, 2, 2] and vc["present"].tolist() == [True, False]
+    assert vc["block_ids"].tolist() == [(1 * 64 + 2) * 64 + 3, (63 * 64 + 0) * 64 + 5]
+    assert vc["masks"].tolist() == [0xFF, 1 << 63] and r["edge_caches"]["masks"].tolist() == [7]
+    # writer reproduces the same bytes
+    g = tmp_path / "again.rmp"
+    # (a missing tip cannot be expressed per vertex through the array API: write with all tips absent or present)
+    rmp.write_rmp(str(g), r["states"], None, r["edges"], r["weights"], vc, r["edge_caches"], N=256, limits=r["limits"])
+    r2 = rmp.read_rmp(str(g))
+    for k in ("states", "edges", "weights"):
+        assert np.array_equal(r[k], r2[k])
+    for c in ("vertex_caches", "edge_caches"):
+        for k in ("offsets", "block_ids", "masks", "present"):
+            assert np.array_equal(r[c][k], r2[c][k])
+    # no voxels at all
+    h = tmp_path / "plain.rmp"
+    rmp.write_rmp(str(h), r["states"], np.array([[0.1, 0.2, 0.3], [0.4, 0.5, 0.6]]), r["edges"], r["weights"])
+    r3 = rmp.read_rmp(str(h))
+    assert r3["vertex_caches"] is None and np.array_equal(r3["tips"][1], [0.4, 0.5, 0.6])
+    assert h.stat().st_size == 9 + 2 * (8 + 24 + 1 + 24) + 16
