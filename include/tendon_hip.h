@@ -163,6 +163,14 @@ typedef struct {
 int tr_validate_edges(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
                       int64_t n_edges, uint64_t *valid_bits, int32_t *n_fk, int64_t *n_domain_errors);
 
+/* Batched checkMotion(s1, s2, last_valid) (AbstractVoxelMotionValidator.h:153-169 ->
+ * voxelize_until_invalid, VoxelBackboneMotionValidator.cpp:83-91): same verdict bits, plus per edge
+ * last_valid_t = PartialVoxelization::t, the largest sampled interpolation parameter below the first
+ * invalid sample (1.0 for a valid edge, 0.0 when already the start is invalid).  The caller obtains
+ * last_valid.first with its own space->interpolate(s1, s2, t). */
+int tr_validate_edges_last_valid(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
+                                 int64_t n_edges, uint64_t *valid_bits, double *last_valid_t, int32_t *n_fk);
+
 /* ---- cached voxel sets vs obstacles: VoxelOctree::collides on roadmap caches ------------ */
 
 /* Batched `obstacles.collides(*cached_voxels)` for roadmap vertices / edges

@@ -124,5 +124,12 @@ class VoxelBackboneMotionValidator:
     def check_motion(self, a, b):
         return self.check_motion_detail(a, b)["valid"]
 
+    def check_motion_last_valid(self, a, b):
+        """checkMotion(s1, s2, last_valid) for a batch: (valid, last_valid_t); last_valid.first is
+        interpolate(s1, s2, last_valid_t) in the caller's state space."""
+        d = self.engine.validate_edges_last_valid(a, b, self.min_tension_change, self.min_rotation_change,
+                                                  self.min_retraction_change)
+        return d["valid"], d["last_valid_t"]
+
     def checkMotion(self, s1, s2):
         return bool(self.check_motion(np.asarray(s1, float).reshape(1, -1), np.asarray(s2, float).reshape(1, -1))[0])

@@ -133,6 +133,8 @@ def _load(kind="strict"):
     lib.orc_state_distance.restype = C.c_double
     lib.orc_check_motion.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p, c_double_p,
                                      c_double_p, P(OrcGrid), P(C.c_int), P(C.c_int), c_double_p]
+    lib.orc_check_motion_until_invalid.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p, c_double_p,
+                                                   c_double_p, P(C.c_int), c_double_p]
     lib.orc_check_motion_batch.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p,
                                            c_double_p, c_double_p, C.c_long, P(C.c_uint8),
                                            P(C.c_int32), C.c_int]
@@ -411,6 +413,15 @@ def check_motion(robot, grid, a, b, sp=None, inv_rot=IDENTITY, want_swept=False)
                                    swept.ptr if swept else None, C.byref(nfk), C.byref(fully), C.byref(lvt))
     return dict(valid=(v == 1), domain_error=(v < 0), n_fk=nfk.value, is_fully_valid=bool(fully.value),
                 last_valid_t=lvt.value, swept=swept)
+
+
+def check_motion_until_invalid(robot, grid, a, b, sp=None, inv_rot=IDENTITY):
+    sp = sp or space_params()
+    a, b, inv_rot = _f64(a), _f64(b), _f64(inv_rot).reshape(9)
+    nfk, lvt = C.c_int(0), C.c_double(0)
+    fully = robot.lib.orc_check_motion_until_invalid(C.byref(robot.c), C.byref(sp), grid.ptr, _dp(inv_rot), _dp(a), _dp(b),
+                                                     C.byref(nfk), C.byref(lvt))
+    return dict(is_fully_valid=bool(fully), last_valid_t=lvt.value, n_fk=nfk.value)
 
 
 def check_motion_batch(robot, grid, a, b, sp=None, inv_rot=IDENTITY, nthreads=1, lib=None):

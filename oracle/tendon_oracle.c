@@ -1165,10 +1165,11 @@ typedef struct { double t; double *pts; int n; int is_valid; } fk_sample;
 /* motion-planning/VoxelEnvironment.cpp:207-444 driven as VoxelBackboneMotionValidator.cpp:19-81
  * drives it (per-sample validity = is_valid_shape only; obstacles tested on the union) and
  * AbstractVoxelMotionValidator.h:143-151 (checkMotion). */
-int orc_check_motion(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
-                     const double inv_rot[9], const double *a, const double *b,
-                     orc_grid *swept, int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
+static int check_motion_impl(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                             const double inv_rot[9], const double *a, const double *b, int until_invalid,
+                             orc_grid *swept, int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
   const int S = orc_state_size(rb);
+  orc_grid *sample_vox = until_invalid ? orc_grid_empty_copy(obstacles) : NULL;
   const int cap = max_points(rb);
   unsigned nseg = orc_valid_segment_count(rb, sp, a, b);
   double rel_threshold = 1.0 / (double)nseg;
@@ -1189,6 +1190,14 @@ int orc_check_motion(const orc_robot *rb, const orc_space_params *sp, const orc_
     fks[nfk].pts = (double *)malloc(sizeof(double) * 3 * (size_t)fk.n); \
     memcpy(fks[nfk].pts, fk.p, sizeof(double) * 3 * (size_t)fk.n); \
     orc_rotate_points(inv_rot, fks[nfk].pts, fk.n); \
+    if (ok_ && until_invalid) { /* voxelize_until_invalid_impl: validity also needs !_vc->collides(shape) */ \
+      orc_grid_clear(sample_vox); \
+      orc_grid_add_piecewise_line(sample_vox, fks[nfk].pts, fk.n); \
+      if (orc_grid_collides(obstacles, sample_vox)) { \
+        ok_ = 0; fks[nfk].is_valid = 0; \
+        if ((tt) < first_invalid_t) first_invalid_t = (tt); \
+      } \
+    } \
     nfk++; } while (0)
 
   ADD_FK(0.0, a);
@@ -1251,6 +1260,7 @@ int orc_check_motion(const orc_robot *rb, const orc_space_params *sp, const orc_
   if (last_valid_t_out) *last_valid_t_out = last_valid_t;
 
   if (!swept) orc_grid_free(vox);
+  if (sample_vox) orc_grid_free(sample_vox);
   for (int i = 0; i < nfk; i++) free(fks[i].pts);
   free(fks); free(stack); free(cur);
   result_free(&fk); result_free(&home);
@@ -1258,6 +1268,23 @@ int orc_check_motion(const orc_robot *rb, const orc_space_params *sp, const orc_
 #undef ADD_FK
 #undef SHOULD_SUBDIVIDE
 #undef PUSH
+}
+
+int orc_check_motion(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                     const double inv_rot[9], const double *a, const double *b,
+                     orc_grid *swept, int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
+  return check_motion_impl(rb, sp, obstacles, inv_rot, a, b, 0, swept, n_fk_out, is_fully_valid_out, last_valid_t_out);
+}
+
+/* checkMotion(s1, s2, last_valid) (AbstractVoxelMotionValidator.h:153-169) over voxelize_until_invalid
+ * (VoxelBackboneMotionValidator.cpp:83-91): per-sample validity = is_valid_shape && !collides(shape).
+ * Returns is_fully_valid; *last_valid_t = partial.t. */
+int orc_check_motion_until_invalid(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                                   const double inv_rot[9], const double *a, const double *b,
+                                   int *n_fk_out, double *last_valid_t_out) {
+  int fully = 0;
+  check_motion_impl(rb, sp, obstacles, inv_rot, a, b, 1, NULL, n_fk_out, &fully, last_valid_t_out);
+  return fully;
 }
 
 int orc_check_motion_batch(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,

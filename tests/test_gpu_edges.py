@@ -82,3 +82,20 @@ def test_edges_leaving_the_voxel_domain_are_reported(irt):
     b = np.array([[6.0, 0.0, 0.0], [0.2, 0.1, 0.0]])
     d = mv.check_motion_detail(a, b)
     assert d["n_domain_errors"] >= 1 and not d["valid"][0]
+
+
+def test_check_motion_with_last_valid(irt, orc, helpers):
+    """checkMotion(s1, s2, last_valid): verdict and PartialVoxelization::t against the oracle's DFS."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    a, b = _edges(robot, irt, 500, seed=33, step=6.0)
+    valid, lvt = mv.check_motion_last_valid(a, b)
+    assert np.array_equal(valid, mv.check_motion(a, b))          # same boolean as the two-argument form
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    for i in range(len(a)):
+        w = orc.check_motion_until_invalid(orb, og, a[i], b[i])
+        assert valid[i] == w["is_fully_valid"] and lvt[i] == w["last_valid_t"], (i, lvt[i], w)
+    assert (lvt[valid] == 1.0).all() and ((lvt[~valid] > 0) & (lvt[~valid] < 1)).sum() > 10
