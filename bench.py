@@ -84,16 +84,24 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    # TENDON_BENCH_SHARED_GPU=1 is a REHEARSAL mode for boxes with one GPU: every rank uses cuda:0 and the
+    # mask is gathered with gloo through host memory, so the N>1 control flow can be exercised (the numbers
+    # mean nothing).  The real N>1 path below is one rank per GPU with RCCL.
+    rehearsal = os.environ.get("TENDON_BENCH_SHARED_GPU") == "1"
+    dev_index = 0 if rehearsal else local_rank
+    torch.cuda.set_device(dev_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     irt = importlib.import_module("interactive-rate-tendons_amd")
     W = irt.workloads
     robot = W.robot_config2()
     vox, _ = W.reach_environment(seed=7, n_spheres=64)
-    checker = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox, device=local_rank)
+    checker = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox, device=dev_index)
     eng = checker.engine
     n = 1 << args.batch_log2
     S, P, N = eng.state_size, eng.num_points, eng.n_tendons
@@ -105,10 +113,15 @@ def main():
     d_all = torch.zeros(world * (n // 64), dtype=torch.int64, device="cuda") if world > 1 else None
     eng.reserve(n)
 
+    h_all = torch.zeros(world * (n // 64), dtype=torch.int64) if (world > 1 and rehearsal) else None
+
     def step():
         eng.validate_batch_dev(d_states, n, d_bits, d_tips)
         if world > 1:
-            dist.all_gather_into_tensor(d_all, d_bits)
+            if rehearsal:
+                dist.all_gather_into_tensor(h_all, d_bits.cpu())
+            else:
+                dist.all_gather_into_tensor(d_all, d_bits)
 
     def fence():
         if world > 1:
@@ -127,9 +140,14 @@ def main():
     prof = eng.profile_read()
     eng.profile_end()
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        # every rank's shard of the gathered mask must be that rank's own verdicts
+        gathered = (h_all if rehearsal else d_all.cpu()).numpy().view(np.uint64)
+        mine = d_bits.cpu().numpy().view(np.uint64)
+        if not np.array_equal(gathered[rank * (n // 64):(rank + 1) * (n // 64)], mine):
+            raise SystemExit("rank %d: gathered validity mask does not contain this rank's shard" % rank)
 
     valid_bits = d_bits.cpu().numpy().view(np.uint64)
     valid = irt.unpack_bits(valid_bits, n)
@@ -168,7 +186,7 @@ def main():
             "config": {"workload": "configs[1]: 3-tendon helical-routed robot (C=[2*pi*k/3, 5], D=[0.01], L=0.2, dL=L/128, "
                                    "129 backbone points), 2^%d seeded configs per GPU per step (tau~U[0,10)^3), batched FK + "
                                    "256^3 voxel collision (64 seeded spheres r=0.02 in reach)" % args.batch_log2,
-                       "batch_per_gpu": n, "parallelism": "shard%d+allgather(bitmask)" % world if world > 1 else "single",
+                       "rehearsal_shared_gpu": rehearsal, "batch_per_gpu": n, "parallelism": "shard%d+allgather(bitmask)" % world if world > 1 else "single",
                        "valid_fraction_rank0": float(valid.mean())},
             "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
