@@ -253,3 +253,51 @@ def test_tip_jacobian_batch(irt, orc, helpers):
     # rotation column: d tip / d theta = e_z x tip
     tips = robot.shape_batch(st)["p"][:, -1]
     assert np.abs(J[:, 0, 4] + tips[:, 1]).max() < 1e-6 and np.abs(J[:, 1, 4] - tips[:, 0]).max() < 1e-6
+
+
+@pytest.mark.parametrize("n_tendons", [1, 2, 5, 6, 8])
+def test_fk_other_tendon_counts(irt, orc, helpers, n_tendons):
+    """Every instantiated kernel width (1..8 tendons), with rotation, mixed routing."""
+    rng = np.random.default_rng(n_tendons)
+    tendons = [irt.TendonSpecs(C=[2 * np.pi * k / n_tendons, float(rng.uniform(-6, 6)), float(rng.uniform(-10, 10))],
+                               D=[0.01, float(rng.uniform(-0.01, 0.01))], max_tension=12.0) for k in range(n_tendons)]
+    robot = irt.TendonRobot(tendons=tendons, specs=irt.BackboneSpecs(dL=0.004), enable_rotation=True)
+    states = irt.workloads.random_states(robot, 200, seed=7 + n_tendons, tau_max=12.0 / np.sqrt(n_tendons))
+    _fk_check(irt, orc, helpers, robot, states)
+
+
+def test_fk_step_not_dividing_length(irt, orc, helpers):
+    """L is not a multiple of dL: with dL = 3.5 mm the first interval is 4 mm = 1.14 dL and takes two RK4
+    steps (integrate_times); with dL = 3 mm it is 2 mm (one short step).  Both run on the shared-grid
+    kernel's host-built step list."""
+    robot = irt.workloads.robot_config2()
+    robot.specs.dL = 0.003
+    _fk_check(irt, orc, helpers, robot, irt.workloads.random_states(robot, 200, seed=16, tau_max=15.0))
+    robot = irt.workloads.robot_config2()
+    robot.specs.dL = 0.0035
+    orb = helpers.oracle_robot(orc, robot)
+    t = orb.t_range()
+    assert t[1] - t[0] > 0.0035 * 1.1 and len(t) == 58
+    _fk_check(irt, orc, helpers, robot, irt.workloads.random_states(robot, 300, seed=17, tau_max=15.0))
+
+
+@pytest.mark.parametrize("N,lim", [(128, (-0.25, 0.25, -0.25, 0.25, -0.05, 0.45)), (64, (-0.3, 0.3, -0.2, 0.4, -0.1, 0.3)),
+                                   (512, (-0.4, 0.4, -0.4, 0.4, -0.4, 0.4))])
+def test_validity_other_grids(irt, orc, helpers, N, lim):
+    """Grid sizes other than 256 and anisotropic voxels (dx != dy != dz)."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox = irt.VoxelOctree(N)
+    vox.set_xlim(lim[0], lim[1]); vox.set_ylim(lim[2], lim[3]); vox.set_zlim(lim[4], lim[5])
+    rng = np.random.default_rng(N)
+    for _ in range(40):
+        c = rng.uniform(-0.2, 0.2, 3)
+        c[2] = abs(c[2])
+        if np.hypot(c[0], c[1]) > 0.05:
+            vox.add_sphere(c, 0.02)
+    chk = _checker(irt, robot, vox)
+    states = W.random_states(robot, 3000, seed=N, tau_max=20.0)
+    want, _, _ = orc.validate_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), states,
+                                    nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(chk.is_valid(states), want)
+    assert 0.1 < want.mean() < 0.95
