@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -56,6 +57,9 @@ struct EventPair { hipEvent_t a, b; };
 }  // namespace
 
 struct tr_ctx {
+  // One workspace per context: the entry points serialise on this mutex, so concurrent callers (the
+  // reference calls isValid from OpenMP threads, VoxelCachedLazyPRM.cpp:1448-1455) are safe, one at a time.
+  std::recursive_mutex mu;
   int device = 0;
   std::string err;
   RobotK K{};
@@ -463,6 +467,7 @@ int tr_set_debug(tr_ctx *c, uint32_t bits) { if (!c) return TR_ERR_INVALID_ARG; 
 
 int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *blocks, const double inv_rot[9]) {
   if (!c || !lim || !blocks) return fail(c, TR_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (N < 4 || N > 512 || (N & (N - 1)))       // collision/VoxelOctree.cpp:98-116
     return fail(c, TR_ERR_INVALID_ARG, "unsupported voxel dimension: " + std::to_string(N));
   if (!(lim[0] < lim[1]) || !(lim[2] < lim[3]) || !(lim[4] < lim[5]))   // VoxelOctree.cpp:152-177
@@ -504,6 +509,7 @@ int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *bloc
 
 int tr_reserve(tr_ctx *c, int64_t n) {
   if (!c || n < 0) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   int rc = ensure_workspace(c, n);
   if (rc) return rc;
@@ -515,6 +521,7 @@ int tr_fk_batch_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t ld, do
                     double *d_pz, double *d_R, double *d_L, double *d_Li, uint8_t *d_converged,
                     int32_t *d_n_points, void *stream) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
   if (n == 0) return TR_OK;
   if (!d_states || !d_px || !d_py || !d_pz) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
@@ -530,6 +537,7 @@ int tr_fk_batch_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t ld, do
 int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R, double *L, double *L_i,
                 uint8_t *converged, int32_t *n_points) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || (n > 0 && !states)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -591,6 +599,7 @@ int tr_validate_shapes_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px,
                            const uint8_t *d_converged, int check_voxels, uint64_t *d_valid_bits,
                            uint8_t *d_flags, void *stream) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
   if (n == 0) return TR_OK;
   if (!d_px || !d_py || !d_pz || !d_Li || !d_converged || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
@@ -611,6 +620,7 @@ int tr_validate_shapes_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px,
 int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
                           double *d_tips, uint8_t *d_flags, void *stream) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0) return fail(c, TR_ERR_INVALID_ARG, "negative batch size");
   if (n == 0) return TR_OK;
   if (!d_states || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
@@ -634,6 +644,7 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
 
 int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *valid_bits, double *tips, uint8_t *flags) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || (n > 0 && (!states || !valid_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -654,6 +665,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
 int tr_check_cached_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_masks, const int64_t *d_offsets,
                         int64_t n_items, uint64_t *d_hit_bits, void *stream) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n_items < 0) return fail(c, TR_ERR_INVALID_ARG, "negative item count");
   if (n_items == 0) return TR_OK;
   if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
@@ -670,6 +682,7 @@ int tr_check_cached_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_mask
 int tr_check_cached(tr_ctx *c, const uint32_t *ids, const uint64_t *masks, const int64_t *offsets,
                     int64_t n_items, uint64_t *hit_bits) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n_items < 0 || (n_items > 0 && (!offsets || !hit_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n_items == 0) return TR_OK;
   HIP_TRY(c, hipSetDevice(c->device));
@@ -767,6 +780,7 @@ int voxelize_samples(tr_ctx *c, int64_t m, int64_t ld, const int32_t *d_np, cons
 
 int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offsets, uint64_t *shape_valid_bits, double *tips) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || (n > 0 && (!states || !offsets || !shape_valid_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   c->vox_ids.clear(); c->vox_masks.clear();
   if (offsets) offsets[0] = 0;
@@ -802,6 +816,7 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
 
 int tr_voxelize_fetch(tr_ctx *c, uint32_t *block_ids, uint64_t *masks, int64_t capacity) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   const int64_t nnz = (int64_t)c->vox_ids.size();
   if (capacity < nnz) return fail(c, TR_ERR_INVALID_ARG, "capacity smaller than the stored block lists");
   if (nnz > 0) {
@@ -815,6 +830,7 @@ int tr_voxelize_fetch(tr_ctx *c, uint32_t *block_ids, uint64_t *masks, int64_t c
 // ---- nearest neighbours ---------------------------------------------------------------------
 int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || k < 1 || (n > 0 && (!states || !idx || !dist))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
   if ((size_t)k * 64 * 12 > 60 * 1024) return fail(c, TR_ERR_INVALID_ARG, "k too large (at most 80)");
@@ -850,12 +866,14 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
 // ---- instrumentation -----------------------------------------------------------------------
 int tr_profile_begin(tr_ctx *c) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   for (auto &v : c->events) { for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } v.clear(); }
   c->profiling = true;
   return TR_OK;
 }
 int tr_profile_read(tr_ctx *c, int64_t launches[TR_PROFILE_SLOTS], double total_ms[TR_PROFILE_SLOTS]) {
   if (!c || !launches || !total_ms) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   for (int s = 0; s < TR_PROFILE_SLOTS; s++) {
     launches[s] = (int64_t)c->events[s].size();
@@ -872,6 +890,7 @@ int tr_profile_read(tr_ctx *c, int64_t launches[TR_PROFILE_SLOTS], double total_
 }
 int tr_profile_end(tr_ctx *c) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
   c->profiling = false;
   for (auto &v : c->events) { for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); } v.clear(); }
   return TR_OK;

@@ -301,3 +301,26 @@ def test_validity_other_grids(irt, orc, helpers, N, lim):
                                     nthreads=0, lib=orc.omp_lib())
     assert np.array_equal(chk.is_valid(states), want)
     assert 0.1 < want.mean() < 0.95
+
+
+def test_concurrent_single_state_calls(irt, orc, helpers):
+    """isValid from many host threads on ONE context (the reference calls it from OpenMP threads,
+    VoxelCachedLazyPRM.cpp:1448-1455): calls serialise on the context mutex and stay correct."""
+    import threading
+    W = irt.workloads
+    robot = W.robot_config2()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = _checker(irt, robot, vox)
+    states = W.random_states(robot, 256, seed=23, tau_max=20.0)
+    want = chk.is_valid(states)
+    got = np.zeros(len(states), bool)
+
+    def work(lo, hi):
+        for i in range(lo, hi):
+            got[i] = chk.isValid(states[i])
+            if i % 16 == 0:                                  # interleave a different entry point
+                robot.shape_batch(states[i:i + 3])
+    ths = [threading.Thread(target=work, args=(k * 32, (k + 1) * 32)) for k in range(8)]
+    [t.start() for t in ths]
+    [t.join() for t in ths]
+    assert np.array_equal(got, want) and 0 < want.sum() < len(want)
