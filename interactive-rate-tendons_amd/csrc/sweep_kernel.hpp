@@ -378,6 +378,16 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
       const int64_t o = (int64_t)(u < P ? u : P - 1) * ld + ic;
       ring[u] = V3{in.px[o], in.py[o], in.pz[o]};
     }
+    // Per-point quantities are computed once and carried to the next segment (a point is the end of one
+    // segment and the start of the next): "strictly inside the domain by the 1e-6 margin", the voxel
+    // coordinates (a - ll) * (1/d) exactly as add_line forms them, and the cell index.
+    const double bx0 = g.xmin + 1e-6 * (g.xmax - g.xmin), bx1 = g.xmax - 1e-6 * (g.xmax - g.xmin);
+    const double by0 = g.ymin + 1e-6 * (g.ymax - g.ymin), by1 = g.ymax - 1e-6 * (g.ymax - g.ymin);
+    const double bz0 = g.zmin + 1e-6 * (g.zmax - g.zmin), bz1 = g.zmax - 1e-6 * (g.zmax - g.zmin);
+    const bool use_near = near.blocks != nullptr;
+    bool in_prev = false;
+    V3 Aprev = {0, 0, 0};
+    int cpx = 0, cpy = 0, cpz = 0;
     auto visit = [&](int j, const V3 &q) {
       if (j == 0) prev = q;
       const float dx = (float)(q.x - prev.x), dy = (float)(q.y - prev.y), dz = (float)(q.z - prev.z);
@@ -396,8 +406,21 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
           qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
           qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
         }
-        if (j > 0) hit = line_hits(prevr, qr, g, gc, near, bad);
-        prevr = qr;
+        const bool in_q = qr.x > bx0 && qr.x < bx1 && qr.y > by0 && qr.y < by1 && qr.z > bz0 && qr.z < bz1;
+        const V3 Bq = {(qr.x - g.xmin) * g.inv_dx, (qr.y - g.ymin) * g.inv_dy, (qr.z - g.zmin) * g.inv_dz};
+        // inside the margin box the voxel coordinates are in (0, N): floor == truncation, no range checks
+        const int cqx = (int)Bq.x, cqy = (int)Bq.y, cqz = (int)Bq.z;
+        if (j > 0) {
+          if (in_prev && in_q) {
+            const int ddx = cqx - cpx, ddy = cqy - cpy, ddz = cqz - cpz;
+            const bool nearby = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1;
+            if (!(use_near && nearby && !near.occupied(cpx, cpy, cpz)))
+              hit = walk_cells(Aprev, Bq, g, [&](int x, int y, int z) { return gc.occupied(x, y, z); });
+          } else {
+            hit = line_hits(prevr, qr, g, gc, near, bad);      // near or outside the domain boundary: full reference path
+          }
+        }
+        prevr = qr; in_prev = in_q; Aprev = Bq; cpx = cqx; cpy = cqy; cpz = cqz;
       }
     };
     for (int j0 = 0; j0 < P; j0 += PF) {
