@@ -86,6 +86,15 @@ struct tr_ctx {
   uint32_t *d_vids = nullptr; uint64_t *d_vmasks = nullptr; int32_t *d_vcounts = nullptr; int64_t *d_voffsets = nullptr;
   uint32_t *d_cids = nullptr; uint64_t *d_cmasks = nullptr; uint64_t *d_vbits = nullptr;
   int64_t vox_cap = 0, vox_cnnz = 0;
+  // host-buffer pipeline of tr_validate_batch: pinned staging, copy/compute streams
+  struct Pipe {
+    bool ready = false;
+    int64_t chunk = 0;
+    hipStream_t s_up = nullptr, s_comp = nullptr, s_down = nullptr;
+    double *h_states[2] = {nullptr, nullptr}; double *h_tips[2] = {nullptr, nullptr};
+    uint64_t *h_bits[2] = {nullptr, nullptr}; uint8_t *h_flags[2] = {nullptr, nullptr};
+    hipEvent_t up[2], done[2], down[2];
+  } pipe;
   // instrumentation
   bool profiling = false;
   std::vector<EventPair> events[TR_PROFILE_SLOTS];
@@ -445,6 +454,13 @@ void tr_destroy(tr_ctx *c) {
   (void)hipSetDevice(c->device);
   (void)hipDeviceSynchronize();
   for (auto &v : c->events) for (auto &e : v) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  if (c->pipe.ready) {
+    for (int b = 0; b < 2; b++) {
+      (void)hipHostFree(c->pipe.h_states[b]); (void)hipHostFree(c->pipe.h_tips[b]); (void)hipHostFree(c->pipe.h_bits[b]); (void)hipHostFree(c->pipe.h_flags[b]);
+      (void)hipEventDestroy(c->pipe.up[b]); (void)hipEventDestroy(c->pipe.done[b]); (void)hipEventDestroy(c->pipe.down[b]);
+    }
+    (void)hipStreamDestroy(c->pipe.s_up); (void)hipStreamDestroy(c->pipe.s_comp); (void)hipStreamDestroy(c->pipe.s_down);
+  }
   Workspace &w = c->ws;
   void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_grid, c->d_near, w.homeLi, w.np, c->d_vids, c->d_vmasks, c->d_vcounts,
                   c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
@@ -642,22 +658,84 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
   return TR_OK;
 }
 
+namespace {
+// Host-buffer batches are pipelined in chunks: the caller's (pageable) arrays are staged through two
+// pinned buffers, uploads / kernels / downloads run on three streams chained by events, so PCIe
+// transfers and the host-side staging copies of chunk i+1 overlap the kernels of chunk i.  Kernels of
+// successive chunks share the FK workspace and stay ordered on the one compute stream.
+int ensure_pipe(tr_ctx *c) {
+  tr_ctx::Pipe &p = c->pipe;
+  if (p.ready) return TR_OK;
+  const int64_t CH = 1 << 18;
+  const int S = c->K.state_size;
+  HIP_TRY(c, hipStreamCreateWithFlags(&p.s_up, hipStreamNonBlocking));
+  HIP_TRY(c, hipStreamCreateWithFlags(&p.s_comp, hipStreamNonBlocking));
+  HIP_TRY(c, hipStreamCreateWithFlags(&p.s_down, hipStreamNonBlocking));
+  for (int b = 0; b < 2; b++) {
+    HIP_TRY(c, hipHostMalloc((void **)&p.h_states[b], (size_t)CH * S * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void **)&p.h_tips[b], (size_t)CH * 3 * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void **)&p.h_bits[b], (size_t)(CH / 64) * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void **)&p.h_flags[b], (size_t)CH, hipHostMallocDefault));
+    HIP_TRY(c, hipEventCreateWithFlags(&p.up[b], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&p.done[b], hipEventDisableTiming));
+    HIP_TRY(c, hipEventCreateWithFlags(&p.down[b], hipEventDisableTiming));
+  }
+  p.chunk = CH;
+  p.ready = true;
+  return TR_OK;
+}
+}  // namespace
+
 int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *valid_bits, double *tips, uint8_t *flags) {
   if (!c) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || (n > 0 && (!states || !valid_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
-  if ((rc = ensure_staging(c, n))) return rc;
+  if ((rc = ensure_pipe(c))) return rc;
+  tr_ctx::Pipe &p = c->pipe;
+  const int64_t CH = p.chunk;
+  if ((rc = ensure_staging(c, std::min(n, 2 * CH)))) return rc;
+  if ((rc = ensure_workspace(c, std::min(n, CH)))) return rc;
+  HIP_TRY(c, hipDeviceSynchronize());          // earlier work on other streams (e.g. a *_dev call) is finished
   Workspace &w = c->ws;
   const int S = c->K.state_size;
-  HIP_TRY(c, hipMemcpy(w.states, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice));
-  if ((rc = tr_validate_batch_dev(c, w.states, n, w.bits, tips ? w.tips : nullptr, flags ? w.flags : nullptr, nullptr))) return rc;
-  HIP_TRY(c, hipDeviceSynchronize());
-  HIP_TRY(c, hipMemcpy(valid_bits, w.bits, (size_t)((n + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  if (tips) HIP_TRY(c, hipMemcpy(tips, w.tips, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost));
-  if (flags) HIP_TRY(c, hipMemcpy(flags, w.flags, (size_t)n, hipMemcpyDeviceToHost));
+  const int64_t nchunks = (n + CH - 1) / CH;
+  auto drain = [&](int64_t i) -> int {         // copy chunk i's results out of its pinned buffers
+    const int b = (int)(i & 1);
+    const int64_t off = i * CH, m = std::min(CH, n - off);
+    HIP_TRY(c, hipEventSynchronize(p.down[b]));
+    std::memcpy(valid_bits + off / 64, p.h_bits[b], (size_t)((m + 63) / 64) * sizeof(uint64_t));
+    if (tips) std::memcpy(tips + 3 * off, p.h_tips[b], (size_t)m * 3 * sizeof(double));
+    if (flags) std::memcpy(flags + off, p.h_flags[b], (size_t)m);
+    return TR_OK;
+  };
+  for (int64_t i = 0; i < nchunks; i++) {
+    const int b = (int)(i & 1);
+    const int64_t off = i * CH, m = std::min(CH, n - off);
+    if (i >= 2 && (rc = drain(i - 2))) return rc;             // pinned buffers b are free again
+    // device staging slots alternate with the pinned buffers
+    double *d_st = w.states + (size_t)b * CH * S;
+    uint64_t *d_bits = w.bits + (size_t)b * (CH / 64);
+    double *d_tips = w.tips + (size_t)b * CH * 3;
+    uint8_t *d_flags = w.flags + (size_t)b * CH;
+    std::memcpy(p.h_states[b], states + off * S, (size_t)m * S * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(d_st, p.h_states[b], (size_t)m * S * sizeof(double), hipMemcpyHostToDevice, p.s_up));
+    HIP_TRY(c, hipEventRecord(p.up[b], p.s_up));
+    HIP_TRY(c, hipStreamWaitEvent(p.s_comp, p.up[b], 0));
+    if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(p.s_comp, p.down[b], 0));   // slot b's previous results have left the device
+    if ((rc = tr_validate_batch_dev(c, d_st, m, d_bits, tips ? d_tips : nullptr, flags ? d_flags : nullptr, p.s_comp))) return rc;
+    HIP_TRY(c, hipEventRecord(p.done[b], p.s_comp));
+    HIP_TRY(c, hipStreamWaitEvent(p.s_down, p.done[b], 0));
+    HIP_TRY(c, hipMemcpyAsync(p.h_bits[b], d_bits, (size_t)((m + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, p.s_down));
+    if (tips) HIP_TRY(c, hipMemcpyAsync(p.h_tips[b], d_tips, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost, p.s_down));
+    if (flags) HIP_TRY(c, hipMemcpyAsync(p.h_flags[b], d_flags, (size_t)m, hipMemcpyDeviceToHost, p.s_down));
+    HIP_TRY(c, hipEventRecord(p.down[b], p.s_down));
+  }
+  for (int64_t i = std::max<int64_t>(0, nchunks - 2); i < nchunks; i++)
+    if ((rc = drain(i))) return rc;
   return TR_OK;
 }
 
