@@ -1,10 +1,19 @@
-// edge_kernel.hpp -- K3 helper `pair_cells_differ`: the `should_subdivide` test of
-// VoxelEnvironment::voxelize_valid_backbone_motion (motion-planning/VoxelEnvironment.cpp:304-341)
-// for a batch of sample pairs: do two backbone shapes differ by more than one voxel, on any axis,
-// at any backbone point?  Points are rotated into the voxel frame first (the reference stores the
-// rotated shapes, :262-272) and located with find_cell (collision/VoxelOctree.cpp:309-317: closed
-// domain check, then size_t((x - min) / d) -- a DIVISION, unlike add_line's reciprocal multiply).
-// IEEE fp64, no contraction: the flags are integer-exact functions of the points.
+// edge_kernel.hpp -- K3: the device-resident frontier of the batched swept-volume edge check
+// (VoxelEnvironment::voxelize_valid_backbone_motion, motion-planning/VoxelEnvironment.cpp:304-424,
+// driven by AbstractVoxelMotionValidator::checkMotion, AbstractVoxelMotionValidator.h:143-151).
+//
+// One bisection level of all edges at a time (edge_host.inc explains why that equals the reference's
+// depth-first order): `edge_open` turns the frontier intervals that are still undecided into new FK
+// samples (OMPL interpolate), K1 + K2 evaluate them, `edge_fold` folds the verdicts into per-edge
+// state, `edge_filter` runs the reference's `should_subdivide` on both halves of every interval and
+// emits the next frontier.  The host only reads one counter per level.
+//
+// `cells_differ` is `should_subdivide` (:304-341): do two backbone shapes differ by more than one
+// voxel, on any axis, at any backbone point?  Points are rotated into the voxel frame first (the
+// reference stores the rotated shapes, :262-272) and located with find_cell
+// (collision/VoxelOctree.cpp:309-317: closed domain check, then size_t((x - min) / d) -- a DIVISION,
+// unlike add_line's reciprocal multiply).  IEEE fp64, no contraction: the flags are integer-exact
+// functions of the points, the interpolated states bit-equal to the host / oracle arithmetic.
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
@@ -12,25 +21,39 @@
 
 namespace trk {
 
-struct PairK { int32_t a, b; };
+struct EdgeIv { int32_t e, sa, sb, pad; double ta, tb; };   // interval [ta, tb] of edge e between pool samples sa, sb
 
-// out[i]: 0 = do not subdivide, 1 = subdivide, 2 = a point lies outside the voxel domain
-// (std::domain_error in the reference).  Points are visited from the tip down, as the reference
-// does, so an early "subdivide" wins over a later out-of-domain point exactly as it does there.
-__global__ __launch_bounds__(256) void pair_cells_differ(
-    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz, int64_t ld, int P,
-    const int32_t *__restrict__ n_points /* per sample, or null = P */, const PairK *__restrict__ pairs, int64_t n_pairs, GridK g, uint8_t *__restrict__ out) {
+// OMPL 1.5.0 state-space constants as wired by motion-planning/Problem.cpp:101-163 (host-computed
+// so that device and host use the same bits): longest valid segment length per subspace.
+struct EdgeSpaceK { int N, rot, retr, S; double lvs_tension, lvs_rot, lvs_retr; };
+
+enum { EC_FRONT = 0, EC_OPEN = 1, EC_DOMAIN = 2, EC_COUNT = 4 };
+
+struct EdgeState {
+  const double *A, *B;          // [E][S] end states of the chunk's edges
+  double *rel;                  // [E] 1 / validSegmentCount
+  uint32_t *edge_ok;            // [E]
+  int32_t *nfk;                 // [E] FK samples evaluated
+  unsigned long long *first_inv;// [E] bits of the smallest invalid t (10.0 = none); "until invalid" mode only
+  unsigned long long *last_t;   // [E] bits of the largest sampled t below first_inv
+  int32_t *sample_edge;         // [cap] pool slot -> edge (-1 = padding)
+  double *sample_t;             // [cap] pool slot -> t
+  const uint64_t *bits;         // [cap/64] pool slot -> K2 verdict
+  uint32_t *counters;           // [EC_COUNT]
+};
+
+// 0 = do not subdivide, 1 = subdivide, 2 = a point lies outside the voxel domain (std::domain_error
+// in the reference).  Points are visited from the tip down, as the reference does, so an early
+// "subdivide" wins over a later out-of-domain point exactly as it does there.
+__device__ inline int cells_differ(const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+                                   int64_t ld, int P, const int32_t *__restrict__ n_points, int64_t sa, int64_t sb, const GridK &g) {
 #pragma clang fp contract(off)
-  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n_pairs) return;
-  const int64_t sa = pairs[i].a, sb = pairs[i].b;
-  uint8_t res = 0;
   int Pm = P;
   if (n_points) {
     // retraction: backbones of different lengths (VoxelEnvironment.cpp:317-326): more than one link
     // apart -> subdivide; otherwise compare the common prefix of points
     const int na = n_points[sa], nb = n_points[sb];
-    if (na + 1 < nb || na > nb + 1) { out[i] = 1; return; }
+    if (na + 1 < nb || na > nb + 1) return 1;
     Pm = na < nb ? na : nb;
   }
   for (int j = Pm - 1; j >= 0; j--) {
@@ -49,13 +72,185 @@ __global__ __launch_bounds__(256) void pair_cells_differ(
     const bool in_b = !(B.x < g.xmin || g.xmax < B.x || B.y < g.ymin || g.ymax < B.y || B.z < g.zmin || g.zmax < B.z);
     // NaN compares false everywhere above, i.e. "inside"; treat non-finite as a domain error too
     if (!in_a || !in_b || !(fabs(A.x) < 1e300) || !(fabs(B.x) < 1e300) || !(fabs(A.y) < 1e300) || !(fabs(B.y) < 1e300) ||
-        !(fabs(A.z) < 1e300) || !(fabs(B.z) < 1e300)) { res = 2; break; }
+        !(fabs(A.z) < 1e300) || !(fabs(B.z) < 1e300)) return 2;
     const long ax = (long)((A.x - g.xmin) / g.dx), ay = (long)((A.y - g.ymin) / g.dy), az = (long)((A.z - g.zmin) / g.dz);
     const long bx = (long)((B.x - g.xmin) / g.dx), by = (long)((B.y - g.ymin) / g.dy), bz = (long)((B.z - g.zmin) / g.dz);
     const long dx = ax > bx ? ax - bx : bx - ax, dy = ay > by ? ay - by : by - ay, dz = az > bz ? az - bz : bz - az;
-    if (dx > 1 || dy > 1 || dz > 1) { res = 1; break; }
+    if (dx > 1 || dy > 1 || dz > 1) return 1;
   }
-  out[i] = res;
+  return 0;
+}
+
+// One slot per lane with pred set, one atomic per wave.  Every lane of the wave must call it.
+__device__ inline uint32_t wave_alloc(bool pred, uint32_t *counter) {
+  const unsigned long long mask = __ballot(pred);
+  const int lane = (int)(threadIdx.x & 63);
+  uint32_t base = 0;
+  if (mask != 0) {
+    const int leader = __ffsll((long long)mask) - 1;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader);
+  }
+  return base + (uint32_t)__popcll(mask & (((unsigned long long)1 << lane) - 1));
+}
+
+// StateSpace::validSegmentCount of the compound space: max over subspaces of ceil(distance / lvs).
+__device__ inline unsigned valid_segment_count_dev(const EdgeSpaceK &sk, const double *a, const double *b) {
+#pragma clang fp contract(off)
+  unsigned sc = 0;
+  {
+    double s = 0;
+    for (int i = 0; i < sk.N; i++) { const double d = a[i] - b[i]; s += d * d; }
+    const unsigned v = (unsigned)ceil(sqrt(s) / sk.lvs_tension);
+    sc = v > sc ? v : sc;
+  }
+  if (sk.rot) {
+    double d = fabs(a[sk.N] - b[sk.N]);
+    d = (d > M_PI) ? 2.0 * M_PI - d : d;
+    const unsigned v = (unsigned)ceil(d / sk.lvs_rot);
+    sc = v > sc ? v : sc;
+  }
+  if (sk.retr) {
+    const int k = sk.N + sk.rot;
+    const double d = a[k] - b[k];
+    const unsigned v = (unsigned)ceil(sqrt(d * d) / sk.lvs_retr);
+    sc = v > sc ? v : sc;
+  }
+  return sc;
+}
+
+// CompoundStateSpace::interpolate: linear per tension / retraction, shortest arc on SO2.
+__device__ inline void interpolate_state_dev(const EdgeSpaceK &sk, const double *a, const double *b, double t, double *out) {
+#pragma clang fp contract(off)
+  for (int i = 0; i < sk.N; i++) out[i] = a[i] + (b[i] - a[i]) * t;
+  if (sk.rot) {
+    const int N = sk.N;
+    double diff = b[N] - a[N];
+    if (fabs(diff) <= M_PI) out[N] = a[N] + diff * t;
+    else {
+      if (diff > 0.0) diff = 2.0 * M_PI - diff; else diff = -2.0 * M_PI - diff;
+      double v = a[N] - diff * t;
+      if (v > M_PI) v -= 2.0 * M_PI; else if (v < -M_PI) v += 2.0 * M_PI;
+      out[N] = v;
+    }
+  }
+  if (sk.retr) {
+    const int k = sk.N + sk.rot;
+    out[k] = a[k] + (b[k] - a[k]) * t;
+  }
+}
+
+// level 0: both end states of every edge become pool samples 2k, 2k + 1
+__global__ __launch_bounds__(256) void edge_init(EdgeState st, EdgeSpaceK sk, int64_t E, double *__restrict__ lvl_states) {
+#pragma clang fp contract(off)
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= E) return;
+  const double *a = st.A + k * sk.S, *b = st.B + k * sk.S;
+  for (int i = 0; i < sk.S; i++) { lvl_states[(2 * k) * sk.S + i] = a[i]; lvl_states[(2 * k + 1) * sk.S + i] = b[i]; }
+  st.sample_edge[2 * k] = st.sample_edge[2 * k + 1] = (int32_t)k;
+  st.sample_t[2 * k] = 0.0; st.sample_t[2 * k + 1] = 1.0;
+  st.rel[k] = 1.0 / (double)valid_segment_count_dev(sk, a, b);
+  st.edge_ok[k] = 1; st.nfk[k] = 0;
+  st.first_inv[k] = (unsigned long long)__double_as_longlong(10.0);
+  st.last_t[k] = 0;
+}
+
+// fold the verdicts of pool samples [s0, s0 + m) into their edges
+__global__ __launch_bounds__(256) void edge_fold(EdgeState st, int64_t s0, int64_t m, int until_invalid) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (q >= m) return;
+  const int64_t s = s0 + q;
+  const int32_t e = st.sample_edge[s];
+  if (e < 0) return;
+  atomicAdd(&st.nfk[e], 1);
+  const bool ok = (st.bits[s >> 6] >> (s & 63)) & 1ull;
+  if (!ok) {
+    st.edge_ok[e] = 0;
+    // t >= 0, so the bit patterns order like the values
+    if (until_invalid) atomicMin(&st.first_inv[e], (unsigned long long)__double_as_longlong(st.sample_t[s]));
+  }
+}
+
+// should_subdivide on the candidate intervals of this level; survivors form the next frontier.
+// LEVEL0: candidate i is the whole edge i.  Otherwise candidates 2q, 2q + 1 are the distal
+// (:387-390) and proximal (:393-396) halves of open interval q, whose midpoint is pool sample s0 + q.
+template <bool LEVEL0>
+__global__ __launch_bounds__(256) void edge_filter(EdgeState st, const EdgeIv *__restrict__ open, int64_t n_cand, int64_t s0,
+                                                   const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
+                                                   int64_t ld, int P, const int32_t *__restrict__ n_points, GridK g, int until_invalid,
+                                                   EdgeIv *__restrict__ frontier) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool emit = false;
+  EdgeIv c{};
+  if (i < n_cand) {
+    if (LEVEL0) c = EdgeIv{(int32_t)i, (int32_t)(2 * i), (int32_t)(2 * i + 1), 0, 0.0, 1.0};
+    else {
+      const EdgeIv iv = open[i >> 1];
+      const double tm = (iv.ta + iv.tb) / 2;                   // :382
+      const int32_t sm = (int32_t)(s0 + (i >> 1));
+      c = (i & 1) ? EdgeIv{iv.e, iv.sa, sm, 0, iv.ta, tm} : EdgeIv{iv.e, sm, iv.sb, 0, tm, iv.tb};
+    }
+    // should_subdivide is false when the first shape is invalid (:307-310); intervals of decided edges are dropped
+    bool keep;
+    if (until_invalid) {
+      const bool va = (st.bits[c.sa >> 6] >> (c.sa & 63)) & 1ull;
+      keep = va && !(__longlong_as_double((long long)st.first_inv[c.e]) <= c.ta);
+    } else keep = st.edge_ok[c.e] != 0;
+    if (keep) {
+      const int f = cells_differ(px, py, pz, ld, P, n_points, c.sa, c.sb, g);
+      if (f == 2) {                                            // std::domain_error in the reference
+        if (atomicExch(&st.edge_ok[c.e], 0u) != 0u) atomicAdd(&st.counters[EC_DOMAIN], 1u);
+        if (until_invalid) st.first_inv[c.e] = 0;              // t = 0.0: nothing of this edge is usable
+      } else if (f == 1 && (c.tb - c.ta) > st.rel[c.e]) emit = true;   // width rule of :369-372, applied at push time
+    }
+  }
+  const uint32_t slot = wave_alloc(emit, &st.counters[EC_FRONT]);
+  if (emit) frontier[slot] = c;
+}
+
+// pop time: intervals of edges decided since they were pushed are skipped (:373-376); the rest get
+// their midpoint state and a pool slot s0 + slot.  Slots beyond the pool are counted, not written.
+__global__ __launch_bounds__(256) void edge_open(EdgeState st, EdgeSpaceK sk, const EdgeIv *__restrict__ frontier, int64_t n_bound,
+                                                 int64_t s0, int64_t cap, int until_invalid, EdgeIv *__restrict__ open,
+                                                 double *__restrict__ lvl_states) {
+#pragma clang fp contract(off)
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t n = st.counters[EC_FRONT] < n_bound ? (int64_t)st.counters[EC_FRONT] : n_bound;
+  bool take = false;
+  EdgeIv iv{};
+  if (i < n) {
+    iv = frontier[i];
+    take = until_invalid ? !(__longlong_as_double((long long)st.first_inv[iv.e]) <= iv.ta) : (st.edge_ok[iv.e] != 0);
+  }
+  const uint32_t slot = wave_alloc(take, &st.counters[EC_OPEN]);
+  if (take && s0 + (int64_t)slot < cap) {
+    open[slot] = iv;
+    const double tm = (iv.ta + iv.tb) / 2;
+    interpolate_state_dev(sk, st.A + (int64_t)iv.e * sk.S, st.B + (int64_t)iv.e * sk.S, tm, lvl_states + (int64_t)slot * sk.S);
+    st.sample_edge[s0 + slot] = iv.e;
+    st.sample_t[s0 + slot] = tm;
+  }
+}
+
+// partial.t of checkMotion(s1, s2, last_valid): the largest sampled t below the first invalid one
+// (VoxelEnvironment.cpp:403-424)
+__global__ __launch_bounds__(256) void edge_last_valid_t(EdgeState st, int64_t pool) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= pool) return;
+  const int32_t e = st.sample_edge[s];
+  if (e < 0) return;
+  const double t = st.sample_t[s];
+  if (t < __longlong_as_double((long long)st.first_inv[e])) atomicMax(&st.last_t[e], (unsigned long long)__double_as_longlong(t));
+}
+
+// bit s = pool sample s belongs to a fully valid edge (its backbone joins the edge's voxel cache)
+__global__ __launch_bounds__(256) void edge_sample_bits(EdgeState st, int64_t pool, uint64_t *__restrict__ out) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  bool on = false;
+  if (s < pool) { const int32_t e = st.sample_edge[s]; on = e >= 0 && st.edge_ok[e] != 0; }
+  const unsigned long long m = __ballot(on);
+  if ((threadIdx.x & 63) == 0 && s < pool) out[s >> 6] = m;
 }
 
 }  // namespace trk

@@ -54,6 +54,20 @@ struct Workspace {
 
 struct EventPair { hipEvent_t a, b; };
 
+// device state of the edge frontier (edge_kernel.hpp / edge_host.inc)
+struct EdgeDev {
+  int64_t cap = 0;                // pool capacity this was sized for; edges per chunk <= cap / 2
+  double *lvl_states = nullptr;   // [cap][S]  states of the level being evaluated
+  uint64_t *bits = nullptr;       // [cap/64]  K2 verdict per pool sample
+  int32_t *sample_edge = nullptr; // [cap]
+  double *sample_t = nullptr;     // [cap]
+  trk::EdgeIv *open = nullptr, *frontier = nullptr;   // [cap], [2 cap]
+  double *A = nullptr, *B = nullptr, *rel = nullptr;  // [cap/2][S] x 2, [cap/2]
+  uint32_t *edge_ok = nullptr; int32_t *nfk = nullptr;
+  unsigned long long *first_inv = nullptr, *last_t = nullptr;
+  uint32_t *counters = nullptr;
+};
+
 }  // namespace
 
 struct tr_ctx {
@@ -77,6 +91,7 @@ struct tr_ctx {
   uint64_t *d_near = nullptr;     // obstacle grid dilated by 2 cells (Chebyshev), same layout
   uint32_t n_blocks = 0;
   Workspace ws;
+  EdgeDev edge;
   int64_t max_chunk = 1 << 20;
   int64_t edge_pool_max = 1 << 22; // samples held at once by tr_validate_edges / tr_voxelize_edges
   double ch_scale = 2.0;          // milestone spacing of K2 in robot radii (env TENDON_HIP_CH_SCALE, tuning only)
@@ -464,7 +479,9 @@ void tr_destroy(tr_ctx *c) {
   Workspace &w = c->ws;
   void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_grid, c->d_near, w.homeLi, w.np, c->d_vids, c->d_vmasks, c->d_vcounts,
                   c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
-                  w.states, w.bits, w.tips, w.flags, w.L, w.npts};
+                  w.states, w.bits, w.tips, w.flags, w.L, w.npts,
+                  c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   delete c;
 }
