@@ -36,6 +36,7 @@ def main():
     edges = rb.knn_edges_gpu(states, args.k + 1)                     # k counts the vertex itself (nearestK semantics)
     edges_host = rb.knn_edges(states, args.k)
     assert np.array_equal(edges, edges_host)
+    chk.engine.reserve_edges(len(edges))
     valid, nfk = rb.validate_edges(states, edges)
     t = rb.timing
     out = {

@@ -98,6 +98,10 @@ int tr_set_grid(tr_ctx *ctx, uint32_t N, const double lim[6], const uint64_t *bl
  * calls grow it on demand, which allocates and therefore synchronises). */
 int tr_reserve(tr_ctx *ctx, int64_t n);
 
+/* Pre-size the FK sample pool and the device frontier of the edge calls (tr_validate_edges*,
+ * tr_voxelize_edges) for batches of up to n_edges edges (optional, as above). */
+int tr_reserve_edges(tr_ctx *ctx, int64_t n_edges);
+
 /* ---- forward kinematics: TendonRobot::shape / forward_kinematics ------------------------ */
 
 /* Batched TendonRobot::shape(state) (tendon/TendonRobot.h:105-131 -> tension_shape,

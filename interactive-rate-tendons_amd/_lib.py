@@ -24,7 +24,7 @@ PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_
 # every symbol include/tendon_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
     "tr_create", "tr_destroy", "tr_last_error", "tr_state_size", "tr_num_points", "tr_device",
-    "tr_home_lengths", "tr_set_grid", "tr_reserve", "tr_fk_batch", "tr_fk_batch_dev",
+    "tr_home_lengths", "tr_set_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev",
     "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_last_valid",
     "tr_check_cached", "tr_check_cached_dev", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_knn", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug",
@@ -85,25 +85,62 @@ _EXC = {TR_ERR_INVALID_ARG: InvalidArgument, TR_ERR_OUT_OF_RANGE: OutOfRange, TR
         TR_ERR_UNSUPPORTED: Unsupported}
 
 
-def hipcc_command(out=LIB_PATH):
-    return ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-            "-o", out, os.path.join(SRC_DIR, "tendon_hip.hip")]
+HIPCC_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
+OBJ_DIR = os.path.join(SRC_DIR, "_obj")
+
+
+def _units():
+    """(object name, source, extra flags): the C ABI + K2..K6, the cache merge, and K1 once per
+    (tendon count, kernel) so its 64 instantiations compile in parallel."""
+    fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "tr_types.hpp"]
+    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip"]
+    main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
+    u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),
+         ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"])]
+    for n in range(1, 9):
+        for r in (0, 1):
+            u.append(("fk_%s%d.o" % ("r" if r else "u", n), "fk_inst.hip",
+                      ["-DTRK_INST_N=%d" % n, "-DTRK_INST_RETRACT=%d" % r], fk_deps))
+    return u
 
 
 def _sources():
-    return [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR))] + [HEADER]
+    return [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR)) if not f.startswith("_")] + [HEADER]
 
 
-def build(force=False, verbose=False):
-    """Compile libtendon_hip.so in-tree for gfx950 if it is missing or older than its sources."""
-    if not force and os.path.exists(LIB_PATH):
-        t = os.path.getmtime(LIB_PATH)
-        if all(os.path.getmtime(s) <= t for s in _sources()):
-            return LIB_PATH
-    cmd = hipcc_command()
+def build(force=False, verbose=False, jobs=None):
+    """Compile libtendon_hip.so in-tree for gfx950 if it is missing or older than its sources.
+    Objects go to csrc/_obj/ (git-ignored); a unit is recompiled when any source or header is newer."""
+    newest = max(os.path.getmtime(s) for s in _sources())
+    if not force and os.path.exists(LIB_PATH) and newest <= os.path.getmtime(LIB_PATH):
+        return LIB_PATH
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    todo = []
+    for obj, src, extra, deps in _units():
+        o = os.path.join(OBJ_DIR, obj)
+        dep_t = max(os.path.getmtime(os.path.join(SRC_DIR, f)) for f in deps)
+        if force or not os.path.exists(o) or os.path.getmtime(o) < dep_t:
+            todo.append(["hipcc"] + HIPCC_FLAGS + extra + ["-c", os.path.join(SRC_DIR, src), "-o", o])
+    jobs = jobs or max(1, min(len(todo), os.cpu_count() or 1))
+    running, failed = [], None
+    while (todo or running) and failed is None:
+        while todo and len(running) < jobs:
+            cmd = todo.pop(0)
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            running.append((cmd, subprocess.Popen(cmd)))
+        cmd, p = running.pop(0)
+        if p.wait() != 0:
+            failed = cmd
+    for _, p in running:
+        p.wait()
+    if failed is not None:
+        raise subprocess.CalledProcessError(1, failed)
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + \
+           [os.path.join(OBJ_DIR, u[0]) for u in _units()]
     if verbose:
-        print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+        print(" ".join(link), flush=True)
+    subprocess.check_call(link)
     return LIB_PATH
 
 
@@ -136,6 +173,7 @@ def lib():
     L.tr_home_lengths.argtypes = [vp, dp]
     L.tr_set_grid.argtypes = [vp, C.c_uint32, dp, P(C.c_uint64), dp]
     L.tr_reserve.argtypes = [vp, i64]
+    L.tr_reserve_edges.argtypes = [vp, i64]
     L.tr_fk_batch.argtypes = [vp, dp, i64, dp, dp, dp, dp, P(C.c_uint8), P(C.c_int32)]
     L.tr_fk_batch_dev.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.tr_validate_batch.argtypes = [vp, dp, i64, P(C.c_uint64), dp, P(C.c_uint8)]

@@ -1,0 +1,137 @@
+// cache_merge.hip -- see cache_merge.hpp.  Pipeline, all on one stream:
+//   counts -> exclusive scan -> (edge, block id) keys + masks -> radix sort on the key bits in use
+//   -> reduce-by-key with OR -> block ids and per-edge counts.
+// HBM-bound integer work: ~16 B per entry per sort pass, (id_bits + edge_bits) / 8 passes.
+#include "cache_merge.hpp"
+
+#include <cstring>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_reduce_by_key.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+namespace trk {
+namespace {
+
+__global__ __launch_bounds__(256) void merge_counts(const int32_t *__restrict__ counts, const int32_t *__restrict__ sample_edge,
+                                                    int64_t pool, int64_t *__restrict__ cnt, uint64_t *__restrict__ scalars) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pool) return;
+  const int c = counts[i];
+  if (c < 0) scalars[1] = 1;
+  cnt[i] = (sample_edge[i] >= 0 && c > 0) ? c : 0;
+}
+
+__global__ __launch_bounds__(256) void merge_keys(const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks,
+                                                  const int64_t *__restrict__ cnt, const int64_t *__restrict__ offs,
+                                                  const int32_t *__restrict__ sample_edge, int64_t pool, int64_t ld, int id_bits,
+                                                  uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= pool) return;
+  const int64_t c = cnt[i], o = offs[i];
+  if (c == 0) return;
+  const uint64_t hi = (uint64_t)(uint32_t)sample_edge[i] << id_bits;
+  for (int64_t k = 0; k < c; k++) {
+    keys[o + k] = hi | ids[k * ld + i];
+    vals[o + k] = masks[k * ld + i];
+  }
+}
+
+__global__ __launch_bounds__(256) void merge_finish(const uint64_t *__restrict__ ukeys, const uint64_t *__restrict__ scalars,
+                                                    int id_bits, uint32_t *__restrict__ uids, int32_t *__restrict__ ecount) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)scalars[0]) return;
+  const uint64_t k = ukeys[i];
+  uids[i] = (uint32_t)(k & (((uint64_t)1 << id_bits) - 1));
+  atomicAdd(&ecount[k >> id_bits], 1);
+}
+
+struct BitOr { __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a | b; } };
+
+int bits_for(uint64_t n) { int b = 1; while (((uint64_t)1 << b) < n) b++; return b; }
+
+template <typename T>
+hipError_t grow(T **p, size_t count) {
+  if (*p) { (void)hipFree(*p); *p = nullptr; }
+  return hipMalloc((void **)p, (count ? count : 1) * sizeof(T));
+}
+
+#define MERGE_TRY(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return e_; } while (0)
+
+}  // namespace
+
+void merge_free(MergeScratch &ms) {
+  void *ptrs[] = {ms.cnt, ms.offs, ms.keys[0], ms.keys[1], ms.vals[0], ms.vals[1], ms.ukeys, ms.uvals, ms.uids, ms.ecount, ms.scalars, ms.tmp};
+  for (void *p : ptrs) if (p) (void)hipFree(p);
+  ms = MergeScratch{};
+}
+
+hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint64_t *d_masks, const int32_t *d_counts,
+                             const int32_t *d_sample_edge, int64_t pool, int64_t ld, uint32_t n_blocks, int64_t n_edges,
+                             int64_t *n_unique, int *overflow, hipStream_t stream) {
+  *n_unique = 0; *overflow = 0;
+  if (pool <= 0 || n_edges <= 0) return hipSuccess;
+  const int id_bits = bits_for(n_blocks), e_bits = bits_for((uint64_t)n_edges);
+  if (id_bits + e_bits > 64) return hipErrorInvalidValue;
+  if (ms.cap_items < pool + 1) {
+    MERGE_TRY(grow(&ms.cnt, (size_t)pool + 1));
+    MERGE_TRY(grow(&ms.offs, (size_t)pool + 1));
+    ms.cap_items = pool + 1;
+  }
+  if (ms.cap_edges < n_edges) { MERGE_TRY(grow(&ms.ecount, (size_t)n_edges)); ms.cap_edges = n_edges; }
+  if (!ms.scalars) MERGE_TRY(grow(&ms.scalars, 2));
+  auto need_tmp = [&](size_t bytes) -> hipError_t {
+    if (ms.cap_tmp >= bytes) return hipSuccess;
+    MERGE_TRY(grow((char **)&ms.tmp, bytes + bytes / 4));
+    ms.cap_tmp = bytes + bytes / 4;
+    return hipSuccess;
+  };
+  const dim3 gp((unsigned)((pool + 255) / 256)), b256(256);
+
+  MERGE_TRY(hipMemsetAsync(ms.scalars, 0, 2 * sizeof(uint64_t), stream));
+  MERGE_TRY(hipMemsetAsync(ms.ecount, 0, (size_t)n_edges * sizeof(int32_t), stream));
+  MERGE_TRY(hipMemsetAsync(ms.cnt + pool, 0, sizeof(int64_t), stream));
+  hipLaunchKernelGGL(merge_counts, gp, b256, 0, stream, d_counts, d_sample_edge, pool, ms.cnt, ms.scalars);
+  MERGE_TRY(hipGetLastError());
+  size_t bytes = 0;
+  MERGE_TRY(rocprim::exclusive_scan(nullptr, bytes, ms.cnt, ms.offs, (int64_t)0, (size_t)pool + 1, rocprim::plus<int64_t>(), stream));
+  MERGE_TRY(need_tmp(bytes));
+  MERGE_TRY(rocprim::exclusive_scan(ms.tmp, bytes, ms.cnt, ms.offs, (int64_t)0, (size_t)pool + 1, rocprim::plus<int64_t>(), stream));
+  int64_t nnz = 0;
+  uint64_t sc[2];
+  MERGE_TRY(hipMemcpyAsync(&nnz, ms.offs + pool, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+  MERGE_TRY(hipMemcpyAsync(sc, ms.scalars, sizeof(sc), hipMemcpyDeviceToHost, stream));
+  MERGE_TRY(hipStreamSynchronize(stream));
+  if (sc[1]) { *overflow = 1; return hipSuccess; }
+  if (nnz == 0) return hipSuccess;
+  if (ms.cap_nnz < nnz) {
+    const size_t want = (size_t)nnz + (size_t)nnz / 4 + 1024;
+    for (int b = 0; b < 2; b++) { MERGE_TRY(grow(&ms.keys[b], want)); MERGE_TRY(grow(&ms.vals[b], want)); }
+    MERGE_TRY(grow(&ms.ukeys, want));
+    MERGE_TRY(grow(&ms.uvals, want));
+    MERGE_TRY(grow(&ms.uids, want));
+    ms.cap_nnz = (int64_t)want;
+  }
+  hipLaunchKernelGGL(merge_keys, gp, b256, 0, stream, d_ids, d_masks, ms.cnt, ms.offs, d_sample_edge, pool, ld, id_bits, ms.keys[0], ms.vals[0]);
+  MERGE_TRY(hipGetLastError());
+
+  rocprim::double_buffer<uint64_t> kb(ms.keys[0], ms.keys[1]), vb(ms.vals[0], ms.vals[1]);
+  bytes = 0;
+  MERGE_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kb, vb, (size_t)nnz, 0u, (unsigned)(id_bits + e_bits), stream));
+  MERGE_TRY(need_tmp(bytes));
+  MERGE_TRY(rocprim::radix_sort_pairs(ms.tmp, bytes, kb, vb, (size_t)nnz, 0u, (unsigned)(id_bits + e_bits), stream));
+
+  bytes = 0;
+  MERGE_TRY(rocprim::reduce_by_key(nullptr, bytes, kb.current(), vb.current(), (size_t)nnz, ms.ukeys, ms.uvals, ms.scalars, BitOr(),
+                                   rocprim::equal_to<uint64_t>(), stream));
+  MERGE_TRY(need_tmp(bytes));
+  MERGE_TRY(rocprim::reduce_by_key(ms.tmp, bytes, kb.current(), vb.current(), (size_t)nnz, ms.ukeys, ms.uvals, ms.scalars, BitOr(),
+                                   rocprim::equal_to<uint64_t>(), stream));
+  hipLaunchKernelGGL(merge_finish, dim3((unsigned)((nnz + 255) / 256)), b256, 0, stream, ms.ukeys, ms.scalars, id_bits, ms.uids, ms.ecount);
+  MERGE_TRY(hipGetLastError());
+  MERGE_TRY(hipMemcpyAsync(sc, ms.scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  MERGE_TRY(hipStreamSynchronize(stream));
+  *n_unique = (int64_t)sc[0];
+  return hipSuccess;
+}
+
+}  // namespace trk

@@ -1,0 +1,35 @@
+// cache_merge.hpp -- device-side union of the voxel sets of an edge's FK samples: the roadmap's
+// edge voxel cache (VoxelEnvironment.cpp:406-422 ORs the sampled backbones into one VoxelOctree;
+// VoxelCachedLazyPRM.cpp:1751-1775 stores it per edge).  Separate translation unit (rocPRIM's sort /
+// scan / reduce-by-key templates compile independently of the FK kernels).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace trk {
+
+// Scratch owned by the merge; grows on demand, freed by merge_free.
+struct MergeScratch {
+  int64_t cap_items = 0, cap_nnz = 0;
+  size_t cap_tmp = 0;
+  int64_t *cnt = nullptr, *offs = nullptr;        // [items + 1]
+  uint64_t *keys[2] = {nullptr, nullptr};         // [nnz] (edge << id_bits) | block id
+  uint64_t *vals[2] = {nullptr, nullptr};         // [nnz] masks
+  uint64_t *ukeys = nullptr, *uvals = nullptr;    // [nnz] unique keys, OR-ed masks
+  uint32_t *uids = nullptr;                       // [nnz] block id of each unique key
+  int32_t *ecount = nullptr;                      // [edges]
+  int64_t cap_edges = 0;
+  uint64_t *scalars = nullptr;                    // [0] unique count, [1] overflow flag
+  void *tmp = nullptr;
+};
+
+// Per-sample block lists (ids / masks stored as columns [maxB][ld], counts[i] entries, counts < 0 =
+// overflow) of pool samples [0, pool) -> per-edge sorted, duplicate-free lists on the device:
+//   ms.uids / ms.uvals [*n_unique] ordered by (edge, block id), ms.ecount[e] entries per edge.
+// Returns hipSuccess, or an error; *overflow != 0 when a sample's list had overflowed.
+hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint64_t *d_masks, const int32_t *d_counts,
+                             const int32_t *d_sample_edge, int64_t pool, int64_t ld, uint32_t n_blocks, int64_t n_edges,
+                             int64_t *n_unique, int *overflow, hipStream_t stream);
+void merge_free(MergeScratch &ms);
+
+}  // namespace trk

@@ -294,16 +294,6 @@ __device__ __forceinline__ void rk4_step_routed(double (&R)[9], double (&v)[3], 
   for (int q = 0; q < 3; q++) { v[q] = av[q]; u[q] = au[q]; }
 }
 
-struct FkOut {
-  double *__restrict__ px, *__restrict__ py, *__restrict__ pz;   // [P][ld]
-  double *__restrict__ R;                                        // [9][P][ld] or null
-  double *__restrict__ L;                                        // [n] or null
-  double *__restrict__ Li;                                       // [N][ld] or null
-  double *__restrict__ tips;                                     // [n][3] or null
-  uint8_t *__restrict__ converged;                               // [n] or null
-  int32_t *__restrict__ n_points;                                // [n] or null
-  double *__restrict__ home_Li;                                  // [N][ld] or null (retraction kernel only)
-};
 
 // K1 for the shared arc-length grid (retraction disabled).
 //   tab:   [(nsteps*3 + 1)][N][6] routing table; entry 0 = base (s_start), then 3 per step

@@ -1,0 +1,29 @@
+// fk_launch.hpp -- host-side launch interface of K1.  Each (tendon count, kernel) pair is its own
+// translation unit (fk_inst.hip compiled with -DTRK_INST_N=.. -DTRK_INST_RETRACT=..) so the 64
+// instantiations compile in parallel; tendon_hip.hip only sees these declarations.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+
+namespace trk {
+
+struct FkLaunch {
+  const double *d_states; int64_t n, ld;
+  RobotK K;
+  bool rotation, write_R;
+  // shared arc-length grid (retraction disabled)
+  const double *d_tab; const StepK *d_steps; int n_steps;
+  // per-lane grid (retraction enabled)
+  const PolyK *d_poly; double *pscr;
+  FkOut out;
+  hipStream_t stream;
+};
+
+template <int N> void launch_fk_uniform(const FkLaunch &a);
+template <int N> void launch_fk_retract(const FkLaunch &a);
+
+#define TRK_DECL_FK(N) template <> void launch_fk_uniform<N>(const FkLaunch &); template <> void launch_fk_retract<N>(const FkLaunch &);
+TRK_DECL_FK(1) TRK_DECL_FK(2) TRK_DECL_FK(3) TRK_DECL_FK(4) TRK_DECL_FK(5) TRK_DECL_FK(6) TRK_DECL_FK(7) TRK_DECL_FK(8)
+#undef TRK_DECL_FK
+
+}  // namespace trk

@@ -25,11 +25,11 @@
 
 #include "../../include/tendon_hip.h"
 #include "tr_types.hpp"
-#include "fk_kernel.hpp"
-#include "fk_retract_kernel.hpp"
+#include "fk_launch.hpp"
 #include "sweep_kernel.hpp"
 #include "edge_kernel.hpp"
 #include "knn_kernel.hpp"
+#include "cache_merge.hpp"
 
 namespace {
 
@@ -92,6 +92,7 @@ struct tr_ctx {
   uint32_t n_blocks = 0;
   Workspace ws;
   EdgeDev edge;
+  trk::MergeScratch merge;       // device-side union of edge voxel caches (cache_merge.hip)
   int64_t max_chunk = 1 << 20;
   int64_t edge_pool_max = 1 << 22; // samples held at once by tr_validate_edges / tr_voxelize_edges
   double ch_scale = 2.0;          // milestone spacing of K2 in robot radii (env TENDON_HIP_CH_SCALE, tuning only)
@@ -277,62 +278,20 @@ struct ProfScope {
   }
 };
 
-// ---- K1 launch -----------------------------------------------------------------------------
-template <int N, bool ROT, bool WR>
-void launch_fk_t(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
-  const unsigned grid = (unsigned)((n + 63) / 64);
-  hipLaunchKernelGGL((trk::fk_rk4_batch_uniform<N, ROT, WR>), dim3(grid), dim3(64), 0, s, d_states, n, ld, ctx->K,
-                     ctx->d_tab, ctx->d_steps, (int)ctx->steps.size(), out);
-}
-template <int N>
-void launch_fk_n(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
-  const bool rot = ctx->K.enable_rotation, wr = out.R != nullptr;
-  if (rot) { if (wr) launch_fk_t<N, true, true>(ctx, d_states, n, ld, out, s); else launch_fk_t<N, true, false>(ctx, d_states, n, ld, out, s); }
-  else     { if (wr) launch_fk_t<N, false, true>(ctx, d_states, n, ld, out, s); else launch_fk_t<N, false, false>(ctx, d_states, n, ld, out, s); }
-}
-template <int N, bool ROT, bool WR>
-void launch_fkr_t(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
-  const unsigned grid = (unsigned)((n + 63) / 64);
-  hipLaunchKernelGGL((trk::fk_rk4_batch_retract<N, ROT, WR>), dim3(grid), dim3(64), 0, s, d_states, n, ld, ctx->K,
-                     ctx->d_poly, ctx->ws.acc, out);
-}
-template <int N>
-void launch_fkr_n(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
-  const bool rot = ctx->K.enable_rotation, wr = out.R != nullptr;
-  if (rot) { if (wr) launch_fkr_t<N, true, true>(ctx, d_states, n, ld, out, s); else launch_fkr_t<N, true, false>(ctx, d_states, n, ld, out, s); }
-  else     { if (wr) launch_fkr_t<N, false, true>(ctx, d_states, n, ld, out, s); else launch_fkr_t<N, false, false>(ctx, d_states, n, ld, out, s); }
-}
-
+// ---- K1 launch (instantiations live in fk_inst.hip objects) ------------------------------------
 // With retraction the kernel uses ws.acc (leading dimension ws.ld) as scratch for the range()
 // abscissae, so ld must equal ws.ld there.
 int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
   if (n <= 0) return TR_OK;
   ProfScope ps(ctx, 0, s);
-  if (ctx->K.enable_retraction) {
-    if (ld != ctx->ws.ld) return fail(ctx, TR_ERR_INVALID_ARG, "retraction: ld must equal the workspace leading dimension (tr_reserve)");
-    switch (ctx->K.n_tendons) {
-      case 1: launch_fkr_n<1>(ctx, d_states, n, ld, out, s); break;
-      case 2: launch_fkr_n<2>(ctx, d_states, n, ld, out, s); break;
-      case 3: launch_fkr_n<3>(ctx, d_states, n, ld, out, s); break;
-      case 4: launch_fkr_n<4>(ctx, d_states, n, ld, out, s); break;
-      case 5: launch_fkr_n<5>(ctx, d_states, n, ld, out, s); break;
-      case 6: launch_fkr_n<6>(ctx, d_states, n, ld, out, s); break;
-      case 7: launch_fkr_n<7>(ctx, d_states, n, ld, out, s); break;
-      case 8: launch_fkr_n<8>(ctx, d_states, n, ld, out, s); break;
-      default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
-    }
-    HIP_TRY(ctx, hipGetLastError());
-    return TR_OK;
-  }
+  const bool ret = ctx->K.enable_retraction;
+  if (ret && ld != ctx->ws.ld) return fail(ctx, TR_ERR_INVALID_ARG, "retraction: ld must equal the workspace leading dimension (tr_reserve)");
+  const trk::FkLaunch a{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, out.R != nullptr, ctx->d_tab, ctx->d_steps,
+                        (int)ctx->steps.size(), ctx->d_poly, ctx->ws.acc, out, s};
   switch (ctx->K.n_tendons) {
-    case 1: launch_fk_n<1>(ctx, d_states, n, ld, out, s); break;
-    case 2: launch_fk_n<2>(ctx, d_states, n, ld, out, s); break;
-    case 3: launch_fk_n<3>(ctx, d_states, n, ld, out, s); break;
-    case 4: launch_fk_n<4>(ctx, d_states, n, ld, out, s); break;
-    case 5: launch_fk_n<5>(ctx, d_states, n, ld, out, s); break;
-    case 6: launch_fk_n<6>(ctx, d_states, n, ld, out, s); break;
-    case 7: launch_fk_n<7>(ctx, d_states, n, ld, out, s); break;
-    case 8: launch_fk_n<8>(ctx, d_states, n, ld, out, s); break;
+#define TRK_CASE(N) case N: if (ret) trk::launch_fk_retract<N>(a); else trk::launch_fk_uniform<N>(a); break;
+    TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
+#undef TRK_CASE
     default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
   }
   HIP_TRY(ctx, hipGetLastError());
@@ -483,6 +442,7 @@ void tr_destroy(tr_ctx *c) {
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
                   c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters};
   for (void *p : ptrs) if (p) (void)hipFree(p);
+  trk::merge_free(c->merge);
   delete c;
 }
 
@@ -882,7 +842,7 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
   if (n == 0) return TR_OK;
   if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   HIP_TRY(c, hipSetDevice(c->device));
-  const int64_t chunk = std::min<int64_t>(c->max_chunk, 1 << 15);
+  const int64_t chunk = std::min<int64_t>(c->max_chunk, 1 << 18);   // block-list scratch: 12 B x (2P + 16) per configuration
   int rc;
   if ((rc = ensure_workspace(c, std::min(n, chunk)))) return rc;
   if ((rc = ensure_staging(c, std::min(n, chunk)))) return rc;

@@ -53,3 +53,19 @@ struct GridK {
   int32_t rot_is_identity;
   int32_t pad_;
 };
+
+namespace trk {
+
+// Outputs of K1 (both kernels); null = not wanted.
+struct FkOut {
+  double *__restrict__ px, *__restrict__ py, *__restrict__ pz;   // [P][ld]
+  double *__restrict__ R;                                        // [9][P][ld] or null
+  double *__restrict__ L;                                        // [n] or null
+  double *__restrict__ Li;                                       // [N][ld] or null
+  double *__restrict__ tips;                                     // [n][3] or null
+  uint8_t *__restrict__ converged;                               // [n] or null
+  int32_t *__restrict__ n_points;                                // [n] or null
+  double *__restrict__ home_Li;                                  // [N][ld] or null (retraction kernel only)
+};
+
+}  // namespace trk

@@ -98,6 +98,10 @@ class Engine:
     def reserve(self, n):
         L.check(self._ctx, self.lib.tr_reserve(self._ctx, int(n)))
 
+    def reserve_edges(self, n_edges):
+        """Pre-size the sample pool / device frontier of the edge calls."""
+        L.check(self._ctx, self.lib.tr_reserve_edges(self._ctx, int(n_edges)))
+
     def set_debug(self, bits):
         L.check(self._ctx, self.lib.tr_set_debug(self._ctx, int(bits)))
 
