@@ -175,6 +175,15 @@ int tr_validate_edges(tr_ctx *ctx, const tr_space_params *sp, const double *a, c
 int tr_validate_edges_last_valid(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
                                  int64_t n_edges, uint64_t *valid_bits, double *last_valid_t, int32_t *n_fk);
 
+/* Batched discrete edge check: VoxelBackboneDiscreteMotionValidator::generic_voxelize
+ * (motion-planning/VoxelBackboneDiscreteMotionValidator.cpp:9-79, the loop of
+ * ompl::base::DiscreteMotionValidator::checkMotion): samples a, interpolate(i / nd) for
+ * i = 1 .. nd-1 with nd = validSegmentCount(a, b), then b; the edge is valid iff every sample is a
+ * valid state.  last_valid_t (optional) = PartialVoxelization::t, n_fk (optional) = samples the
+ * reference's sequential loop evaluates (it stops after the first invalid one). */
+int tr_validate_edges_discrete(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
+                               int64_t n_edges, uint64_t *valid_bits, double *last_valid_t, int32_t *n_fk);
+
 /* ---- cached voxel sets vs obstacles: VoxelOctree::collides on roadmap caches ------------ */
 
 /* Batched `obstacles.collides(*cached_voxels)` for roadmap vertices / edges

@@ -7,6 +7,8 @@
 //   motion_planning::VoxelEnvironment                                   motion-planning/VoxelEnvironment.h:31-49
 //   motion_planning::VoxelBackboneValidityChecker                       motion-planning/VoxelBackboneValidityChecker.h:28-58
 //   motion_planning::VoxelBackboneMotionValidator                       motion-planning/VoxelBackboneMotionValidator.h
+//   motion_planning::VoxelBackboneDiscreteMotionValidator               motion-planning/VoxelBackboneDiscreteMotionValidator.h
+//   motion_planning::VoxelCaches, voxelize_states, caches_collide       the cache loops of VoxelCachedLazyPRM.cpp
 //
 // Error behaviour: every tr_status is rethrown as the C++ exception type the reference throws at
 // the same condition (std::invalid_argument, std::out_of_range, std::domain_error,
@@ -254,30 +256,135 @@ class VoxelBackboneValidityChecker {
   tr_ctx *ctx_;
 };
 
-/// VoxelBackboneMotionValidator: checkMotion(s1, s2) and its batched form.
+/// Sparse voxel set as the roadmap caches store it (VoxelCachedLazyPRM.h:165-179; CSR over items).
+struct VoxelCaches {
+  std::vector<int64_t> offsets{0};          // [items + 1]
+  std::vector<uint32_t> block_ids;          // ((bx * Nb) + by) * Nb + bz
+  std::vector<uint64_t> masks;              // bit x*16 + y*4 + z
+  std::vector<bool> usable;                 // shape-valid vertex / fully valid edge
+  size_t items() const { return offsets.size() - 1; }
+};
+
+namespace detail {
+inline std::vector<bool> unpack(const std::vector<uint64_t> &bits, size_t n) {
+  std::vector<bool> out(n);
+  for (size_t i = 0; i < n; i++) out[i] = (bits[i >> 6] >> (i & 63)) & 1u;
+  return out;
+}
+inline void fetch(tr_ctx *c, VoxelCaches &vc) {
+  const size_t nnz = (size_t)vc.offsets.back();
+  vc.block_ids.resize(nnz); vc.masks.resize(nnz);
+  check(c, tr_voxelize_fetch(c, vc.block_ids.data(), vc.masks.data(), (int64_t)nnz));
+}
+}  // namespace detail
+
+/// AbstractVoxelValidityChecker::voxelize for a batch of states (VoxelCachedLazyPRM.cpp:2816-2823):
+/// the backbone voxel set of every shape-valid state, plus fk_shape.p.back() as the vertex tip.
+inline VoxelCaches voxelize_states(const VoxelBackboneValidityChecker &vc, const std::vector<double> &states, size_t n,
+                                   std::vector<double> *tips = nullptr) {
+  if (states.size() != n * vc.robot().state_size()) throw std::invalid_argument("State is not the right size");
+  VoxelCaches out;
+  out.offsets.assign(n + 1, 0);
+  std::vector<uint64_t> bits((n + 63) / 64);
+  if (tips) tips->resize(3 * n);
+  check(vc.context(), tr_voxelize_batch(vc.context(), states.data(), (int64_t)n, out.offsets.data(), bits.data(),
+                                        tips ? tips->data() : nullptr));
+  out.usable = detail::unpack(bits, n);
+  detail::fetch(vc.context(), out);
+  return out;
+}
+
+/// obstacles.collides(*cached_voxels) for every cached item against the checker's current grid
+/// (VoxelCachedLazyPRM.cpp:2397-2411, :2497-2509).
+inline std::vector<bool> caches_collide(const VoxelBackboneValidityChecker &vc, const VoxelCaches &caches) {
+  const size_t n = caches.items();
+  std::vector<uint64_t> bits((n + 63) / 64);
+  check(vc.context(), tr_check_cached(vc.context(), caches.block_ids.data(), caches.masks.data(), caches.offsets.data(),
+                                      (int64_t)n, bits.data()));
+  return detail::unpack(bits, n);
+}
+
+/// VoxelBackboneMotionValidator: checkMotion(s1, s2), checkMotion(s1, s2, last_valid), voxelize(a, b)
+/// and their batched forms.
 class VoxelBackboneMotionValidator {
  public:
   explicit VoxelBackboneMotionValidator(const VoxelBackboneValidityChecker &vc) : vc_(vc) {}
+  virtual ~VoxelBackboneMotionValidator() = default;
   tr_space_params space{0.02, 0.01, 0.0001};      // Problem.h:59-62
 
   bool checkMotion(const std::vector<double> &a, const std::vector<double> &b) const {   // AbstractVoxelMotionValidator.h:143-151
     return checkMotionBatch(a, b, 1)[0];
   }
+  /// AbstractVoxelMotionValidator.h:153-169: last_valid = (interpolate(a, b, t), t) with t = PartialVoxelization::t
+  bool checkMotion(const std::vector<double> &a, const std::vector<double> &b,
+                   std::pair<std::vector<double>, double> &last_valid) const {
+    std::vector<double> t;
+    const bool ok = checkMotionBatch(a, b, 1, nullptr, &t)[0];
+    last_valid.second = t[0];
+    last_valid.first = interpolate(a, b, t[0]);
+    return ok;
+  }
   std::vector<bool> checkMotionBatch(const std::vector<double> &a, const std::vector<double> &b, size_t n,
-                                     std::vector<int32_t> *n_fk = nullptr) const {
+                                     std::vector<int32_t> *n_fk = nullptr, std::vector<double> *last_valid_t = nullptr) const {
     const size_t S = vc_.robot().state_size();
     if (a.size() != n * S || b.size() != n * S) throw std::invalid_argument("start and end are different sizes");
     std::vector<uint64_t> bits((n + 63) / 64);
     if (n_fk) n_fk->resize(n);
-    check(vc_.context(), tr_validate_edges(vc_.context(), &space, a.data(), b.data(), (int64_t)n, bits.data(),
-                                           n_fk ? n_fk->data() : nullptr, nullptr));
-    std::vector<bool> out(n);
-    for (size_t i = 0; i < n; i++) out[i] = (bits[i >> 6] >> (i & 63)) & 1u;
+    if (last_valid_t) last_valid_t->resize(n);
+    check(vc_.context(), run(a.data(), b.data(), (int64_t)n, bits.data(), n_fk ? n_fk->data() : nullptr,
+                             last_valid_t ? last_valid_t->data() : nullptr));
+    return detail::unpack(bits, n);
+  }
+  /// AbstractVoxelMotionValidator::voxelize(a, b) for a batch of edges (VoxelCachedLazyPRM.cpp:2890-2898):
+  /// the swept voxel set of every fully valid edge.
+  VoxelCaches voxelizeBatch(const std::vector<double> &a, const std::vector<double> &b, size_t n) const {
+    const size_t S = vc_.robot().state_size();
+    if (a.size() != n * S || b.size() != n * S) throw std::invalid_argument("start and end are different sizes");
+    VoxelCaches out;
+    out.offsets.assign(n + 1, 0);
+    std::vector<uint64_t> bits((n + 63) / 64);
+    check(vc_.context(), tr_voxelize_edges(vc_.context(), &space, a.data(), b.data(), (int64_t)n, out.offsets.data(), bits.data(), nullptr));
+    out.usable = detail::unpack(bits, n);
+    detail::fetch(vc_.context(), out);
+    return out;
+  }
+  /// CompoundStateSpace::interpolate as wired by Problem.cpp:101-163: linear, shortest arc on the SO2 rotation
+  std::vector<double> interpolate(const std::vector<double> &a, const std::vector<double> &b, double t) const {
+    const auto &rb = vc_.robot();
+    const size_t N = rb.tendons.size();
+    std::vector<double> out(a.size());
+    for (size_t i = 0; i < a.size(); i++) out[i] = a[i] + (b[i] - a[i]) * t;
+    if (rb.enable_rotation) {
+      const double kPi = 3.14159265358979323846;
+      double diff = b[N] - a[N];
+      if (std::fabs(diff) > kPi) {
+        diff = diff > 0.0 ? 2.0 * kPi - diff : -2.0 * kPi - diff;
+        double v = a[N] - diff * t;
+        if (v > kPi) v -= 2.0 * kPi; else if (v < -kPi) v += 2.0 * kPi;
+        out[N] = v;
+      }
+    }
     return out;
   }
 
- private:
+ protected:
+  virtual int run(const double *a, const double *b, int64_t n, uint64_t *bits, int32_t *n_fk, double *t) const {
+    if (t) return tr_validate_edges_last_valid(vc_.context(), &space, a, b, n, bits, t, n_fk);
+    return tr_validate_edges(vc_.context(), &space, a, b, n, bits, n_fk, nullptr);
+  }
   const VoxelBackboneValidityChecker &vc_;
+};
+
+/// VoxelBackboneDiscreteMotionValidator (motion-planning/VoxelBackboneDiscreteMotionValidator.cpp:9-79):
+/// same interface, samples at a, i / validSegmentCount, b.
+class VoxelBackboneDiscreteMotionValidator : public VoxelBackboneMotionValidator {
+ public:
+  using VoxelBackboneMotionValidator::VoxelBackboneMotionValidator;
+
+ protected:
+  int run(const double *a, const double *b, int64_t n, uint64_t *bits, int32_t *n_fk, double *t) const override {
+    return tr_validate_edges_discrete(vc_.context(), &space, a, b, n, bits, t, n_fk);
+  }
 };
 
 }  // namespace motion_planning

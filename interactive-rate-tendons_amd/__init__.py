@@ -15,13 +15,13 @@ from .engine import Engine, unpack_bits
 from .tendon import BackboneSpecs, TendonSpecs, TendonResult, TendonRobot
 from .collision import VoxelOctree
 from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelBackboneMotionValidator,
-                              FunctionTimer)
+                              VoxelBackboneDiscreteMotionValidator, FunctionTimer)
 from . import workloads, distributed, roadmap, rmp
 from .roadmap import RoadmapBuilder
 
 __all__ = [
     "TendonHipError", "InvalidArgument", "OutOfRange", "DomainError", "LengthError", "HipError", "Unsupported",
     "build", "LIB_PATH", "Engine", "unpack_bits", "BackboneSpecs", "TendonSpecs", "TendonResult", "TendonRobot",
-    "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelBackboneMotionValidator",
+    "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelBackboneMotionValidator", "VoxelBackboneDiscreteMotionValidator",
     "FunctionTimer", "workloads", "distributed", "roadmap", "RoadmapBuilder",
 ]

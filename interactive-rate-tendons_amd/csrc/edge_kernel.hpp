@@ -253,4 +253,63 @@ __global__ __launch_bounds__(256) void edge_sample_bits(EdgeState st, int64_t po
   if ((threadIdx.x & 63) == 0 && s < pool) out[s >> 6] = m;
 }
 
+// ---- discrete variant (VoxelBackboneDiscreteMotionValidator.cpp:9-79; the loop of
+// ompl::base::DiscreteMotionValidator::checkMotion): samples a, interpolate(i / nd) for i = 1..nd-1, b.
+// Edge e owns pool samples [offs[e], offs[e+1]); all of them are evaluated in one K1 + K2 pass.
+
+// per-edge validSegmentCount and sample count (a and b are always sampled)
+__global__ __launch_bounds__(256) void discrete_count(EdgeState st, EdgeSpaceK sk, int64_t E, uint32_t *__restrict__ nd, int64_t *__restrict__ cnt) {
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= E) return;
+  const unsigned n = valid_segment_count_dev(sk, st.A + k * sk.S, st.B + k * sk.S);
+  nd[k] = n;
+  cnt[k] = (int64_t)(n > 1 ? n : 1) + 1;
+}
+
+__device__ inline int64_t edge_of_sample(const int64_t *__restrict__ offs, int64_t E, int64_t q) {
+  int64_t lo = 0, hi = E;                   // offs[lo] <= q < offs[hi]
+  while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (offs[mid] <= q) lo = mid; else hi = mid; }
+  return lo;
+}
+
+// e0 = first edge of this pass, q0 = offs[e0]; pool slot of sample q is q - q0
+__global__ __launch_bounds__(256) void discrete_samples(EdgeState st, EdgeSpaceK sk, const uint32_t *__restrict__ nd, const int64_t *__restrict__ offs,
+                                                        int64_t E, int64_t q0, int64_t m, double *__restrict__ lvl_states) {
+#pragma clang fp contract(off)
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= m) return;
+  const int64_t e = edge_of_sample(offs, E, q0 + s);
+  const int64_t i = q0 + s - offs[e], cnt = offs[e + 1] - offs[e];
+  const double *a = st.A + e * sk.S, *b = st.B + e * sk.S;
+  double *out = lvl_states + s * sk.S;
+  double t;
+  if (i == 0) { t = 0.0; for (int k = 0; k < sk.S; k++) out[k] = a[k]; }
+  else if (i == cnt - 1) { t = 1.0; for (int k = 0; k < sk.S; k++) out[k] = b[k]; }
+  else { t = (double)i / (double)nd[e]; interpolate_state_dev(sk, a, b, t, out); }
+  st.sample_edge[s] = (int32_t)e;
+  st.sample_t[s] = t;
+}
+
+// first invalid sample index per edge (st.nfk doubles as that minimum, initialised to INT32_MAX)
+__global__ __launch_bounds__(256) void discrete_fold(EdgeState st, const int64_t *__restrict__ offs, int64_t q0, int64_t m) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= m) return;
+  if ((st.bits[s >> 6] >> (s & 63)) & 1ull) return;
+  const int32_t e = st.sample_edge[s];
+  atomicMin(&st.nfk[e], (int32_t)(q0 + s - offs[e]));
+}
+
+// verdict, samples the sequential loop would have evaluated, and v.t (the last valid sample's t)
+__global__ __launch_bounds__(256) void discrete_finish(EdgeState st, const uint32_t *__restrict__ nd, const int64_t *__restrict__ offs, int64_t e0, int64_t e1) {
+  const int64_t e = e0 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= e1) return;
+  const int32_t fb = st.nfk[e];
+  const int64_t cnt = offs[e + 1] - offs[e];
+  const bool ok = fb == 0x7fffffff;
+  st.edge_ok[e] = ok ? 1u : 0u;
+  st.nfk[e] = ok ? (int32_t)cnt : fb + 1;
+  const double t = ok ? 1.0 : (fb <= 1 ? 0.0 : (double)(fb - 1) / (double)nd[e]);
+  st.last_t[e] = (unsigned long long)__double_as_longlong(t);
+}
+
 }  // namespace trk

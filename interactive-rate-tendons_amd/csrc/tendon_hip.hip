@@ -66,6 +66,7 @@ struct EdgeDev {
   uint32_t *edge_ok = nullptr; int32_t *nfk = nullptr;
   unsigned long long *first_inv = nullptr, *last_t = nullptr;
   uint32_t *counters = nullptr;
+  uint32_t *nd = nullptr; int64_t *cnt = nullptr;      // discrete variant: validSegmentCount, sample offsets [cap/2 + 2]
 };
 
 }  // namespace
@@ -440,7 +441,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   delete c;

@@ -169,6 +169,21 @@ class Engine:
             nfk.ctypes.data_as(C.POINTER(C.c_int32))))
         return dict(valid=unpack_bits(bits, n), last_valid_t=lvt, n_fk=nfk)
 
+    def validate_edges_discrete(self, a, b, min_tension_change=0.02, min_rotation_change=0.01,
+                                min_retraction_change=0.0001):
+        a, b = self._states(a), self._states(b)
+        if a.shape != b.shape:
+            raise L.InvalidArgument("start and end are different sizes")
+        n = a.shape[0]
+        sp = L.TrSpaceParams(min_tension_change, min_rotation_change, min_retraction_change)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        lvt = np.zeros(n)
+        nfk = np.zeros(n, dtype=np.int32)
+        L.check(self._ctx, self.lib.tr_validate_edges_discrete(
+            self._ctx, C.byref(sp), _dp(a), _dp(b), n, bits.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(lvt),
+            nfk.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(valid=unpack_bits(bits, n), last_valid_t=lvt, n_fk=nfk)
+
     def check_cached(self, block_ids, masks, offsets):
         ids = np.ascontiguousarray(block_ids, dtype=np.uint32)
         mk = np.ascontiguousarray(masks, dtype=np.uint64)

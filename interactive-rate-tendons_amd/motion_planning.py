@@ -133,3 +133,17 @@ class VoxelBackboneMotionValidator:
 
     def checkMotion(self, s1, s2):
         return bool(self.check_motion(np.asarray(s1, float).reshape(1, -1), np.asarray(s2, float).reshape(1, -1))[0])
+
+
+class VoxelBackboneDiscreteMotionValidator(VoxelBackboneMotionValidator):
+    """motion-planning/VoxelBackboneDiscreteMotionValidator.{h,cpp}: the same interface, but an edge is
+    sampled at a, interpolate(i / validSegmentCount), b instead of bisected adaptively."""
+
+    def check_motion_detail(self, a, b):
+        return self._timers["voxelize-swept-volume"].time(
+            self.engine.validate_edges_discrete, a, b, self.min_tension_change, self.min_rotation_change,
+            self.min_retraction_change)
+
+    def check_motion_last_valid(self, a, b):
+        d = self.check_motion_detail(a, b)
+        return d["valid"], d["last_valid_t"]

@@ -1287,6 +1287,58 @@ int orc_check_motion_until_invalid(const orc_robot *rb, const orc_space_params *
   return fully;
 }
 
+/* motion-planning/VoxelBackboneDiscreteMotionValidator.cpp:9-79 (generic_voxelize) driven as
+ * AbstractVoxelMotionValidator drives it: until_invalid = 0 is voxelize_impl (per-sample validity =
+ * is_valid_shape, obstacles tested on the union, checkMotion(s1, s2), .h:143-151); until_invalid = 1 is
+ * voxelize_until_invalid_impl (per-sample validity also needs !collides(sample), .h:153-169).
+ * Returns the checkMotion verdict; *last_valid_t = PartialVoxelization::t. */
+int orc_check_motion_discrete(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                              const double inv_rot[9], const double *a, const double *b, int until_invalid,
+                              int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
+  const int S = orc_state_size(rb);
+  const int cap = max_points(rb);
+  orc_result fk, home; result_alloc(&fk, cap); result_alloc(&home, cap);
+  orc_grid *vox = orc_grid_empty_copy(obstacles), *one = orc_grid_empty_copy(obstacles);
+  double *test = (double *)malloc(sizeof(double) * (size_t)S), *pts = (double *)malloc(sizeof(double) * 3 * (size_t)cap);
+  int nfk = 0, fully;
+  double vt = 0.0;
+
+  /* one sample: FK, validity, and (if valid) its backbone joins the union */
+#define SAMPLE(cfg, ok_out) do { \
+    orc_shape(rb, (cfg), &fk); orc_home_shape_state(rb, (cfg), &home); nfk++; \
+    memcpy(pts, fk.p, sizeof(double) * 3 * (size_t)fk.n); \
+    orc_rotate_points(inv_rot, pts, fk.n); \
+    (ok_out) = orc_is_valid_shape(rb, &fk, &home); \
+    if ((ok_out) && until_invalid) { \
+      orc_grid_clear(one); orc_grid_add_piecewise_line(one, pts, fk.n); \
+      if (orc_grid_collides(obstacles, one)) (ok_out) = 0; \
+    } } while (0)
+
+  SAMPLE(a, fully);                                             /* :24-28: a is voxelised whatever its validity */
+  orc_grid_add_piecewise_line(vox, pts, fk.n);
+  unsigned nd = orc_valid_segment_count(rb, sp, a, b);          /* :40 */
+  if (nd > 1) {
+    for (unsigned i = 1; fully && i < nd; ++i) {                /* :45-58 */
+      double t = (double)i / (double)nd;
+      orc_interpolate_state(rb, a, b, t, test);
+      SAMPLE(test, fully);
+      if (fully) { vt = t; orc_grid_add_piecewise_line(vox, pts, fk.n); }
+    }
+  }
+  if (fully) {                                                   /* :62-72 */
+    SAMPLE(b, fully);
+    if (fully) { vt = 1; orc_grid_add_piecewise_line(vox, pts, fk.n); }
+  }
+#undef SAMPLE
+  int valid = fully && !orc_grid_collides(obstacles, vox);
+  if (n_fk_out) *n_fk_out = nfk;
+  if (is_fully_valid_out) *is_fully_valid_out = fully;
+  if (last_valid_t_out) *last_valid_t_out = vt;
+  orc_grid_free(vox); orc_grid_free(one); free(test); free(pts);
+  result_free(&fk); result_free(&home);
+  return valid;
+}
+
 int orc_check_motion_batch(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
                            const double inv_rot[9], const double *a, const double *b, long n,
                            uint8_t *valid, int32_t *n_fk, int nthreads) {

@@ -144,6 +144,9 @@ int  orc_check_motion(const orc_robot *rb, const orc_space_params *sp, const orc
 int  orc_check_motion_until_invalid(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
                                     const double inv_rot[9], const double *a, const double *b,
                                     int *n_fk, double *last_valid_t);
+int  orc_check_motion_discrete(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                               const double inv_rot[9], const double *a, const double *b, int until_invalid,
+                               int *n_fk, int *is_fully_valid, double *last_valid_t);
 int  orc_check_motion_batch(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
                             const double inv_rot[9], const double *a, const double *b, long n,
                             uint8_t *valid, int32_t *n_fk, int nthreads);

@@ -45,6 +45,27 @@ int main(int argc, char **argv) {
   std::vector<double> tips; std::vector<uint8_t> flags;
   auto v = vc.isValidBatch(flat, states.size(), &tips, &flags);
   for (size_t i = 0; i < v.size(); i++) std::printf("batch %d %u %.17g\n", (int)v[i], flags[i], tips[3 * i]);
+  // edges: adaptive bisection, its last_valid form, the discrete validator, swept-volume caches
+  motion_planning::VoxelBackboneMotionValidator mv(vc);
+  motion_planning::VoxelBackboneDiscreteMotionValidator dmv(vc);
+  const std::vector<std::vector<double>> ea = {{0, 0, 0}, {8, 3, 1}, {1.0, 2.0, 0.5}}, eb = {{2.5, 9.0, 4.0}, {8.5, 3.5, 1.2}, {1.5, 2.2, 0.4}};
+  std::vector<double> fa, fb;
+  for (size_t i = 0; i < ea.size(); i++) {
+    std::pair<std::vector<double>, double> lv, dlv;
+    const bool ok = mv.checkMotion(ea[i], eb[i]), ok2 = mv.checkMotion(ea[i], eb[i], lv), okd = dmv.checkMotion(ea[i], eb[i], dlv);
+    std::printf("edge %d %d %.17g %.17g %d %.17g\n", (int)ok, (int)ok2, lv.second, lv.first[0], (int)okd, dlv.second);
+    fa.insert(fa.end(), ea[i].begin(), ea[i].end()); fb.insert(fb.end(), eb[i].begin(), eb[i].end());
+  }
+  std::vector<int32_t> nfk;
+  auto ev = dmv.checkMotionBatch(fa, fb, ea.size(), &nfk);
+  for (size_t i = 0; i < ev.size(); i++) std::printf("dbatch %d %d\n", (int)ev[i], nfk[i]);
+  auto ec = mv.voxelizeBatch(fa, fb, ea.size());
+  auto vcaches = motion_planning::voxelize_states(vc, flat, states.size());
+  auto ehit = motion_planning::caches_collide(vc, ec), vhit = motion_planning::caches_collide(vc, vcaches);
+  for (size_t i = 0; i < ec.items(); i++)
+    std::printf("ecache %d %lld %d\n", (int)ec.usable[i], (long long)(ec.offsets[i + 1] - ec.offsets[i]), (int)ehit[i]);
+  for (size_t i = 0; i < vcaches.items(); i++)
+    std::printf("vcache %d %lld %d\n", (int)vcaches.usable[i], (long long)(vcaches.offsets[i + 1] - vcaches.offsets[i]), (int)vhit[i]);
   try {
     collision::VoxelOctree fine(512);
     fine.set_xlim(-0.25, 0.25); fine.set_ylim(-0.25, 0.25); fine.set_zlim(-0.25, 0.25);

@@ -56,3 +56,24 @@ def test_shim_results_match_oracle(tmp_path, irt, orc, helpers):
     assert len(set(single)) == 2                       # the slab blocks some and not others
     errs = [l for l in out if l.startswith("invalid_argument")]
     assert len(errs) == 2 and "State is not the right size" in errs[0] and "VoxelBackboneValidityChecker" in errs[1]
+    # edges through the shim: bisection, last_valid, discrete, caches
+    ea, eb = [[0, 0, 0], [8, 3, 1], [1.0, 2.0, 0.5]], [[2.5, 9.0, 4.0], [8.5, 3.5, 1.2], [1.5, 2.2, 0.4]]
+    edges = [l.split() for l in out if l.startswith("edge ")]
+    dbatch = [l.split() for l in out if l.startswith("dbatch")]
+    ecache = [l.split() for l in out if l.startswith("ecache")]
+    vcache = [l.split() for l in out if l.startswith("vcache")]
+    assert len(edges) == len(dbatch) == len(ecache) == 3 and len(vcache) == 4
+    for a, b, row, drow, crow in zip(ea, eb, edges, dbatch, ecache):
+        w = orc.check_motion(orb, og, a, b, want_swept=True)
+        wu = orc.check_motion_until_invalid(orb, og, a, b)
+        wd = orc.check_motion_discrete(orb, og, a, b, until_invalid=True)
+        assert int(row[1]) == int(w["valid"]) and int(row[2]) == int(wu["is_fully_valid"]) and float(row[3]) == wu["last_valid_t"]
+        assert float(row[4]) == a[0] + (b[0] - a[0]) * wu["last_valid_t"]
+        assert int(row[5]) == int(wd["is_fully_valid"]) and float(row[6]) == wd["last_valid_t"]
+        assert [int(drow[1]), int(drow[2])] == [int(wd["is_fully_valid"]), wd["n_fk"]]
+        assert int(crow[1]) == int(w["is_fully_valid"])
+        if w["is_fully_valid"]:
+            assert int(crow[2]) == w["swept"].nblocks() and int(crow[3]) == int(og.collides(w["swept"]))
+    for s, row in zip(states, vcache):
+        ok, _, fl = orc.is_valid_state(orb, og, s)
+        assert int(row[1]) == int((fl & 7) == 7) and (not int(row[1]) or int(row[3]) == int(not (fl & 8)))

@@ -99,3 +99,26 @@ def test_check_motion_with_last_valid(irt, orc, helpers):
         w = orc.check_motion_until_invalid(orb, og, a[i], b[i])
         assert valid[i] == w["is_fully_valid"] and lvt[i] == w["last_valid_t"], (i, lvt[i], w)
     assert (lvt[valid] == 1.0).all() and ((lvt[~valid] > 0) & (lvt[~valid] < 1)).sum() > 10
+
+
+def test_discrete_motion_validator_matches_oracle(irt, orc, helpers):
+    """VoxelBackboneDiscreteMotionValidator: verdict of checkMotion(s1, s2) (union tested against the
+    obstacles) and verdict / t / sample count of checkMotion(s1, s2, last_valid) (sequential loop)."""
+    W = irt.workloads
+    rot = W.robot_config2()
+    rot.enable_rotation = True
+    for robot, seed, step in ((W.robot_config3(), 35, 1.5), (rot, 36, 2.5)):
+        vox, _ = W.reach_environment(seed=7, n_spheres=64)
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        mv = irt.VoxelBackboneDiscreteMotionValidator(chk)
+        a, b = _edges(robot, irt, 160, seed=seed, step=step)
+        b[:3] = a[:3]                                                 # nd = 0: a and b only
+        d = mv.check_motion_detail(a, b)
+        orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+        for i in range(len(a)):
+            w0 = orc.check_motion_discrete(orb, og, a[i], b[i], until_invalid=False)
+            w1 = orc.check_motion_discrete(orb, og, a[i], b[i], until_invalid=True)
+            assert d["valid"][i] == w0["valid"] == w1["is_fully_valid"], (i, w0, w1)
+            assert d["last_valid_t"][i] == w1["last_valid_t"] and d["n_fk"][i] == w1["n_fk"], (i, d["n_fk"][i], w1)
+        assert (d["n_fk"][:3] <= 2).all() and (d["n_fk"][:3][d["valid"][:3]] == 2).all()
+        assert 0.05 < d["valid"].mean() < 0.98 and d["n_fk"].max() > 50

@@ -437,3 +437,33 @@ def test_golden_config3(orc):
     fk = rb.fk_batch(d["states"][:64])
     assert np.array_equal(fk["p"][:, -1], d["tips"][:64]) and np.array_equal(fk["L_i"], d["L_i"][:64])
     assert np.array_equal(rb.home_shape()["L_i"], d["home_L_i"])
+
+
+def test_edge_oracles_invariants(orc):
+    """The two edge checks (adaptive bisection, VoxelEnvironment.cpp:207-444; discrete sampling,
+    VoxelBackboneDiscreteMotionValidator.cpp:9-79) against facts that hold by construction."""
+    rb = straight_robot(orc, dL=0.2 / 64)
+    g = orc.Grid(128, (-0.25, 0.25) * 3)
+    sp = orc.space_params(min_tension_change=0.5)
+    a, b = np.array([0.5, 0.0, 0.2]), np.array([5.8, 0.9, 0.2])
+    nd = int(np.ceil(np.linalg.norm(a - b) / 0.5))                   # 10.75 -> 11
+    # free space: both valid; the discrete check takes a, nd - 1 interior samples and b
+    d = orc.check_motion_discrete(rb, g, a, b, sp)
+    m = orc.check_motion(rb, g, a, b, sp)
+    assert d["valid"] and m["valid"] and d["n_fk"] == nd + 1 and d["last_valid_t"] == 1.0 and m["last_valid_t"] == 1.0
+    assert 3 <= m["n_fk"] <= 2 * nd + 1
+    # a == b: two samples either way
+    assert orc.check_motion_discrete(rb, g, a, a, sp)["n_fk"] == 2 and orc.check_motion(rb, g, a, a, sp)["n_fk"] == 2
+    # an obstacle on the tip of an interior sample: both invalid; the discrete loop stops right there
+    k = nd // 2
+    mid = a + (b - a) * (k / nd)
+    _, tip, _ = orc.is_valid_state(rb, g, mid)
+    g.add_sphere(tip, 0.006)
+    assert not orc.is_valid_state(rb, g, mid)[0] and orc.is_valid_state(rb, g, a)[0] and orc.is_valid_state(rb, g, b)[0]
+    d0 = orc.check_motion_discrete(rb, g, a, b, sp)
+    d1 = orc.check_motion_discrete(rb, g, a, b, sp, until_invalid=True)
+    assert not d0["valid"] and d0["is_fully_valid"] and d0["n_fk"] == nd + 1      # shapes are fine, the union collides
+    assert not d1["is_fully_valid"] and d1["n_fk"] <= k + 1 and d1["last_valid_t"] == (d1["n_fk"] - 2) / nd
+    m0 = orc.check_motion(rb, g, a, b, sp)
+    m1 = orc.check_motion_until_invalid(rb, g, a, b, sp)
+    assert not m0["valid"] and not m1["is_fully_valid"] and 0.0 <= m1["last_valid_t"] < k / nd + 1e-12
