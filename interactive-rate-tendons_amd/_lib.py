@@ -24,7 +24,8 @@ PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_
 # every symbol include/tendon_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
     "tr_create", "tr_destroy", "tr_last_error", "tr_state_size", "tr_num_points", "tr_device",
-    "tr_home_lengths", "tr_set_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev",
+    "tr_home_lengths", "tr_set_grid", "tr_grid_add_spheres", "tr_grid_remove_interior", "tr_grid_dilate",
+    "tr_grid_dilate_sphere", "tr_get_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev",
     "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_last_valid",
     "tr_validate_edges_discrete",
     "tr_check_cached", "tr_check_cached_dev", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_knn", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
@@ -173,6 +174,11 @@ def lib():
         getattr(L, f).argtypes = [vp]
     L.tr_home_lengths.argtypes = [vp, dp]
     L.tr_set_grid.argtypes = [vp, C.c_uint32, dp, P(C.c_uint64), dp]
+    L.tr_grid_add_spheres.argtypes = [vp, dp, i64]
+    L.tr_grid_remove_interior.argtypes = [vp, C.c_int32]
+    L.tr_grid_dilate.argtypes = [vp, C.c_int32, C.c_int32]
+    L.tr_grid_dilate_sphere.argtypes = [vp, C.c_double]
+    L.tr_get_grid.argtypes = [vp, P(C.c_uint64)]
     L.tr_reserve.argtypes = [vp, i64]
     L.tr_reserve_edges.argtypes = [vp, i64]
     L.tr_fk_batch.argtypes = [vp, dp, i64, dp, dp, dp, dp, P(C.c_uint8), P(C.c_int32)]

@@ -30,6 +30,7 @@
 #include "edge_kernel.hpp"
 #include "knn_kernel.hpp"
 #include "cache_merge.hpp"
+#include "env_kernel.hpp"
 
 namespace {
 
@@ -91,6 +92,8 @@ struct tr_ctx {
   uint64_t *d_grid = nullptr;
   uint64_t *d_near = nullptr;     // obstacle grid dilated by 2 cells (Chebyshev), same layout
   uint32_t n_blocks = 0;
+  uint64_t *d_envw[2] = {nullptr, nullptr};   // environment-preparation scratch: two (Nb+2)^3 apron grids
+  uint32_t envw_blocks = 0;
   Workspace ws;
   EdgeDev edge;
   trk::MergeScratch merge;       // device-side union of edge voxel caches (cache_merge.hip)
@@ -441,7 +444,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1]};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   delete c;
@@ -499,6 +502,117 @@ int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *bloc
   c->G = g;
   c->has_grid = true;
   return TR_OK;
+}
+
+// ---- environment preparation on the resident grid (env_kernel.hpp) ---------------------------
+namespace {
+int env_begin(tr_ctx *c) {
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  const uint32_t nbw = (uint32_t)((c->G.Nb + 2) * (c->G.Nb + 2) * (c->G.Nb + 2));
+  if (c->envw_blocks < nbw) {
+    HIP_TRY(c, hipDeviceSynchronize());
+    for (int k = 0; k < 2; k++) { int rc = dev_alloc(c, &c->d_envw[k], (size_t)nbw); if (rc) return rc; }
+    c->envw_blocks = nbw;
+  }
+  return TR_OK;
+}
+// the fast-skip grid of K2 follows every edit of the obstacle grid
+int env_end(tr_ctx *c) {
+  hipLaunchKernelGGL(trk::dilate2_blocks, dim3(c->n_blocks), dim3(64), 0, nullptr, c->d_grid, c->d_near, c->G.Nb);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipDeviceSynchronize());
+  return TR_OK;
+}
+}  // namespace
+
+int tr_get_grid(tr_ctx *c, uint64_t *blocks) {
+  if (!c || !blocks) return fail(c, TR_ERR_INVALID_ARG, "null argument");
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipMemcpy(blocks, c->d_grid, (size_t)c->n_blocks * sizeof(uint64_t), hipMemcpyDeviceToHost));
+  return TR_OK;
+}
+
+int tr_grid_add_spheres(tr_ctx *c, const double *spheres, int64_t n) {
+  if (!c || n < 0 || (n > 0 && !spheres)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  int rc;
+  if ((rc = env_begin(c))) return rc;
+  if (n == 0) return TR_OK;
+  const GridK &g = c->G;
+  // nearest_block_idx (collision/VoxelOctree.cpp:272-283): int((x - min) / d), / 4 toward zero, clamped
+  auto blk = [&](double v, double lo, double dd) {
+    const int i = (int)((v - lo) / dd);
+    return std::min(g.Nb - 1, std::max(0, i / 4));
+  };
+  std::vector<trk::SphereK> hs((size_t)n);
+  for (int64_t k = 0; k < n; k++) {
+    const double cx = spheres[4 * k], cy = spheres[4 * k + 1], cz = spheres[4 * k + 2], r = spheres[4 * k + 3];
+    trk::SphereK &q = hs[(size_t)k];
+    q.cx = cx; q.cy = cy; q.cz = cz; q.rr = r * r;
+    q.lo[0] = blk(cx - r, g.xmin, g.dx); q.lo[1] = blk(cy - r, g.ymin, g.dy); q.lo[2] = blk(cz - r, g.zmin, g.dz);
+    q.hi[0] = blk(cx + r, g.xmin, g.dx); q.hi[1] = blk(cy + r, g.ymin, g.dy); q.hi[2] = blk(cz + r, g.zmin, g.dz);
+    // add_point (:319-323): closed domain test, then nearest_cell = int((x - min) / d) clamped (:295-307)
+    const bool in = !(cx < g.xmin || g.xmax < cx || cy < g.ymin || g.ymax < cy || cz < g.zmin || g.zmax < cz);
+    auto cell = [&](double v, double lo, double dd) { return std::min(g.N - 1, std::max(0, (int)((v - lo) / dd))); };
+    q.pc[0] = in ? cell(cx, g.xmin, g.dx) : -1; q.pc[1] = in ? cell(cy, g.ymin, g.dy) : -1; q.pc[2] = in ? cell(cz, g.zmin, g.dz) : -1;
+    q.pad_ = 0;
+  }
+  trk::SphereK *d_s = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_s, hs.size() * sizeof(trk::SphereK)));
+  hipError_t e = hipMemcpy(d_s, hs.data(), hs.size() * sizeof(trk::SphereK), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const int per = 4096;                                     // spheres per launch (a wave loops over them)
+    for (int64_t k = 0; k < n && e == hipSuccess; k += per) {
+      hipLaunchKernelGGL(trk::grid_add_spheres, dim3(c->n_blocks), dim3(64), 0, nullptr, c->d_grid, g, d_s + k, (int)std::min<int64_t>(per, n - k));
+      e = hipGetLastError();
+    }
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipFree(d_s);
+  HIP_TRY(c, e);
+  return env_end(c);
+}
+
+int tr_grid_remove_interior(tr_ctx *c, int32_t keep_diagonal) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  int rc;
+  if ((rc = env_begin(c))) return rc;
+  hipLaunchKernelGGL(trk::grid_remove_interior, dim3(c->n_blocks), dim3(64), 0, nullptr, c->d_grid, c->d_envw[0], c->G.Nb, (int)(keep_diagonal != 0));
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipMemcpy(c->d_grid, c->d_envw[0], (size_t)c->n_blocks * sizeof(uint64_t), hipMemcpyDeviceToDevice));
+  return env_end(c);
+}
+
+int tr_grid_dilate(tr_ctx *c, int32_t num, int32_t use_diagonal) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  int rc;
+  if ((rc = env_begin(c))) return rc;
+  const int Nb = c->G.Nb, NbW = Nb + 2;
+  const unsigned nbw = (unsigned)(NbW * NbW * NbW);
+  // four dilations at a time, clipped to the grid after each group (dilate_one_impl, VoxelOctree.cpp:693-762)
+  for (; num > 0; num -= 4) {
+    const int n = std::min(num, 4);
+    hipLaunchKernelGGL(trk::grid_embed, dim3((nbw + 255) / 256), dim3(256), 0, nullptr, c->d_grid, c->d_envw[0], Nb);
+    int cur = 0;
+    for (int s = 0; s < n; s++, cur ^= 1)
+      hipLaunchKernelGGL(trk::grid_dilate_step, dim3(nbw), dim3(64), 0, nullptr, c->d_envw[cur], c->d_envw[cur ^ 1], NbW, (int)(use_diagonal != 0));
+    hipLaunchKernelGGL(trk::grid_extract, dim3((c->n_blocks + 255) / 256), dim3(256), 0, nullptr, c->d_envw[cur], c->d_grid, Nb);
+    HIP_TRY(c, hipGetLastError());
+  }
+  return env_end(c);
+}
+
+int tr_grid_dilate_sphere(tr_ctx *c, double r) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  // "over-approximation with multiple dilations" (VoxelOctree.cpp:950-952)
+  return tr_grid_dilate(c, (int)std::round(r / std::min(c->G.dx, std::min(c->G.dy, c->G.dz))), 0);
 }
 
 int tr_reserve(tr_ctx *c, int64_t n) {

@@ -94,6 +94,27 @@ class Engine:
                                                 blk.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                 _dp(rot) if rot is not None else None))
         self.has_grid = True
+        self._grid_nb = (int(N) // 4) ** 3
+
+    # ---- environment preparation on the resident grid (collision::VoxelOctree's editing operations) ----
+    def grid_add_spheres(self, spheres):
+        sp = _f64(spheres).reshape(-1, 4)
+        L.check(self._ctx, self.lib.tr_grid_add_spheres(self._ctx, _dp(sp), sp.shape[0]))
+
+    def grid_remove_interior(self, keep_diagonal=True):
+        L.check(self._ctx, self.lib.tr_grid_remove_interior(self._ctx, int(bool(keep_diagonal))))
+
+    def grid_dilate(self, num=1, use_diagonal=False):
+        L.check(self._ctx, self.lib.tr_grid_dilate(self._ctx, int(num), int(bool(use_diagonal))))
+
+    def grid_dilate_sphere(self, r):
+        L.check(self._ctx, self.lib.tr_grid_dilate_sphere(self._ctx, float(r)))
+
+    def get_grid(self):
+        """uint64[Nb^3]: the obstacle blocks as they are on the device now."""
+        blk = np.empty(self._grid_nb, dtype=np.uint64)
+        L.check(self._ctx, self.lib.tr_get_grid(self._ctx, blk.ctypes.data_as(C.POINTER(C.c_uint64))))
+        return blk
 
     def reserve(self, n):
         L.check(self._ctx, self.lib.tr_reserve(self._ctx, int(n)))

@@ -92,6 +92,27 @@ class VoxelBackboneValidityChecker:
         """valid, tips (fk_shape.p.back(), VoxelCachedLazyPRM.cpp:1438) and TR_FLAG_* bits."""
         return self._timers["is_valid"].time(self.engine.validate_batch, robot_states, True, True)
 
+    # ---- obstacle-set edits on the device (collision::VoxelOctree's add_sphere / dilate / remove_interior,
+    # as apps/prepare_voxel_env.cpp:247-315 applies them); the resident grid is the checker's obstacle set ----
+    def add_spheres(self, spheres):
+        """VoxelOctree::add_sphere for rows (cx, cy, cz, r)."""
+        self.engine.grid_add_spheres(spheres)
+
+    def dilate(self, num=1, use_diagonal=False):
+        self.engine.grid_dilate(num, use_diagonal)
+
+    def dilate_sphere(self, r):
+        self.engine.grid_dilate_sphere(r)
+
+    def remove_interior(self, keep_diagonal=True):
+        self.engine.grid_remove_interior(keep_diagonal)
+
+    def obstacles(self):
+        """The obstacle set as it is on the device now (a VoxelOctree with the same limits)."""
+        v = self._voxels.empty_copy()
+        v.blocks[...] = self.engine.get_grid().reshape(v.blocks.shape)
+        return v
+
     def isValid(self, robot_state):
         """Single state, reference spelling."""
         return bool(self.is_valid(np.asarray(robot_state, float).reshape(1, -1))[0])

@@ -113,6 +113,12 @@ def _load(kind="strict"):
     lib.orc_grid_add_line.argtypes = [P(OrcGrid), c_double_p, c_double_p]
     lib.orc_grid_add_piecewise_line.argtypes = [P(OrcGrid), c_double_p, C.c_int]
     lib.orc_grid_add_sphere.argtypes = [P(OrcGrid), c_double_p, C.c_double]
+    lib.orc_grid_remove_interior.argtypes = [P(OrcGrid), C.c_int]
+    lib.orc_grid_remove_interior.restype = None
+    lib.orc_grid_dilate.argtypes = [P(OrcGrid), C.c_int, C.c_int]
+    lib.orc_grid_dilate.restype = None
+    lib.orc_grid_dilate_sphere.argtypes = [P(OrcGrid), C.c_double]
+    lib.orc_grid_dilate_sphere.restype = None
     lib.orc_grid_collides.argtypes = [P(OrcGrid), P(OrcGrid)]
     lib.orc_grid_collides_point.argtypes = [P(OrcGrid)] + [C.c_double] * 3
     lib.orc_grid_nblocks.argtypes = [P(OrcGrid)]
@@ -356,6 +362,15 @@ class Grid:
     def add_sphere(self, c, r):
         c = _f64(c)
         self.lib.orc_grid_add_sphere(self.ptr, _dp(c), float(r))
+
+    def remove_interior(self, keep_diagonal=True):
+        self.lib.orc_grid_remove_interior(self.ptr, int(bool(keep_diagonal)))
+
+    def dilate(self, num=1, use_diagonal=False):
+        self.lib.orc_grid_dilate(self.ptr, int(num), int(bool(use_diagonal)))
+
+    def dilate_sphere(self, r):
+        self.lib.orc_grid_dilate_sphere(self.ptr, float(r))
 
     def collides(self, other):
         if isinstance(other, Grid):

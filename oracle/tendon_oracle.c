@@ -827,6 +827,85 @@ void orc_grid_add_sphere(orc_grid *g, const double c[3], double r) {
       }
 }
 
+/* collision/VoxelOctree.cpp:533-689: remove_interior_6neighbor / remove_interior_27neighbor.  Works
+ * from a copy; only non-empty blocks are visited (visit_leaves); blocks beyond the grid count as full. */
+static uint64_t blk_or_full(const orc_grid *g, const uint64_t *src, long bx, long by, long bz) {
+  if (bx < 0 || bx >= g->Nb || by < 0 || by >= g->Nb || bz < 0 || bz >= g->Nb) return ~(uint64_t)0;
+  return src[block_index(g, (int)bx, (int)by, (int)bz)];
+}
+void orc_grid_remove_interior(orc_grid *g, int keep_diagonal) {
+  const size_t nb = (size_t)g->Nb * g->Nb * g->Nb;
+  uint64_t *copy = (uint64_t *)malloc(nb * sizeof(uint64_t));
+  memcpy(copy, g->blocks, nb * sizeof(uint64_t));
+  for (int bx = 0; bx < g->Nb; bx++) for (int by = 0; by < g->Nb; by++) for (int bz = 0; bz < g->Nb; bz++) {
+    const uint64_t old_b = copy[block_index(g, bx, by, bz)];
+    if (!old_b) continue;
+    uint64_t nbh[3][3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++)
+      nbh[i][j][k] = blk_or_full(g, copy, (long)bx - 1 + i, (long)by - 1 + j, (long)bz - 1 + k);
+    uint64_t new_b = old_b;
+    for (int ix = 0; ix < 4; ix++) for (int iy = 0; iy < 4; iy++) for (int iz = 0; iz < 4; iz++) {
+      int interior = 1;
+      for (int i = -1; i <= 1 && interior; i++) for (int j = -1; j <= 1 && interior; j++) for (int k = -1; k <= 1; k++) {
+        if (!keep_diagonal && (abs(i) + abs(j) + abs(k) > 1)) continue;     /* 6-neighbour form: the cell and its face neighbours (:552-577) */
+        int x = ix + i, y = iy + j, z = iz + k, nx = 1, ny = 1, nz = 1;      /* :646-657 */
+        if (x == -1) { x = 3; nx = 0; } else if (x == 4) { x = 0; nx = 2; }
+        if (y == -1) { y = 3; ny = 0; } else if (y == 4) { y = 0; ny = 2; }
+        if (z == -1) { z = 3; nz = 0; } else if (z == 4) { z = 0; nz = 2; }
+        if (!(nbh[nx][ny][nz] & orc_bitmask(x, y, z))) { interior = 0; break; }
+      }
+      if (interior) new_b &= ~orc_bitmask(ix, iy, iz);
+    }
+    g->blocks[block_index(g, bx, by, bz)] = new_b;
+  }
+  free(copy);
+}
+
+/* collision/VoxelOctree.cpp:693-818: dilate_6neighbor / dilate_27neighbor through dilate_one_impl --
+ * per non-empty block of a copy, a depth-limited search from every occupied cell inside the 12^3
+ * neighbourhood (at most four steps), the touched 3x3x3 blocks OR-ed into the live grid; repeated
+ * four dilations at a time.  The 27-neighbour move list (:776-804) names (x+1,y+1,z+1) twice and
+ * (x-1,y+1,z+1) never; that is reproduced here. */
+typedef struct { uint8_t depths[12][12][12]; uint64_t voxels[3][3][3]; } depth_set;
+static const int MOVES6[6][3] = {{-1,0,0},{1,0,0},{0,-1,0},{0,1,0},{0,0,-1},{0,0,1}};
+static const int MOVES27[27][3] = {
+  {0,0,0},{-1,0,0},{1,0,0},{0,-1,0},{-1,-1,0},{1,-1,0},{0,1,0},{-1,1,0},{1,1,0},
+  {0,0,-1},{-1,0,-1},{1,0,-1},{0,-1,-1},{-1,-1,-1},{1,-1,-1},{0,1,-1},{-1,1,-1},{1,1,-1},
+  {0,0,1},{-1,0,1},{1,0,1},{0,-1,1},{-1,-1,1},{1,-1,1},{0,1,1},{1,1,1},{1,1,1}};
+static void dilate_dfs(depth_set *v, int x, int y, int z, int d, int diag) {
+  if (d == 0 || d <= v->depths[x][y][z]) return;             /* DepthSet::in / add (:707-719) */
+  v->depths[x][y][z] = (uint8_t)d;
+  v->voxels[x / 4][y / 4][z / 4] |= orc_bitmask(x % 4, y % 4, z % 4);
+  const int (*mv)[3] = diag ? MOVES27 : MOVES6;
+  const int nm = diag ? 27 : 6;
+  for (int m = 0; m < nm; m++) dilate_dfs(v, x + mv[m][0], y + mv[m][1], z + mv[m][2], d - 1, diag);
+}
+void orc_grid_dilate(orc_grid *g, int num, int use_diagonal) {
+  const size_t nb = (size_t)g->Nb * g->Nb * g->Nb;
+  uint64_t *copy = (uint64_t *)malloc(nb * sizeof(uint64_t));
+  depth_set *v = (depth_set *)malloc(sizeof(depth_set));
+  for (; num > 0; num -= 4) {
+    const int n = num < 4 ? num : 4;
+    memcpy(copy, g->blocks, nb * sizeof(uint64_t));
+    for (int bx = 0; bx < g->Nb; bx++) for (int by = 0; by < g->Nb; by++) for (int bz = 0; bz < g->Nb; bz++) {
+      const uint64_t old_b = copy[block_index(g, bx, by, bz)];
+      if (!old_b) continue;
+      memset(v, 0, sizeof(*v));
+      for (int x = 0; x < 4; x++) for (int y = 0; y < 4; y++) for (int z = 0; z < 4; z++)
+        if (old_b & orc_bitmask(x, y, z)) dilate_dfs(v, x + 4, y + 4, z + 4, n + 1, use_diagonal);
+      for (int nx = 0; nx < 3; nx++) for (int ny = 0; ny < 3; ny++) for (int nz = 0; nz < 3; nz++) {
+        const int qx = bx + nx - 1, qy = by + ny - 1, qz = bz + nz - 1;
+        if (qx < 0 || qx >= g->Nb || qy < 0 || qy >= g->Nb || qz < 0 || qz >= g->Nb) continue;
+        g->blocks[block_index(g, qx, qy, qz)] |= v->voxels[nx][ny][nz];
+      }
+    }
+  }
+  free(copy); free(v);
+}
+void orc_grid_dilate_sphere(orc_grid *g, double r) {           /* :950-952 */
+  orc_grid_dilate(g, (int)round(r / fmin(g->dx, fmin(g->dy, g->dz))), 0);
+}
+
 /* :973-978 -> detail/TreeNode.hxx:164-174,268: any block with a & b != 0.
  * Dimension mismatch (std::invalid_argument in the reference) returns -1. */
 int orc_grid_collides(const orc_grid *a, const orc_grid *b) {

@@ -104,6 +104,9 @@ void orc_grid_add_point(orc_grid *g, double x, double y, double z);
 void orc_grid_add_line(orc_grid *g, const double a[3], const double b[3]);
 void orc_grid_add_piecewise_line(orc_grid *g, const double *pts, int n);
 void orc_grid_add_sphere(orc_grid *g, const double c[3], double r);
+void orc_grid_remove_interior(orc_grid *g, int keep_diagonal);
+void orc_grid_dilate(orc_grid *g, int num, int use_diagonal);
+void orc_grid_dilate_sphere(orc_grid *g, double r);
 int  orc_grid_collides(const orc_grid *a, const orc_grid *b);
 int  orc_grid_collides_point(const orc_grid *g, double x, double y, double z);
 size_t orc_grid_nblocks(const orc_grid *g);

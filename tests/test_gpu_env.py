@@ -1,0 +1,86 @@
+"""Environment preparation on the resident grid (tr_grid_*: VoxelOctree::add_sphere, dilate_6/27neighbor,
+dilate_sphere, remove_interior_6/27neighbor) -- bit-exact against the oracle's restatement, and the
+edited obstacle set is the one K2 then tests against."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _checker(irt, N=256, lim=0.25):
+    robot = irt.workloads.robot_config2()
+    vox = irt.VoxelOctree(N)
+    vox.set_xlim(-lim, lim); vox.set_ylim(-lim, lim); vox.set_zlim(-lim, lim)
+    return robot, vox, irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+
+
+def _oracle_grid(orc, vox):
+    g = orc.Grid(vox.Nx(), vox.limits())
+    g.blocks()[...] = vox.blocks
+    return g
+
+
+def test_add_spheres_matches_oracle(irt, orc):
+    robot, vox, chk = _checker(irt)
+    rng = np.random.default_rng(3)
+    sp = np.column_stack([rng.uniform(-0.3, 0.3, (200, 3)), rng.uniform(0.0005, 0.04, 200)])
+    sp[0] = [0.0, 0.0, 0.0, 0.0]                      # radius 0: only add_point(centre)
+    sp[1] = [0.2499, -0.2499, 0.25, 0.01]             # on the closed upper face
+    sp[2] = [0.4, 0.0, 0.0, 0.2]                      # centre outside, ball reaches in
+    sp[3] = [1.0, 1.0, 1.0, 0.1]                      # entirely outside (clamped block range, no cell inside)
+    chk.add_spheres(sp)
+    g = _oracle_grid(orc, vox)
+    for row in sp:
+        g.add_sphere(row[:3], row[3])
+    got = chk.engine.get_grid()
+    assert np.array_equal(got, np.asarray(g.blocks()).ravel())
+    assert np.count_nonzero(got) > 1000
+    chk.add_spheres(np.zeros((0, 4)))                 # empty batch is a no-op
+    assert np.array_equal(chk.engine.get_grid(), got)
+
+
+@pytest.mark.parametrize("N", [64, 256])
+def test_dilate_and_remove_interior_match_oracle(irt, orc, N):
+    robot, vox, chk = _checker(irt, N)
+    rng = np.random.default_rng(4)
+    sp = np.column_stack([rng.uniform(-0.25, 0.25, (24, 3)), rng.uniform(0.01, 0.06, 24)])
+    chk.add_spheres(sp)
+    g = _oracle_grid(orc, vox)
+    for row in sp:
+        g.add_sphere(row[:3], row[3])
+    for cell in ((0, 0, 0), (N - 1, N - 1, N - 1), (0, N // 2, N - 1)):       # grid corners / faces
+        g.set_cell(*cell)
+    vox2 = irt.VoxelOctree(N); vox2.set_xlim(-0.25, 0.25); vox2.set_ylim(-0.25, 0.25); vox2.set_zlim(-0.25, 0.25)
+    vox2.blocks[...] = np.asarray(g.blocks()).reshape(vox2.blocks.shape)
+    base = vox2.blocks.copy()
+    for op, args in (("dilate", (1, False)), ("dilate", (3, False)), ("dilate", (6, False)), ("dilate", (1, True)),
+                     ("dilate", (5, True)), ("remove_interior", (True,)), ("remove_interior", (False,)),
+                     ("dilate_sphere", (0.015,))):
+        chk.engine.set_grid(N, vox2.limits(), base, None)
+        getattr(chk, op)(*args)
+        h = orc.Grid(N, vox2.limits()); h.blocks()[...] = base.reshape(np.asarray(h.blocks()).shape)
+        getattr(h, op)(*args)
+        got = chk.engine.get_grid()
+        assert np.array_equal(got, np.asarray(h.blocks()).ravel()), (op, args, int(np.count_nonzero(got != np.asarray(h.blocks()).ravel())))
+        assert not np.array_equal(got, base.ravel())
+
+
+def test_edited_obstacles_are_what_validity_sees(irt, orc, helpers):
+    """prepare -> validate without the grid leaving the device: dilate the obstacles by the robot radius
+    (dilate_sphere) and compare verdicts with the oracle on the same edited grid."""
+    W = irt.workloads
+    robot, vox, chk = _checker(irt)
+    _, centres = W.reach_environment(seed=7, n_spheres=48)
+    sp = np.column_stack([centres, np.full(len(centres), 0.006)])
+    chk.add_spheres(sp)
+    chk.dilate_sphere(robot.r)
+    g = _oracle_grid(orc, vox)
+    for row in sp:
+        g.add_sphere(row[:3], row[3])
+    g.dilate_sphere(robot.r)
+    assert np.array_equal(chk.engine.get_grid(), np.asarray(g.blocks()).ravel())
+    states = W.random_states(robot, 4096, seed=77, tau_max=12.0)
+    got = chk.is_valid(states)
+    want, _, _ = orc.validate_batch(helpers.oracle_robot(orc, robot), g, states, nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(got, want) and 0.05 < want.mean() < 0.95
+    assert np.array_equal(chk.obstacles().blocks.ravel(), np.asarray(g.blocks()).ravel())

@@ -467,3 +467,57 @@ def test_edge_oracles_invariants(orc):
     m0 = orc.check_motion(rb, g, a, b, sp)
     m1 = orc.check_motion_until_invalid(rb, g, a, b, sp)
     assert not m0["valid"] and not m1["is_fully_valid"] and 0.0 <= m1["last_valid_t"] < k / nd + 1e-12
+
+
+def _cells(g):
+    """bool[N,N,N] view of an oracle grid (block ((bx*Nb)+by)*Nb+bz, bit x*16+y*4+z)."""
+    Nb = g.N // 4
+    blk = np.asarray(g.blocks()).reshape(Nb, Nb, Nb)
+    out = np.zeros((g.N,) * 3, dtype=bool)
+    for x in range(4):
+        for y in range(4):
+            for z in range(4):
+                out[x::4, y::4, z::4] = (blk >> np.uint64(x * 16 + y * 4 + z)) & np.uint64(1)
+    return out
+
+
+def _np_dilate(c, n, moves):
+    for _ in range(n):
+        p = np.pad(c, 1)
+        out = c.copy()
+        for dx, dy, dz in moves:
+            out |= p[1 - dx:1 - dx + c.shape[0], 1 - dy:1 - dy + c.shape[1], 1 - dz:1 - dz + c.shape[2]]
+        c = out
+    return c
+
+
+def test_environment_edits_against_numpy_morphology(orc):
+    """remove_interior / dilate (VoxelOctree.cpp:533-818) against a plain numpy statement of what they
+    compute: erosion-style shelling with the outside counted as occupied, and n-step dilation by the
+    reference's move lists (the 27-neighbour list lacks (-1,+1,+1))."""
+    rng = np.random.default_rng(5)
+    g = orc.Grid(32, (0, 1, 0, 1, 0, 1))
+    for c in rng.uniform(0.1, 0.9, (6, 3)):
+        g.add_sphere(c, rng.uniform(0.05, 0.2))
+    g.set_cell(0, 0, 0); g.set_cell(31, 31, 31); g.set_cell(0, 17, 31)
+    base = _cells(g)
+    m6 = [(-1, 0, 0), (1, 0, 0), (0, -1, 0), (0, 1, 0), (0, 0, -1), (0, 0, 1)]
+    m27 = [(i, j, k) for i in (-1, 0, 1) for j in (-1, 0, 1) for k in (-1, 0, 1) if (i, j, k) != (-1, 1, 1)]
+    for num, diag, moves in ((1, False, m6), (3, False, m6), (6, False, m6), (1, True, m27), (5, True, m27)):
+        h = orc.Grid(32, (0, 1, 0, 1, 0, 1)); h.blocks()[...] = g.blocks()
+        h.dilate(num, diag)
+        assert np.array_equal(_cells(h), _np_dilate(base, num, moves)), (num, diag)
+    for diag in (True, False):
+        h = orc.Grid(32, (0, 1, 0, 1, 0, 1)); h.blocks()[...] = g.blocks()
+        h.remove_interior(diag)
+        p = np.pad(base, 1, constant_values=True)
+        full = np.ones_like(base)
+        for i in (-1, 0, 1):
+            for j in (-1, 0, 1):
+                for k in (-1, 0, 1):
+                    if diag or abs(i) + abs(j) + abs(k) <= 1:
+                        full &= p[1 + i:33 + i, 1 + j:33 + j, 1 + k:33 + k]
+        assert np.array_equal(_cells(h), base & ~full), diag
+    h = orc.Grid(32, (0, 1, 0, 1, 0, 1)); h.blocks()[...] = g.blocks()
+    h.dilate_sphere(0.07)                                   # round(0.07 / (1/32)) = 2 six-neighbour steps
+    assert np.array_equal(_cells(h), _np_dilate(base, 2, m6))
