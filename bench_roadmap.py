@@ -83,7 +83,21 @@ def main():
     for _ in range(5):
         chk.engine.set_grid(new_vox.Nx(), new_vox.limits(), new_vox.blocks)
     t_grid = (time.perf_counter() - t0) / 5
+    # interactive edit of the environment on the device: 8 more obstacles, then the whole set grown by the robot radius
+    rng = np.random.default_rng(5)
+    extra = np.column_stack([rng.uniform(-0.15, 0.15, (8, 3)), np.full(8, 0.02)])
+    t_edit = {}
+    for name, fn in (("add_8_spheres_ms", lambda: chk.add_spheres(extra)),
+                     ("dilate_sphere_robot_radius_ms", lambda: chk.dilate_sphere(robot.r)),
+                     ("remove_interior_ms", lambda: chk.remove_interior())):
+        ts = []
+        for _ in range(5):
+            chk.engine.set_grid(new_vox.Nx(), new_vox.limits(), new_vox.blocks)
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        t_edit[name] = 1e3 * float(np.median(ts))
+    chk.engine.set_grid(new_vox.Nx(), new_vox.limits(), new_vox.blocks)
     out["config5"] = {
+        "environment_edit_on_device": t_edit,
         "device_resident": {"items_per_s": (nv + ne) / t_dev, "k4_kernel_ms_avg": k4["total_ms"] / max(1, k4["launches"]),
                             "k4_algorithmic_GBps": 12.0 * (int(vc["offsets"][-1]) + int(ec["offsets"][-1])) / 2
                                                    / (k4["total_ms"] / max(1, k4["launches"]) * 1e-3) / 1e9,
