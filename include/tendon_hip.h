@@ -248,8 +248,9 @@ int tr_knn(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_d
 /* Time the last `which` kernel launches with HIP events on the stream they ran on.
  * tr_profile_begin enables event recording around every kernel launched by this context;
  * tr_profile_read returns, per kernel slot, launches and total milliseconds since begin.
- * slots: 0 = fk_rk4_batch, 1 = backbone_voxel_sweep, 2 = cached_blocks_vs_grid, 3 = edge helpers */
-#define TR_PROFILE_SLOTS 4
+ * slots: 0 = fk_rk4_batch, 1 = backbone_voxel_sweep, 2 = cached_blocks_vs_grid, 3 = edge helpers,
+ * 4 = fk_sweep_fused (K1 + K2 in one launch, the verdict path of tr_validate_batch*) */
+#define TR_PROFILE_SLOTS 5
 int tr_profile_begin(tr_ctx *ctx);
 int tr_profile_read(tr_ctx *ctx, int64_t launches[TR_PROFILE_SLOTS], double total_ms[TR_PROFILE_SLOTS]);
 int tr_profile_end(tr_ctx *ctx);

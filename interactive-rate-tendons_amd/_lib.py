@@ -18,8 +18,8 @@ TR_OK, TR_ERR_INVALID_ARG, TR_ERR_OUT_OF_RANGE, TR_ERR_DOMAIN, TR_ERR_LENGTH, TR
     TR_ERR_HIP, TR_ERR_UNSUPPORTED = range(8)
 
 TR_FLAG_CONVERGED, TR_FLAG_LENGTH_OK, TR_FLAG_NO_SELFCOL, TR_FLAG_NO_VOXCOL, TR_FLAG_DOMAIN = 1, 2, 4, 8, 16
-TR_PROFILE_SLOTS = 4
-PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_grid", "edge_helpers")
+TR_PROFILE_SLOTS = 5
+PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_grid", "edge_helpers", "fk_sweep_fused")
 
 # every symbol include/tendon_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
@@ -93,16 +93,16 @@ OBJ_DIR = os.path.join(SRC_DIR, "_obj")
 
 def _units():
     """(object name, source, extra flags): the C ABI + K2..K6, the cache merge, and K1 once per
-    (tendon count, kernel) so its 64 instantiations compile in parallel."""
-    fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "tr_types.hpp"]
+    (tendon count, kernel: shared grid / retraction / fused with K2) so its 64 instantiations compile in parallel."""
+    fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "sweep_kernel.hpp",
+               "tr_types.hpp"]
     fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip"]
     main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
     u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),
          ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"])]
     for n in range(1, 9):
-        for r in (0, 1):
-            u.append(("fk_%s%d.o" % ("r" if r else "u", n), "fk_inst.hip",
-                      ["-DTRK_INST_N=%d" % n, "-DTRK_INST_RETRACT=%d" % r], fk_deps))
+        for kind, tag in ((0, "u"), (1, "r"), (2, "f")):
+            u.append(("fk_%s%d.o" % (tag, n), "fk_inst.hip", ["-DTRK_INST_N=%d" % n, "-DTRK_INST_KIND=%d" % kind], fk_deps))
     return u
 
 

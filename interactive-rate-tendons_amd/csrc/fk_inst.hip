@@ -1,14 +1,28 @@
 // fk_inst.hip -- one K1 instantiation set per object file: compiled once per tendon count and
-// kernel with -DTRK_INST_N=<1..8> -DTRK_INST_RETRACT=<0|1> (see _lib.py: build()).
+// kernel with -DTRK_INST_N=<1..8> -DTRK_INST_KIND=<0 uniform | 1 retract | 2 fused with K2>
+// (see _lib.py: build()).
 #include "fk_launch.hpp"
 #include "fk_kernel.hpp"
-#if TRK_INST_RETRACT
+#if TRK_INST_KIND == 1
 #include "fk_retract_kernel.hpp"
+#elif TRK_INST_KIND == 2
+#include "fused_kernel.hpp"
 #endif
 
 namespace trk {
 
-#if TRK_INST_RETRACT
+#if TRK_INST_KIND == 2
+template <bool ROT>
+static void go(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds) {
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  hipLaunchKernelGGL((fk_sweep_fused<TRK_INST_N, ROT>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.ld, a.K,
+                     a.d_tab, a.d_steps, a.n_steps, a.out, sweep);
+}
+template <> void launch_fk_sweep_fused<TRK_INST_N>(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds) {
+  if (a.rotation) go<true>(a, sweep, lds); else go<false>(a, sweep, lds);
+}
+#else
+#if TRK_INST_KIND == 1
 template <bool ROT, bool WR>
 static void go(const FkLaunch &a) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);
@@ -28,5 +42,6 @@ template <> void launch_fk_uniform<TRK_INST_N>(const FkLaunch &a) {
   if (a.rotation) { if (a.write_R) go<true, true>(a); else go<true, false>(a); }
   else            { if (a.write_R) go<false, true>(a); else go<false, false>(a); }
 }
+#endif
 
 }  // namespace trk

@@ -28,14 +28,6 @@
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
 
-// Up to this many tendons the shared-grid kernel is held to 256 registers (two waves per SIMD); wider
-// robots spill too much at that budget and run one wave per SIMD with the full 512-register file.
-// Measured, ms per 2^19 configurations (two waves | one wave): N=4 5.7 | 7.0, N=5 6.9 | 7.7, N=6 8.4 | 9.7,
-// N=8 12.9 | 11.0.
-#ifndef TRK_K1_TWO_WAVE_MAXN
-#define TRK_K1_TWO_WAVE_MAXN 6
-#endif
-
 namespace trk {
 
 // 1/x and 1/sqrt(x) from the hardware seed + two Newton steps (|rel err| ~ 1e-16).
@@ -299,9 +291,9 @@ __device__ __forceinline__ void rk4_step_routed(double (&R)[9], double (&v)[3], 
 //   tab:   [(nsteps*3 + 1)][N][6] routing table; entry 0 = base (s_start), then 3 per step
 //   steps: [nsteps]
 template <int N, bool ROT, bool WRITE_R>
-__global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_rk4_batch_uniform(
-    const double *__restrict__ states, int64_t n, int64_t ld, RobotK K,
-    const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, FkOut out) {
+__device__ __forceinline__ void fk_uniform_body(
+    const double *__restrict__ states, int64_t n, int64_t ld, const RobotK &K,
+    const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, const FkOut &out) {
 #pragma clang fp contract(fast)
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = i < n;
@@ -423,6 +415,13 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_rk
       out.tips[3 * i + 0] = x; out.tips[3 * i + 1] = y; out.tips[3 * i + 2] = z;
     }
   }
+}
+
+template <int N, bool ROT, bool WRITE_R>
+__global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_rk4_batch_uniform(
+    const double *__restrict__ states, int64_t n, int64_t ld, RobotK K,
+    const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, FkOut out) {
+  fk_uniform_body<N, ROT, WRITE_R>(states, n, ld, K, tab, steps, nsteps, out);
 }
 
 }  // namespace trk

@@ -1,5 +1,5 @@
 // fk_launch.hpp -- host-side launch interface of K1.  Each (tendon count, kernel) pair is its own
-// translation unit (fk_inst.hip compiled with -DTRK_INST_N=.. -DTRK_INST_RETRACT=..) so the 64
+// translation unit (fk_inst.hip compiled with -DTRK_INST_N=.. -DTRK_INST_KIND=..) so the 64
 // instantiations compile in parallel; tendon_hip.hip only sees these declarations.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -19,10 +19,14 @@ struct FkLaunch {
   hipStream_t stream;
 };
 
+struct FusedSweepArgs;
 template <int N> void launch_fk_uniform(const FkLaunch &a);
+// K1 + K2 fused (fused_kernel.hpp): `sweep` is a device pointer, `lds` the sweep's dynamic LDS bytes
+template <int N> void launch_fk_sweep_fused(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds);
 template <int N> void launch_fk_retract(const FkLaunch &a);
 
-#define TRK_DECL_FK(N) template <> void launch_fk_uniform<N>(const FkLaunch &); template <> void launch_fk_retract<N>(const FkLaunch &);
+#define TRK_DECL_FK(N) template <> void launch_fk_uniform<N>(const FkLaunch &); template <> void launch_fk_retract<N>(const FkLaunch &); \
+  template <> void launch_fk_sweep_fused<N>(const FkLaunch &, const FusedSweepArgs *, size_t);
 TRK_DECL_FK(1) TRK_DECL_FK(2) TRK_DECL_FK(3) TRK_DECL_FK(4) TRK_DECL_FK(5) TRK_DECL_FK(6) TRK_DECL_FK(7) TRK_DECL_FK(8)
 #undef TRK_DECL_FK
 

@@ -242,6 +242,18 @@ struct SweepIn {
   double *__restrict__ acc;                                            // [P][ld] scratch: accumulated chord lengths
 };
 
+// Arguments of the sweep when it runs fused behind K1 (fused_kernel.hpp): they travel through memory,
+// so they hold no SGPRs during the RK4 loop.
+struct FusedSweepArgs {
+  SweepIn in;
+  int P, CH, NM, check_voxels;
+  uint32_t debug, pad_;
+  GridK g;
+  const uint64_t *grid, *near_grid;
+  uint64_t *valid_bits;
+  uint8_t *flags;
+};
+
 // Exact self-collision sweep for one lane set (collision/collision.cpp:6-46), reading the lane's
 // points and accumulated chord lengths from global memory.  The (a, b) loops are wave-uniform; a lane
 // skips ahead over pairs that provably cannot collide (distance bound) or are provably gated out
@@ -326,8 +338,8 @@ __device__ __forceinline__ bool exact_self_collision(const SweepIn &in, int64_t 
 // cleared falls back to pass 3, the exact pairwise sweep -- rare (tight curls only).
 //   debug bit0: brute-force pairs in pass 3;  bit1: skip pass 2 (every lane takes pass 3);
 //         bit2: disable the dilated-grid fast path of the voxel walk.
-__global__ __launch_bounds__(64) void backbone_voxel_sweep(
-    SweepIn in, int64_t n, int64_t ld, int P, int CH, int NM, RobotK K, GridK g, const uint64_t *__restrict__ grid,
+__device__ __forceinline__ void sweep_body(
+    const SweepIn &in, int64_t n, int64_t ld, int P, int CH, int NM, const RobotK &K, const GridK &g, const uint64_t *__restrict__ grid,
     const uint64_t *__restrict__ near_grid, int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits,
     uint8_t *__restrict__ flags) {
 #pragma clang fp contract(off)
@@ -514,6 +526,15 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
   if (flags && live) flags[i] = (uint8_t)fl;
 }
 
+// The kernels below are defined once (tendon_hip.hip); the fused K1 + K2 objects only take the bodies above.
+#ifndef TRK_DEVICE_BODIES_ONLY
+__global__ __launch_bounds__(64) void backbone_voxel_sweep(
+    SweepIn in, int64_t n, int64_t ld, int P, int CH, int NM, RobotK K, GridK g, const uint64_t *__restrict__ grid,
+    const uint64_t *__restrict__ near_grid, int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits,
+    uint8_t *__restrict__ flags) {
+  sweep_body(in, n, ld, P, CH, NM, K, g, grid, near_grid, check_voxels, debug, valid_bits, flags);
+}
+
 // K5 `backbone_voxelize`: the robot's own voxel set (what voxelize_impl returns,
 // VoxelBackboneValidityChecker.h:49-57) as a sparse list of (block id, 64-bit mask) per configuration --
 // the form roadmap voxel caches are stored in (VoxelCachedLazyPRM.cpp:2816-2823).  One lane per
@@ -650,5 +671,7 @@ __global__ __launch_bounds__(1024) void cached_blocks_vs_grid(
   __syncthreads();
   if (threadIdx.x == 0) hit_bits[blockIdx.x] = word;
 }
+
+#endif  // TRK_DEVICE_BODIES_ONLY
 
 }  // namespace trk

@@ -100,6 +100,16 @@ struct tr_ctx {
   int64_t max_chunk = 1 << 20;
   int64_t edge_pool_max = 1 << 22; // samples held at once by tr_validate_edges / tr_voxelize_edges
   double ch_scale = 2.0;          // milestone spacing of K2 in robot radii (env TENDON_HIP_CH_SCALE, tuning only)
+  int64_t k1_round = 1 << 17;     // configurations in one resident round of K1 waves (CUs x 4 SIMDs x waves/SIMD x 64)
+  // tr_validate_batch*: K1 + K2 as one kernel (fused_kernel.hpp).  env TENDON_HIP_FUSED=0 keeps them apart.
+  bool fuse = true;
+  struct FusedRing {
+    static constexpr int kSlots = 16;
+    trk::FusedSweepArgs *d_slots = nullptr;
+    hipEvent_t ev[kSlots];
+    bool used[kSlots] = {};
+    int next = 0;
+  } fused;
   // result of the last tr_voxelize_* call (host side) and its device scratch
   std::vector<uint32_t> vox_ids;
   std::vector<uint64_t> vox_masks;
@@ -302,24 +312,78 @@ int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const 
   return TR_OK;
 }
 
+// milestone spacing for the LDS self-collision proof: about two robot radii of arc per chunk,
+// coarser if needed to keep the per-wave LDS image (4 * NM * 64 floats) within 48 KiB
+void sweep_geometry(const tr_ctx *ctx, int &CH, int &NM, size_t &lds) {
+  const int P = ctx->K.n_points;
+  CH = (int)std::lround(ctx->ch_scale * ctx->K.radius / ctx->K.dL);
+  if (CH < 1) CH = 1;
+  while ((P - 1 + CH - 1) / CH + 1 > 48) CH++;
+  NM = (P - 1 + CH - 1) / CH + 1;
+  lds = (size_t)4 * NM * 64 * sizeof(float);
+}
+
 int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int check_voxels,
                  uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
   if (n <= 0) return TR_OK;
   if (check_voxels && !ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   ProfScope ps(ctx, 1, s);
-  // milestone spacing for the LDS self-collision proof: about one robot radius of arc per chunk,
-  // coarser if needed to keep the per-wave LDS image (4 * NM * 64 floats) within 48 KiB
-  const int P = ctx->K.n_points;
-  int CH = (int)std::lround(ctx->ch_scale * ctx->K.radius / ctx->K.dL);
-  if (CH < 1) CH = 1;
-  while ((P - 1 + CH - 1) / CH + 1 > 48) CH++;
-  const int NM = (P - 1 + CH - 1) / CH + 1;
-  const size_t lds = (size_t)4 * NM * 64 * sizeof(float);
+  int CH, NM; size_t lds;
+  sweep_geometry(ctx, CH, NM, lds);
   const unsigned grid = (unsigned)((n + 63) / 64);
-  hipLaunchKernelGGL(trk::backbone_voxel_sweep, dim3(grid), dim3(64), lds, s, in, n, ld, P, CH, NM, ctx->K,
+  hipLaunchKernelGGL(trk::backbone_voxel_sweep, dim3(grid), dim3(64), lds, s, in, n, ld, ctx->K.n_points, CH, NM, ctx->K,
                      ctx->G, ctx->d_grid, ctx->d_near, check_voxels, ctx->debug, d_bits, d_flags);
   HIP_TRY(ctx, hipGetLastError());
   return TR_OK;
+}
+
+// K1 + K2 in one launch (fused_kernel.hpp; shared arc-length grid only).  The sweep's arguments go
+// through a small ring of device slots, each guarded by an event so a slot is not rewritten while
+// a launch on another stream may still read it.
+int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
+                 int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
+  if (n <= 0) return TR_OK;
+  if (check_voxels && !ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  tr_ctx::FusedRing &fr = ctx->fused;
+  if (!fr.d_slots) {
+    HIP_TRY(ctx, hipMalloc((void **)&fr.d_slots, sizeof(trk::FusedSweepArgs) * tr_ctx::FusedRing::kSlots));
+    for (auto &e : fr.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int slot = fr.next;
+  fr.next = (fr.next + 1) % tr_ctx::FusedRing::kSlots;
+  if (fr.used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(s, fr.ev[slot], 0));
+  trk::FusedSweepArgs a{};
+  a.in = in;
+  size_t lds;
+  sweep_geometry(ctx, a.CH, a.NM, lds);
+  a.P = ctx->K.n_points; a.check_voxels = check_voxels; a.debug = ctx->debug;
+  a.g = ctx->G; a.grid = ctx->d_grid; a.near_grid = ctx->d_near; a.valid_bits = d_bits; a.flags = d_flags;
+  HIP_TRY(ctx, hipMemcpyAsync(fr.d_slots + slot, &a, sizeof(a), hipMemcpyHostToDevice, s));   // pageable source: staged before return
+  {
+    ProfScope ps(ctx, 4, s);
+    const trk::FkLaunch fl{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
+                           (int)ctx->steps.size(), ctx->d_poly, ctx->ws.acc, out, s};
+    switch (ctx->K.n_tendons) {
+#define TRK_CASE(N) case N: trk::launch_fk_sweep_fused<N>(fl, fr.d_slots + slot, lds); break;
+      TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
+#undef TRK_CASE
+      default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(fr.ev[slot], s));
+  fr.used[slot] = true;
+  return TR_OK;
+}
+
+// K1 then K2 on one stream: a single fused launch when the robot uses the shared arc-length grid.
+int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
+                    int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
+  if (ctx->fuse && !ctx->K.enable_retraction && !out.R)
+    return launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s);
+  int rc;
+  if ((rc = launch_fk(ctx, d_states, n, ld, out, s))) return rc;
+  return launch_sweep(ctx, in, n, ld, check_voxels, d_bits, d_flags, s);
 }
 
 }  // namespace
@@ -350,8 +414,14 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (device < 0 || device >= ndev) return fail(nullptr, TR_ERR_INVALID_ARG, "bad device ordinal");
   tr_ctx *c = new tr_ctx();
   c->device = device;
+  if (const char *e = std::getenv("TENDON_HIP_FUSED")) c->fuse = std::atoi(e) != 0;
   if (const char *e = std::getenv("TENDON_HIP_CH_SCALE")) { const double v = std::atof(e); if (v > 0.05 && v < 50) c->ch_scale = v; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, TR_ERR_HIP, "hipSetDevice failed"); }
+  {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
+      c->k1_round = (int64_t)cus * 4 * (rb->n_tendons <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1) * 64;
+  }
 
   RobotK &K = c->K;
   const int N = rb->n_tendons;
@@ -447,6 +517,7 @@ void tr_destroy(tr_ctx *c) {
                   c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1]};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
+  if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
   delete c;
 }
 
@@ -738,14 +809,13 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
   Workspace &w = c->ws;
   hipStream_t s = (hipStream_t)stream;
   const int S = c->K.state_size;
+  const bool ret = c->K.enable_retraction;
   for (int64_t off = 0; off < n; off += w.ld) {
     const int64_t m = std::min<int64_t>(w.ld, n - off);
-    const bool ret = c->K.enable_retraction;
     trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, d_tips ? d_tips + 3 * off : nullptr, w.conv,
                    ret ? w.np : nullptr, ret ? w.homeLi : nullptr};
-    if ((rc = launch_fk(c, d_states + off * S, m, w.ld, out, s))) return rc;
     trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
-    if ((rc = launch_sweep(c, in, m, w.ld, 1, d_valid_bits + off / 64, d_flags ? d_flags + off : nullptr, s))) return rc;
+    if ((rc = launch_fk_sweep(c, d_states + off * S, m, w.ld, out, in, 1, d_valid_bits + off / 64, d_flags ? d_flags + off : nullptr, s))) return rc;
   }
   return TR_OK;
 }
@@ -970,9 +1040,8 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
     HIP_TRY(c, hipMemcpy(w.states, states + off * S, (size_t)m * S * sizeof(double), hipMemcpyHostToDevice));
     trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, tips ? w.tips : nullptr, w.conv, ret ? w.np : nullptr,
                    ret ? w.homeLi : nullptr};
-    if ((rc = launch_fk(c, w.states, m, w.ld, out, nullptr))) return rc;
     trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
-    if ((rc = launch_sweep(c, in, m, w.ld, 0, w.bits, nullptr, nullptr))) return rc;     // is_valid_shape only
+    if ((rc = launch_fk_sweep(c, w.states, m, w.ld, out, in, 0, w.bits, nullptr, nullptr))) return rc;     // is_valid_shape only
     if ((rc = voxelize_samples(c, m, w.ld, ret ? w.np : nullptr, w.bits, counts, offs, ids, masks))) return rc;
     HIP_TRY(c, hipMemcpy(shape_valid_bits + off / 64, w.bits, (size_t)((m + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (tips) HIP_TRY(c, hipMemcpy(tips + 3 * off, w.tips, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost));

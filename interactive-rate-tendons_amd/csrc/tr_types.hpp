@@ -54,6 +54,14 @@ struct GridK {
   int32_t pad_;
 };
 
+// Up to this many tendons the shared-grid kernel is held to 256 registers (two waves per SIMD); wider
+// robots spill too much at that budget and run one wave per SIMD with the full 512-register file.
+// Measured, ms per 2^19 configurations (two waves | one wave): N=4 5.7 | 7.0, N=5 6.9 | 7.7, N=6 8.4 | 9.7,
+// N=8 12.9 | 11.0.
+#ifndef TRK_K1_TWO_WAVE_MAXN
+#define TRK_K1_TWO_WAVE_MAXN 6
+#endif
+
 namespace trk {
 
 // Outputs of K1 (both kernels); null = not wanted.

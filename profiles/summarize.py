@@ -27,7 +27,8 @@ for d in ("sq", "grbm"):
     f = glob.glob(f"{src}/{d}/**/*_counter_collection.csv", recursive=True)[0]
     agg, dur = collections.defaultdict(list), collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
-        k = "fk_rk4_batch" if "fk_rk4" in r["Kernel_Name"] else ("backbone_voxel_sweep" if "voxel_sweep" in r["Kernel_Name"] else None)
+        kn = r["Kernel_Name"]
+        k = "fk_sweep_fused" if "fk_sweep_fused" in kn else ("fk_rk4_batch" if "fk_rk4" in kn else ("backbone_voxel_sweep" if "voxel_sweep" in kn else None))
         if not k:
             continue
         agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))

@@ -42,7 +42,7 @@ def test_shared_library_exports_every_symbol(irt):
 
 def test_library_contains_gfx950_code_object(irt):
     data = open(irt.LIB_PATH, "rb").read()
-    assert b"gfx950" in data and b"fk_rk4_batch_uniform" in data and b"backbone_voxel_sweep" in data
+    assert b"gfx950" in data and b"fk_rk4_batch_uniform" in data and b"backbone_voxel_sweep" in data and b"fk_sweep_fused" in data
 
 
 @pytest.mark.skipif(_has_gpu(), reason="checks the no-GPU failure mode")
