@@ -95,3 +95,43 @@ class ShardedVertexValidator:
         full = allgather_mask(local)
         # world_size * shard/64 words; bits of items >= M are zero.  unpack_bits(words, M) is the mask.
         return full.cpu().numpy().view(np.uint64)
+
+
+class ShardedEdgeValidator:
+    """The second phase of SURVEY section 8(e): every rank holds the same edge list (the host connects
+    edges from the gathered vertex mask, VoxelCachedLazyPRM.cpp:1463-1502), validates its contiguous
+    shard of it (checkMotion per edge, :1520-1542) and the packed verdicts are all-gathered.
+
+    validate_local(a, b) -> uint64/int64 mask words for the shard's edges; in production
+    Engine.validate_edges on the rank's GPU (packed with pack_bits), the oracle in the CPU tests.
+    """
+
+    def __init__(self, validate_local, device="cpu"):
+        self.validate_local, self.device = validate_local, device
+
+    def run(self, a, b, rank=None, world_size=None):
+        import torch
+        import torch.distributed as dist
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_initialized() else 1
+        M = len(a)
+        start, stop, shard = shard_bounds(M, world_size, rank)
+        n_real = max(0, min(stop, M) - start)
+        words = np.zeros(shard // WORD, dtype=np.uint64)
+        if n_real > 0:
+            w = np.asarray(self.validate_local(a[start:start + n_real], b[start:start + n_real])).view(np.uint64)
+            words[: w.size] = w
+            if n_real % WORD:
+                words[n_real // WORD] &= np.uint64((1 << (n_real % WORD)) - 1)
+        local = torch.from_numpy(words.view(np.int64)).to(self.device)
+        return allgather_mask(local).cpu().numpy().view(np.uint64)
+
+
+def pack_bits(mask):
+    """bool[n] -> uint64 words, bit i & 63 of word i >> 6 (the layout of every verdict mask here)."""
+    mask = np.asarray(mask, dtype=bool)
+    pad = (-len(mask)) % WORD
+    bits = np.concatenate([mask, np.zeros(pad, dtype=bool)]).reshape(-1, WORD)
+    return (bits.astype(np.uint64) << np.arange(WORD, dtype=np.uint64)).sum(axis=1, dtype=np.uint64)

@@ -188,8 +188,17 @@ def validate_local(states):                      # the oracle stands in for the 
     return np.packbits(np.pad(v, (0, -len(v) %% 64)), bitorder="little").view(np.uint64)
 M = int(sys.argv[1])
 mask = D.ShardedVertexValidator(robot, validate_local, seed=3).run(M)
+valid = irt.unpack_bits(mask, M)
+# phase 2: every rank connects the same edges from the gathered mask, validates its shard, gathers the verdicts
+states = D.candidate_states(robot, 3, 0, M)[valid][:131]
+a, b = states[:-1], states[1:]
+def edges_local(ea, eb):
+    v, _, _ = orc.check_motion_batch(orb, og, ea, eb)
+    return D.pack_bits(v)
+emask = D.ShardedEdgeValidator(edges_local).run(a, b)
 if rank == 0:
-    np.save(sys.argv[2], irt.unpack_bits(mask, M))
+    np.save(sys.argv[2], valid)
+    np.save(sys.argv[2] + ".edges.npy", irt.unpack_bits(emask, len(a)))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -212,6 +221,15 @@ def test_sharded_validation_gloo_world2_matches_world1(irt, tmp_path):
     a, b = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
     assert a.shape == (M,) and np.array_equal(a, b)
     assert 0 < a.sum() < M
+    ea, eb = np.load(tmp_path / "w1.npy.edges.npy"), np.load(tmp_path / "w2.npy.edges.npy")
+    assert ea.shape == (130,) and np.array_equal(ea, eb) and 0 < ea.sum() < 130      # 130 edges: shards are not whole words
+
+
+def test_pack_bits_roundtrip(irt):
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 63, 64, 65, 1000):
+        m = rng.random(n) < 0.5
+        assert np.array_equal(irt.unpack_bits(irt.distributed.pack_bits(m), n), m)
 
 
 # ---- .rmp roadmap files <-> CSR voxel caches ------------------------------------------------------------------
