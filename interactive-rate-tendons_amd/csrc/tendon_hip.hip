@@ -415,6 +415,10 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   tr_ctx *c = new tr_ctx();
   c->device = device;
   if (const char *e = std::getenv("TENDON_HIP_FUSED")) c->fuse = std::atoi(e) != 0;
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
+    const long long v = std::atoll(e);
+    if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = (int64_t)round_up(v, 64);
+  }
   if (const char *e = std::getenv("TENDON_HIP_CH_SCALE")) { const double v = std::atof(e); if (v > 0.05 && v < 50) c->ch_scale = v; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, TR_ERR_HIP, "hipSetDevice failed"); }
   {

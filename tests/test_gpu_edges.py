@@ -122,3 +122,64 @@ def test_discrete_motion_validator_matches_oracle(irt, orc, helpers):
             assert d["last_valid_t"][i] == w1["last_valid_t"] and d["n_fk"][i] == w1["n_fk"], (i, d["n_fk"][i], w1)
         assert (d["n_fk"][:3] <= 2).all() and (d["n_fk"][:3][d["valid"][:3]] == 2).all()
         assert 0.05 < d["valid"].mean() < 0.98 and d["n_fk"].max() > 50
+
+
+def _with_env(irt, env, fn):
+    """Run fn with environment overrides that libtendon_hip reads when a context is created."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_small_sample_pool_gives_the_same_edge_results(irt):
+    """The edge calls process edges in chunks that fit the sample pool and halve a chunk whose bisection
+    outgrows it; a pool of 1024 samples forces both paths.  Results must not depend on the pool size."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    a, b = _edges(robot, irt, 700, seed=41, step=4.0)
+
+    def run():
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        mv = irt.VoxelBackboneMotionValidator(chk)
+        d, (v2, lvt) = mv.check_motion_detail(a, b), mv.check_motion_last_valid(a, b)
+        dd = irt.VoxelBackboneDiscreteMotionValidator(chk).check_motion_detail(a[:60], b[:60])
+        ec = chk.engine.voxelize_edges(a[:200], b[:200])
+        return d, v2, lvt, dd, ec
+
+    big = run()
+    small = _with_env(irt, {"TENDON_HIP_EDGE_POOL": "1024"}, run)
+    assert np.array_equal(big[0]["valid"], small[0]["valid"]) and np.array_equal(big[0]["n_fk"], small[0]["n_fk"])
+    assert big[0]["n_domain_errors"] == small[0]["n_domain_errors"]
+    assert np.array_equal(big[1], small[1]) and np.array_equal(big[2], small[2])
+    for k in ("valid", "n_fk", "last_valid_t"):
+        assert np.array_equal(big[3][k], small[3][k]), k
+    for k in ("offsets", "block_ids", "masks", "fully_valid"):
+        assert np.array_equal(big[4][k], small[4][k]), k
+    assert big[0]["n_fk"].max() > 8 and 0.05 < big[0]["valid"].mean() < 0.95
+
+
+def test_fused_and_separate_kernels_give_identical_bits(irt):
+    """fk_sweep_fused is K1's and K2's bodies in one launch: same verdict bits, flags and tips as the two
+    kernels launched one after the other (TENDON_HIP_FUSED=0)."""
+    W = irt.workloads
+    for robot in (W.robot_config2(), W.robot_config3()):
+        vox, _ = W.reach_environment(seed=7, n_spheres=64)
+        states = W.random_states(robot, 20000 + 37, seed=91, tau_max=14.0)
+
+        def run():
+            chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+            return chk.is_valid_detail(states)
+
+        f, s = run(), _with_env(irt, {"TENDON_HIP_FUSED": "0"}, run)
+        for k in ("valid", "flags", "tips"):
+            assert np.array_equal(f[k], s[k]), k
+        assert 0.2 < f["valid"].mean() < 0.95

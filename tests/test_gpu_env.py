@@ -84,3 +84,22 @@ def test_edited_obstacles_are_what_validity_sees(irt, orc, helpers):
     want, _, _ = orc.validate_batch(helpers.oracle_robot(orc, robot), g, states, nthreads=0, lib=orc.omp_lib())
     assert np.array_equal(got, want) and 0.05 < want.mean() < 0.95
     assert np.array_equal(chk.obstacles().blocks.ravel(), np.asarray(g.blocks()).ravel())
+
+
+def test_environment_edits_on_an_anisotropic_grid(irt, orc):
+    """dx != dy != dz: nearest_block_idx / voxel centres per axis, dilate_sphere's min(dx, dy, dz)."""
+    robot = irt.workloads.robot_config1()              # dL = 5 mm: needs a voxel edge at least that long
+    vox = irt.VoxelOctree(64)
+    vox.set_xlim(-0.3, 0.3); vox.set_ylim(-0.2, 0.25); vox.set_zlim(-0.1, 0.35)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rng = np.random.default_rng(8)
+    sp = np.column_stack([rng.uniform(-0.3, 0.3, (40, 3)), rng.uniform(0.005, 0.05, 40)])
+    chk.add_spheres(sp)
+    chk.dilate_sphere(0.02)
+    chk.remove_interior(False)
+    g = orc.Grid(64, vox.limits())
+    for row in sp:
+        g.add_sphere(row[:3], row[3])
+    g.dilate_sphere(0.02)
+    g.remove_interior(False)
+    assert np.array_equal(chk.engine.get_grid(), np.asarray(g.blocks()).ravel()) and np.count_nonzero(chk.engine.get_grid()) > 200

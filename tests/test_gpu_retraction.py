@@ -88,3 +88,24 @@ def test_edges_with_retraction(irt, orc, helpers):
     assert np.array_equal(got["valid"], want)
     assert np.array_equal(got["n_fk"][want], nfk[want])
     assert 0.05 < want.mean() < 0.98
+
+
+def test_discrete_edges_and_last_valid_with_retraction(irt, orc, helpers):
+    W = irt.workloads
+    robot = _robot(irt, "helix")
+    vox, _ = W.reach_environment(seed=7, n_spheres=48)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rng = np.random.default_rng(64)
+    a = W.random_states(robot, 120, seed=64, tau_max=15.0)
+    b = a + rng.normal(size=a.shape) * np.array([0.6, 0.6, 0.6, 0.004])
+    b[:, :3] = np.clip(b[:, :3], 0, 20)
+    b[:, 3] = np.clip(b[:, 3], 0, 0.2)
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    d = irt.VoxelBackboneDiscreteMotionValidator(chk).check_motion_detail(a, b)
+    valid, lvt = irt.VoxelBackboneMotionValidator(chk).check_motion_last_valid(a, b)
+    for i in range(len(a)):
+        w = orc.check_motion_discrete(orb, og, a[i], b[i], until_invalid=True)
+        assert (d["valid"][i], d["last_valid_t"][i], d["n_fk"][i]) == (w["is_fully_valid"], w["last_valid_t"], w["n_fk"]), (i, w)
+        u = orc.check_motion_until_invalid(orb, og, a[i], b[i])
+        assert valid[i] == u["is_fully_valid"] and lvt[i] == u["last_valid_t"], (i, u)
+    assert 0.05 < d["valid"].mean() < 0.98 and d["n_fk"].max() > 20
