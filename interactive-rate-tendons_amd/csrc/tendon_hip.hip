@@ -105,7 +105,7 @@ struct tr_ctx {
   bool fuse = true;
   struct FusedRing {
     static constexpr int kSlots = 16;
-    trk::FusedSweepArgs *d_slots = nullptr;
+    trk::FusedSweepArgs *d_slots = nullptr, *h_slots = nullptr;   // device ring and its pinned host image
     hipEvent_t ev[kSlots];
     bool used[kSlots] = {};
     int next = 0;
@@ -338,8 +338,8 @@ int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int
 }
 
 // K1 + K2 in one launch (fused_kernel.hpp; shared arc-length grid only).  The sweep's arguments go
-// through a small ring of device slots, each guarded by an event so a slot is not rewritten while
-// a launch on another stream may still read it.
+// through a small ring of device slots filled from pinned host memory (an asynchronous copy on the
+// launch stream), each guarded by an event so a slot is not rewritten while a launch may still read it.
 int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
                  int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
   if (n <= 0) return TR_OK;
@@ -347,18 +347,22 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
   tr_ctx::FusedRing &fr = ctx->fused;
   if (!fr.d_slots) {
     HIP_TRY(ctx, hipMalloc((void **)&fr.d_slots, sizeof(trk::FusedSweepArgs) * tr_ctx::FusedRing::kSlots));
+    HIP_TRY(ctx, hipHostMalloc((void **)&fr.h_slots, sizeof(trk::FusedSweepArgs) * tr_ctx::FusedRing::kSlots, hipHostMallocDefault));
     for (auto &e : fr.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
   }
   const int slot = fr.next;
   fr.next = (fr.next + 1) % tr_ctx::FusedRing::kSlots;
-  if (fr.used[slot]) HIP_TRY(ctx, hipStreamWaitEvent(s, fr.ev[slot], 0));
-  trk::FusedSweepArgs a{};
+  // the slot's previous launch (kSlots launches ago, possibly on another stream) must be done before its
+  // host image is rewritten and its device copy replaced
+  if (fr.used[slot]) HIP_TRY(ctx, hipEventSynchronize(fr.ev[slot]));
+  trk::FusedSweepArgs &a = fr.h_slots[slot];
+  a = trk::FusedSweepArgs{};
   a.in = in;
   size_t lds;
   sweep_geometry(ctx, a.CH, a.NM, lds);
   a.P = ctx->K.n_points; a.check_voxels = check_voxels; a.debug = ctx->debug;
   a.g = ctx->G; a.grid = ctx->d_grid; a.near_grid = ctx->d_near; a.valid_bits = d_bits; a.flags = d_flags;
-  HIP_TRY(ctx, hipMemcpyAsync(fr.d_slots + slot, &a, sizeof(a), hipMemcpyHostToDevice, s));   // pageable source: staged before return
+  HIP_TRY(ctx, hipMemcpyAsync(fr.d_slots + slot, &a, sizeof(a), hipMemcpyHostToDevice, s));   // pinned source: asynchronous
   {
     ProfScope ps(ctx, 4, s);
     const trk::FkLaunch fl{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
@@ -521,7 +525,7 @@ void tr_destroy(tr_ctx *c) {
                   c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1]};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
-  if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
+  if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
   delete c;
 }
 
