@@ -22,6 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vertices", type=int, default=100000)
     ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--queries", type=int, default=200)
     ap.add_argument("--cache-items", type=int, default=200000)
     args = ap.parse_args()
     irt = importlib.import_module("interactive-rate-tendons_amd")
@@ -110,6 +111,48 @@ def main():
         "vertex_hit_fraction": float(vh.mean()), "edge_hit_fraction": float(eh.mean()),
         "note": "host API: includes set_grid (2 MiB upload + dilation) and CSR upload every call",
     }
+    # config 5 queries: the whole roadmap is re-validated against the changed environment on the device (K4 on
+    # every cached vertex and edge set), then each (start, goal) query is a host graph search over the
+    # surviving edges -- what VoxelCachedLazyPRM::solveWithRoadmap's lazy A* reduces to once validity is known.
+    from scipy.sparse import csr_matrix
+    from scipy.sparse.csgraph import dijkstra
+    nq = args.queries
+    ok_v = np.ones(len(states), dtype=bool); ok_v[:nv] = ~vh
+    ok_e = valid.copy(); ok_e[:ne] &= ~eh
+    keep = ok_e & ok_v[edges[:, 0]] & ok_v[edges[:, 1]]
+    wgt = np.linalg.norm(states[edges[keep, 0]] - states[edges[keep, 1]], axis=1)
+    gph = csr_matrix((wgt, (edges[keep, 0], edges[keep, 1])), shape=(len(states),) * 2)
+    rngq = np.random.default_rng(17)
+    pairs = rngq.choice(np.flatnonzero(ok_v), size=(nq, 2))
+    t0 = time.perf_counter()
+    dist = dijkstra(gph, directed=False, indices=pairs[:, 0])
+    t_q = time.perf_counter() - t0
+    reach = np.isfinite(dist[np.arange(nq), pairs[:, 1]])
+    out["config5"]["queries"] = {"n": nq, "host_graph_search_queries_per_s": nq / t_q, "reachable_fraction": float(reach.mean()),
+                                 "roadmap_revalidation_ms_device": 1e3 * t_dev,
+                                 "note": "scipy Dijkstra per start vertex on the host; the GPU part of a query batch is the one re-validation"}
+    # config 1 shape: FK only, 3-tendon linear-routed robot (P = 41), small and large batches
+    r1 = W.robot_config1()
+    e1 = r1.engine(0)
+    fk = {}
+    for nb in (1000, 1 << 20):
+        st1 = W.random_states(r1, nb, seed=42)
+        d_st = torch.from_numpy(st1).cuda()
+        ld = (nb + 63) // 64 * 64
+        P1 = e1.num_points
+        px, py, pz = (torch.empty(P1 * ld, dtype=torch.float64, device="cuda") for _ in range(3))
+        conv = torch.empty(ld, dtype=torch.uint8, device="cuda")
+        Li = torch.empty(3 * ld, dtype=torch.float64, device="cuda")
+        for _ in range(3):
+            e1.fk_batch_dev(d_st, nb, ld, px, py, pz, d_Li=Li, d_conv=conv)
+        torch.cuda.synchronize()
+        reps = 50 if nb <= 1000 else 10
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            e1.fk_batch_dev(d_st, nb, ld, px, py, pz, d_Li=Li, d_conv=conv)
+        torch.cuda.synchronize()
+        fk["fk_per_s_batch_%d" % nb] = nb * reps / (time.perf_counter() - t0)
+    out["config1"] = dict(fk, robot="3-tendon linear-routed (workloads.robot_config1), P = 41, FK only, states resident in HBM")
     print(json.dumps(out))
 
 
