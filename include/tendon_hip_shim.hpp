@@ -251,6 +251,26 @@ class VoxelBackboneValidityChecker {
   }
   tr_ctx *context() const { return ctx_; }
 
+  // ---- edits of the obstacle set where it lives (collision::VoxelOctree's add_sphere / dilate* /
+  // remove_interior, VoxelOctree.cpp:434-469, :533-952, as apps/prepare_voxel_env.cpp:269-315 applies them) ----
+  void add_spheres(const std::vector<double> &spheres /* n x (cx, cy, cz, r) */) const {
+    check(ctx_, tr_grid_add_spheres(ctx_, spheres.data(), (int64_t)(spheres.size() / 4)));
+  }
+  void dilate(int num = 1, bool use_diagonal = false) const { check(ctx_, tr_grid_dilate(ctx_, num, use_diagonal)); }
+  void dilate_sphere(double r) const { check(ctx_, tr_grid_dilate_sphere(ctx_, r)); }
+  void remove_interior(bool keep_diagonal = true) const { check(ctx_, tr_grid_remove_interior(ctx_, keep_diagonal)); }
+  /// the obstacle set as it is on the device now, into a VoxelOctree of the same dimension
+  void obstacles(collision::VoxelOctree &out) const { check(ctx_, tr_get_grid(ctx_, out.blocks().data())); }
+
+  /// connectionStrategy_(v) for every state at once (VoxelCachedLazyPRM.cpp:1491-1502): the k nearest states
+  /// (self included) in the compound state-space metric of Problem.cpp:112-152; idx is n x k, -1 = none in range
+  void nearest_k(const std::vector<double> &states, size_t n, int k, std::vector<int32_t> &idx, std::vector<double> &dist,
+                 double max_distance = 1e300) const {
+    if (states.size() != n * robot_.state_size()) throw std::invalid_argument("State is not the right size");
+    idx.resize(n * (size_t)k); dist.resize(n * (size_t)k);
+    check(ctx_, tr_knn(ctx_, states.data(), (int64_t)n, k, max_distance, idx.data(), dist.data()));
+  }
+
  private:
   const tendon::TendonRobot &robot_;
   tr_ctx *ctx_;

@@ -66,6 +66,20 @@ int main(int argc, char **argv) {
     std::printf("ecache %d %lld %d\n", (int)ec.usable[i], (long long)(ec.offsets[i + 1] - ec.offsets[i]), (int)ehit[i]);
   for (size_t i = 0; i < vcaches.items(); i++)
     std::printf("vcache %d %lld %d\n", (int)vcaches.usable[i], (long long)(vcaches.offsets[i + 1] - vcaches.offsets[i]), (int)vhit[i]);
+  // obstacle edits on the device + k nearest states
+  {
+    vc.add_spheres({0.05, 0.05, 0.1, 0.02, -0.1, 0.0, 0.05, 0.01});
+    vc.dilate_sphere(0.004);
+    vc.remove_interior();
+    collision::VoxelOctree now(256);
+    vc.obstacles(now);
+    size_t cells = 0;
+    for (uint64_t b : now.blocks()) cells += (size_t)__builtin_popcountll(b);
+    std::printf("edited %zu %d %d\n", cells, (int)now.cell(166, 166, 179), (int)now.cell(128, 128, 128));
+    std::vector<int32_t> idx; std::vector<double> dist;
+    vc.nearest_k(flat, states.size(), 2, idx, dist);
+    for (size_t i = 0; i < states.size(); i++) std::printf("knn %d %d %.17g\n", idx[2 * i], idx[2 * i + 1], dist[2 * i + 1]);
+  }
   try {
     collision::VoxelOctree fine(512);
     fine.set_xlim(-0.25, 0.25); fine.set_ylim(-0.25, 0.25); fine.set_zlim(-0.25, 0.25);

@@ -77,3 +77,16 @@ def test_shim_results_match_oracle(tmp_path, irt, orc, helpers):
     for s, row in zip(states, vcache):
         ok, _, fl = orc.is_valid_state(orb, og, s)
         assert int(row[1]) == int((fl & 7) == 7) and (not int(row[1]) or int(row[3]) == int(not (fl & 8)))
+    # obstacle edits and k-NN through the shim
+    g2 = helpers.oracle_grid(orc, vox)
+    g2.blocks()[...] = og.blocks()
+    g2.add_sphere([0.05, 0.05, 0.1], 0.02); g2.add_sphere([-0.1, 0.0, 0.05], 0.01)
+    g2.dilate_sphere(0.004); g2.remove_interior(True)
+    ed = [l.split() for l in out if l.startswith("edited")][0]
+    assert int(ed[1]) == g2.ncells() and int(ed[2]) == int(g2.cell(166, 166, 179)) and int(ed[3]) == int(g2.cell(128, 128, 128))
+    knn = [l.split() for l in out if l.startswith("knn")]
+    S = np.array(states, float)
+    D = np.linalg.norm(S[:, None, :] - S[None, :, :], axis=2)
+    for i, row in enumerate(knn):
+        order = np.argsort(D[i], kind="stable")
+        assert int(row[1]) == i and int(row[2]) == order[1] and abs(float(row[3]) - D[i, order[1]]) < 1e-12
