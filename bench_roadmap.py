@@ -153,6 +153,29 @@ def main():
         torch.cuda.synchronize()
         fk["fk_per_s_batch_%d" % nb] = nb * reps / (time.perf_counter() - t0)
     out["config1"] = dict(fk, robot="3-tendon linear-routed (workloads.robot_config1), P = 41, FK only, states resident in HBM")
+    # VoxelValidityChecker (sphere-swept robot against the raw environment), config 2 robot, states resident in HBM
+    r2 = W.robot_config2()
+    raw = irt.VoxelOctree(256)
+    raw.set_xlim(-0.25, 0.25); raw.set_ylim(-0.25, 0.25); raw.set_zlim(-0.25, 0.25)
+    _, centres = W.reach_environment(seed=7, n_spheres=64)
+    for c in centres:
+        raw.add_sphere(c, 0.005)                        # the un-dilated obstacles: r = 5 mm instead of 20 mm
+    sc = irt.VoxelValidityChecker(r2, irt.VoxelEnvironment(), raw)
+    nb = 1 << 20
+    st2 = torch.from_numpy(W.random_states(r2, nb, seed=3, tau_max=10.0)).cuda()
+    bits = torch.zeros(nb // 64, dtype=torch.int64, device="cuda")
+    sc.engine.reserve(nb)
+    for _ in range(2):
+        sc.engine.validate_batch_dev(st2, nb, bits)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        sc.engine.validate_batch_dev(st2, nb, bits)
+    torch.cuda.synchronize()
+    ts = (time.perf_counter() - t0) / 5
+    out["sphere_checker"] = {"checks_per_s": nb / ts, "ms_per_2^20": 1e3 * ts,
+                             "valid_fraction": float(irt.unpack_bits(bits.cpu().numpy().view(np.uint64), nb).mean()),
+                             "note": "VoxelValidityChecker: 64 raw spheres r = 5 mm, robot radius 15 mm swept as spheres"}
     print(json.dumps(out))
 
 

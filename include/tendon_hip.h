@@ -94,6 +94,18 @@ int tr_home_lengths(const tr_ctx *ctx, double *L_i /*[n_tendons]*/);
 int tr_set_grid(tr_ctx *ctx, uint32_t N, const double lim[6], const uint64_t *blocks,
                 const double inv_rot[9]);
 
+/* Which robot voxelisation the state checks use (tr_validate_batch*, tr_validate_edges_discrete):
+ * TR_CHECKER_BACKBONE = motion_planning::VoxelBackboneValidityChecker (the backbone polyline against a
+ * pre-dilated environment, VoxelBackboneValidityChecker.h:28-58; the default),
+ * TR_CHECKER_SPHERES  = motion_planning::VoxelValidityChecker (a sphere of the robot radius at every
+ * backbone point against the raw environment, VoxelValidityChecker.h:18-26).
+ * The swept-volume edge calls (tr_validate_edges, _last_valid, tr_voxelize_*) are VoxelBackbone* classes
+ * in the reference and always use the backbone.  Call it before tr_set_grid: the dL <= voxel size check of
+ * tr_set_grid is the backbone checker's constructor check and is skipped for TR_CHECKER_SPHERES. */
+#define TR_CHECKER_BACKBONE 0
+#define TR_CHECKER_SPHERES 1
+int tr_set_checker(tr_ctx *ctx, int32_t checker);
+
 /* ---- environment preparation on the resident obstacle grid ------------------------------
  * collision::VoxelOctree's editing operations, applied to the grid tr_set_grid uploaded, without it
  * leaving the device (apps/prepare_voxel_env.cpp:247-315 runs them on the host octree):

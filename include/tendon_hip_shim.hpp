@@ -6,6 +6,7 @@
 //   collision::VoxelOctree (dense view)                                 collision/VoxelOctree.h:68-330
 //   motion_planning::VoxelEnvironment                                   motion-planning/VoxelEnvironment.h:31-49
 //   motion_planning::VoxelBackboneValidityChecker                       motion-planning/VoxelBackboneValidityChecker.h:28-58
+//   motion_planning::VoxelValidityChecker                               motion-planning/VoxelValidityChecker.h:18-26
 //   motion_planning::VoxelBackboneMotionValidator                       motion-planning/VoxelBackboneMotionValidator.h
 //   motion_planning::VoxelBackboneDiscreteMotionValidator               motion-planning/VoxelBackboneDiscreteMotionValidator.h
 //   motion_planning::VoxelCaches, voxelize_states, caches_collide       the cache loops of VoxelCachedLazyPRM.cpp
@@ -66,6 +67,17 @@ class TendonRobot {                 // tendon/TendonRobot.h:52-355
   std::vector<TendonSpecs> tendons;
   bool enable_rotation = false, enable_retraction = false;
   double residual_threshold = 5e-6;
+
+  TendonRobot() = default;
+  /// value semantics as in the reference; a copy gets its own GPU context on first use
+  TendonRobot(const TendonRobot &o)
+      : r(o.r), specs(o.specs), tendons(o.tendons), enable_rotation(o.enable_rotation), enable_retraction(o.enable_retraction),
+        residual_threshold(o.residual_threshold) {}
+  TendonRobot &operator=(const TendonRobot &o) {
+    r = o.r; specs = o.specs; tendons = o.tendons; enable_rotation = o.enable_rotation; enable_retraction = o.enable_retraction;
+    residual_threshold = o.residual_threshold; ctx_.reset();
+    return *this;
+  }
 
   size_t state_size() const { return tendons.size() + (enable_rotation ? 1 : 0) + (enable_retraction ? 1 : 0); }
 
@@ -221,8 +233,9 @@ struct VoxelEnvironment {           // motion-planning/VoxelEnvironment.h:46-49 
 class VoxelBackboneValidityChecker {
  public:
   VoxelBackboneValidityChecker(const tendon::TendonRobot &robot, const VoxelEnvironment &venv,
-                               const collision::VoxelOctree &voxels, int device = 0)
+                               const collision::VoxelOctree &voxels, int device = 0, int checker = TR_CHECKER_BACKBONE)
       : robot_(robot), ctx_(robot.context(device)) {
+    check(ctx_, tr_set_checker(ctx_, checker));
     // throws std::invalid_argument when robot.specs.dL exceeds the largest voxel edge (VoxelBackboneValidityChecker.h:37-45)
     check(ctx_, tr_set_grid(ctx_, (uint32_t)voxels.Nx(), voxels.limits(), voxels.blocks().data(), venv.inv_rotation));
   }
@@ -274,6 +287,17 @@ class VoxelBackboneValidityChecker {
  private:
   const tendon::TendonRobot &robot_;
   tr_ctx *ctx_;
+};
+
+/// VoxelValidityChecker (motion-planning/VoxelValidityChecker.h:18-26): the same interface; the robot is
+/// voxelised as a sphere of its radius at every backbone point and tested against the raw environment.
+/// The GPU context belongs to the TendonRobot object: give this checker its own copy of the robot if a
+/// backbone checker on the same robot is alive at the same time.
+class VoxelValidityChecker : public VoxelBackboneValidityChecker {
+ public:
+  VoxelValidityChecker(const tendon::TendonRobot &robot, const VoxelEnvironment &venv, const collision::VoxelOctree &voxels,
+                       int device = 0)
+      : VoxelBackboneValidityChecker(robot, venv, voxels, device, TR_CHECKER_SPHERES) {}
 };
 
 /// Sparse voxel set as the roadmap caches store it (VoxelCachedLazyPRM.h:165-179; CSR over items).

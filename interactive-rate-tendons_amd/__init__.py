@@ -14,7 +14,7 @@ from ._lib import (TendonHipError, InvalidArgument, OutOfRange, DomainError, Len
 from .engine import Engine, unpack_bits
 from .tendon import BackboneSpecs, TendonSpecs, TendonResult, TendonRobot
 from .collision import VoxelOctree
-from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelBackboneMotionValidator,
+from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelValidityChecker, VoxelBackboneMotionValidator,
                               VoxelBackboneDiscreteMotionValidator, FunctionTimer)
 from . import workloads, distributed, roadmap, rmp
 from .roadmap import RoadmapBuilder
@@ -22,6 +22,6 @@ from .roadmap import RoadmapBuilder
 __all__ = [
     "TendonHipError", "InvalidArgument", "OutOfRange", "DomainError", "LengthError", "HipError", "Unsupported",
     "build", "LIB_PATH", "Engine", "unpack_bits", "BackboneSpecs", "TendonSpecs", "TendonResult", "TendonRobot",
-    "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelBackboneMotionValidator", "VoxelBackboneDiscreteMotionValidator",
+    "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelValidityChecker", "VoxelBackboneMotionValidator", "VoxelBackboneDiscreteMotionValidator",
     "FunctionTimer", "workloads", "distributed", "roadmap", "RoadmapBuilder",
 ]

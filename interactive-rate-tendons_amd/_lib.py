@@ -18,13 +18,14 @@ TR_OK, TR_ERR_INVALID_ARG, TR_ERR_OUT_OF_RANGE, TR_ERR_DOMAIN, TR_ERR_LENGTH, TR
     TR_ERR_HIP, TR_ERR_UNSUPPORTED = range(8)
 
 TR_FLAG_CONVERGED, TR_FLAG_LENGTH_OK, TR_FLAG_NO_SELFCOL, TR_FLAG_NO_VOXCOL, TR_FLAG_DOMAIN = 1, 2, 4, 8, 16
+TR_CHECKER_BACKBONE, TR_CHECKER_SPHERES = 0, 1
 TR_PROFILE_SLOTS = 5
 PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_grid", "edge_helpers", "fk_sweep_fused")
 
 # every symbol include/tendon_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
     "tr_create", "tr_destroy", "tr_last_error", "tr_state_size", "tr_num_points", "tr_device",
-    "tr_home_lengths", "tr_set_grid", "tr_grid_add_spheres", "tr_grid_remove_interior", "tr_grid_dilate",
+    "tr_home_lengths", "tr_set_grid", "tr_set_checker", "tr_grid_add_spheres", "tr_grid_remove_interior", "tr_grid_dilate",
     "tr_grid_dilate_sphere", "tr_get_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev",
     "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_last_valid",
     "tr_validate_edges_discrete",
@@ -174,6 +175,7 @@ def lib():
         getattr(L, f).argtypes = [vp]
     L.tr_home_lengths.argtypes = [vp, dp]
     L.tr_set_grid.argtypes = [vp, C.c_uint32, dp, P(C.c_uint64), dp]
+    L.tr_set_checker.argtypes = [vp, C.c_int32]
     L.tr_grid_add_spheres.argtypes = [vp, dp, i64]
     L.tr_grid_remove_interior.argtypes = [vp, C.c_int32]
     L.tr_grid_dilate.argtypes = [vp, C.c_int32, C.c_int32]

@@ -31,6 +31,7 @@
 #include "knn_kernel.hpp"
 #include "cache_merge.hpp"
 #include "env_kernel.hpp"
+#include "sphere_kernel.hpp"
 
 namespace {
 
@@ -92,6 +93,10 @@ struct tr_ctx {
   uint64_t *d_grid = nullptr;
   uint64_t *d_near = nullptr;     // obstacle grid dilated by 2 cells (Chebyshev), same layout
   uint32_t n_blocks = 0;
+  // VoxelValidityChecker mode (sphere-swept robot, sphere_kernel.hpp): obstacles dilated by ceil(r/d) + 1 cells
+  int checker = TR_CHECKER_BACKBONE;
+  uint64_t *d_sph_near = nullptr;
+  bool sph_near_valid = false;
   uint64_t *d_envw[2] = {nullptr, nullptr};   // environment-preparation scratch: two (Nb+2)^3 apron grids
   uint32_t envw_blocks = 0;
   Workspace ws;
@@ -380,14 +385,52 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
   return TR_OK;
 }
 
+// Obstacles dilated (Chebyshev) by ceil(r/d) + 1 cells per axis: the cells whose sphere could reach an occupied one.
+int ensure_sphere_near(tr_ctx *c, hipStream_t s) {
+  if (c->sph_near_valid) return TR_OK;
+  const uint32_t nbw = (uint32_t)((c->G.Nb + 2) * (c->G.Nb + 2) * (c->G.Nb + 2));
+  HIP_TRY(c, hipDeviceSynchronize());                          // (re)allocation and scratch shared with the environment edits
+  if (c->envw_blocks < nbw) {
+    for (int k = 0; k < 2; k++) { int rc = dev_alloc(c, &c->d_envw[k], (size_t)nbw); if (rc) return rc; }
+    c->envw_blocks = nbw;
+  }
+  if (c->d_sph_near) { (void)hipFree(c->d_sph_near); c->d_sph_near = nullptr; }
+  HIP_TRY(c, hipMalloc((void **)&c->d_sph_near, (size_t)c->n_blocks * sizeof(uint64_t)));
+  const double r = c->K.radius;
+  const int R[3] = {(int)std::ceil(r / c->G.dx) + 1, (int)std::ceil(r / c->G.dy) + 1, (int)std::ceil(r / c->G.dz) + 1};
+  hipLaunchKernelGGL(trk::cheb_dilate_axis, dim3(c->n_blocks), dim3(64), 0, s, c->d_grid, c->d_envw[0], c->G.Nb, 0, R[0]);
+  hipLaunchKernelGGL(trk::cheb_dilate_axis, dim3(c->n_blocks), dim3(64), 0, s, c->d_envw[0], c->d_envw[1], c->G.Nb, 1, R[1]);
+  hipLaunchKernelGGL(trk::cheb_dilate_axis, dim3(c->n_blocks), dim3(64), 0, s, c->d_envw[1], c->d_sph_near, c->G.Nb, 2, R[2]);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(s));
+  c->sph_near_valid = true;
+  return TR_OK;
+}
+
 // K1 then K2 on one stream: a single fused launch when the robot uses the shared arc-length grid.
+// voxel_test: 0 = is_valid_shape only, 1 = backbone voxels (VoxelBackboneValidityChecker), 2 = sphere-swept
+// robot (VoxelValidityChecker: K2 without the voxel test, then K8 on the survivors).
 int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
-                    int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
-  if (ctx->fuse && !ctx->K.enable_retraction && !out.R)
-    return launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s);
+                    int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
+  const int check_voxels = voxel_test == 1 ? 1 : 0;
   int rc;
-  if ((rc = launch_fk(ctx, d_states, n, ld, out, s))) return rc;
-  return launch_sweep(ctx, in, n, ld, check_voxels, d_bits, d_flags, s);
+  if (voxel_test == 2) {
+    if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+    if ((rc = ensure_sphere_near(ctx, s))) return rc;
+  }
+  if (ctx->fuse && !ctx->K.enable_retraction && !out.R) {
+    if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s))) return rc;
+  } else {
+    if ((rc = launch_fk(ctx, d_states, n, ld, out, s))) return rc;
+    if ((rc = launch_sweep(ctx, in, n, ld, check_voxels, d_bits, d_flags, s))) return rc;
+  }
+  if (voxel_test == 2) {
+    ProfScope ps(ctx, 3, s);
+    hipLaunchKernelGGL(trk::spheres_vs_grid, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, in.px, in.py, in.pz, in.n_points, n, ld,
+                       (int)ctx->K.n_points, ctx->K.radius, ctx->G, ctx->d_grid, ctx->d_sph_near, d_bits, d_flags);
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  return TR_OK;
 }
 
 }  // namespace
@@ -522,7 +565,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1]};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1], c->d_sph_near};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
@@ -536,6 +579,16 @@ int tr_device(const tr_ctx *c) { return c ? c->device : -1; }
 int tr_home_lengths(const tr_ctx *c, double *L_i) {
   if (!c || !L_i) return TR_ERR_INVALID_ARG;
   for (int j = 0; j < c->K.n_tendons; j++) L_i[j] = c->K.home_Li[j];
+  return TR_OK;
+}
+
+int tr_set_checker(tr_ctx *c, int32_t checker) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  if (checker != TR_CHECKER_BACKBONE && checker != TR_CHECKER_SPHERES) return fail(c, TR_ERR_INVALID_ARG, "unknown checker");
+  if (checker == TR_CHECKER_BACKBONE && c->has_grid && c->K.dL > std::max({c->G.dx, c->G.dy, c->G.dz}))
+    return fail(c, TR_ERR_INVALID_ARG, "robot.specs.dL is larger than expected by VoxelBackboneValidityChecker");
+  c->checker = checker;
   return TR_OK;
 }
 
@@ -555,7 +608,7 @@ int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *bloc
   g.inv_dx = 1 / g.dx; g.inv_dy = 1 / g.dy; g.inv_dz = 1 / g.dz;
   // VoxelBackboneValidityChecker.h:37-45
   const double max_dim = std::max({g.dx, g.dy, g.dz});
-  if (c->K.dL > max_dim) {
+  if (c->checker == TR_CHECKER_BACKBONE && c->K.dL > max_dim) {    // the sphere checker has no such constructor check
     char buf[160];
     snprintf(buf, sizeof buf, "robot.specs.dL is larger than expected by VoxelBackboneValidityChecker (%g > %g)", c->K.dL, max_dim);
     return fail(c, TR_ERR_INVALID_ARG, buf);
@@ -580,6 +633,7 @@ int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *bloc
   HIP_TRY(c, hipDeviceSynchronize());
   c->G = g;
   c->has_grid = true;
+  c->sph_near_valid = false;
   return TR_OK;
 }
 
@@ -598,6 +652,7 @@ int env_begin(tr_ctx *c) {
 }
 // the fast-skip grid of K2 follows every edit of the obstacle grid
 int env_end(tr_ctx *c) {
+  c->sph_near_valid = false;
   hipLaunchKernelGGL(trk::dilate2_blocks, dim3(c->n_blocks), dim3(64), 0, nullptr, c->d_grid, c->d_near, c->G.Nb);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipDeviceSynchronize());
@@ -823,7 +878,8 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
     trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, d_tips ? d_tips + 3 * off : nullptr, w.conv,
                    ret ? w.np : nullptr, ret ? w.homeLi : nullptr};
     trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
-    if ((rc = launch_fk_sweep(c, d_states + off * S, m, w.ld, out, in, 1, d_valid_bits + off / 64, d_flags ? d_flags + off : nullptr, s))) return rc;
+    if ((rc = launch_fk_sweep(c, d_states + off * S, m, w.ld, out, in, c->checker == TR_CHECKER_SPHERES ? 2 : 1, d_valid_bits + off / 64,
+                              d_flags ? d_flags + off : nullptr, s))) return rc;
   }
   return TR_OK;
 }

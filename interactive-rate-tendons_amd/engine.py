@@ -116,6 +116,10 @@ class Engine:
         L.check(self._ctx, self.lib.tr_get_grid(self._ctx, blk.ctypes.data_as(C.POINTER(C.c_uint64))))
         return blk
 
+    def set_checker(self, spheres):
+        """False: VoxelBackboneValidityChecker (default); True: VoxelValidityChecker (sphere-swept robot)."""
+        L.check(self._ctx, self.lib.tr_set_checker(self._ctx, L.TR_CHECKER_SPHERES if spheres else L.TR_CHECKER_BACKBONE))
+
     def reserve(self, n):
         L.check(self._ctx, self.lib.tr_reserve(self._ctx, int(n)))
 

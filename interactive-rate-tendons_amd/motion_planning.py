@@ -118,6 +118,21 @@ class VoxelBackboneValidityChecker:
         return bool(self.is_valid(np.asarray(robot_state, float).reshape(1, -1))[0])
 
 
+class VoxelValidityChecker(VoxelBackboneValidityChecker):
+    """motion-planning/VoxelValidityChecker.h:18-26: the same chain, but the robot is voxelised as a sphere of
+    its radius at every backbone point (add_sphere) and tested against the raw, un-dilated environment.  Uses
+    its own engine context, so a backbone checker on the same robot is not affected."""
+
+    def __init__(self, robot: TendonRobot, venv: VoxelEnvironment, voxels: VoxelOctree, device=0):
+        from .engine import Engine
+        self._robot, self._venv, self._voxels = robot, venv, voxels
+        self._timers = {k: FunctionTimer() for k in
+                        ("fk", "collision", "self_collision", "voxelize", "collision-without-voxelizing", "is_valid")}
+        self.engine = Engine(robot, device)
+        self.engine.set_checker(True)            # before the grid: the dL <= voxel check belongs to the backbone checker only
+        self.engine.set_grid(voxels.Nx(), voxels.limits(), voxels.blocks, venv.inv_rotation)
+
+
 class VoxelBackboneMotionValidator:
     """motion-planning/VoxelBackboneMotionValidator.{h,cpp} over AbstractVoxelMotionValidator:
     `check_motion(a, b)` is checkMotion(s1, s2) (AbstractVoxelMotionValidator.h:143-151) for a

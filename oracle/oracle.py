@@ -128,6 +128,7 @@ def _load(kind="strict"):
     lib.orc_segment_aabox_intersect.argtypes = [c_double_p] * 4
     lib.orc_rotate_points.argtypes = [c_double_p, c_double_p, C.c_int]
     lib.orc_is_valid_state.argtypes = [P(OrcRobot), P(OrcGrid), c_double_p, c_double_p, c_double_p, P(C.c_int)]
+    lib.orc_is_valid_state_spheres.argtypes = [P(OrcRobot), P(OrcGrid), c_double_p, c_double_p, c_double_p, P(C.c_int)]
     lib.orc_validate_batch.argtypes = [P(OrcRobot), P(OrcGrid), c_double_p, c_double_p, C.c_long,
                                        P(C.c_uint8), c_double_p, C.c_int]
     lib.orc_fk_batch.argtypes = [P(OrcRobot), c_double_p, C.c_long, c_double_p, c_double_p, c_double_p,
@@ -403,6 +404,15 @@ def is_valid_state(robot, grid, state, inv_rot=IDENTITY):
     flags = C.c_int(0)
     v = robot.lib.orc_is_valid_state(C.byref(robot.c), grid.ptr, _dp(inv_rot), _dp(state), _dp(tip),
                                      C.byref(flags))
+    return bool(v), tip, flags.value
+
+
+def is_valid_state_spheres(robot, grid, state, inv_rot=IDENTITY):
+    """VoxelValidityChecker: the robot voxelised as spheres of its radius at every backbone point."""
+    state, inv_rot = _f64(state), _f64(inv_rot).reshape(9)
+    tip = np.zeros(3)
+    flags = C.c_int(0)
+    v = robot.lib.orc_is_valid_state_spheres(C.byref(robot.c), grid.ptr, _dp(inv_rot), _dp(state), _dp(tip), C.byref(flags))
     return bool(v), tip, flags.value
 
 

@@ -952,9 +952,20 @@ void orc_rotate_points(const double inv_rot[9], double *pts, int n) {
  * one state-validity check: motion-planning/AbstractValidityChecker.cpp:124-133 with
  * AbstractVoxelValidityChecker.h:55-57 and VoxelBackboneValidityChecker.h:49-57
  * ---------------------------------------------------------------------------------------- */
+static int is_valid_state_ws2(const orc_robot *rb, const orc_grid *obstacles, const double inv_rot[9],
+                              const double *state, double tip[3], int *flags,
+                              orc_result *fk, orc_result *home, orc_grid *robot_vox, int spheres);
 static int is_valid_state_ws(const orc_robot *rb, const orc_grid *obstacles, const double inv_rot[9],
                              const double *state, double tip[3], int *flags,
                              orc_result *fk, orc_result *home, orc_grid *robot_vox) {
+  return is_valid_state_ws2(rb, obstacles, inv_rot, state, tip, flags, fk, home, robot_vox, 0);
+}
+/* spheres = 0: VoxelBackboneValidityChecker::voxelize_impl (VoxelBackboneValidityChecker.h:49-57);
+ * spheres = 1: VoxelValidityChecker::voxelize_impl (VoxelValidityChecker.h:18-26): a sphere of the
+ * robot radius at every rotated backbone point. */
+static int is_valid_state_ws2(const orc_robot *rb, const orc_grid *obstacles, const double inv_rot[9],
+                              const double *state, double tip[3], int *flags,
+                              orc_result *fk, orc_result *home, orc_grid *robot_vox, int spheres) {
   int fl = 0;
   if (tip) tip[0] = tip[1] = tip[2] = NAN;
   orc_shape(rb, state, fk);
@@ -973,7 +984,8 @@ static int is_valid_state_ws(const orc_robot *rb, const orc_grid *obstacles, con
     memcpy(rot, fk->p, sizeof(double) * 3 * (size_t)fk->n);
     orc_rotate_points(inv_rot, rot, fk->n);
     orc_grid_clear(robot_vox);
-    orc_grid_add_piecewise_line(robot_vox, rot, fk->n);
+    if (spheres) { for (int j = 0; j < fk->n; j++) orc_grid_add_sphere(robot_vox, rot + 3 * j, rb->r); }
+    else orc_grid_add_piecewise_line(robot_vox, rot, fk->n);
     free(rot);
     if (orc_grid_collides(obstacles, robot_vox)) break;
     fl |= 8;
@@ -1000,6 +1012,18 @@ int orc_is_valid_state(const orc_robot *rb, const orc_grid *obstacles, const dou
   result_alloc(&fk, cap); result_alloc(&home, cap);
   orc_grid *rv = orc_grid_empty_copy(obstacles);
   int v = is_valid_state_ws(rb, obstacles, inv_rot, state, tip, flags, &fk, &home, rv);
+  orc_grid_free(rv); result_free(&fk); result_free(&home);
+  return v;
+}
+
+/* AbstractValidityChecker::isValid with VoxelValidityChecker (sphere-swept robot, VoxelValidityChecker.h:18-26) */
+int orc_is_valid_state_spheres(const orc_robot *rb, const orc_grid *obstacles, const double inv_rot[9],
+                               const double *state, double tip[3], int *flags) {
+  orc_result fk, home;
+  int cap = max_points(rb);
+  result_alloc(&fk, cap); result_alloc(&home, cap);
+  orc_grid *rv = orc_grid_empty_copy(obstacles);
+  int v = is_valid_state_ws2(rb, obstacles, inv_rot, state, tip, flags, &fk, &home, rv, 1);
   orc_grid_free(rv); result_free(&fk); result_free(&home);
   return v;
 }

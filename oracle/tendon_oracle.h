@@ -119,6 +119,10 @@ void orc_rotate_points(const double inv_rot[9], double *pts, int n);
 int  orc_is_valid_state(const orc_robot *rb, const orc_grid *obstacles, const double inv_rot[9],
                         const double *state, double tip[3], int *flags);
 
+/* the same with VoxelValidityChecker's robot voxelisation: a sphere of radius rb->r at every backbone point */
+int  orc_is_valid_state_spheres(const orc_robot *rb, const orc_grid *obstacles, const double inv_rot[9],
+                                const double *state, double tip[3], int *flags);
+
 /* Batch of state-validity checks, OpenMP over configurations when built with -fopenmp
  * (mirrors motion-planning/VoxelCachedLazyPRM.cpp:1448-1455). Returns threads used. */
 int  orc_validate_batch(const orc_robot *rb, const orc_grid *obstacles, const double inv_rot[9],

@@ -80,6 +80,13 @@ int main(int argc, char **argv) {
     vc.nearest_k(flat, states.size(), 2, idx, dist);
     for (size_t i = 0; i < states.size(); i++) std::printf("knn %d %d %.17g\n", idx[2 * i], idx[2 * i + 1], dist[2 * i + 1]);
   }
+  // the sphere-swept checker on its own copy of the robot, same obstacle slab
+  {
+    tendon::TendonRobot robot2 = robot;                  // a copy has its own GPU context
+    motion_planning::VoxelValidityChecker sv(robot2, env, vox);
+    auto v2 = sv.isValidBatch(flat, states.size());
+    for (size_t i = 0; i < v2.size(); i++) std::printf("spheres %d\n", (int)v2[i]);
+  }
   try {
     collision::VoxelOctree fine(512);
     fine.set_xlim(-0.25, 0.25); fine.set_ylim(-0.25, 0.25); fine.set_zlim(-0.25, 0.25);
