@@ -189,7 +189,7 @@ def main():
                 traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # counted from the gfx950 ISA of fk_rk4_batch_uniform<3>: 2184 fp64 VALU instructions per RK4
+        # counted from the gfx950 ISA of fk_rk4_batch_uniform<3>: 2112 fp64 VALU instructions per RK4
         # step (762+ of them FMAs = 2 flops) -> ~3250 flop/step x 128 steps
         flops_per_check = 4.2e5
         out = {

@@ -51,11 +51,12 @@ __device__ __forceinline__ double fast_rsqrt(double x) {
 }
 
 // Right-hand side for the strain part of the state: (v', u') and the length rates.
-// ri: wave-uniform pointer to N x 6 doubles {rx, ry, rdx, rdy, rddx, rddy} per tendon.
-template <int N>
-__device__ __forceinline__ void strain_rates(const double v[3], const double u[3], const double (&tau)[N],
-                                             const double *__restrict__ ri, const RobotK &K,
-                                             double dv[3], double du[3], double (&sdot)[N]) {
+// route(j, r6) yields tendon j's routing {rx, ry, rdx, rdy, rddx, rddy} when the tendon loop reaches it
+// (a table row for the shared-grid kernel, an on-the-fly evaluation for the retraction kernel).
+template <int N, class Route>
+__device__ __forceinline__ void strain_rates_routed(const double v[3], const double u[3], const double (&tau)[N],
+                                                    Route &&route, const RobotK &K,
+                                                    double dv[3], double du[3], double (&sdot)[N]) {
 #pragma clang fp contract(fast)
   // Sums over tendons, using A_i = c (pd pd^T - |pd|^2 I), c = -tau/|pd|^3, q = c pd, e = r x pd, g = c e:
   //   A = sum q pd^T - (sum c|pd|^2) I
@@ -68,9 +69,11 @@ __device__ __forceinline__ void strain_rates(const double v[3], const double u[3
   double ax = 0, ay = 0, az = 0, bx = 0, by = 0, bz = 0;
 #pragma unroll
   for (int j = 0; j < N; j++) {
-    const double rx = ri[6 * j + 0], ry = ri[6 * j + 1];
-    const double rdx = ri[6 * j + 2], rdy = ri[6 * j + 3];
-    const double rddx = ri[6 * j + 4], rddy = ri[6 * j + 5];
+    double r6[6];
+    route(j, r6);
+    const double rx = r6[0], ry = r6[1];
+    const double rdx = r6[2], rdy = r6[3];
+    const double rddx = r6[4], rddy = r6[5];
     // pd = u x r + r' + v
     const double pdx = (v[0] + rdx) - u[2] * ry;
     const double pdy = (v[1] + rdy) + u[2] * rx;
@@ -154,6 +157,17 @@ __device__ __forceinline__ void strain_rates(const double v[3], const double u[3
   dv[2] = yz - (T02 * du[0] + T12 * du[1] + T22 * du[2]);
 }
 
+// ri: wave-uniform pointer to N x 6 doubles {rx, ry, rdx, rdy, rddx, rddy} per tendon.
+template <int N>
+__device__ __forceinline__ void strain_rates(const double v[3], const double u[3], const double (&tau)[N],
+                                             const double *__restrict__ ri, const RobotK &K,
+                                             double dv[3], double du[3], double (&sdot)[N]) {
+  strain_rates_routed<N>(v, u, tau, [&](int j, double (&r6)[6]) {
+#pragma unroll
+    for (int q = 0; q < 6; q++) r6[q] = ri[6 * j + q];
+  }, K, dv, du, sdot);
+}
+
 // solve_initial_bending + base residual.  Written without contraction and with IEEE div/sqrt so
 // the data-dependent iteration count follows the same decisions as a plain fp64 evaluation.
 // rb: wave-uniform pointer to N x 6 routing values at s_start (only the first 4 of each are used).
@@ -222,7 +236,7 @@ __device__ __forceinline__ void initial_bending(const double (&tau)[N], const do
 
 // One classical RK4 step of size h (Boost.odeint runge_kutta4 tableau: a = {1/2},{0,1/2},{0,0,1};
 // b = {1/6,1/3,1/3,1/6}; c = {0,1/2,1/2,1}) of the state (R, v, u | p, L, L_i), with the routing
-// produced on demand by `route(t, ri)` at t, t + h/2 (shared by stages 2 and 3) and t + h.
+// produced on demand, tendon by tendon, by `route(t, j, r6)` at t, t + h/2 (stages 2 and 3) and t + h.
 // Used by the retraction kernel; the shared-grid kernel below carries the same statements inline
 // (as a function taking three table rows it made hipcc hoist all scalar loads and spill ~100 VGPRs).
 template <int N, class Route>
@@ -242,16 +256,17 @@ __device__ __forceinline__ void rk4_step_routed(double (&R)[9], double (&v)[3], 
   for (int q = 0; q < 9; q++) sR[q] = R[q];
 #pragma unroll
   for (int q = 0; q < 3; q++) { sv[q] = v[q]; su[q] = u[q]; }
-  double ri[N * 6];
 #pragma unroll
   for (int st = 0; st < 4; st++) {
-    if (st == 0) route(t, ri);
-    if (st == 1) route(t + h * 0.5, ri);
-    if (st == 3) route(t + h, ri);
+    // The routing depends on the abscissa only, so the scheduler would evaluate all four stages' routing
+    // up front and keep it live (measured: +170 registers).  Tying the abscissa to the stage state keeps
+    // each evaluation next to its use.
+    double ts = (st == 0) ? t : ((st == 3) ? t + h : t + hh);
+    asm volatile("" : "+v"(ts) : "v"(sv[0]), "v"(su[0]));
     const double bw = (st == 0 || st == 3) ? b1 : b2;
     const double aw = (st == 2) ? h : hh;
     double dv[3], du[3], sd[N];
-    strain_rates<N>(sv, su, tau, ri, K, dv, du, sd);
+    strain_rates_routed<N>(sv, su, tau, [&](int j, double (&r6)[6]) { route(ts, j, r6); }, K, dv, du, sd);
     p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
     p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
     p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);

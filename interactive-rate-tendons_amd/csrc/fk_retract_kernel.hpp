@@ -3,7 +3,7 @@
 // backbone points, a first interval in [dL/2, 1.5 dL) that may need two RK4 steps
 // (integrate_times, call site TendonRobot.cpp:458-462), and its own home-shape tendon lengths
 // (home_shape(s_start), TendonRobot.cpp:249-314).  The routing r(t), r'(t), r''(t) is evaluated per
-// lane (polynomials with scalar coefficients + sincos) on demand per RK4 stage (rk4_step_routed).
+// lane, tendon by tendon, where the RK4 stage needs it (rk4_step_routed, route_tendon).
 //
 // Lanes run their intervals aligned at the base (interval j of every lane in iteration j); lanes
 // with a retracted, shorter backbone idle at the end of the wave's loop.
@@ -12,32 +12,59 @@
 
 namespace trk {
 
-// get_poly_vecs + get_r_info2 (tendon/get_r_info.cpp:17-40,105-144) for one lane's abscissa t.
+// Per-lane routing (get_poly_vecs + get_r_info2, tendon/get_r_info.cpp:17-40,105-144).  A lane carries, per
+// tendon, the routing angle theta at the abscissa it was last evaluated at together with its sine and
+// cosine.  Evaluating at a new abscissa is Horner for theta, rho and their first two derivatives (scalar
+// coefficient loads, wave-uniform degree) plus a rotation of (sin, cos) by dtheta = theta_new - theta_old
+// with an 11th/12th-order Taylor pair -- |dtheta| is ~1e-2 for a half step; beyond 1/8 rad it falls back to
+// sincos.  Re-evaluating at the same abscissa rotates by exactly zero.  (FK parity is a 1e-9 m tolerance:
+// the rotations add ~1e-16 each.)
 template <int N>
-__device__ __forceinline__ void routing_lane(const PolyK *__restrict__ pk, int n_a, int n_m, double t, double (&out)[N * 6]) {
-#pragma clang fp contract(off)
-  double S[TRK_MAX_COEF], Sd[TRK_MAX_COEF], Sdd[TRK_MAX_COEF];
-  S[0] = 1; Sd[0] = 0; Sdd[0] = 0;
-  S[1] = t; Sd[1] = 1; Sdd[1] = 0;
-#pragma unroll
-  for (int i = 2; i < TRK_MAX_COEF; i++) { S[i] = t * S[i - 1]; Sd[i] = i * S[i - 1]; Sdd[i] = i * (i - 1) * S[i - 2]; }
+struct RouteCarry { double th[N], sn[N], cs[N]; };
+
+// value, first and second derivative of sum_i c[i] t^i, c wave-uniform
+__device__ __forceinline__ void horner3(const double *__restrict__ c, int n, double t, double &p, double &d1, double &d2) {
+  p = 0.0; d1 = 0.0; d2 = 0.0;
+  for (int i = n - 1; i >= 0; --i) { d2 = d2 * t + d1; d1 = d1 * t + p; p = p * t + c[i]; }
+  d2 = d2 + d2;
+}
+
+template <int N>
+__device__ __forceinline__ void route_anchor(const PolyK *__restrict__ pk, int n_a, double t, RouteCarry<N> &rc) {
 #pragma unroll
   for (int j = 0; j < N; j++) {
-    double C_a = 0, C_ad = 0, C_add = 0, D_m = 0, D_md = 0, D_mdd = 0;
-#pragma unroll
-    for (int i = 0; i < TRK_MAX_COEF; i++) {
-      if (i < n_a) { const double c = pk->C[j][i]; C_a += c * S[i]; C_ad += c * Sd[i]; C_add += c * Sdd[i]; }
-      if (i < n_m) { const double d = pk->D[j][i]; D_m += d * S[i]; D_md += d * Sd[i]; D_mdd += d * Sdd[i]; }
-    }
-    double sa, ca;
-    sincos(C_a, &sa, &ca);
-    out[6 * j + 0] = D_m * sa;
-    out[6 * j + 1] = D_m * ca;
-    out[6 * j + 2] = D_md * sa + D_m * (ca * C_ad);
-    out[6 * j + 3] = D_md * ca + D_m * (-sa * C_ad);
-    out[6 * j + 4] = D_mdd * sa + 2 * D_md * (ca * C_ad) - D_m * (sa * C_ad * C_ad) + D_m * (ca * C_add);
-    out[6 * j + 5] = D_mdd * ca + 2 * D_md * (-sa * C_ad) - D_m * (ca * C_ad * C_ad) + D_m * (-sa * C_add);
+    double th, a1, a2;
+    horner3(pk->C[j], n_a, t, th, a1, a2);
+    rc.th[j] = th;
+    sincos(th, &rc.sn[j], &rc.cs[j]);
   }
+}
+
+template <int N>
+__device__ __forceinline__ void route_tendon(const PolyK *__restrict__ pk, int n_a, int n_m, int j, double t, RouteCarry<N> &rc,
+                                             double (&r6)[6]) {
+#pragma clang fp contract(fast)
+  double th, C_ad, C_add, D_m, D_md, D_mdd;
+  horner3(pk->C[j], n_a, t, th, C_ad, C_add);
+  horner3(pk->D[j], n_m, t, D_m, D_md, D_mdd);
+  const double dth = th - rc.th[j];
+  double sa, ca;
+  if (fabs(dth) <= 0.125) {
+    const double x2 = dth * dth;
+    const double sd = dth * (1.0 + x2 * (-1.0 / 6 + x2 * (1.0 / 120 + x2 * (-1.0 / 5040 + x2 * (1.0 / 362880 + x2 * (-1.0 / 39916800))))));
+    const double cd = 1.0 + x2 * (-0.5 + x2 * (1.0 / 24 + x2 * (-1.0 / 720 + x2 * (1.0 / 40320 + x2 * (-1.0 / 3628800 + x2 * (1.0 / 479001600))))));
+    sa = rc.sn[j] * cd + rc.cs[j] * sd;
+    ca = rc.cs[j] * cd - rc.sn[j] * sd;
+  } else {
+    sincos(th, &sa, &ca);
+  }
+  rc.th[j] = th; rc.sn[j] = sa; rc.cs[j] = ca;
+  r6[0] = D_m * sa;
+  r6[1] = D_m * ca;
+  r6[2] = D_md * sa + D_m * (ca * C_ad);
+  r6[3] = D_md * ca + D_m * (-sa * C_ad);
+  r6[4] = D_mdd * sa + 2 * D_md * (ca * C_ad) - D_m * (sa * C_ad * C_ad) + D_m * (ca * C_add);
+  r6[5] = D_mdd * ca + 2 * D_md * (-sa * C_ad) - D_m * (ca * C_ad * C_ad) + D_m * (-sa * C_add);
 }
 
 // integrand of the home tendon length: sqrt(rho'^2 + rho^2 theta'^2 + 1) (TendonRobot.cpp:300-307,
@@ -55,8 +82,14 @@ __device__ __forceinline__ double home_ldot(const PolyK *__restrict__ pk, int j,
   return sqrt(dd * dd + (d * d) * (cd * cd) + 1);
 }
 
+// One wave per SIMD: the per-lane routing state (carried angles, abscissae, home-length sums) adds ~70
+// registers to K1's 255; held to 256 registers (two waves) the kernel spills ~290 and runs 50 % slower
+// (measured: 12.7 vs 8.5 ms per 2^19 three-tendon configurations).
+#ifndef TRK_K1R_WAVES
+#define TRK_K1R_WAVES 1
+#endif
 template <int N, bool ROT, bool WRITE_R>
-__global__ __launch_bounds__(64) void fk_rk4_batch_retract(
+__global__ __launch_bounds__(64, TRK_K1R_WAVES) void fk_rk4_batch_retract(
     const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const PolyK *__restrict__ pk,
     double *__restrict__ pscr /* [P][ld] scratch for the range() abscissae */, FkOut out) {
 #pragma clang fp contract(fast)
@@ -94,8 +127,16 @@ __global__ __launch_bounds__(64) void fk_rk4_batch_retract(
   }
   const int P_lane = single ? 1 : m + 1;
 
+  RouteCarry<N> rcy;
+  route_anchor<N>(pk, K.n_a, s, rcy);
   double rloc[N * 6];
-  routing_lane<N>(pk, K.n_a, K.n_m, s, rloc);
+#pragma unroll
+  for (int j = 0; j < N; j++) {
+    double r6[6];
+    route_tendon<N>(pk, K.n_a, K.n_m, j, s, rcy, r6);
+#pragma unroll
+    for (int q = 0; q < 6; q++) rloc[6 * j + q] = r6[q];
+  }
   double v[3], u[3];
   bool conv;
   initial_bending<N>(tau, rloc, K, v, u, conv);
@@ -159,7 +200,7 @@ __global__ __launch_bounds__(64) void fk_rk4_batch_retract(
       if (go) {
         const double h = (dL < tn - cur) ? dL : (tn - cur);
         rk4_step_routed<N>(R, v, u, p, Lb, Li, tau, K, cur, h,
-                           [&](double tt, double (&ri)[N * 6]) { routing_lane<N>(pk, K.n_a, K.n_m, tt, ri); });
+                           [&](double tt, int j, double (&r6)[6]) { route_tendon<N>(pk, K.n_a, K.n_m, j, tt, rcy, r6); });
         cur += h;
       }
     }

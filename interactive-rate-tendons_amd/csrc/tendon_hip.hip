@@ -783,6 +783,7 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
   if (n < 0 || (n > 0 && !states)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());          // the workspace is shared with *_dev calls that may still run on other streams
   const int S = c->K.state_size, P = c->K.n_points, N = c->K.n_tendons;
   const int64_t chunk_max = std::min<int64_t>(c->max_chunk, 1 << 16);
   int rc;
@@ -1091,6 +1092,7 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
   if (n == 0) return TR_OK;
   if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());
   const int64_t chunk = std::min<int64_t>(c->max_chunk, 1 << 18);   // block-list scratch: 12 B x (2P + 16) per configuration
   int rc;
   if ((rc = ensure_workspace(c, std::min(n, chunk)))) return rc;

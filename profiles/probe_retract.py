@@ -1,0 +1,31 @@
+"""K1r (retraction kernel, per-lane arc-length grid) against K1 + K2 on the same robot: device-resident rates."""
+import importlib, os, sys, time
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))
+import numpy as np, torch
+irt = importlib.import_module("interactive-rate-tendons_amd")
+W = irt.workloads
+vox, _ = W.reach_environment(seed=7, n_spheres=64)
+for ret in (False, True):
+    for mk in (W.robot_config2, W.robot_config3):
+        robot = mk()
+        robot.enable_retraction = ret
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        n = 1 << 19
+        st = W.random_states(robot, n, seed=1, tau_max=10.0)
+        if ret:
+            st[:, -1] = np.random.default_rng(2).uniform(0, 0.1, n)
+        d = torch.from_numpy(st).cuda()
+        bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
+        chk.engine.reserve(n)
+        for _ in range(2):
+            chk.engine.validate_batch_dev(d, n, bits)
+        torch.cuda.synchronize()
+        chk.engine.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            chk.engine.validate_batch_dev(d, n, bits)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 5
+        pr = chk.engine.profile_read(); chk.engine.profile_end()
+        print("retract", ret, "tendons", len(robot.tendons), "ms per 2^19", round(dt * 1e3, 2), "checks/s %.3g" % (n / dt),
+              {k: round(v["total_ms"] / max(1, v["launches"]), 2) for k, v in pr.items() if v["launches"]})
