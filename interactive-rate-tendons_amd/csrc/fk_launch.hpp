@@ -14,7 +14,7 @@ struct FkLaunch {
   // shared arc-length grid (retraction disabled)
   const double *d_tab; const StepK *d_steps; int n_steps;
   // per-lane grid (retraction enabled)
-  const PolyK *d_poly; double *pscr;
+  const PolyK *d_poly; int k_first; const double *d_tgrid, *d_hl;
   FkOut out;
   hipStream_t stream;
 };

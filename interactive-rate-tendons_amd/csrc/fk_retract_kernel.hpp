@@ -5,8 +5,14 @@
 // (home_shape(s_start), TendonRobot.cpp:249-314).  The routing r(t), r'(t), r''(t) is evaluated per
 // lane, tendon by tendon, where the RK4 stage needs it (rk4_step_routed, route_tendon).
 //
-// Lanes run their intervals aligned at the base (interval j of every lane in iteration j); lanes
-// with a retracted, shorter backbone idle at the end of the wave's loop.
+// t_range spaces its abscissae uniformly FROM THE TIP: apart from the first interval (s_start to the first
+// grid point, length in [dL/2, 1.5 dL)) every lane integrates over the same grid L - k dL as the
+// unretracted robot, to an ulp.  So a lane first covers its own first interval with per-lane routing
+// (route_tendon), and then the wave runs TIP-ALIGNED: iteration = interval of the shared grid, retracted
+// lanes join late instead of finishing early, and the routing comes from K1's scalar table -- K1's
+// inner loop and K1's two-wave register budget.  A lane's point i is the shared grid's point
+// i + (P - P_lane); it is stored in the lane's own row i (stores are therefore not coalesced across lanes:
+// ~4x write amplification on 3 KB per configuration, far below what HBM sustains).
 #pragma once
 #include "fk_kernel.hpp"
 
@@ -82,16 +88,17 @@ __device__ __forceinline__ double home_ldot(const PolyK *__restrict__ pk, int j,
   return sqrt(dd * dd + (d * d) * (cd * cd) + 1);
 }
 
-// One wave per SIMD: the per-lane routing state (carried angles, abscissae, home-length sums) adds ~70
-// registers to K1's 255; held to 256 registers (two waves) the kernel spills ~290 and runs 50 % slower
-// (measured: 12.7 vs 8.5 ms per 2^19 three-tendon configurations).
-#ifndef TRK_K1R_WAVES
-#define TRK_K1R_WAVES 1
+// Two waves per SIMD up to 3 tendons; from 4 the lane-private bookkeeping on top of K1's budget spills too much
+// (measured, ms per 2^19 configurations, two waves | one wave: N=4 9.0 | 8.4).
+#ifndef TRK_K1R_TWO_WAVE_MAXN
+#define TRK_K1R_TWO_WAVE_MAXN 3
 #endif
 template <int N, bool ROT, bool WRITE_R>
-__global__ __launch_bounds__(64, TRK_K1R_WAVES) void fk_rk4_batch_retract(
+__global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_rk4_batch_retract(
     const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const PolyK *__restrict__ pk,
-    double *__restrict__ pscr /* [P][ld] scratch for the range() abscissae */, FkOut out) {
+    const double *__restrict__ tab /* K1's routing table of the s_start = 0 grid */, const StepK *__restrict__ steps, int nsteps,
+    int k_first /* first step after the grid's own first interval */, const double *__restrict__ tgrid /* [P] shared abscissae */,
+    const double *__restrict__ hl /* [P][N] home-length integrand at the shared abscissae */, FkOut out) {
 #pragma clang fp contract(fast)
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = i < n;
@@ -115,31 +122,34 @@ __global__ __launch_bounds__(64, TRK_K1R_WAVES) void fk_rk4_batch_retract(
   if (s > L) s = L;                                  // TendonRobot.cpp:359
   const bool single = (s == L) || negative;          // :361-372
 
-  // forward pass of util::range: p_0 = s, p_{k+1} = p_k + dL while p <= L - dL/2
+  // forward pass of util::range: p_0 = s, p_{k+1} = p_k + dL while p <= L - dL/2 -> number of points
   int m = 0;
   {
     double q = s;
     for (int k = 0; k < Pmax; k++) {
       const bool go = !single && (q <= L - (dL / 2)) && k < Pmax - 1;
       if (!__any(go)) break;
-      if (go) { pscr[(int64_t)k * ld + ic] = q; m = k + 1; q += dL; }
+      if (go) { m = k + 1; q += dL; }
     }
   }
   const int P_lane = single ? 1 : m + 1;
+  const int shift = Pmax - P_lane;                   // lane point i = shared grid point i + shift (i >= 1)
 
   RouteCarry<N> rcy;
   route_anchor<N>(pk, K.n_a, s, rcy);
-  double rloc[N * 6];
-#pragma unroll
-  for (int j = 0; j < N; j++) {
-    double r6[6];
-    route_tendon<N>(pk, K.n_a, K.n_m, j, s, rcy, r6);
-#pragma unroll
-    for (int q = 0; q < 6; q++) rloc[6 * j + q] = r6[q];
-  }
   double v[3], u[3];
   bool conv;
-  initial_bending<N>(tau, rloc, K, v, u, conv);
+  {
+    double rloc[N * 6];
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double r6[6];
+      route_tendon<N>(pk, K.n_a, K.n_m, j, s, rcy, r6);
+#pragma unroll
+      for (int q = 0; q < 6; q++) rloc[6 * j + q] = r6[q];
+    }
+    initial_bending<N>(tau, rloc, K, v, u, conv);
+  }
   if (single) { conv = !negative; }                  // early return keeps the default converged = true
 
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
@@ -166,36 +176,13 @@ __global__ __launch_bounds__(64, TRK_K1R_WAVES) void fk_rk4_batch_retract(
   };
   if (live) store_point(0);
 
-  // home-shape tendon lengths: home_shape clamps s_start into [0, L] (TendonRobot.cpp:257-258)
-  bool any_general = false;
-#pragma unroll
-  for (int j = 0; j < N; j++) any_general = any_general || (pk->home_kind[j] == 2);
-  const int nint = P_lane - 1;
-  const int ne = (nint % 2 != 0) ? nint - 1 : nint;  // intervals covered by Simpson's rule
-  double hsum[N], hodd[N];
-#pragma unroll
-  for (int j = 0; j < N; j++) { hsum[j] = 0; hodd[j] = 0; }
-  auto home_visit = [&](int jpt, double t) {
-    if (!any_general || single) return;
-#pragma unroll
-    for (int j = 0; j < N; j++) {
-      if (pk->home_kind[j] != 2) continue;
-      const double val = home_ldot(pk, j, K.n_a, K.n_m, t);
-      if (ne > 0 && jpt <= ne) hsum[j] += ((jpt == 0 || jpt == ne) ? 1.0 : ((jpt & 1) ? 4.0 : 2.0)) * val;
-      if (nint % 2 != 0 && jpt >= P_lane - 2) hodd[j] += val;
-    }
-  };
-
-  double cur = L - (L - s);                          // t[0]: the mirrored `end` sample of t_range
-  home_visit(0, cur);
-  for (int j = 0; j < Pmax - 1; j++) {
-    const bool act = j < P_lane - 1;
-    if (!__any(act)) break;
-    double tn = cur;
-    if (act) tn = L - (pscr[(int64_t)(m - 1 - j) * ld + ic] - s);      // t[j+1]
-    // integrate_times: steps of min(dL, t[j+1] - cur) while t[j+1] - cur > eps
+  // the lane's own first interval: s -> shared grid point shift + 1, steps of min(dL, remaining) while
+  // remaining > eps (integrate_times), routing evaluated per lane
+  if (__any(!single)) {
+    double cur = L - (L - s);                        // t[0]: the mirrored `end` sample of t_range
+    const double tn = single ? cur : tgrid[shift + 1];
     for (int sub = 0; sub < 4; sub++) {
-      const bool go = act && (tn - cur > 2.220446049250313e-16);
+      const bool go = !single && (tn - cur > 2.220446049250313e-16);
       if (!__any(go)) break;
       if (go) {
         const double h = (dL < tn - cur) ? dL : (tn - cur);
@@ -204,12 +191,106 @@ __global__ __launch_bounds__(64, TRK_K1R_WAVES) void fk_rk4_batch_retract(
         cur += h;
       }
     }
+    if (!single && live) store_point(1);
+  }
+
+  // tip-aligned: step k of the shared grid ends at its point steps[k].obs = the lane's point obs - shift
+  for (int k = k_first; k < nsteps; k++) {
+    const int obs = steps[k].obs;
+    const int ipt = obs - shift;
+    const bool act = !single && ipt >= 2;
+    if (!__any(act)) continue;
     if (act) {
-      cur = tn;                                      // the next interval restarts at exactly t[j+1]
-      if (live) store_point(j + 1);
-      home_visit(j + 1, tn);
+      const double h = steps[k].h;
+      const double *__restrict__ rt = tab + (size_t)(1 + 3 * k) * (N * 6);
+      const double hh = h * 0.5;
+      const double b1 = h * (1.0 / 6.0), b2 = h * (1.0 / 3.0);
+      double aR[9], av[3], au[3];
+#pragma unroll
+      for (int q = 0; q < 9; q++) aR[q] = R[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { av[q] = v[q]; au[q] = u[q]; }
+      double sR[9], sv[3], su[3];
+#pragma unroll
+      for (int q = 0; q < 9; q++) sR[q] = R[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { sv[q] = v[q]; su[q] = u[q]; }
+#pragma unroll
+      for (int st = 0; st < 4; st++) {
+        const double *__restrict__ ri = rt + (st == 0 ? 0 : (st == 3 ? 2 : 1)) * (N * 6);
+        const double bw = (st == 0 || st == 3) ? b1 : b2;
+        const double aw = (st == 2) ? h : hh;
+        double dv[3], du[3], sd[N];
+        strain_rates<N>(sv, su, tau, ri, K, dv, du, sd);
+        p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
+        p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
+        p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);
+        {
+          const double v2 = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2];
+          Lb += bw * (v2 * fast_rsqrt(v2));
+        }
+#pragma unroll
+        for (int j = 0; j < N; j++) Li[j] += bw * sd[j];
+        double dR[9];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+          const double r0 = sR[0 + r], r1 = sR[3 + r], r2 = sR[6 + r];
+          dR[0 + r] = r1 * su[2] - r2 * su[1];
+          dR[3 + r] = r2 * su[0] - r0 * su[2];
+          dR[6 + r] = r0 * su[1] - r1 * su[0];
+        }
+#pragma unroll
+        for (int q = 0; q < 9; q++) aR[q] += bw * dR[q];
+#pragma unroll
+        for (int q = 0; q < 3; q++) { av[q] += bw * dv[q]; au[q] += bw * du[q]; }
+        if (st < 3) {
+#pragma unroll
+          for (int q = 0; q < 9; q++) sR[q] = R[q] + aw * dR[q];
+#pragma unroll
+          for (int q = 0; q < 3; q++) { sv[q] = v[q] + aw * dv[q]; su[q] = u[q] + aw * du[q]; }
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 9; q++) R[q] = aR[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { v[q] = av[q]; u[q] = au[q]; }
+      if (live) store_point(ipt);
     }
   }
+
+  // home-shape tendon lengths: home_shape clamps s_start into [0, L] (TendonRobot.cpp:257-258); composite
+  // Simpson over the lane's points with a trapezoid for a trailing odd interval (see tendon_hip.hip: home_lengths)
+  bool any_general = false;
+#pragma unroll
+  for (int j = 0; j < N; j++) any_general = any_general || (pk->home_kind[j] == 2);
+  const int nint = P_lane - 1;
+  const int ne = (nint % 2 != 0) ? nint - 1 : nint;  // intervals covered by Simpson's rule
+  double hsum[N], hodd[N];
+#pragma unroll
+  for (int j = 0; j < N; j++) { hsum[j] = 0; hodd[j] = 0; }
+  auto home_add = [&](int jpt, int j, double val) {
+    if (ne > 0 && jpt <= ne) hsum[j] += ((jpt == 0 || jpt == ne) ? 1.0 : ((jpt & 1) ? 4.0 : 2.0)) * val;
+    if (nint % 2 != 0 && jpt >= P_lane - 2) hodd[j] += val;
+  };
+  if (any_general && __any(!single)) {
+    // the integrand at the lane's points: its own base abscissa, then the shared grid (a pass of its own after
+    // the RK4 loop, so that the sums are not live -- 2 N more registers -- across it)
+    if (!single) {
+#pragma unroll
+      for (int j = 0; j < N; j++)
+        if (pk->home_kind[j] == 2) home_add(0, j, home_ldot(pk, j, K.n_a, K.n_m, L - (L - s)));
+    }
+    for (int ipt = 1; ipt < Pmax; ipt++) {
+      const bool on = !single && ipt < P_lane;
+      if (!__any(on)) break;
+      if (on) {
+#pragma unroll
+        for (int j = 0; j < N; j++)
+          if (pk->home_kind[j] == 2) home_add(ipt, j, hl[(int64_t)(ipt + shift) * N + j]);
+      }
+    }
+  }
+
 
   if (live) {
     if (out.L) out.L[i] = Lb;

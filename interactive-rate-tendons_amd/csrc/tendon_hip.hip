@@ -87,6 +87,9 @@ struct tr_ctx {
   double *d_tab = nullptr;
   StepK *d_steps = nullptr;
   PolyK *d_poly = nullptr;        // routing polynomials (retraction kernel)
+  double *d_tgrid = nullptr;      // [P] abscissae of the s_start = 0 grid (retraction kernel: shared, tip-anchored grid)
+  double *d_hl = nullptr;         // [P][N] home-length integrand at those abscissae
+  int k_first = 0;                // first step after the grid's own first interval
   // obstacle grid
   bool has_grid = false;
   GridK G{};
@@ -298,15 +301,12 @@ struct ProfScope {
 };
 
 // ---- K1 launch (instantiations live in fk_inst.hip objects) ------------------------------------
-// With retraction the kernel uses ws.acc (leading dimension ws.ld) as scratch for the range()
-// abscissae, so ld must equal ws.ld there.
 int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
   if (n <= 0) return TR_OK;
   ProfScope ps(ctx, 0, s);
   const bool ret = ctx->K.enable_retraction;
-  if (ret && ld != ctx->ws.ld) return fail(ctx, TR_ERR_INVALID_ARG, "retraction: ld must equal the workspace leading dimension (tr_reserve)");
   const trk::FkLaunch a{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, out.R != nullptr, ctx->d_tab, ctx->d_steps,
-                        (int)ctx->steps.size(), ctx->d_poly, ctx->ws.acc, out, s};
+                        (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, out, s};
   switch (ctx->K.n_tendons) {
 #define TRK_CASE(N) case N: if (ret) trk::launch_fk_retract<N>(a); else trk::launch_fk_uniform<N>(a); break;
     TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
@@ -371,7 +371,7 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
   {
     ProfScope ps(ctx, 4, s);
     const trk::FkLaunch fl{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
-                           (int)ctx->steps.size(), ctx->d_poly, ctx->ws.acc, out, s};
+                           (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, out, s};
     switch (ctx->K.n_tendons) {
 #define TRK_CASE(N) case N: trk::launch_fk_sweep_fused<N>(fl, fr.d_slots + slot, lds); break;
       TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
@@ -526,6 +526,19 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
     routing_at(c, tk + h, &tab[(1 + 3 * k + 2) * ent]);
   }
   home_lengths(c, c->t, 0.0, K.home_Li);
+  // retraction kernel: the step after the grid's own first interval, and the home-length integrand
+  // sqrt(rho'^2 + rho^2 theta'^2 + 1) (TendonRobot.cpp:300-307) at every shared abscissa
+  for (size_t k = 0; k < c->steps.size(); k++) if (c->steps[k].obs == 1) c->k_first = (int)k + 1;
+  std::vector<double> hl(c->t.size() * (size_t)N);
+  for (size_t q = 0; q < c->t.size(); q++)
+    for (int j = 0; j < N; j++) {
+      const double *Cj = &c->C[(size_t)j * rb->n_a], *Dj = &c->D[(size_t)j * rb->n_m];
+      double Cdot[TRK_MAX_COEF] = {0}, Ddot[TRK_MAX_COEF] = {0};
+      for (int k = 1; k < rb->n_a; k++) Cdot[k - 1] = k * Cj[k];
+      for (int k = 1; k < rb->n_m; k++) Ddot[k - 1] = k * Dj[k];
+      const double dd = poly_at(Ddot, rb->n_m, c->t[q]), dv = poly_at(Dj, rb->n_m, c->t[q]), cd = poly_at(Cdot, rb->n_a, c->t[q]);
+      hl[q * N + j] = std::sqrt(dd * dd + (dv * dv) * (cd * cd) + 1);
+    }
   PolyK poly{};
   for (int j = 0; j < N; j++) {
     for (int i = 0; i < rb->n_a; i++) poly.C[j][i] = c->C[(size_t)j * rb->n_a + i];
@@ -539,6 +552,10 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   auto bail = [&](const char *what) { std::string m = what; tr_destroy(c); return fail(nullptr, TR_ERR_HIP, m); };
   if (hipMalloc((void **)&c->d_poly, sizeof(PolyK)) != hipSuccess) return bail("hipMalloc(poly)");
   if (hipMemcpy(c->d_poly, &poly, sizeof(PolyK), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy(poly)");
+  if (hipMalloc((void **)&c->d_tgrid, c->t.size() * sizeof(double)) != hipSuccess ||
+      hipMalloc((void **)&c->d_hl, hl.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc(tgrid)");
+  if (hipMemcpy(c->d_tgrid, c->t.data(), c->t.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess ||
+      hipMemcpy(c->d_hl, hl.data(), hl.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy(tgrid)");
   if (hipMalloc((void **)&c->d_tab, tab.size() * sizeof(double)) != hipSuccess) return bail("hipMalloc(tab)");
   if (hipMemcpy(c->d_tab, tab.data(), tab.size() * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return bail("hipMemcpy(tab)");
   if (hipMalloc((void **)&c->d_steps, std::max<size_t>(1, c->steps.size()) * sizeof(StepK)) != hipSuccess) return bail("hipMalloc(steps)");
@@ -561,7 +578,7 @@ void tr_destroy(tr_ctx *c) {
     (void)hipStreamDestroy(c->pipe.s_up); (void)hipStreamDestroy(c->pipe.s_comp); (void)hipStreamDestroy(c->pipe.s_down);
   }
   Workspace &w = c->ws;
-  void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_grid, c->d_near, w.homeLi, w.np, c->d_vids, c->d_vmasks, c->d_vcounts,
+  void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_tgrid, c->d_hl, c->d_grid, c->d_near, w.homeLi, w.np, c->d_vids, c->d_vmasks, c->d_vcounts,
                   c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
@@ -767,11 +784,6 @@ int tr_fk_batch_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t ld, do
   if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
   if (n == 0) return TR_OK;
   if (!d_states || !d_px || !d_py || !d_pz) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
-  if (c->K.enable_retraction) {
-    // the retraction kernel keeps its range() scratch in the workspace, whose leading dimension it shares
-    if (c->ws.ld == 0) { int rc = ensure_workspace(c, ld); if (rc) return rc; }
-    if (ld != c->ws.ld) return fail(c, TR_ERR_INVALID_ARG, "retraction: ld must equal the reserved workspace size (tr_reserve(ld))");
-  }
   trk::FkOut out{d_px, d_py, d_pz, d_R, d_L, d_Li, nullptr, d_converged, d_n_points, nullptr};
   return launch_fk(c, d_states, n, ld, out, (hipStream_t)stream);
 }
