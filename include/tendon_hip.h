@@ -144,7 +144,9 @@ int tr_fk_batch(tr_ctx *ctx, const double *states, int64_t n,
 
 /* Device form.  Points are written structure-of-arrays, lane-contiguous:
  * d_px[j*ld + i] is x of point j of configuration i (ld >= n, multiple of 64).  d_R (optional)
- * is [9][P][ld].  d_Li is [N][ld]. */
+ * is [9][P][ld].  d_Li is [N][ld].
+ * With retraction enabled a configuration has d_n_points[i] <= P points and its rows are aligned at the
+ * TIP: point j of configuration i is in row j + (P - d_n_points[i]) (the tip always in row P - 1). */
 int tr_fk_batch_dev(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld,
                     double *d_px, double *d_py, double *d_pz, double *d_R,
                     double *d_L, double *d_Li, uint8_t *d_converged, int32_t *d_n_points,
@@ -167,7 +169,8 @@ int tr_validate_batch_dev(tr_ctx *ctx, const double *d_states, int64_t n,
 
 /* The second stage alone, on caller-supplied backbone shapes (is_valid_shape + voxelize +
  * collides on given TendonResults: AbstractValidityChecker.cpp:99-122).  Device pointers, SoA as
- * produced by tr_fk_batch_dev.  d_n_points may be NULL (all P).  check_voxels = 0 skips the
+ * produced by tr_fk_batch_dev (with d_n_points given, rows aligned at the tip as described there).
+ * d_n_points may be NULL (all P).  check_voxels = 0 skips the
  * obstacle test (the "is_valid_shape only" predicate used while voxelising edges,
  * VoxelBackboneMotionValidator.cpp:29-36). */
 int tr_validate_shapes_dev(tr_ctx *ctx, int64_t n, int64_t ld,

@@ -55,6 +55,7 @@ __device__ inline int cells_differ(const double *__restrict__ px, const double *
     const int na = n_points[sa], nb = n_points[sb];
     if (na + 1 < nb || na > nb + 1) return 1;
     Pm = na < nb ? na : nb;
+    sa += (int64_t)(P - na) * ld; sb += (int64_t)(P - nb) * ld;    // K1r's rows are aligned at the tip: point j is in row j + (P - n)
   }
   for (int j = Pm - 1; j >= 0; j--) {
     const int64_t oa = (int64_t)j * ld + sa, ob = (int64_t)j * ld + sb;

@@ -11,8 +11,8 @@
 // (route_tendon), and then the wave runs TIP-ALIGNED: iteration = interval of the shared grid, retracted
 // lanes join late instead of finishing early, and the routing comes from K1's scalar table -- K1's
 // inner loop and K1's two-wave register budget.  A lane's point i is the shared grid's point
-// i + (P - P_lane); it is stored in the lane's own row i (stores are therefore not coalesced across lanes:
-// ~4x write amplification on 3 KB per configuration, far below what HBM sustains).
+// i + (P - P_lane) and is stored in THAT row, so the stores of a wave stay coalesced; every consumer of a
+// retraction robot's points (K2, K5, K8, the edge pair test, the host unpack) adds the same row offset.
 #pragma once
 #include "fk_kernel.hpp"
 
@@ -174,15 +174,18 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
       }
     }
   };
-  if (live) store_point(0);
+  if (live) store_point(shift);                     // rows are aligned at the tip: the lane's point j goes to row j + shift
 
   // the lane's own first interval: s -> shared grid point shift + 1, steps of min(dL, remaining) while
   // remaining > eps (integrate_times), routing evaluated per lane
-  if (__any(!single)) {
+  // (s_start within dL/2 of L gives a one-point backbone that is not the `single` early return: no interval at all)
+  const bool first = !single && P_lane >= 2;
+  if (__any(first)) {
     double cur = L - (L - s);                        // t[0]: the mirrored `end` sample of t_range
-    const double tn = single ? cur : tgrid[shift + 1];
+    double tn = cur;
+    if (first) tn = tgrid[shift + 1];
     for (int sub = 0; sub < 4; sub++) {
-      const bool go = !single && (tn - cur > 2.220446049250313e-16);
+      const bool go = first && (tn - cur > 2.220446049250313e-16);
       if (!__any(go)) break;
       if (go) {
         const double h = (dL < tn - cur) ? dL : (tn - cur);
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
         cur += h;
       }
     }
-    if (!single && live) store_point(1);
+    if (first && live) store_point(shift + 1);
   }
 
   // tip-aligned: step k of the shared grid ends at its point steps[k].obs = the lane's point obs - shift
@@ -254,7 +257,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
       for (int q = 0; q < 9; q++) R[q] = aR[q];
 #pragma unroll
       for (int q = 0; q < 3; q++) { v[q] = av[q]; u[q] = au[q]; }
-      if (live) store_point(ipt);
+      if (live) store_point(obs);
     }
   }
 

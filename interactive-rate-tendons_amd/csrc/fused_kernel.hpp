@@ -23,7 +23,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_sw
   fk_uniform_body<N, ROT, false>(states, n, ld, K, tab, steps, nsteps, out);
   __syncthreads();
   const FusedSweepArgs a = *sa;
-  sweep_body(a.in, n, ld, a.P, a.CH, a.NM, K, a.g, a.grid, a.near_grid, a.check_voxels, a.debug, a.valid_bits, a.flags);
+  sweep_body<false>(a.in, n, ld, a.P, a.CH, a.NM, K, a.g, a.grid, a.near_grid, a.check_voxels, a.debug, a.valid_bits, a.flags);
 }
 
 }  // namespace trk

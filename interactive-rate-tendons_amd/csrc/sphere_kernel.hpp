@@ -54,6 +54,7 @@ __global__ __launch_bounds__(64) void spheres_vs_grid(
   bool alive = live && ((word >> lane) & 1ull);
   bool hit = false;
   const int np = n_points ? n_points[ic] : P;
+  const int64_t ib = ic + (int64_t)(P - np) * ld;        // retraction robots: the lane's point j is in row j + (P - np)
   const double rr = radius * radius;
   const int Nb = g.Nb, N = g.N;
   for (int j = 0; j < P; j++) {
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(64) void spheres_vs_grid(
     double x = 0, y = 0, z = 0;
     bool want = alive && !hit && j < np;
     if (want) {
-      const int64_t o = (int64_t)j * ld + ic;
+      const int64_t o = (int64_t)j * ld + ib;
       const double x0 = px[o], y0 = py[o], z0 = pz[o];
       if (g.rot_is_identity) { x = x0; y = y0; z = z0; }
       else {

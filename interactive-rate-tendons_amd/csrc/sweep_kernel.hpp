@@ -338,6 +338,9 @@ __device__ __forceinline__ bool exact_self_collision(const SweepIn &in, int64_t 
 // cleared falls back to pass 3, the exact pairwise sweep -- rare (tight curls only).
 //   debug bit0: brute-force pairs in pass 3;  bit1: skip pass 2 (every lane takes pass 3);
 //         bit2: disable the dilated-grid fast path of the voxel walk.
+// TIPROWS (retraction robots, in.n_points set): K1r stores a lane's point j in row j + (P - n_points), i.e. rows
+// are aligned at the tip like K1r's iterations, so that its stores -- and the loads here -- stay coalesced.
+template <bool TIPROWS>
 __device__ __forceinline__ void sweep_body(
     const SweepIn &in, int64_t n, int64_t ld, int P, int CH, int NM, const RobotK &K, const GridK &g, const uint64_t *__restrict__ grid,
     const uint64_t *__restrict__ near_grid, int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits,
@@ -369,7 +372,8 @@ __device__ __forceinline__ void sweep_body(
     }
     len_ok = ok; alive = ok;
   }
-  const int np = in.n_points ? in.n_points[ic] : P;
+  const int np = TIPROWS ? in.n_points[ic] : P;
+  const int shift = TIPROWS ? P - np : 0;                // row of the lane's point j is j + shift
   const int Kl = (np - 1 + CH - 1) / CH;                 // this lane's last milestone index
 
   // Pass 1: one streaming read of the points.  Arc positions of the milestones are accumulated in
@@ -435,8 +439,8 @@ __device__ __forceinline__ void sweep_body(
         prevr = qr; in_prev = in_q; Aprev = Bq; cpx = cqx; cpy = cqy; cpz = cqz;
       }
     };
-    for (int j0 = 0; j0 < P; j0 += PF) {
-      if (!__any(alive && j0 < np)) break;
+    for (int j0 = 0; j0 < P; j0 += PF) {                 // rows; the lane's point index is row - shift
+      if (!__any(alive && j0 < np + shift)) break;
 #pragma unroll
       for (int u = 0; u < PF; u++) {
         const int j = j0 + u;
@@ -446,7 +450,7 @@ __device__ __forceinline__ void sweep_body(
           const int64_t o = (int64_t)(jn < P ? jn : P - 1) * ld + ic;
           ring[u] = V3{in.px[o], in.py[o], in.pz[o]};
         }
-        if (alive && j < np) visit(j, q);
+        if (alive && j >= shift && j < np + shift) visit(j - shift, q);
       }
     }
   }
@@ -498,9 +502,10 @@ __device__ __forceinline__ void sweep_body(
     double hmax = 0.0;
     if (need_exact) {
       double dd = 0.0;
-      V3 prev = {in.px[ic], in.py[ic], in.pz[ic]};
+      const int64_t ib = ic + (int64_t)shift * ld;       // the lane's rows start at `shift`
+      V3 prev = {in.px[ib], in.py[ib], in.pz[ib]};
       for (int j = 0; j < np; j++) {
-        const int64_t o = (int64_t)j * ld + ic;
+        const int64_t o = (int64_t)j * ld + ib;
         const V3 q = {in.px[o], in.py[o], in.pz[o]};
         const V3 d = {q.x - prev.x, q.y - prev.y, q.z - prev.z};
         const double h = sqrt(dot3(d, d));
@@ -510,7 +515,7 @@ __device__ __forceinline__ void sweep_body(
         prev = q;
       }
     }
-    selfhit = exact_self_collision(in, ic, ld, P, np, need_exact, hmax, K.radius, (debug & 1u) != 0);
+    selfhit = exact_self_collision(in, ic + (int64_t)shift * ld, ld, P, np, need_exact, hmax, K.radius, (debug & 1u) != 0);
   }
 
   uint32_t fl = 0;
@@ -532,7 +537,8 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
     SweepIn in, int64_t n, int64_t ld, int P, int CH, int NM, RobotK K, GridK g, const uint64_t *__restrict__ grid,
     const uint64_t *__restrict__ near_grid, int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits,
     uint8_t *__restrict__ flags) {
-  sweep_body(in, n, ld, P, CH, NM, K, g, grid, near_grid, check_voxels, debug, valid_bits, flags);
+  if (in.n_points) sweep_body<true>(in, n, ld, P, CH, NM, K, g, grid, near_grid, check_voxels, debug, valid_bits, flags);
+  else sweep_body<false>(in, n, ld, P, CH, NM, K, g, grid, near_grid, check_voxels, debug, valid_bits, flags);
 }
 
 // K5 `backbone_voxelize`: the robot's own voxel set (what voxelize_impl returns,
@@ -550,6 +556,7 @@ __global__ __launch_bounds__(64) void backbone_voxelize(
   if (i >= n) return;
   if (!((shape_valid_bits[i >> 6] >> (i & 63)) & 1ull)) { counts[i] = 0; return; }
   const int np = n_points ? n_points[i] : P;
+  const int64_t ib = i + (int64_t)(P - np) * ld;         // retraction robots: the lane's point j is in row j + (P - np)
   int cnt = 0;
   bool overflow = false, bad = false;
   int cur_id = -1;
@@ -572,7 +579,7 @@ __global__ __launch_bounds__(64) void backbone_voxelize(
   };
   V3 prev = {0, 0, 0};
   for (int j = 0; j < np; j++) {
-    const int64_t o = (int64_t)j * ld + i;
+    const int64_t o = (int64_t)j * ld + ib;
     const double x = px[o], y = py[o], z = pz[o];
     V3 q;
     if (g.rot_is_identity) { q = V3{x, y, z}; }

@@ -820,20 +820,28 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
       HIP_TRY(c, hipMemcpy2D(hz.data(), (size_t)m * 8, w.pz, (size_t)ld * 8, (size_t)m * 8, (size_t)P, hipMemcpyDeviceToHost));
       hn.resize((size_t)m);
       HIP_TRY(c, hipMemcpy(hn.data(), w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
-      for (int64_t i = 0; i < m; i++)
+      for (int64_t i = 0; i < m; i++) {
+        const int sh = P - hn[(size_t)i];               // device rows are aligned at the tip: point j is in row j + (P - n_points)
         for (int j = 0; j < P; j++) {
           double *o = p + ((size_t)(off + i) * P + j) * 3;
-          if (j < hn[(size_t)i]) { o[0] = hx[(size_t)j * m + i]; o[1] = hy[(size_t)j * m + i]; o[2] = hz[(size_t)j * m + i]; }
+          if (j < hn[(size_t)i]) { o[0] = hx[(size_t)(j + sh) * m + i]; o[1] = hy[(size_t)(j + sh) * m + i]; o[2] = hz[(size_t)(j + sh) * m + i]; }
           else o[0] = o[1] = o[2] = std::numeric_limits<double>::quiet_NaN();
         }
+      }
     }
     if (R) {
       hR.resize((size_t)9 * P * m);
       HIP_TRY(c, hipMemcpy2D(hR.data(), (size_t)m * 8, d_R, (size_t)ld * 8, (size_t)m * 8, (size_t)9 * P, hipMemcpyDeviceToHost));
-      for (int64_t i = 0; i < m; i++)
+      if (hn.size() != (size_t)m) {
+        hn.resize((size_t)m);
+        HIP_TRY(c, hipMemcpy(hn.data(), w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+      }
+      for (int64_t i = 0; i < m; i++) {
+        const int np_i = hn[(size_t)i], sh = P - np_i;
         for (int j = 0; j < P; j++)
           for (int q = 0; q < 9; q++)
-            R[((size_t)(off + i) * P + j) * 9 + q] = hR[((size_t)q * P + j) * m + i];
+            R[((size_t)(off + i) * P + j) * 9 + q] = j < np_i ? hR[((size_t)q * P + j + sh) * m + i] : std::numeric_limits<double>::quiet_NaN();
+      }
     }
     if (L) HIP_TRY(c, hipMemcpy(L + off, w.L, (size_t)m * sizeof(double), hipMemcpyDeviceToHost));
     if (L_i) {

@@ -109,3 +109,25 @@ def test_discrete_edges_and_last_valid_with_retraction(irt, orc, helpers):
         u = orc.check_motion_until_invalid(orb, og, a[i], b[i])
         assert valid[i] == u["is_fully_valid"] and lvt[i] == u["last_valid_t"], (i, u)
     assert 0.05 < d["valid"].mean() < 0.98 and d["n_fk"].max() > 20
+
+
+def test_one_point_backbones_and_repeatability(irt, orc, helpers):
+    """s_start within dL/2 of L gives a one-point backbone without being the s_start == L early return
+    (t_range pushes only `end`); such lanes take no RK4 interval at all.  Results must also be bit-identical
+    from call to call (a stray store would show up as a changing neighbour)."""
+    robot = _robot(irt, "helix")
+    L, dL = robot.specs.L, robot.specs.dL
+    st = irt.workloads.random_states(robot, 700, seed=62, tau_max=15.0)
+    st[::7, -1] = np.linspace(L - 0.49 * dL, L - 1e-9, len(st[::7]))
+    outs = [robot.shape_batch(st) for _ in range(6)]
+    for o in outs[1:]:
+        for k in ("L", "L_i", "converged", "n_points"):
+            assert np.array_equal(outs[0][k], o[k]), k
+        assert np.array_equal(np.nan_to_num(outs[0]["p"]), np.nan_to_num(o["p"]))
+    got = outs[0]
+    assert (got["n_points"][::7] == 1).all() and (got["L"][::7] == 0).all() and (got["L_i"][::7] == 0).all()
+    want = helpers.oracle_robot(orc, robot).fk_batch(st)
+    P = got["p"].shape[1]
+    assert np.array_equal(np.isnan(got["p"]), np.isnan(want["p"][:, :P]))
+    assert np.nanmax(np.abs(got["p"] - want["p"][:, :P])) <= TIP_TOL
+    assert np.abs(got["L_i"] - want["L_i"]).max() <= 1e-10 and np.array_equal(got["converged"], want["converged"])
