@@ -77,3 +77,21 @@ def test_sphere_checker_follows_grid_edits(irt, orc, helpers):
     orb = helpers.oracle_robot(orc, robot)
     want = np.array([orc.is_valid_state_spheres(orb, og, s)[0] for s in states])
     assert np.array_equal(after, want) and (before & ~after).sum() > 5
+
+
+def test_sphere_checker_with_retraction(irt, orc, helpers):
+    """per-configuration point counts, rows aligned at the tip (fk_retract_kernel.hpp)"""
+    W = irt.workloads
+    robot = W.robot_config2()
+    robot.enable_retraction = True
+    vox = _env(irt, 23, 200, rmin=0.006, rmax=0.016)
+    chk = irt.VoxelValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    states = W.random_states(robot, 600, seed=8, tau_max=14.0)
+    states[:, -1] = np.random.default_rng(9).uniform(0.0, 0.07, len(states))
+    states[:4, -1] = [0.0, robot.specs.L, robot.specs.L - robot.specs.dL / 4, 0.1]
+    got = chk.is_valid_detail(states)
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    want = [orc.is_valid_state_spheres(orb, og, s) for s in states]
+    assert np.array_equal(got["valid"], [w[0] for w in want])
+    assert np.array_equal(got["flags"] & 15, [w[2] for w in want])
+    assert 0.1 < np.mean([w[0] for w in want]) < 0.97

@@ -89,3 +89,51 @@ def test_voxelize_empty(irt):
     e = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
     out = e.voxelize_batch(np.zeros((0, 3)))
     assert out["offsets"].tolist() == [0] and out["block_ids"].size == 0
+
+
+def test_voxel_sets_with_retraction(irt, orc, helpers):
+    """Retraction robots: per-configuration point counts and rows aligned at the tip -- vertex sets equal the
+    oracle's add_piecewise_line of the same points, edge sets are consistent with checkMotion."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    robot.enable_retraction = True
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    st = W.random_states(robot, 500, seed=73, tau_max=14.0)
+    st[:, -1] = np.random.default_rng(74).uniform(0.0, 0.12, len(st))
+    st[:3, -1] = [0.0, robot.specs.L, robot.specs.L - robot.specs.dL / 4]
+    out = chk.engine.voxelize_batch(st)
+    det = chk.is_valid_detail(st)
+    want_shape = (det["flags"] & 7) == 7
+    assert np.array_equal(out["shape_valid"], want_shape) and want_shape.sum() > 100
+    fk = robot.shape_batch(st)
+    ref = orc.Grid(256, vox.limits())
+    for i in range(len(st)):
+        ids, masks = _item(out, i)
+        if not want_shape[i]:
+            assert ids.size == 0
+            continue
+        g = ref.empty_copy()
+        g.add_piecewise_line(fk["p"][i, :fk["n_points"][i]])
+        wi, wm = g.export_blocks()
+        assert np.array_equal(ids, wi) and np.array_equal(masks, wm), i
+    hit = chk.engine.check_cached(out["block_ids"], out["masks"], out["offsets"])
+    assert np.array_equal(hit[want_shape], ((det["flags"] & 8) == 0)[want_shape])
+    rng = np.random.default_rng(75)
+    a = st[:200]
+    b = a + rng.normal(size=a.shape) * np.array([0.8, 0.8, 0.8, 0.004])
+    b[:, :3] = np.clip(b[:, :3], 0, 20); b[:, 3] = np.clip(b[:, 3], 0, 0.2)
+    ec = chk.engine.voxelize_edges(a, b)
+    ehit = chk.engine.check_cached(ec["block_ids"], ec["masks"], ec["offsets"])
+    verdict = irt.VoxelBackboneMotionValidator(chk).check_motion(a, b)
+    assert np.array_equal(verdict, ec["fully_valid"] & ~ehit) and 0.05 < verdict.mean() < 0.98
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    for i in range(0, 200, 9):
+        w = orc.check_motion(orb, og, a[i], b[i], want_swept=True)
+        assert ec["fully_valid"][i] == w["is_fully_valid"]
+        if w["is_fully_valid"]:
+            ids, masks = _item(ec, i)
+            wi, wm = w["swept"].export_blocks()
+            d = {int(k): int(v) for k, v in zip(ids, masks)}
+            e = {int(k): int(v) for k, v in zip(wi, wm)}
+            assert sum(bin(d.get(k, 0) ^ e.get(k, 0)).count("1") for k in set(d) | set(e)) <= 2
