@@ -635,9 +635,9 @@ int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *bloc
   g.rot_is_identity = 1;
   for (int i = 0; i < 9; i++) { g.inv_rot[i] = r[i]; if (r[i] != I9[i]) g.rot_is_identity = 0; }
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());          // launches that still read the previous grid (any stream) finish first
   const size_t nb = (size_t)g.Nb * g.Nb * g.Nb;
   if (c->n_blocks != nb) {
-    HIP_TRY(c, hipDeviceSynchronize());
     if (c->d_grid) { (void)hipFree(c->d_grid); c->d_grid = nullptr; }
     if (c->d_near) { (void)hipFree(c->d_near); c->d_near = nullptr; }
     HIP_TRY(c, hipMalloc((void **)&c->d_grid, nb * sizeof(uint64_t)));
@@ -659,6 +659,7 @@ namespace {
 int env_begin(tr_ctx *c) {
   if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());          // launches that still read the grid (any stream) finish before it is edited
   const uint32_t nbw = (uint32_t)((c->G.Nb + 2) * (c->G.Nb + 2) * (c->G.Nb + 2));
   if (c->envw_blocks < nbw) {
     HIP_TRY(c, hipDeviceSynchronize());
