@@ -8,33 +8,56 @@
 // whose centre is within r, so enumerating a superset of it and applying the same IEEE distance test
 // gives the same set.)
 //
-// One lane per configuration decides which of its points lie near obstacles at all: the obstacle
-// grid dilated by ceil(r/d) + 1 cells per axis (Chebyshev; `sphere_near`, built by three
-// `cheb_dilate_axis` passes whenever the grid changes) holds every cell whose sphere could touch an
-// occupied cell -- a point outside the domain is looked up at its projection onto the domain, which
-// is closer to every cell than the point itself.  Flagged (lane, point) pairs are then served by the
-// whole wave: each lane takes blocks of the point's block range, skips empty ones and tests the set
-// bits' centres with the reference's arithmetic (fp64, no contraction).
+// One lane per configuration classifies each of its points with ONE gather from a distance field: the
+// distance from the centre of the point's cell to the nearest occupied cell centre (`obstacle_distance_*`,
+// an exact windowed separable transform rebuilt whenever the grid changes; float, used only with margins).
+// With hd the half diagonal of a cell: field - hd > r means no occupied centre can be within r of the point
+// (a point outside the domain is looked up at its projection onto it, which is closer to every cell than the
+// point itself); field + hd < r means one certainly is.  Only the thin shell in between -- and the points
+// outside the domain -- are served exactly, by the whole wave: each lane takes blocks of the point's block
+// range, skips empty ones and tests the set bits' centres with the reference's arithmetic (fp64, no contraction).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
 
 namespace trk {
 
-// out(c) = OR of in(c + k e_axis), |k| <= R, inside the grid.  One wave per block, lane = cell.
-__global__ __launch_bounds__(64) void cheb_dilate_axis(const uint64_t *__restrict__ in, uint64_t *__restrict__ out, int Nb, int axis, int R) {
+#define TRK_EDT_FAR 1e30f
+
+// pass 1: squared distance (metres^2) along x to the nearest occupied cell within +-R cells.  One wave per
+// block, lane = cell.
+__global__ __launch_bounds__(64) void obstacle_distance_x(const uint64_t *__restrict__ grid, float *__restrict__ out, int Nb, int R, float dx) {
   const int b = blockIdx.x;
   const int bz = b % Nb, by = (b / Nb) % Nb, bx = b / (Nb * Nb);
   const int lane = threadIdx.x, N = 4 * Nb;
   const int X = 4 * bx + (lane >> 4), Y = 4 * by + ((lane >> 2) & 3), Z = 4 * bz + (lane & 3);
-  bool on = false;
-  for (int k = -R; k <= R && !on; k++) {
-    const int x = X + (axis == 0 ? k : 0), y = Y + (axis == 1 ? k : 0), z = Z + (axis == 2 ? k : 0);
-    if (x < 0 || x >= N || y < 0 || y >= N || z < 0 || z >= N) continue;
-    on = (in[((size_t)(x >> 2) * Nb + (y >> 2)) * Nb + (z >> 2)] >> (((x & 3) << 4) | ((y & 3) << 2) | (z & 3))) & 1ull;
+  float best = TRK_EDT_FAR;
+  for (int k = -R; k <= R; k++) {
+    const int x = X + k;
+    if (x < 0 || x >= N) continue;
+    if ((grid[((size_t)(x >> 2) * Nb + (Y >> 2)) * Nb + (Z >> 2)] >> (((x & 3) << 4) | ((Y & 3) << 2) | (Z & 3))) & 1ull) {
+      const float dd = (float)k * dx;
+      best = fminf(best, dd * dd);
+    }
   }
-  const unsigned long long m = __ballot(on);
-  if (lane == 0) out[b] = m;
+  out[((size_t)X * N + Y) * N + Z] = best;
+}
+
+// passes 2 and 3: out(c) = min over |k| <= R of in(c + k e_axis) + (k d)^2; the last pass stores the root.
+__global__ __launch_bounds__(256) void obstacle_distance_axis(const float *__restrict__ in, float *__restrict__ out, int N, int axis, int R,
+                                                              float dd, int take_root) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)N * N * N) return;
+  const int Z = (int)(i % N), Y = (int)((i / N) % N);
+  const int c = axis == 1 ? Y : Z;
+  const int64_t stride = axis == 1 ? N : 1;
+  float best = TRK_EDT_FAR;
+  for (int k = -R; k <= R; k++) {
+    if (c + k < 0 || c + k >= N) continue;
+    const float e = (float)k * dd;
+    best = fminf(best, in[i + k * stride] + e * e);
+  }
+  out[i] = take_root ? sqrtf(best) : best;
 }
 
 // valid_bits (in/out): bit i = configuration i passed is_valid_shape (K2 with check_voxels = 0); cleared
@@ -43,7 +66,7 @@ __global__ __launch_bounds__(64) void cheb_dilate_axis(const uint64_t *__restric
 __global__ __launch_bounds__(64) void spheres_vs_grid(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
     const int32_t *__restrict__ n_points, int64_t n, int64_t ld, int P, double radius, GridK g,
-    const uint64_t *__restrict__ grid, const uint64_t *__restrict__ sphere_near,
+    const uint64_t *__restrict__ grid, const float *__restrict__ field /* [N][N][N] distance to the nearest occupied centre */,
     uint64_t *__restrict__ valid_bits, uint8_t *__restrict__ flags) {
 #pragma clang fp contract(off)
   const int lane = threadIdx.x;
@@ -57,6 +80,8 @@ __global__ __launch_bounds__(64) void spheres_vs_grid(
   const int64_t ib = ic + (int64_t)(P - np) * ld;        // retraction robots: the lane's point j is in row j + (P - np)
   const double rr = radius * radius;
   const int Nb = g.Nb, N = g.N;
+  const float hd = 0.5f * sqrtf((float)(g.dx * g.dx + g.dy * g.dy + g.dz * g.dz));
+  const float r_lo = (float)radius - hd - 1e-6f, r_hi = (float)radius + hd + 1e-6f;
   for (int j = 0; j < P; j++) {
     if (!__any(alive && !hit && j < np)) break;
     // this lane's point j, rotated into the voxel frame
@@ -78,10 +103,13 @@ __global__ __launch_bounds__(64) void spheres_vs_grid(
       const double cx = fmin(fmax(x, g.xmin), g.xmax), cy = fmin(fmax(y, g.ymin), g.ymax), cz = fmin(fmax(z, g.zmin), g.zmax);
       int ix = (int)((cx - g.xmin) / g.dx), iy = (int)((cy - g.ymin) / g.dy), iz = (int)((cz - g.zmin) / g.dz);
       ix = ix < 0 ? 0 : (ix > N - 1 ? N - 1 : ix); iy = iy < 0 ? 0 : (iy > N - 1 ? N - 1 : iy); iz = iz < 0 ? 0 : (iz > N - 1 ? N - 1 : iz);
-      want = (sphere_near[((size_t)(ix >> 2) * Nb + (iy >> 2)) * Nb + (iz >> 2)] >> (((ix & 3) << 4) | ((iy & 3) << 2) | (iz & 3))) & 1ull;
+      const float dn = field[((size_t)ix * N + iy) * N + iz];
+      const bool inside = cx == x && cy == y && cz == z;
+      if (dn > r_hi) want = false;                             // no occupied centre within r of any point of this cell
+      else if (inside && dn < r_lo) { hit = true; want = false; }   // one certainly is (also add_point's own cell: dn = 0)
       // add_point (:319-323): the point's own cell, if the point is inside the closed domain
-      if (want && cx == x && cy == y && cz == z &&
-          ((grid[((size_t)(ix >> 2) * Nb + (iy >> 2)) * Nb + (iz >> 2)] >> (((ix & 3) << 4) | ((iy & 3) << 2) | (iz & 3))) & 1ull)) {
+      else if (inside &&
+               ((grid[((size_t)(ix >> 2) * Nb + (iy >> 2)) * Nb + (iz >> 2)] >> (((ix & 3) << 4) | ((iy & 3) << 2) | (iz & 3))) & 1ull)) {
         hit = true; want = false;
       }
     }

@@ -96,9 +96,9 @@ struct tr_ctx {
   uint64_t *d_grid = nullptr;
   uint64_t *d_near = nullptr;     // obstacle grid dilated by 2 cells (Chebyshev), same layout
   uint32_t n_blocks = 0;
-  // VoxelValidityChecker mode (sphere-swept robot, sphere_kernel.hpp): obstacles dilated by ceil(r/d) + 1 cells
+  // VoxelValidityChecker mode (sphere-swept robot, sphere_kernel.hpp): distance to the nearest occupied cell centre
   int checker = TR_CHECKER_BACKBONE;
-  uint64_t *d_sph_near = nullptr;
+  float *d_sph_near = nullptr, *d_sph_tmp = nullptr;   // [N^3] each
   bool sph_near_valid = false;
   uint64_t *d_envw[2] = {nullptr, nullptr};   // environment-preparation scratch: two (Nb+2)^3 apron grids
   uint32_t envw_blocks = 0;
@@ -385,22 +385,22 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
   return TR_OK;
 }
 
-// Obstacles dilated (Chebyshev) by ceil(r/d) + 1 cells per axis: the cells whose sphere could reach an occupied one.
+// Distance from every cell centre to the nearest occupied cell centre, exact within the window that matters
+// (r + a cell diagonal), TRK_EDT_FAR beyond: three separable min-plus passes (x on the bit grid, then y, z).
 int ensure_sphere_near(tr_ctx *c, hipStream_t s) {
   if (c->sph_near_valid) return TR_OK;
-  const uint32_t nbw = (uint32_t)((c->G.Nb + 2) * (c->G.Nb + 2) * (c->G.Nb + 2));
-  HIP_TRY(c, hipDeviceSynchronize());                          // (re)allocation and scratch shared with the environment edits
-  if (c->envw_blocks < nbw) {
-    for (int k = 0; k < 2; k++) { int rc = dev_alloc(c, &c->d_envw[k], (size_t)nbw); if (rc) return rc; }
-    c->envw_blocks = nbw;
-  }
+  HIP_TRY(c, hipDeviceSynchronize());
+  const size_t ncell = (size_t)c->G.N * c->G.N * c->G.N;
   if (c->d_sph_near) { (void)hipFree(c->d_sph_near); c->d_sph_near = nullptr; }
-  HIP_TRY(c, hipMalloc((void **)&c->d_sph_near, (size_t)c->n_blocks * sizeof(uint64_t)));
-  const double r = c->K.radius;
-  const int R[3] = {(int)std::ceil(r / c->G.dx) + 1, (int)std::ceil(r / c->G.dy) + 1, (int)std::ceil(r / c->G.dz) + 1};
-  hipLaunchKernelGGL(trk::cheb_dilate_axis, dim3(c->n_blocks), dim3(64), 0, s, c->d_grid, c->d_envw[0], c->G.Nb, 0, R[0]);
-  hipLaunchKernelGGL(trk::cheb_dilate_axis, dim3(c->n_blocks), dim3(64), 0, s, c->d_envw[0], c->d_envw[1], c->G.Nb, 1, R[1]);
-  hipLaunchKernelGGL(trk::cheb_dilate_axis, dim3(c->n_blocks), dim3(64), 0, s, c->d_envw[1], c->d_sph_near, c->G.Nb, 2, R[2]);
+  if (c->d_sph_tmp) { (void)hipFree(c->d_sph_tmp); c->d_sph_tmp = nullptr; }
+  HIP_TRY(c, hipMalloc((void **)&c->d_sph_near, ncell * sizeof(float)));
+  HIP_TRY(c, hipMalloc((void **)&c->d_sph_tmp, ncell * sizeof(float)));
+  const double reach = c->K.radius + std::sqrt(c->G.dx * c->G.dx + c->G.dy * c->G.dy + c->G.dz * c->G.dz);
+  const int R[3] = {(int)std::ceil(reach / c->G.dx) + 1, (int)std::ceil(reach / c->G.dy) + 1, (int)std::ceil(reach / c->G.dz) + 1};
+  const unsigned gcell = (unsigned)((ncell + 255) / 256);
+  hipLaunchKernelGGL(trk::obstacle_distance_x, dim3(c->n_blocks), dim3(64), 0, s, c->d_grid, c->d_sph_near, c->G.Nb, R[0], (float)c->G.dx);
+  hipLaunchKernelGGL(trk::obstacle_distance_axis, dim3(gcell), dim3(256), 0, s, c->d_sph_near, c->d_sph_tmp, c->G.N, 1, R[1], (float)c->G.dy, 0);
+  hipLaunchKernelGGL(trk::obstacle_distance_axis, dim3(gcell), dim3(256), 0, s, c->d_sph_tmp, c->d_sph_near, c->G.N, 2, R[2], (float)c->G.dz, 1);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(s));
   c->sph_near_valid = true;
@@ -582,7 +582,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1], c->d_sph_near};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
