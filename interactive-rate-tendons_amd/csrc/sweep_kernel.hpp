@@ -352,6 +352,10 @@ __device__ __forceinline__ void sweep_body(
   float *__restrict__ my = mx + (size_t)NM * 64;
   float *__restrict__ mz = my + (size_t)NM * 64;
   float *__restrict__ ma = mz + (size_t)NM * 64;
+  // deferred voxel walks (see pass 1): a ring of (owner lane << 16 | end row) and one hit flag per lane
+  uint32_t *__restrict__ wq = (uint32_t *)(lds + (size_t)4 * NM * 64);
+  uint32_t *__restrict__ wflag = wq + 128;
+  wflag[lane] = 0;
 
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const bool live = i < n;
@@ -402,9 +406,9 @@ __device__ __forceinline__ void sweep_body(
     const double bz0 = g.zmin + 1e-6 * (g.zmax - g.zmin), bz1 = g.zmax - 1e-6 * (g.zmax - g.zmin);
     const bool use_near = near.blocks != nullptr;
     bool in_prev = false;
-    V3 Aprev = {0, 0, 0};
     int cpx = 0, cpy = 0, cpz = 0;
-    auto visit = [&](int j, const V3 &q) {
+    auto visit = [&](int j, const V3 &q) -> bool {
+      bool need = false;
       if (j == 0) prev = q;
       const float dx = (float)(q.x - prev.x), dy = (float)(q.y - prev.y), dz = (float)(q.z - prev.z);
       dist += sqrtf(dx * dx + dy * dy + dz * dz);
@@ -430,14 +434,48 @@ __device__ __forceinline__ void sweep_body(
           if (in_prev && in_q) {
             const int ddx = cqx - cpx, ddy = cqy - cpy, ddz = cqz - cpz;
             const bool nearby = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1;
-            if (!(use_near && nearby && !near.occupied(cpx, cpy, cpz)))
-              hit = walk_cells(Aprev, Bq, g, [&](int x, int y, int z) { return gc.occupied(x, y, z); });
+            need = !(use_near && nearby && !near.occupied(cpx, cpy, cpz));   // the walk itself is deferred (below)
           } else {
             hit = line_hits(prevr, qr, g, gc, near, bad);      // near or outside the domain boundary: full reference path
           }
         }
-        prevr = qr; in_prev = in_q; Aprev = Bq; cpx = cqx; cpy = cqy; cpz = cqz;
+        prevr = qr; in_prev = in_q; cpx = cqx; cpy = cqy; cpz = cqz;
       }
+      return need;
+    };
+    // Only ~3 % of the segments need the DDA walk, but with 64 independent configurations per wave some lane
+    // needs one at almost every second point, and the wave would run the (long) walk code each time for a
+    // lane or two.  The walks are queued instead -- (owner lane, end row) in LDS -- and run 64 at a time, one
+    // per lane, on the owners' points re-read from memory and turned into voxel coordinates by the same
+    // expressions; a hit comes back through the owner's LDS flag.  Verdicts do not depend on the order.
+    int qhead = 0, qcount = 0;
+    auto flush = [&]() {
+      __syncthreads();
+      const int cnt = qcount < 64 ? qcount : 64;
+      if (lane < cnt) {
+        const uint32_t e = wq[(qhead + lane) & 127];
+        const int owner = (int)(e >> 16), r = (int)(e & 0xffffu);
+        const int64_t oc = (int64_t)blockIdx.x * 64 + owner;
+        const int64_t oa = (int64_t)(r - 1) * ld + oc, ob = (int64_t)r * ld + oc;
+        V3 a = {in.px[oa], in.py[oa], in.pz[oa]}, b = {in.px[ob], in.py[ob], in.pz[ob]};
+        if (!g.rot_is_identity) {
+          const V3 a0 = a, b0 = b;
+          a.x = g.inv_rot[0] * a0.x + g.inv_rot[1] * a0.y + g.inv_rot[2] * a0.z;
+          a.y = g.inv_rot[3] * a0.x + g.inv_rot[4] * a0.y + g.inv_rot[5] * a0.z;
+          a.z = g.inv_rot[6] * a0.x + g.inv_rot[7] * a0.y + g.inv_rot[8] * a0.z;
+          b.x = g.inv_rot[0] * b0.x + g.inv_rot[1] * b0.y + g.inv_rot[2] * b0.z;
+          b.y = g.inv_rot[3] * b0.x + g.inv_rot[4] * b0.y + g.inv_rot[5] * b0.z;
+          b.z = g.inv_rot[6] * b0.x + g.inv_rot[7] * b0.y + g.inv_rot[8] * b0.z;
+        }
+        const V3 A = {(a.x - g.xmin) * g.inv_dx, (a.y - g.ymin) * g.inv_dy, (a.z - g.zmin) * g.inv_dz};
+        const V3 B = {(b.x - g.xmin) * g.inv_dx, (b.y - g.ymin) * g.inv_dy, (b.z - g.zmin) * g.inv_dz};
+        GridCursor wc{grid, g.Nb, -1, 0ull};
+        if (walk_cells(A, B, g, [&](int x, int y, int z) { return wc.occupied(x, y, z); })) wflag[owner] = 1u;
+      }
+      qhead = (qhead + cnt) & 127;
+      qcount -= cnt;
+      __syncthreads();
+      if (wflag[lane]) hit = true;
     };
     for (int j0 = 0; j0 < P; j0 += PF) {                 // rows; the lane's point index is row - shift
       if (!__any(alive && j0 < np + shift)) break;
@@ -450,9 +488,17 @@ __device__ __forceinline__ void sweep_body(
           const int64_t o = (int64_t)(jn < P ? jn : P - 1) * ld + ic;
           ring[u] = V3{in.px[o], in.py[o], in.pz[o]};
         }
-        if (alive && j >= shift && j < np + shift) visit(j - shift, q);
+        bool need = false;
+        if (alive && j >= shift && j < np + shift) need = visit(j - shift, q);
+        const unsigned long long wm = __ballot(need);
+        if (wm) {
+          if (need) wq[(qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & 127] = ((uint32_t)lane << 16) | (uint32_t)j;
+          qcount += __popcll(wm);
+          if (qcount >= 64) flush();
+        }
       }
     }
+    while (qcount > 0) flush();
   }
   if (alive && !(dist < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
 
