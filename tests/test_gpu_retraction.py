@@ -131,3 +131,30 @@ def test_one_point_backbones_and_repeatability(irt, orc, helpers):
     assert np.array_equal(np.isnan(got["p"]), np.isnan(want["p"][:, :P]))
     assert np.nanmax(np.abs(got["p"] - want["p"][:, :P])) <= TIP_TOL
     assert np.abs(got["L_i"] - want["L_i"]).max() <= 1e-10 and np.array_equal(got["converged"], want["converged"])
+
+
+@pytest.mark.parametrize("n_tendons", [1, 2, 5, 7, 8])
+def test_retraction_other_tendon_counts(irt, orc, helpers, n_tendons):
+    """Every instantiated width of the retraction kernel (two waves per SIMD up to 3 tendons, one beyond), with
+    rotation, general routing (numerically integrated home lengths) and dL not dividing L (two-step first
+    interval of the shared grid)."""
+    rng = np.random.default_rng(40 + n_tendons)
+    tendons = [irt.TendonSpecs(C=[2 * np.pi * k / n_tendons, float(rng.uniform(-6, 6)), float(rng.uniform(-10, 10))],
+                               D=[0.01, float(rng.uniform(-0.01, 0.01))], max_tension=12.0) for k in range(n_tendons)]
+    robot = irt.TendonRobot(tendons=tendons, specs=irt.BackboneSpecs(dL=0.0035), enable_rotation=True, enable_retraction=True)
+    st = irt.workloads.random_states(robot, 300, seed=50 + n_tendons, tau_max=12.0 / np.sqrt(n_tendons))
+    L, dL = robot.specs.L, robot.specs.dL
+    st[:8, -1] = [0.0, L, L - dL / 4, L - 0.75 * dL, L - 1.25 * dL, dL / 3, 0.1, 17.5 * dL]
+    got = robot.shape_batch(st)
+    want = helpers.oracle_robot(orc, robot).fk_batch(st)
+    P = got["p"].shape[1]
+    assert np.array_equal(np.isnan(got["p"]), np.isnan(want["p"][:, :P]))
+    assert np.nanmax(np.abs(got["p"] - want["p"][:, :P])) <= TIP_TOL
+    assert np.abs(got["L_i"] - want["L_i"]).max() <= 1e-10 and np.array_equal(got["converged"], want["converged"])
+    # validity (home lengths per configuration feed the length limits)
+    vox, _ = irt.workloads.reach_environment(seed=7, n_spheres=48, N=128)      # 3.9 mm voxels >= dL
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    det = chk.is_valid_detail(st)
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    w = [orc.is_valid_state(orb, og, s) for s in st]
+    assert np.array_equal(det["valid"], [x[0] for x in w]) and np.array_equal(det["flags"] & 15, [x[2] for x in w])
