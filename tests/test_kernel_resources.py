@@ -30,3 +30,29 @@ def test_fk_kernel_register_budget(tmp_path):
     assert get("ScratchSize") <= 32
     assert get("VGPRs Spill") <= 4
     assert get("AGPRs") == 0
+
+
+FUSED_TU = r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "fused_kernel.hpp"
+template __global__ void trk::fk_sweep_fused<3, false>(const double*, int64_t, int64_t, RobotK, const double*, const StepK*, int,
+                                                       trk::FkOut, const trk::FusedSweepArgs*);
+'''
+
+
+def test_fused_kernel_register_budget(tmp_path):
+    """The kernel the headline runs: K1's loop must stay as it is inside fk_sweep_fused (two waves per SIMD, a
+    handful of spilled registers) -- the sweep behind it may not push the allocation over."""
+    src = tmp_path / "kf.hip"
+    src.write_text(FUSED_TU)
+    out = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-c",
+                          "--cuda-device-only", "-Rpass-analysis=kernel-resource-usage", "-I", CSRC, str(src), "-o",
+                          str(tmp_path / "kf.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    txt = out.stderr
+    get = lambda key: int(re.search(key + r"[^:]*: (\d+)", txt).group(1))
+    assert get("Occupancy") == 2
+    assert get("ScratchSize") <= 48
+    assert get("VGPRs Spill") <= 10
+    assert get("AGPRs") == 0
