@@ -152,6 +152,14 @@ int tr_fk_batch_dev(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld,
                     double *d_L, double *d_Li, uint8_t *d_converged, int32_t *d_n_points,
                     void *stream);
 
+/* The same for retraction-enabled robots, whose home-shape tendon lengths depend on the configuration
+ * (home_shape(s_start), tendon/TendonRobot.cpp:249-314): d_n_points and d_home_Li ([N][ld]) are mandatory
+ * outputs; rows are aligned at the tip as described above.  Feeds tr_validate_shapes_retraction_dev. */
+int tr_fk_batch_retraction_dev(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld,
+                               double *d_px, double *d_py, double *d_pz, double *d_R,
+                               double *d_L, double *d_Li, uint8_t *d_converged, int32_t *d_n_points,
+                               double *d_home_Li, void *stream);
+
 /* ---- state validity: StateValidityChecker::isValid -------------------------------------- */
 
 /* Batched AbstractValidityChecker::isValid (motion-planning/AbstractValidityChecker.cpp:124-133)
@@ -169,14 +177,20 @@ int tr_validate_batch_dev(tr_ctx *ctx, const double *d_states, int64_t n,
 
 /* The second stage alone, on caller-supplied backbone shapes (is_valid_shape + voxelize +
  * collides on given TendonResults: AbstractValidityChecker.cpp:99-122).  Device pointers, SoA as
- * produced by tr_fk_batch_dev (with d_n_points given, rows aligned at the tip as described there).
- * d_n_points may be NULL (all P).  check_voxels = 0 skips the
+ * produced by tr_fk_batch_dev.  d_n_points is ignored (a robot without retraction has all P points in
+ * every configuration; kept in the signature for symmetry).  check_voxels = 0 skips the
  * obstacle test (the "is_valid_shape only" predicate used while voxelising edges,
- * VoxelBackboneMotionValidator.cpp:29-36). */
+ * VoxelBackboneMotionValidator.cpp:29-36).  Retraction-enabled robots: the _retraction_ form below. */
 int tr_validate_shapes_dev(tr_ctx *ctx, int64_t n, int64_t ld,
                            const double *d_px, const double *d_py, const double *d_pz,
                            const int32_t *d_n_points, const double *d_Li, const uint8_t *d_converged,
                            int check_voxels, uint64_t *d_valid_bits, uint8_t *d_flags, void *stream);
+/* ... on the outputs of tr_fk_batch_retraction_dev (per-configuration point counts and home lengths). */
+int tr_validate_shapes_retraction_dev(tr_ctx *ctx, int64_t n, int64_t ld,
+                                      const double *d_px, const double *d_py, const double *d_pz,
+                                      const int32_t *d_n_points, const double *d_Li, const double *d_home_Li,
+                                      const uint8_t *d_converged, int check_voxels,
+                                      uint64_t *d_valid_bits, uint8_t *d_flags, void *stream);
 
 /* ---- motion validity: MotionValidator::checkMotion -------------------------------------- */
 

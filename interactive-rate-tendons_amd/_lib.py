@@ -26,7 +26,8 @@ PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_
 ABI_SYMBOLS = (
     "tr_create", "tr_destroy", "tr_last_error", "tr_state_size", "tr_num_points", "tr_device",
     "tr_home_lengths", "tr_set_grid", "tr_set_checker", "tr_grid_add_spheres", "tr_grid_remove_interior", "tr_grid_dilate",
-    "tr_grid_dilate_sphere", "tr_get_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev",
+    "tr_grid_dilate_sphere", "tr_get_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev", "tr_fk_batch_retraction_dev",
+    "tr_validate_shapes_retraction_dev",
     "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_last_valid",
     "tr_validate_edges_discrete",
     "tr_check_cached", "tr_check_cached_dev", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_knn", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
@@ -185,6 +186,8 @@ def lib():
     L.tr_reserve_edges.argtypes = [vp, i64]
     L.tr_fk_batch.argtypes = [vp, dp, i64, dp, dp, dp, dp, P(C.c_uint8), P(C.c_int32)]
     L.tr_fk_batch_dev.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tr_fk_batch_retraction_dev.argtypes = [vp, vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.tr_validate_shapes_retraction_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.tr_validate_batch.argtypes = [vp, dp, i64, P(C.c_uint64), dp, P(C.c_uint8)]
     L.tr_validate_batch_dev.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.tr_validate_shapes_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]

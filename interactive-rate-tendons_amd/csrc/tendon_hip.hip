@@ -789,6 +789,19 @@ int tr_fk_batch_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t ld, do
   return launch_fk(c, d_states, n, ld, out, (hipStream_t)stream);
 }
 
+int tr_fk_batch_retraction_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t ld, double *d_px, double *d_py,
+                               double *d_pz, double *d_R, double *d_L, double *d_Li, uint8_t *d_converged,
+                               int32_t *d_n_points, double *d_home_Li, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  if (!c->K.enable_retraction) return fail(c, TR_ERR_INVALID_ARG, "robot has no retraction: use tr_fk_batch_dev (home lengths: tr_home_lengths)");
+  if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
+  if (n == 0) return TR_OK;
+  if (!d_states || !d_px || !d_py || !d_pz || !d_n_points || !d_home_Li) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  trk::FkOut out{d_px, d_py, d_pz, d_R, d_L, d_Li, nullptr, d_converged, d_n_points, d_home_Li};
+  return launch_fk(c, d_states, n, ld, out, (hipStream_t)stream);
+}
+
 int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R, double *L, double *L_i,
                 uint8_t *converged, int32_t *n_points) {
   if (!c) return TR_ERR_INVALID_ARG;
@@ -868,16 +881,37 @@ int tr_validate_shapes_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px,
   if (n == 0) return TR_OK;
   if (!d_px || !d_py || !d_pz || !d_Li || !d_converged || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
   if (c->K.enable_retraction)
-    return fail(c, TR_ERR_UNSUPPORTED, "tr_validate_shapes_dev needs per-configuration home lengths with retraction; use tr_validate_batch");
+    return fail(c, TR_ERR_UNSUPPORTED, "with retraction the home lengths are per configuration: use tr_validate_shapes_retraction_dev");
   int rc;
   // the accumulated-chord scratch has the caller's leading dimension
   if (c->ws.ld < ld) {
     if (ld > c->max_chunk) return fail(c, TR_ERR_INVALID_ARG, "ld exceeds the workspace chunk size; call in smaller batches");
     if ((rc = ensure_workspace(c, ld))) return rc;
   }
-  trk::SweepIn in{d_px, d_py, d_pz, d_n_points, d_Li, d_converged, nullptr, c->ws.acc};
+  (void)d_n_points;                     // every configuration of a robot without retraction has all P points
+  trk::SweepIn in{d_px, d_py, d_pz, nullptr, d_Li, d_converged, nullptr, c->ws.acc};
   // acc scratch is laid out [P][ws.ld]; the kernel indexes it with ld, which is <= ws.ld: fine as
   // long as P*ld <= P*ws.ld (it only needs P*ld doubles).
+  return launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream);
+}
+
+int tr_validate_shapes_retraction_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px, const double *d_py,
+                                      const double *d_pz, const int32_t *d_n_points, const double *d_Li,
+                                      const double *d_home_Li, const uint8_t *d_converged, int check_voxels,
+                                      uint64_t *d_valid_bits, uint8_t *d_flags, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  if (!c->K.enable_retraction) return fail(c, TR_ERR_INVALID_ARG, "robot has no retraction: use tr_validate_shapes_dev");
+  if (n < 0 || ld < n || (ld & 63)) return fail(c, TR_ERR_INVALID_ARG, "ld must be a multiple of 64 and >= n");
+  if (n == 0) return TR_OK;
+  if (!d_px || !d_py || !d_pz || !d_n_points || !d_Li || !d_home_Li || !d_converged || !d_valid_bits)
+    return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  int rc;
+  if (c->ws.ld < ld) {
+    if (ld > c->max_chunk) return fail(c, TR_ERR_INVALID_ARG, "ld exceeds the workspace chunk size; call in smaller batches");
+    if ((rc = ensure_workspace(c, ld))) return rc;
+  }
+  trk::SweepIn in{d_px, d_py, d_pz, d_n_points, d_Li, d_converged, d_home_Li, c->ws.acc};
   return launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream);
 }
 

@@ -305,6 +305,31 @@ class Engine:
         L.check(self._ctx, self.lib.tr_fk_batch_dev(self._ctx, ps, int(n), int(ld), px, py, pz, pR, pL, pLi, pc, pn,
                                                     self._stream_ptr(stream)))
 
+    def fk_batch_retraction_dev(self, d_states, n, ld, d_px, d_py, d_pz, d_Li, d_conv, d_npts, d_home_Li, d_L=None, stream=None):
+        """Retraction robots: FK with per-configuration point counts and home lengths (rows aligned at the tip)."""
+        torch = _torch()
+        P, N = self.num_points, self.n_tendons
+        L.check(self._ctx, self.lib.tr_fk_batch_retraction_dev(
+            self._ctx, self._check_dev(d_states, torch.float64, n * self.state_size, "d_states"), int(n), int(ld),
+            self._check_dev(d_px, torch.float64, P * ld, "d_px"), self._check_dev(d_py, torch.float64, P * ld, "d_py"),
+            self._check_dev(d_pz, torch.float64, P * ld, "d_pz"), None,
+            self._check_dev(d_L, torch.float64, n, "d_L") if d_L is not None else None,
+            self._check_dev(d_Li, torch.float64, N * ld, "d_Li"), self._check_dev(d_conv, torch.uint8, n, "d_conv"),
+            self._check_dev(d_npts, torch.int32, n, "d_npts"), self._check_dev(d_home_Li, torch.float64, N * ld, "d_home_Li"),
+            self._stream_ptr(stream)))
+
+    def validate_shapes_retraction_dev(self, n, ld, d_px, d_py, d_pz, d_npts, d_Li, d_home_Li, d_conv, d_bits, d_flags=None,
+                                       check_voxels=True, stream=None):
+        torch = _torch()
+        P, N = self.num_points, self.n_tendons
+        L.check(self._ctx, self.lib.tr_validate_shapes_retraction_dev(
+            self._ctx, int(n), int(ld), self._check_dev(d_px, torch.float64, P * ld, "d_px"),
+            self._check_dev(d_py, torch.float64, P * ld, "d_py"), self._check_dev(d_pz, torch.float64, P * ld, "d_pz"),
+            self._check_dev(d_npts, torch.int32, n, "d_npts"), self._check_dev(d_Li, torch.float64, N * ld, "d_Li"),
+            self._check_dev(d_home_Li, torch.float64, N * ld, "d_home_Li"), self._check_dev(d_conv, torch.uint8, n, "d_conv"),
+            int(bool(check_voxels)), self._check_dev(d_bits, torch.int64, (n + 63) // 64, "d_bits"),
+            self._check_dev(d_flags, torch.uint8, n, "d_flags") if d_flags is not None else None, self._stream_ptr(stream)))
+
     def validate_shapes_dev(self, n, ld, d_px, d_py, d_pz, d_Li, d_conv, d_bits, d_flags=None, d_npts=None,
                             check_voxels=True, stream=None):
         torch = _torch()

@@ -158,3 +158,36 @@ def test_retraction_other_tendon_counts(irt, orc, helpers, n_tendons):
     orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
     w = [orc.is_valid_state(orb, og, s) for s in st]
     assert np.array_equal(det["valid"], [x[0] for x in w]) and np.array_equal(det["flags"] & 15, [x[2] for x in w])
+
+
+def test_device_resident_two_stage_path_with_retraction(irt):
+    """tr_fk_batch_retraction_dev -> tr_validate_shapes_retraction_dev equals tr_validate_batch (same kernels,
+    caller-owned buffers: per-configuration point counts, home lengths, rows aligned at the tip)."""
+    import torch
+    W = irt.workloads
+    robot = _robot(irt, "quad")
+    vox, _ = W.reach_environment(seed=7, n_spheres=48)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    eng = chk.engine
+    n, ld = 1000, 1024
+    st = _states(irt, robot, n, seed=66)
+    want = chk.is_valid_detail(st)
+    P, N = eng.num_points, eng.n_tendons
+    dev = "cuda"
+    d_st = torch.from_numpy(st).to(dev)
+    px, py, pz = (torch.zeros(P * ld, dtype=torch.float64, device=dev) for _ in range(3))
+    Li, hLi = torch.zeros(N * ld, dtype=torch.float64, device=dev), torch.zeros(N * ld, dtype=torch.float64, device=dev)
+    conv = torch.zeros(n, dtype=torch.uint8, device=dev)
+    npts = torch.zeros(n, dtype=torch.int32, device=dev)
+    bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device=dev)
+    flags = torch.zeros(n, dtype=torch.uint8, device=dev)
+    eng.fk_batch_retraction_dev(d_st, n, ld, px, py, pz, Li, conv, npts, hLi)
+    eng.validate_shapes_retraction_dev(n, ld, px, py, pz, npts, Li, hLi, conv, bits, flags)
+    torch.cuda.synchronize()
+    got = irt.unpack_bits(bits.cpu().numpy().view(np.uint64), n)
+    assert np.array_equal(got, want["valid"]) and np.array_equal(flags.cpu().numpy(), want["flags"])
+    # the tip is always in the last row
+    tips = np.stack([px.view(P, ld)[P - 1, :n].cpu().numpy(), py.view(P, ld)[P - 1, :n].cpu().numpy(), pz.view(P, ld)[P - 1, :n].cpu().numpy()], 1)
+    assert np.array_equal(tips, want["tips"])
+    with pytest.raises(irt.Unsupported):
+        eng.validate_shapes_dev(n, ld, px, py, pz, Li, conv, bits)
