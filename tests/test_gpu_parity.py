@@ -324,3 +324,34 @@ def test_concurrent_single_state_calls(irt, orc, helpers):
     [t.start() for t in ths]
     [t.join() for t in ths]
     assert np.array_equal(got, want) and 0 < want.sum() < len(want)
+
+
+def test_error_paths_of_the_batch_entry_points(irt):
+    """Status codes of the C ABI mapped to the reference's exception types: calls that need a grid before
+    tr_set_grid, size mismatches, bad parameters -- none of them may touch the device state."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    eng = irt.Engine(robot)                            # no grid yet
+    st = W.random_states(robot, 8, seed=1)
+    for call in (lambda: eng.validate_batch(st, False, False), lambda: eng.validate_edges(st[:4], st[4:]),
+                 lambda: eng.validate_edges_discrete(st[:4], st[4:]), lambda: eng.voxelize_batch(st),
+                 lambda: eng.grid_add_spheres([[0, 0, 0, 0.01]]), lambda: eng.grid_dilate(1)):
+        with pytest.raises(irt.InvalidArgument):
+            call()
+    assert eng.fk_batch(st)["p"].shape == (8, eng.num_points, 3)          # FK needs no grid
+    vox, _ = W.reach_environment(seed=7, n_spheres=4)
+    eng.set_grid(vox.Nx(), vox.limits(), vox.blocks)
+    with pytest.raises(irt.InvalidArgument):
+        eng.validate_edges(st[:4], st[4:], min_tension_change=0.0)       # would divide by a zero segment length
+    with pytest.raises(irt.InvalidArgument):
+        eng.validate_edges(st[:4], st[3:])                                # different sizes
+    with pytest.raises(irt.InvalidArgument):
+        eng.knn(st, 0)
+    with pytest.raises(irt.InvalidArgument):
+        irt._lib.check(eng._ctx, eng.lib.tr_set_checker(eng._ctx, 7))                    # unknown checker
+    assert eng.validate_edges(np.zeros((0, 3)), np.zeros((0, 3)))["valid"].size == 0
+    assert eng.validate_edges_discrete(np.zeros((0, 3)), np.zeros((0, 3)))["valid"].size == 0
+    out = eng.voxelize_edges(np.zeros((0, 3)), np.zeros((0, 3)))
+    assert out["offsets"].tolist() == [0] and out["block_ids"].size == 0
+    # after all that the context still works
+    assert eng.validate_batch(st, False, False)["valid"].shape == (8,)
