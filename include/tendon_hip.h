@@ -210,6 +210,14 @@ typedef struct {
 int tr_validate_edges(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
                       int64_t n_edges, uint64_t *valid_bits, int32_t *n_fk, int64_t *n_domain_errors);
 
+/* The same for a roadmap: edge e joins states[edges[2e]] and states[edges[2e + 1]] (rows of one n_states x S
+ * array, the graph's vertices).  Every vertex is evaluated once for all of its edges -- the reference's
+ * checkMotion recomputes both end shapes for every edge (VoxelEnvironment.cpp:262-272) -- with identical
+ * verdicts and n_fk (which keeps counting the two ends per edge, as the reference does). */
+int tr_validate_edges_indexed(tr_ctx *ctx, const tr_space_params *sp, const double *states, int64_t n_states,
+                              const int32_t *edges, int64_t n_edges, uint64_t *valid_bits, int32_t *n_fk,
+                              int64_t *n_domain_errors);
+
 /* Batched checkMotion(s1, s2, last_valid) (AbstractVoxelMotionValidator.h:153-169 ->
  * voxelize_until_invalid, VoxelBackboneMotionValidator.cpp:83-91): same verdict bits, plus per edge
  * last_valid_t = PartialVoxelization::t, the largest sampled interpolation parameter below the first

@@ -379,6 +379,18 @@ class VoxelBackboneMotionValidator {
                              last_valid_t ? last_valid_t->data() : nullptr));
     return detail::unpack(bits, n);
   }
+  /// Roadmap form (the loops of VoxelCachedLazyPRM.cpp:1520-1542, :1621-1641): edge e joins rows edges[2e] and
+  /// edges[2e + 1] of `states`; every vertex is evaluated once for all of its edges.
+  std::vector<bool> checkMotionIndexed(const std::vector<double> &states, size_t n_states, const std::vector<int32_t> &edges,
+                                       std::vector<int32_t> *n_fk = nullptr) const {
+    if (states.size() != n_states * vc_.robot().state_size()) throw std::invalid_argument("State is not the right size");
+    const size_t n = edges.size() / 2;
+    std::vector<uint64_t> bits((n + 63) / 64);
+    if (n_fk) n_fk->resize(n);
+    check(vc_.context(), tr_validate_edges_indexed(vc_.context(), &space, states.data(), (int64_t)n_states, edges.data(), (int64_t)n,
+                                                   bits.data(), n_fk ? n_fk->data() : nullptr, nullptr));
+    return detail::unpack(bits, n);
+  }
   /// AbstractVoxelMotionValidator::voxelize(a, b) for a batch of edges (VoxelCachedLazyPRM.cpp:2890-2898):
   /// the swept voxel set of every fully valid edge.
   VoxelCaches voxelizeBatch(const std::vector<double> &a, const std::vector<double> &b, size_t n) const {

@@ -28,7 +28,7 @@ ABI_SYMBOLS = (
     "tr_home_lengths", "tr_set_grid", "tr_set_checker", "tr_grid_add_spheres", "tr_grid_remove_interior", "tr_grid_dilate",
     "tr_grid_dilate_sphere", "tr_get_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev", "tr_fk_batch_retraction_dev",
     "tr_validate_shapes_retraction_dev",
-    "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_last_valid",
+    "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_indexed", "tr_validate_edges_last_valid",
     "tr_validate_edges_discrete",
     "tr_check_cached", "tr_check_cached_dev", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_knn", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug",
@@ -192,6 +192,7 @@ def lib():
     L.tr_validate_batch_dev.argtypes = [vp, vp, i64, vp, vp, vp, vp]
     L.tr_validate_shapes_dev.argtypes = [vp, i64, i64, vp, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.tr_validate_edges.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(C.c_uint64), P(C.c_int32), P(i64)]
+    L.tr_validate_edges_indexed.argtypes = [vp, P(TrSpaceParams), dp, i64, P(C.c_int32), i64, P(C.c_uint64), P(C.c_int32), P(i64)]
     L.tr_validate_edges_last_valid.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(C.c_uint64), dp, P(C.c_int32)]
     L.tr_validate_edges_discrete.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(C.c_uint64), dp, P(C.c_int32)]
     L.tr_check_cached.argtypes = [vp, P(C.c_uint32), P(C.c_uint64), P(i64), i64, P(C.c_uint64)]

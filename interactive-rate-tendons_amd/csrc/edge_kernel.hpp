@@ -156,6 +156,24 @@ __global__ __launch_bounds__(256) void edge_init(EdgeState st, EdgeSpaceK sk, in
   st.last_t[k] = 0;
 }
 
+// Indexed edges (tr_validate_edges_indexed): the end states are roadmap vertices evaluated ONCE for all their
+// edges (pool slots = vertex indices).  Gathers the chunk's end states for interpolation and seeds the per-edge
+// state from the vertices' verdict bits; the reference's count of FK calls per edge starts at the two ends.
+__global__ __launch_bounds__(256) void edge_init_indexed(EdgeState st, EdgeSpaceK sk, int64_t E, const double *__restrict__ states,
+                                                         const int32_t *__restrict__ idx, double *__restrict__ A, double *__restrict__ B) {
+#pragma clang fp contract(off)
+  const int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (k >= E) return;
+  const int64_t sa = idx[2 * k], sb = idx[2 * k + 1];
+  for (int i = 0; i < sk.S; i++) { A[k * sk.S + i] = states[sa * sk.S + i]; B[k * sk.S + i] = states[sb * sk.S + i]; }
+  st.rel[k] = 1.0 / (double)valid_segment_count_dev(sk, states + sa * sk.S, states + sb * sk.S);
+  const bool va = (st.bits[sa >> 6] >> (sa & 63)) & 1ull, vb = (st.bits[sb >> 6] >> (sb & 63)) & 1ull;
+  st.edge_ok[k] = (va && vb) ? 1u : 0u;
+  st.nfk[k] = 2;
+  st.first_inv[k] = (unsigned long long)__double_as_longlong(10.0);
+  st.last_t[k] = 0;
+}
+
 // fold the verdicts of pool samples [s0, s0 + m) into their edges
 __global__ __launch_bounds__(256) void edge_fold(EdgeState st, int64_t s0, int64_t m, int until_invalid) {
   const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -176,7 +194,8 @@ __global__ __launch_bounds__(256) void edge_fold(EdgeState st, int64_t s0, int64
 // LEVEL0: candidate i is the whole edge i.  Otherwise candidates 2q, 2q + 1 are the distal
 // (:387-390) and proximal (:393-396) halves of open interval q, whose midpoint is pool sample s0 + q.
 template <bool LEVEL0>
-__global__ __launch_bounds__(256) void edge_filter(EdgeState st, const EdgeIv *__restrict__ open, int64_t n_cand, int64_t s0,
+__global__ __launch_bounds__(256) void edge_filter(EdgeState st, const EdgeIv *__restrict__ open, const int32_t *__restrict__ idx /* LEVEL0: end-state pool slots per edge, or null */,
+                                                   int64_t n_cand, int64_t s0,
                                                    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
                                                    int64_t ld, int P, const int32_t *__restrict__ n_points, GridK g, int until_invalid,
                                                    EdgeIv *__restrict__ frontier) {
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(256) void edge_filter(EdgeState st, const EdgeIv *_
   bool emit = false;
   EdgeIv c{};
   if (i < n_cand) {
-    if (LEVEL0) c = EdgeIv{(int32_t)i, (int32_t)(2 * i), (int32_t)(2 * i + 1), 0, 0.0, 1.0};
+    if (LEVEL0) c = idx ? EdgeIv{(int32_t)i, idx[2 * i], idx[2 * i + 1], 0, 0.0, 1.0} : EdgeIv{(int32_t)i, (int32_t)(2 * i), (int32_t)(2 * i + 1), 0, 0.0, 1.0};
     else {
       const EdgeIv iv = open[i >> 1];
       const double tm = (iv.ta + iv.tb) / 2;                   // :382

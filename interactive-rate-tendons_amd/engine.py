@@ -179,6 +179,20 @@ class Engine:
             nfk.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nde)))
         return dict(valid=unpack_bits(bits, n), bits=bits, n_fk=nfk, n_domain_errors=nde.value)
 
+    def validate_edges_indexed(self, states, edges, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001):
+        """Roadmap form: edges (n_edges, 2) index rows of states; every vertex is evaluated once for all its edges."""
+        st = self._states(states)
+        e = np.ascontiguousarray(np.asarray(edges).reshape(-1, 2), dtype=np.int32)
+        n = e.shape[0]
+        sp = L.TrSpaceParams(min_tension_change, min_rotation_change, min_retraction_change)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        nfk = np.zeros(n, dtype=np.int32)
+        nd = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_validate_edges_indexed(
+            self._ctx, C.byref(sp), _dp(st), st.shape[0], e.ctypes.data_as(C.POINTER(C.c_int32)), n,
+            bits.ctypes.data_as(C.POINTER(C.c_uint64)), nfk.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(nd)))
+        return dict(valid=unpack_bits(bits, n), n_fk=nfk, n_domain_errors=int(nd.value))
+
     def validate_edges_last_valid(self, a, b, min_tension_change=0.02, min_rotation_change=0.01,
                                   min_retraction_change=0.0001):
         a, b = self._states(a), self._states(b)

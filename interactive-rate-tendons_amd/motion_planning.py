@@ -160,6 +160,13 @@ class VoxelBackboneMotionValidator:
     def check_motion(self, a, b):
         return self.check_motion_detail(a, b)["valid"]
 
+    def check_motion_indexed(self, states, edges):
+        """checkMotion for roadmap edges given as index pairs into one vertex array: same verdicts and n_fk, but
+        every vertex is evaluated once for all of its edges (tr_validate_edges_indexed)."""
+        return self._timers["voxelize-swept-volume"].time(
+            self.engine.validate_edges_indexed, states, edges, self.min_tension_change, self.min_rotation_change,
+            self.min_retraction_change)
+
     def check_motion_last_valid(self, a, b):
         """checkMotion(s1, s2, last_valid) for a batch: (valid, last_valid_t); last_valid.first is
         interpolate(s1, s2, last_valid_t) in the caller's state space."""

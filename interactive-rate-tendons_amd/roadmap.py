@@ -89,7 +89,7 @@ class RoadmapBuilder:
     # ---- phase 4: edge validity --------------------------------------------------------------------------
     def validate_edges(self, states, edges):
         t0 = time.perf_counter()
-        out = self.mv.check_motion_detail(states[edges[:, 0]], states[edges[:, 1]])
+        out = self.mv.check_motion_indexed(states, edges)          # vertices evaluated once for all their edges
         self.timing["edges"] = dict(seconds=time.perf_counter() - t0, edges=len(edges), fk_samples=int(out["n_fk"].sum()))
         return out["valid"], out["n_fk"]
 

@@ -56,6 +56,18 @@ int main(int argc, char **argv) {
     std::printf("edge %d %d %.17g %.17g %d %.17g\n", (int)ok, (int)ok2, lv.second, lv.first[0], (int)okd, dlv.second);
     fa.insert(fa.end(), ea[i].begin(), ea[i].end()); fb.insert(fb.end(), eb[i].begin(), eb[i].end());
   }
+  {
+    // the same three edges as index pairs into one vertex array
+    std::vector<double> verts; std::vector<int32_t> eidx;
+    for (size_t i = 0; i < ea.size(); i++) {
+      verts.insert(verts.end(), ea[i].begin(), ea[i].end()); verts.insert(verts.end(), eb[i].begin(), eb[i].end());
+      eidx.push_back((int32_t)(2 * i)); eidx.push_back((int32_t)(2 * i + 1));
+    }
+    std::vector<int32_t> infk;
+    auto iv = mv.checkMotionIndexed(verts, 2 * ea.size(), eidx, &infk);
+    auto pv = mv.checkMotionBatch(fa, fb, ea.size());
+    for (size_t i = 0; i < iv.size(); i++) std::printf("indexed %d %d %d\n", (int)iv[i], (int)pv[i], infk[i]);
+  }
   std::vector<int32_t> nfk;
   auto ev = dmv.checkMotionBatch(fa, fb, ea.size(), &nfk);
   for (size_t i = 0; i < ev.size(); i++) std::printf("dbatch %d %d\n", (int)ev[i], nfk[i]);

@@ -92,3 +92,5 @@ def test_shim_results_match_oracle(tmp_path, irt, orc, helpers):
         assert int(row[1]) == i and int(row[2]) == order[1] and abs(float(row[3]) - D[i, order[1]]) < 1e-12
     sph = [int(l.split()[1]) for l in out if l.startswith("spheres")]
     assert sph == [int(orc.is_valid_state_spheres(orb, og, s)[0]) for s in states]
+    idx = [l.split() for l in out if l.startswith("indexed")]
+    assert len(idx) == 3 and all(r[1] == r[2] for r in idx) and [int(r[1]) for r in idx] == [int(e[1]) for e in edges]

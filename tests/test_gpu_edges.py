@@ -183,3 +183,32 @@ def test_fused_and_separate_kernels_give_identical_bits(irt):
         for k in ("valid", "flags", "tips"):
             assert np.array_equal(f[k], s[k]), k
         assert 0.2 < f["valid"].mean() < 0.95
+
+
+def test_indexed_edges_equal_the_pairwise_form(irt):
+    """tr_validate_edges_indexed evaluates every vertex once for all of its edges; verdicts, n_fk and the count of
+    domain errors equal tr_validate_edges on the gathered end states -- also with a pool so small that the vertex
+    block does not fit (host-gather fallback) and chunks overflow."""
+    W = irt.workloads
+    for mk, rot in ((W.robot_config3, False), (W.robot_config2, True)):
+        robot = mk()
+        robot.enable_rotation = rot
+        vox, _ = W.reach_environment(seed=7, n_spheres=64)
+        states = W.random_states(robot, 900, seed=45)
+        rng = np.random.default_rng(46)
+        near = np.argsort(np.linalg.norm(states[:, None, :len(robot.tendons)] - states[None, :, :len(robot.tendons)], axis=2), axis=1)[:, 1:7]
+        edges = np.stack([np.repeat(np.arange(900), 6), near.reshape(-1)], 1)
+        edges = np.concatenate([edges, [[5, 5], [7, 3], [3, 7]]])                       # a == b, both orientations
+
+        def run():
+            chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+            mv = irt.VoxelBackboneMotionValidator(chk)
+            return mv.check_motion_indexed(states, edges), mv.check_motion_detail(states[edges[:, 0]], states[edges[:, 1]])
+
+        for env in ({}, {"TENDON_HIP_EDGE_POOL": "1024"}, {"TENDON_HIP_EDGE_POOL": "4096"}):
+            got, want = _with_env(irt, env, run)
+            for k in ("valid", "n_fk", "n_domain_errors"):
+                assert np.array_equal(got[k], want[k]), (k, env)
+        assert 0.05 < got["valid"].mean() < 0.99 and got["n_fk"].max() > 4
+    with pytest.raises(irt.OutOfRange):
+        irt.VoxelBackboneMotionValidator(irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)).check_motion_indexed(states, [[0, 900]])
