@@ -22,6 +22,7 @@ struct KnnMetric {
 
 constexpr int KNN_SMAX = TRK_MAX_TENDONS + 2;
 
+template <int NT>            // tension dimensions, compile time: the inner product is 3 NT straight-line fp64 operations
 __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ states, int64_t n, KnnMetric m, int k,
                                                      double max_dist, int32_t *__restrict__ out_idx,
                                                      double *__restrict__ out_dist) {
@@ -32,19 +33,19 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
   const int64_t q = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = q < n;
   const int64_t qc = live ? q : n - 1;
-  const int S = m.S, NT = m.n_tension;
+  const int S = m.S;
   double x[KNN_SMAX];
 #pragma unroll
   for (int d = 0; d < KNN_SMAX; d++) x[d] = d < S ? states[qc * S + d] : 0.0;
   for (int p = 0; p < k; p++) { bd[p * 64] = 1.0 / 0.0; bi[p * 64] = -1; }
   double worst = 1.0 / 0.0;
   const bool plain = !m.has_rot && !m.has_ret;      // tension only: order by squared distance, sqrt at the end
+#pragma unroll 8
   for (int64_t j = 0; j < n; j++) {
     const double *__restrict__ c = states + j * S;  // wave-uniform
     double s2 = 0.0;
 #pragma unroll
-    for (int d = 0; d < TRK_MAX_TENDONS; d++)
-      if (d < NT) { const double t = x[d] - c[d]; s2 += t * t; }
+    for (int d = 0; d < NT; d++) { const double t = x[d] - c[d]; s2 += t * t; }
     double dist = s2;
     if (!plain) {
       dist = sqrt(s2);

@@ -1214,8 +1214,14 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
     if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
-      hipLaunchKernelGGL(trk::knn_bruteforce, dim3((unsigned)((n + 63) / 64)), dim3(64), (size_t)k * 64 * 12, nullptr, d_s, n, m, (int)k,
-                         max_distance, d_i, d_d);
+      const dim3 grid((unsigned)((n + 63) / 64));
+      const size_t lds = (size_t)k * 64 * 12;
+      switch (N) {
+#define TRK_CASE(NT) case NT: hipLaunchKernelGGL(trk::knn_bruteforce<NT>, grid, dim3(64), lds, nullptr, d_s, n, m, (int)k, max_distance, d_i, d_d); break;
+        TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
+#undef TRK_CASE
+        default: break;
+      }
     }
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, TR_ERR_HIP, "knn launch failed"); break; }
     if (hipMemcpy(idx, d_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
