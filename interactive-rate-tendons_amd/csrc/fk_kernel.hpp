@@ -315,7 +315,7 @@ __device__ __forceinline__ void rk4_step_routed(double (&R)[9], double (&v)[3], 
 // K1 for the shared arc-length grid (retraction disabled).
 //   tab:   [(nsteps*3 + 1)][N][6] routing table; entry 0 = base (s_start), then 3 per step
 //   steps: [nsteps]
-template <int N, bool ROT, bool WRITE_R>
+template <int N, bool ROT, bool WRITE_R, bool WANT_L = true>
 __device__ __forceinline__ void fk_uniform_body(
     const double *__restrict__ states, int64_t n, int64_t ld, const RobotK &K,
     const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, const FkOut &out) {
@@ -393,7 +393,7 @@ __device__ __forceinline__ void fk_uniform_body(
       p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
       p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
       p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);
-      {
+      if (WANT_L) {
         const double v2 = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2];
         Lb += bw * (v2 * fast_rsqrt(v2));
       }

@@ -20,7 +20,7 @@ template <int N, bool ROT>
 __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_sweep_fused(
     const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, FkOut out, const FusedSweepArgs *__restrict__ sa) {
-  fk_uniform_body<N, ROT, false>(states, n, ld, K, tab, steps, nsteps, out);
+  fk_uniform_body<N, ROT, false, false>(states, n, ld, K, tab, steps, nsteps, out);   // the verdict paths never ask for the backbone length
   __syncthreads();
   const FusedSweepArgs a = *sa;
   sweep_body<false>(a.in, n, ld, a.P, a.CH, a.NM, K, a.g, a.grid, a.near_grid, a.check_voxels, a.debug, a.valid_bits, a.flags);
