@@ -418,7 +418,7 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
     if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
     if ((rc = ensure_sphere_near(ctx, s))) return rc;
   }
-  if (ctx->fuse && !ctx->K.enable_retraction && !out.R) {
+  if (ctx->fuse && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s))) return rc;
   } else {
     if ((rc = launch_fk(ctx, d_states, n, ld, out, s))) return rc;
