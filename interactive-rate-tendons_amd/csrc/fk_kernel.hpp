@@ -393,7 +393,7 @@ __device__ __forceinline__ void fk_uniform_body(
       p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
       p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
       p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);
-      if (WANT_L) {
+      if (WANT_L && out.L) {                               // wave-uniform
         const double v2 = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2];
         Lb += bw * (v2 * fast_rsqrt(v2));
       }

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
         p[0] += bw * (sR[0] * sv[0] + sR[3] * sv[1] + sR[6] * sv[2]);
         p[1] += bw * (sR[1] * sv[0] + sR[4] * sv[1] + sR[7] * sv[2]);
         p[2] += bw * (sR[2] * sv[0] + sR[5] * sv[1] + sR[8] * sv[2]);
-        {
+        if (out.L) {                                       // wave-uniform: the validity paths do not ask for the backbone length
           const double v2 = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2];
           Lb += bw * (v2 * fast_rsqrt(v2));
         }
