@@ -189,7 +189,7 @@ def main():
                 traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        # counted from the gfx950 ISA of the RK4 loop inside fk_sweep_fused<3>: 2032 fp64 VALU instructions per
+        # counted from the gfx950 ISA of the RK4 loop inside fk_sweep_fused<3>: 1908 fp64 VALU instructions per
         # step (FMA = 2 flops) -> ~3100 flop/step x 128 steps; the sweep's flops are not counted
         flops_per_check = 3.95e5
         out = {

@@ -87,7 +87,7 @@ __device__ __forceinline__ void strain_rates_routed(const double v[3], const dou
     // pd = u x r + r' + v
     const double pdx = (v[0] + rdx) - u[2] * ry;
     const double pdy = (v[1] + rdy) + u[2] * rx;
-    const double pdz = v[2] + (u[0] * ry - u[1] * rx);
+    const double pdz = __builtin_fma(u[0], ry, __builtin_fma(-u[1], rx, v[2]));
     const double s2 = pdx * pdx + pdy * pdy + pdz * pdz;
     const double rs = fast_rsqrt(s2);
     sdot[j] = s2 * rs;
@@ -107,64 +107,71 @@ __device__ __forceinline__ void strain_rates_routed(const double v[3], const dou
     P1 += t1 * rx; P2 += t1 * ry; P3 += t2 * ry;
     // w = u x (pd + r') + r''
     const double hx = pdx + rdx, hy = pdy + rdy, hz = pdz;
-    const double wx = (u[1] * hz - u[2] * hy) + rddx;
-    const double wy = (u[2] * hx - u[0] * hz) + rddy;
+    const double wx = __builtin_fma(u[1], hz, __builtin_fma(-u[2], hy, rddx));
+    const double wy = __builtin_fma(u[2], hx, __builtin_fma(-u[0], hz, rddy));
     const double wz = u[0] * hy - u[1] * hx;
     const double pw = pdx * wx + pdy * wy + pdz * wz;
     const double aix = qx * pw - cs2 * wx, aiy = qy * pw - cs2 * wy, aiz = qz * pw - cs2 * wz;
     ax += aix; ay += aiy; az += aiz;
     bx += ry * aiz; by -= rx * aiz; bz += rx * aiy - ry * aix;
   }
-  Axx -= Z; Ayy -= Z; Azz -= Z;
+  // The tail below is written as explicit FMA chains: without re-association the compiler keeps the a - (b*c + d*e)
+  // shapes as written and spends an extra add / negate on each (~90 instructions per RK4 step).
+#define TRK_FMA __builtin_fma
   // - sum c|pd|^2 rhat, rhat = [[0,0,ry],[0,0,-rx],[-ry,rx,0]]
   B02 -= Q2; B12 += Q1; B20 += Q2; B21 -= Q1;
   // + sum c|pd|^2 rhat^2, rhat^2 = [[-ry^2, rx ry, 0],[rx ry, -rx^2, 0],[0,0,-(rx^2+ry^2)]]
-  Hxx -= P3; Hxy += P2; Hyy -= P1; Hzz -= (P1 + P3);
+  Hxy += P2;
   // c = -u x (K_bt u) - v x (K_se (v - e3)) - b ;  d = -u x (K_se (v - e3)) - a
   const double kux = K.kb0 * u[0], kuy = K.kb0 * u[1], kuz = K.kb2 * u[2];
   const double svx = K.ks0 * v[0], svy = K.ks0 * v[1], svz = K.ks2 * (v[2] - 1.0);
-  const double cx = -(u[1] * kuz - u[2] * kuy) - (v[1] * svz - v[2] * svy) - bx;
-  const double cy = -(u[2] * kux - u[0] * kuz) - (v[2] * svx - v[0] * svz) - by;
-  const double cz = -(u[0] * kuy - u[1] * kux) - (v[0] * svy - v[1] * svx) - bz;
-  const double dx = -(u[1] * svz - u[2] * svy) - ax;
-  const double dy = -(u[2] * svx - u[0] * svz) - ay;
-  const double dz = -(u[0] * svy - u[1] * svx) - az;
-  // M11 = K_se + A (symmetric); inverse by adjugate
-  const double m00 = K.ks0 + Axx, m01 = Axy, m02 = Axz, m11 = K.ks0 + Ayy, m12 = Ayz, m22 = K.ks2 + Azz;
-  const double c00 = m11 * m22 - m12 * m12, c01 = m02 * m12 - m01 * m22, c02 = m01 * m12 - m02 * m11;
-  const double c11 = m00 * m22 - m02 * m02, c12 = m01 * m02 - m00 * m12, c22 = m00 * m11 - m01 * m01;
-  const double idet = fast_rcp(m00 * c00 + m01 * c01 + m02 * c02);
+  const double cx = TRK_FMA(u[2], kuy, TRK_FMA(-u[1], kuz, TRK_FMA(v[2], svy, TRK_FMA(-v[1], svz, -bx))));
+  const double cy = TRK_FMA(u[0], kuz, TRK_FMA(-u[2], kux, TRK_FMA(v[0], svz, TRK_FMA(-v[2], svx, -by))));
+  const double cz = TRK_FMA(u[1], kux, TRK_FMA(-u[0], kuy, TRK_FMA(v[1], svx, TRK_FMA(-v[0], svy, -bz))));
+  const double dx = TRK_FMA(u[2], svy, TRK_FMA(-u[1], svz, -ax));
+  const double dy = TRK_FMA(u[0], svz, TRK_FMA(-u[2], svx, -ay));
+  const double dz = TRK_FMA(u[1], svx, TRK_FMA(-u[0], svy, -az));
+  // M11 = K_se + A - Z I (symmetric); inverse by adjugate
+  const double ksz0 = K.ks0 - Z, ksz2 = K.ks2 - Z;
+  const double m00 = ksz0 + Axx, m01 = Axy, m02 = Axz, m11 = ksz0 + Ayy, m12 = Ayz, m22 = ksz2 + Azz;
+  const double c00 = TRK_FMA(m11, m22, -(m12 * m12)), c01 = TRK_FMA(m02, m12, -(m01 * m22)), c02 = TRK_FMA(m01, m12, -(m02 * m11));
+  const double c11 = TRK_FMA(m00, m22, -(m02 * m02)), c12 = TRK_FMA(m01, m02, -(m00 * m12)), c22 = TRK_FMA(m00, m11, -(m01 * m01));
+  const double idet = fast_rcp(TRK_FMA(m00, c00, TRK_FMA(m01, c01, m02 * c02)));
   const double i00 = c00 * idet, i01 = c01 * idet, i02 = c02 * idet, i11 = c11 * idet, i12 = c12 * idet, i22 = c22 * idet;
   // y = M11^-1 d
-  const double yx = i00 * dx + i01 * dy + i02 * dz;
-  const double yy_ = i01 * dx + i11 * dy + i12 * dz;
-  const double yz = i02 * dx + i12 * dy + i22 * dz;
+  const double yx = TRK_FMA(i00, dx, TRK_FMA(i01, dy, i02 * dz));
+  const double yy_ = TRK_FMA(i01, dx, TRK_FMA(i11, dy, i12 * dz));
+  const double yz = TRK_FMA(i02, dx, TRK_FMA(i12, dy, i22 * dz));
   // T = B M11^-1
-  const double T00 = B00 * i00 + B01 * i01 + B02 * i02, T01 = B00 * i01 + B01 * i11 + B02 * i12, T02 = B00 * i02 + B01 * i12 + B02 * i22;
-  const double T10 = B10 * i00 + B11 * i01 + B12 * i02, T11 = B10 * i01 + B11 * i11 + B12 * i12, T12 = B10 * i02 + B11 * i12 + B12 * i22;
-  const double T20 = B20 * i00 + B21 * i01 + B22 * i02, T21 = B20 * i01 + B21 * i11 + B22 * i12, T22 = B20 * i02 + B21 * i12 + B22 * i22;
-  // Schur complement S = (K_bt + H) - T B^T (symmetric)
-  const double s00 = (K.kb0 + Hxx) - (T00 * B00 + T01 * B01 + T02 * B02);
-  const double s01 = Hxy - (T00 * B10 + T01 * B11 + T02 * B12);
-  const double s02 = Hxz - (T00 * B20 + T01 * B21 + T02 * B22);
-  const double s11 = (K.kb0 + Hyy) - (T10 * B10 + T11 * B11 + T12 * B12);
-  const double s12 = Hyz - (T10 * B20 + T11 * B21 + T12 * B22);
-  const double s22 = (K.kb2 + Hzz) - (T20 * B20 + T21 * B21 + T22 * B22);
+  const double T00 = TRK_FMA(B00, i00, TRK_FMA(B01, i01, B02 * i02)), T01 = TRK_FMA(B00, i01, TRK_FMA(B01, i11, B02 * i12)),
+               T02 = TRK_FMA(B00, i02, TRK_FMA(B01, i12, B02 * i22));
+  const double T10 = TRK_FMA(B10, i00, TRK_FMA(B11, i01, B12 * i02)), T11 = TRK_FMA(B10, i01, TRK_FMA(B11, i11, B12 * i12)),
+               T12 = TRK_FMA(B10, i02, TRK_FMA(B11, i12, B12 * i22));
+  const double T20 = TRK_FMA(B20, i00, TRK_FMA(B21, i01, B22 * i02)), T21 = TRK_FMA(B20, i01, TRK_FMA(B21, i11, B22 * i12)),
+               T22 = TRK_FMA(B20, i02, TRK_FMA(B21, i12, B22 * i22));
+  // Schur complement S = (K_bt + H) - T B^T (symmetric), with H's rhat^2 terms folded into the first operand
+  const double s00 = TRK_FMA(-T02, B02, TRK_FMA(-T01, B01, TRK_FMA(-T00, B00, (K.kb0 - P3) + Hxx)));
+  const double s01 = TRK_FMA(-T02, B12, TRK_FMA(-T01, B11, TRK_FMA(-T00, B10, Hxy)));
+  const double s02 = TRK_FMA(-T02, B22, TRK_FMA(-T01, B21, TRK_FMA(-T00, B20, Hxz)));
+  const double s11 = TRK_FMA(-T12, B12, TRK_FMA(-T11, B11, TRK_FMA(-T10, B10, (K.kb0 - P1) + Hyy)));
+  const double s12 = TRK_FMA(-T12, B22, TRK_FMA(-T11, B21, TRK_FMA(-T10, B20, Hyz)));
+  const double s22 = TRK_FMA(-T22, B22, TRK_FMA(-T21, B21, TRK_FMA(-T20, B20, ((K.kb2 - P1) - P3) + Hzz)));
   // rhs = c - B y
-  const double ex = cx - (B00 * yx + B01 * yy_ + B02 * yz);
-  const double ey = cy - (B10 * yx + B11 * yy_ + B12 * yz);
-  const double ez = cz - (B20 * yx + B21 * yy_ + B22 * yz);
+  const double ex = TRK_FMA(-B02, yz, TRK_FMA(-B01, yy_, TRK_FMA(-B00, yx, cx)));
+  const double ey = TRK_FMA(-B12, yz, TRK_FMA(-B11, yy_, TRK_FMA(-B10, yx, cy)));
+  const double ez = TRK_FMA(-B22, yz, TRK_FMA(-B21, yy_, TRK_FMA(-B20, yx, cz)));
   // u' = S^-1 rhs (adjugate)
-  const double g00 = s11 * s22 - s12 * s12, g01 = s02 * s12 - s01 * s22, g02 = s01 * s12 - s02 * s11;
-  const double g11 = s00 * s22 - s02 * s02, g12 = s01 * s02 - s00 * s12, g22 = s00 * s11 - s01 * s01;
-  const double isd = fast_rcp(s00 * g00 + s01 * g01 + s02 * g02);
-  du[0] = (g00 * ex + g01 * ey + g02 * ez) * isd;
-  du[1] = (g01 * ex + g11 * ey + g12 * ez) * isd;
-  du[2] = (g02 * ex + g12 * ey + g22 * ez) * isd;
+  const double g00 = TRK_FMA(s11, s22, -(s12 * s12)), g01 = TRK_FMA(s02, s12, -(s01 * s22)), g02 = TRK_FMA(s01, s12, -(s02 * s11));
+  const double g11 = TRK_FMA(s00, s22, -(s02 * s02)), g12 = TRK_FMA(s01, s02, -(s00 * s12)), g22 = TRK_FMA(s00, s11, -(s01 * s01));
+  const double isd = fast_rcp(TRK_FMA(s00, g00, TRK_FMA(s01, g01, s02 * g02)));
+  du[0] = TRK_FMA(g00, ex, TRK_FMA(g01, ey, g02 * ez)) * isd;
+  du[1] = TRK_FMA(g01, ex, TRK_FMA(g11, ey, g12 * ez)) * isd;
+  du[2] = TRK_FMA(g02, ex, TRK_FMA(g12, ey, g22 * ez)) * isd;
   // v' = y - T^T u'
-  dv[0] = yx - (T00 * du[0] + T10 * du[1] + T20 * du[2]);
-  dv[1] = yy_ - (T01 * du[0] + T11 * du[1] + T21 * du[2]);
-  dv[2] = yz - (T02 * du[0] + T12 * du[1] + T22 * du[2]);
+  dv[0] = TRK_FMA(-T20, du[2], TRK_FMA(-T10, du[1], TRK_FMA(-T00, du[0], yx)));
+  dv[1] = TRK_FMA(-T21, du[2], TRK_FMA(-T11, du[1], TRK_FMA(-T01, du[0], yy_)));
+  dv[2] = TRK_FMA(-T22, du[2], TRK_FMA(-T12, du[1], TRK_FMA(-T02, du[0], yz)));
+#undef TRK_FMA
 }
 
 // ri: wave-uniform pointer to N x 6 doubles {rx, ry, rdx, rdy, rddx, rddy} per tendon.
