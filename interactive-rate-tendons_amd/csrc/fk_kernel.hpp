@@ -91,8 +91,10 @@ __device__ __forceinline__ void strain_rates_routed(const double v[3], const dou
     const double s2 = pdx * pdx + pdy * pdy + pdz * pdz;
     const double rs = fast_rsqrt(s2);
     sdot[j] = s2 * rs;
-    const double c = -tau[j] * (rs * rs * rs);
-    const double qx = c * pdx, qy = c * pdy, qz = c * pdz, cs2 = c * s2;
+    // c = -tau / |pd|^3 and c |pd|^2 = -tau / |pd| from the same reciprocal root (one multiply fewer than c * s2)
+    const double cs2 = -tau[j] * rs;
+    const double c = cs2 * (rs * rs);
+    const double qx = c * pdx, qy = c * pdy, qz = c * pdz;
     Axx += qx * pdx; Axy += qx * pdy; Axz += qx * pdz; Ayy += qy * pdy; Ayz += qy * pdz; Azz += qz * pdz;
     Z += cs2;
     // e = r x pd, g = c e  (r_z = 0)
