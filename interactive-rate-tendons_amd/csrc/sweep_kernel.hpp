@@ -407,6 +407,7 @@ __device__ __forceinline__ void sweep_body(
     const bool use_near = near.blocks != nullptr;
     bool in_prev = false;
     int cpx = 0, cpy = 0, cpz = 0;
+    uint64_t near_prev = 0;                               // dilated-grid word of the previous point's block
     auto visit = [&](int j, const V3 &q) -> bool {
       bool need = false;
       if (j == 0) prev = q;
@@ -434,12 +435,16 @@ __device__ __forceinline__ void sweep_body(
           if (in_prev && in_q) {
             const int ddx = cqx - cpx, ddy = cqy - cpy, ddz = cqz - cpz;
             const bool nearby = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1;
-            need = !(use_near && nearby && !near.occupied(cpx, cpy, cpz));   // the walk itself is deferred (below)
+            // start cell free in the dilated grid?  Its word was requested when that point was visited (below),
+            // so the answer does not wait for a dependent load here
+            const bool start_free = use_near && !((near_prev >> (((cpx & 3) << 4) | ((cpy & 3) << 2) | (cpz & 3))) & 1ull);
+            need = !(nearby && start_free);                    // the walk itself is deferred (below)
           } else {
             hit = line_hits(prevr, qr, g, gc, near, bad);      // near or outside the domain boundary: full reference path
           }
         }
         prevr = qr; in_prev = in_q; cpx = cqx; cpy = cqy; cpz = cqz;
+        if (use_near && in_q) near_prev = near.blocks[((size_t)(cqx >> 2) * g.Nb + (cqy >> 2)) * g.Nb + (cqz >> 2)];
       }
       return need;
     };
