@@ -12,6 +12,9 @@
 #pragma once
 #include "fk_kernel.hpp"
 #define TRK_DEVICE_BODIES_ONLY
+#ifndef TRK_K2_PF
+#define TRK_K2_PF 8          // behind the FK the sweep has registers to spare: 8 points in flight per lane (4 standalone); 12 measured worse
+#endif
 #include "sweep_kernel.hpp"
 
 namespace trk {
