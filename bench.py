@@ -7,7 +7,10 @@ the all-gather of the validity bitmask) over one batch of 2^20 synthetic configu
 configs[1] as specified in BASELINE.md section 2 (seeded, synthetic).
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+N > 1 works both ways: under an external launcher (python -m torch.distributed.run --nproc-per-node N ...,
+which sets RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), or as the bare command above -- then this process
+starts N fresh rank processes itself, BEFORE it has imported torch or touched the GPU, waits for them and
+exits non-zero if any of them failed.
 
 Rank 0 prints ONE JSON line; see README / DESIGN.md for the `roofline` and `cpu_baseline` objects.
 """
@@ -78,6 +81,53 @@ def cpu_baseline(irt, robot, vox, states, budget_s=12.0):
                        % (m, len(states), dt)), valid, m
 
 
+def spawn_ranks(n_ranks):
+    """`python bench.py --gpus N` without a launcher: start N fresh children (one per GPU) with the
+    torch.distributed environment set, relay their exit status.  Nothing in this parent process has initialised
+    HIP or imported torch at this point, and the children are new processes (no fork of GPU state, no exec of a
+    process that touched the GPU)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                code = p.poll()
+                if code is None:
+                    continue
+                pending.remove(p)
+                if code != 0 and rc == 0:
+                    rc = code if code > 0 else 1
+                    for q in pending:                 # a rank died: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def load_isa_counts():
+    """profiles/isa_counts.json (written by profiles/count_isa.py from the gfx950 assembly of this source tree;
+    tests/test_kernel_resources.py fails when it is stale): fp64 flops per RK4 step of the hot kernels."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+    except Exception:
+        return {}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -89,13 +139,16 @@ def main():
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)" % (args.gpus, world))
+        raise SystemExit("--gpus %d but the launcher set WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
     # TENDON_BENCH_SHARED_GPU=1 is a REHEARSAL mode for boxes with one GPU: every rank uses cuda:0 and the
@@ -103,8 +156,13 @@ def main():
     # mean nothing).  The real N>1 path below is one rank per GPU with RCCL.
     rehearsal = os.environ.get("TENDON_BENCH_SHARED_GPU") == "1"
     dev_index = 0 if rehearsal else local_rank
+    if dev_index >= torch.cuda.device_count():
+        raise SystemExit("rank %d needs cuda:%d but this node has %d GPU(s) (TENDON_BENCH_SHARED_GPU=1 rehearses N>1 on one GPU)"
+                         % (rank, dev_index, torch.cuda.device_count()))
     torch.cuda.set_device(dev_index)
-    if world > 1:
+    # a launcher's environment (even with one rank) selects the distributed path: process group + all-gather
+    use_dist = world > 1 or ("WORLD_SIZE" in os.environ and "MASTER_PORT" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if rehearsal:
             dist.init_process_group("gloo")
@@ -124,21 +182,21 @@ def main():
     d_states = torch.from_numpy(states).cuda()
     d_bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
     d_tips = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
-    d_all = torch.zeros(world * (n // 64), dtype=torch.int64, device="cuda") if world > 1 else None
+    d_all = torch.zeros(world * (n // 64), dtype=torch.int64, device="cuda") if use_dist else None
     eng.reserve(n)
 
-    h_all = torch.zeros(world * (n // 64), dtype=torch.int64) if (world > 1 and rehearsal) else None
+    h_all = torch.zeros(world * (n // 64), dtype=torch.int64) if (use_dist and rehearsal) else None
 
     def step():
         eng.validate_batch_dev(d_states, n, d_bits, d_tips)
-        if world > 1:
+        if use_dist:
             if rehearsal:
                 dist.all_gather_into_tensor(h_all, d_bits.cpu())
             else:
                 dist.all_gather_into_tensor(d_all, d_bits)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -153,7 +211,7 @@ def main():
     elapsed = time.perf_counter() - t0
     prof = eng.profile_read()
     eng.profile_end()
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -182,16 +240,43 @@ def main():
         dom_name, dom, dom_ms, dom_bytes = max(cands, key=lambda c: c[1]["total_ms"])
         units_per_launch = n * args.steps / max(1, dom["launches"])
         achieved = dom_bytes * units_per_launch / (dom_ms * 1e-3) / 1e9
-        traffic = None
+        # measured HBM traffic of the dominant kernel: a separate rocprofv3 --pmc pass (profiles/collect.sh), valid only
+        # for the kernel sources it was collected on (source_hash), else null
+        traffic, traffic_source = None, None
         if os.path.exists(args.traffic_json):
             try:
                 tj = json.load(open(args.traffic_json))
-                traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+                if tj.get("source_hash") == irt._lib.source_hash():
+                    traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+                    traffic_source = tj.get("source")
+                else:
+                    traffic_source = "stale: %s was collected on other kernel sources" % os.path.relpath(args.traffic_json, ROOT)
             except Exception:
                 traffic = None
-        # counted from the gfx950 ISA of the RK4 loop inside fk_sweep_fused<3>: 1908 fp64 VALU instructions per
-        # step (FMA = 2 flops) -> ~3100 flop/step x 128 steps; the sweep's flops are not counted
-        flops_per_check = 3.95e5
+        # fp64 flops per check: flops per RK4 step counted from this source tree's gfx950 assembly
+        # (profiles/isa_counts.json <- profiles/count_isa.py; FMA = 2) x RK4 steps per configuration.  Initial
+        # bending and the sweep's arithmetic are not counted.
+        isa = load_isa_counts()
+        isa_key = {"fk_sweep_fused": "fk_sweep_fused<%d,false>" % N, "fk_rk4_batch": "fk_rk4_batch_uniform<%d,false,false>" % N}.get(dom_name)
+        flops_per_step = isa.get(isa_key, {}).get("flops_per_step")
+        flops_per_check = flops_per_step * (P - 1) if flops_per_step else None
+        hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+               "algorithmic_bytes_per_check": dom_bytes}
+        valu = None
+        if flops_per_check:
+            tf = flops_per_check * units_per_launch / (dom_ms * 1e-3) / 1e12
+            valu = {"achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TF,
+                    "flops_per_check": flops_per_check, "flops_per_rk4_step": flops_per_step, "rk4_steps": P - 1,
+                    "flops_source": "profiles/isa_counts.json[%s]" % isa_key}
+        # the roofline that binds the kernel is the one it sits closest to; the other is kept beside it
+        if valu and valu["frac"] >= hbm["frac"]:
+            roofline = dict(bound="fp64_valu", kernel=dom_name, achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"],
+                            frac=valu["frac"], traffic=traffic, traffic_source=traffic_source, avg_launch_ms=dom_ms,
+                            flops_per_check=flops_per_check, flops_source=valu["flops_source"], hbm=hbm)
+        else:
+            roofline = dict(bound="hbm", kernel=dom_name, achieved=hbm["achieved"], peak=hbm["peak"], unit=hbm["unit"],
+                            frac=hbm["frac"], traffic=traffic, traffic_source=traffic_source, avg_launch_ms=dom_ms,
+                            algorithmic_bytes_per_check=dom_bytes, fp64_valu=valu)
         out = {
             "metric": "FK+collision checks/sec (3-tendon, 256^3 voxel env)",
             "value": checks / elapsed,
@@ -206,18 +291,13 @@ def main():
             "config": {"workload": "configs[1]: 3-tendon helical-routed robot (C=[2*pi*k/3, 5], D=[0.01], L=0.2, dL=L/128, "
                                    "129 backbone points), 2^%d seeded configs per GPU per step (tau~U[0,10)^3), batched FK + "
                                    "256^3 voxel collision (64 seeded spheres r=0.02 in reach)" % args.batch_log2,
-                       "rehearsal_shared_gpu": rehearsal, "batch_per_gpu": n, "parallelism": "shard%d+allgather(bitmask)" % world if world > 1 else "single",
+                       "rehearsal_shared_gpu": rehearsal, "batch_per_gpu": n, "parallelism": "shard%d+allgather(bitmask)" % world if use_dist else "single",
+                       "collective": ("gloo(host)" if rehearsal else "rccl") if use_dist else None,
                        "valid_fraction_rank0": float(valid.mean())},
-            "roofline": {"bound": "hbm", "kernel": dom_name, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "algorithmic_bytes_per_check": dom_bytes, "avg_launch_ms": dom_ms},
+            "roofline": roofline,
             "kernels": {"fk_sweep_fused": {"avg_ms": kf_ms, "launches": kf["launches"], "bytes_per_check": k1b + k2b},
                         "fk_rk4_batch": {"avg_ms": k1_ms, "launches": k1["launches"], "bytes_per_check": k1b},
                         "backbone_voxel_sweep": {"avg_ms": k2_ms, "launches": k2["launches"], "bytes_per_check": k2b}},
-            "valu_fp64": {"achieved_tflops": flops_per_check * units_per_launch / (dom_ms * 1e-3) / 1e12,
-                          "peak_tflops": FP64_VALU_PEAK_TF,
-                          "frac": flops_per_check * units_per_launch / (dom_ms * 1e-3) / 1e12 / FP64_VALU_PEAK_TF,
-                          "note": "K1 is fp64-VALU-bound (SURVEY 8d); flops/check counted from this build's ISA"},
         }
         if world == 1 and not args.no_cpu_baseline:
             # PCIe-inclusive rate through the host-buffer entry point (pageable numpy arrays in, bits + tips out);
@@ -230,7 +310,7 @@ def main():
             out["cpu_baseline"] = cb
             out["config"]["verdicts_match_cpu_sample"] = bool(np.array_equal(valid[:m], cpu_valid))
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -112,6 +112,16 @@ def _sources():
     return [os.path.join(SRC_DIR, f) for f in sorted(os.listdir(SRC_DIR)) if not f.startswith("_")] + [HEADER]
 
 
+def source_hash():
+    """sha1 over the kernel / ABI sources: ties a profile (profiles/traffic_latest.json) to the code it was taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in _sources():
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(force=False, verbose=False, jobs=None):
     """Compile libtendon_hip.so in-tree for gfx950 if it is missing or older than its sources.
     Objects go to csrc/_obj/ (git-ignored); a unit is recompiled when any source or header is newer."""

@@ -55,7 +55,7 @@ def allgather_mask(local_words, group=None):
     """All-gather equal-length int64 mask shards into the global mask (rank-major)."""
     import torch
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local_words.clone()
     world = dist.get_world_size(group)
     out = torch.empty(world * local_words.numel(), dtype=local_words.dtype, device=local_words.device)

@@ -59,12 +59,42 @@ class OrcSpaceParams(C.Structure):
                 ("min_retraction_change", C.c_double)]
 
 
+def _cpu_stamp():
+    """Identity of the host CPU the -march=native build is valid for (model name + ISA flags)."""
+    model, flags = "", ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and not model:
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("flags") and not flags:
+                flags = " ".join(sorted(line.split(":", 1)[1].split()))
+            if model and flags:
+                break
+    except OSError:
+        pass
+    import hashlib
+    return model + " " + hashlib.sha1(flags.encode()).hexdigest()[:16]
+
+
 def build(force=False):
-    """Compile oracle/_build/liboracle{,_omp}.so with gcc (seconds)."""
+    """Compile oracle/_build/liboracle{,_omp}.so with gcc (seconds).  The OpenMP library is built with
+    -march=native, so it is rebuilt when this host's CPU is not the one it was built on
+    (the prebuilt file travels from the dev container to the GPU box)."""
     out = os.path.join(_HERE, "_build", "liboracle.so")
+    omp = os.path.join(_HERE, "_build", "liboracle_omp.so")
+    stamp = os.path.join(_HERE, "_build", "omp.cpu")
     src = os.path.join(_HERE, "tendon_oracle.c")
-    if force or not os.path.exists(out) or os.path.getmtime(out) < os.path.getmtime(src):
-        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    newest = max(os.path.getmtime(src), os.path.getmtime(os.path.join(_HERE, "Makefile")))
+    here = _cpu_stamp()
+    same_cpu = os.path.exists(stamp) and open(stamp).read() == here
+    if force or not os.path.exists(out) or os.path.getmtime(out) < newest:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_build/liboracle.so"])
+    if force or not same_cpu or not os.path.exists(omp) or os.path.getmtime(omp) < newest:
+        if os.path.exists(omp):
+            os.remove(omp)
+        subprocess.check_call(["make", "-C", _HERE, "-s", "_build/liboracle_omp.so"])
+        with open(stamp, "w") as f:
+            f.write(here)
     return out
 
 
@@ -76,8 +106,7 @@ def _load(kind="strict"):
         return _libs[kind]
     name = {"strict": "liboracle.so", "omp": "liboracle_omp.so"}[kind]
     path = os.path.join(_HERE, "_build", name)
-    if not os.path.exists(path):
-        build()
+    build()                      # no-op when up to date; rebuilds the -march=native library on a different host CPU
     lib = C.CDLL(path)
     P = C.POINTER
     lib.orc_state_size.argtypes = [P(OrcRobot)]

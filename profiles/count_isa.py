@@ -1,0 +1,143 @@
+#!/usr/bin/env python3
+"""Counts the fp64 VALU work of the RK4 loop of the hot kernels from the gfx950 ISA hipcc emits, and writes
+profiles/isa_counts.json -- the figure bench.py turns into `roofline.achieved` for the fp64-VALU roofline
+(flops per check = flops per RK4 step x steps per configuration; FMA = 2 flops).
+
+    python profiles/count_isa.py            # rewrite profiles/isa_counts.json
+    python profiles/count_isa.py --check    # exit 1 if the tracked file is stale (tests/test_kernel_resources.py does the same)
+
+How: the kernel is compiled to assembly (`hipcc -S --cuda-device-only`, same flags as the build); LLVM annotates
+every basic block with the loop it belongs to ("in Loop: Header=BBx_y"); the RK4 loop is the loop holding the
+most v_fma_f64 instructions; every v_*_f64 instruction in its blocks is counted once (the loop body is
+straight-line per step: the only inner branches are exec-mask skips of the point store).
+"""
+import collections
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "interactive-rate-tendons_amd", "csrc")
+OUT = os.path.join(ROOT, "profiles", "isa_counts.json")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off"]
+
+# flops per instruction; everything else matching v_*_f64 (moves, compares, conversions, min/max, ldexp ...) counts 0
+FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_rcp_f64": 1, "v_rsq_f64": 1, "v_sqrt_f64": 1,
+         "v_div_fmas_f64": 2, "v_div_fixup_f64": 1, "v_div_scale_f64": 1, "v_pk_fma_f64": 4, "v_pk_mul_f64": 2,
+         "v_pk_add_f64": 2}
+
+KERNELS = {
+    # name -> (translation unit, steps per configuration are supplied by the caller: P - 1)
+    "fk_sweep_fused<3,false>": r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "fused_kernel.hpp"
+template __global__ void trk::fk_sweep_fused<3, false>(const double*, int64_t, int64_t, RobotK, const double*, const StepK*, int,
+                                                       trk::FkOut, const trk::FusedSweepArgs*);
+''',
+    "fk_sweep_fused<4,false>": r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "fused_kernel.hpp"
+template __global__ void trk::fk_sweep_fused<4, false>(const double*, int64_t, int64_t, RobotK, const double*, const StepK*, int,
+                                                       trk::FkOut, const trk::FusedSweepArgs*);
+''',
+    "fk_rk4_batch_uniform<3,false,false>": r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "fk_kernel.hpp"
+template __global__ void trk::fk_rk4_batch_uniform<3, false, false>(const double*, int64_t, int64_t, RobotK,
+                                                                     const double*, const StepK*, int, trk::FkOut);
+''',
+    "fk_rk4_batch_uniform<4,false,false>": r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "fk_kernel.hpp"
+template __global__ void trk::fk_rk4_batch_uniform<4, false, false>(const double*, int64_t, int64_t, RobotK,
+                                                                     const double*, const StepK*, int, trk::FkOut);
+''',
+}
+
+_BLOCK = re.compile(r"^(\.LBB\d+_\d+):\s*(?:;\s*(.*))?$")
+_HDR = re.compile(r"Header=(BB\d+_\d+)")
+_INSN = re.compile(r"^\s+([vs]_[a-z0-9_]+)")
+
+
+def count_asm(asm):
+    """-> dict for the loop with the most v_fma_f64: histogram of v_*_f64 opcodes, totals."""
+    loops = collections.defaultdict(collections.Counter)      # header label -> opcode histogram
+    valu = collections.Counter()                              # header label -> all VALU instructions
+    cur = None
+    for line in asm.splitlines():
+        m = _BLOCK.match(line)
+        if m:
+            label, note = m.group(1)[1:], m.group(2) or ""    # "LBB0_30" -> "BB0_30" below
+            label = label[1:]
+            if "This Inner Loop Header" in note or "This Loop Header" in note:
+                cur = label
+            else:
+                h = _HDR.search(note)
+                cur = h.group(1) if h else None
+            continue
+        if cur is None:
+            continue
+        m = _INSN.match(line)
+        if not m:
+            continue
+        op = m.group(1)
+        for suffix in ("_e32", "_e64", "_dpp", "_sdwa"):
+            if op.endswith(suffix):
+                op = op[: -len(suffix)]
+        if op.startswith("v_"):
+            valu[cur] += 1
+            if op.endswith("_f64"):
+                loops[cur][op] += 1
+    if not loops:
+        raise RuntimeError("no fp64 loop found in the assembly")
+    hdr = max(loops, key=lambda h: loops[h]["v_fma_f64"] + loops[h]["v_fmac_f64"])
+    hist = dict(sorted(loops[hdr].items()))
+    return {"loop": hdr, "fp64_valu_instructions_per_step": int(sum(hist.values())),
+            "valu_instructions_per_step": int(valu[hdr]),
+            "flops_per_step": int(sum(FLOPS.get(op, 0) * c for op, c in hist.items())),
+            "opcodes": hist}
+
+
+def compile_asm(tu, workdir):
+    src = os.path.join(workdir, "k.hip")
+    with open(src, "w") as f:
+        f.write(tu)
+    out = os.path.join(workdir, "k.s")
+    subprocess.run(["hipcc"] + FLAGS + ["--cuda-device-only", "-S", "-I", CSRC, src, "-o", out], check=True,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    return open(out).read()
+
+
+def count_all(names=None):
+    res = {}
+    for name, tu in KERNELS.items():
+        if names and name not in names:
+            continue
+        with tempfile.TemporaryDirectory() as d:
+            res[name] = count_asm(compile_asm(tu, d))
+    return res
+
+
+def main():
+    res = count_all()
+    if "--check" in sys.argv:
+        old = json.load(open(OUT))
+        bad = [k for k in res if old.get(k, {}).get("flops_per_step") != res[k]["flops_per_step"]]
+        if bad:
+            print("stale:", bad)
+            sys.exit(1)
+        return
+    json.dump(res, open(OUT, "w"), indent=1, sort_keys=True)
+    for k, v in res.items():
+        print(k, v["fp64_valu_instructions_per_step"], "fp64 instr/step,", v["flops_per_step"], "flop/step")
+
+
+if __name__ == "__main__":
+    main()

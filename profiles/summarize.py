@@ -21,6 +21,12 @@ for name, out in (("bench_default.log", f"bench_{tag}.json"), ("bench_stats.log"
     open(f"{dst}/{out}", "w").write(line)
 subprocess.check_call([sys.executable, f"{here}/collect_traffic.py", f"{src}/pmc_fetch", f"{src}/pmc_write", f"{dst}/traffic_{tag}.json"],
                       stdout=subprocess.DEVNULL)
+sys.path.insert(0, os.path.dirname(here))
+import importlib
+tj = json.load(open(f"{dst}/traffic_{tag}.json"))
+tj["source"] = os.path.relpath(f"{dst}/traffic_{tag}.json", os.path.dirname(here))
+tj["source_hash"] = importlib.import_module("interactive-rate-tendons_amd._lib").source_hash()   # run on the tree the profile was taken on
+json.dump(tj, open(f"{dst}/traffic_{tag}.json", "w"), indent=1)
 shutil.copy(f"{dst}/traffic_{tag}.json", f"{here}/traffic_latest.json")
 out = {}
 for d in ("sq", "grbm"):

@@ -1,0 +1,111 @@
+"""The multi-GPU leg on hardware: RCCL (`nccl` backend) process group, the validity bitmask all-gathered as DEVICE
+tensors (distributed.allgather_mask -> dist.all_gather_into_tensor), in fresh rank processes -- a one-GPU box can
+run world size 1 of it (RCCL refuses two ranks on one device); world size 2 of the sharding logic is the gloo test
+in tests/test_host.py, and `bench.py --gpus 2` is rehearsed here with both ranks on cuda:0 (gloo through host
+memory for the collective).  Replaces the exchange the reference gets from shared memory
+(motion-planning/VoxelCachedLazyPRM.cpp:1446-1483)."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = r'''
+import importlib, os, sys
+import numpy as np
+sys.path.insert(0, %(root)r)
+import torch
+import torch.distributed as dist
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
+assert dist.get_backend() == "nccl"
+irt = importlib.import_module("interactive-rate-tendons_amd")
+W, D = irt.workloads, irt.distributed
+robot = W.robot_config3()
+vox, _ = W.reach_environment(seed=7, n_spheres=64)
+chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+seen = {}
+def validate_local(states):
+    d = torch.from_numpy(states).cuda()
+    bits = torch.zeros((len(states) + 63) // 64, dtype=torch.int64, device="cuda")
+    chk.engine.validate_batch_dev(d, len(states), bits)
+    torch.cuda.synchronize()
+    return bits.cpu().numpy()
+M = int(sys.argv[1])
+# the collective itself, on device tensors
+local = torch.arange(5, dtype=torch.int64, device="cuda") + 100 * dist.get_rank()
+full = D.allgather_mask(local)
+assert full.is_cuda and full.numel() == 5 * dist.get_world_size() and torch.equal(full[:5].cpu(), torch.arange(5))
+mask = irt.unpack_bits(D.ShardedVertexValidator(robot, validate_local, seed=3, device="cuda").run(M), M)
+cand = D.candidate_states(robot, 3, 0, M)
+mv = irt.VoxelBackboneMotionValidator(chk)
+idx = np.flatnonzero(mask)[:261]
+a, b = cand[idx[:-1]], cand[idx[1:]]
+emask = irt.unpack_bits(D.ShardedEdgeValidator(lambda ea, eb: D.pack_bits(mv.check_motion(ea, eb)), device="cuda").run(a, b), len(a))
+if dist.get_rank() == 0:
+    np.savez(sys.argv[2], mask=mask, emask=emask, direct=chk.is_valid(cand), edirect=mv.check_motion(a, b))
+dist.barrier()
+dist.destroy_process_group()
+print("nccl-ok")
+'''
+
+
+def _env(**kw):
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29650 + os.getpid() % 300), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.update(kw)
+    return env
+
+
+def test_nccl_world1_allgather_on_device_tensors(tmp_path, orc, irt, helpers):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER % {"root": ROOT})
+    out = str(tmp_path / "res.npz")
+    M = 5000
+    p = subprocess.run([sys.executable, str(script), str(M), out], env=_env(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "nccl-ok" in p.stdout, p.stderr[-3000:]
+    r = np.load(out)
+    assert np.array_equal(r["mask"], r["direct"]) and np.array_equal(r["emask"], r["edirect"])
+    robot = irt.workloads.robot_config3()
+    vox, _ = irt.workloads.reach_environment(seed=7, n_spheres=64)
+    cand = irt.distributed.candidate_states(robot, 3, 0, M)
+    want, _, _ = orc.validate_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), cand,
+                                    nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(r["mask"], want) and 0 < want.sum() < M
+
+
+def _bench(args, **env):
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, env=_env(**env), capture_output=True,
+                       text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_rccl_path_with_one_rank():
+    """bench.py under a launcher's environment with one rank: init_process_group("nccl") + all_gather_into_tensor of
+    the device bitmask + the all_reduce of the timing, exactly the statements the N = 2, 4, 8 runs execute."""
+    out = _bench(["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch-log2", "15", "--no-cpu-baseline"],
+                 RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    assert out["n_gpus"] == 1 and out["config"]["collective"] == "rccl" and out["value"] > 0
+
+
+def test_bench_gpus2_from_a_bare_command_shared_gpu():
+    """`python bench.py --gpus 2` with no launcher: the parent starts the two ranks itself.  Both share cuda:0 here
+    (rehearsal mode), so the numbers mean nothing; the control flow is the N > 1 one."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--batch-log2", "15", "--no-cpu-baseline"], env=dict(env, TENDON_BENCH_SHARED_GPU="1"),
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["rehearsal_shared_gpu"] is True

@@ -225,6 +225,18 @@ def test_sharded_validation_gloo_world2_matches_world1(irt, tmp_path):
     assert ea.shape == (130,) and np.array_equal(ea, eb) and 0 < ea.sum() < 130      # 130 edges: shards are not whole words
 
 
+def test_bench_spawns_its_own_ranks_and_relays_failure():
+    """`python bench.py --gpus 2` with no launcher starts two rank processes (before touching torch / the GPU) and
+    exits non-zero when a rank fails -- here both do, there is no GPU in this container."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    import torch
+    if not torch.cuda.is_available():
+        assert p.returncode != 0
+        assert p.stderr.count("needs a GPU") + p.stderr.count("GPU(s)") == 2, p.stderr[-2000:]
+
+
 def test_pack_bits_roundtrip(irt):
     rng = np.random.default_rng(1)
     for n in (0, 1, 63, 64, 65, 1000):

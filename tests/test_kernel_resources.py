@@ -57,3 +57,20 @@ def test_fused_kernel_register_budget(tmp_path):
     assert get("ScratchSize") <= 160       # measured faster than the 24-byte variant that still integrates the backbone length
     assert get("VGPRs Spill") <= 40
     assert get("AGPRs") == 0
+
+
+def test_isa_counts_are_current():
+    """profiles/isa_counts.json -- the flops per RK4 step bench.py prices the fp64-VALU roofline with -- must be the
+    count of THIS source tree's gfx950 assembly (profiles/count_isa.py rewrites it)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("count_isa", os.path.join(ROOT, "profiles", "count_isa.py"))
+    ci = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ci)
+    tracked = json.load(open(ci.OUT))
+    fresh = ci.count_all(["fk_sweep_fused<3,false>"])
+    for k, v in fresh.items():
+        assert tracked[k]["flops_per_step"] == v["flops_per_step"], "run `python profiles/count_isa.py`"
+        assert tracked[k]["fp64_valu_instructions_per_step"] == v["fp64_valu_instructions_per_step"]
+        # sanity of the count itself: an RK4 step is 4 evaluations of a ~770-flop right-hand side plus the stage updates
+        assert 2500 < v["flops_per_step"] < 4500 and v["opcodes"].get("v_rcp_f64", 0) >= 8
