@@ -94,14 +94,20 @@ int tr_home_lengths(const tr_ctx *ctx, double *L_i /*[n_tendons]*/);
 int tr_set_grid(tr_ctx *ctx, uint32_t N, const double lim[6], const uint64_t *blocks,
                 const double inv_rot[9]);
 
-/* Which robot voxelisation the state checks use (tr_validate_batch*, tr_validate_edges_discrete):
+/* Which state validity checker is installed (si->setStateValidityChecker, motion-planning/Problem.h:175-197):
  * TR_CHECKER_BACKBONE = motion_planning::VoxelBackboneValidityChecker (the backbone polyline against a
  * pre-dilated environment, VoxelBackboneValidityChecker.h:28-58; the default),
  * TR_CHECKER_SPHERES  = motion_planning::VoxelValidityChecker (a sphere of the robot radius at every
  * backbone point against the raw environment, VoxelValidityChecker.h:18-26).
- * The swept-volume edge calls (tr_validate_edges, _last_valid, tr_voxelize_*) are VoxelBackbone* classes
- * in the reference and always use the backbone.  Call it before tr_set_grid: the dL <= voxel size check of
- * tr_set_grid is the backbone checker's constructor check and is skipped for TR_CHECKER_SPHERES. */
+ * It decides tr_validate_batch* (isValid) and -- exactly where the reference's motion validators ask the installed
+ * checker, `_vc->collides(shape)` in voxelize_until_invalid_impl (VoxelBackboneMotionValidator.cpp:83-91) -- the
+ * per-sample test of the checkMotion(s1, s2, last_valid) forms: tr_validate_edges_last_valid and
+ * tr_validate_edges_discrete with a last_valid_t output.  checkMotion(s1, s2) itself (tr_validate_edges,
+ * tr_validate_edges_indexed, tr_validate_edges_discrete without last_valid_t) and the voxel caches (tr_voxelize_*)
+ * sweep the BACKBONE against the voxels under either checker, as AbstractVoxelMotionValidator::checkMotion does
+ * (AbstractVoxelMotionValidator.h:143-151: voxelize() = is_valid_shape only, then collides(partial.voxels)).
+ * Call it before tr_set_grid: the dL <= voxel size check of tr_set_grid is the backbone checker's constructor check
+ * and is skipped for TR_CHECKER_SPHERES. */
 #define TR_CHECKER_BACKBONE 0
 #define TR_CHECKER_SPHERES 1
 int tr_set_checker(tr_ctx *ctx, int32_t checker);
@@ -222,7 +228,8 @@ int tr_validate_edges_indexed(tr_ctx *ctx, const tr_space_params *sp, const doub
  * voxelize_until_invalid, VoxelBackboneMotionValidator.cpp:83-91): same verdict bits, plus per edge
  * last_valid_t = PartialVoxelization::t, the largest sampled interpolation parameter below the first
  * invalid sample (1.0 for a valid edge, 0.0 when already the start is invalid).  The caller obtains
- * last_valid.first with its own space->interpolate(s1, s2, t). */
+ * last_valid.first with its own space->interpolate(s1, s2, t).  A sample is judged by the installed state
+ * checker (tr_set_checker), as voxelize_until_invalid_impl does. */
 int tr_validate_edges_last_valid(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
                                  int64_t n_edges, uint64_t *valid_bits, double *last_valid_t, int32_t *n_fk);
 
@@ -231,7 +238,9 @@ int tr_validate_edges_last_valid(tr_ctx *ctx, const tr_space_params *sp, const d
  * ompl::base::DiscreteMotionValidator::checkMotion): samples a, interpolate(i / nd) for
  * i = 1 .. nd-1 with nd = validSegmentCount(a, b), then b; the edge is valid iff every sample is a
  * valid state.  last_valid_t (optional) = PartialVoxelization::t, n_fk (optional) = samples the
- * reference's sequential loop evaluates (it stops after the first invalid one). */
+ * reference's sequential loop evaluates (it stops after the first invalid one).  With last_valid_t the call is
+ * checkMotion(s1, s2, last_valid) and a sample is judged by the installed state checker; without it the call is
+ * checkMotion(s1, s2): shape validity per sample plus the swept backbone volume (see tr_set_checker). */
 int tr_validate_edges_discrete(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
                                int64_t n_edges, uint64_t *valid_bits, double *last_valid_t, int32_t *n_fk);
 

@@ -816,24 +816,31 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
   if ((rc = ensure_workspace(c, std::min(n, chunk_max)))) return rc;
   if ((rc = ensure_staging(c, std::min(n, chunk_max)))) return rc;
   Workspace &w = c->ws;
-  double *d_R = nullptr;
+  struct DevBuf {                               // freed on every return path
+    double *p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+  } dR;
   std::vector<double> hx, hy, hz, hR, hLi;
   std::vector<int32_t> hn;
   for (int64_t off = 0; off < n; off += chunk_max) {
-    const int64_t m = std::min(chunk_max, n - off), ld = w.ld;
+    // the chunk uses its own leading dimension (the workspace may have been grown to 2^22 columns by an edge call:
+    // an R buffer of that width would be 39 GB at P = 129)
+    const int64_t m = std::min(chunk_max, n - off), ld = round_up(m, 64);
     HIP_TRY(c, hipMemcpy(w.states, states + off * S, (size_t)m * S * sizeof(double), hipMemcpyHostToDevice));
-    if (R && !d_R) HIP_TRY(c, hipMalloc((void **)&d_R, (size_t)9 * P * ld * sizeof(double)));
-    trk::FkOut out{w.px, w.py, w.pz, d_R, w.L, w.Li, nullptr, w.conv, w.npts, nullptr};
-    if ((rc = launch_fk(c, w.states, m, ld, out, nullptr))) { if (d_R) (void)hipFree(d_R); return rc; }
+    if (R && !dR.p) HIP_TRY(c, hipMalloc((void **)&dR.p, (size_t)9 * P * round_up(std::min(chunk_max, n), 64) * sizeof(double)));
+    trk::FkOut out{w.px, w.py, w.pz, dR.p, w.L, w.Li, nullptr, w.conv, w.npts, nullptr};
+    if ((rc = launch_fk(c, w.states, m, ld, out, nullptr))) return rc;
     HIP_TRY(c, hipDeviceSynchronize());
+    if (p || R) {                               // point counts of THIS chunk (retraction robots: rows are aligned at the tip)
+      hn.resize((size_t)m);
+      HIP_TRY(c, hipMemcpy(hn.data(), w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
     // device planes are [P][ld]; only the first m columns are copied (2-D copies, host pitch m)
     if (p) {
       hx.resize((size_t)P * m); hy.resize((size_t)P * m); hz.resize((size_t)P * m);
       HIP_TRY(c, hipMemcpy2D(hx.data(), (size_t)m * 8, w.px, (size_t)ld * 8, (size_t)m * 8, (size_t)P, hipMemcpyDeviceToHost));
       HIP_TRY(c, hipMemcpy2D(hy.data(), (size_t)m * 8, w.py, (size_t)ld * 8, (size_t)m * 8, (size_t)P, hipMemcpyDeviceToHost));
       HIP_TRY(c, hipMemcpy2D(hz.data(), (size_t)m * 8, w.pz, (size_t)ld * 8, (size_t)m * 8, (size_t)P, hipMemcpyDeviceToHost));
-      hn.resize((size_t)m);
-      HIP_TRY(c, hipMemcpy(hn.data(), w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < m; i++) {
         const int sh = P - hn[(size_t)i];               // device rows are aligned at the tip: point j is in row j + (P - n_points)
         for (int j = 0; j < P; j++) {
@@ -845,11 +852,7 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
     }
     if (R) {
       hR.resize((size_t)9 * P * m);
-      HIP_TRY(c, hipMemcpy2D(hR.data(), (size_t)m * 8, d_R, (size_t)ld * 8, (size_t)m * 8, (size_t)9 * P, hipMemcpyDeviceToHost));
-      if (hn.size() != (size_t)m) {
-        hn.resize((size_t)m);
-        HIP_TRY(c, hipMemcpy(hn.data(), w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
-      }
+      HIP_TRY(c, hipMemcpy2D(hR.data(), (size_t)m * 8, dR.p, (size_t)ld * 8, (size_t)m * 8, (size_t)9 * P, hipMemcpyDeviceToHost));
       for (int64_t i = 0; i < m; i++) {
         const int np_i = hn[(size_t)i], sh = P - np_i;
         for (int j = 0; j < P; j++)
@@ -866,7 +869,6 @@ int tr_fk_batch(tr_ctx *c, const double *states, int64_t n, double *p, double *R
     if (converged) HIP_TRY(c, hipMemcpy(converged + off, w.conv, (size_t)m, hipMemcpyDeviceToHost));
     if (n_points) HIP_TRY(c, hipMemcpy(n_points + off, w.npts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
   }
-  if (d_R) (void)hipFree(d_R);
   return TR_OK;
 }
 

@@ -209,7 +209,9 @@ class Engine:
         return dict(valid=unpack_bits(bits, n), last_valid_t=lvt, n_fk=nfk)
 
     def validate_edges_discrete(self, a, b, min_tension_change=0.02, min_rotation_change=0.01,
-                                min_retraction_change=0.0001):
+                                min_retraction_change=0.0001, last_valid=True):
+        """last_valid = True: checkMotion(s1, s2, last_valid) (the installed state checker judges every sample);
+        False: checkMotion(s1, s2) (shape validity + swept backbone volume); the two differ under the sphere checker only."""
         a, b = self._states(a), self._states(b)
         if a.shape != b.shape:
             raise L.InvalidArgument("start and end are different sizes")
@@ -219,9 +221,9 @@ class Engine:
         lvt = np.zeros(n)
         nfk = np.zeros(n, dtype=np.int32)
         L.check(self._ctx, self.lib.tr_validate_edges_discrete(
-            self._ctx, C.byref(sp), _dp(a), _dp(b), n, bits.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(lvt),
-            nfk.ctypes.data_as(C.POINTER(C.c_int32))))
-        return dict(valid=unpack_bits(bits, n), last_valid_t=lvt, n_fk=nfk)
+            self._ctx, C.byref(sp), _dp(a), _dp(b), n, bits.ctypes.data_as(C.POINTER(C.c_uint64)),
+            _dp(lvt) if last_valid else None, nfk.ctypes.data_as(C.POINTER(C.c_int32))))
+        return dict(valid=unpack_bits(bits, n), last_valid_t=lvt if last_valid else None, n_fk=nfk)
 
     def check_cached(self, block_ids, masks, offsets):
         ids = np.ascontiguousarray(block_ids, dtype=np.uint32)

@@ -61,13 +61,17 @@ class VoxelEnvironment:                    # motion-planning/VoxelEnvironment.h:
 class VoxelBackboneValidityChecker:
     """motion-planning/VoxelBackboneValidityChecker.h:28-58 over AbstractVoxelValidityChecker /
     AbstractValidityChecker.  `is_valid(states)` is AbstractValidityChecker::isValid
-    (AbstractValidityChecker.cpp:124-133) for a batch: one K1 + one K2 launch."""
+    (AbstractValidityChecker.cpp:124-133) for a batch: one K1 + one K2 launch.
+    Every checker owns its engine context -- robot constants as they are now, its own obstacle grid and
+    inv_rotation -- like the reference's checkers own their `_voxels` (AbstractVoxelValidityChecker.h:63-64): a
+    second checker on the same robot cannot replace this one's environment."""
 
     def __init__(self, robot: TendonRobot, venv: VoxelEnvironment, voxels: VoxelOctree, device=0):
+        from .engine import Engine
         self._robot, self._venv, self._voxels = robot, venv, voxels
         self._timers = {k: FunctionTimer() for k in
                         ("fk", "collision", "self_collision", "voxelize", "collision-without-voxelizing", "is_valid")}
-        self.engine = robot.engine(device)
+        self.engine = Engine(robot, device)
         # constructor check of VoxelBackboneValidityChecker.h:37-45 is enforced by tr_set_grid
         self.engine.set_grid(voxels.Nx(), voxels.limits(), voxels.blocks, venv.inv_rotation)
 
@@ -120,8 +124,7 @@ class VoxelBackboneValidityChecker:
 
 class VoxelValidityChecker(VoxelBackboneValidityChecker):
     """motion-planning/VoxelValidityChecker.h:18-26: the same chain, but the robot is voxelised as a sphere of
-    its radius at every backbone point (add_sphere) and tested against the raw, un-dilated environment.  Uses
-    its own engine context, so a backbone checker on the same robot is not affected."""
+    its radius at every backbone point (add_sphere) and tested against the raw, un-dilated environment."""
 
     def __init__(self, robot: TendonRobot, venv: VoxelEnvironment, voxels: VoxelOctree, device=0):
         from .engine import Engine
@@ -136,7 +139,10 @@ class VoxelValidityChecker(VoxelBackboneValidityChecker):
 class VoxelBackboneMotionValidator:
     """motion-planning/VoxelBackboneMotionValidator.{h,cpp} over AbstractVoxelMotionValidator:
     `check_motion(a, b)` is checkMotion(s1, s2) (AbstractVoxelMotionValidator.h:143-151) for a
-    batch of edges."""
+    batch of edges.  As in the reference (Problem.h:175-210 installs any state checker next to this validator),
+    check_motion sweeps the BACKBONE against the checker's voxels whichever checker it is, while
+    check_motion_last_valid asks the checker itself about every sample (`_vc->collides`,
+    VoxelBackboneMotionValidator.cpp:83-91) -- the sphere-swept robot for a VoxelValidityChecker."""
 
     def __init__(self, checker: VoxelBackboneValidityChecker, min_tension_change=0.02,
                  min_rotation_change=0.01, min_retraction_change=0.0001):
@@ -182,11 +188,11 @@ class VoxelBackboneDiscreteMotionValidator(VoxelBackboneMotionValidator):
     """motion-planning/VoxelBackboneDiscreteMotionValidator.{h,cpp}: the same interface, but an edge is
     sampled at a, interpolate(i / validSegmentCount), b instead of bisected adaptively."""
 
-    def check_motion_detail(self, a, b):
+    def check_motion_detail(self, a, b, last_valid=False):
         return self._timers["voxelize-swept-volume"].time(
             self.engine.validate_edges_discrete, a, b, self.min_tension_change, self.min_rotation_change,
-            self.min_retraction_change)
+            self.min_retraction_change, last_valid)
 
     def check_motion_last_valid(self, a, b):
-        d = self.check_motion_detail(a, b)
+        d = self.check_motion_detail(a, b, last_valid=True)
         return d["valid"], d["last_valid_t"]

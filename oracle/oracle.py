@@ -173,6 +173,10 @@ def _load(kind="strict"):
                                                    c_double_p, P(C.c_int), c_double_p]
     lib.orc_check_motion_discrete.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p, c_double_p,
                                               c_double_p, C.c_int, P(C.c_int), P(C.c_int), c_double_p]
+    lib.orc_check_motion_until_invalid_vc.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p, c_double_p,
+                                                      c_double_p, C.c_int, P(C.c_int), c_double_p]
+    lib.orc_check_motion_discrete_vc.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p, c_double_p,
+                                                 c_double_p, C.c_int, C.c_int, P(C.c_int), P(C.c_int), c_double_p]
     lib.orc_check_motion_batch.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p,
                                            c_double_p, c_double_p, C.c_long, P(C.c_uint8),
                                            P(C.c_int32), C.c_int]
@@ -471,21 +475,22 @@ def check_motion(robot, grid, a, b, sp=None, inv_rot=IDENTITY, want_swept=False)
                 last_valid_t=lvt.value, swept=swept)
 
 
-def check_motion_until_invalid(robot, grid, a, b, sp=None, inv_rot=IDENTITY):
+def check_motion_until_invalid(robot, grid, a, b, sp=None, inv_rot=IDENTITY, vc_spheres=False):
+    """vc_spheres: the installed state checker is VoxelValidityChecker (sphere-swept samples)."""
     sp = sp or space_params()
     a, b, inv_rot = _f64(a), _f64(b), _f64(inv_rot).reshape(9)
     nfk, lvt = C.c_int(0), C.c_double(0)
-    fully = robot.lib.orc_check_motion_until_invalid(C.byref(robot.c), C.byref(sp), grid.ptr, _dp(inv_rot), _dp(a), _dp(b),
-                                                     C.byref(nfk), C.byref(lvt))
+    fully = robot.lib.orc_check_motion_until_invalid_vc(C.byref(robot.c), C.byref(sp), grid.ptr, _dp(inv_rot), _dp(a), _dp(b),
+                                                        int(vc_spheres), C.byref(nfk), C.byref(lvt))
     return dict(is_fully_valid=bool(fully), last_valid_t=lvt.value, n_fk=nfk.value)
 
 
-def check_motion_discrete(robot, grid, a, b, sp=None, inv_rot=IDENTITY, until_invalid=False):
+def check_motion_discrete(robot, grid, a, b, sp=None, inv_rot=IDENTITY, until_invalid=False, vc_spheres=False):
     sp = sp or space_params()
     a, b, inv_rot = _f64(a), _f64(b), _f64(inv_rot).reshape(9)
     nfk, fully, lvt = C.c_int(0), C.c_int(0), C.c_double(0)
-    valid = robot.lib.orc_check_motion_discrete(C.byref(robot.c), C.byref(sp), grid.ptr, _dp(inv_rot), _dp(a), _dp(b),
-                                                int(until_invalid), C.byref(nfk), C.byref(fully), C.byref(lvt))
+    valid = robot.lib.orc_check_motion_discrete_vc(C.byref(robot.c), C.byref(sp), grid.ptr, _dp(inv_rot), _dp(a), _dp(b),
+                                                   int(until_invalid), int(vc_spheres), C.byref(nfk), C.byref(fully), C.byref(lvt))
     return dict(valid=bool(valid), is_fully_valid=bool(fully), last_valid_t=lvt.value, n_fk=nfk.value)
 
 

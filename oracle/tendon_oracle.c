@@ -1269,7 +1269,7 @@ typedef struct { double t; double *pts; int n; int is_valid; } fk_sample;
  * drives it (per-sample validity = is_valid_shape only; obstacles tested on the union) and
  * AbstractVoxelMotionValidator.h:143-151 (checkMotion). */
 static int check_motion_impl(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
-                             const double inv_rot[9], const double *a, const double *b, int until_invalid,
+                             const double inv_rot[9], const double *a, const double *b, int until_invalid, int vc_spheres,
                              orc_grid *swept, int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
   const int S = orc_state_size(rb);
   orc_grid *sample_vox = until_invalid ? orc_grid_empty_copy(obstacles) : NULL;
@@ -1293,9 +1293,11 @@ static int check_motion_impl(const orc_robot *rb, const orc_space_params *sp, co
     fks[nfk].pts = (double *)malloc(sizeof(double) * 3 * (size_t)fk.n); \
     memcpy(fks[nfk].pts, fk.p, sizeof(double) * 3 * (size_t)fk.n); \
     orc_rotate_points(inv_rot, fks[nfk].pts, fk.n); \
-    if (ok_ && until_invalid) { /* voxelize_until_invalid_impl: validity also needs !_vc->collides(shape) */ \
+    if (ok_ && until_invalid) { /* voxelize_until_invalid_impl: validity also needs !_vc->collides(shape), i.e. the \
+                                   installed state checker's own voxelize_impl (backbone, or a sphere per point) */ \
       orc_grid_clear(sample_vox); \
-      orc_grid_add_piecewise_line(sample_vox, fks[nfk].pts, fk.n); \
+      if (vc_spheres) { for (int j_ = 0; j_ < fk.n; j_++) orc_grid_add_sphere(sample_vox, fks[nfk].pts + 3 * j_, rb->r); } \
+      else orc_grid_add_piecewise_line(sample_vox, fks[nfk].pts, fk.n); \
       if (orc_grid_collides(obstacles, sample_vox)) { \
         ok_ = 0; fks[nfk].is_valid = 0; \
         if ((tt) < first_invalid_t) first_invalid_t = (tt); \
@@ -1376,7 +1378,7 @@ static int check_motion_impl(const orc_robot *rb, const orc_space_params *sp, co
 int orc_check_motion(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
                      const double inv_rot[9], const double *a, const double *b,
                      orc_grid *swept, int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
-  return check_motion_impl(rb, sp, obstacles, inv_rot, a, b, 0, swept, n_fk_out, is_fully_valid_out, last_valid_t_out);
+  return check_motion_impl(rb, sp, obstacles, inv_rot, a, b, 0, 0, swept, n_fk_out, is_fully_valid_out, last_valid_t_out);
 }
 
 /* checkMotion(s1, s2, last_valid) (AbstractVoxelMotionValidator.h:153-169) over voxelize_until_invalid
@@ -1386,7 +1388,18 @@ int orc_check_motion_until_invalid(const orc_robot *rb, const orc_space_params *
                                    const double inv_rot[9], const double *a, const double *b,
                                    int *n_fk_out, double *last_valid_t_out) {
   int fully = 0;
-  check_motion_impl(rb, sp, obstacles, inv_rot, a, b, 1, NULL, n_fk_out, &fully, last_valid_t_out);
+  check_motion_impl(rb, sp, obstacles, inv_rot, a, b, 1, 0, NULL, n_fk_out, &fully, last_valid_t_out);
+  return fully;
+}
+
+/* The same with motion_planning::VoxelValidityChecker installed as the state checker (Problem.h:175-180 next to
+ * :203-210): `_vc->collides(shape)` voxelises the shape as a sphere of the robot radius at every backbone point
+ * (VoxelValidityChecker.h:18-26). */
+int orc_check_motion_until_invalid_vc(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                                      const double inv_rot[9], const double *a, const double *b, int vc_spheres,
+                                      int *n_fk_out, double *last_valid_t_out) {
+  int fully = 0;
+  check_motion_impl(rb, sp, obstacles, inv_rot, a, b, 1, vc_spheres, NULL, n_fk_out, &fully, last_valid_t_out);
   return fully;
 }
 
@@ -1395,9 +1408,18 @@ int orc_check_motion_until_invalid(const orc_robot *rb, const orc_space_params *
  * is_valid_shape, obstacles tested on the union, checkMotion(s1, s2), .h:143-151); until_invalid = 1 is
  * voxelize_until_invalid_impl (per-sample validity also needs !collides(sample), .h:153-169).
  * Returns the checkMotion verdict; *last_valid_t = PartialVoxelization::t. */
+int orc_check_motion_discrete_vc(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                                 const double inv_rot[9], const double *a, const double *b, int until_invalid, int vc_spheres,
+                                 int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out);
 int orc_check_motion_discrete(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
                               const double inv_rot[9], const double *a, const double *b, int until_invalid,
                               int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
+  return orc_check_motion_discrete_vc(rb, sp, obstacles, inv_rot, a, b, until_invalid, 0, n_fk_out, is_fully_valid_out, last_valid_t_out);
+}
+/* vc_spheres: the installed state checker is VoxelValidityChecker (matters for until_invalid only, see above) */
+int orc_check_motion_discrete_vc(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                                 const double inv_rot[9], const double *a, const double *b, int until_invalid, int vc_spheres,
+                                 int *n_fk_out, int *is_fully_valid_out, double *last_valid_t_out) {
   const int S = orc_state_size(rb);
   const int cap = max_points(rb);
   orc_result fk, home; result_alloc(&fk, cap); result_alloc(&home, cap);
@@ -1413,7 +1435,9 @@ int orc_check_motion_discrete(const orc_robot *rb, const orc_space_params *sp, c
     orc_rotate_points(inv_rot, pts, fk.n); \
     (ok_out) = orc_is_valid_shape(rb, &fk, &home); \
     if ((ok_out) && until_invalid) { \
-      orc_grid_clear(one); orc_grid_add_piecewise_line(one, pts, fk.n); \
+      orc_grid_clear(one); \
+      if (vc_spheres) { for (int j_ = 0; j_ < fk.n; j_++) orc_grid_add_sphere(one, pts + 3 * j_, rb->r); } \
+      else orc_grid_add_piecewise_line(one, pts, fk.n); \
       if (orc_grid_collides(obstacles, one)) (ok_out) = 0; \
     } } while (0)
 

@@ -154,6 +154,15 @@ int  orc_check_motion_until_invalid(const orc_robot *rb, const orc_space_params 
 int  orc_check_motion_discrete(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
                                const double inv_rot[9], const double *a, const double *b, int until_invalid,
                                int *n_fk, int *is_fully_valid, double *last_valid_t);
+/* The last_valid forms with motion_planning::VoxelValidityChecker installed as the state checker (vc_spheres = 1):
+ * `_vc->collides(shape)` of voxelize_until_invalid_impl (VoxelBackboneMotionValidator.cpp:83-91) then voxelises a
+ * sphere of the robot radius at every backbone point (VoxelValidityChecker.h:18-26). */
+int  orc_check_motion_until_invalid_vc(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                                       const double inv_rot[9], const double *a, const double *b, int vc_spheres,
+                                       int *n_fk, double *last_valid_t);
+int  orc_check_motion_discrete_vc(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
+                                  const double inv_rot[9], const double *a, const double *b, int until_invalid, int vc_spheres,
+                                  int *n_fk, int *is_fully_valid, double *last_valid_t);
 int  orc_check_motion_batch(const orc_robot *rb, const orc_space_params *sp, const orc_grid *obstacles,
                             const double inv_rot[9], const double *a, const double *b, long n,
                             uint8_t *valid, int32_t *n_fk, int nthreads);

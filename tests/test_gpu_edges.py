@@ -113,7 +113,8 @@ def test_discrete_motion_validator_matches_oracle(irt, orc, helpers):
         mv = irt.VoxelBackboneDiscreteMotionValidator(chk)
         a, b = _edges(robot, irt, 160, seed=seed, step=step)
         b[:3] = a[:3]                                                 # nd = 0: a and b only
-        d = mv.check_motion_detail(a, b)
+        d = mv.check_motion_detail(a, b, last_valid=True)
+        assert np.array_equal(mv.check_motion(a, b), d["valid"])     # the two-argument form: same verdict under the backbone checker
         orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
         for i in range(len(a)):
             w0 = orc.check_motion_discrete(orb, og, a[i], b[i], until_invalid=False)
@@ -151,7 +152,7 @@ def test_small_sample_pool_gives_the_same_edge_results(irt):
         chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
         mv = irt.VoxelBackboneMotionValidator(chk)
         d, (v2, lvt) = mv.check_motion_detail(a, b), mv.check_motion_last_valid(a, b)
-        dd = irt.VoxelBackboneDiscreteMotionValidator(chk).check_motion_detail(a[:60], b[:60])
+        dd = irt.VoxelBackboneDiscreteMotionValidator(chk).check_motion_detail(a[:60], b[:60], last_valid=True)
         ec = chk.engine.voxelize_edges(a[:200], b[:200])
         return d, v2, lvt, dd, ec
 

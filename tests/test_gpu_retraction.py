@@ -101,7 +101,7 @@ def test_discrete_edges_and_last_valid_with_retraction(irt, orc, helpers):
     b[:, :3] = np.clip(b[:, :3], 0, 20)
     b[:, 3] = np.clip(b[:, 3], 0, 0.2)
     orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
-    d = irt.VoxelBackboneDiscreteMotionValidator(chk).check_motion_detail(a, b)
+    d = irt.VoxelBackboneDiscreteMotionValidator(chk).check_motion_detail(a, b, last_valid=True)
     valid, lvt = irt.VoxelBackboneMotionValidator(chk).check_motion_last_valid(a, b)
     for i in range(len(a)):
         w = orc.check_motion_discrete(orb, og, a[i], b[i], until_invalid=True)

@@ -95,3 +95,69 @@ def test_sphere_checker_with_retraction(irt, orc, helpers):
     assert np.array_equal(got["valid"], [w[0] for w in want])
     assert np.array_equal(got["flags"] & 15, [w[2] for w in want])
     assert 0.1 < np.mean([w[0] for w in want]) < 0.97
+
+
+def _edge_pairs(irt, robot, n, seed, step):
+    rng = np.random.default_rng(seed)
+    a = irt.workloads.random_states(robot, n, seed=seed, tau_max=12.0)
+    d = rng.normal(size=a.shape)
+    d *= step / np.linalg.norm(d, axis=1, keepdims=True)
+    b = np.clip(a + d, 0.0, 19.9)
+    return a, b
+
+
+def test_motion_validators_next_to_the_sphere_checker(irt, orc, helpers):
+    """Problem.h:175-210 installs VoxelValidityChecker next to VoxelBackboneMotionValidator: checkMotion(s1, s2)
+    keeps sweeping the backbone against the same voxels (AbstractVoxelMotionValidator.h:143-151), while
+    checkMotion(s1, s2, last_valid) asks the installed checker about every sample (`_vc->collides`,
+    VoxelBackboneMotionValidator.cpp:83-91) -- the sphere-swept robot.  Both against the oracle's restatement."""
+    robot = irt.workloads.robot_config2()
+    vox = _env(irt, 21, 90)
+    chk = irt.VoxelValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    a, b = _edge_pairs(irt, robot, 96, seed=9, step=1.2)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    two = mv.check_motion_detail(a, b)
+    valid3, lvt = mv.check_motion_last_valid(a, b)
+    dm = irt.VoxelBackboneDiscreteMotionValidator(chk)
+    d2 = dm.check_motion_detail(a, b, last_valid=False)
+    d3 = dm.check_motion_detail(a, b, last_valid=True)
+    n_diff = 0
+    for i in range(len(a)):
+        w2 = orc.check_motion(orb, og, a[i], b[i])
+        assert two["valid"][i] == w2["valid"] and (not w2["valid"] or two["n_fk"][i] == w2["n_fk"]), i
+        w3 = orc.check_motion_until_invalid(orb, og, a[i], b[i], vc_spheres=True)
+        assert valid3[i] == w3["is_fully_valid"] and lvt[i] == w3["last_valid_t"], (i, lvt[i], w3)
+        wd2 = orc.check_motion_discrete(orb, og, a[i], b[i], until_invalid=False)
+        wd3 = orc.check_motion_discrete(orb, og, a[i], b[i], until_invalid=True, vc_spheres=True)
+        assert d2["valid"][i] == wd2["valid"], i
+        assert d3["valid"][i] == wd3["is_fully_valid"] and d3["last_valid_t"][i] == wd3["last_valid_t"] and d3["n_fk"][i] == wd3["n_fk"], (i, wd3)
+        n_diff += int(w2["valid"] != w3["is_fully_valid"])
+    assert n_diff > 3 and 0 < valid3.sum() < len(a)       # the two forms really differ under this checker
+
+
+def test_two_checkers_on_one_robot_keep_their_own_environment(irt, orc, helpers):
+    """Each checker owns its obstacle set (AbstractVoxelValidityChecker.h:63-64): building a second checker on the
+    same robot, with other obstacles and another rotation, must not change what the first one tests against."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    voxA, _ = W.reach_environment(seed=7, n_spheres=48)
+    voxB, _ = W.reach_environment(seed=8, n_spheres=80)
+    envB = irt.VoxelEnvironment()
+    envB.inv_rotation = np.array([[0.0, -1.0, 0], [1.0, 0, 0], [0, 0, 1.0]])
+    states = W.random_states(robot, 2000, seed=77, tau_max=14.0)
+    chkA = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), voxA)
+    before = chkA.is_valid(states)
+    mvA = irt.VoxelBackboneMotionValidator(chkA)
+    a, b = _edge_pairs(irt, robot, 200, seed=3, step=1.0)
+    eA = mvA.check_motion(a, b)
+    chkB = irt.VoxelBackboneValidityChecker(robot, envB, voxB)
+    robot.r = 0.02                                            # a later edit of the robot reaches only checkers built after it
+    gotB = chkB.is_valid(states)
+    assert chkA.engine is not chkB.engine
+    assert np.array_equal(chkA.is_valid(states), before) and np.array_equal(mvA.check_motion(a, b), eA)
+    robot.r = 0.015
+    orb = helpers.oracle_robot(orc, robot, lib="omp")
+    wantA, _, _ = orc.validate_batch(orb, helpers.oracle_grid(orc, voxA), states, nthreads=0, lib=orc.omp_lib())
+    wantB, _, _ = orc.validate_batch(orb, helpers.oracle_grid(orc, voxB), states, envB.inv_rotation, nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(before, wantA) and np.array_equal(gotB, wantB) and (wantA != wantB).sum() > 50

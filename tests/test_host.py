@@ -234,7 +234,8 @@ def test_bench_spawns_its_own_ranks_and_relays_failure():
     import torch
     if not torch.cuda.is_available():
         assert p.returncode != 0
-        assert p.stderr.count("needs a GPU") + p.stderr.count("GPU(s)") == 2, p.stderr[-2000:]
+        # (the parent terminates the surviving rank as soon as one has failed, so one or two messages arrive)
+        assert 1 <= p.stderr.count("needs a GPU") + p.stderr.count("GPU(s)") <= 2, p.stderr[-2000:]
 
 
 def test_pack_bits_roundtrip(irt):
