@@ -22,7 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--vertices", type=int, default=100000)
     ap.add_argument("--k", type=int, default=10)
-    ap.add_argument("--queries", type=int, default=200)
+    ap.add_argument("--queries", type=int, default=10000)
+    ap.add_argument("--no-cpu", action="store_true", help="skip the sequential CPU port of the query loop")
     ap.add_argument("--cache-items", type=int, default=200000)
     args = ap.parse_args()
     irt = importlib.import_module("interactive-rate-tendons_amd")
@@ -111,26 +112,67 @@ def main():
         "vertex_hit_fraction": float(vh.mean()), "edge_hit_fraction": float(eh.mean()),
         "note": "host API: includes set_grid (2 MiB upload + dilation) and CSR upload every call",
     }
-    # config 5 queries: the whole roadmap is re-validated against the changed environment on the device (K4 on
-    # every cached vertex and edge set), then each (start, goal) query is a host graph search over the
-    # surviving edges -- what VoxelCachedLazyPRM::solveWithRoadmap's lazy A* reduces to once validity is known.
-    from scipy.sparse import csr_matrix
-    from scipy.sparse.csgraph import dijkstra
+    # config 5 queries: VoxelCachedLazyPRM::solveWithRoadmap for a batch of (start, goal) pairs on the cached roadmap in
+    # the changed environment (tr_roadmap_*): lazy = validity discovered per round for the candidate paths only (one K4
+    # launch per round over all queries' unknown items); eager = one K4 pass over every cached set, then pure graph search
     nq = args.queries
-    ok_v = np.ones(len(states), dtype=bool); ok_v[:nv] = ~vh
-    ok_e = valid.copy(); ok_e[:ne] &= ~eh
-    keep = ok_e & ok_v[edges[:, 0]] & ok_v[edges[:, 1]]
-    wgt = np.linalg.norm(states[edges[keep, 0]] - states[edges[keep, 1]], axis=1)
-    gph = csr_matrix((wgt, (edges[keep, 0], edges[keep, 1])), shape=(len(states),) * 2)
-    rngq = np.random.default_rng(17)
-    pairs = rngq.choice(np.flatnonzero(ok_v), size=(nq, 2))
+    e_ok = edges[valid]                                         # createRoadmap removes invalid edges (:1543-1551)
+    vc_all = vc if nv == len(states) else rb.vertex_caches(states)
+    ec_all = rb.edge_caches(states, e_ok)
+    chk.engine.set_grid(vox.Nx(), vox.limits(), vox.blocks)
+    prm = irt.VoxelCachedLazyPRM(chk, states, e_ok)
     t0 = time.perf_counter()
-    dist = dijkstra(gph, directed=False, indices=pairs[:, 0])
-    t_q = time.perf_counter() - t0
-    reach = np.isfinite(dist[np.arange(nq), pairs[:, 1]])
-    out["config5"]["queries"] = {"n": nq, "host_graph_search_queries_per_s": nq / t_q, "reachable_fraction": float(reach.mean()),
-                                 "roadmap_revalidation_ms_device": 1e3 * t_dev,
-                                 "note": "scipy Dijkstra per start vertex on the host; the GPU part of a query batch is the one re-validation"}
+    prm.set_caches(vc_all, ec_all)
+    t_upload = time.perf_counter() - t0
+    rngq = np.random.default_rng(17)
+    pairs = rngq.integers(0, len(states), size=(nq, 2))
+    prm.set_obstacles(new_vox)
+    prm.solveWithRoadmap(pairs[:64, 0], pairs[:64, 1])          # warm-up: thread scratch, device lists
+    prm.clearValidity()
+    chk.engine.profile_begin()
+    t0 = time.perf_counter()
+    lazy = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    t_lazy = time.perf_counter() - t0
+    st_lazy = dict(prm.stats)
+    k4l = chk.engine.profile_read()["cached_blocks_vs_grid"]
+    chk.engine.profile_end()
+    prm.clearValidity()
+    t0 = time.perf_counter()
+    n_bad_v, n_bad_e = prm.revalidate()
+    t_reval = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eager = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    t_eager = time.perf_counter() - t0
+    st_eager = dict(prm.stats)
+    assert np.array_equal(lazy["status"], eager["status"]) and np.array_equal(lazy["cost"], eager["cost"])
+    plen = np.diff(lazy["path_offsets"])[lazy["status"] == 0]
+    q5 = {"n": nq, "roadmap_vertices": len(states), "roadmap_edges": int(len(e_ok)), "cache_blocks": int(vc_all["offsets"][-1] + ec_all["offsets"][-1]),
+          "cache_upload_s": t_upload,
+          "lazy": {"queries_per_s": nq / t_lazy, "seconds": t_lazy, **st_lazy, "k4_launches": k4l["launches"], "k4_ms_total": k4l["total_ms"]},
+          "eager": {"queries_per_s_incl_revalidation": nq / (t_eager + t_reval), "revalidate_all_ms": 1e3 * t_reval,
+                    "items_per_s_revalidation": (len(states) + len(e_ok)) / t_reval, "search_seconds": t_eager, **st_eager,
+                    "invalid_vertices": n_bad_v, "invalid_edges": n_bad_e},
+          "solved_fraction": float((lazy["status"] == 0).mean()), "no_path": int((lazy["status"] == 1).sum()),
+          "invalid_endpoint": int((lazy["status"] >= 2).sum()),
+          "path_vertices": {"mean": float(plen.mean()) if len(plen) else 0.0, "max": int(plen.max()) if len(plen) else 0}}
+    if not args.no_cpu:
+        # the oracle's sequential restatement of the same loop (one query at a time, cached-set test on the host) on a bounded sample
+        from oracle import oracle as orc
+        s_ = robot.specs
+        orb = orc.Robot([t_.C for t_ in robot.tendons], [t_.D for t_ in robot.tendons], r=robot.r, L=s_.L, dL=s_.dL, ro=s_.ro, ri=s_.ri,
+                        E=s_.E, nu=s_.nu, max_tension=[t_.max_tension for t_ in robot.tendons],
+                        min_length=[t_.min_length for t_ in robot.tendons], max_length=[t_.max_length for t_ in robot.tendons], lib="omp")
+        og = orc.Grid(new_vox.Nx(), new_vox.limits(), lib="omp")
+        og.blocks()[...] = new_vox.blocks
+        orm = orc.Roadmap(orb, states, e_ok, None, vc_all, ec_all, lib=orc.omp_lib())
+        m, t0, agree = 0, time.perf_counter(), True
+        while m < nq and time.perf_counter() - t0 < 15.0:
+            w_ = orm.query(og, pairs[m, 0], pairs[m, 1])
+            agree &= (w_["n"] > 0) == (lazy["status"][m] == 0) and (w_["n"] <= 0 or (w_["cost"] == lazy["cost"][m] and np.array_equal(w_["path"], lazy["paths"][m])))
+            m += 1
+        q5["cpu_sequential_port"] = {"queries_per_s": m / (time.perf_counter() - t0), "sample": "first %d queries, 1 thread" % m,
+                                     "paths_equal_gpu_batch": bool(agree)}
+    out["config5"]["queries"] = q5
     # config 1 shape: FK only, 3-tendon linear-routed robot (P = 41), small and large batches
     r1 = W.robot_config1()
     e1 = r1.engine(0)

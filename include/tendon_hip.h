@@ -255,6 +255,14 @@ int tr_check_cached(tr_ctx *ctx, const uint32_t *block_ids, const uint64_t *mask
 int tr_check_cached_dev(tr_ctx *ctx, const uint32_t *d_block_ids, const uint64_t *d_masks,
                         const int64_t *d_offsets, int64_t n_items, uint64_t *d_hit_bits, void *stream);
 
+/* The same test for a SUBSET of the items: d_list[q] names an item, d_hit[q] (one byte) receives its verdict.
+ * The lazy query loop (tr_roadmap_solve) validates the unknown items of all candidate paths of a round with one
+ * launch of this -- the batched form of computeVertexValidity / computeEdgeValidity on cached sets
+ * (motion-planning/VoxelCachedLazyPRM.cpp:2607-2631). */
+int tr_check_cached_subset_dev(tr_ctx *ctx, const uint32_t *d_block_ids, const uint64_t *d_masks,
+                               const int64_t *d_offsets, int64_t n_items, const int32_t *d_list, int64_t n_list,
+                               uint8_t *d_hit, void *stream);
+
 /* ---- robot voxel sets for roadmap caches: voxelizeVertex / voxelizeEdge -------------------------- */
 
 /* Batched VoxelCachedLazyPRM::voxelizeVertex (motion-planning/VoxelCachedLazyPRM.cpp:2803-2837),
@@ -288,6 +296,62 @@ int tr_voxelize_fetch(tr_ctx *ctx, uint32_t *block_ids, uint64_t *masks, int64_t
  * idx, dist: n x k row-major, ascending distance.  Exact (brute force). */
 int tr_knn(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_distance,
            int32_t *idx, double *dist);
+
+/* Layout and metric of the state space built by motion_planning::Problem::create_space_information
+ * (motion-planning/Problem.cpp:101-163): number of tension dimensions, whether a rotation / retraction coordinate
+ * follows, and the weights of those two subspaces in CompoundStateSpace::distance (tension weight 1). */
+int tr_state_layout(const tr_ctx *ctx, int32_t *n_tendons, int32_t *has_rotation, int32_t *has_retraction);
+int tr_space_weights(const tr_ctx *ctx, double *w_rotation, double *w_retraction);
+
+/* ---- interactive queries on a cached roadmap (BASELINE config 5) -------------------------------------
+ * motion_planning::VoxelCachedLazyPRM::solveWithRoadmap / constructSolution
+ * (motion-planning/VoxelCachedLazyPRM.cpp:1977-2096, :2689-2771) for a BATCH of (start, goal) vertex pairs:
+ * A* with the state-space distance as heuristic (astarSearch :2950-2976, costHeuristic :2773-2775) on the host
+ * cores, validity of the candidate paths' vertices and edges from their cached voxel sets -- resident in HBM --
+ * with one K4 launch per round over all queries' unknown items (computeVertexValidity / computeEdgeValidity
+ * :2607-2631), invalid items leave the graph (removeVertices / removeEdge), repeat until every query has a valid
+ * path or its start and goal are disconnected.  Accepted paths equal the reference's (equal cost; equal vertex
+ * sequence unless two paths tie exactly).  The roadmap object borrows `ctx` (obstacle grid, device) and must be
+ * destroyed before it. */
+typedef struct tr_roadmap tr_roadmap;
+typedef struct {
+  int64_t rounds;          /* search / validate rounds of the last solve                        */
+  int64_t items_checked;   /* cached sets tested against the obstacle grid (K4 work)            */
+  int64_t astar_runs;      /* A* searches (>= queries: a query searches again after removals)    */
+  int64_t expanded;        /* vertices taken off the open lists                                  */
+} tr_roadmap_stats;
+#define TR_QUERY_SOLVED        0
+#define TR_QUERY_NO_PATH       1   /* start and goal are in different components (solveWithRoadmap :2026-2036) */
+#define TR_QUERY_INVALID_START 2   /* ob::PlannerStatus::INVALID_START (solvePrep :2995-2998)                  */
+#define TR_QUERY_INVALID_GOAL  3
+/* Graph of a loaded roadmap (fromRoadmapParser :2357-2580): n_vertices x S states, n_edges index pairs,
+ * edge weights (weightProperty_; NULL = state-space distance, what connectVertices stores :2857-2861). */
+int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, const int32_t *edges,
+                      const double *weights, int64_t n_edges, tr_roadmap **out);
+void tr_roadmap_destroy(tr_roadmap *rm);
+const char *tr_roadmap_last_error(const tr_roadmap *rm);
+/* Upload the cached voxel sets (vertexVoxelsProperty_ / edgeVoxelsProperty_) as CSR block lists -- the output of
+ * tr_voxelize_batch / tr_voxelize_edges* or of a .rmp file.  present bits (optional): a 0 bit = no cache, because
+ * voxelizeVertex / voxelizeEdge found the shape invalid (:2803-2837, :2879-2902): such an item is invalid in every
+ * environment. */
+int tr_roadmap_set_caches(tr_roadmap *rm, const int64_t *v_offsets, const uint32_t *v_block_ids, const uint64_t *v_masks,
+                          const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *e_block_ids,
+                          const uint64_t *e_masks, const uint64_t *e_present_bits);
+/* clearValidity (:1656-1663): everything unknown again, removed items back in the graph -- call it after the
+ * obstacle grid of `ctx` changed (tr_set_grid / tr_grid_*). */
+int tr_roadmap_clear_validity(tr_roadmap *rm);
+/* Eager form of the loading loops (:2397-2411, :2486-2526): every cached set against the current grid in one K4
+ * launch; afterwards no query finds an unknown item. */
+int tr_roadmap_revalidate(tr_roadmap *rm, int64_t *n_invalid_vertices, int64_t *n_invalid_edges);
+/* status per item: 0 unknown, 1 valid, 2 invalid (removed) */
+int tr_roadmap_get_validity(tr_roadmap *rm, uint8_t *vertex_status /*[n_vertices]*/, uint8_t *edge_status /*[n_edges]*/);
+/* The batched query loop.  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
+ * query q's path (start ... goal) is entries path_offsets[q] .. path_offsets[q+1]-1 of the array
+ * tr_roadmap_fetch_paths copies out.  n_threads = host threads for the A* searches (0 = the process's CPU share).
+ * Validity discovered by a call is kept for the next one (as the reference's graph keeps it between queries). */
+int tr_roadmap_solve(tr_roadmap *rm, const int32_t *starts, const int32_t *goals, int64_t n_queries, int32_t n_threads,
+                     int32_t *status, double *cost, int64_t *path_offsets, tr_roadmap_stats *stats);
+int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capacity);
 
 /* ---- instrumentation ---------------------------------------------------------------------- */
 

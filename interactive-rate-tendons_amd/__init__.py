@@ -17,11 +17,11 @@ from .collision import VoxelOctree
 from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelValidityChecker, VoxelBackboneMotionValidator,
                               VoxelBackboneDiscreteMotionValidator, FunctionTimer)
 from . import workloads, distributed, roadmap, rmp, tip_control
-from .roadmap import RoadmapBuilder
+from .roadmap import RoadmapBuilder, VoxelCachedLazyPRM
 
 __all__ = [
     "TendonHipError", "InvalidArgument", "OutOfRange", "DomainError", "LengthError", "HipError", "Unsupported",
     "build", "LIB_PATH", "Engine", "unpack_bits", "BackboneSpecs", "TendonSpecs", "TendonResult", "TendonRobot",
     "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelValidityChecker", "VoxelBackboneMotionValidator", "VoxelBackboneDiscreteMotionValidator",
-    "FunctionTimer", "workloads", "distributed", "roadmap", "RoadmapBuilder", "tip_control",
+    "FunctionTimer", "workloads", "distributed", "roadmap", "RoadmapBuilder", "VoxelCachedLazyPRM", "tip_control",
 ]

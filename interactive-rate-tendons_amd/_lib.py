@@ -30,7 +30,9 @@ ABI_SYMBOLS = (
     "tr_validate_shapes_retraction_dev",
     "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_indexed", "tr_validate_edges_last_valid",
     "tr_validate_edges_discrete",
-    "tr_check_cached", "tr_check_cached_dev", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_knn", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
+    "tr_check_cached", "tr_check_cached_dev", "tr_check_cached_subset_dev", "tr_state_layout", "tr_space_weights",
+    "tr_roadmap_create", "tr_roadmap_destroy", "tr_roadmap_last_error", "tr_roadmap_set_caches", "tr_roadmap_clear_validity",
+    "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_fetch", "tr_knn", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug",
 )
 
@@ -52,6 +54,13 @@ class TrRobotDesc(C.Structure):
 class TrSpaceParams(C.Structure):
     _fields_ = [("min_tension_change", C.c_double), ("min_rotation_change", C.c_double),
                 ("min_retraction_change", C.c_double)]
+
+
+class TrRoadmapStats(C.Structure):
+    _fields_ = [("rounds", C.c_int64), ("items_checked", C.c_int64), ("astar_runs", C.c_int64), ("expanded", C.c_int64)]
+
+
+TR_QUERY_SOLVED, TR_QUERY_NO_PATH, TR_QUERY_INVALID_START, TR_QUERY_INVALID_GOAL = range(4)
 
 
 class TendonHipError(RuntimeError):
@@ -98,10 +107,11 @@ def _units():
     (tendon count, kernel: shared grid / retraction / fused with K2) so its 64 instantiations compile in parallel."""
     fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "sweep_kernel.hpp",
                "tr_types.hpp"]
-    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip"]
+    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip"]
     main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
     u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),
-         ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"])]
+         ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"]),
+         ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", HEADER])]
     for n in range(1, 9):
         for kind, tag in ((0, "u"), (1, "r"), (2, "f")):
             u.append(("fk_%s%d.o" % (tag, n), "fk_inst.hip", ["-DTRK_INST_N=%d" % n, "-DTRK_INST_KIND=%d" % kind], fk_deps))
@@ -150,7 +160,7 @@ def build(force=False, verbose=False, jobs=None):
         p.wait()
     if failed is not None:
         raise subprocess.CalledProcessError(1, failed)
-    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_PATH] + \
+    link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB_PATH] + \
            [os.path.join(OBJ_DIR, u[0]) for u in _units()]
     if verbose:
         print(" ".join(link), flush=True)
@@ -207,6 +217,21 @@ def lib():
     L.tr_validate_edges_discrete.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(C.c_uint64), dp, P(C.c_int32)]
     L.tr_check_cached.argtypes = [vp, P(C.c_uint32), P(C.c_uint64), P(i64), i64, P(C.c_uint64)]
     L.tr_check_cached_dev.argtypes = [vp, vp, vp, vp, i64, vp, vp]
+    L.tr_check_cached_subset_dev.argtypes = [vp, vp, vp, vp, i64, vp, i64, vp, vp]
+    L.tr_state_layout.argtypes = [vp, P(C.c_int32), P(C.c_int32), P(C.c_int32)]
+    L.tr_space_weights.argtypes = [vp, dp, dp]
+    L.tr_roadmap_create.argtypes = [vp, dp, i64, P(C.c_int32), dp, i64, P(vp)]
+    L.tr_roadmap_destroy.argtypes = [vp]
+    L.tr_roadmap_destroy.restype = None
+    L.tr_roadmap_last_error.argtypes = [vp]
+    L.tr_roadmap_last_error.restype = C.c_char_p
+    L.tr_roadmap_set_caches.argtypes = [vp, P(i64), P(C.c_uint32), P(C.c_uint64), P(C.c_uint64), P(i64), P(C.c_uint32),
+                                        P(C.c_uint64), P(C.c_uint64)]
+    L.tr_roadmap_clear_validity.argtypes = [vp]
+    L.tr_roadmap_revalidate.argtypes = [vp, P(i64), P(i64)]
+    L.tr_roadmap_get_validity.argtypes = [vp, P(C.c_uint8), P(C.c_uint8)]
+    L.tr_roadmap_solve.argtypes = [vp, P(C.c_int32), P(C.c_int32), i64, C.c_int32, P(C.c_int32), dp, P(i64), P(TrRoadmapStats)]
+    L.tr_roadmap_fetch_paths.argtypes = [vp, P(C.c_int32), i64]
     L.tr_voxelize_batch.argtypes = [vp, dp, i64, P(i64), P(C.c_uint64), dp]
     L.tr_voxelize_edges.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(i64), P(C.c_uint64), P(C.c_int32)]
     L.tr_voxelize_fetch.argtypes = [vp, P(C.c_uint32), P(C.c_uint64), i64]

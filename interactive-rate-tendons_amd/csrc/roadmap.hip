@@ -1,0 +1,467 @@
+// roadmap.hip -- tr_roadmap_*: the interactive query loop of motion_planning::VoxelCachedLazyPRM on a cached
+// roadmap (BASELINE config 5): solveWithRoadmap / constructSolution
+// (motion-planning/VoxelCachedLazyPRM.cpp:1977-2096, :2689-2771), astarSearch (:2950-2976),
+// computeVertexValidity / computeEdgeValidity on cached voxel sets (:2607-2631), clearValidity (:1656-1663).
+//
+// The reference answers one (start, goal) pair at a time: A* over the Boost graph, then every interior vertex of the
+// candidate path is tested (cached voxel set AND obstacle octree), ALL invalid ones are removed, else the path's edges are
+// tested from the goal side and the FIRST invalid one is removed; repeat until a path survives or start and goal fall
+// into different components.  Each test is a tiny octree intersection -- latency-bound on the CPU and far too small for a
+// GPU launch of its own.  Here a whole batch of queries advances in rounds:
+//   round = [A* for every unresolved query, in parallel on the host cores, on the graph minus what is known invalid]
+//           -> the union of the still-unknown vertices and edges on all candidate paths -> ONE K4 launch on that subset
+//              (cached_subset_vs_grid; the caches live in HBM as one CSR) -> validity recorded, invalid items leave the graph
+//   queries whose candidate path turned out all valid are done; the others search again next round.
+// tr_roadmap_revalidate is the eager form: one K4 pass over every cached set (well under a millisecond for 10^5..10^6
+// items), after which every query resolves in its first round.
+// Returned paths are the reference's: a path is accepted only when all its items are valid, and it is the shortest path
+// of the graph minus the invalid items discovered so far -- which, all of its own items being valid, is also the
+// shortest path of the graph minus ALL invalid items, whatever subset has been discovered (equal costs; equal vertex
+// sequences unless two paths tie exactly).  What differs is bookkeeping only: every unknown edge of a vertex-clean path
+// is tested in the round (the reference stops at the first invalid one), so the set of DISCOVERED invalid edges is a superset.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/tendon_hip.h"
+
+namespace {
+
+enum : uint8_t { V_UNKNOWN = 0, V_VALID = 1, V_INVALID = 2 };   // VALIDITY_UNKNOWN / VALIDITY_TRUE / removed from the graph
+
+int host_threads(int want) {
+  if (want > 0) return want;
+  unsigned n = std::thread::hardware_concurrency();
+  cpu_set_t set;
+  if (sched_getaffinity(0, sizeof(set), &set) == 0) n = (unsigned)CPU_COUNT(&set);
+  if (FILE *f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {          // a container's CPU quota
+    long long quota = 0, period = 0;
+    char q[32] = {0};
+    if (std::fscanf(f, "%31s %lld", q, &period) == 2 && std::strcmp(q, "max") != 0 && period > 0) {
+      quota = std::atoll(q);
+      if (quota > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, quota / period));
+    }
+    std::fclose(f);
+  }
+  return (int)std::max(1u, std::min(n, 64u));
+}
+
+struct Scratch {                       // per host thread, reused across queries: generation-stamped A* state
+  std::vector<double> g;
+  std::vector<int32_t> parent, parent_edge;
+  std::vector<uint32_t> stamp;
+  std::vector<uint8_t> closed;
+  std::vector<std::pair<double, int32_t>> heap;
+  uint32_t gen = 0;
+};
+
+}  // namespace
+
+struct tr_roadmap {
+  std::mutex mu;
+  tr_ctx *ctx = nullptr;
+  std::string err;
+  int S = 0, NT = 0;
+  bool rot = false, ret = false;
+  double w_rot = 0, w_ret = 0;
+  int64_t V = 0, E = 0;
+  std::vector<double> states;
+  std::vector<int32_t> eu, ev;
+  std::vector<double> w;
+  std::vector<int64_t> adj_off;        // CSR adjacency, both directions
+  std::vector<int32_t> adj_v, adj_e;
+  std::vector<uint8_t> vstat, estat;   // V_*
+  std::vector<uint8_t> vpresent, epresent;
+  // cached voxel sets in HBM: one CSR, items [0, V) = vertices, [V, V + E) = edges
+  bool has_caches = false;
+  uint32_t *d_ids = nullptr; uint64_t *d_masks = nullptr; int64_t *d_off = nullptr;
+  int32_t *d_list = nullptr; uint8_t *d_hit = nullptr; uint64_t *d_bits = nullptr;
+  int64_t list_cap = 0;
+  int64_t nnz = 0;
+  // results of the last tr_roadmap_solve
+  std::vector<int64_t> path_off;
+  std::vector<int32_t> path_v;
+  // statistics of the last solve
+  int64_t st_rounds = 0, st_items_checked = 0, st_astar_runs = 0, st_expanded = 0;
+  std::vector<Scratch> scratch;
+};
+
+namespace {
+
+int rfail(tr_roadmap *r, int code, const std::string &m) { if (r) r->err = m; return code; }
+
+#define RM_HIP(r, expr)                                                                      \
+  do {                                                                                       \
+    hipError_t e_ = (expr);                                                                  \
+    if (e_ != hipSuccess) return rfail(r, TR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+// CompoundStateSpace::distance with the subspace weights of motion-planning/Problem.cpp:112-152
+inline double state_distance(const tr_roadmap *r, const double *a, const double *b) {
+  double s = 0;
+  for (int i = 0; i < r->NT; i++) { const double d = a[i] - b[i]; s += d * d; }
+  double dist = std::sqrt(s);
+  int k = r->NT;
+  if (r->rot) {
+    double d = std::fabs(a[k] - b[k]);
+    d = (d > M_PI) ? 2.0 * M_PI - d : d;
+    dist += r->w_rot * d;
+    k++;
+  }
+  if (r->ret) { const double d = a[k] - b[k]; dist += r->w_ret * std::sqrt(d * d); }
+  return dist;
+}
+
+// astarSearch (:2950-2976): A* with the state-space distance to the goal as heuristic (costHeuristic :2773-2775 ->
+// motionCostHeuristic), edge weights as given; stops when the goal is taken off the open list (AStarGoalVisitor).
+// Vertices / edges known invalid are not part of the graph (the reference has removed them).  Returns false when the
+// goal cannot be reached.  path: goal ... start (vertex ids), path_e: the edges between them.
+bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::vector<int32_t> &path, std::vector<int32_t> &path_e,
+           int64_t &expanded) {
+  if (sc.stamp.size() != (size_t)r->V) {
+    sc.g.assign((size_t)r->V, 0.0); sc.parent.assign((size_t)r->V, -1); sc.parent_edge.assign((size_t)r->V, -1);
+    sc.stamp.assign((size_t)r->V, 0u); sc.closed.assign((size_t)r->V, 0); sc.gen = 0;
+  }
+  if (++sc.gen == 0) { std::fill(sc.stamp.begin(), sc.stamp.end(), 0u); sc.gen = 1; }
+  const uint32_t gen = sc.gen;
+  auto &heap = sc.heap;
+  heap.clear();
+  const double *sg = &r->states[(size_t)goal * r->S];
+  auto cmp = [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; };
+  sc.stamp[start] = gen; sc.g[start] = 0.0; sc.parent[start] = start; sc.parent_edge[start] = -1; sc.closed[start] = 0;
+  heap.emplace_back(state_distance(r, &r->states[(size_t)start * r->S], sg), start);
+  bool found = false;
+  while (!heap.empty()) {
+    std::pop_heap(heap.begin(), heap.end(), cmp);
+    const int32_t u = heap.back().second;
+    heap.pop_back();
+    if (sc.closed[u]) continue;                 // a stale entry of a vertex already expanded with a better cost
+    sc.closed[u] = 1;
+    expanded++;
+    if (u == goal) { found = true; break; }
+    const double gu = sc.g[u];
+    for (int64_t k = r->adj_off[u]; k < r->adj_off[u + 1]; k++) {
+      const int32_t e = r->adj_e[k], v = r->adj_v[k];
+      if (r->estat[e] == V_INVALID || r->vstat[v] == V_INVALID) continue;
+      const double gv = gu + r->w[e];
+      if (sc.stamp[v] != gen) { sc.stamp[v] = gen; sc.closed[v] = 0; }
+      else if (sc.closed[v] || !(gv < sc.g[v])) continue;
+      sc.g[v] = gv; sc.parent[v] = u; sc.parent_edge[v] = e;
+      heap.emplace_back(gv + state_distance(r, &r->states[(size_t)v * r->S], sg), v);
+      std::push_heap(heap.begin(), heap.end(), cmp);
+    }
+  }
+  if (!found) return false;
+  path.clear(); path_e.clear();
+  for (int32_t v = goal;; v = sc.parent[v]) {
+    path.push_back(v);
+    if (v == start) break;
+    path_e.push_back(sc.parent_edge[v]);
+  }
+  return true;
+}
+
+void free_dev(tr_roadmap *r) {
+  void *p[] = {r->d_ids, r->d_masks, r->d_off, r->d_list, r->d_hit, r->d_bits};
+  for (void *q : p) if (q) (void)hipFree(q);
+  r->d_ids = nullptr; r->d_masks = nullptr; r->d_off = nullptr; r->d_list = nullptr; r->d_hit = nullptr; r->d_bits = nullptr;
+  r->list_cap = 0; r->has_caches = false;
+}
+
+// validity of the listed combined items (vertex v -> v, edge e -> V + e) against the current obstacle grid: one K4 launch
+int check_items(tr_roadmap *r, const std::vector<int32_t> &list, std::vector<uint8_t> &hit) {
+  hit.assign(list.size(), 0);
+  if (list.empty()) return TR_OK;
+  if (!r->has_caches) return rfail(r, TR_ERR_INVALID_ARG, "no voxel caches attached (tr_roadmap_set_caches)");
+  const int64_t n = (int64_t)list.size();
+  if (n > r->list_cap) {
+    if (r->d_list) (void)hipFree(r->d_list);
+    if (r->d_hit) (void)hipFree(r->d_hit);
+    r->d_list = nullptr; r->d_hit = nullptr;
+    r->list_cap = std::max<int64_t>(n + n / 2, 1 << 14);
+    RM_HIP(r, hipMalloc((void **)&r->d_list, (size_t)r->list_cap * sizeof(int32_t)));
+    RM_HIP(r, hipMalloc((void **)&r->d_hit, (size_t)r->list_cap));
+  }
+  RM_HIP(r, hipMemcpy(r->d_list, list.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
+  const int rc = tr_check_cached_subset_dev(r->ctx, r->d_ids, r->d_masks, r->d_off, r->V + r->E, r->d_list, n, r->d_hit, nullptr);
+  if (rc) return rfail(r, rc, tr_last_error(r->ctx));
+  RM_HIP(r, hipMemcpy(hit.data(), r->d_hit, (size_t)n, hipMemcpyDeviceToHost));     // synchronises with the launch
+  return TR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *tr_roadmap_last_error(const tr_roadmap *r) { return r ? r->err.c_str() : "null roadmap"; }
+
+int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, const int32_t *edges, const double *weights,
+                      int64_t n_edges, tr_roadmap **out) {
+  if (!ctx || !out || n_vertices < 0 || n_edges < 0 || (n_vertices > 0 && !states) || (n_edges > 0 && !edges)) return TR_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (n_vertices > std::numeric_limits<int32_t>::max() / 2 || n_edges > std::numeric_limits<int32_t>::max() / 2) return TR_ERR_INVALID_ARG;
+  tr_roadmap *r = new tr_roadmap();
+  r->ctx = ctx;
+  r->S = tr_state_size(ctx);
+  r->V = n_vertices; r->E = n_edges;
+  tr_space_weights(ctx, &r->w_rot, &r->w_ret);
+  {
+    int rot = 0, ret = 0, nt = 0;
+    tr_state_layout(ctx, &nt, &rot, &ret);
+    r->NT = nt; r->rot = rot != 0; r->ret = ret != 0;
+  }
+  r->states.assign(states, states + (size_t)n_vertices * r->S);
+  r->eu.resize((size_t)n_edges); r->ev.resize((size_t)n_edges); r->w.resize((size_t)n_edges);
+  std::vector<int64_t> deg((size_t)n_vertices + 1, 0);
+  for (int64_t e = 0; e < n_edges; e++) {
+    const int32_t a = edges[2 * e], b = edges[2 * e + 1];
+    if (a < 0 || a >= n_vertices || b < 0 || b >= n_vertices) { delete r; return TR_ERR_OUT_OF_RANGE; }
+    r->eu[(size_t)e] = a; r->ev[(size_t)e] = b;
+    // edge cost = opt_->motionCost = si->distance(a, b) unless the file supplies one (weightProperty_, :2598-2603)
+    r->w[(size_t)e] = weights ? weights[e] : state_distance(r, &r->states[(size_t)a * r->S], &r->states[(size_t)b * r->S]);
+    if (!(r->w[(size_t)e] >= 0)) { delete r; return TR_ERR_INVALID_ARG; }
+    deg[(size_t)a + 1]++; deg[(size_t)b + 1]++;
+  }
+  r->adj_off.assign((size_t)n_vertices + 1, 0);
+  for (int64_t v = 0; v < n_vertices; v++) r->adj_off[(size_t)v + 1] = r->adj_off[(size_t)v] + deg[(size_t)v + 1];
+  r->adj_v.resize((size_t)r->adj_off[(size_t)n_vertices]); r->adj_e.resize(r->adj_v.size());
+  std::vector<int64_t> fill(r->adj_off.begin(), r->adj_off.end() - 1);
+  for (int64_t e = 0; e < n_edges; e++) {
+    const int32_t a = r->eu[(size_t)e], b = r->ev[(size_t)e];
+    r->adj_v[(size_t)fill[(size_t)a]] = b; r->adj_e[(size_t)fill[(size_t)a]++] = (int32_t)e;
+    r->adj_v[(size_t)fill[(size_t)b]] = a; r->adj_e[(size_t)fill[(size_t)b]++] = (int32_t)e;
+  }
+  r->vstat.assign((size_t)n_vertices, V_UNKNOWN); r->estat.assign((size_t)n_edges, V_UNKNOWN);
+  r->vpresent.assign((size_t)n_vertices, 1); r->epresent.assign((size_t)n_edges, 1);
+  *out = r;
+  return TR_OK;
+}
+
+void tr_roadmap_destroy(tr_roadmap *r) {
+  if (!r) return;
+  (void)hipSetDevice(tr_device(r->ctx));
+  free_dev(r);
+  delete r;
+}
+
+int tr_roadmap_set_caches(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *v_ids, const uint64_t *v_masks,
+                          const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *e_ids,
+                          const uint64_t *e_masks, const uint64_t *e_present_bits) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  if (!v_offsets || !e_offsets) return rfail(r, TR_ERR_INVALID_ARG, "null offsets");
+  const int64_t nv = v_offsets[r->V], ne = e_offsets[r->E];
+  if (nv < 0 || ne < 0 || (nv > 0 && (!v_ids || !v_masks)) || (ne > 0 && (!e_ids || !e_masks))) return rfail(r, TR_ERR_INVALID_ARG, "bad CSR arrays");
+  for (int64_t i = 0; i < r->V; i++) if (v_offsets[i] > v_offsets[i + 1]) return rfail(r, TR_ERR_INVALID_ARG, "offsets must be non-decreasing");
+  for (int64_t i = 0; i < r->E; i++) if (e_offsets[i] > e_offsets[i + 1]) return rfail(r, TR_ERR_INVALID_ARG, "offsets must be non-decreasing");
+  RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
+  free_dev(r);
+  const int64_t items = r->V + r->E;
+  r->nnz = nv + ne;
+  std::vector<int64_t> off((size_t)items + 1);
+  for (int64_t i = 0; i <= r->V; i++) off[(size_t)i] = v_offsets[i];
+  for (int64_t i = 0; i <= r->E; i++) off[(size_t)(r->V + i)] = nv + e_offsets[i];
+  RM_HIP(r, hipMalloc((void **)&r->d_ids, std::max<size_t>(1, (size_t)r->nnz) * sizeof(uint32_t)));
+  RM_HIP(r, hipMalloc((void **)&r->d_masks, std::max<size_t>(1, (size_t)r->nnz) * sizeof(uint64_t)));
+  RM_HIP(r, hipMalloc((void **)&r->d_off, off.size() * sizeof(int64_t)));
+  RM_HIP(r, hipMalloc((void **)&r->d_bits, ((size_t)items / 64 + 1) * sizeof(uint64_t)));
+  if (nv) {
+    RM_HIP(r, hipMemcpy(r->d_ids, v_ids, (size_t)nv * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RM_HIP(r, hipMemcpy(r->d_masks, v_masks, (size_t)nv * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  if (ne) {
+    RM_HIP(r, hipMemcpy(r->d_ids + nv, e_ids, (size_t)ne * sizeof(uint32_t), hipMemcpyHostToDevice));
+    RM_HIP(r, hipMemcpy(r->d_masks + nv, e_masks, (size_t)ne * sizeof(uint64_t), hipMemcpyHostToDevice));
+  }
+  RM_HIP(r, hipMemcpy(r->d_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
+  for (int64_t i = 0; i < r->V; i++) r->vpresent[(size_t)i] = v_present_bits ? (uint8_t)((v_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
+  for (int64_t i = 0; i < r->E; i++) r->epresent[(size_t)i] = e_present_bits ? (uint8_t)((e_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
+  r->has_caches = true;
+  return TR_OK;
+}
+
+int tr_roadmap_clear_validity(tr_roadmap *r) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  std::fill(r->vstat.begin(), r->vstat.end(), (uint8_t)V_UNKNOWN);
+  std::fill(r->estat.begin(), r->estat.end(), (uint8_t)V_UNKNOWN);
+  return TR_OK;
+}
+
+int tr_roadmap_revalidate(tr_roadmap *r, int64_t *n_invalid_vertices, int64_t *n_invalid_edges) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  if (!r->has_caches) return rfail(r, TR_ERR_INVALID_ARG, "no voxel caches attached (tr_roadmap_set_caches)");
+  RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
+  const int64_t items = r->V + r->E;
+  int64_t nv = 0, ne = 0;
+  if (items > 0) {
+    const int rc = tr_check_cached_dev(r->ctx, r->d_ids, r->d_masks, r->d_off, items, r->d_bits, nullptr);
+    if (rc) return rfail(r, rc, tr_last_error(r->ctx));
+    std::vector<uint64_t> bits((size_t)(items + 63) / 64);
+    RM_HIP(r, hipMemcpy(bits.data(), r->d_bits, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < r->V; i++) {
+      const bool bad = ((bits[(size_t)i >> 6] >> (i & 63)) & 1) || !r->vpresent[(size_t)i];
+      r->vstat[(size_t)i] = bad ? V_INVALID : V_VALID; nv += bad;
+    }
+    for (int64_t i = 0; i < r->E; i++) {
+      const int64_t q = r->V + i;
+      const bool bad = ((bits[(size_t)q >> 6] >> (q & 63)) & 1) || !r->epresent[(size_t)i];
+      r->estat[(size_t)i] = bad ? V_INVALID : V_VALID; ne += bad;
+    }
+  }
+  if (n_invalid_vertices) *n_invalid_vertices = nv;
+  if (n_invalid_edges) *n_invalid_edges = ne;
+  return TR_OK;
+}
+
+int tr_roadmap_get_validity(tr_roadmap *r, uint8_t *vertex_status, uint8_t *edge_status) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  if (vertex_status) std::memcpy(vertex_status, r->vstat.data(), r->vstat.size());
+  if (edge_status) std::memcpy(edge_status, r->estat.data(), r->estat.size());
+  return TR_OK;
+}
+
+int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals, int64_t n_queries, int32_t n_threads,
+                     int32_t *status, double *cost, int64_t *path_offsets, tr_roadmap_stats *stats) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  if (n_queries < 0 || (n_queries > 0 && (!starts || !goals || !status || !path_offsets))) return rfail(r, TR_ERR_INVALID_ARG, "bad argument");
+  r->path_off.assign((size_t)n_queries + 1, 0); r->path_v.clear();
+  r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
+  if (path_offsets) path_offsets[0] = 0;
+  if (n_queries == 0) { if (stats) *stats = tr_roadmap_stats{0, 0, 0, 0}; return TR_OK; }
+  for (int64_t q = 0; q < n_queries; q++)
+    if (starts[q] < 0 || starts[q] >= r->V || goals[q] < 0 || goals[q] >= r->V) return rfail(r, TR_ERR_OUT_OF_RANGE, "query vertex outside the roadmap");
+  RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
+  const int T = host_threads(n_threads);
+  if ((int)r->scratch.size() < T) r->scratch.resize((size_t)T);
+  std::vector<std::vector<int32_t>> paths((size_t)n_queries), paths_e((size_t)n_queries);
+  std::vector<int32_t> list;
+  std::vector<uint8_t> hit;
+  std::vector<uint8_t> vmark((size_t)r->V, 0), emark((size_t)r->E, 0);
+  int rc;
+
+  // items become known: a missing cache (the voxelisation found the shape invalid when the cache was built) is invalid for good
+  auto record = [&](const std::vector<int32_t> &lst, const std::vector<uint8_t> &h) {
+    for (size_t k = 0; k < lst.size(); k++) {
+      const int64_t it = lst[k];
+      if (it < r->V) r->vstat[(size_t)it] = (h[k] || !r->vpresent[(size_t)it]) ? V_INVALID : V_VALID;
+      else r->estat[(size_t)(it - r->V)] = (h[k] || !r->epresent[(size_t)(it - r->V)]) ? V_INVALID : V_VALID;
+    }
+    r->st_items_checked += (int64_t)lst.size();
+  };
+
+  // the query end points first (solvePrep :2978-3010 only admits valid start / goal states)
+  for (int64_t q = 0; q < n_queries; q++) {
+    for (int32_t v : {starts[q], goals[q]})
+      if (r->vstat[(size_t)v] == V_UNKNOWN && !vmark[(size_t)v]) { vmark[(size_t)v] = 1; list.push_back(v); }
+  }
+  if (!list.empty()) {
+    if ((rc = check_items(r, list, hit))) return rc;
+    record(list, hit);
+    for (int32_t v : list) vmark[(size_t)v] = 0;
+  }
+  std::vector<int64_t> active;
+  for (int64_t q = 0; q < n_queries; q++) {
+    status[q] = TR_QUERY_SOLVED;
+    if (cost) cost[q] = std::numeric_limits<double>::infinity();
+    if (r->vstat[(size_t)starts[q]] == V_INVALID) status[q] = TR_QUERY_INVALID_START;
+    else if (r->vstat[(size_t)goals[q]] == V_INVALID) status[q] = TR_QUERY_INVALID_GOAL;
+    else if (starts[q] == goals[q]) { paths[(size_t)q] = {starts[q]}; if (cost) cost[q] = 0.0; }   // constructSolution :2696-2701
+    else active.push_back(q);
+  }
+
+  std::vector<uint8_t> found;
+  while (!active.empty()) {
+    r->st_rounds++;
+    // A* for every unresolved query, on the host cores
+    found.assign(active.size(), 0);
+    std::atomic<int64_t> next{0}, expanded{0};
+    auto worker = [&](int t) {
+      Scratch &sc = r->scratch[(size_t)t];
+      int64_t ex = 0;
+      for (;;) {
+        const int64_t k = next.fetch_add(1);
+        if (k >= (int64_t)active.size()) break;
+        const int64_t q = active[(size_t)k];
+        found[(size_t)k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+      }
+      expanded += ex;
+    };
+    {
+      const int nt = (int)std::min<int64_t>(T, (int64_t)active.size());
+      std::vector<std::thread> th;
+      for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
+      worker(0);
+      for (auto &x : th) x.join();
+    }
+    r->st_astar_runs += (int64_t)active.size();
+    r->st_expanded += expanded.load();
+    // unknown items on the candidate paths: all interior vertices, and the edges of paths without an unknown vertex
+    // are only worth testing once the vertices are clean -- but testing them in the same launch costs nothing, saves
+    // a round, and removing more invalid items never changes an accepted path (see the header comment)
+    list.clear();
+    for (size_t k = 0; k < active.size(); k++) {
+      if (!found[k]) continue;
+      const int64_t q = active[k];
+      const auto &pv = paths[(size_t)q];
+      const auto &pe = paths_e[(size_t)q];
+      for (size_t i = 1; i + 1 < pv.size(); i++) {
+        const int32_t v = pv[i];
+        if (r->vstat[(size_t)v] == V_UNKNOWN && !vmark[(size_t)v]) { vmark[(size_t)v] = 1; list.push_back(v); }
+      }
+      for (int32_t e : pe)
+        if (r->estat[(size_t)e] == V_UNKNOWN && !emark[(size_t)e]) { emark[(size_t)e] = 1; list.push_back((int32_t)(r->V + e)); }
+    }
+    if (!list.empty()) {
+      if ((rc = check_items(r, list, hit))) return rc;
+      record(list, hit);
+      for (int32_t it : list) { if (it < r->V) vmark[(size_t)it] = 0; else emark[(size_t)(it - r->V)] = 0; }
+    }
+    std::vector<int64_t> still;
+    for (size_t k = 0; k < active.size(); k++) {
+      const int64_t q = active[k];
+      if (!found[k]) { status[q] = TR_QUERY_NO_PATH; paths[(size_t)q].clear(); continue; }   // different components (:2026-2036)
+      bool ok = true;
+      for (size_t i = 1; i + 1 < paths[(size_t)q].size() && ok; i++) ok = r->vstat[(size_t)paths[(size_t)q][i]] == V_VALID;
+      for (size_t i = 0; i < paths_e[(size_t)q].size() && ok; i++) ok = r->estat[(size_t)paths_e[(size_t)q][i]] == V_VALID;
+      if (ok) {
+        if (cost) { double c = 0; for (size_t i = paths_e[(size_t)q].size(); i-- > 0;) c += r->w[(size_t)paths_e[(size_t)q][i]]; cost[q] = c; }
+      } else still.push_back(q);
+    }
+    active.swap(still);
+  }
+  for (int64_t q = 0; q < n_queries; q++) {
+    const auto &pv = paths[(size_t)q];
+    if (status[q] == TR_QUERY_SOLVED) r->path_v.insert(r->path_v.end(), pv.rbegin(), pv.rend());     // start ... goal
+    r->path_off[(size_t)q + 1] = (int64_t)r->path_v.size();
+    path_offsets[q + 1] = r->path_off[(size_t)q + 1];
+  }
+  if (stats) *stats = tr_roadmap_stats{r->st_rounds, r->st_items_checked, r->st_astar_runs, r->st_expanded};
+  return TR_OK;
+}
+
+int tr_roadmap_fetch_paths(tr_roadmap *r, int32_t *path_vertices, int64_t capacity) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  const int64_t n = (int64_t)r->path_v.size();
+  if (capacity < n) return rfail(r, TR_ERR_INVALID_ARG, "capacity smaller than the stored paths");
+  if (n > 0) {
+    if (!path_vertices) return rfail(r, TR_ERR_INVALID_ARG, "null output");
+    std::memcpy(path_vertices, r->path_v.data(), (size_t)n * sizeof(int32_t));
+  }
+  return TR_OK;
+}
+
+}  // extern "C"

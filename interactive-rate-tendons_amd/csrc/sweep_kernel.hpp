@@ -730,6 +730,29 @@ __global__ __launch_bounds__(1024) void cached_blocks_vs_grid(
   if (threadIdx.x == 0) hit_bits[blockIdx.x] = word;
 }
 
+// K4 on a SUBSET of the cached items: list[q] names an item of the CSR; one wave per listed item, the verdict
+// goes to hit[q] (one byte).  The lazy query loop (roadmap.hip) validates the unknown vertices / edges of all
+// candidate paths of a round with one launch of this.
+__global__ __launch_bounds__(256) void cached_subset_vs_grid(
+    const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int64_t *__restrict__ offsets,
+    const int32_t *__restrict__ list, int64_t n_list, int64_t n_items, const uint64_t *__restrict__ grid, uint32_t n_blocks,
+    uint8_t *__restrict__ hit_out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t q = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= n_list) return;
+  const int64_t item = list[q];
+  bool hit = false;
+  if (item >= 0 && item < n_items) {
+    const int64_t b = offsets[item], e = offsets[item + 1];
+    for (int64_t k = b + lane; k < e && !hit; k += 64) {
+      const uint32_t id = ids[k];
+      hit = id < n_blocks && (grid[id] & masks[k]) != 0;
+    }
+  }
+  const bool any = __any(hit);
+  if (lane == 0) hit_out[q] = any ? 1 : 0;
+}
+
 #endif  // TRK_DEVICE_BODIES_ONLY
 
 }  // namespace trk

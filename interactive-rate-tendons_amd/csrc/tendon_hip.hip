@@ -1045,6 +1045,40 @@ int tr_check_cached_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_mask
   return TR_OK;
 }
 
+int tr_check_cached_subset_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_masks, const int64_t *d_offsets,
+                               int64_t n_items, const int32_t *d_list, int64_t n_list, uint8_t *d_hit, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  if (n_items < 0 || n_list < 0) return fail(c, TR_ERR_INVALID_ARG, "negative count");
+  if (n_list == 0) return TR_OK;
+  if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  if (!d_ids || !d_masks || !d_offsets || !d_list || !d_hit) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
+  hipStream_t s = (hipStream_t)stream;
+  ProfScope ps(c, 2, s);
+  hipLaunchKernelGGL(trk::cached_subset_vs_grid, dim3((unsigned)((n_list + 3) / 4)), dim3(256), 0, s, d_ids, d_masks, d_offsets,
+                     d_list, n_list, n_items, c->d_grid, c->n_blocks, d_hit);
+  HIP_TRY(c, hipGetLastError());
+  return TR_OK;
+}
+
+int tr_state_layout(const tr_ctx *c, int32_t *n_tendons, int32_t *has_rotation, int32_t *has_retraction) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (n_tendons) *n_tendons = c->K.n_tendons;
+  if (has_rotation) *has_rotation = c->K.enable_rotation;
+  if (has_retraction) *has_retraction = c->K.enable_retraction;
+  return TR_OK;
+}
+
+int tr_space_weights(const tr_ctx *c, double *w_rotation, double *w_retraction) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  double ext2 = 0;
+  for (int i = 0; i < c->K.n_tendons; i++) ext2 += c->max_tension[i] * c->max_tension[i];
+  const double ext = std::sqrt(ext2);                         // RealVectorStateSpace::getMaximumExtent, bounds [0, max_tension]
+  if (w_rotation) *w_rotation = ext / (4.0 * M_PI);           // Problem.cpp:131-137
+  if (w_retraction) *w_retraction = 2.0 * ext / c->K.L;       // Problem.cpp:144-152
+  return TR_OK;
+}
+
 int tr_check_cached(tr_ctx *c, const uint32_t *ids, const uint64_t *masks, const int64_t *offsets,
                     int64_t n_items, uint64_t *hit_bits) {
   if (!c) return TR_ERR_INVALID_ARG;

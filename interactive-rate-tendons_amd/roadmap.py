@@ -150,3 +150,115 @@ def gathered_vertex_mask(robot, validate_bits_dev, M, seed, tau_max, device):
     as the local validator)."""
     v = D.ShardedVertexValidator(robot, validate_bits_dev, seed=seed, tau_max=tau_max, device=device)
     return unpack_bits(v.run(M), M)
+
+
+class VoxelCachedLazyPRM:
+    """The query side of motion_planning::VoxelCachedLazyPRM on a roadmap with voxel caches (BASELINE config 5):
+    `solveWithRoadmap` (motion-planning/VoxelCachedLazyPRM.cpp:1977-2096 -> constructSolution :2689-2771) for a batch
+    of (start, goal) roadmap vertices, `clearValidity` (:1656-1663), and `revalidate`, the eager form of the loading
+    loops (:2397-2411, :2486-2526).  Graph search runs in the native library on the host cores, validity comes from
+    the cached voxel sets resident in HBM through K4 (tr_roadmap_* in include/tendon_hip.h)."""
+
+    def __init__(self, checker, states, edges, weights=None):
+        import ctypes as C
+        from . import _lib as L
+        self._C, self._L = C, L
+        self.engine = checker.engine
+        self.checker = checker
+        self.lib = L.lib()
+        self.states = np.ascontiguousarray(states, dtype=np.float64)
+        self.edges = np.ascontiguousarray(np.asarray(edges).reshape(-1, 2), dtype=np.int32)
+        w = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
+        rm = C.c_void_p()
+        st = self.lib.tr_roadmap_create(self.engine._ctx, self.states.ctypes.data_as(C.POINTER(C.c_double)), len(self.states),
+                                        self.edges.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        w.ctypes.data_as(C.POINTER(C.c_double)) if w is not None else None, len(self.edges),
+                                        C.byref(rm))
+        if st != L.TR_OK:
+            raise L._EXC.get(st, L.TendonHipError)("tr_roadmap_create failed (status %d)" % st)
+        self._rm = rm
+        self.stats = None
+
+    def _check(self, st):
+        if st != self._L.TR_OK:
+            msg = self.lib.tr_roadmap_last_error(self._rm)
+            raise self._L._EXC.get(st, self._L.TendonHipError)(msg.decode() if msg else "status %d" % st)
+
+    def close(self):
+        if getattr(self, "_rm", None) is not None:
+            self.lib.tr_roadmap_destroy(self._rm)
+            self._rm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_caches(self, vertex_caches, edge_caches):
+        """Upload vertexVoxelsProperty_ / edgeVoxelsProperty_ as CSR (dicts of offsets, block_ids, masks as returned by
+        Engine.voxelize_batch / voxelize_edges or rmp.read_rmp; optional boolean 'shape_valid' / 'fully_valid' /
+        'present' = which items have a cache at all)."""
+        C = self._C
+        from .distributed import pack_bits
+
+        def arrs(c, keys):
+            off = np.ascontiguousarray(c["offsets"], dtype=np.int64)
+            ids = np.ascontiguousarray(c["block_ids"], dtype=np.uint32)
+            mk = np.ascontiguousarray(c["masks"], dtype=np.uint64)
+            present = next((c[k] for k in keys if k in c and c[k] is not None), None)
+            pb = None if present is None else np.ascontiguousarray(pack_bits(np.asarray(present, dtype=bool)))
+            return off, ids, mk, pb
+        vo, vi, vm, vp = arrs(vertex_caches, ("present", "shape_valid"))
+        eo, ei, em, ep = arrs(edge_caches, ("present", "fully_valid"))
+        if len(vo) != len(self.states) + 1 or len(eo) != len(self.edges) + 1:
+            raise self._L.InvalidArgument("cache offsets do not match the roadmap")
+        u32, u64, i64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+        self._check(self.lib.tr_roadmap_set_caches(
+            self._rm, vo.ctypes.data_as(i64), vi.ctypes.data_as(u32), vm.ctypes.data_as(u64),
+            vp.ctypes.data_as(u64) if vp is not None else None, eo.ctypes.data_as(i64), ei.ctypes.data_as(u32),
+            em.ctypes.data_as(u64), ep.ctypes.data_as(u64) if ep is not None else None))
+
+    def set_obstacles(self, voxels, env=None):
+        """A changed environment: new obstacle grid for the checker's engine, every validity unknown again."""
+        self.engine.set_grid(voxels.Nx(), voxels.limits(), voxels.blocks, None if env is None else env.inv_rotation)
+        self.clearValidity()
+
+    def clearValidity(self):
+        self._check(self.lib.tr_roadmap_clear_validity(self._rm))
+
+    def revalidate(self):
+        """Every cached set against the current grid (one K4 launch) -> (#invalid vertices, #invalid edges)."""
+        C = self._C
+        nv, ne = C.c_int64(0), C.c_int64(0)
+        self._check(self.lib.tr_roadmap_revalidate(self._rm, C.byref(nv), C.byref(ne)))
+        return nv.value, ne.value
+
+    def validity(self):
+        """(vertex status, edge status): 0 unknown, 1 valid, 2 invalid / removed."""
+        C = self._C
+        v, e = np.zeros(len(self.states), dtype=np.uint8), np.zeros(len(self.edges), dtype=np.uint8)
+        self._check(self.lib.tr_roadmap_get_validity(self._rm, v.ctypes.data_as(C.POINTER(C.c_uint8)), e.ctypes.data_as(C.POINTER(C.c_uint8))))
+        return v, e
+
+    def solveWithRoadmap(self, starts, goals, n_threads=0):
+        """Batch of queries -> dict(status, cost, paths): paths[q] = vertex indices start ... goal (empty unless solved)."""
+        C, L = self._C, self._L
+        s = np.ascontiguousarray(starts, dtype=np.int32).reshape(-1)
+        g = np.ascontiguousarray(goals, dtype=np.int32).reshape(-1)
+        if s.shape != g.shape:
+            raise L.InvalidArgument("starts and goals differ in length")
+        n = len(s)
+        status = np.zeros(n, dtype=np.int32)
+        cost = np.zeros(n)
+        off = np.zeros(n + 1, dtype=np.int64)
+        st = L.TrRoadmapStats()
+        i32 = C.POINTER(C.c_int32)
+        self._check(self.lib.tr_roadmap_solve(self._rm, s.ctypes.data_as(i32), g.ctypes.data_as(i32), n, int(n_threads),
+                                              status.ctypes.data_as(i32), cost.ctypes.data_as(C.POINTER(C.c_double)),
+                                              off.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(st)))
+        pv = np.zeros(int(off[-1]), dtype=np.int32)
+        self._check(self.lib.tr_roadmap_fetch_paths(self._rm, pv.ctypes.data_as(i32), len(pv)))
+        self.stats = dict(rounds=st.rounds, items_checked=st.items_checked, astar_runs=st.astar_runs, expanded=st.expanded)
+        return dict(status=status, cost=cost, path_offsets=off, path_vertices=pv,
+                    paths=[pv[off[q]:off[q + 1]] for q in range(n)])

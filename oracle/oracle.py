@@ -180,6 +180,18 @@ def _load(kind="strict"):
     lib.orc_check_motion_batch.argtypes = [P(OrcRobot), P(OrcSpaceParams), P(OrcGrid), c_double_p,
                                            c_double_p, c_double_p, C.c_long, P(C.c_uint8),
                                            P(C.c_int32), C.c_int]
+    lib.orc_roadmap_create.argtypes = [P(OrcRobot), c_double_p, C.c_long, P(C.c_int32), c_double_p, C.c_long,
+                                       P(C.c_int64), P(C.c_uint32), P(C.c_uint64), P(C.c_uint8),
+                                       P(C.c_int64), P(C.c_uint32), P(C.c_uint64), P(C.c_uint8)]
+    lib.orc_roadmap_create.restype = C.c_void_p
+    lib.orc_roadmap_free.argtypes = [C.c_void_p]
+    lib.orc_roadmap_free.restype = None
+    lib.orc_roadmap_clear_validity.argtypes = [C.c_void_p]
+    lib.orc_roadmap_clear_validity.restype = None
+    lib.orc_roadmap_get_validity.argtypes = [C.c_void_p, P(C.c_uint8), P(C.c_uint8)]
+    lib.orc_roadmap_get_validity.restype = None
+    lib.orc_roadmap_query.argtypes = [C.c_void_p, P(OrcGrid), C.c_int, C.c_int, P(C.c_int32), C.c_int, c_double_p,
+                                      P(C.c_int), P(C.c_long)]
     lib.orc_check_cached.argtypes = [P(OrcGrid), P(C.c_uint32), P(C.c_uint64), P(C.c_int64), C.c_long,
                                      P(C.c_uint8)]
     lib.orc_grid_export_blocks.argtypes = [P(OrcGrid), P(C.c_uint32), P(C.c_uint64), C.c_long]
@@ -526,3 +538,53 @@ def omp_lib():
 
 def max_threads():
     return int(_load("omp").orc_max_threads())
+
+
+class Roadmap:
+    """Sequential restatement of VoxelCachedLazyPRM's query loop on a cached roadmap (orc_roadmap_*)."""
+
+    def __init__(self, robot, states, edges, weights, vertex_caches, edge_caches, lib=None):
+        self.lib = lib or robot.lib
+        self.robot = robot
+        self.states = _f64(states)
+        self.edges = np.ascontiguousarray(np.asarray(edges).reshape(-1, 2), dtype=np.int32)
+        self.w = None if weights is None else _f64(weights)
+
+        def arrs(c, keys):
+            present = next((c[k] for k in keys if k in c and c[k] is not None), None)
+            return (np.ascontiguousarray(c["offsets"], dtype=np.int64), np.ascontiguousarray(c["block_ids"], dtype=np.uint32),
+                    np.ascontiguousarray(c["masks"], dtype=np.uint64),
+                    None if present is None else np.ascontiguousarray(present, dtype=np.uint8))
+        self._v = arrs(vertex_caches, ("present", "shape_valid"))
+        self._e = arrs(edge_caches, ("present", "fully_valid"))
+        pa = lambda a, t: a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+        self.ptr = self.lib.orc_roadmap_create(
+            C.byref(robot.c), _dp(self.states), len(self.states), self.edges.ctypes.data_as(C.POINTER(C.c_int32)),
+            _dp(self.w) if self.w is not None else None, len(self.edges),
+            pa(self._v[0], C.c_int64), pa(self._v[1], C.c_uint32), pa(self._v[2], C.c_uint64), pa(self._v[3], C.c_uint8),
+            pa(self._e[0], C.c_int64), pa(self._e[1], C.c_uint32), pa(self._e[2], C.c_uint64), pa(self._e[3], C.c_uint8))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self.lib.orc_roadmap_free(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+    def clear_validity(self):
+        self.lib.orc_roadmap_clear_validity(self.ptr)
+
+    def validity(self):
+        v, e = np.zeros(len(self.states), dtype=np.uint8), np.zeros(len(self.edges), dtype=np.uint8)
+        self.lib.orc_roadmap_get_validity(self.ptr, v.ctypes.data_as(C.POINTER(C.c_uint8)), e.ctypes.data_as(C.POINTER(C.c_uint8)))
+        return v, e
+
+    def query(self, grid, start, goal):
+        """-> dict(n, path, cost, iterations, checked): n > 0 solved, 0 disconnected, -2 / -3 invalid start / goal."""
+        cap = len(self.states)
+        path = np.zeros(cap, dtype=np.int32)
+        cost, it, chk = C.c_double(0), C.c_int(0), C.c_long(0)
+        n = self.lib.orc_roadmap_query(self.ptr, grid.ptr, int(start), int(goal), path.ctypes.data_as(C.POINTER(C.c_int32)), cap,
+                                       C.byref(cost), C.byref(it), C.byref(chk))
+        return dict(n=n, path=path[:max(n, 0)].copy(), cost=cost.value, iterations=it.value, checked=chk.value)

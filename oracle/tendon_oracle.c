@@ -1504,3 +1504,188 @@ void orc_check_cached(const orc_grid *obstacles, const uint32_t *block_ids, cons
     hit[i] = h;
   }
 }
+
+/* ------------------------------------------------------------------------------------------
+ * The interactive query loop on a cached roadmap: VoxelCachedLazyPRM::solveWithRoadmap's inner loop
+ * (motion-planning/VoxelCachedLazyPRM.cpp:2066-2071) over constructSolution (:2689-2771), astarSearch
+ * (:2950-2976, Boost astar_search with costHeuristic = state-space distance, :2773-2775),
+ * computeVertexValidity / computeEdgeValidity on cached voxel sets (:2607-2631), removeVertices / removeEdge,
+ * clearValidity (:1656-1663).  One query at a time, sequentially, exactly as the reference proceeds: all invalid
+ * interior vertices of the candidate path are removed, else the FIRST invalid edge from the goal side.
+ * Boost.Graph is third-party (not under /root/reference): A* is restated from its published algorithm (best-first
+ * on g + h, consistent heuristic, stop when the goal is examined).
+ * ---------------------------------------------------------------------------------------- */
+struct orc_roadmap {
+  const orc_robot *rb;
+  long V, E;
+  int S;
+  double *states; int32_t *eu, *ev; double *w;
+  int64_t *adj_off; int32_t *adj_v, *adj_e;
+  const int64_t *v_off, *e_off; const uint32_t *v_ids, *e_ids; const uint64_t *v_masks, *e_masks;
+  const uint8_t *v_present, *e_present;
+  uint8_t *vstat, *estat;            /* 0 unknown, 1 VALIDITY_TRUE, 2 removed from the graph */
+  /* A* scratch */
+  double *g; int32_t *parent, *parent_e; uint32_t *stamp; uint8_t *closed; uint32_t gen;
+  double *hkey; int32_t *hval; long hn, hcap;
+};
+
+orc_roadmap *orc_roadmap_create(const orc_robot *rb, const double *states, long V, const int32_t *edges, const double *weights, long E,
+                                const int64_t *v_off, const uint32_t *v_ids, const uint64_t *v_masks, const uint8_t *v_present,
+                                const int64_t *e_off, const uint32_t *e_ids, const uint64_t *e_masks, const uint8_t *e_present) {
+  orc_roadmap *r = (orc_roadmap *)calloc(1, sizeof(orc_roadmap));
+  r->rb = rb; r->V = V; r->E = E; r->S = orc_state_size(rb);
+  r->states = (double *)malloc(sizeof(double) * (size_t)(V * r->S + 1));
+  memcpy(r->states, states, sizeof(double) * (size_t)(V * r->S));
+  r->eu = (int32_t *)malloc(sizeof(int32_t) * (size_t)(E + 1)); r->ev = (int32_t *)malloc(sizeof(int32_t) * (size_t)(E + 1));
+  r->w = (double *)malloc(sizeof(double) * (size_t)(E + 1));
+  r->adj_off = (int64_t *)calloc((size_t)V + 2, sizeof(int64_t));
+  for (long e = 0; e < E; e++) {
+    r->eu[e] = edges[2 * e]; r->ev[e] = edges[2 * e + 1];
+    r->w[e] = weights ? weights[e] : orc_state_distance(rb, states + (size_t)r->eu[e] * r->S, states + (size_t)r->ev[e] * r->S);
+    r->adj_off[r->eu[e] + 1]++; r->adj_off[r->ev[e] + 1]++;
+  }
+  for (long v = 0; v < V; v++) r->adj_off[v + 1] += r->adj_off[v];
+  r->adj_v = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * E + 1)); r->adj_e = (int32_t *)malloc(sizeof(int32_t) * (size_t)(2 * E + 1));
+  int64_t *fill = (int64_t *)malloc(sizeof(int64_t) * (size_t)(V + 1));
+  memcpy(fill, r->adj_off, sizeof(int64_t) * (size_t)(V + 1));
+  for (long e = 0; e < E; e++) {
+    r->adj_v[fill[r->eu[e]]] = r->ev[e]; r->adj_e[fill[r->eu[e]]++] = (int32_t)e;
+    r->adj_v[fill[r->ev[e]]] = r->eu[e]; r->adj_e[fill[r->ev[e]]++] = (int32_t)e;
+  }
+  free(fill);
+  r->v_off = v_off; r->v_ids = v_ids; r->v_masks = v_masks; r->v_present = v_present;
+  r->e_off = e_off; r->e_ids = e_ids; r->e_masks = e_masks; r->e_present = e_present;
+  r->vstat = (uint8_t *)calloc((size_t)V + 1, 1); r->estat = (uint8_t *)calloc((size_t)E + 1, 1);
+  r->g = (double *)malloc(sizeof(double) * (size_t)(V + 1));
+  r->parent = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V + 1)); r->parent_e = (int32_t *)malloc(sizeof(int32_t) * (size_t)(V + 1));
+  r->stamp = (uint32_t *)calloc((size_t)V + 1, sizeof(uint32_t)); r->closed = (uint8_t *)calloc((size_t)V + 1, 1);
+  r->hcap = 1024; r->hkey = (double *)malloc(sizeof(double) * (size_t)r->hcap); r->hval = (int32_t *)malloc(sizeof(int32_t) * (size_t)r->hcap);
+  return r;
+}
+
+void orc_roadmap_free(orc_roadmap *r) {
+  if (!r) return;
+  free(r->states); free(r->eu); free(r->ev); free(r->w); free(r->adj_off); free(r->adj_v); free(r->adj_e);
+  free(r->vstat); free(r->estat); free(r->g); free(r->parent); free(r->parent_e); free(r->stamp); free(r->closed);
+  free(r->hkey); free(r->hval); free(r);
+}
+
+void orc_roadmap_clear_validity(orc_roadmap *r) {          /* :1656-1663 (and the graph as loaded) */
+  memset(r->vstat, 0, (size_t)r->V); memset(r->estat, 0, (size_t)r->E);
+}
+void orc_roadmap_get_validity(const orc_roadmap *r, uint8_t *vstat, uint8_t *estat) {
+  if (vstat) memcpy(vstat, r->vstat, (size_t)r->V);
+  if (estat) memcpy(estat, r->estat, (size_t)r->E);
+}
+
+static void heap_push(orc_roadmap *r, double key, int32_t val) {
+  if (r->hn == r->hcap) {
+    r->hcap *= 2;
+    r->hkey = (double *)realloc(r->hkey, sizeof(double) * (size_t)r->hcap); r->hval = (int32_t *)realloc(r->hval, sizeof(int32_t) * (size_t)r->hcap);
+  }
+  long i = r->hn++;
+  while (i > 0) {
+    long p = (i - 1) / 2;
+    if (!(key < r->hkey[p])) break;
+    r->hkey[i] = r->hkey[p]; r->hval[i] = r->hval[p]; i = p;
+  }
+  r->hkey[i] = key; r->hval[i] = val;
+}
+static int32_t heap_pop(orc_roadmap *r) {
+  int32_t top = r->hval[0];
+  double key = r->hkey[--r->hn]; int32_t val = r->hval[r->hn];
+  long i = 0;
+  for (;;) {
+    long c = 2 * i + 1;
+    if (c >= r->hn) break;
+    if (c + 1 < r->hn && r->hkey[c + 1] < r->hkey[c]) c++;
+    if (!(r->hkey[c] < key)) break;
+    r->hkey[i] = r->hkey[c]; r->hval[i] = r->hval[c]; i = c;
+  }
+  r->hkey[i] = key; r->hval[i] = val;
+  return top;
+}
+
+static int roadmap_astar(orc_roadmap *r, int start, int goal) {
+  if (++r->gen == 0) { memset(r->stamp, 0, sizeof(uint32_t) * (size_t)r->V); r->gen = 1; }
+  const uint32_t gen = r->gen;
+  const double *sg = r->states + (size_t)goal * r->S;
+  r->hn = 0;
+  r->stamp[start] = gen; r->g[start] = 0.0; r->parent[start] = start; r->parent_e[start] = -1; r->closed[start] = 0;
+  heap_push(r, orc_state_distance(r->rb, r->states + (size_t)start * r->S, sg), start);
+  while (r->hn > 0) {
+    int32_t u = heap_pop(r);
+    if (r->closed[u]) continue;
+    r->closed[u] = 1;
+    if (u == goal) return 1;                                  /* AStarGoalVisitor::examine_vertex */
+    for (int64_t k = r->adj_off[u]; k < r->adj_off[u + 1]; k++) {
+      int32_t e = r->adj_e[k], v = r->adj_v[k];
+      if (r->estat[e] == 2 || r->vstat[v] == 2) continue;      /* removed from the graph */
+      double gv = r->g[u] + r->w[e];
+      if (r->stamp[v] != gen) { r->stamp[v] = gen; r->closed[v] = 0; }
+      else if (r->closed[v] || !(gv < r->g[v])) continue;
+      r->g[v] = gv; r->parent[v] = u; r->parent_e[v] = e;
+      heap_push(r, gv + orc_state_distance(r->rb, r->states + (size_t)v * r->S, sg), v);
+    }
+  }
+  return 0;
+}
+
+static int cached_collides(const orc_grid *obstacles, const int64_t *off, const uint32_t *ids, const uint64_t *masks, long i) {
+  for (int64_t k = off[i]; k < off[i + 1]; k++) if (obstacles->blocks[ids[k]] & masks[k]) return 1;
+  return 0;
+}
+static int vertex_validity(orc_roadmap *r, const orc_grid *obstacles, int v, long *checked) {      /* computeVertexValidity */
+  if (r->vstat[v] == 0) {
+    (*checked)++;
+    int ok = (!r->v_present || r->v_present[v]) && !cached_collides(obstacles, r->v_off, r->v_ids, r->v_masks, v);
+    r->vstat[v] = ok ? 1 : 2;
+  }
+  return r->vstat[v] == 1;
+}
+static int edge_validity(orc_roadmap *r, const orc_grid *obstacles, int e, long *checked) {        /* computeEdgeValidity */
+  if (r->estat[e] == 0) {
+    (*checked)++;
+    int ok = (!r->e_present || r->e_present[e]) && !cached_collides(obstacles, r->e_off, r->e_ids, r->e_masks, e);
+    r->estat[e] = ok ? 1 : 2;
+  }
+  return r->estat[e] == 1;
+}
+
+/* Returns the number of path vertices written to path_out (start ... goal), 0 when start and goal are not connected,
+ * -2 / -3 when the start / goal vertex is itself invalid in this environment. */
+int orc_roadmap_query(orc_roadmap *r, const orc_grid *obstacles, int start, int goal, int32_t *path_out, int cap,
+                      double *cost_out, int *iterations_out, long *checked_out) {
+  long checked = 0;
+  int iters = 0, n = 0;
+  double cost = 0.0;
+  if (!vertex_validity(r, obstacles, start, &checked)) { n = -2; goto done; }
+  if (!vertex_validity(r, obstacles, goal, &checked)) { n = -3; goto done; }
+  if (start == goal) { if (cap > 0) path_out[0] = start; n = 1; goto done; }               /* :2696-2701 */
+  for (;;) {
+    iters++;
+    if (!roadmap_astar(r, start, goal)) { n = 0; break; }
+    int removed = 0;
+    for (int pos = r->parent[goal]; r->parent[pos] != pos; pos = r->parent[pos])             /* :2711-2714 */
+      if (!vertex_validity(r, obstacles, pos, &checked)) removed++;                          /* marking 2 = removeVertices(:2726) */
+    if (removed) continue;
+    int bad_edge = 0;
+    for (int v = goal; v != start; v = r->parent[v])                                         /* :2745-2762, from the goal side */
+      if (!edge_validity(r, obstacles, r->parent_e[v], &checked)) { bad_edge = 1; break; }   /* first invalid edge only */
+    if (bad_edge) continue;
+    int len = 0;
+    for (int v = goal;; v = r->parent[v]) { len++; if (v == start) break; }
+    if (len <= cap) {
+      int i = len - 1;
+      for (int v = goal;; v = r->parent[v]) { path_out[i--] = v; if (v == start) break; }
+    }
+    for (int v = goal; v != start; v = r->parent[v]) cost += r->w[r->parent_e[v]];
+    n = len;
+    break;
+  }
+done:
+  if (cost_out) *cost_out = cost;
+  if (iterations_out) *iterations_out = iters;
+  if (checked_out) *checked_out = checked;
+  return n;
+}

@@ -169,6 +169,17 @@ int  orc_check_motion_batch(const orc_robot *rb, const orc_space_params *sp, con
 
 /* cached-voxel re-validation: sparse (block id, mask) lists vs dense obstacle grid
  * (VoxelCachedLazyPRM.cpp:2397-2411 -> VoxelOctree::collides) */
+/* Interactive queries on a cached roadmap: VoxelCachedLazyPRM::solveWithRoadmap / constructSolution, sequential,
+ * one query at a time as the reference proceeds (see the .c file).  The CSR cache arrays are borrowed. */
+typedef struct orc_roadmap orc_roadmap;
+orc_roadmap *orc_roadmap_create(const orc_robot *rb, const double *states, long V, const int32_t *edges, const double *weights, long E,
+                                const int64_t *v_off, const uint32_t *v_ids, const uint64_t *v_masks, const uint8_t *v_present,
+                                const int64_t *e_off, const uint32_t *e_ids, const uint64_t *e_masks, const uint8_t *e_present);
+void orc_roadmap_free(orc_roadmap *r);
+void orc_roadmap_clear_validity(orc_roadmap *r);
+void orc_roadmap_get_validity(const orc_roadmap *r, uint8_t *vstat, uint8_t *estat);
+int  orc_roadmap_query(orc_roadmap *r, const orc_grid *obstacles, int start, int goal, int32_t *path_out, int cap,
+                       double *cost_out, int *iterations_out, long *checked_out);
 void orc_check_cached(const orc_grid *obstacles, const uint32_t *block_ids, const uint64_t *masks,
                       const int64_t *offsets, long n_items, uint8_t *hit);
 /* export occupied blocks of g: returns count; ids/masks may be NULL to count only */

@@ -525,3 +525,42 @@ def test_environment_edits_against_numpy_morphology(orc):
     h = orc.Grid(32, (0, 1, 0, 1, 0, 1)); h.blocks()[...] = g.blocks()
     h.dilate_sphere(0.07)                                   # round(0.07 / (1/32)) = 2 six-neighbour steps
     assert np.array_equal(_cells(h), _np_dilate(base, 2, m6))
+
+
+def test_lazy_prm_query_loop_hand_traced(orc):
+    """orc_roadmap_query on a 6-vertex graph where the lazy loop can be followed by hand (constructSolution,
+    VoxelCachedLazyPRM.cpp:2689-2771): the cheapest path runs through an invalid vertex (ALL invalid interior vertices
+    of the candidate path are removed, :2711-2733), the next one over an invalid edge (only the FIRST invalid edge from
+    the goal side is removed, :2745-2757), the third is clean."""
+    rb = orc.Robot([[0.0], [2.0]], [[0.01], [0.01]])                       # 2 tendons: states are points of the plane
+    st = np.array([[0, 0], [1, 0.2], [2, 0], [1, -1], [1, 1.5], [0.5, 3.0]], float)
+    edges = np.array([[0, 1], [1, 2], [0, 3], [3, 2], [0, 4], [4, 2], [4, 5]])
+    g = orc.Grid(16, (-1, 1) * 3)
+    g.set_cell(3, 3, 3)                                                     # block 0, bit of cell (3, 3, 3)
+    bm = lambda x, y, z: np.uint64(int(orc._load().orc_bitmask(x, y, z)))
+    hitmask, free = bm(3, 3, 3), bm(0, 0, 0)
+    # vertex 1 collides; edge 3-2 (index 3) collides; everything else is free
+    vc = dict(offsets=np.arange(7), block_ids=np.zeros(6, np.uint32), masks=np.array([free, hitmask, free, free, free, free]))
+    ec = dict(offsets=np.arange(8), block_ids=np.zeros(7, np.uint32), masks=np.array([free, free, free, hitmask, free, free, free]))
+    rm = orc.Roadmap(rb, st, edges, None, vc, ec)
+    q = rm.query(g, 0, 2)
+    assert q["n"] == 3 and list(q["path"]) == [0, 4, 2] and q["iterations"] == 3
+    assert abs(q["cost"] - 2 * np.hypot(1, 1.5)) < 1e-15
+    vs, es = rm.validity()
+    # 0-1, 1-2 never looked at (vertex 1 went first); 0-3 neither: the edges are walked from the goal and 3-2 failed first
+    assert list(vs) == [1, 2, 1, 1, 1, 0] and list(es) == [0, 0, 0, 2, 1, 1, 0]
+    assert q["checked"] == 2 + 1 + 1 + 1 + 1 + 2      # start, goal | v1 | v3 | e(3,2) | v4 | e(4,2), e(0,4)
+    # known validity is kept: the second query searches once and checks nothing on that path
+    q2 = rm.query(g, 2, 0)
+    assert list(q2["path"]) == [2, 4, 0] and q2["iterations"] == 1 and q2["checked"] == 0
+    assert rm.query(g, 0, 0)["n"] == 1 and rm.query(g, 1, 2)["n"] == -2 and rm.query(g, 2, 1)["n"] == -3
+    # an empty grid after clearValidity: the direct route again
+    rm.clear_validity()
+    g.clear()
+    q3 = rm.query(g, 0, 2)
+    assert list(q3["path"]) == [0, 1, 2] and q3["iterations"] == 1
+    # disconnected: vertex 5 hangs on one edge, and that edge collides
+    ec2 = dict(ec, masks=np.array([free, free, free, free, free, free, hitmask]))
+    rm2 = orc.Roadmap(rb, st, edges, None, vc, ec2)
+    g.set_cell(3, 3, 3)
+    assert rm2.query(g, 0, 5)["n"] == 0
