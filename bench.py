@@ -227,16 +227,21 @@ def main():
 
     if rank == 0:
         k1b, k2b = algorithmic_bytes_per_check(S, P, N)
+        kvb = 8 * S + 24 + 0.125                   # fk_verdict: state in, tip + one verdict bit out (fused verdict-only variant)
         k1 = prof["fk_rk4_batch"]
         k2 = prof["backbone_voxel_sweep"]
         kf = prof.get("fk_sweep_fused", {"launches": 0, "total_ms": 0.0})
+        kv = prof.get("fk_verdict", {"launches": 0, "total_ms": 0.0})
         k1_ms = k1["total_ms"] / max(1, k1["launches"])
         k2_ms = k2["total_ms"] / max(1, k2["launches"])
         kf_ms = kf["total_ms"] / max(1, kf["launches"])
-        # dominant = most device time in the timed region.  The verdict path normally runs K1 and K2 as ONE
-        # kernel (fk_sweep_fused: its algorithmic bytes are K1's writes plus K2's reads of the same points);
-        # TENDON_HIP_FUSED=0 launches them separately.
-        cands = [("fk_sweep_fused", kf, kf_ms, k1b + k2b), ("fk_rk4_batch", k1, k1_ms, k1b), ("backbone_voxel_sweep", k2, k2_ms, k2b)]
+        kv_ms = kv["total_ms"] / max(1, kv["launches"])
+        # dominant = most device time in the timed region.  tr_validate_batch* normally runs fk_verdict (the whole
+        # predicate in one pass, no point storage) followed by fk_sweep_fused_list on the few configurations that need
+        # the exact self-collision sweep (slot fk_sweep_fused); TENDON_HIP_FUSED=1 runs K1 + K2 as one kernel over
+        # stored points (fk_sweep_fused: K1's writes plus K2's reads of the same points), =0 launches them separately.
+        cands = [("fk_verdict", kv, kv_ms, kvb), ("fk_sweep_fused", kf, kf_ms, k1b + k2b), ("fk_rk4_batch", k1, k1_ms, k1b),
+                 ("backbone_voxel_sweep", k2, k2_ms, k2b)]
         dom_name, dom, dom_ms, dom_bytes = max(cands, key=lambda c: c[1]["total_ms"])
         units_per_launch = n * args.steps / max(1, dom["launches"])
         achieved = dom_bytes * units_per_launch / (dom_ms * 1e-3) / 1e9
@@ -257,7 +262,10 @@ def main():
         # (profiles/isa_counts.json <- profiles/count_isa.py; FMA = 2) x RK4 steps per configuration.  Initial
         # bending and the sweep's arithmetic are not counted.
         isa = load_isa_counts()
-        isa_key = {"fk_sweep_fused": "fk_sweep_fused<%d,false>" % N, "fk_rk4_batch": "fk_rk4_batch_uniform<%d,false,false>" % N}.get(dom_name)
+        # fk_verdict runs the RK4 step of fk_sweep_fused (same body, same instantiation flags); its own per-point sweep
+        # (~25 fp64 instructions per point) and the deferred walks are NOT counted as useful flops
+        isa_key = {"fk_verdict": "fk_sweep_fused<%d,false>" % N, "fk_sweep_fused": "fk_sweep_fused<%d,false>" % N,
+                   "fk_rk4_batch": "fk_rk4_batch_uniform<%d,false,false>" % N}.get(dom_name)
         flops_per_step = isa.get(isa_key, {}).get("flops_per_step")
         flops_per_check = flops_per_step * (P - 1) if flops_per_step else None
         hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -295,7 +303,8 @@ def main():
                        "collective": ("gloo(host)" if rehearsal else "rccl") if use_dist else None,
                        "valid_fraction_rank0": float(valid.mean())},
             "roofline": roofline,
-            "kernels": {"fk_sweep_fused": {"avg_ms": kf_ms, "launches": kf["launches"], "bytes_per_check": k1b + k2b},
+            "kernels": {"fk_verdict": {"avg_ms": kv_ms, "launches": kv["launches"], "bytes_per_check": kvb},
+                        "fk_sweep_fused": {"avg_ms": kf_ms, "launches": kf["launches"], "bytes_per_check": k1b + k2b},
                         "fk_rk4_batch": {"avg_ms": k1_ms, "launches": k1["launches"], "bytes_per_check": k1b},
                         "backbone_voxel_sweep": {"avg_ms": k2_ms, "launches": k2["launches"], "bytes_per_check": k2b}},
         }

@@ -359,8 +359,9 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
  * tr_profile_begin enables event recording around every kernel launched by this context;
  * tr_profile_read returns, per kernel slot, launches and total milliseconds since begin.
  * slots: 0 = fk_rk4_batch, 1 = backbone_voxel_sweep, 2 = cached_blocks_vs_grid, 3 = edge helpers,
- * 4 = fk_sweep_fused (K1 + K2 in one launch, the verdict path of tr_validate_batch*) */
-#define TR_PROFILE_SLOTS 5
+ * 4 = fk_sweep_fused (K1 + K2 in one launch over stored points: edge samples, voxel caches, the sphere checker, and the
+ *     fallback pass of the verdict path), 5 = fk_verdict (the verdict-only kernel of tr_validate_batch*) */
+#define TR_PROFILE_SLOTS 6
 int tr_profile_begin(tr_ctx *ctx);
 int tr_profile_read(tr_ctx *ctx, int64_t launches[TR_PROFILE_SLOTS], double total_ms[TR_PROFILE_SLOTS]);
 int tr_profile_end(tr_ctx *ctx);

@@ -19,8 +19,8 @@ TR_OK, TR_ERR_INVALID_ARG, TR_ERR_OUT_OF_RANGE, TR_ERR_DOMAIN, TR_ERR_LENGTH, TR
 
 TR_FLAG_CONVERGED, TR_FLAG_LENGTH_OK, TR_FLAG_NO_SELFCOL, TR_FLAG_NO_VOXCOL, TR_FLAG_DOMAIN = 1, 2, 4, 8, 16
 TR_CHECKER_BACKBONE, TR_CHECKER_SPHERES = 0, 1
-TR_PROFILE_SLOTS = 5
-PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_grid", "edge_helpers", "fk_sweep_fused")
+TR_PROFILE_SLOTS = 6
+PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_grid", "edge_helpers", "fk_sweep_fused", "fk_verdict")
 
 # every symbol include/tendon_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
@@ -105,15 +105,15 @@ OBJ_DIR = os.path.join(SRC_DIR, "_obj")
 def _units():
     """(object name, source, extra flags): the C ABI + K2..K6, the cache merge, and K1 once per
     (tendon count, kernel: shared grid / retraction / fused with K2) so its 64 instantiations compile in parallel."""
-    fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "sweep_kernel.hpp",
-               "tr_types.hpp"]
+    fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "verdict_kernel.hpp",
+               "sweep_kernel.hpp", "tr_types.hpp"]
     fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip"]
     main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
     u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),
          ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"]),
          ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", HEADER])]
     for n in range(1, 9):
-        for kind, tag in ((0, "u"), (1, "r"), (2, "f")):
+        for kind, tag in ((0, "u"), (1, "r"), (2, "f"), (3, "v")):
             u.append(("fk_%s%d.o" % (tag, n), "fk_inst.hip", ["-DTRK_INST_N=%d" % n, "-DTRK_INST_KIND=%d" % kind], fk_deps))
     return u
 

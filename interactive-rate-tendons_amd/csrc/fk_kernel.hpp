@@ -324,14 +324,31 @@ __device__ __forceinline__ void rk4_step_routed(double (&R)[9], double (&v)[3], 
 // K1 for the shared arc-length grid (retraction disabled).
 //   tab:   [(nsteps*3 + 1)][N][6] routing table; entry 0 = base (s_start), then 3 per step
 //   steps: [nsteps]
-template <int N, bool ROT, bool WRITE_R, bool WANT_L = true>
+// What a lane knows about its configuration when the integration ends (the verdict-only kernel continues from here).
+template <int N>
+struct FkLane {
+  bool converged;
+  double Li[N];
+};
+
+struct NoPointHook {
+  __device__ __forceinline__ void begin(bool) const {}
+  __device__ __forceinline__ void operator()(int, double, double, double) const {}
+};
+
+// on_point(j, x, y, z): called for every observed backbone point (after rotate_z), in order j = 0 .. P-1 -- the
+// verdict-only kernel sweeps the point there instead of storing it; on_point.begin(converged && live) precedes point 0.  row_map (optional): lane i integrates
+// configuration row_map[i] of `states` (the fallback pass of the verdict path works on a compacted list).
+template <int N, bool ROT, bool WRITE_R, bool WANT_L = true, class OnPoint = NoPointHook>
 __device__ __forceinline__ void fk_uniform_body(
     const double *__restrict__ states, int64_t n, int64_t ld, const RobotK &K,
-    const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, const FkOut &out) {
+    const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, const FkOut &out,
+    OnPoint &&on_point = NoPointHook(), const int32_t *__restrict__ row_map = nullptr, FkLane<N> *lane_out = nullptr) {
 #pragma clang fp contract(fast)
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = i < n;
-  const int64_t ic = live ? i : (n - 1);       // tail lanes recompute the last configuration, stores masked
+  const int64_t il = live ? i : (n - 1);       // tail lanes recompute the last configuration, stores masked
+  const int64_t ic = row_map ? (int64_t)row_map[il] : il;
   const int S = K.state_size;
   double tau[N];
 #pragma unroll
@@ -346,6 +363,7 @@ __device__ __forceinline__ void fk_uniform_body(
   double v[3], u[3];
   bool conv;
   initial_bending<N>(tau, tab, K, v, u, conv);
+  on_point.begin(conv && live);
 
   // state
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};   // column-major: R[c*3+r]
@@ -356,11 +374,13 @@ __device__ __forceinline__ void fk_uniform_body(
   for (int j = 0; j < N; j++) Li[j] = 0;
 
   auto store_point = [&](int j) {
-    if (!live) return;
     const int64_t o = (int64_t)j * ld + i;
     double x = p[0], y = p[1], z = p[2];
-    if (ROT) { const double x2 = rc * x - rs * y, y2 = rs * x + rc * y; x = x2; y = y2; z = r22 * z; }
-    out.px[o] = x; out.py[o] = y; out.pz[o] = z;
+    // rotate_z (tendon/TendonResult.cpp:13-18); explicit FMAs so that every kernel holding this body forms the same bits
+    if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
+    on_point(j, x, y, z);
+    if (!live) return;
+    if (out.px) { out.px[o] = x; out.py[o] = y; out.pz[o] = z; }
     if (WRITE_R) {
       const int64_t PS = (int64_t)K.n_points * ld;
 #pragma unroll
@@ -445,9 +465,14 @@ __device__ __forceinline__ void fk_uniform_body(
     if (out.n_points) out.n_points[i] = K.n_points;
     if (out.tips) {
       double x = p[0], y = p[1], z = p[2];
-      if (ROT) { const double x2 = rc * x - rs * y, y2 = rs * x + rc * y; x = x2; y = y2; z = r22 * z; }
+      if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
       out.tips[3 * i + 0] = x; out.tips[3 * i + 1] = y; out.tips[3 * i + 2] = z;
     }
+  }
+  if (lane_out) {
+    lane_out->converged = conv;
+#pragma unroll
+    for (int j = 0; j < N; j++) lane_out->Li[j] = Li[j];
   }
 }
 

@@ -29,4 +29,28 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_sw
   sweep_body<false>(a.in, n, ld, a.P, a.CH, a.NM, K, a.g, a.grid, a.near_grid, a.check_voxels, a.debug, a.valid_bits, a.flags);
 }
 
+// The same on a compacted list of configurations: this is the fallback pass of the verdict-only kernel
+// (verdict_kernel.hpp) for the few configurations whose self-collision test needs the exact pairwise sweep, i.e. all of
+// their backbone points at once: they are integrated again, this time storing the points in a small workspace of `cap`
+// columns.  Block b owns columns [64 b, 64 b + 64) and walks the list in strides of `cap`: in round r its lane i takes
+// configuration list[r cap + 64 b + i] (while that index is below *count) and ORs its verdict bit into the mask.  A block
+// leaves as soon as its slice of the list is exhausted, so with an empty list the launch costs nothing.
+template <int N, bool ROT>
+__global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_sweep_fused_list(
+    const double *__restrict__ states, int64_t cap, int64_t ld, RobotK K, const double *__restrict__ tab,
+    const StepK *__restrict__ steps, int nsteps, FkOut out, const FusedSweepArgs *__restrict__ sa,
+    const int32_t *__restrict__ list, const uint32_t *__restrict__ count) {
+  const int64_t total = (int64_t)*count;
+  for (int64_t offset = 0; offset < total; offset += cap) {
+    const int64_t left = total - offset;
+    const int64_t m = left < cap ? left : cap;
+    if ((int64_t)blockIdx.x * 64 >= m) break;                     // wave-uniform
+    fk_uniform_body<N, ROT, false, false>(states, m, ld, K, tab, steps, nsteps, out, NoPointHook(), list + offset);
+    __syncthreads();
+    const FusedSweepArgs a = *sa;
+    sweep_body<false>(a.in, m, ld, a.P, a.CH, a.NM, K, a.g, a.grid, a.near_grid, a.check_voxels, a.debug, a.valid_bits, a.flags, list + offset);
+    __syncthreads();
+  }
+}
+
 }  // namespace trk

@@ -321,6 +321,47 @@ __device__ __forceinline__ bool exact_self_collision(const SweepIn &in, int64_t 
   return selfhit;
 }
 
+// Pass 2 of the sweep: proves the absence of self collision from the LDS milestones alone whenever it can (the three
+// tests are described above sweep_body).  mx .. ma: the lane's milestone columns ([k * 64]); Kl: the lane's last milestone
+// index; on: the lane takes part.  Returns true for a lane some span of which could not be cleared.
+__device__ __forceinline__ bool milestones_unresolved(const float *__restrict__ mx, const float *__restrict__ my, const float *__restrict__ mz,
+                                                      const float *__restrict__ ma, int NM, int Kl, bool on, float r) {
+#pragma clang fp contract(off)
+  const float mrg = 1e-6f;
+  const float gate = 3.0f * r - mrg, aslack = r - mrg, bclear = 2.0f * r + mrg;
+  bool unresolved = false;
+  for (int a = 0; a < NM - 1; ++a) {
+    const bool on_a = on && !unresolved && a < Kl;
+    if (!__any(on_a)) break;
+    if (on_a) {
+      const float ax = mx[a * 64], ay = my[a * 64], az = mz[a * 64], aa = ma[a * 64];
+      // whole remaining span first: s - c is monotone in the span, so this clears the row
+      {
+        const float ex = mx[Kl * 64] - ax, ey = my[Kl * 64] - ay, ez = mz[Kl * 64] - az;
+        const float s = ma[Kl * 64] - aa;
+        if (s < gate || s - sqrtf(ex * ex + ey * ey + ez * ez) < aslack) continue;
+      }
+      const float a1x = mx[(a + 1) * 64], a1y = my[(a + 1) * 64], a1z = mz[(a + 1) * 64], a1a = ma[(a + 1) * 64];
+      const float Max = 0.5f * (ax + a1x), May = 0.5f * (ay + a1y), Maz = 0.5f * (az + a1z);
+      const float rho_a = 0.5f * (a1a - aa);
+      for (int b = a + 1; b <= Kl; ++b) {
+        const float bx = mx[b * 64], by = my[b * 64], bz = mz[b * 64], ba = ma[b * 64];
+        const float s = ba - aa;
+        if (s < gate) continue;
+        const float ex = bx - ax, ey = by - ay, ez = bz - az;
+        if (s - sqrtf(ex * ex + ey * ey + ez * ez) < aslack) continue;
+        // (B) first chunk [a, a+1] vs last chunk [b-1, b] of the span
+        const float cx = mx[(b - 1) * 64], cy = my[(b - 1) * 64], cz = mz[(b - 1) * 64], ca = ma[(b - 1) * 64];
+        const float fx = 0.5f * (bx + cx) - Max, fy = 0.5f * (by + cy) - May, fz = 0.5f * (bz + cz) - Maz;
+        if (sqrtf(fx * fx + fy * fy + fz * fz) - rho_a - 0.5f * (ba - ca) > bclear) continue;
+        unresolved = true;
+        break;
+      }
+    }
+  }
+  return unresolved;
+}
+
 // K2.  One wave per block; dynamic LDS = 4 * NM * 64 floats (milestone x, y, z, arc per lane).
 //
 // Pass 1 streams every backbone point ONCE (coalesced, lane-contiguous): accumulated chord length,
@@ -338,13 +379,14 @@ __device__ __forceinline__ bool exact_self_collision(const SweepIn &in, int64_t 
 // cleared falls back to pass 3, the exact pairwise sweep -- rare (tight curls only).
 //   debug bit0: brute-force pairs in pass 3;  bit1: skip pass 2 (every lane takes pass 3);
 //         bit2: disable the dilated-grid fast path of the voxel walk.
+// out_map (optional): see the end of the function.
 // TIPROWS (retraction robots, in.n_points set): K1r stores a lane's point j in row j + (P - n_points), i.e. rows
 // are aligned at the tip like K1r's iterations, so that its stores -- and the loads here -- stay coalesced.
 template <bool TIPROWS>
 __device__ __forceinline__ void sweep_body(
     const SweepIn &in, int64_t n, int64_t ld, int P, int CH, int NM, const RobotK &K, const GridK &g, const uint64_t *__restrict__ grid,
     const uint64_t *__restrict__ near_grid, int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits,
-    uint8_t *__restrict__ flags) {
+    uint8_t *__restrict__ flags, const int32_t *__restrict__ out_map = nullptr) {
 #pragma clang fp contract(off)
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
@@ -507,44 +549,9 @@ __device__ __forceinline__ void sweep_body(
   }
   if (alive && !(dist < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
 
-  // Pass 2: milestone proof of "no self collision".
+  // Pass 2: milestone proof of "no self collision" (milestones_unresolved).
   bool need_exact = alive && np > 2;
-  if (!(debug & 2u) && __any(need_exact)) {
-    const float r = (float)K.radius;
-    const float mrg = 1e-6f;
-    const float gate = 3.0f * r - mrg, aslack = r - mrg, bclear = 2.0f * r + mrg;
-    bool unresolved = false;
-    for (int a = 0; a < NM - 1; ++a) {
-      const bool on_a = need_exact && !unresolved && a < Kl;
-      if (!__any(on_a)) break;
-      if (on_a) {
-        const float ax = mx[a * 64], ay = my[a * 64], az = mz[a * 64], aa = ma[a * 64];
-        // whole remaining span first: s - c is monotone in the span, so this clears the row
-        {
-          const float ex = mx[Kl * 64] - ax, ey = my[Kl * 64] - ay, ez = mz[Kl * 64] - az;
-          const float s = ma[Kl * 64] - aa;
-          if (s < gate || s - sqrtf(ex * ex + ey * ey + ez * ez) < aslack) continue;
-        }
-        const float a1x = mx[(a + 1) * 64], a1y = my[(a + 1) * 64], a1z = mz[(a + 1) * 64], a1a = ma[(a + 1) * 64];
-        const float Max = 0.5f * (ax + a1x), May = 0.5f * (ay + a1y), Maz = 0.5f * (az + a1z);
-        const float rho_a = 0.5f * (a1a - aa);
-        for (int b = a + 1; b <= Kl; ++b) {
-          const float bx = mx[b * 64], by = my[b * 64], bz = mz[b * 64], ba = ma[b * 64];
-          const float s = ba - aa;
-          if (s < gate) continue;
-          const float ex = bx - ax, ey = by - ay, ez = bz - az;
-          if (s - sqrtf(ex * ex + ey * ey + ez * ez) < aslack) continue;
-          // (B) first chunk [a, a+1] vs last chunk [b-1, b] of the span
-          const float cx = mx[(b - 1) * 64], cy = my[(b - 1) * 64], cz = mz[(b - 1) * 64], ca = ma[(b - 1) * 64];
-          const float fx = 0.5f * (bx + cx) - Max, fy = 0.5f * (by + cy) - May, fz = 0.5f * (bz + cz) - Maz;
-          if (sqrtf(fx * fx + fy * fy + fz * fz) - rho_a - 0.5f * (ba - ca) > bclear) continue;
-          unresolved = true;
-          break;
-        }
-      }
-    }
-    need_exact = unresolved;
-  }
+  if (!(debug & 2u) && __any(need_exact)) need_exact = milestones_unresolved(mx, my, mz, ma, NM, Kl, need_exact, (float)K.radius);
 
   // Pass 3 (rare): exact pairwise sweep for the lanes pass 2 could not clear: accumulated chord
   // lengths in fp64 exactly as collision.cpp:21-30 forms them, then the pair loops.
@@ -577,6 +584,16 @@ __device__ __forceinline__ void sweep_body(
   if (valid) { if (!selfhit) fl |= 4u; else valid = false; }
   if (valid && check_voxels) { if (!hit) fl |= 8u; else valid = false; }
 
+  if (out_map) {
+    // compacted list (the fallback pass of the verdict path): column i is configuration out_map[i]; its verdict bit is
+    // still 0 in the mask, its flags are overwritten
+    if (live) {
+      const int64_t c = out_map[i];
+      if (valid) atomicOr((unsigned long long *)&valid_bits[c >> 6], 1ull << (c & 63));
+      if (flags) flags[c] = (uint8_t)fl;
+    }
+    return;
+  }
   const uint64_t bits = __ballot(valid && live);
   if (lane == 0 && i < n) valid_bits[i >> 6] = bits;
   if (flags && live) flags[i] = (uint8_t)fl;

@@ -27,6 +27,7 @@
 #include "tr_types.hpp"
 #include "fk_launch.hpp"
 #include "sweep_kernel.hpp"
+#include "verdict_kernel.hpp"
 #include "edge_kernel.hpp"
 #include "knn_kernel.hpp"
 #include "cache_merge.hpp"
@@ -109,8 +110,19 @@ struct tr_ctx {
   int64_t edge_pool_max = 1 << 22; // samples held at once by tr_validate_edges / tr_voxelize_edges
   double ch_scale = 2.0;          // milestone spacing of K2 in robot radii (env TENDON_HIP_CH_SCALE, tuning only)
   int64_t k1_round = 1 << 17;     // configurations in one resident round of K1 waves (CUs x 4 SIMDs x waves/SIMD x 64)
-  // tr_validate_batch*: K1 + K2 as one kernel (fused_kernel.hpp).  env TENDON_HIP_FUSED=0 keeps them apart.
-  bool fuse = true;
+  // tr_validate_batch*: 2 (default) = verdict-only kernel (verdict_kernel.hpp: no point storage) for the backbone checker
+  // on robots without retraction, 1 = K1 + K2 as one kernel over stored points (fused_kernel.hpp), 0 = separate launches.
+  // env TENDON_HIP_FUSED selects; the edge calls, the sphere checker and the voxel caches need the points and use 1 / 0.
+  int fuse = 2;
+  int64_t fb_cap = 1 << 16;       // columns of the fallback pass's point workspace (env TENDON_HIP_FB_CAP: testing)
+  int32_t *d_fb_list = nullptr; uint32_t *d_fb_count = nullptr; int64_t fb_list_cap = 0;
+  struct VerdictRing {
+    static constexpr int kSlots = 16;
+    trk::VerdictArgs *d_slots = nullptr, *h_slots = nullptr;
+    hipEvent_t ev[kSlots];
+    bool used[kSlots] = {};
+    int next = 0;
+  } vring;
   struct FusedRing {
     static constexpr int kSlots = 16;
     trk::FusedSweepArgs *d_slots = nullptr, *h_slots = nullptr;   // device ring and its pinned host image
@@ -342,13 +354,11 @@ int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int
   return TR_OK;
 }
 
-// K1 + K2 in one launch (fused_kernel.hpp; shared arc-length grid only).  The sweep's arguments go
-// through a small ring of device slots filled from pinned host memory (an asynchronous copy on the
-// launch stream), each guarded by an event so a slot is not rewritten while a launch may still read it.
-int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
-                 int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
-  if (n <= 0) return TR_OK;
-  if (check_voxels && !ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+// A device copy of the sweep's arguments for one fused launch: a small ring of device slots filled from pinned host
+// memory (an asynchronous copy on the launch stream), each guarded by an event so a slot is not rewritten while a
+// launch may still read it.  *slot_out receives the slot (record fr.ev[slot] on the stream after the launch).
+int fused_args_slot(tr_ctx *ctx, const trk::SweepIn &in, int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s,
+                    const trk::FusedSweepArgs **d_args, size_t *lds, int *slot_out) {
   tr_ctx::FusedRing &fr = ctx->fused;
   if (!fr.d_slots) {
     HIP_TRY(ctx, hipMalloc((void **)&fr.d_slots, sizeof(trk::FusedSweepArgs) * tr_ctx::FusedRing::kSlots));
@@ -363,25 +373,115 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
   trk::FusedSweepArgs &a = fr.h_slots[slot];
   a = trk::FusedSweepArgs{};
   a.in = in;
-  size_t lds;
-  sweep_geometry(ctx, a.CH, a.NM, lds);
+  sweep_geometry(ctx, a.CH, a.NM, *lds);
   a.P = ctx->K.n_points; a.check_voxels = check_voxels; a.debug = ctx->debug;
   a.g = ctx->G; a.grid = ctx->d_grid; a.near_grid = ctx->d_near; a.valid_bits = d_bits; a.flags = d_flags;
   HIP_TRY(ctx, hipMemcpyAsync(fr.d_slots + slot, &a, sizeof(a), hipMemcpyHostToDevice, s));   // pinned source: asynchronous
+  *d_args = fr.d_slots + slot;
+  *slot_out = slot;
+  return TR_OK;
+}
+
+// K1 + K2 in one launch (fused_kernel.hpp; shared arc-length grid only).
+int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
+                 int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
+  if (n <= 0) return TR_OK;
+  if (check_voxels && !ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  const trk::FusedSweepArgs *d_args; size_t lds; int slot, rc;
+  if ((rc = fused_args_slot(ctx, in, check_voxels, d_bits, d_flags, s, &d_args, &lds, &slot))) return rc;
   {
     ProfScope ps(ctx, 4, s);
     const trk::FkLaunch fl{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                            (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, out, s};
     switch (ctx->K.n_tendons) {
-#define TRK_CASE(N) case N: trk::launch_fk_sweep_fused<N>(fl, fr.d_slots + slot, lds); break;
+#define TRK_CASE(N) case N: trk::launch_fk_sweep_fused<N>(fl, d_args, lds); break;
       TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
       default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
     }
     HIP_TRY(ctx, hipGetLastError());
   }
-  HIP_TRY(ctx, hipEventRecord(fr.ev[slot], s));
-  fr.used[slot] = true;
+  HIP_TRY(ctx, hipEventRecord(ctx->fused.ev[slot], s));
+  ctx->fused.used[slot] = true;
+  return TR_OK;
+}
+
+// The verdict path of tr_validate_batch* (verdict_kernel.hpp): fk_verdict over the n configurations -- no backbone point
+// is stored -- then ONE launch of fk_sweep_fused_list, which integrates again, with stored points, the configurations whose
+// self-collision test needs the exact pairwise sweep (their indices and count stay on the device; with an empty list its
+// blocks return at once).  d_bits / d_flags / d_tips as in tr_validate_batch_dev; n <= 2^31.
+int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_bits, double *d_tips, uint8_t *d_flags, hipStream_t s) {
+  if (n <= 0) return TR_OK;
+  if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  int rc;
+  Workspace &w = ctx->ws;
+  if (ctx->fb_list_cap < n) {
+    HIP_TRY(ctx, hipDeviceSynchronize());
+    if ((rc = dev_alloc(ctx, &ctx->d_fb_list, (size_t)round_up(n, 64)))) return rc;
+    if (!ctx->d_fb_count && (rc = dev_alloc(ctx, &ctx->d_fb_count, 1))) return rc;
+    ctx->fb_list_cap = round_up(n, 64);
+  }
+  const int64_t cap = std::min<int64_t>(ctx->fb_cap, round_up(n, 64));
+  if ((rc = ensure_workspace(ctx, cap))) return rc;
+  tr_ctx::VerdictRing &vr = ctx->vring;
+  if (!vr.d_slots) {
+    HIP_TRY(ctx, hipMalloc((void **)&vr.d_slots, sizeof(trk::VerdictArgs) * tr_ctx::VerdictRing::kSlots));
+    HIP_TRY(ctx, hipHostMalloc((void **)&vr.h_slots, sizeof(trk::VerdictArgs) * tr_ctx::VerdictRing::kSlots, hipHostMallocDefault));
+    for (auto &e : vr.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int vslot = vr.next;
+  vr.next = (vr.next + 1) % tr_ctx::VerdictRing::kSlots;
+  if (vr.used[vslot]) HIP_TRY(ctx, hipEventSynchronize(vr.ev[vslot]));
+  trk::VerdictArgs &a = vr.h_slots[vslot];
+  a = trk::VerdictArgs{};
+  size_t lds_k2;
+  sweep_geometry(ctx, a.CH, a.NM, lds_k2);
+  a.P = ctx->K.n_points; a.debug = ctx->debug;
+  a.g = ctx->G; a.grid = ctx->d_grid; a.near_grid = ctx->d_near; a.valid_bits = d_bits; a.flags = d_flags;
+  {
+    const GridK &g = ctx->G;            // sweep_body's margin box, same expressions (this file is compiled without contraction)
+    a.box[0] = g.xmin + 1e-6 * (g.xmax - g.xmin); a.box[1] = g.xmax - 1e-6 * (g.xmax - g.xmin);
+    a.box[2] = g.ymin + 1e-6 * (g.ymax - g.ymin); a.box[3] = g.ymax - 1e-6 * (g.ymax - g.ymin);
+    a.box[4] = g.zmin + 1e-6 * (g.zmax - g.zmin); a.box[5] = g.zmax - 1e-6 * (g.zmax - g.zmin);
+  }
+  a.fb_list = ctx->d_fb_list; a.fb_count = ctx->d_fb_count;
+  HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
+  HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb_count, 0, sizeof(uint32_t), s));
+  // the fallback pass sweeps columns of the small point workspace
+  trk::SweepIn in{w.px, w.py, w.pz, nullptr, w.Li, w.conv, nullptr, w.acc};
+  const trk::FusedSweepArgs *d_fargs; size_t lds_f; int fslot;
+  if ((rc = fused_args_slot(ctx, in, 1, d_bits, d_flags, s, &d_fargs, &lds_f, &fslot))) return rc;
+  const trk::FkOut vout{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_tips, nullptr, nullptr, nullptr};
+  const trk::FkLaunch vl{d_states, n, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
+                         (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, vout, s};
+  const trk::FkOut fout{w.px, w.py, w.pz, nullptr, nullptr, w.Li, nullptr, w.conv, nullptr, nullptr};
+  const trk::FkLaunch fl{d_states, cap, w.ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
+                         (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, fout, s};
+  const size_t lds_v = trk::verdict_lds_bytes(a.NM);
+  {
+    ProfScope ps(ctx, 5, s);
+    switch (ctx->K.n_tendons) {
+#define TRK_CASE(N) case N: trk::launch_fk_verdict<N>(vl, vr.d_slots + vslot, lds_v); break;
+      TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
+#undef TRK_CASE
+      default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  {
+    ProfScope ps(ctx, 4, s);
+    switch (ctx->K.n_tendons) {
+#define TRK_CASE(N) case N: trk::launch_fk_sweep_fused_list<N>(fl, d_fargs, lds_f, ctx->d_fb_list, ctx->d_fb_count); break;
+      TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
+#undef TRK_CASE
+      default: break;
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(vr.ev[vslot], s));
+  vr.used[vslot] = true;
+  HIP_TRY(ctx, hipEventRecord(ctx->fused.ev[fslot], s));
+  ctx->fused.used[fslot] = true;
   return TR_OK;
 }
 
@@ -418,7 +518,7 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
     if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
     if ((rc = ensure_sphere_near(ctx, s))) return rc;
   }
-  if (ctx->fuse && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
+  if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s))) return rc;
   } else {
     if ((rc = launch_fk(ctx, d_states, n, ld, out, s))) return rc;
@@ -461,7 +561,8 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (device < 0 || device >= ndev) return fail(nullptr, TR_ERR_INVALID_ARG, "bad device ordinal");
   tr_ctx *c = new tr_ctx();
   c->device = device;
-  if (const char *e = std::getenv("TENDON_HIP_FUSED")) c->fuse = std::atoi(e) != 0;
+  if (const char *e = std::getenv("TENDON_HIP_FUSED")) { const int v = std::atoi(e); c->fuse = v < 0 ? 0 : (v > 2 ? 2 : v); }
+  if (const char *e = std::getenv("TENDON_HIP_FB_CAP")) { const long long v = std::atoll(e); if (v >= 64 && v <= (1ll << 20)) c->fb_cap = (int64_t)round_up(v, 64); }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
     if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = (int64_t)round_up(v, 64);
@@ -586,6 +687,9 @@ void tr_destroy(tr_ctx *c) {
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
+  if (c->vring.d_slots) { (void)hipFree(c->vring.d_slots); (void)hipHostFree(c->vring.h_slots); for (auto &e : c->vring.ev) (void)hipEventDestroy(e); }
+  if (c->d_fb_list) (void)hipFree(c->d_fb_list);
+  if (c->d_fb_count) (void)hipFree(c->d_fb_count);
   delete c;
 }
 
@@ -771,7 +875,19 @@ int tr_reserve(tr_ctx *c, int64_t n) {
   if (!c || n < 0) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
-  int rc = ensure_workspace(c, n);
+  int rc;
+  if (c->fuse == 2 && !c->K.enable_retraction && c->checker == TR_CHECKER_BACKBONE) {
+    // the verdict path keeps no points: a list of fallback candidates and the fallback pass's small workspace
+    if (c->fb_list_cap < n) {
+      HIP_TRY(c, hipDeviceSynchronize());
+      if ((rc = dev_alloc(c, &c->d_fb_list, (size_t)round_up(std::max<int64_t>(n, 64), 64)))) return rc;
+      if (!c->d_fb_count && (rc = dev_alloc(c, &c->d_fb_count, 1))) return rc;
+      c->fb_list_cap = round_up(std::max<int64_t>(n, 64), 64);
+    }
+    rc = ensure_workspace(c, std::min<int64_t>(c->fb_cap, std::max<int64_t>(n, 64)));
+  } else {
+    rc = ensure_workspace(c, n);
+  }
   if (rc) return rc;
   return ensure_staging(c, n);
 }
@@ -926,11 +1042,21 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
   if (!d_states || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
   if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   int rc;
-  if ((rc = ensure_workspace(c, n))) return rc;
-  Workspace &w = c->ws;
   hipStream_t s = (hipStream_t)stream;
   const int S = c->K.state_size;
   const bool ret = c->K.enable_retraction;
+  if (c->fuse == 2 && !ret && c->checker == TR_CHECKER_BACKBONE) {
+    // verdict-only kernel: nothing but the verdict (and the tips) leaves the chip, no point workspace to size
+    const int64_t chunk = (int64_t)1 << 26;                 // list indices are 32-bit; per-launch grid stays far below 2^31 blocks
+    for (int64_t off = 0; off < n; off += chunk) {
+      const int64_t m = std::min<int64_t>(chunk, n - off);
+      if ((rc = launch_verdict(c, d_states + off * S, m, d_valid_bits + off / 64, d_tips ? d_tips + 3 * off : nullptr,
+                               d_flags ? d_flags + off : nullptr, s))) return rc;
+    }
+    return TR_OK;
+  }
+  if ((rc = ensure_workspace(c, n))) return rc;
+  Workspace &w = c->ws;
   for (int64_t off = 0; off < n; off += w.ld) {
     const int64_t m = std::min<int64_t>(w.ld, n - off);
     trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, d_tips ? d_tips + 3 * off : nullptr, w.conv,
@@ -986,7 +1112,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
   tr_ctx::Pipe &p = c->pipe;
   const int64_t CH = p.chunk;
   if ((rc = ensure_staging(c, std::min(n, 2 * CH)))) return rc;
-  if ((rc = ensure_workspace(c, std::min(n, CH)))) return rc;
+  if (!(c->fuse == 2 && !c->K.enable_retraction && c->checker == TR_CHECKER_BACKBONE) && (rc = ensure_workspace(c, std::min(n, CH)))) return rc;
   HIP_TRY(c, hipDeviceSynchronize());          // earlier work on other streams (e.g. a *_dev call) is finished
   Workspace &w = c->ws;
   const int S = c->K.state_size;

@@ -1,0 +1,242 @@
+// verdict_kernel.hpp -- `fk_verdict`: the whole validity predicate of a configuration in ONE pass, without ever storing
+// its backbone: every point leaves the RK4 loop straight into the sweep (what K2 `backbone_voxel_sweep` does on stored
+// points, sweep_kernel.hpp) and only the verdict bit (+ the tip, + optional flags) reaches memory -- 24 B in, ~24 B
+// out per configuration instead of the 6 274 B the K1 -> K2 pair moves through HBM, and no 4 GB point workspace.
+//
+// Per observed point, between two RK4 steps (the integrator's temporaries are dead there, so this costs the hot loop
+// two live registers -- the prefetched dilated-grid word -- and nothing else; all other per-lane sweep state sits in LDS):
+//   * chord length in float and, every CH-th point, a milestone (x, y, z, arc) for the self-collision proof;
+//   * the point's cell; a segment whose end cells differ by at most one per axis and whose START cell is free in the
+//     2-cell-dilated grid cannot touch an occupied cell (see line_hits) and is done;
+//   * every other segment (~3 %: larger cell steps, near obstacles, at the domain boundary) is queued in LDS with both
+//     of its end points, and the queue is worked off 64 at a time, one add_line walk per lane (walk_cells: the
+//     reference's DDA, bit-exact), a hit returning through the owner lane's LDS flag.
+// After the loop: the milestone proof of "no self collision" (milestones_unresolved).  The few configurations it
+// cannot clear need the exact pairwise sweep over ALL their points, which no longer exist: their indices go to a
+// compacted list and `fk_sweep_fused_list` (fused_kernel.hpp) integrates just those again with stored points and ORs
+// their bits into the mask.  Every decision is formed by the same expressions as in sweep_body, so the verdict bits and
+// flags are identical to those of the separate kernels.
+#pragma once
+#include "fk_kernel.hpp"
+#define TRK_DEVICE_BODIES_ONLY
+#include "sweep_kernel.hpp"
+
+namespace trk {
+
+struct VerdictArgs {
+  int P, CH, NM, pad0_;
+  uint32_t debug, pad1_;
+  double box[6];                  // the margin box of sweep_body: {x0, x1, y0, y1, z0, z1} = limits -+ 1e-6 of the extent (same expressions, formed on the host)
+  GridK g;
+  const uint64_t *grid, *near_grid;
+  uint64_t *valid_bits;
+  uint8_t *flags;                 // optional
+  int32_t *fb_list;               // configurations that need the exact self-collision sweep
+  uint32_t *fb_count;
+};
+
+constexpr int VQ = 128;           // ring of deferred segments per wave
+
+// Dynamic LDS of one wave.  Everything is addressed as vlds[constant + lane] (never through a stored pointer: hipcc then
+// keeps the accesses in the LDS address space -- ds_read / ds_write -- instead of falling back to flat accesses).
+//   doubles [0, 192)           prev[3][64]     previous point (as produced, before the environment rotation)
+//   doubles [192, 192 + 6 VQ)  qe[6][VQ]       deferred segments: rotated end points a, b
+//   words from 2 * (192 + 6 VQ):  qowner[VQ] | cell[3][64] | inprev[64] | hitflag[64] | dist[64] | milestones float[4][NM][64]
+extern __shared__ double vlds[];
+constexpr int VL_QE = 3 * 64;
+constexpr int VL_W0 = 2 * (VL_QE + 6 * VQ);
+constexpr int VL_QOWNER = VL_W0, VL_CELL = VL_QOWNER + VQ, VL_INPREV = VL_CELL + 3 * 64, VL_HIT = VL_INPREV + 64,
+              VL_DIST = VL_HIT + 64, VL_MS = VL_DIST + 64;
+__host__ __device__ inline size_t verdict_lds_bytes(int NM) { return (size_t)VL_MS * 4 + (size_t)4 * NM * 64 * sizeof(float); }
+
+// (plain accesses: hipcc does not move `volatile` ones into the LDS address space; the compiler barriers at both ends of
+// the per-point code keep it from promoting this state to registers across the RK4 loop)
+#define VL_D(i) (((double *)vlds)[(i)])
+#define VL_U(i) (((uint32_t *)vlds)[(i)])
+#define VL_I(i) (((int32_t *)vlds)[(i)])
+#define VL_F(i) (((float *)vlds)[(i)])
+#define VL_BARRIER() asm volatile("" ::: "memory")
+
+// The per-point sweep: what sweep_body's pass 1 does with a stored point, done when the point is produced.
+struct PointSweep {
+  const VerdictArgs *va;
+  uint64_t near_prev;             // dilated-grid word of the previous point's block (requested one point ahead)
+  int qhead, qcount;              // wave-uniform
+  int P, CH, NM, Kl, ms_next, ms_k;   // wave-uniform: point count, milestone spacing / count, last milestone, next milestone row / index
+  bool active;                    // live && converged: only these lanes test voxels
+
+  __device__ __forceinline__ void begin(bool on) { active = on; }
+
+  __device__ __forceinline__ const VerdictArgs &args() const {
+    // index the argument block with a zero the optimiser cannot see through: the address is then not loop-invariant, so
+    // the arguments are re-read through the scalar cache when a point is swept (s_load: the pointer still is the kernel's
+    // read-only argument) instead of occupying ~60 SGPRs across the RK4 loop
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    return va[zero];
+  }
+
+  __device__ __forceinline__ void flush() {
+#pragma clang fp contract(off)
+    const VerdictArgs &a = args();
+    const int lane = threadIdx.x;
+    __syncthreads();
+    const int cnt = qcount < 64 ? qcount : 64;
+    if (lane < cnt) {
+      const int slot = (qhead + lane) & (VQ - 1);
+      const V3 pa = {VL_D(VL_QE + 0 * VQ + slot), VL_D(VL_QE + 1 * VQ + slot), VL_D(VL_QE + 2 * VQ + slot)};
+      const V3 pb = {VL_D(VL_QE + 3 * VQ + slot), VL_D(VL_QE + 4 * VQ + slot), VL_D(VL_QE + 5 * VQ + slot)};
+      const int owner = (int)VL_U(VL_QOWNER + slot);
+      V3 A, B;
+      bool inside, bad = false, h = false;
+      if (line_setup(pa, pb, a.g, A, B, inside, bad)) {
+        GridCursor wc{a.grid, a.g.Nb, -1, 0ull};
+        h = walk_cells(A, B, a.g, [&](int x, int y, int z) { return wc.occupied(x, y, z); });
+      }
+      if (h || bad) atomicOr(&((uint32_t *)vlds)[VL_HIT + owner], (h ? 1u : 0u) | (bad ? 2u : 0u));
+    }
+    qhead = (qhead + cnt) & (VQ - 1);
+    qcount -= cnt;
+    __syncthreads();
+  }
+
+  // point j of the lane's backbone (j = 0 .. P-1, in order)
+  __device__ __forceinline__ void operator()(int j, double x, double y, double z) {
+#pragma clang fp contract(off)
+    VL_BARRIER();
+    const VerdictArgs &a = args();
+    const GridK &g = a.g;
+    const int lane = threadIdx.x;
+    const V3 q = {x, y, z};
+    V3 pv = q;
+    float d = 0.0f;
+    if (j > 0) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(VL_DIST + lane); }
+    {
+      const float dx = (float)(q.x - pv.x), dy = (float)(q.y - pv.y), dz = (float)(q.z - pv.z);
+      d += sqrtf(dx * dx + dy * dy + dz * dz);
+      VL_F(VL_DIST + lane) = d;
+    }
+    if (j == ms_next || j == P - 1) {                       // wave-uniform: every CH-th point and the tip
+      const int k = (j == P - 1) ? Kl : ms_k;
+      const int o = VL_MS + k * 64 + lane, pl = NM * 64;
+      VL_F(o) = (float)q.x; VL_F(o + pl) = (float)q.y; VL_F(o + 2 * pl) = (float)q.z; VL_F(o + 3 * pl) = d;
+      if (j == ms_next) { ms_next += CH; ms_k++; }
+    }
+    VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
+    bool need = false;
+    V3 pr = pv, qr = q;
+    if (active && !VL_U(VL_HIT + lane)) {
+      if (!g.rot_is_identity) {
+        qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
+        qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
+        qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
+        pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
+        pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
+        pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
+      }
+      const bool in_q = qr.x > a.box[0] && qr.x < a.box[1] && qr.y > a.box[2] && qr.y < a.box[3] && qr.z > a.box[4] && qr.z < a.box[5];
+      const V3 Bq = {(qr.x - g.xmin) * g.inv_dx, (qr.y - g.ymin) * g.inv_dy, (qr.z - g.zmin) * g.inv_dz};
+      // inside the margin box the voxel coordinates are in (0, N): floor == truncation, no range checks
+      const int cqx = (int)Bq.x, cqy = (int)Bq.y, cqz = (int)Bq.z;
+      const bool use_near = a.near_grid != nullptr && !(a.debug & 4u);
+      if (j > 0) {
+        need = true;                                        // at the domain boundary: the full reference path, in the flush
+        if (VL_U(VL_INPREV + lane) && in_q) {
+          const int cpx = VL_I(VL_CELL + lane), cpy = VL_I(VL_CELL + 64 + lane), cpz = VL_I(VL_CELL + 128 + lane);
+          const int ddx = cqx - cpx, ddy = cqy - cpy, ddz = cqz - cpz;
+          const bool nearby = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1;
+          const bool start_free = use_near && !((near_prev >> (((cpx & 3) << 4) | ((cpy & 3) << 2) | (cpz & 3))) & 1ull);
+          need = !(nearby && start_free);
+        }
+      }
+      VL_I(VL_CELL + lane) = cqx; VL_I(VL_CELL + 64 + lane) = cqy; VL_I(VL_CELL + 128 + lane) = cqz;
+      VL_U(VL_INPREV + lane) = in_q ? 1u : 0u;
+      if (use_near && in_q) near_prev = a.near_grid[((size_t)(cqx >> 2) * g.Nb + (cqy >> 2)) * g.Nb + (cqz >> 2)];
+    }
+    const unsigned long long wm = __ballot(need);
+    if (wm) {
+      if (need) {
+        const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
+        VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
+        VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z;
+        VL_U(VL_QOWNER + slot) = (uint32_t)lane;
+      }
+      qcount += __popcll(wm);
+      if (qcount >= 64) flush();
+    }
+    VL_BARRIER();
+  }
+};
+
+template <int N, bool ROT>
+__global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
+    const double *__restrict__ states, int64_t n, RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps,
+    int nsteps, double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
+  const int lane = threadIdx.x;
+  PointSweep ps;
+  ps.va = va;
+  ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
+  ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
+  VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
+  __syncthreads();
+
+  FkLane<N> fl_;
+  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tips, nullptr, nullptr, nullptr};
+  fk_uniform_body<N, ROT, false, false>(states, n, 0, K, tab, steps, nsteps, out, ps, nullptr, &fl_);
+
+  // ---- what sweep_body does after its pass 1 (comparisons and one subtraction: nothing here can contract) ----
+  while (ps.qcount > 0) ps.flush();
+  __syncthreads();
+  const VerdictArgs a = *va;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i < n;
+  const int P = a.P;
+  const int Kl = (P - 1 + a.CH - 1) / a.CH;
+  const bool conv_ok = live && fl_.converged;
+  bool len_ok = false;
+  if (conv_ok) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double dl = K.home_Li[j] - fl_.Li[j];
+      if (dl < K.min_len[j] || K.max_len[j] < dl) ok = false;
+    }
+    len_ok = ok;
+  }
+  bool alive = conv_ok && len_ok;
+  const uint32_t hf = VL_U(VL_HIT + lane);
+  const bool hit = (hf & 1u) != 0;
+  bool bad = (hf & 2u) != 0;
+  if (alive && !(VL_F(VL_DIST + lane) < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
+  bool need_exact = alive && P > 2;
+  if (!(a.debug & 2u) && __any(need_exact)) {
+    const float *mx = (const float *)vlds + VL_MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
+    need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)K.radius);
+  }
+
+  uint32_t fl = 0;
+  if (conv_ok) fl |= 1u;
+  if (conv_ok && len_ok) fl |= 2u;
+  bool valid = conv_ok && len_ok;
+  if (valid && bad) { fl |= 16u; valid = false; }
+  // unresolved self collision: decided by the fallback pass -- unless an obstacle hit already settles the verdict and
+  // nobody asked for the flags (which record the self-collision result on their own)
+  const bool pending = valid && need_exact && (a.flags != nullptr || !hit);
+  if (valid && !pending) {
+    if (!need_exact) { fl |= 4u; if (!hit) fl |= 8u; else valid = false; }
+    else valid = false;                                       // hit, flags not wanted
+  }
+  if (pending) valid = false;                                 // its bit is ORed in by fk_sweep_fused_list
+  const uint64_t bits = __ballot(valid && live);
+  if (lane == 0 && live) a.valid_bits[i >> 6] = bits;
+  if (a.flags && live) a.flags[i] = (uint8_t)fl;
+  const unsigned long long pm = __ballot(pending);
+  if (pm) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.fb_count, (uint32_t)__popcll(pm));
+    base = __shfl(base, 0, 64);
+    if (pending) a.fb_list[base + __popcll(pm & (((unsigned long long)1 << lane) - 1))] = (int32_t)i;
+  }
+}
+
+}  // namespace trk

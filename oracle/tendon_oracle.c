@@ -1679,7 +1679,13 @@ int orc_roadmap_query(orc_roadmap *r, const orc_grid *obstacles, int start, int 
       int i = len - 1;
       for (int v = goal;; v = r->parent[v]) { path_out[i--] = v; if (v == start) break; }
     }
-    for (int v = goal; v != start; v = r->parent[v]) cost += r->w[r->parent_e[v]];
+    {  /* solution->cost(opt_) (:2080): ompl::geometric::PathGeometric::cost accumulates from the start state on */
+      int32_t *pe = (int32_t *)malloc(sizeof(int32_t) * (size_t)len);
+      int k = 0;
+      for (int v = goal; v != start; v = r->parent[v]) pe[k++] = r->parent_e[v];
+      while (k-- > 0) cost += r->w[pe[k]];
+      free(pe);
+    }
     n = len;
     break;
   }

@@ -14,7 +14,7 @@ import glob
 import json
 import sys
 
-NAMES = {"fk_sweep_fused": "fk_sweep_fused", "fk_rk4_batch": "fk_rk4_batch", "backbone_voxel_sweep": "backbone_voxel_sweep",
+NAMES = {"fk_verdict": "fk_verdict", "fk_sweep_fused": "fk_sweep_fused", "fk_rk4_batch": "fk_rk4_batch", "backbone_voxel_sweep": "backbone_voxel_sweep",
          "cached_blocks_vs_grid": "cached_blocks_vs_grid"}
 
 

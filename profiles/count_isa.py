@@ -8,8 +8,10 @@ profiles/isa_counts.json -- the figure bench.py turns into `roofline.achieved` f
 
 How: the kernel is compiled to assembly (`hipcc -S --cuda-device-only`, same flags as the build); LLVM annotates
 every basic block with the loop it belongs to ("in Loop: Header=BBx_y"); the RK4 loop is the loop holding the
-most v_fma_f64 instructions; every v_*_f64 instruction in its blocks is counted once (the loop body is
-straight-line per step: the only inner branches are exec-mask skips of the point store).
+most v_fma_f64 instructions; every v_*_f64 instruction in its blocks is counted once.  Blocks of loops nested inside it
+(the DDA walk of fk_verdict's deferred segments) are not counted, and neither are `rare_blocks`: blocks of the RK4 loop
+that hold IEEE division / square-root expansions (v_div_scale_f64 ...), which the RK4 step itself never uses -- in
+fk_verdict they are the set-up of the deferred walks, executed for ~3 % of the points by a few lanes.
 """
 import collections
 import json
@@ -31,6 +33,18 @@ FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_rcp
 
 KERNELS = {
     # name -> (translation unit, steps per configuration are supplied by the caller: P - 1)
+    "fk_verdict<3,false>": r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "verdict_kernel.hpp"
+template __global__ void trk::fk_verdict<3, false>(const double*, int64_t, RobotK, const double*, const StepK*, int, double*, const trk::VerdictArgs*);
+''',
+    "fk_verdict<4,false>": r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "verdict_kernel.hpp"
+template __global__ void trk::fk_verdict<4, false>(const double*, int64_t, RobotK, const double*, const StepK*, int, double*, const trk::VerdictArgs*);
+''',
     "fk_sweep_fused<3,false>": r'''
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
@@ -62,27 +76,26 @@ template __global__ void trk::fk_rk4_batch_uniform<4, false, false>(const double
 }
 
 _BLOCK = re.compile(r"^(\.LBB\d+_\d+):\s*(?:;\s*(.*))?$")
+_FALL = re.compile(r"^; (%bb\.\d+):\s*(?:;\s*(.*))?$")          # fall-through block without a label
 _HDR = re.compile(r"Header=(BB\d+_\d+)")
 _INSN = re.compile(r"^\s+([vs]_[a-z0-9_]+)")
 
 
 def count_asm(asm):
     """-> dict for the loop with the most v_fma_f64: histogram of v_*_f64 opcodes, totals."""
-    loops = collections.defaultdict(collections.Counter)      # header label -> opcode histogram
-    valu = collections.Counter()                              # header label -> all VALU instructions
-    cur = None
+    blocks = []                                               # (loop header or None, opcode histogram, #VALU) per basic block
+    cur, hist, nv = None, collections.Counter(), 0
     for line in asm.splitlines():
-        m = _BLOCK.match(line)
+        m = _BLOCK.match(line) or _FALL.match(line)
         if m:
-            label, note = m.group(1)[1:], m.group(2) or ""    # "LBB0_30" -> "BB0_30" below
-            label = label[1:]
-            if "This Inner Loop Header" in note or "This Loop Header" in note:
-                cur = label
+            blocks.append((cur, hist, nv))
+            hist, nv = collections.Counter(), 0
+            note = m.group(2) or ""
+            if "Loop Header" in note and "This" in note:
+                cur = m.group(1)[2:] if m.group(1).startswith(".L") else None     # a loop header always carries a label
             else:
                 h = _HDR.search(note)
                 cur = h.group(1) if h else None
-            continue
-        if cur is None:
             continue
         m = _INSN.match(line)
         if not m:
@@ -92,15 +105,26 @@ def count_asm(asm):
             if op.endswith(suffix):
                 op = op[: -len(suffix)]
         if op.startswith("v_"):
-            valu[cur] += 1
+            nv += 1
             if op.endswith("_f64"):
-                loops[cur][op] += 1
+                hist[op] += 1
+    blocks.append((cur, hist, nv))
+    loops = collections.defaultdict(collections.Counter)
+    valu, rare = collections.Counter(), collections.Counter()
+    for hdr, h, n in blocks:
+        if hdr is None:
+            continue
+        if any(op.startswith("v_div_") for op in h):
+            rare[hdr] += 1
+            continue
+        loops[hdr].update(h)
+        valu[hdr] += n
     if not loops:
         raise RuntimeError("no fp64 loop found in the assembly")
     hdr = max(loops, key=lambda h: loops[h]["v_fma_f64"] + loops[h]["v_fmac_f64"])
     hist = dict(sorted(loops[hdr].items()))
     return {"loop": hdr, "fp64_valu_instructions_per_step": int(sum(hist.values())),
-            "valu_instructions_per_step": int(valu[hdr]),
+            "valu_instructions_per_step": int(valu[hdr]), "rare_blocks": int(rare[hdr]),
             "flops_per_step": int(sum(FLOPS.get(op, 0) * c for op, c in hist.items())),
             "opcodes": hist}
 

@@ -34,7 +34,7 @@ for d in ("sq", "grbm"):
     agg, dur = collections.defaultdict(list), collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         kn = r["Kernel_Name"]
-        k = "fk_sweep_fused" if "fk_sweep_fused" in kn else ("fk_rk4_batch" if "fk_rk4" in kn else ("backbone_voxel_sweep" if "voxel_sweep" in kn else None))
+        k = "fk_verdict" if "fk_verdict" in kn else "fk_sweep_fused" if "fk_sweep_fused" in kn else ("fk_rk4_batch" if "fk_rk4" in kn else ("backbone_voxel_sweep" if "voxel_sweep" in kn else None))
         if not k:
             continue
         agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))

@@ -169,8 +169,9 @@ def test_small_sample_pool_gives_the_same_edge_results(irt):
 
 
 def test_fused_and_separate_kernels_give_identical_bits(irt):
-    """fk_sweep_fused is K1's and K2's bodies in one launch: same verdict bits, flags and tips as the two
-    kernels launched one after the other (TENDON_HIP_FUSED=0)."""
+    """The three schedules of tr_validate_batch* -- fk_verdict (no point storage; the default), fk_sweep_fused (K1's and
+    K2's bodies in one launch over stored points) and the two kernels launched one after the other -- give the same
+    verdict bits, flags and tips."""
     W = irt.workloads
     for robot in (W.robot_config2(), W.robot_config3()):
         vox, _ = W.reach_environment(seed=7, n_spheres=64)
@@ -180,10 +181,58 @@ def test_fused_and_separate_kernels_give_identical_bits(irt):
             chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
             return chk.is_valid_detail(states)
 
-        f, s = run(), _with_env(irt, {"TENDON_HIP_FUSED": "0"}, run)
+        v, f, s = run(), _with_env(irt, {"TENDON_HIP_FUSED": "1"}, run), _with_env(irt, {"TENDON_HIP_FUSED": "0"}, run)
         for k in ("valid", "flags", "tips"):
-            assert np.array_equal(f[k], s[k]), k
+            assert np.array_equal(f[k], s[k]) and np.array_equal(v[k], s[k]), k
         assert 0.2 < f["valid"].mean() < 0.95
+
+
+def test_verdict_only_kernel_all_branches(irt):
+    """fk_verdict against the stored-point kernels where the predicate's rarer branches are busy: self collisions (the
+    fallback pass: exact pairwise sweep on re-integrated points, here through a 64-column workspace so that the list
+    is worked off in many rounds), length limits, non-converged base solves, a rotated environment, a rotating robot,
+    points leaving the voxel domain, and the debug switches (every lane through the fallback; brute-force pairs; no
+    dilated-grid fast path = every segment through the deferred DDA walk)."""
+    W = irt.workloads
+    thin = W.robot_config1()
+    thin.specs.dL = 0.2 / 128
+    thin.r = 0.01
+    for t in thin.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 0.08
+    hard = W.robot_config2()
+    for t in hard.tendons:
+        t.max_tension, t.max_length = 60.0, 0.02
+    spin = W.robot_config2()
+    spin.enable_rotation = True
+    small, _ = W.sphere_environment(seed=5, n_spheres=40, radius=0.01, N=128, half=0.12, keepout=0.02)   # the robot reaches out of it
+    a = 0.4
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    cases = [(thin, 100.0, None, None, 6000), (hard, 45.0, None, None, 4000), (spin, 12.0, rot, None, 6000), (W.robot_config3(), 20.0, rot, None, 5000),
+             (W.robot_config2(), 14.0, None, small, 5000)]
+    seen = np.zeros(32, int)
+    for robot, tau_max, inv_rot, vox, n in cases:
+        if vox is None:
+            vox, _ = W.reach_environment(seed=3, n_spheres=48)
+        env = irt.VoxelEnvironment()
+        if inv_rot is not None:
+            env.inv_rotation = inv_rot
+        states = W.random_states(robot, n + 21, seed=17, tau_max=tau_max)
+
+        def run(debug=0, detail=True):
+            chk = irt.VoxelBackboneValidityChecker(robot, env, vox)
+            chk.engine.set_debug(debug)
+            return chk.is_valid_detail(states) if detail else dict(valid=chk.is_valid(states))
+
+        want = _with_env(irt, {"TENDON_HIP_FUSED": "0"}, run)
+        for debug in (0, 2, 3, 4):
+            got = _with_env(irt, {"TENDON_HIP_FB_CAP": "64"}, lambda: run(debug))
+            for k in ("valid", "flags", "tips"):
+                assert np.array_equal(got[k], want[k]), (k, debug, np.flatnonzero(got[k] != want[k])[:8])
+        # without the flags output an obstacle hit settles a configuration whatever its self-collision test would say
+        assert np.array_equal(run(0, detail=False)["valid"], want["valid"])
+        seen += np.bincount(want["flags"], minlength=32)
+    print("flag histogram", seen)
+    assert seen[15] > 0 and seen[7] > 0 and seen[3] > 0 and seen[1] > 0 and seen[0] > 0
 
 
 def test_indexed_edges_equal_the_pairwise_form(irt):

@@ -59,6 +59,33 @@ def test_fused_kernel_register_budget(tmp_path):
     assert get("AGPRs") == 0
 
 
+VERDICT_TU = r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "verdict_kernel.hpp"
+template __global__ void trk::fk_verdict<3, false>(const double*, int64_t, RobotK, const double*, const StepK*, int, double*, const trk::VerdictArgs*);
+'''
+
+
+def test_verdict_kernel_register_budget_and_lds_address_space(tmp_path):
+    """fk_verdict, the kernel the headline runs: two waves per SIMD with K1's loop essentially unspilled, and its
+    per-point sweep state must be addressed as LDS (ds_*), not through flat pointers (an earlier version kept that state
+    behind stored / volatile pointers and hipcc emitted 120 flat accesses with a wait after each)."""
+    src = tmp_path / "kv.hip"
+    src.write_text(VERDICT_TU)
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-I", CSRC, str(src)]
+    out = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "kv.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    get = lambda key: int(re.search(key + r"[^:]*: (\d+)", out.stderr).group(1))
+    assert get("Occupancy") == 2
+    assert get("ScratchSize") <= 160
+    assert get("VGPRs Spill") <= 40
+    assert get("AGPRs") == 0
+    asm = subprocess.run(base + ["-S", "-o", "-"], capture_output=True, text=True).stdout
+    assert asm.count("ds_read") + asm.count("ds_write") >= 30
+    assert len(re.findall(r"\bflat_(load|store)", asm)) <= 16       # grid words and the epilogue's outputs only
+
+
 def test_isa_counts_are_current():
     """profiles/isa_counts.json -- the flops per RK4 step bench.py prices the fp64-VALU roofline with -- must be the
     count of THIS source tree's gfx950 assembly (profiles/count_isa.py rewrites it)."""
