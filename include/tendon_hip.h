@@ -116,11 +116,14 @@ int tr_set_checker(tr_ctx *ctx, int32_t checker);
  * collision::VoxelOctree's editing operations, applied to the grid tr_set_grid uploaded, without it
  * leaving the device (apps/prepare_voxel_env.cpp:247-315 runs them on the host octree):
  *   tr_grid_add_spheres      add_sphere for n spheres, (cx, cy, cz, r) each (VoxelOctree.cpp:434-469)
+ *   tr_grid_add_capsules     add_capsule for n capsules, (ax, ay, az, bx, by, bz, r) each (:471-515) -- with add_spheres
+ *                            everything Environment::voxelize rasterises (motion-planning/Environment.cpp:62-100)
  *   tr_grid_remove_interior  remove_interior(keep_diagonal) (:533-689; VoxelOctree.h:207-210)
  *   tr_grid_dilate           dilate(num, use_diagonal) (:693-818; VoxelOctree.h:215-218)
  *   tr_grid_dilate_sphere    dilate_sphere(r) (:950-952)
  *   tr_get_grid              download the current blocks ((N/4)^3 words, layout as tr_set_grid) */
 int tr_grid_add_spheres(tr_ctx *ctx, const double *spheres, int64_t n);
+int tr_grid_add_capsules(tr_ctx *ctx, const double *capsules, int64_t n);
 int tr_grid_remove_interior(tr_ctx *ctx, int32_t keep_diagonal);
 int tr_grid_dilate(tr_ctx *ctx, int32_t num, int32_t use_diagonal);
 int tr_grid_dilate_sphere(tr_ctx *ctx, double r);

@@ -25,7 +25,7 @@ PROFILE_SLOT_NAMES = ("fk_rk4_batch", "backbone_voxel_sweep", "cached_blocks_vs_
 # every symbol include/tendon_hip.h declares (tests check the .so exports exactly these)
 ABI_SYMBOLS = (
     "tr_create", "tr_destroy", "tr_last_error", "tr_state_size", "tr_num_points", "tr_device",
-    "tr_home_lengths", "tr_set_grid", "tr_set_checker", "tr_grid_add_spheres", "tr_grid_remove_interior", "tr_grid_dilate",
+    "tr_home_lengths", "tr_set_grid", "tr_set_checker", "tr_grid_add_spheres", "tr_grid_add_capsules", "tr_grid_remove_interior", "tr_grid_dilate",
     "tr_grid_dilate_sphere", "tr_get_grid", "tr_reserve", "tr_reserve_edges", "tr_fk_batch", "tr_fk_batch_dev", "tr_fk_batch_retraction_dev",
     "tr_validate_shapes_retraction_dev",
     "tr_validate_batch", "tr_validate_batch_dev", "tr_validate_shapes_dev", "tr_validate_edges", "tr_validate_edges_indexed", "tr_validate_edges_last_valid",
@@ -198,6 +198,7 @@ def lib():
     L.tr_set_grid.argtypes = [vp, C.c_uint32, dp, P(C.c_uint64), dp]
     L.tr_set_checker.argtypes = [vp, C.c_int32]
     L.tr_grid_add_spheres.argtypes = [vp, dp, i64]
+    L.tr_grid_add_capsules.argtypes = [vp, dp, i64]
     L.tr_grid_remove_interior.argtypes = [vp, C.c_int32]
     L.tr_grid_dilate.argtypes = [vp, C.c_int32, C.c_int32]
     L.tr_grid_dilate_sphere.argtypes = [vp, C.c_double]

@@ -150,6 +150,33 @@ class VoxelOctree:
         masks = (cells.astype(np.uint64) * w).sum(axis=-1, dtype=np.uint64)
         self.blocks[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] |= masks
 
+    def add_capsule(self, a, b, r):
+        """Voxel centres within r of the segment a-b, plus the end points' cells (VoxelOctree.cpp:471-515;
+        collides(Capsule, Point), collision.hxx:83-87)."""
+        a, b, r = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), float(r)
+        self.add_point(a); self.add_point(b)
+        lo = self._nearest_block_idx(*(np.minimum(a, b) - r))
+        hi = self._nearest_block_idx(*(np.maximum(a, b) + r))
+        ix, iy, iz = (np.arange(lo[d] * 4, hi[d] * 4 + 4) for d in range(3))
+        X = (self._xmin + self._dx * (ix + 0.5))[:, None, None]
+        Y = (self._ymin + self._dy * (iy + 0.5))[None, :, None]
+        Z = (self._zmin + self._dz * (iz + 0.5))[None, None, :]
+        d = b - a
+        dsq = (d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]
+        eps = np.finfo(np.float64).eps
+        if dsq <= eps * eps:
+            t = np.zeros(np.broadcast_shapes(X.shape, Y.shape, Z.shape))
+        else:
+            t = ((d[0] * (X - a[0]) + d[1] * (Y - a[1])) + d[2] * (Z - a[2])) / dsq
+        t = np.maximum(0.0, np.minimum(1.0, t))
+        e0, e1, e2 = (a[0] + d[0] * t) - X, (a[1] + d[1] * t) - Y, (a[2] + d[2] * t) - Z
+        inside = ((e0 * e0 + e1 * e1) + e2 * e2) <= r * r
+        nbx, nby, nbz = len(ix) // 4, len(iy) // 4, len(iz) // 4
+        cells = inside.reshape(nbx, 4, nby, 4, nbz, 4).transpose(0, 2, 4, 1, 3, 5).reshape(nbx, nby, nbz, 64)
+        w = (np.uint64(1) << np.arange(64, dtype=np.uint64))
+        masks = (cells.astype(np.uint64) * w).sum(axis=-1, dtype=np.uint64)
+        self.blocks[lo[0]:hi[0] + 1, lo[1]:hi[1] + 1, lo[2]:hi[2] + 1] |= masks
+
     def add_voxels(self, other):
         if other._N != self._N:
             raise L.InvalidArgument("voxel dimension mismatch (%d != %d)" % (self._N, other._N))

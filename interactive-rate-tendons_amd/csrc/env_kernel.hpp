@@ -1,5 +1,6 @@
 // env_kernel.hpp -- K7: environment preparation on the dense bit-packed grid, resident in HBM:
 //   grid_add_spheres      VoxelOctree::add_sphere            (collision/VoxelOctree.cpp:434-469)
+//   grid_add_capsules     VoxelOctree::add_capsule           (:471-515)
 //   grid_remove_interior  remove_interior_6/27neighbor       (:533-689)
 //   grid_dilate_step      one step of dilate_6/27neighbor    (:693-818), dilate_sphere (:950-952)
 // One wave per 4x4x4 block, lane = cell (bit x*16 + y*4 + z), the 64 verdicts packed with a ballot.
@@ -32,6 +33,42 @@ __global__ __launch_bounds__(64) void grid_add_spheres(uint64_t *__restrict__ bl
     if (bx < q.lo[0] || bx > q.hi[0] || by < q.lo[1] || by > q.hi[1] || bz < q.lo[2] || bz > q.hi[2]) continue;
     const double d0 = q.cx - x, d1 = q.cy - y, d2 = q.cz - z;
     on = on || (d0 * d0 + d1 * d1 + d2 * d2 <= q.rr);
+  }
+  const unsigned long long m = __ballot(on);
+  if (lane == 0 && m) blocks[b] |= m;
+}
+
+// Host-prepared capsule: end points, r^2, block range of the bounding box, and the cells add_point(a), add_point(b) set.
+struct CapsuleK { double a[3], b[3], rr; int32_t lo[3], hi[3], pa[3], pb[3]; };
+
+// VoxelOctree::add_capsule (:471-515): a voxel is set when its centre lies within r of the segment a-b --
+// collides(Capsule, Point) (collision/collision.hxx:83-87): t = closest_t_segment (collision_primitives.h:33-49), the
+// point a + (b - a) t, then |closest - p|^2 <= r^2 -- plus the cells of the two end points.
+__global__ __launch_bounds__(64) void grid_add_capsules(uint64_t *__restrict__ blocks, GridK g, const CapsuleK *__restrict__ cp, int n) {
+#pragma clang fp contract(off)
+  const int b = blockIdx.x;
+  const int bz = b % g.Nb, by = (b / g.Nb) % g.Nb, bx = b / (g.Nb * g.Nb);
+  const int lane = threadIdx.x, i = lane >> 4, j = (lane >> 2) & 3, k = lane & 3;
+  const double x = g.xmin + g.dx * ((double)((bx << 2) + i) + 0.5);
+  const double y = g.ymin + g.dy * ((double)((by << 2) + j) + 0.5);
+  const double z = g.zmin + g.dz * ((double)((bz << 2) + k) + 0.5);
+  const double eps = 2.220446049250313e-16;
+  bool on = false;
+  for (int s = 0; s < n; s++) {
+    const CapsuleK q = cp[s];                                  // wave-uniform
+    if (q.pa[0] >= 0 && (q.pa[0] >> 2) == bx && (q.pa[1] >> 2) == by && (q.pa[2] >> 2) == bz)
+      on = on || ((q.pa[0] & 3) == i && (q.pa[1] & 3) == j && (q.pa[2] & 3) == k);
+    if (q.pb[0] >= 0 && (q.pb[0] >> 2) == bx && (q.pb[1] >> 2) == by && (q.pb[2] >> 2) == bz)
+      on = on || ((q.pb[0] & 3) == i && (q.pb[1] & 3) == j && (q.pb[2] & 3) == k);
+    if (bx < q.lo[0] || bx > q.hi[0] || by < q.lo[1] || by > q.hi[1] || bz < q.lo[2] || bz > q.hi[2]) continue;
+    const double d0 = q.b[0] - q.a[0], d1 = q.b[1] - q.a[1], d2 = q.b[2] - q.a[2];
+    const double dsq = d0 * d0 + d1 * d1 + d2 * d2;
+    double t = 0.0;
+    if (!(dsq <= eps * eps)) t = (d0 * (x - q.a[0]) + d1 * (y - q.a[1]) + d2 * (z - q.a[2])) / dsq;
+    t = fmax(0.0, fmin(1.0, t));
+    const double c0 = q.a[0] + d0 * t, c1 = q.a[1] + d1 * t, c2 = q.a[2] + d2 * t;
+    const double e0 = c0 - x, e1 = c1 - y, e2 = c2 - z;
+    on = on || (e0 * e0 + e1 * e1 + e2 * e2 <= q.rr);
   }
   const unsigned long long m = __ballot(on);
   if (lane == 0 && m) blocks[b] |= m;

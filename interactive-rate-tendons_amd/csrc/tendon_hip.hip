@@ -57,6 +57,8 @@ struct Workspace {
 
 struct EventPair { hipEvent_t a, b; };
 
+constexpr int64_t kSmallBatch = 4096;   // tr_validate_batch: up to here the single-stream path without a device-wide sync
+
 // device state of the edge frontier (edge_kernel.hpp / edge_host.inc)
 struct EdgeDev {
   int64_t cap = 0;                // pool capacity this was sized for; edges per chunk <= cap / 2
@@ -145,6 +147,10 @@ struct tr_ctx {
     uint64_t *h_bits[2] = {nullptr, nullptr}; uint8_t *h_flags[2] = {nullptr, nullptr};
     hipEvent_t up[2], done[2], down[2];
   } pipe;
+  // last work enqueued by a *_dev entry point on a caller's stream: the small-batch host path waits for it on its own
+  // stream instead of synchronising the whole device
+  hipEvent_t last_dev_ev = nullptr;
+  bool last_dev_used = false;
   // instrumentation
   bool profiling = false;
   std::vector<EventPair> events[TR_PROFILE_SLOTS];
@@ -311,6 +317,14 @@ struct ProfScope {
     if (on) { (void)hipEventRecord(ev.b, s); ctx->events[slot].push_back(ev); }
   }
 };
+
+// *_dev entry points call this after enqueueing their work
+int note_dev_work(tr_ctx *ctx, hipStream_t s) {
+  if (!ctx->last_dev_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->last_dev_ev, hipEventDisableTiming));
+  HIP_TRY(ctx, hipEventRecord(ctx->last_dev_ev, s));
+  ctx->last_dev_used = true;
+  return TR_OK;
+}
 
 // ---- K1 launch (instantiations live in fk_inst.hip objects) ------------------------------------
 int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
@@ -688,6 +702,7 @@ void tr_destroy(tr_ctx *c) {
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
   if (c->vring.d_slots) { (void)hipFree(c->vring.d_slots); (void)hipHostFree(c->vring.h_slots); for (auto &e : c->vring.ev) (void)hipEventDestroy(e); }
+  if (c->last_dev_ev) (void)hipEventDestroy(c->last_dev_ev);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);
   delete c;
@@ -828,6 +843,50 @@ int tr_grid_add_spheres(tr_ctx *c, const double *spheres, int64_t n) {
   }
   if (e == hipSuccess) e = hipDeviceSynchronize();
   (void)hipFree(d_s);
+  HIP_TRY(c, e);
+  return env_end(c);
+}
+
+int tr_grid_add_capsules(tr_ctx *c, const double *capsules, int64_t n) {
+  if (!c || n < 0 || (n > 0 && !capsules)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  int rc;
+  if ((rc = env_begin(c))) return rc;
+  if (n == 0) return TR_OK;
+  const GridK &g = c->G;
+  auto blk = [&](double v, double lo, double dd) {              // nearest_block_idx (VoxelOctree.cpp:272-283)
+    const int i = (int)((v - lo) / dd);
+    return std::min(g.Nb - 1, std::max(0, i / 4));
+  };
+  auto cell = [&](double v, double lo, double dd) { return std::min(g.N - 1, std::max(0, (int)((v - lo) / dd))); };
+  std::vector<trk::CapsuleK> hc((size_t)n);
+  for (int64_t k = 0; k < n; k++) {
+    const double *p = capsules + 7 * k, r = p[6];
+    trk::CapsuleK &q = hc[(size_t)k];
+    for (int d = 0; d < 3; d++) { q.a[d] = p[d]; q.b[d] = p[3 + d]; }
+    q.rr = r * r;
+    const double lo3[3] = {g.xmin, g.ymin, g.zmin}, dd3[3] = {g.dx, g.dy, g.dz};
+    for (int d = 0; d < 3; d++) {
+      q.lo[d] = blk(std::min(p[d], p[3 + d]) - r, lo3[d], dd3[d]);
+      q.hi[d] = blk(std::max(p[d], p[3 + d]) + r, lo3[d], dd3[d]);
+    }
+    // add_point (:319-323): closed domain test, then nearest_cell (:295-307)
+    auto inside = [&](const double *v) { return !(v[0] < g.xmin || g.xmax < v[0] || v[1] < g.ymin || g.ymax < v[1] || v[2] < g.zmin || g.zmax < v[2]); };
+    const bool ia = inside(p), ib = inside(p + 3);
+    for (int d = 0; d < 3; d++) { q.pa[d] = ia ? cell(p[d], lo3[d], dd3[d]) : -1; q.pb[d] = ib ? cell(p[3 + d], lo3[d], dd3[d]) : -1; }
+  }
+  trk::CapsuleK *d_c = nullptr;
+  HIP_TRY(c, hipMalloc((void **)&d_c, hc.size() * sizeof(trk::CapsuleK)));
+  hipError_t e = hipMemcpy(d_c, hc.data(), hc.size() * sizeof(trk::CapsuleK), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    const int per = 4096;
+    for (int64_t k = 0; k < n && e == hipSuccess; k += per) {
+      hipLaunchKernelGGL(trk::grid_add_capsules, dim3(c->n_blocks), dim3(64), 0, nullptr, c->d_grid, g, d_c + k, (int)std::min<int64_t>(per, n - k));
+      e = hipGetLastError();
+    }
+  }
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  (void)hipFree(d_c);
   HIP_TRY(c, e);
   return env_end(c);
 }
@@ -1010,7 +1069,8 @@ int tr_validate_shapes_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px,
   trk::SweepIn in{d_px, d_py, d_pz, nullptr, d_Li, d_converged, nullptr, c->ws.acc};
   // acc scratch is laid out [P][ws.ld]; the kernel indexes it with ld, which is <= ws.ld: fine as
   // long as P*ld <= P*ws.ld (it only needs P*ld doubles).
-  return launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream);
+  if ((rc = launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream))) return rc;
+  return note_dev_work(c, (hipStream_t)stream);
 }
 
 int tr_validate_shapes_retraction_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px, const double *d_py,
@@ -1030,13 +1090,28 @@ int tr_validate_shapes_retraction_dev(tr_ctx *c, int64_t n, int64_t ld, const do
     if ((rc = ensure_workspace(c, ld))) return rc;
   }
   trk::SweepIn in{d_px, d_py, d_pz, d_n_points, d_Li, d_converged, d_home_Li, c->ws.acc};
-  return launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream);
+  if ((rc = launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream))) return rc;
+  return note_dev_work(c, (hipStream_t)stream);
 }
 
+}  // extern "C"
+namespace {
+int validate_batch_dev_impl(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
+                            double *d_tips, uint8_t *d_flags, void *stream);
+}
+extern "C" {
 int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
                           double *d_tips, uint8_t *d_flags, void *stream) {
   if (!c) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  const int rc = validate_batch_dev_impl(c, d_states, n, d_valid_bits, d_tips, d_flags, stream);
+  if (rc == TR_OK && n > 0) return note_dev_work(c, (hipStream_t)stream);
+  return rc;
+}
+}  // extern "C"
+namespace {
+int validate_batch_dev_impl(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
+                            double *d_tips, uint8_t *d_flags, void *stream) {
   if (n < 0) return fail(c, TR_ERR_INVALID_ARG, "negative batch size");
   if (n == 0) return TR_OK;
   if (!d_states || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
@@ -1067,6 +1142,8 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
   }
   return TR_OK;
 }
+}  // namespace
+extern "C" {
 
 namespace {
 // Host-buffer batches are pipelined in chunks: the caller's (pageable) arrays are staged through two
@@ -1111,6 +1188,28 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
   if ((rc = ensure_pipe(c))) return rc;
   tr_ctx::Pipe &p = c->pipe;
   const int64_t CH = p.chunk;
+  if (n <= kSmallBatch && n <= CH) {
+    // A single state (isValid from a serial planner) or a handful: one stream, one pinned buffer, no device-wide
+    // synchronisation -- the stream only waits for the last *_dev call that may still use this context's workspace.
+    // What remains is the kernel itself: one lane integrates its configuration serially (INTEGRATION.md has the numbers).
+    const int S = c->K.state_size;
+    const bool verdict = c->fuse == 2 && !c->K.enable_retraction && c->checker == TR_CHECKER_BACKBONE;
+    if ((rc = ensure_staging(c, n))) return rc;
+    if (!verdict && (rc = ensure_workspace(c, n))) return rc;
+    Workspace &w = c->ws;
+    if (c->last_dev_used) HIP_TRY(c, hipStreamWaitEvent(p.s_comp, c->last_dev_ev, 0));
+    std::memcpy(p.h_states[0], states, (size_t)n * S * sizeof(double));
+    HIP_TRY(c, hipMemcpyAsync(w.states, p.h_states[0], (size_t)n * S * sizeof(double), hipMemcpyHostToDevice, p.s_comp));
+    if ((rc = validate_batch_dev_impl(c, w.states, n, w.bits, tips ? w.tips : nullptr, flags ? w.flags : nullptr, p.s_comp))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(p.h_bits[0], w.bits, (size_t)((n + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, p.s_comp));
+    if (tips) HIP_TRY(c, hipMemcpyAsync(p.h_tips[0], w.tips, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, p.s_comp));
+    if (flags) HIP_TRY(c, hipMemcpyAsync(p.h_flags[0], w.flags, (size_t)n, hipMemcpyDeviceToHost, p.s_comp));
+    HIP_TRY(c, hipStreamSynchronize(p.s_comp));
+    std::memcpy(valid_bits, p.h_bits[0], (size_t)((n + 63) / 64) * sizeof(uint64_t));
+    if (tips) std::memcpy(tips, p.h_tips[0], (size_t)n * 3 * sizeof(double));
+    if (flags) std::memcpy(flags, p.h_flags[0], (size_t)n);
+    return TR_OK;
+  }
   if ((rc = ensure_staging(c, std::min(n, 2 * CH)))) return rc;
   if (!(c->fuse == 2 && !c->K.enable_retraction && c->checker == TR_CHECKER_BACKBONE) && (rc = ensure_workspace(c, std::min(n, CH)))) return rc;
   HIP_TRY(c, hipDeviceSynchronize());          // earlier work on other streams (e.g. a *_dev call) is finished
@@ -1140,7 +1239,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
     HIP_TRY(c, hipEventRecord(p.up[b], p.s_up));
     HIP_TRY(c, hipStreamWaitEvent(p.s_comp, p.up[b], 0));
     if (i >= 2) HIP_TRY(c, hipStreamWaitEvent(p.s_comp, p.down[b], 0));   // slot b's previous results have left the device
-    if ((rc = tr_validate_batch_dev(c, d_st, m, d_bits, tips ? d_tips : nullptr, flags ? d_flags : nullptr, p.s_comp))) return rc;
+    if ((rc = validate_batch_dev_impl(c, d_st, m, d_bits, tips ? d_tips : nullptr, flags ? d_flags : nullptr, p.s_comp))) return rc;
     HIP_TRY(c, hipEventRecord(p.done[b], p.s_comp));
     HIP_TRY(c, hipStreamWaitEvent(p.s_down, p.done[b], 0));
     HIP_TRY(c, hipMemcpyAsync(p.h_bits[b], d_bits, (size_t)((m + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost, p.s_down));

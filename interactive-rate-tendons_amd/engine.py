@@ -101,6 +101,10 @@ class Engine:
         sp = _f64(spheres).reshape(-1, 4)
         L.check(self._ctx, self.lib.tr_grid_add_spheres(self._ctx, _dp(sp), sp.shape[0]))
 
+    def grid_add_capsules(self, capsules):
+        cp = _f64(capsules).reshape(-1, 7)
+        L.check(self._ctx, self.lib.tr_grid_add_capsules(self._ctx, _dp(cp), cp.shape[0]))
+
     def grid_remove_interior(self, keep_diagonal=True):
         L.check(self._ctx, self.lib.tr_grid_remove_interior(self._ctx, int(bool(keep_diagonal))))
 

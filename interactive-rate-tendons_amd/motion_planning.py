@@ -102,6 +102,10 @@ class VoxelBackboneValidityChecker:
         """VoxelOctree::add_sphere for rows (cx, cy, cz, r)."""
         self.engine.grid_add_spheres(spheres)
 
+    def add_capsules(self, capsules):
+        """VoxelOctree::add_capsule for rows (ax, ay, az, bx, by, bz, r)."""
+        self.engine.grid_add_capsules(capsules)
+
     def dilate(self, num=1, use_diagonal=False):
         self.engine.grid_dilate(num, use_diagonal)
 

@@ -142,6 +142,9 @@ def _load(kind="strict"):
     lib.orc_grid_add_line.argtypes = [P(OrcGrid), c_double_p, c_double_p]
     lib.orc_grid_add_piecewise_line.argtypes = [P(OrcGrid), c_double_p, C.c_int]
     lib.orc_grid_add_sphere.argtypes = [P(OrcGrid), c_double_p, C.c_double]
+    lib.orc_grid_add_capsule.argtypes = [P(OrcGrid), c_double_p, c_double_p, C.c_double]
+    lib.orc_grid_add_capsule.restype = None
+    lib.orc_capsule_contains.argtypes = [c_double_p, c_double_p, C.c_double, c_double_p]
     lib.orc_grid_remove_interior.argtypes = [P(OrcGrid), C.c_int]
     lib.orc_grid_remove_interior.restype = None
     lib.orc_grid_dilate.argtypes = [P(OrcGrid), C.c_int, C.c_int]
@@ -408,6 +411,10 @@ class Grid:
     def add_sphere(self, c, r):
         c = _f64(c)
         self.lib.orc_grid_add_sphere(self.ptr, _dp(c), float(r))
+
+    def add_capsule(self, a, b, r):
+        a, b = _f64(a), _f64(b)
+        self.lib.orc_grid_add_capsule(self.ptr, _dp(a), _dp(b), float(r))
 
     def remove_interior(self, keep_diagonal=True):
         self.lib.orc_grid_remove_interior(self.ptr, int(bool(keep_diagonal)))

@@ -827,6 +827,45 @@ void orc_grid_add_sphere(orc_grid *g, const double c[3], double r) {
       }
 }
 
+/* collision/collision.hxx:83-87 collides(Capsule, Point): closest point of the segment (closest_t_segment,
+ * collision_primitives.h:33-49: t = diff.(p - a) / diff.diff clamped to [0, 1], 0 when a == b to eps^2), then the sphere
+ * test around it (:65-68). */
+int orc_capsule_contains(const double a[3], const double b[3], double r, const double p[3]) {
+  const double eps = 2.220446049250313e-16;
+  double diff[3] = { b[0] - a[0], b[1] - a[1], b[2] - a[2] };
+  double dsq = v3_dot(diff, diff);
+  double t = 0.0;
+  if (!(dsq <= eps * eps)) {
+    double pa[3] = { p[0] - a[0], p[1] - a[1], p[2] - a[2] };
+    t = v3_dot(diff, pa) / dsq;
+  }
+  t = fmax(0.0, fmin(1.0, t));
+  double c[3] = { a[0] + diff[0] * t, a[1] + diff[1] * t, a[2] + diff[2] * t };   /* interpolate: a + (b - a) * t */
+  double d[3] = { c[0] - p[0], c[1] - p[1], c[2] - p[2] };
+  return v3_dot(d, d) <= r * r;
+}
+
+/* :471-515 VoxelOctree::add_capsule: both end points' cells, then every voxel centre inside the capsule within the
+ * block range of its bounding box */
+void orc_grid_add_capsule(orc_grid *g, const double a[3], const double b[3], double r) {
+  orc_grid_add_point(g, a[0], a[1], a[2]);
+  orc_grid_add_point(g, b[0], b[1], b[2]);
+  int lo[3], hi[3];
+  nearest_block_idx(g, fmin(a[0], b[0]) - r, fmin(a[1], b[1]) - r, fmin(a[2], b[2]) - r, lo);
+  nearest_block_idx(g, fmax(a[0], b[0]) + r, fmax(a[1], b[1]) + r, fmax(a[2], b[2]) + r, hi);
+  for (int bx = lo[0]; bx <= hi[0]; bx++)
+    for (int by = lo[1]; by <= hi[1]; by++)
+      for (int bz = lo[2]; bz <= hi[2]; bz++) {
+        uint64_t bm = 0;
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) for (int k = 0; k < 4; k++) {
+          double p[3] = { g->xmin + g->dx * ((bx << 2) + i + 0.5), g->ymin + g->dy * ((by << 2) + j + 0.5),
+                          g->zmin + g->dz * ((bz << 2) + k + 0.5) };
+          if (orc_capsule_contains(a, b, r, p)) bm |= orc_bitmask(i, j, k);
+        }
+        if (bm) g->blocks[block_index(g, bx, by, bz)] |= bm;
+      }
+}
+
 /* collision/VoxelOctree.cpp:533-689: remove_interior_6neighbor / remove_interior_27neighbor.  Works
  * from a copy; only non-empty blocks are visited (visit_leaves); blocks beyond the grid count as full. */
 static uint64_t blk_or_full(const orc_grid *g, const uint64_t *src, long bx, long by, long bz) {

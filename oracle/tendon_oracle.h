@@ -104,6 +104,8 @@ void orc_grid_add_point(orc_grid *g, double x, double y, double z);
 void orc_grid_add_line(orc_grid *g, const double a[3], const double b[3]);
 void orc_grid_add_piecewise_line(orc_grid *g, const double *pts, int n);
 void orc_grid_add_sphere(orc_grid *g, const double c[3], double r);
+int  orc_capsule_contains(const double a[3], const double b[3], double r, const double p[3]);
+void orc_grid_add_capsule(orc_grid *g, const double a[3], const double b[3], double r);   /* VoxelOctree.cpp:471-515 */
 void orc_grid_remove_interior(orc_grid *g, int keep_diagonal);
 void orc_grid_dilate(orc_grid *g, int num, int use_diagonal);
 void orc_grid_dilate_sphere(orc_grid *g, double r);

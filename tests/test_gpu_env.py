@@ -20,6 +20,36 @@ def _oracle_grid(orc, vox):
     return g
 
 
+def test_add_capsules_matches_oracle(irt, orc):
+    """tr_grid_add_capsules = VoxelOctree::add_capsule (VoxelOctree.cpp:471-515), bit for bit; with add_spheres it serves
+    everything Environment::voxelize rasterises (motion-planning/Environment.cpp:62-100)."""
+    robot, vox, chk = _checker(irt)
+    rng = np.random.default_rng(8)
+    cp = np.column_stack([rng.uniform(-0.3, 0.3, (150, 3)), rng.uniform(-0.3, 0.3, (150, 3)), rng.uniform(0.0005, 0.03, 150)])
+    cp[0, 3:6] = cp[0, :3]                            # a == b: a sphere
+    cp[1] = [0.0, 0.0, 0.0, 0.0, 0.0, 0.1, 0.0]       # radius 0: the end points' cells and the centres exactly on the axis
+    cp[2] = [0.24, 0.0, 0.0, 0.6, 0.0, 0.0, 0.02]     # leaves the domain
+    cp[3] = [1.0, 1.0, 1.0, 2.0, 1.0, 1.0, 0.1]       # entirely outside
+    chk.add_capsules(cp)
+    g = _oracle_grid(orc, vox)
+    for row in cp:
+        g.add_capsule(row[:3], row[3:6], row[6])
+    got = chk.engine.get_grid()
+    assert np.array_equal(got, np.asarray(g.blocks()).ravel())
+    assert np.count_nonzero(got) > 1000
+    chk.add_capsules(np.zeros((0, 7)))
+    assert np.array_equal(chk.engine.get_grid(), got)
+    # the host mirror builds the same set
+    v = vox.empty_copy()
+    v.blocks[...] = vox.blocks
+    for row in cp[:20]:
+        v.add_capsule(row[:3], row[3:6], row[6])
+    g2 = _oracle_grid(orc, vox)
+    for row in cp[:20]:
+        g2.add_capsule(row[:3], row[3:6], row[6])
+    assert np.array_equal(v.blocks.ravel(), np.asarray(g2.blocks()).ravel())
+
+
 def test_add_spheres_matches_oracle(irt, orc):
     robot, vox, chk = _checker(irt)
     rng = np.random.default_rng(3)

@@ -76,7 +76,9 @@ def test_three_routes_to_the_voxel_verdict_agree(irt, setup):
     shape_ok = (fl & 7) == 7
     assert np.array_equal(out["shape_valid"], shape_ok)
     assert np.array_equal(~hit[shape_ok], (fl[shape_ok] & 8) != 0)
-    assert np.array_equal(out["tips"], setup["tips"][:n])
+    # (the voxel caches come from the stored-point kernel, the flags above from fk_verdict: the same RK4 body in two kernels,
+    # whose multiply-adds hipcc may contract differently -- equal to rounding)
+    assert np.abs(out["tips"] - setup["tips"][:n]).max() <= 1e-13
 
 
 def test_fk_rotation_equivariance_full_size(irt):

@@ -77,6 +77,11 @@ def test_voxel_octree_matches_oracle_grid(irt, orc):
     for _ in range(12):
         c, r = rng.uniform(-0.3, 0.5, 3), rng.uniform(0.005, 0.08)
         v.add_sphere(c, r); g.add_sphere(c, r)
+    for _ in range(10):                                    # add_capsule (VoxelOctree.cpp:471-515), also degenerate and reaching outside
+        a, b, r = rng.uniform(-0.35, 0.55, 3), rng.uniform(-0.35, 0.55, 3), rng.uniform(0.004, 0.05)
+        if _ == 0:
+            b = a.copy()
+        v.add_capsule(a, b, r); g.add_capsule(a, b, r)
     for _ in range(50):
         p = rng.uniform(-0.4, 0.6, 3)
         v.add_point(p); g.add_point(p)

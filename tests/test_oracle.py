@@ -527,6 +527,40 @@ def test_environment_edits_against_numpy_morphology(orc):
     assert np.array_equal(_cells(h), _np_dilate(base, 2, m6))
 
 
+def test_add_capsule_voxel_centres(orc):
+    """orc_grid_add_capsule (VoxelOctree.cpp:471-515) against a brute-force mask: voxel centres whose distance to the
+    segment is <= r (collides(Capsule, Point), collision.hxx:83-87), plus the two end points' cells."""
+    rng = np.random.default_rng(12)
+    for trial in range(6):
+        g = orc.Grid(32, (-1, 1, -0.5, 0.5, 0, 2))
+        a, b = rng.uniform([-1, -0.5, 0], [1, 0.5, 2]), rng.uniform([-1.2, -0.6, -0.2], [1.2, 0.6, 2.2])
+        r = rng.uniform(0.03, 0.3)
+        if trial == 0:
+            b = a.copy()                                     # degenerate capsule = sphere
+        g.add_capsule(a, b, r)
+        dx, dy, dz = g.cell_size
+        X = (-1 + dx * (np.arange(32) + 0.5))[:, None, None]
+        Y = (-0.5 + dy * (np.arange(32) + 0.5))[None, :, None]
+        Z = (0 + dz * (np.arange(32) + 0.5))[None, None, :]
+        d = b - a
+        dsq = d @ d
+        t = np.zeros((32, 32, 32)) if dsq <= 1e-30 else np.clip((d[0] * (X - a[0]) + d[1] * (Y - a[1]) + d[2] * (Z - a[2])) / dsq, 0, 1)
+        dist2 = (a[0] + d[0] * t - X) ** 2 + (a[1] + d[1] * t - Y) ** 2 + (a[2] + d[2] * t - Z) ** 2
+        want = dist2 <= r * r
+        for p in (a, b):
+            if g.is_in_domain(*p):
+                want[tuple(g.nearest_cell(*p))] = True
+        got = np.zeros((32, 32, 32), bool)
+        for c in g.cells():
+            got[tuple(c)] = True
+        near = np.abs(dist2 - r * r) < 1e-12                 # centres on the surface to rounding: either answer
+        assert np.array_equal(got | near, want | near) and want.sum() > 20
+        if trial == 0:
+            s = orc.Grid(32, (-1, 1, -0.5, 0.5, 0, 2))
+            s.add_sphere(a, r)
+            assert np.array_equal(s.blocks(), g.blocks())
+
+
 def test_lazy_prm_query_loop_hand_traced(orc):
     """orc_roadmap_query on a 6-vertex graph where the lazy loop can be followed by hand (constructSolution,
     VoxelCachedLazyPRM.cpp:2689-2771): the cheapest path runs through an invalid vertex (ALL invalid interior vertices
