@@ -285,6 +285,12 @@ int tr_voxelize_batch(tr_ctx *ctx, const double *states, int64_t n, int64_t *off
 int tr_voxelize_edges(tr_ctx *ctx, const tr_space_params *sp, const double *a, const double *b,
                       int64_t n_edges, int64_t *offsets, uint64_t *fully_valid_bits, int32_t *n_fk);
 
+/* The same for a roadmap: edge e joins states[edges[2e]] and states[edges[2e + 1]]; every vertex is integrated and
+ * voxelised ONCE for all of its edges (the loop at :1751-1775 recomputes both end shapes per edge).  Same sets. */
+int tr_voxelize_edges_indexed(tr_ctx *ctx, const tr_space_params *sp, const double *states, int64_t n_states,
+                              const int32_t *edges, int64_t n_edges, int64_t *offsets, uint64_t *fully_valid_bits,
+                              int32_t *n_fk);
+
 /* Copy the block lists of the last tr_voxelize_* call; capacity must be >= its offsets[n]. */
 int tr_voxelize_fetch(tr_ctx *ctx, uint32_t *block_ids, uint64_t *masks, int64_t capacity);
 

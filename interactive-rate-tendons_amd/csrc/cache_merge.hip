@@ -12,27 +12,31 @@
 namespace trk {
 namespace {
 
-__global__ __launch_bounds__(256) void merge_counts(const int32_t *__restrict__ counts, const int32_t *__restrict__ sample_edge,
-                                                    int64_t pool, int64_t *__restrict__ cnt, uint64_t *__restrict__ scalars) {
+// item i = the block list of pool sample src[i] (i itself when src is null) as part of edge item_edge[i] (< 0: of none)
+__global__ __launch_bounds__(256) void merge_counts(const int32_t *__restrict__ counts, const int32_t *__restrict__ src,
+                                                    const int32_t *__restrict__ item_edge,
+                                                    int64_t n_items, int64_t *__restrict__ cnt, uint64_t *__restrict__ scalars) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= pool) return;
-  const int c = counts[i];
+  if (i >= n_items) return;
+  if (item_edge[i] < 0) { cnt[i] = 0; return; }
+  const int c = counts[src ? src[i] : i];
   if (c < 0) scalars[1] = 1;
-  cnt[i] = (sample_edge[i] >= 0 && c > 0) ? c : 0;
+  cnt[i] = c > 0 ? c : 0;
 }
 
 __global__ __launch_bounds__(256) void merge_keys(const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks,
                                                   const int64_t *__restrict__ cnt, const int64_t *__restrict__ offs,
-                                                  const int32_t *__restrict__ sample_edge, int64_t pool, int64_t ld, int id_bits,
-                                                  uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
+                                                  const int32_t *__restrict__ src, const int32_t *__restrict__ item_edge, int64_t n_items,
+                                                  int64_t ld, int id_bits, uint64_t *__restrict__ keys, uint64_t *__restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= pool) return;
+  if (i >= n_items) return;
   const int64_t c = cnt[i], o = offs[i];
   if (c == 0) return;
-  const uint64_t hi = (uint64_t)(uint32_t)sample_edge[i] << id_bits;
+  const int64_t col = src ? src[i] : i;
+  const uint64_t hi = (uint64_t)(uint32_t)item_edge[i] << id_bits;
   for (int64_t k = 0; k < c; k++) {
-    keys[o + k] = hi | ids[k * ld + i];
-    vals[o + k] = masks[k * ld + i];
+    keys[o + k] = hi | ids[k * ld + col];
+    vals[o + k] = masks[k * ld + col];
   }
 }
 
@@ -66,8 +70,8 @@ void merge_free(MergeScratch &ms) {
 }
 
 hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint64_t *d_masks, const int32_t *d_counts,
-                             const int32_t *d_sample_edge, int64_t pool, int64_t ld, uint32_t n_blocks, int64_t n_edges,
-                             int64_t *n_unique, int *overflow, hipStream_t stream) {
+                             const int32_t *d_item_src, const int32_t *d_sample_edge, int64_t pool, int64_t ld, uint32_t n_blocks,
+                             int64_t n_edges, int64_t *n_unique, int *overflow, hipStream_t stream) {
   *n_unique = 0; *overflow = 0;
   if (pool <= 0 || n_edges <= 0) return hipSuccess;
   const int id_bits = bits_for(n_blocks), e_bits = bits_for((uint64_t)n_edges);
@@ -90,7 +94,7 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
   MERGE_TRY(hipMemsetAsync(ms.scalars, 0, 2 * sizeof(uint64_t), stream));
   MERGE_TRY(hipMemsetAsync(ms.ecount, 0, (size_t)n_edges * sizeof(int32_t), stream));
   MERGE_TRY(hipMemsetAsync(ms.cnt + pool, 0, sizeof(int64_t), stream));
-  hipLaunchKernelGGL(merge_counts, gp, b256, 0, stream, d_counts, d_sample_edge, pool, ms.cnt, ms.scalars);
+  hipLaunchKernelGGL(merge_counts, gp, b256, 0, stream, d_counts, d_item_src, d_sample_edge, pool, ms.cnt, ms.scalars);
   MERGE_TRY(hipGetLastError());
   size_t bytes = 0;
   MERGE_TRY(rocprim::exclusive_scan(nullptr, bytes, ms.cnt, ms.offs, (int64_t)0, (size_t)pool + 1, rocprim::plus<int64_t>(), stream));
@@ -111,7 +115,7 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
     MERGE_TRY(grow(&ms.uids, want));
     ms.cap_nnz = (int64_t)want;
   }
-  hipLaunchKernelGGL(merge_keys, gp, b256, 0, stream, d_ids, d_masks, ms.cnt, ms.offs, d_sample_edge, pool, ld, id_bits, ms.keys[0], ms.vals[0]);
+  hipLaunchKernelGGL(merge_keys, gp, b256, 0, stream, d_ids, d_masks, ms.cnt, ms.offs, d_item_src, d_sample_edge, pool, ld, id_bits, ms.keys[0], ms.vals[0]);
   MERGE_TRY(hipGetLastError());
 
   rocprim::double_buffer<uint64_t> kb(ms.keys[0], ms.keys[1]), vb(ms.vals[0], ms.vals[1]);

@@ -24,12 +24,14 @@ struct MergeScratch {
 };
 
 // Per-sample block lists (ids / masks stored as columns [maxB][ld], counts[i] entries, counts < 0 =
-// overflow) of pool samples [0, pool) -> per-edge sorted, duplicate-free lists on the device:
+// overflow) -> per-edge sorted, duplicate-free lists on the device:
 //   ms.uids / ms.uvals [*n_unique] ordered by (edge, block id), ms.ecount[e] entries per edge.
+// `pool` items: item i is the list of pool sample d_item_src[i] (i itself when d_item_src is null) taken as part of
+// edge d_sample_edge[i] (< 0: skipped) -- with an explicit source a sample (a roadmap vertex) can join many edges.
 // Returns hipSuccess, or an error; *overflow != 0 when a sample's list had overflowed.
 hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint64_t *d_masks, const int32_t *d_counts,
-                             const int32_t *d_sample_edge, int64_t pool, int64_t ld, uint32_t n_blocks, int64_t n_edges,
-                             int64_t *n_unique, int *overflow, hipStream_t stream);
+                             const int32_t *d_item_src, const int32_t *d_sample_edge, int64_t pool, int64_t ld, uint32_t n_blocks,
+                             int64_t n_edges, int64_t *n_unique, int *overflow, hipStream_t stream);
 void merge_free(MergeScratch &ms);
 
 }  // namespace trk

@@ -273,6 +273,24 @@ __global__ __launch_bounds__(256) void edge_sample_bits(EdgeState st, int64_t po
   if ((threadIdx.x & 63) == 0 && s < pool) out[s >> 6] = m;
 }
 
+// Indexed voxel caches (tr_voxelize_edges_indexed): the items of the cache merge.  Items [0, pool) are the pool samples
+// with their edges (vertex slots carry -1 there); items pool + 2k, pool + 2k + 1 are the two END vertices of edge k --
+// their block lists were built once for all edges -- taken as part of edge k when the edge is fully valid.
+__global__ __launch_bounds__(256) void edge_cache_items(EdgeState st, int64_t pool, int64_t E, const int32_t *__restrict__ idx,
+                                                        int32_t *__restrict__ item_src, int32_t *__restrict__ item_edge) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= pool + 2 * E) return;
+  if (t < pool) {
+    const int32_t e = st.sample_edge[t];
+    item_src[t] = (int32_t)t;
+    item_edge[t] = (e >= 0 && st.edge_ok[e] != 0) ? e : -1;
+  } else {
+    const int64_t k = (t - pool) >> 1;
+    item_src[t] = idx[t - pool];
+    item_edge[t] = st.edge_ok[k] != 0 ? (int32_t)k : -1;
+  }
+}
+
 // ---- discrete variant (VoxelBackboneDiscreteMotionValidator.cpp:9-79; the loop of
 // ompl::base::DiscreteMotionValidator::checkMotion): samples a, interpolate(i / nd) for i = 1..nd-1, b.
 // Edge e owns pool samples [offs[e], offs[e+1]); all of them are evaluated in one K1 + K2 pass.

@@ -138,6 +138,7 @@ struct tr_ctx {
   uint32_t *d_vids = nullptr; uint64_t *d_vmasks = nullptr; int32_t *d_vcounts = nullptr; int64_t *d_voffsets = nullptr;
   uint32_t *d_cids = nullptr; uint64_t *d_cmasks = nullptr; uint64_t *d_vbits = nullptr;
   int64_t vox_cap = 0, vox_cnnz = 0;
+  int32_t *d_item_src = nullptr, *d_item_edge = nullptr; int64_t vox_items_cap = 0;   // items of the indexed edge-cache merge
   // host-buffer pipeline of tr_validate_batch: pinned staging, copy/compute streams
   struct Pipe {
     bool ready = false;
@@ -703,6 +704,8 @@ void tr_destroy(tr_ctx *c) {
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
   if (c->vring.d_slots) { (void)hipFree(c->vring.d_slots); (void)hipHostFree(c->vring.h_slots); for (auto &e : c->vring.ev) (void)hipEventDestroy(e); }
   if (c->last_dev_ev) (void)hipEventDestroy(c->last_dev_ev);
+  if (c->d_item_src) (void)hipFree(c->d_item_src);
+  if (c->d_item_edge) (void)hipFree(c->d_item_edge);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);
   delete c;

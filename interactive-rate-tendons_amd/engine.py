@@ -286,6 +286,22 @@ class Engine:
         ids, masks = self._fetch_lists(int(offsets[-1]))
         return dict(offsets=offsets, block_ids=ids, masks=masks, fully_valid=unpack_bits(bits, n), n_fk=nfk)
 
+    def voxelize_edges_indexed(self, states, edges, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001):
+        """voxelizeEdge for roadmap edges given as index pairs: every vertex integrated and voxelised once."""
+        st = self._states(states)
+        e = np.ascontiguousarray(np.asarray(edges).reshape(-1, 2), dtype=np.int32)
+        n = e.shape[0]
+        sp = L.TrSpaceParams(min_tension_change, min_rotation_change, min_retraction_change)
+        offsets = np.zeros(n + 1, dtype=np.int64)
+        bits = np.zeros((n + 63) // 64, dtype=np.uint64)
+        nfk = np.zeros(n, dtype=np.int32)
+        L.check(self._ctx, self.lib.tr_voxelize_edges_indexed(
+            self._ctx, C.byref(sp), _dp(st), st.shape[0], e.ctypes.data_as(C.POINTER(C.c_int32)), n,
+            offsets.ctypes.data_as(C.POINTER(C.c_int64)), bits.ctypes.data_as(C.POINTER(C.c_uint64)),
+            nfk.ctypes.data_as(C.POINTER(C.c_int32))))
+        ids, masks = self._fetch_lists(int(offsets[-1]))
+        return dict(offsets=offsets, block_ids=ids, masks=masks, fully_valid=unpack_bits(bits, n), n_fk=nfk)
+
     # ---- device-buffer calls (torch tensors on this engine's GPU) -------------------------------
     @staticmethod
     def _stream_ptr(stream):

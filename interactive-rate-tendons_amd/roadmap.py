@@ -102,8 +102,8 @@ class RoadmapBuilder:
 
     def edge_caches(self, states, edges):
         t0 = time.perf_counter()
-        out = self.engine.voxelize_edges(states[edges[:, 0]], states[edges[:, 1]], self.mv.min_tension_change,
-                                         self.mv.min_rotation_change, self.mv.min_retraction_change)
+        out = self.engine.voxelize_edges_indexed(states, edges, self.mv.min_tension_change,
+                                                 self.mv.min_rotation_change, self.mv.min_retraction_change)
         self.timing["edge_caches"] = dict(seconds=time.perf_counter() - t0, items=len(edges), blocks=int(out["offsets"][-1]))
         return out
 

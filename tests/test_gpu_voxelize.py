@@ -138,3 +138,43 @@ def test_voxel_sets_with_retraction(irt, orc, helpers):
             d = {int(k): int(v) for k, v in zip(ids, masks)}
             e = {int(k): int(v) for k, v in zip(wi, wm)}
             assert sum(bin(d.get(k, 0) ^ e.get(k, 0)).count("1") for k in set(d) | set(e)) <= 2
+
+
+def test_indexed_edge_caches_equal_the_pairwise_form(irt):
+    """tr_voxelize_edges_indexed integrates and voxelises every roadmap vertex once for all of its edges; the swept-volume
+    sets, fully-valid bits and sample counts equal tr_voxelize_edges on the gathered end states -- also for a retraction
+    robot (rows aligned at the tip), with shape-invalid vertices, and with a sample pool so small that the chunks overflow
+    and the vertex block does not fit (host-gather fallback)."""
+    import os
+    W = irt.workloads
+    ret = W.robot_config2()
+    ret.enable_retraction = True
+    hard = W.robot_config3()
+    for t in hard.tendons:
+        t.max_length = 0.012                                   # many length-limit violations: edges without a cache
+    for robot, tau in ((W.robot_config3(), 20.0), (ret, 14.0), (hard, 20.0)):
+        vox, _ = W.reach_environment(seed=7, n_spheres=64)
+        states = W.random_states(robot, 700, seed=81, tau_max=tau)
+        if robot.enable_retraction:
+            states[:, -1] = np.random.default_rng(82).uniform(0.0, 0.1, len(states))
+        nt = len(robot.tendons)
+        near = np.argsort(np.linalg.norm(states[:, None, :nt] - states[None, :, :nt], axis=2), axis=1)[:, 1:6]
+        edges = np.stack([np.repeat(np.arange(len(states)), 5), near.reshape(-1)], 1)
+        edges = edges[edges[:, 0] < edges[:, 1]]
+
+        def run():
+            eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+            return eng.voxelize_edges_indexed(states, edges), eng.voxelize_edges(states[edges[:, 0]], states[edges[:, 1]])
+
+        for env in ({}, {"TENDON_HIP_EDGE_POOL": "4096"}, {"TENDON_HIP_EDGE_POOL": "1024"}):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)
+            try:
+                ix, pw = run()
+            finally:
+                for k, v in old.items():
+                    os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+            for k in ("offsets", "block_ids", "masks", "fully_valid", "n_fk"):
+                assert np.array_equal(ix[k], pw[k]), (k, env)
+        assert 0.02 < ix["fully_valid"].mean() <= 1.0 and ix["offsets"][-1] > 1000
+    assert not ix["fully_valid"].all()                         # the last robot leaves edges without a cache
