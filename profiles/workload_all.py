@@ -1,0 +1,159 @@
+#!/usr/bin/env python3
+"""One pass over EVERY kernel of the library at BASELINE sizes, for rocprofv3 (profiles/collect_all.sh runs it under
+--kernel-trace --stats and under separate --pmc passes).  Writes <out>/units.json: per kernel name the ALGORITHMIC work
+of all of its launches in this run (bytes and / or fp64 flops, SURVEY.md section 8d's per-unit figures x units), which
+profiles/summarize_all.py divides by the kernel's total duration.
+
+    python profiles/workload_all.py <out_dir> [--small]
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def with_env(env, fn):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+
+def main():
+    out_dir = sys.argv[1]
+    small = "--small" in sys.argv
+    os.makedirs(out_dir, exist_ok=True)
+    import torch
+    irt = importlib.import_module("interactive-rate-tendons_amd")
+    W = irt.workloads
+    isa = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))
+    units = {}
+
+    def add(kernel, **kw):
+        u = units.setdefault(kernel, {"bytes": 0.0, "flops": 0.0, "units": 0.0, "unit": kw.pop("unit", "")})
+        for k, v in kw.items():
+            u[k] = u.get(k, 0.0) + float(v)
+
+    vox, centres = W.reach_environment(seed=7, n_spheres=64)
+    reps = 3
+    # ---- tr_validate_batch_dev in its three schedules, 3- and 4-tendon robots (configs 2 and 3) -------------------
+    for robot, tag, tau, logn in ((W.robot_config2(), 3, 10.0, 20), (W.robot_config3(), 4, 20.0, 19)):
+        n = 1 << (logn - (4 if small else 0))
+        P, S, N = 129, robot.state_size(), len(robot.tendons)
+        st = torch.from_numpy(W.random_states(robot, n, seed=3, tau_max=tau)).cuda()
+        bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
+        tips = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        fl_fused = isa["fk_sweep_fused<%d,false>" % N]["flops_per_step"] * (P - 1)
+        fl_k1 = isa["fk_rk4_batch_uniform<%d,false,false>" % N]["flops_per_step"] * (P - 1)
+        for mode, names in (("2", ("fk_verdict",)), ("1", ("fk_sweep_fused",)), ("0", ("fk_rk4_batch_uniform", "backbone_voxel_sweep"))):
+            chk = with_env({"TENDON_HIP_FUSED": mode}, lambda: irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox))
+            chk.engine.reserve(n)
+            for _ in range(reps):
+                chk.engine.validate_batch_dev(st, n, bits, tips)
+            torch.cuda.synchronize()
+            k1b = 8 * S + 24 * P + 8 * (N + 1) + 1 + 24
+            k2b = 24 * P + 8 * N + 1 + 0.125
+            if mode == "2":
+                add("fk_verdict<%d>" % N, bytes=reps * n * (8 * S + 24 + 0.125), flops=reps * n * fl_fused, units=reps * n, unit="checks")
+            elif mode == "1":
+                add("fk_sweep_fused<%d>" % N, bytes=reps * n * (k1b + k2b), flops=reps * n * fl_fused, units=reps * n, unit="checks")
+            else:
+                add("fk_rk4_batch_uniform<%d>" % N, bytes=reps * n * k1b, flops=reps * n * fl_k1, units=reps * n, unit="FK")
+                add("backbone_voxel_sweep", bytes=reps * n * k2b, units=reps * n, unit="shapes")
+            del chk
+    # ---- retraction robots: K1r + K2 (tip-aligned rows) ---------------------------------------------------------------
+    for mk, N in ((W.robot_config2, 3), (W.robot_config3, 4)):
+        robot = mk()
+        robot.enable_retraction = True
+        n = 1 << (19 - (4 if small else 0))
+        stn = W.random_states(robot, n, seed=4, tau_max=10.0 if N == 3 else 20.0)
+        stn[:, -1] = np.random.default_rng(5).uniform(0.0, 0.1, n)
+        st = torch.from_numpy(stn).cuda()
+        bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        chk.engine.reserve(n)
+        for _ in range(reps):
+            chk.engine.validate_batch_dev(st, n, bits)
+        torch.cuda.synchronize()
+        # points per configuration ~ 129 * (1 - s/L) on average: count the algorithmic bytes of the mean
+        pm = float(np.mean(np.ceil((0.2 - stn[:, -1]) / (0.2 / 128)) + 1))
+        add("fk_rk4_batch_retract<%d>" % N, bytes=reps * n * (8 * (N + 1) + 24 * pm + 16 * N + 5), units=reps * n, unit="FK",
+            flops=reps * n * isa["fk_rk4_batch_uniform<%d,false,false>" % N]["flops_per_step"] * (pm - 1))
+        add("backbone_voxel_sweep", bytes=reps * n * (24 * pm + 16 * N + 5), units=reps * n, unit="shapes")
+        del chk
+    # ---- config 3 roadmap: vertices, k-NN, indexed edges, caches, K4 ---------------------------------------------------
+    robot = W.robot_config3()
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
+    V = 100000 // (16 if small else 1)
+    states, _ = rb.sample_valid_vertices(V, batch=1 << 17)
+    k = 10
+    edges = rb.knn_edges_gpu(states, k + 1)
+    add("knn_bruteforce<4>", units=float(V) * V, unit="pair distances", flops=float(V) * V * (3 * 4 + 1), bytes=float(V) * 4 * 8 * (V / 64.0))
+    chk.engine.reserve_edges(len(edges))
+    chk.engine.profile_begin()
+    valid, nfk = rb.validate_edges(states, edges)
+    prof_e = chk.engine.profile_read()
+    chk.engine.profile_end()
+    n_samples = int(nfk.sum()) - 2 * len(edges) + V          # FK samples actually integrated (vertices once)
+    add("edge path (tr_validate_edges_indexed)", units=len(edges), unit="edges", fk_samples=n_samples)
+    add("edge_filter", bytes=2.0 * 129 * 24 * (n_samples + len(edges)), units=n_samples + len(edges), unit="interval tests (upper bound: early exit from the tip)")
+    e_ok = edges[valid]
+    vc = rb.vertex_caches(states)
+    ec = rb.edge_caches(states, e_ok)
+    add("backbone_voxelize", bytes=(V + n_samples) * (24.0 * 129) + 12.0 * (int(vc["offsets"][-1])), units=V + n_samples, unit="shapes")
+    add("cache merge (rocPRIM sort + reduce)", units=int(ec["offsets"][-1]), unit="unique edge blocks")
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=72)
+    prm = irt.VoxelCachedLazyPRM(chk, states, e_ok)
+    prm.set_caches(vc, ec)
+    prm.set_obstacles(new_vox)
+    nblk = int(vc["offsets"][-1] + ec["offsets"][-1])
+    for _ in range(5):
+        prm.clearValidity()
+        prm.revalidate()
+    add("cached_blocks_vs_grid", bytes=5 * (12.0 * nblk + 8.0 * (V + len(e_ok))), units=5 * (V + len(e_ok)), unit="cached sets",
+        working_set_MiB=12.0 * nblk / 2 ** 20)
+    rng = np.random.default_rng(17)
+    q = rng.integers(0, V, size=(2000, 2))
+    prm.clearValidity()
+    prm.solveWithRoadmap(q[:, 0], q[:, 1])
+    add("cached_subset_vs_grid", units=prm.stats["items_checked"], unit="cached sets (lazy rounds)")
+    # ---- sphere checker (K8) and environment edits (K7) ------------------------------------------------------------------
+    r2 = W.robot_config2()
+    raw = irt.VoxelOctree(256)
+    raw.set_xlim(-0.25, 0.25); raw.set_ylim(-0.25, 0.25); raw.set_zlim(-0.25, 0.25)
+    for c in centres:
+        raw.add_sphere(c, 0.005)
+    sc = irt.VoxelValidityChecker(r2, irt.VoxelEnvironment(), raw)
+    n = 1 << (20 - (4 if small else 0))
+    st = torch.from_numpy(W.random_states(r2, n, seed=3, tau_max=10.0)).cuda()
+    bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
+    sc.engine.reserve(n)
+    for _ in range(reps):
+        sc.engine.validate_batch_dev(st, n, bits)
+    torch.cuda.synchronize()
+    add("spheres_vs_grid", bytes=reps * n * (24.0 * 129 + 4 * 129), units=reps * n, unit="shapes")
+    extra = np.column_stack([rng.uniform(-0.15, 0.15, (8, 3)), np.full(8, 0.02)])
+    caps = np.column_stack([rng.uniform(-0.15, 0.15, (8, 3)), rng.uniform(-0.15, 0.15, (8, 3)), np.full(8, 0.01)])
+    for _ in range(3):
+        chk.engine.set_grid(new_vox.Nx(), new_vox.limits(), new_vox.blocks)
+        chk.add_spheres(extra); chk.add_capsules(caps); chk.dilate_sphere(robot.r); chk.remove_interior()
+    add("environment edits (grid_add_spheres / grid_add_capsules / grid_dilate_step / grid_remove_interior / dilate2_blocks)",
+        bytes=3 * 2.0 * 2 ** 21, units=3, unit="edit sequences on a 2 MiB grid")
+    units["_edge_path_profile_slots"] = prof_e
+    units["_meta"] = {"vertices": V, "edges": int(len(edges)), "valid_edges": int(len(e_ok)), "fk_samples": n_samples,
+                      "cache_blocks": nblk, "small": small}
+    json.dump(units, open(os.path.join(out_dir, "units.json"), "w"), indent=1)
+    print("workload done:", json.dumps(units["_meta"]))
+
+
+if __name__ == "__main__":
+    main()
