@@ -1469,23 +1469,35 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
   for (int i = 0; i < N; i++) ext2 += c->max_tension[i] * c->max_tension[i];
   const double ext = std::sqrt(ext2);                         // RealVectorStateSpace::getMaximumExtent
   trk::KnnMetric m{N, c->K.enable_rotation, c->K.enable_retraction, S, ext / (4.0 * M_PI), 2.0 * ext / c->K.L};
-  double *d_s = nullptr, *d_d = nullptr; int32_t *d_i = nullptr;
+  // candidate slices: enough waves to keep ~8 on every SIMD (see knn_kernel.hpp); at most 32 slices of at least 256 candidates
+  const int64_t qblocks = (n + 63) / 64;
+  int nslice = (int)std::min<int64_t>(32, std::max<int64_t>(1, (8 * 1024 + qblocks - 1) / qblocks));
+  nslice = (int)std::min<int64_t>(nslice, std::max<int64_t>(1, n / 256));
+  const int64_t slice = (n + nslice - 1) / nslice;
+  nslice = (int)((n + slice - 1) / slice);
+  double *d_s = nullptr, *d_d = nullptr, *d_pd = nullptr; int32_t *d_i = nullptr, *d_pi = nullptr;
   int rc = TR_OK;
   do {
     if (hipMalloc((void **)&d_s, (size_t)n * S * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&d_d, (size_t)n * k * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&d_i, (size_t)n * k * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    if (nslice > 1 && (hipMalloc((void **)&d_pd, (size_t)n * nslice * k * sizeof(double)) != hipSuccess ||
+                       hipMalloc((void **)&d_pi, (size_t)n * nslice * k * sizeof(int32_t)) != hipSuccess)) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
     if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
-      const dim3 grid((unsigned)((n + 63) / 64));
+      const dim3 grid((unsigned)qblocks, (unsigned)nslice);
       const size_t lds = (size_t)k * 64 * 12;
+      int32_t *oi = nslice > 1 ? d_pi : d_i;
+      double *od = nslice > 1 ? d_pd : d_d;
       switch (N) {
-#define TRK_CASE(NT) case NT: hipLaunchKernelGGL(trk::knn_bruteforce<NT>, grid, dim3(64), lds, nullptr, d_s, n, m, (int)k, max_distance, d_i, d_d); break;
+#define TRK_CASE(NT) case NT: hipLaunchKernelGGL(trk::knn_bruteforce<NT>, grid, dim3(64), lds, nullptr, d_s, n, m, (int)k, max_distance, slice, oi, od); break;
         TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
         default: break;
       }
+      if (nslice > 1)
+        hipLaunchKernelGGL(trk::knn_merge, dim3((unsigned)qblocks), dim3(64), (size_t)nslice * 64, nullptr, d_pi, d_pd, n, nslice, (int)k, max_distance, d_i, d_d);
     }
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, TR_ERR_HIP, "knn launch failed"); break; }
     if (hipMemcpy(idx, d_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
@@ -1494,6 +1506,8 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
   if (d_s) (void)hipFree(d_s);
   if (d_d) (void)hipFree(d_d);
   if (d_i) (void)hipFree(d_i);
+  if (d_pd) (void)hipFree(d_pd);
+  if (d_pi) (void)hipFree(d_pi);
   return rc;
 }
 

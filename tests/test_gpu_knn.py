@@ -61,3 +61,22 @@ def test_knn_errors(irt):
     assert idx.shape == (0, 4)
     idx, dist = e.knn(np.array([[1.0, 2.0, 3.0], [1.0, 2.0, 4.0]]), 4)     # fewer states than k
     assert idx.tolist() == [[0, 1, -1, -1], [1, 0, -1, -1]] and np.isinf(dist[:, 2:]).all()
+
+
+def test_knn_ties_follow_a_stable_sort_of_the_distances(irt):
+    """Neighbour lists are ordered by the distance CompoundStateSpace::distance returns, ties in index order -- across
+    the candidate slices the kernel works in, and also where two different squared distances round to the same root."""
+    e = irt.workloads.robot_config2().engine()
+    rng = np.random.default_rng(5)
+    st = rng.integers(0, 7, (3000, 3)).astype(float)          # a small lattice: masses of exact ties and duplicate states
+    idx, dist = e.knn(st, 12)
+    for lo in range(0, 3000, 500):
+        D = np.sqrt(((st[lo:lo + 500, None, :] - st[None, :, :]) ** 2).sum(-1))
+        want = np.argsort(D, axis=1, kind="stable")[:, :12]
+        assert np.array_equal(idx[lo:lo + 500], want)
+        assert np.array_equal(dist[lo:lo + 500], np.take_along_axis(D, want, 1))
+    # 2^60 + 256 and 2^60 are different doubles with the same correctly rounded square root, 2^30
+    big = np.array([[0.0, 0, 0], [2.0 ** 30, 16.0, 0], [2.0 ** 30, 0, 0], [2.0 ** 30, 0, 16.0]])
+    assert np.sqrt(2.0 ** 60 + 256) == 2.0 ** 30
+    idx, dist = e.knn(big, 4)
+    assert idx[0].tolist() == [0, 1, 2, 3] and dist[0].tolist() == [0.0, 2.0 ** 30, 2.0 ** 30, 2.0 ** 30]
