@@ -11,6 +11,7 @@
 // includes v itself (distance 0), which connectVertices then skips (:2848).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "tr_types.hpp"
 
 namespace trk {
@@ -22,6 +23,7 @@ struct KnnMetric {
 
 constexpr int KNN_SMAX = TRK_MAX_TENDONS + 2;
 
+
 // One wave = 64 queries x one slice [j0, j1) of the candidates.  A roadmap of 10^5 vertices is only ~1 600 query waves --
 // fewer than two per SIMD, so every scalar candidate load would be paid in full; slicing the candidate range over
 // blockIdx.y puts 8+ waves on every SIMD (r02 profile: 17 % VALU issue utilisation, 57 % of wave cycles waiting, before).
@@ -30,9 +32,12 @@ constexpr int KNN_SMAX = TRK_MAX_TENDONS + 2;
 // candidates whose squared distances differ but whose square roots round to the same double tie and stay in index order,
 // exactly like a stable sort of the distances.  The square root is only taken for candidates that pass a conservative
 // test on the squared distance (rare once the list has warmed up).
-template <int NT>            // tension dimensions, compile time: the inner product is 3 NT straight-line fp64 operations
+// NT tension dimensions and the presence of the rotation / retraction coordinates are compile-time: a chunk is then
+// straight-line code and its scalar loads are issued back to back.
+template <int NT, bool ROT, bool RET>
 __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ states, int64_t n, KnnMetric m, int k,
-                                                     double max_dist, int64_t slice, int32_t *__restrict__ out_idx,
+                                                     double max_dist, int64_t slice, int64_t n_cand, const double *__restrict__ seed,
+                                                     double *__restrict__ seed_out, int32_t *__restrict__ out_idx,
                                                      double *__restrict__ out_dist) {
 #pragma clang fp contract(off)
   extern __shared__ unsigned char knn_lds[];
@@ -46,43 +51,100 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
 #pragma unroll
   for (int d = 0; d < KNN_SMAX; d++) x[d] = d < S ? states[qc * S + d] : 0.0;
   for (int p = 0; p < k; p++) { bd[p * 64] = 1.0 / 0.0; bi[p * 64] = -1; }
-  double worst = 1.0 / 0.0;                         // distance of the lane's current k-th entry
-  double gate2 = 1.0 / 0.0;                         // plain metric: squared distances at or above this cannot beat `worst`
-  const bool plain = !m.has_rot && !m.has_ret;
-  const int64_t j0 = (int64_t)blockIdx.y * slice, j1 = (j0 + slice < n) ? j0 + slice : n;
-#pragma unroll 8
-  for (int64_t j = j0; j < j1; j++) {
-    const double *__restrict__ c = states + j * S;  // wave-uniform
-    double s2 = 0.0;
+  // `worst`: a candidate must be strictly closer than this to enter the list -- the lane's current k-th entry, or, while
+  // the list is not full, the SEED: the k-th smallest distance of the query to a sample of the candidates (a first,
+  // short launch of this kernel with seed_out set).  The k nearest of all candidates are at most that far, so a slice
+  // starts by accepting exactly the candidates with distance <= seed instead of filling its list with whatever comes
+  // first and shifting it ~k ln(slice / k) times (those insertions, not the distances, were 80 % of the kernel's time).
+  double worst = 1.0 / 0.0;
+  if (seed) {
+    const double t = seed[qc];
+    worst = (t < 1.0 / 0.0) ? __longlong_as_double(__double_as_longlong(t) + 1) : t;     // next double above: "<= seed"
+  }
+  double gate2 = worst * worst * (1.0 + 4.5e-16);   // plain metric: squared distances at or above this cannot beat `worst`
+  constexpr bool plain = !ROT && !RET;
+  const int64_t j0 = (int64_t)blockIdx.y * slice, j1 = (j0 + slice < n_cand) ? j0 + slice : n_cand;
+  // Candidates are taken a chunk at a time: their scalar loads are issued together and the wave leaves the chunk at once
+  // unless some lane can improve its list -- rare after the first few hundred candidates.  (One candidate per iteration
+  // exposed a full scalar-load round trip each time: 300 cycles per candidate against ~40 of arithmetic.)
+  constexpr int SS = NT + (ROT ? 1 : 0) + (RET ? 1 : 0);            // doubles per candidate
+  constexpr int CH = SS <= 4 ? 8 : 4;                               // <= 64 SGPRs of candidate data in flight
+  // FULL chunks address their candidates at compile-time offsets from one pointer (S == SS for this instantiation) and
+  // need no tail masking: ~12 scalar instructions per chunk instead of ~110 (the scalar unit is shared by the CU's four
+  // SIMDs, and 64-bit index arithmetic per candidate cost as many issue cycles as the distances themselves).
+  auto do_chunk = [&](auto full_tag, int64_t jb) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    double cc[CH][SS];
 #pragma unroll
-    for (int d = 0; d < NT; d++) { const double t = x[d] - c[d]; s2 += t * t; }
-    double dist;
-    if (plain) {
-      if (!(s2 < gate2)) continue;
-      dist = sqrt(s2);
-    } else {
-      dist = sqrt(s2);
-      int col = NT;
-      if (m.has_rot) {                              // SO2StateSpace::distance
-        double a = fabs(x[NT] - c[NT]);
-        a = (a > 3.14159265358979323846) ? 2.0 * 3.14159265358979323846 - a : a;
-        dist += m.w_rot * a;
-        col++;
+    for (int u = 0; u < CH; u++) {
+      const int64_t j = (FULL || jb + u < j1) ? jb + u : j1 - 1;  // wave-uniform; a tail chunk repeats the last candidate, masked below
+      const double *__restrict__ c = FULL ? states + jb * SS + u * SS : states + j * SS;
+#pragma unroll
+      for (int d = 0; d < SS; d++) cc[u][d] = c[d];
+    }
+    __builtin_amdgcn_sched_barrier(0);                              // all of the chunk's scalar loads are issued before any of its arithmetic
+    double dd[CH];                                  // plain metric: squared distance; otherwise the distance itself
+#pragma unroll
+    for (int u = 0; u < CH; u++) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < NT; d++) { const double t = x[d] - cc[u][d]; s2 += t * t; }
+      double dist = s2;
+      if constexpr (!plain) {
+        dist = sqrt(s2);
+        if constexpr (ROT) {                                  // SO2StateSpace::distance
+          double a = fabs(x[NT] - cc[u][NT]);
+          a = (a > 3.14159265358979323846) ? 2.0 * 3.14159265358979323846 - a : a;
+          dist += m.w_rot * a;
+        }
+        if constexpr (RET) {
+          const double t = x[SS - 1] - cc[u][SS - 1];
+          dist += m.w_ret * sqrt(t * t);
+        }
       }
-      if (m.has_ret) {
-        const double xs = m.has_rot ? x[NT + 1] : x[NT];
-        const double t = xs - c[col];
-        dist += m.w_ret * sqrt(t * t);
+      dd[u] = (FULL || jb + u < j1) ? dist : 1.0 / 0.0;
+    }
+    double mn = dd[0];
+#pragma unroll
+    for (int u = 1; u < CH; u++) mn = fmin(mn, dd[u]);
+    if (!__any(mn < (plain ? gate2 : worst))) return;
+#pragma unroll
+    for (int u = 0; u < CH; u++) {                  // in index order
+      double dist = dd[u];
+      if (plain) {
+        if (!(dist < gate2)) continue;
+        dist = sqrt(dist);
+      }
+      if (dist < worst) {                           // strict: on exact ties the lower index stays
+        // Sorted insertion without a data-dependent loop: entry e becomes its left neighbour when that one is farther
+        // than the candidate (shift), the candidate when the entry itself is the first one farther, else it stays.  Every
+        // entry is a function of two OLD entries, so the LDS reads do not wait for one another (the shifting while-loop
+        // paid a full LDS round trip per step: ~900 cycles per insertion against ~500 for a chunk's distances).
+        const int32_t cj = (int32_t)(jb + u);
+        double right = bd[(k - 1) * 64];
+        int32_t righti = bi[(k - 1) * 64];
+        for (int e = k - 1; e > 0; e--) {
+          const double left = bd[(e - 1) * 64];
+          const int32_t lefti = bi[(e - 1) * 64];
+          const bool shift = left > dist, take = right > dist;
+          bd[e * 64] = shift ? left : (take ? dist : right);
+          bi[e * 64] = shift ? lefti : (take ? cj : righti);
+          right = left; righti = lefti;
+        }
+        if (right > dist) { bd[0] = dist; bi[0] = cj; }
+        const double kth = bd[(k - 1) * 64];
+        if (kth < worst) worst = kth;               // (an unfilled list keeps the seed as its threshold)
+        // sqrt(s2) < worst needs s2 < worst^2 (1 + 2^-51): beyond that the correctly rounded root is >= worst
+        gate2 = worst * worst * (1.0 + 4.5e-16);
       }
     }
-    if (dist < worst) {                             // strict: on exact ties the lower index stays
-      int p = k - 1;
-      while (p > 0 && bd[(p - 1) * 64] > dist) { bd[p * 64] = bd[(p - 1) * 64]; bi[p * 64] = bi[(p - 1) * 64]; p--; }
-      bd[p * 64] = dist; bi[p * 64] = (int32_t)j;
-      worst = bd[(k - 1) * 64];
-      // sqrt(s2) < worst needs s2 < worst^2 (1 + 2^-51): beyond that the correctly rounded root is >= worst
-      gate2 = worst * worst * (1.0 + 4.5e-16);
-    }
+  };
+  int64_t jb = j0;
+  for (; jb + CH <= j1; jb += CH) do_chunk(std::true_type{}, jb);
+  if (jb < j1) do_chunk(std::false_type{}, jb);
+  if (seed_out) {                                   // sampling pass: only the k-th distance is wanted
+    if (live) seed_out[q] = bd[(k - 1) * 64];
+    return;
   }
   if (live) {
     // slice lists go to out_* laid out [query][slice][k]; with one slice that is the final result

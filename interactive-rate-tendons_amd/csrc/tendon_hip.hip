@@ -1475,9 +1475,12 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
   nslice = (int)std::min<int64_t>(nslice, std::max<int64_t>(1, n / 256));
   const int64_t slice = (n + nslice - 1) / nslice;
   nslice = (int)((n + slice - 1) / slice);
-  double *d_s = nullptr, *d_d = nullptr, *d_pd = nullptr; int32_t *d_i = nullptr, *d_pi = nullptr;
+  double *d_s = nullptr, *d_d = nullptr, *d_pd = nullptr, *d_seed = nullptr; int32_t *d_i = nullptr, *d_pi = nullptr;
+  // seeding pass (knn_kernel.hpp) when the candidates are sliced: the k-th distance to the first n / 16 candidates
+  const int64_t n_sample = (nslice > 1 && n >= 8192) ? std::min<int64_t>(16384, std::max<int64_t>(2048, n / 16)) : 0;
   int rc = TR_OK;
   do {
+    if (n_sample && hipMalloc((void **)&d_seed, (size_t)n * sizeof(double)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
     if (hipMalloc((void **)&d_s, (size_t)n * S * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&d_d, (size_t)n * k * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&d_i, (size_t)n * k * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
@@ -1490,10 +1493,18 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
       const size_t lds = (size_t)k * 64 * 12;
       int32_t *oi = nslice > 1 ? d_pi : d_i;
       double *od = nslice > 1 ? d_pd : d_d;
+      const int variant = (c->K.enable_rotation ? 1 : 0) | (c->K.enable_retraction ? 2 : 0);
+#define TRK_KNN(NT, R, T) do { \
+        if (n_sample) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), dim3((unsigned)qblocks, 1), dim3(64), lds, nullptr, d_s, n, m, (int)k, \
+                                         max_distance, n_sample, n_sample, (const double *)nullptr, d_seed, (int32_t *)nullptr, (double *)nullptr); \
+        hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), grid, dim3(64), lds, nullptr, d_s, n, m, (int)k, max_distance, slice, n, \
+                           (const double *)d_seed, (double *)nullptr, oi, od); } while (0)
       switch (N) {
-#define TRK_CASE(NT) case NT: hipLaunchKernelGGL(trk::knn_bruteforce<NT>, grid, dim3(64), lds, nullptr, d_s, n, m, (int)k, max_distance, slice, oi, od); break;
+#define TRK_CASE(NT) case NT: if (variant == 0) TRK_KNN(NT, false, false); else if (variant == 1) TRK_KNN(NT, true, false); \
+                              else if (variant == 2) TRK_KNN(NT, false, true); else TRK_KNN(NT, true, true); break;
         TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
+#undef TRK_KNN
         default: break;
       }
       if (nslice > 1)
@@ -1508,6 +1519,7 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
   if (d_i) (void)hipFree(d_i);
   if (d_pd) (void)hipFree(d_pd);
   if (d_pi) (void)hipFree(d_pi);
+  if (d_seed) (void)hipFree(d_seed);
   return rc;
 }
 
