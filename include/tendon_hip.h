@@ -274,7 +274,7 @@ int tr_check_cached_subset_dev(tr_ctx *ctx, const uint32_t *d_block_ids, const u
  * of (block id, mask).  Results are CSR: offsets[n+1] is written here (item i owns
  * offsets[i]..offsets[i+1]-1, nothing for an invalid shape); the lists stay inside the context
  * until tr_voxelize_fetch copies them.  shape_valid_bits: ceil(n/64) words; tips optional n x 3.
- * Block order inside an item is unspecified. */
+ * Inside an item the blocks are distinct and ordered by block id. */
 int tr_voxelize_batch(tr_ctx *ctx, const double *states, int64_t n, int64_t *offsets,
                       uint64_t *shape_valid_bits, double *tips);
 

@@ -610,11 +610,15 @@ __global__ __launch_bounds__(64) void backbone_voxel_sweep(
 }
 
 // K5 `backbone_voxelize`: the robot's own voxel set (what voxelize_impl returns,
-// VoxelBackboneValidityChecker.h:49-57) as a sparse list of (block id, 64-bit mask) per configuration --
-// the form roadmap voxel caches are stored in (VoxelCachedLazyPRM.cpp:2816-2823).  One lane per
-// configuration; cells arrive mostly block by block, so the lane keeps the current block in registers
-// and merges it into its list (a column of ids/masks, [maxB][ld]) when the walk leaves the block.
-// counts[i] = number of distinct blocks, or -1 when the list overflowed maxB.
+// VoxelBackboneValidityChecker.h:49-57) as a list of (block id, 64-bit mask) per configuration -- the form roadmap
+// voxel caches are stored in (VoxelCachedLazyPRM.cpp:2816-2823).  One lane per configuration; cells arrive mostly block
+// by block, so the lane keeps the current AND the previous block in registers (a walk that hops back and forth over a
+// block face costs nothing) and appends a block to its list (a column of ids / masks, [maxB][ld]) when the walk has left
+// it for a third one.  A block the backbone RETURNS to later is appended again: the lists may hold a block more than
+// once, and every consumer goes through the sort + reduce-by-key of cache_merge.hip (which ORs duplicates), so the
+// delivered sets are duplicate-free and ordered by block id.  (The first version searched the lane's whole list in
+// global memory on every append: 74 % of the kernel's wave cycles were waits, r02 profile.)
+// counts[i] = entries written, or -1 when the list overflowed maxB or a point left the representable range.
 __global__ __launch_bounds__(64) void backbone_voxelize(
     const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
     const int32_t *__restrict__ n_points, const uint64_t *__restrict__ shape_valid_bits, int64_t n, int64_t ld, int P,
@@ -627,21 +631,22 @@ __global__ __launch_bounds__(64) void backbone_voxelize(
   const int64_t ib = i + (int64_t)(P - np) * ld;         // retraction robots: the lane's point j is in row j + (P - np)
   int cnt = 0;
   bool overflow = false, bad = false;
-  int cur_id = -1;
-  uint64_t cur_mask = 0;
-  auto flush = [&]() {
-    if (cur_id < 0) return;
-    for (int k = 0; k < cnt; k++)
-      if (ids[(int64_t)k * ld + i] == (uint32_t)cur_id) { masks[(int64_t)k * ld + i] |= cur_mask; return; }
+  int cur_id = -1, prev_id = -1;
+  uint64_t cur_mask = 0, prev_mask = 0;
+  auto append = [&](int id, uint64_t m) {
+    if (id < 0) return;
     if (cnt >= maxB) { overflow = true; return; }
-    ids[(int64_t)cnt * ld + i] = (uint32_t)cur_id;
-    masks[(int64_t)cnt * ld + i] = cur_mask;
+    ids[(int64_t)cnt * ld + i] = (uint32_t)id;
+    masks[(int64_t)cnt * ld + i] = m;
     cnt++;
   };
   auto set_cell = [&](int x, int y, int z) {
     const int id = ((x >> 2) * g.Nb + (y >> 2)) * g.Nb + (z >> 2);
     const uint64_t bit = 1ull << (((x & 3) << 4) | ((y & 3) << 2) | (z & 3));
-    if (id != cur_id) { flush(); cur_id = id; cur_mask = 0; }
+    if (id != cur_id) {
+      if (id == prev_id) { const int t = cur_id; cur_id = prev_id; prev_id = t; const uint64_t tm = cur_mask; cur_mask = prev_mask; prev_mask = tm; }
+      else { append(prev_id, prev_mask); prev_id = cur_id; prev_mask = cur_mask; cur_id = id; cur_mask = 0; }
+    }
     cur_mask |= bit;
     return false;
   };
@@ -663,22 +668,14 @@ __global__ __launch_bounds__(64) void backbone_voxelize(
     }
     prev = q;
   }
-  flush();
+  append(prev_id, prev_mask);
+  append(cur_id, cur_mask);
   counts[i] = (overflow || bad) ? -1 : cnt;
 }
 
-// CSR compaction of the per-lane lists: item i's entries go to [offsets[i], offsets[i] + counts[i]).
-__global__ __launch_bounds__(256) void compact_block_lists(
-    const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int32_t *__restrict__ counts,
-    const int64_t *__restrict__ offsets, int64_t n, int64_t ld, uint32_t *__restrict__ out_ids, uint64_t *__restrict__ out_masks) {
+__global__ __launch_bounds__(256) void iota_i32(int32_t *__restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const int c = counts[i];
-  const int64_t o = offsets[i];
-  for (int k = 0; k < c; k++) {
-    out_ids[o + k] = ids[(int64_t)k * ld + i];
-    out_masks[o + k] = masks[(int64_t)k * ld + i];
-  }
+  if (i < n) out[i] = (int32_t)i;
 }
 
 // Obstacle grid dilated by 2 cells in the Chebyshev metric (a cell is set iff some occupied cell

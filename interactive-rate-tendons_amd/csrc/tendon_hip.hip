@@ -135,9 +135,9 @@ struct tr_ctx {
   // result of the last tr_voxelize_* call (host side) and its device scratch
   std::vector<uint32_t> vox_ids;
   std::vector<uint64_t> vox_masks;
-  uint32_t *d_vids = nullptr; uint64_t *d_vmasks = nullptr; int32_t *d_vcounts = nullptr; int64_t *d_voffsets = nullptr;
-  uint32_t *d_cids = nullptr; uint64_t *d_cmasks = nullptr; uint64_t *d_vbits = nullptr;
-  int64_t vox_cap = 0, vox_cnnz = 0;
+  uint32_t *d_vids = nullptr; uint64_t *d_vmasks = nullptr; int32_t *d_vcounts = nullptr;
+  uint64_t *d_vbits = nullptr;
+  int64_t vox_cap = 0;
   int32_t *d_item_src = nullptr, *d_item_edge = nullptr; int64_t vox_items_cap = 0;   // items of the indexed edge-cache merge
   // host-buffer pipeline of tr_validate_batch: pinned staging, copy/compute streams
   struct Pipe {
@@ -695,7 +695,7 @@ void tr_destroy(tr_ctx *c) {
   }
   Workspace &w = c->ws;
   void *ptrs[] = {c->d_tab, c->d_steps, c->d_poly, c->d_tgrid, c->d_hl, c->d_grid, c->d_near, w.homeLi, w.np, c->d_vids, c->d_vmasks, c->d_vcounts,
-                  c->d_voffsets, c->d_cids, c->d_cmasks, c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
+                  c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
                   c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
@@ -1345,7 +1345,8 @@ int tr_check_cached(tr_ctx *c, const uint32_t *ids, const uint64_t *masks, const
 // ---- robot voxel sets -----------------------------------------------------------------------
 namespace {
 
-int vox_max_blocks(const tr_ctx *c) { return 2 * c->K.n_points + 16; }
+// entries of a sample's block list: a backbone of P points enters at most a few hundred blocks even counting re-entries
+int vox_max_blocks(const tr_ctx *c) { return 2 * c->K.n_points + 64; }
 
 int ensure_vox_scratch(tr_ctx *c, int64_t cap) {
   if (c->vox_cap >= cap) return TR_OK;
@@ -1355,7 +1356,6 @@ int ensure_vox_scratch(tr_ctx *c, int64_t cap) {
   if ((rc = dev_alloc(c, &c->d_vids, mb * cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_vmasks, mb * cap))) return rc;
   if ((rc = dev_alloc(c, &c->d_vcounts, (size_t)cap))) return rc;
-  if ((rc = dev_alloc(c, &c->d_voffsets, (size_t)cap + 1))) return rc;
   if ((rc = dev_alloc(c, &c->d_vbits, (size_t)cap / 64 + 1))) return rc;
   c->vox_cap = cap;
   return TR_OK;
@@ -1376,30 +1376,31 @@ int voxelize_samples(tr_ctx *c, int64_t m, int64_t ld, const int32_t *d_np, cons
                        d_bits, m, ld, (int)c->K.n_points, c->G, mb, c->d_vids, c->d_vmasks, c->d_vcounts);
     HIP_TRY(c, hipGetLastError());
   }
-  counts.resize((size_t)m);
-  HIP_TRY(c, hipMemcpy(counts.data(), c->d_vcounts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
-  offs.assign((size_t)m + 1, 0);
-  for (int64_t i = 0; i < m; i++) {
-    if (counts[(size_t)i] < 0) return fail(c, TR_ERR_RUNTIME, "voxel set of a configuration exceeds the block-list capacity or leaves the domain");
-    offs[(size_t)i + 1] = offs[(size_t)i] + counts[(size_t)i];
+  // duplicate-free lists ordered by block id: the sort + reduce-by-key of the edge caches with one "edge" per sample
+  if (c->vox_items_cap < m) {
+    HIP_TRY(c, hipDeviceSynchronize());
+    if ((rc = dev_alloc(c, &c->d_item_src, (size_t)m + m / 4))) return rc;
+    if ((rc = dev_alloc(c, &c->d_item_edge, (size_t)m + m / 4))) return rc;
+    c->vox_items_cap = m + m / 4;
   }
-  const int64_t nnz = offs[(size_t)m];
-  if (nnz > c->vox_cnnz) {
-    if (c->d_cids) (void)hipFree(c->d_cids);
-    if (c->d_cmasks) (void)hipFree(c->d_cmasks);
-    c->d_cids = nullptr; c->d_cmasks = nullptr;
-    c->vox_cnnz = nnz + nnz / 4 + 1024;
-    HIP_TRY(c, hipMalloc((void **)&c->d_cids, (size_t)c->vox_cnnz * sizeof(uint32_t)));
-    HIP_TRY(c, hipMalloc((void **)&c->d_cmasks, (size_t)c->vox_cnnz * sizeof(uint64_t)));
-  }
-  ids.resize((size_t)nnz); masks.resize((size_t)nnz);
-  if (nnz > 0) {
-    HIP_TRY(c, hipMemcpy(c->d_voffsets, offs.data(), (size_t)(m + 1) * sizeof(int64_t), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(trk::compact_block_lists, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nullptr, c->d_vids, c->d_vmasks,
-                       c->d_vcounts, c->d_voffsets, m, ld, c->d_cids, c->d_cmasks);
+  int64_t nu = 0;
+  int ovf = 0;
+  {
+    ProfScope ps(c, 3, nullptr);
+    hipLaunchKernelGGL(trk::iota_i32, dim3((unsigned)((m + 255) / 256)), dim3(256), 0, nullptr, c->d_item_edge, m);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpy(ids.data(), c->d_cids, (size_t)nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(masks.data(), c->d_cmasks, (size_t)nnz * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, trk::merge_edge_caches(c->merge, c->d_vids, c->d_vmasks, c->d_vcounts, nullptr, c->d_item_edge, m, ld, c->n_blocks, m, &nu, &ovf, nullptr));
+  }
+  if (ovf) return fail(c, TR_ERR_RUNTIME, "voxel set of a configuration exceeds the block-list capacity or leaves the domain");
+  counts.resize((size_t)m);
+  HIP_TRY(c, hipMemcpy(counts.data(), c->merge.ecount, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost));
+  offs.assign((size_t)m + 1, 0);
+  for (int64_t i = 0; i < m; i++) offs[(size_t)i + 1] = offs[(size_t)i] + counts[(size_t)i];
+  if (offs[(size_t)m] != nu) return fail(c, TR_ERR_RUNTIME, "voxel cache merge: counts do not add up");
+  ids.resize((size_t)nu); masks.resize((size_t)nu);
+  if (nu > 0) {
+    HIP_TRY(c, hipMemcpy(ids.data(), c->merge.uids, (size_t)nu * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(masks.data(), c->merge.uvals, (size_t)nu * sizeof(uint64_t), hipMemcpyDeviceToHost));
   }
   return TR_OK;
 }

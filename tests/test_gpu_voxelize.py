@@ -178,3 +178,23 @@ def test_indexed_edge_caches_equal_the_pairwise_form(irt):
                 assert np.array_equal(ix[k], pw[k]), (k, env)
         assert 0.02 < ix["fully_valid"].mean() <= 1.0 and ix["offsets"][-1] > 1000
     assert not ix["fully_valid"].all()                         # the last robot leaves edges without a cache
+
+
+def test_vertex_sets_are_duplicate_free_and_ordered(irt):
+    """The per-sample lists may hold a block twice (a backbone that returns to it); what tr_voxelize_batch delivers is
+    duplicate-free and ordered by block id -- also for tightly curled robots, where re-entries are common."""
+    W = irt.workloads
+    thin = W.robot_config1()
+    thin.specs.dL = 0.2 / 128
+    thin.r = 0.002
+    for t in thin.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 1.0
+    vox, _ = W.reach_environment(seed=7, n_spheres=8)
+    eng = irt.VoxelBackboneValidityChecker(thin, irt.VoxelEnvironment(), vox).engine
+    st = W.random_states(thin, 3000, seed=9, tau_max=100.0)
+    out = eng.voxelize_batch(st)
+    off = out["offsets"]
+    assert out["shape_valid"].sum() > 500
+    for i in np.flatnonzero(out["shape_valid"])[:800]:
+        ids = out["block_ids"][off[i]:off[i + 1]]
+        assert (np.diff(ids.astype(np.int64)) > 0).all() and (out["masks"][off[i]:off[i + 1]] != 0).all()
