@@ -135,10 +135,17 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-log2", type=int, default=BATCH_LOG2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", default="config2", choices=["config2", "roadmap"],
+                    help="config2 (default): the headline line.  roadmap: BASELINE configs 3 and 5 at full size on one GPU "
+                         "(bench_roadmap.py: 100k-vertex PRM, k-NN edges, edge validation with the FK-samples/edge histogram, voxel "
+                         "caches, 10k lazy queries) -- prints that script's JSON object instead of the headline line")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
     args = ap.parse_args()
 
+    if args.workload == "roadmap":
+        import bench_roadmap
+        return bench_roadmap.main([] if not args.no_cpu_baseline else ["--no-cpu"])
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
 

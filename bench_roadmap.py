@@ -18,14 +18,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
-def main():
+def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--vertices", type=int, default=100000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the sequential CPU port of the query loop")
     ap.add_argument("--cache-items", type=int, default=200000)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
     irt = importlib.import_module("interactive-rate-tendons_amd")
     W = irt.workloads
     robot = W.robot_config3()
@@ -52,12 +52,14 @@ def main():
             "edges_per_s": len(edges) / t["edges"]["seconds"],
             "edge_fk_samples_per_s": t["edges"]["fk_samples"] / t["edges"]["seconds"],
             "edge_valid_fraction": float(valid.mean()),
-            "fk_samples_per_edge": {"mean": float(nfk.mean()), "p50": float(np.median(nfk)), "max": int(nfk.max())},
+            "fk_samples_per_edge": {"mean": float(nfk.mean()), "p50": float(np.median(nfk)), "max": int(nfk.max()),
+                                    "histogram": {str(k_): int(c_) for k_, c_ in enumerate(np.bincount(nfk)) if c_}},
         }
     }
     # config 5: caches for a slice of the roadmap, then re-validation against a perturbed environment
     nv = min(args.cache_items, len(states))
     ne = min(args.cache_items, len(edges))
+    rb.vertex_caches(states[:4096]); rb.edge_caches(states, edges[:4096])        # warm-up: block-list scratch, merge buffers
     vc = rb.vertex_caches(states[:nv])
     ec = rb.edge_caches(states, edges[:ne])
     new_vox, _ = W.reach_environment(seed=7, n_spheres=72)
