@@ -362,6 +362,12 @@ int tr_roadmap_solve(tr_roadmap *rm, const int32_t *starts, const int32_t *goals
                      int32_t *status, double *cost, int64_t *path_offsets, tr_roadmap_stats *stats);
 int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capacity);
 
+/* k of the PRM* connection strategy for a roadmap of n_milestones vertices (og::KStarStrategy as installed by
+ * setStarConnectionStrategy, motion-planning/VoxelCachedLazyPRM.cpp:1346-1356): ceil((e + e / dim) * ln(n)), dim =
+ * state dimension.  createRoadmap connects after all vertices are in place, so this k applies to every vertex of the
+ * batch: pass k + 1 to tr_knn (row i holds i itself first).  -1 on bad arguments. */
+int tr_kstar_k(const tr_ctx *ctx, int64_t n_milestones);
+
 /* ---- instrumentation ---------------------------------------------------------------------- */
 
 /* Time the last `which` kernel launches with HIP events on the stream they ran on.

@@ -1524,6 +1524,17 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
   return rc;
 }
 
+// KStarStrategy (OMPL 1.5.0 ompl/geometric/planners/prm/ConnectionStrategy.h, installed by setStarConnectionStrategy,
+// motion-planning/VoxelCachedLazyPRM.cpp:1346-1356): k = ceil((e + e / dim) * ln(n)) with n = milestoneCount().  In
+// createRoadmap every vertex is in the nearest-neighbour structure before the connection loop starts (:1463-1502), so
+// one k serves the whole batch.
+int tr_kstar_k(const tr_ctx *c, int64_t n_milestones) {
+  if (!c || n_milestones < 1) return -1;
+  const double e = 2.718281828459045235360287471352662498;   // boost::math::constants::e<double>()
+  const double kc = e + e / (double)c->K.state_size;
+  return (int)std::ceil(kc * std::log((double)n_milestones));
+}
+
 // ---- instrumentation -----------------------------------------------------------------------
 int tr_profile_begin(tr_ctx *c) {
   if (!c) return TR_ERR_INVALID_ARG;

@@ -250,6 +250,13 @@ class Engine:
                                            idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dist)))
         return idx, dist
 
+    def kstar_k(self, n_milestones):
+        """k of og::KStarStrategy for a roadmap of n_milestones vertices (PRM*)."""
+        k = self.lib.tr_kstar_k(self._ctx, int(n_milestones))
+        if k < 0:
+            raise L.InvalidArgument("n_milestones must be positive")
+        return k
+
     def _fetch_lists(self, nnz):
         ids = np.empty(nnz, dtype=np.uint32)
         masks = np.empty(nnz, dtype=np.uint64)

@@ -70,6 +70,11 @@ class RoadmapBuilder:
         self.timing["knn_gpu"] = dict(seconds=time.perf_counter() - t0, edges=len(e))
         return e
 
+    def knn_edges_star(self, states):
+        """The PRM* connection strategy (setStarConnectionStrategy, VoxelCachedLazyPRM.cpp:1346-1356): k grows with the
+        roadmap, k = ceil((e + e/dim) ln n); in createRoadmap all n vertices are in place before connecting."""
+        return self.knn_edges_gpu(states, self.engine.kstar_k(len(states)) + 1)
+
     def knn_edges(self, states, k):
         """Undirected k-NN edge list (i < j).  Distances are the compound-space sums of per-subspace
         norms; for tension-only robots that is the Euclidean norm, which cKDTree handles exactly."""

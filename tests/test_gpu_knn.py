@@ -80,3 +80,21 @@ def test_knn_ties_follow_a_stable_sort_of_the_distances(irt):
     assert np.sqrt(2.0 ** 60 + 256) == 2.0 ** 30
     idx, dist = e.knn(big, 4)
     assert idx[0].tolist() == [0, 1, 2, 3] and dist[0].tolist() == [0.0, 2.0 ** 30, 2.0 ** 30, 2.0 ** 30]
+
+
+def test_kstar_connection_strategy(irt):
+    """og::KStarStrategy: k = ceil((e + e/dim) ln n) -- 40 for the 4-dimensional config-3 space at 10^5 vertices."""
+    W = irt.workloads
+    e4, e3 = W.robot_config3().engine(), W.robot_config2().engine()
+    assert e4.kstar_k(100000) == int(np.ceil((np.e + np.e / 4) * np.log(1e5))) == 40
+    assert e3.kstar_k(1000) == int(np.ceil((np.e + np.e / 3) * np.log(1000)))
+    with pytest.raises(irt.InvalidArgument):
+        e3.kstar_k(0)
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=16)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=2)
+    st = W.random_states(robot, 3000, seed=83)
+    k = chk.engine.kstar_k(len(st))
+    e = rb.knn_edges_star(st)
+    assert np.array_equal(e, rb.knn_edges(st, k)) and len(e) >= len(st) * k // 2
