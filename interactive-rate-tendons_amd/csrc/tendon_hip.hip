@@ -1283,7 +1283,7 @@ int tr_check_cached_subset_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t 
   if (!d_ids || !d_masks || !d_offsets || !d_list || !d_hit) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(c, 2, s);
-  hipLaunchKernelGGL(trk::cached_subset_vs_grid, dim3((unsigned)((n_list + 3) / 4)), dim3(256), 0, s, d_ids, d_masks, d_offsets,
+  hipLaunchKernelGGL(trk::cached_subset_vs_grid, dim3((unsigned)((n_list + 15) / 16)), dim3(256), 0, s, d_ids, d_masks, d_offsets,
                      d_list, n_list, n_items, c->d_grid, c->n_blocks, d_hit);
   HIP_TRY(c, hipGetLastError());
   return TR_OK;
