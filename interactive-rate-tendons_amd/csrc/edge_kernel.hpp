@@ -82,6 +82,29 @@ __device__ inline int cells_differ(const double *__restrict__ px, const double *
   return 0;
 }
 
+// cells_differ on cell signatures (sweep_kernel.hpp: cell_signature): the whole wave tests ONE pair of samples, lanes
+// over backbone points from the tip down, 64 at a time (two coalesced 256-byte reads); the first event in tip-first
+// order decides, a domain error at a point before a difference at that point -- as the sequential loop does.
+__device__ inline int signatures_differ(const uint32_t *__restrict__ sig, int64_t stride, int P, int64_t sa, int64_t sb) {
+  const int lane = (int)(threadIdx.x & 63);
+  const uint32_t *__restrict__ ra = sig + sa * stride, *__restrict__ rb = sig + sb * stride;
+  for (int j0 = P - 1; j0 >= 0; j0 -= 64) {
+    const int j = j0 - lane;
+    uint32_t va = 0, vb = 0;
+    if (j >= 0) { va = ra[j]; vb = rb[j]; }
+    const bool bad = ((va | vb) & SIG_BAD) != 0;
+    const int dx = (int)(va & 1023u) - (int)(vb & 1023u), dy = (int)((va >> 10) & 1023u) - (int)((vb >> 10) & 1023u),
+              dz = (int)((va >> 20) & 1023u) - (int)((vb >> 20) & 1023u);
+    const bool diff = !bad && (dx > 1 || dx < -1 || dy > 1 || dy < -1 || dz > 1 || dz < -1);
+    const unsigned long long mb = __ballot(bad), md = __ballot(diff);
+    if (mb | md) {
+      const int fb = mb ? __ffsll((long long)mb) : 65, fd = md ? __ffsll((long long)md) : 65;
+      return fb <= fd ? 2 : 1;
+    }
+  }
+  return 0;
+}
+
 // One slot per lane with pred set, one atomic per wave.  Every lane of the wave must call it.
 __device__ inline uint32_t wave_alloc(bool pred, uint32_t *counter) {
   const unsigned long long mask = __ballot(pred);
@@ -198,10 +221,10 @@ __global__ __launch_bounds__(256) void edge_filter(EdgeState st, const EdgeIv *_
                                                    int64_t n_cand, int64_t s0,
                                                    const double *__restrict__ px, const double *__restrict__ py, const double *__restrict__ pz,
                                                    int64_t ld, int P, const int32_t *__restrict__ n_points, GridK g, int until_invalid,
-                                                   EdgeIv *__restrict__ frontier) {
+                                                   EdgeIv *__restrict__ frontier, const uint32_t *__restrict__ sig, int64_t sig_stride) {
 #pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  bool emit = false;
+  bool emit = false, keep = false;
   EdgeIv c{};
   if (i < n_cand) {
     if (LEVEL0) c = idx ? EdgeIv{(int32_t)i, idx[2 * i], idx[2 * i + 1], 0, 0.0, 1.0} : EdgeIv{(int32_t)i, (int32_t)(2 * i), (int32_t)(2 * i + 1), 0, 0.0, 1.0};
@@ -212,18 +235,29 @@ __global__ __launch_bounds__(256) void edge_filter(EdgeState st, const EdgeIv *_
       c = (i & 1) ? EdgeIv{iv.e, iv.sa, sm, 0, iv.ta, tm} : EdgeIv{iv.e, sm, iv.sb, 0, tm, iv.tb};
     }
     // should_subdivide is false when the first shape is invalid (:307-310); intervals of decided edges are dropped
-    bool keep;
     if (until_invalid) {
       const bool va = (st.bits[c.sa >> 6] >> (c.sa & 63)) & 1ull;
       keep = va && !(__longlong_as_double((long long)st.first_inv[c.e]) <= c.ta);
     } else keep = st.edge_ok[c.e] != 0;
-    if (keep) {
-      const int f = cells_differ(px, py, pz, ld, P, n_points, c.sa, c.sb, g);
-      if (f == 2) {                                            // std::domain_error in the reference
-        if (atomicExch(&st.edge_ok[c.e], 0u) != 0u) atomicAdd(&st.counters[EC_DOMAIN], 1u);
-        if (until_invalid) st.first_inv[c.e] = 0;              // t = 0.0: nothing of this edge is usable
-      } else if (f == 1 && (c.tb - c.ta) > st.rel[c.e]) emit = true;   // width rule of :369-372, applied at push time
+  }
+  int f = 0;
+  if (sig) {
+    // the wave takes its lanes' surviving candidates one after the other, all 64 lanes on one pair of signature rows
+    unsigned long long todo = __ballot(keep);
+    while (todo) {
+      const int l = __ffsll((long long)todo) - 1;
+      todo &= todo - 1;
+      const int r = signatures_differ(sig, sig_stride, P, __shfl(c.sa, l), __shfl(c.sb, l));
+      if ((int)(threadIdx.x & 63) == l) f = r;
     }
+  } else if (keep) {
+    f = cells_differ(px, py, pz, ld, P, n_points, c.sa, c.sb, g);
+  }
+  if (keep) {
+    if (f == 2) {                                              // std::domain_error in the reference
+      if (atomicExch(&st.edge_ok[c.e], 0u) != 0u) atomicAdd(&st.counters[EC_DOMAIN], 1u);
+      if (until_invalid) st.first_inv[c.e] = 0;                // t = 0.0: nothing of this edge is usable
+    } else if (f == 1 && (c.tb - c.ta) > st.rel[c.e]) emit = true;   // width rule of :369-372, applied at push time
   }
   const uint32_t slot = wave_alloc(emit, &st.counters[EC_FRONT]);
   if (emit) frontier[slot] = c;

@@ -252,6 +252,46 @@ struct FusedSweepArgs {
   const uint64_t *grid, *near_grid;
   uint64_t *valid_bits;
   uint8_t *flags;
+  uint32_t *sig;                 // optional: per-sample cell signatures for the edge bisection (below), [n][sig_stride]
+  int64_t sig_stride;
+};
+
+// Cell signature of a backbone point for `should_subdivide` (VoxelEnvironment.cpp:304-341): the point rotated into the voxel
+// frame and located as find_cell does (collision/VoxelOctree.cpp:309-317: closed domain check, then size_t((x - min) / d)
+// -- a DIVISION, unlike add_line's reciprocal multiply): 10 bits per axis, bit 30 = outside the domain or not finite
+// (std::domain_error in the reference).  Two shapes "differ by more than a voxel" at a point iff their cells there differ
+// by more than 1 on some axis: the bisection compares signatures instead of re-reading 24-byte points (r02 profile:
+// the point-reading edge_filter moved 5.7x its algorithmic bytes, one cache line per 8-byte word).
+constexpr uint32_t SIG_BAD = 1u << 30;
+__device__ __forceinline__ uint32_t cell_signature(double x, double y, double z, const GridK &g) {
+#pragma clang fp contract(off)
+  V3 A = {x, y, z};
+  if (!g.rot_is_identity) {
+    A.x = g.inv_rot[0] * x + g.inv_rot[1] * y + g.inv_rot[2] * z;
+    A.y = g.inv_rot[3] * x + g.inv_rot[4] * y + g.inv_rot[5] * z;
+    A.z = g.inv_rot[6] * x + g.inv_rot[7] * y + g.inv_rot[8] * z;
+  }
+  const bool in = !(A.x < g.xmin || g.xmax < A.x || A.y < g.ymin || g.ymax < A.y || A.z < g.zmin || g.zmax < A.z);
+  // NaN compares false everywhere above, i.e. "inside"; non-finite counts as a domain error too
+  if (!in || !(fabs(A.x) < 1e300) || !(fabs(A.y) < 1e300) || !(fabs(A.z) < 1e300)) return SIG_BAD;
+  const uint32_t cx = (uint32_t)(long)((A.x - g.xmin) / g.dx), cy = (uint32_t)(long)((A.y - g.ymin) / g.dy),
+                 cz = (uint32_t)(long)((A.z - g.zmin) / g.dz);
+  return (cx & 1023u) | ((cy & 1023u) << 10) | ((cz & 1023u) << 20);
+}
+
+// fk_uniform_body's point hook of the stored-point fused kernel: writes the signature of every observed point when the
+// launch asks for them (edge samples).  The arguments are re-read per point through an index the optimiser cannot
+// hoist (as in verdict_kernel.hpp), so they hold no SGPRs across the RK4 loop.
+struct SignatureHook {
+  const FusedSweepArgs *sa;
+  uint32_t *row;                 // this lane's signature row, or null
+  __device__ __forceinline__ void begin(bool) const {}
+  __device__ __forceinline__ void operator()(int j, double x, double y, double z) const {
+    if (!row) return;
+    int zero = 0;
+    asm volatile("" : "+s"(zero));
+    row[j] = cell_signature(x, y, z, sa[zero].g);
+  }
 };
 
 // Exact self-collision sweep for one lane set (collision/collision.cpp:6-46), reading the lane's

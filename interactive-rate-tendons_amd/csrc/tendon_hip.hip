@@ -72,6 +72,7 @@ struct EdgeDev {
   unsigned long long *first_inv = nullptr, *last_t = nullptr;
   uint32_t *counters = nullptr;
   uint32_t *nd = nullptr; int64_t *cnt = nullptr;      // discrete variant: validSegmentCount, sample offsets [cap/2 + 2]
+  uint32_t *sig = nullptr; int64_t sig_stride = 0;     // [cap][sig_stride] cell signatures of the pool samples (sweep_kernel.hpp)
 };
 
 }  // namespace
@@ -373,7 +374,7 @@ int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int
 // memory (an asynchronous copy on the launch stream), each guarded by an event so a slot is not rewritten while a
 // launch may still read it.  *slot_out receives the slot (record fr.ev[slot] on the stream after the launch).
 int fused_args_slot(tr_ctx *ctx, const trk::SweepIn &in, int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s,
-                    const trk::FusedSweepArgs **d_args, size_t *lds, int *slot_out) {
+                    const trk::FusedSweepArgs **d_args, size_t *lds, int *slot_out, uint32_t *sig = nullptr, int64_t sig_stride = 0) {
   tr_ctx::FusedRing &fr = ctx->fused;
   if (!fr.d_slots) {
     HIP_TRY(ctx, hipMalloc((void **)&fr.d_slots, sizeof(trk::FusedSweepArgs) * tr_ctx::FusedRing::kSlots));
@@ -391,6 +392,7 @@ int fused_args_slot(tr_ctx *ctx, const trk::SweepIn &in, int check_voxels, uint6
   sweep_geometry(ctx, a.CH, a.NM, *lds);
   a.P = ctx->K.n_points; a.check_voxels = check_voxels; a.debug = ctx->debug;
   a.g = ctx->G; a.grid = ctx->d_grid; a.near_grid = ctx->d_near; a.valid_bits = d_bits; a.flags = d_flags;
+  a.sig = sig; a.sig_stride = sig_stride;
   HIP_TRY(ctx, hipMemcpyAsync(fr.d_slots + slot, &a, sizeof(a), hipMemcpyHostToDevice, s));   // pinned source: asynchronous
   *d_args = fr.d_slots + slot;
   *slot_out = slot;
@@ -399,11 +401,11 @@ int fused_args_slot(tr_ctx *ctx, const trk::SweepIn &in, int check_voxels, uint6
 
 // K1 + K2 in one launch (fused_kernel.hpp; shared arc-length grid only).
 int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
-                 int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
+                 int check_voxels, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s, uint32_t *sig = nullptr, int64_t sig_stride = 0) {
   if (n <= 0) return TR_OK;
   if (check_voxels && !ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   const trk::FusedSweepArgs *d_args; size_t lds; int slot, rc;
-  if ((rc = fused_args_slot(ctx, in, check_voxels, d_bits, d_flags, s, &d_args, &lds, &slot))) return rc;
+  if ((rc = fused_args_slot(ctx, in, check_voxels, d_bits, d_flags, s, &d_args, &lds, &slot, sig, sig_stride))) return rc;
   {
     ProfScope ps(ctx, 4, s);
     const trk::FkLaunch fl{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
@@ -525,8 +527,12 @@ int ensure_sphere_near(tr_ctx *c, hipStream_t s) {
 // K1 then K2 on one stream: a single fused launch when the robot uses the shared arc-length grid.
 // voxel_test: 0 = is_valid_shape only, 1 = backbone voxels (VoxelBackboneValidityChecker), 2 = sphere-swept
 // robot (VoxelValidityChecker: K2 without the voxel test, then K8 on the survivors).
+// sig (optional, edge samples): the fused launch also writes the samples' cell signatures; use edge_signatures(ctx) to
+// learn whether this context's fused path is active (the separate kernels write none).
+bool edge_signatures(const tr_ctx *ctx) { return ctx->fuse != 0 && !ctx->K.enable_retraction; }
+
 int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
-                    int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s) {
+                    int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s, uint32_t *sig = nullptr, int64_t sig_stride = 0) {
   const int check_voxels = voxel_test == 1 ? 1 : 0;
   int rc;
   if (voxel_test == 2) {
@@ -534,7 +540,7 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
     if ((rc = ensure_sphere_near(ctx, s))) return rc;
   }
   if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
-    if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s))) return rc;
+    if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s, sig, sig_stride))) return rc;
   } else {
     if ((rc = launch_fk(ctx, d_states, n, ld, out, s))) return rc;
     if ((rc = launch_sweep(ctx, in, n, ld, check_voxels, d_bits, d_flags, s))) return rc;
@@ -698,7 +704,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->edge.sig, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
