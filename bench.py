@@ -269,9 +269,9 @@ def main():
         # (profiles/isa_counts.json <- profiles/count_isa.py; FMA = 2) x RK4 steps per configuration.  Initial
         # bending and the sweep's arithmetic are not counted.
         isa = load_isa_counts()
-        # fk_verdict runs the RK4 step of fk_sweep_fused (same body, same instantiation flags); its own per-point sweep
-        # (~25 fp64 instructions per point) and the deferred walks are NOT counted as useful flops
-        isa_key = {"fk_verdict": "fk_sweep_fused<%d,false>" % N, "fk_sweep_fused": "fk_sweep_fused<%d,false>" % N,
+        # fk_verdict and fk_sweep_fused hold the same RK4 step (rk4_step<N>: the body compiled without any per-point hook);
+        # the per-point sweep / signature hooks and the deferred walks are NOT counted as useful flops
+        isa_key = {"fk_verdict": "rk4_step<%d>" % N, "fk_sweep_fused": "rk4_step<%d>" % N,
                    "fk_rk4_batch": "fk_rk4_batch_uniform<%d,false,false>" % N}.get(dom_name)
         flops_per_step = isa.get(isa_key, {}).get("flops_per_step")
         flops_per_check = flops_per_step * (P - 1) if flops_per_step else None

@@ -427,7 +427,8 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
 // is stored -- then ONE launch of fk_sweep_fused_list, which integrates again, with stored points, the configurations whose
 // self-collision test needs the exact pairwise sweep (their indices and count stay on the device; with an empty list its
 // blocks return at once).  d_bits / d_flags / d_tips as in tr_validate_batch_dev; n <= 2^31.
-int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_bits, double *d_tips, uint8_t *d_flags, hipStream_t s) {
+int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_bits, double *d_tips, uint8_t *d_flags, hipStream_t s,
+                   uint32_t *sig = nullptr, int64_t sig_stride = 0) {
   if (n <= 0) return TR_OK;
   if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   int rc;
@@ -462,6 +463,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     a.box[4] = g.zmin + 1e-6 * (g.zmax - g.zmin); a.box[5] = g.zmax - 1e-6 * (g.zmax - g.zmin);
   }
   a.fb_list = ctx->d_fb_list; a.fb_count = ctx->d_fb_count;
+  a.sig = sig; a.sig_stride = sig_stride;
   HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb_count, 0, sizeof(uint32_t), s));
   // the fallback pass sweeps columns of the small point workspace
@@ -528,16 +530,23 @@ int ensure_sphere_near(tr_ctx *c, hipStream_t s) {
 // voxel_test: 0 = is_valid_shape only, 1 = backbone voxels (VoxelBackboneValidityChecker), 2 = sphere-swept
 // robot (VoxelValidityChecker: K2 without the voxel test, then K8 on the survivors).
 // sig (optional, edge samples): the fused launch also writes the samples' cell signatures; use edge_signatures(ctx) to
-// learn whether this context's fused path is active (the separate kernels write none).
+// learn whether this context's fused path is active (the separate kernels write none).  points_unused: the caller will not
+// read the points of this launch (out.px .. may then stay unwritten).
 bool edge_signatures(const tr_ctx *ctx) { return ctx->fuse != 0 && !ctx->K.enable_retraction; }
 
 int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
-                    int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s, uint32_t *sig = nullptr, int64_t sig_stride = 0) {
+                    int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s, uint32_t *sig = nullptr, int64_t sig_stride = 0,
+                    bool points_unused = false) {
   const int check_voxels = voxel_test == 1 ? 1 : 0;
   int rc;
   if (voxel_test == 2) {
     if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
     if ((rc = ensure_sphere_near(ctx, s))) return rc;
+  }
+  if (ctx->fuse == 2 && voxel_test == 1 && points_unused && !ctx->K.enable_retraction && !out.R && !out.L && !out.tips) {
+    // nobody reads this launch's backbone points (edge samples of the checkMotion forms: the bisection compares cell
+    // signatures): the verdict-only kernel, which stores none
+    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride);
   }
   if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s, sig, sig_stride))) return rc;

@@ -33,6 +33,8 @@ struct VerdictArgs {
   uint8_t *flags;                 // optional
   int32_t *fb_list;               // configurations that need the exact self-collision sweep
   uint32_t *fb_count;
+  uint32_t *sig;                  // optional (edge samples): cell signatures [n][sig_stride], see sweep_kernel.hpp
+  int64_t sig_stride;
 };
 
 constexpr int VQ = 128;           // ring of deferred segments per wave
@@ -63,6 +65,7 @@ struct PointSweep {
   uint64_t near_prev;             // dilated-grid word of the previous point's block (requested one point ahead)
   int qhead, qcount;              // wave-uniform
   int P, CH, NM, Kl, ms_next, ms_k;   // wave-uniform: point count, milestone spacing / count, last milestone, next milestone row / index
+  uint32_t *sig_row;              // this lane's signature row (edge samples), or null
   bool active;                    // live && converged: only these lanes test voxels
 
   __device__ __forceinline__ void begin(bool on) { active = on; }
@@ -123,6 +126,7 @@ struct PointSweep {
       if (j == ms_next) { ms_next += CH; ms_k++; }
     }
     VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
+    if (sig_row) sig_row[j] = cell_signature(x, y, z, g);
     bool need = false;
     V3 pr = pv, qr = q;
     if (active && !VL_U(VL_HIT + lane)) {
@@ -178,6 +182,11 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
   ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
   VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
+  {
+    uint32_t *sig = va->sig;
+    const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
+    ps.sig_row = (sig && i0 < n) ? sig + i0 * va->sig_stride : nullptr;
+  }
   __syncthreads();
 
   FkLane<N> fl_;

@@ -31,8 +31,25 @@ FLOPS = {"v_fma_f64": 2, "v_fmac_f64": 2, "v_mul_f64": 1, "v_add_f64": 1, "v_rcp
          "v_div_fmas_f64": 2, "v_div_fixup_f64": 1, "v_div_scale_f64": 1, "v_pk_fma_f64": 4, "v_pk_mul_f64": 2,
          "v_pk_add_f64": 2}
 
+_RK4_ONLY = r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "fk_kernel.hpp"
+namespace trk {
+// the RK4 step as fk_verdict and fk_sweep_fused hold it (no rotation, no R output, no backbone-length quadrature), without
+// any per-point hook: the reference count of useful flops per step
+template <int N> __global__ __launch_bounds__(64, 2) void rk4_step_only(const double *states, int64_t n, int64_t ld, RobotK K,
+                                                                         const double *tab, const StepK *steps, int nsteps, FkOut out) {
+  fk_uniform_body<N, false, false, false>(states, n, ld, K, tab, steps, nsteps, out);
+}
+}
+template __global__ void trk::rk4_step_only<%d>(const double*, int64_t, int64_t, RobotK, const double*, const StepK*, int, trk::FkOut);
+'''
+
 KERNELS = {
     # name -> (translation unit, steps per configuration are supplied by the caller: P - 1)
+    "rk4_step<3>": _RK4_ONLY % 3,
+    "rk4_step<4>": _RK4_ONLY % 4,
     "fk_verdict<3,false>": r'''
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"

@@ -51,7 +51,7 @@ def main():
         st = torch.from_numpy(W.random_states(robot, n, seed=3, tau_max=tau)).cuda()
         bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
         tips = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
-        fl_fused = isa["fk_sweep_fused<%d,false>" % N]["flops_per_step"] * (P - 1)
+        fl_fused = isa["rk4_step<%d>" % N]["flops_per_step"] * (P - 1)
         fl_k1 = isa["fk_rk4_batch_uniform<%d,false,false>" % N]["flops_per_step"] * (P - 1)
         for mode, names in (("2", ("fk_verdict",)), ("1", ("fk_sweep_fused",)), ("0", ("fk_rk4_batch_uniform", "backbone_voxel_sweep"))):
             chk = with_env({"TENDON_HIP_FUSED": mode}, lambda: irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox))
@@ -105,7 +105,7 @@ def main():
     chk.engine.profile_end()
     n_samples = int(nfk.sum()) - 2 * len(edges) + V          # FK samples actually integrated (vertices once)
     add("edge path (tr_validate_edges_indexed)", units=len(edges), unit="edges", fk_samples=n_samples)
-    add("edge_filter", bytes=2.0 * 129 * 24 * (n_samples + len(edges)), units=n_samples + len(edges), unit="interval tests (upper bound: early exit from the tip)")
+    add("edge_filter", bytes=2.0 * 129 * 4 * (n_samples + len(edges)), units=n_samples + len(edges), unit="interval tests on cell signatures (upper bound: early exit from the tip)")
     e_ok = edges[valid]
     vc = rb.vertex_caches(states)
     ec = rb.edge_caches(states, e_ok)

@@ -95,7 +95,7 @@ def test_isa_counts_are_current():
     ci = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ci)
     tracked = json.load(open(ci.OUT))
-    fresh = ci.count_all(["fk_sweep_fused<3,false>"])
+    fresh = ci.count_all(["rk4_step<3>", "fk_sweep_fused<3,false>"])
     for k, v in fresh.items():
         assert tracked[k]["flops_per_step"] == v["flops_per_step"], "run `python profiles/count_isa.py`"
         assert tracked[k]["fp64_valu_instructions_per_step"] == v["fp64_valu_instructions_per_step"]
