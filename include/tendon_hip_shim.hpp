@@ -10,6 +10,7 @@
 //   motion_planning::VoxelBackboneMotionValidator                       motion-planning/VoxelBackboneMotionValidator.h
 //   motion_planning::VoxelBackboneDiscreteMotionValidator               motion-planning/VoxelBackboneDiscreteMotionValidator.h
 //   motion_planning::VoxelCaches, voxelize_states, caches_collide       the cache loops of VoxelCachedLazyPRM.cpp
+//   motion_planning::VoxelCachedLazyPRM                                  solveWithRoadmap for a batch of queries on a cached roadmap
 //
 // Error behaviour: every tr_status is rethrown as the C++ exception type the reference throws at
 // the same condition (std::invalid_argument, std::out_of_range, std::domain_error,
@@ -266,6 +267,10 @@ class VoxelBackboneValidityChecker {
 
   // ---- edits of the obstacle set where it lives (collision::VoxelOctree's add_sphere / dilate* /
   // remove_interior, VoxelOctree.cpp:434-469, :533-952, as apps/prepare_voxel_env.cpp:269-315 applies them) ----
+  /// VoxelOctree::add_capsule on the resident obstacle set (collision/VoxelOctree.cpp:471-515)
+  void add_capsules(const std::vector<double> &capsules /* n x (ax, ay, az, bx, by, bz, r) */) const {
+    check(ctx_, tr_grid_add_capsules(ctx_, capsules.data(), (int64_t)(capsules.size() / 7)));
+  }
   void add_spheres(const std::vector<double> &spheres /* n x (cx, cy, cz, r) */) const {
     check(ctx_, tr_grid_add_spheres(ctx_, spheres.data(), (int64_t)(spheres.size() / 4)));
   }
@@ -404,6 +409,20 @@ class VoxelBackboneMotionValidator {
     detail::fetch(vc_.context(), out);
     return out;
   }
+  /// The same for roadmap edges given as index pairs into one vertex array (VoxelCachedLazyPRM.cpp:1751-1775): every
+  /// vertex is integrated and voxelised once for all of its edges.
+  VoxelCaches voxelizeIndexed(const std::vector<double> &states, size_t n_states, const std::vector<int32_t> &edges) const {
+    if (states.size() != n_states * vc_.robot().state_size()) throw std::invalid_argument("State is not the right size");
+    const size_t n = edges.size() / 2;
+    VoxelCaches out;
+    out.offsets.assign(n + 1, 0);
+    std::vector<uint64_t> bits((n + 63) / 64);
+    check(vc_.context(), tr_voxelize_edges_indexed(vc_.context(), &space, states.data(), (int64_t)n_states, edges.data(), (int64_t)n,
+                                                   out.offsets.data(), bits.data(), nullptr));
+    out.usable = detail::unpack(bits, n);
+    detail::fetch(vc_.context(), out);
+    return out;
+  }
   /// CompoundStateSpace::interpolate as wired by Problem.cpp:101-163: linear, shortest arc on the SO2 rotation
   std::vector<double> interpolate(const std::vector<double> &a, const std::vector<double> &b, double t) const {
     const auto &rb = vc_.robot();
@@ -441,6 +460,71 @@ class VoxelBackboneDiscreteMotionValidator : public VoxelBackboneMotionValidator
   int run(const double *a, const double *b, int64_t n, uint64_t *bits, int32_t *n_fk, double *t) const override {
     return tr_validate_edges_discrete(vc_.context(), &space, a, b, n, bits, t, n_fk);
   }
+};
+
+/// The query side of motion_planning::VoxelCachedLazyPRM on a roadmap with voxel caches: solveWithRoadmap
+/// (motion-planning/VoxelCachedLazyPRM.cpp:1977-2096 -> constructSolution :2689-2771) for a batch of (start, goal)
+/// roadmap vertices, clearValidity (:1656-1663), and the eager re-validation of every cached set.
+class VoxelCachedLazyPRM {
+ public:
+  struct Solution { std::vector<int32_t> status; std::vector<double> cost; std::vector<std::vector<int32_t>> paths; tr_roadmap_stats stats; };
+
+  VoxelCachedLazyPRM(const VoxelBackboneValidityChecker &vc, const std::vector<double> &states, size_t n_states,
+                     const std::vector<int32_t> &edges, const std::vector<double> *weights = nullptr)
+      : vc_(vc) {
+    if (states.size() != n_states * vc.robot().state_size()) throw std::invalid_argument("State is not the right size");
+    const int st = tr_roadmap_create(vc.context(), states.data(), (int64_t)n_states, edges.data(), weights ? weights->data() : nullptr,
+                                     (int64_t)(edges.size() / 2), &rm_);
+    if (st == TR_ERR_OUT_OF_RANGE) throw std::out_of_range("edge refers to a state outside the roadmap");
+    if (st != TR_OK) throw std::invalid_argument("tr_roadmap_create failed");
+  }
+  ~VoxelCachedLazyPRM() { tr_roadmap_destroy(rm_); }
+  VoxelCachedLazyPRM(const VoxelCachedLazyPRM &) = delete;
+  VoxelCachedLazyPRM &operator=(const VoxelCachedLazyPRM &) = delete;
+
+  /// vertexVoxelsProperty_ / edgeVoxelsProperty_ as CSR; `usable` = which items have a cache at all
+  void setCaches(const VoxelCaches &vertices, const VoxelCaches &edges) {
+    auto pack = [](const std::vector<bool> &b) {
+      std::vector<uint64_t> w((b.size() + 63) / 64, 0);
+      for (size_t i = 0; i < b.size(); i++) if (b[i]) w[i >> 6] |= (uint64_t)1 << (i & 63);
+      return w;
+    };
+    const auto vp = pack(vertices.usable), ep = pack(edges.usable);
+    rcheck(tr_roadmap_set_caches(rm_, vertices.offsets.data(), vertices.block_ids.data(), vertices.masks.data(),
+                                 vertices.usable.empty() ? nullptr : vp.data(), edges.offsets.data(), edges.block_ids.data(),
+                                 edges.masks.data(), edges.usable.empty() ? nullptr : ep.data()));
+  }
+  void clearValidity() { rcheck(tr_roadmap_clear_validity(rm_)); }
+  /// every cached set against the checker's current obstacle grid -> (#invalid vertices, #invalid edges)
+  std::pair<int64_t, int64_t> revalidate() {
+    int64_t nv = 0, ne = 0;
+    rcheck(tr_roadmap_revalidate(rm_, &nv, &ne));
+    return {nv, ne};
+  }
+  Solution solveWithRoadmap(const std::vector<int32_t> &starts, const std::vector<int32_t> &goals, int n_threads = 0) {
+    if (starts.size() != goals.size()) throw std::invalid_argument("starts and goals differ in length");
+    const size_t n = starts.size();
+    Solution s;
+    s.status.resize(n); s.cost.resize(n);
+    std::vector<int64_t> off(n + 1, 0);
+    rcheck(tr_roadmap_solve(rm_, starts.data(), goals.data(), (int64_t)n, n_threads, s.status.data(), s.cost.data(), off.data(), &s.stats));
+    std::vector<int32_t> pv((size_t)off[n]);
+    rcheck(tr_roadmap_fetch_paths(rm_, pv.data(), (int64_t)pv.size()));
+    s.paths.resize(n);
+    for (size_t q = 0; q < n; q++) s.paths[q].assign(pv.begin() + off[q], pv.begin() + off[q + 1]);
+    return s;
+  }
+
+ private:
+  void rcheck(int st) const {
+    if (st == TR_OK) return;
+    const std::string m = tr_roadmap_last_error(rm_);
+    if (st == TR_ERR_OUT_OF_RANGE) throw std::out_of_range(m);
+    if (st == TR_ERR_INVALID_ARG) throw std::invalid_argument(m);
+    throw std::runtime_error(m);
+  }
+  const VoxelBackboneValidityChecker &vc_;
+  tr_roadmap *rm_ = nullptr;
 };
 
 }  // namespace motion_planning

@@ -117,7 +117,7 @@ struct tr_ctx {
   // on robots without retraction, 1 = K1 + K2 as one kernel over stored points (fused_kernel.hpp), 0 = separate launches.
   // env TENDON_HIP_FUSED selects; the edge calls, the sphere checker and the voxel caches need the points and use 1 / 0.
   int fuse = 2;
-  int64_t fb_cap = 1 << 16;       // columns of the fallback pass's point workspace (env TENDON_HIP_FB_CAP: testing)
+  int64_t fb_cap = 1 << 17;       // columns of the fallback pass's point workspace: one resident round of waves (tr_create), env TENDON_HIP_FB_CAP
   int32_t *d_fb_list = nullptr; uint32_t *d_fb_count = nullptr; int64_t fb_list_cap = 0;
   struct VerdictRing {
     static constexpr int kSlots = 16;
@@ -592,7 +592,6 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   tr_ctx *c = new tr_ctx();
   c->device = device;
   if (const char *e = std::getenv("TENDON_HIP_FUSED")) { const int v = std::atoi(e); c->fuse = v < 0 ? 0 : (v > 2 ? 2 : v); }
-  if (const char *e = std::getenv("TENDON_HIP_FB_CAP")) { const long long v = std::atoll(e); if (v >= 64 && v <= (1ll << 20)) c->fb_cap = (int64_t)round_up(v, 64); }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
     if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = (int64_t)round_up(v, 64);
@@ -603,7 +602,9 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0)
       c->k1_round = (int64_t)cus * 4 * (rb->n_tendons <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1) * 64;
+    c->fb_cap = c->k1_round;
   }
+  if (const char *e = std::getenv("TENDON_HIP_FB_CAP")) { const long long v = std::atoll(e); if (v >= 64 && v <= (1ll << 20)) c->fb_cap = (int64_t)round_up(v, 64); }
 
   RobotK &K = c->K;
   const int N = rb->n_tendons;

@@ -92,6 +92,27 @@ int main(int argc, char **argv) {
     vc.nearest_k(flat, states.size(), 2, idx, dist);
     for (size_t i = 0; i < states.size(); i++) std::printf("knn %d %d %.17g\n", idx[2 * i], idx[2 * i + 1], dist[2 * i + 1]);
   }
+  // a small cached roadmap through the shim: the four states as vertices, a ring of edges, queries in the slab environment
+  {
+    tendon::TendonRobot robot3 = robot;
+    motion_planning::VoxelBackboneValidityChecker vc3(robot3, env, vox);
+    motion_planning::VoxelBackboneMotionValidator mv3(vc3);
+    const std::vector<int32_t> redges = {0, 1, 1, 2, 2, 3, 3, 0, 0, 2};
+    auto rvc = motion_planning::voxelize_states(vc3, flat, states.size());
+    auto rec = mv3.voxelizeIndexed(flat, states.size(), redges);
+    for (size_t i = 0; i < rec.items(); i++) std::printf("iecache %d %lld\n", (int)rec.usable[i], (long long)(rec.offsets[i + 1] - rec.offsets[i]));
+    motion_planning::VoxelCachedLazyPRM prm(vc3, flat, states.size(), redges);
+    prm.setCaches(rvc, rec);
+    auto sol = prm.solveWithRoadmap({0, 0, 2}, {2, 0, 3});
+    for (size_t q = 0; q < sol.status.size(); q++) {
+      std::printf("query %d %.17g", sol.status[q], sol.cost[q]);
+      for (int32_t v : sol.paths[q]) std::printf(" %d", v);
+      std::printf("\n");
+    }
+    auto inv = prm.revalidate();
+    std::printf("revalidate %lld %lld\n", (long long)inv.first, (long long)inv.second);
+    vc3.add_capsules({0.0, 0.0, 0.3, 0.05, 0.0, 0.3, 0.01});
+  }
   // the sphere-swept checker on its own copy of the robot, same obstacle slab
   {
     tendon::TendonRobot robot2 = robot;                  // a copy has its own GPU context

@@ -92,5 +92,37 @@ def test_shim_results_match_oracle(tmp_path, irt, orc, helpers):
         assert int(row[1]) == i and int(row[2]) == order[1] and abs(float(row[3]) - D[i, order[1]]) < 1e-12
     sph = [int(l.split()[1]) for l in out if l.startswith("spheres")]
     assert sph == [int(orc.is_valid_state_spheres(orb, og, s)[0]) for s in states]
+    # cached roadmap through the shim: same sets as the pairwise form, queries equal the oracle's sequential loop
+    redges = np.array([[0, 1], [1, 2], [2, 3], [3, 0], [0, 2]])
+    S4 = np.array(states, float)
+    iec = [l.split() for l in out if l.startswith("iecache")]
+    assert len(iec) == 5
+    vcs, ecs = [], []
+    for (a_, b_), row in zip(redges, iec):
+        w = orc.check_motion(orb, og, S4[a_], S4[b_], want_swept=True)
+        assert int(row[1]) == int(w["is_fully_valid"]) and (not w["is_fully_valid"] or int(row[2]) == w["swept"].nblocks())
+        ecs.append(w["swept"].export_blocks() if w["is_fully_valid"] else (np.zeros(0, np.uint32), np.zeros(0, np.uint64)))
+    ref = orc.Grid(256, vox.limits())
+    shape_ok = []
+    for s in states:
+        ok, _, fl = orc.is_valid_state(orb, og, s)
+        shape_ok.append((fl & 7) == 7)
+        g_ = ref.empty_copy()
+        if shape_ok[-1]:
+            g_.add_piecewise_line(orb.shape(s)["p"])
+        vcs.append(g_.export_blocks() if shape_ok[-1] else (np.zeros(0, np.uint32), np.zeros(0, np.uint64)))
+    csr = lambda items, present: dict(offsets=np.concatenate([[0], np.cumsum([len(i[0]) for i in items])]),
+                                      block_ids=np.concatenate([i[0] for i in items]), masks=np.concatenate([i[1] for i in items]),
+                                      present=np.array(present, bool))
+    e_present = [bool(int(r[1])) for r in iec]
+    orm = orc.Roadmap(orb, S4, redges, None, csr(vcs, shape_ok), csr(ecs, e_present))
+    queries = [l.split() for l in out if l.startswith("query")]
+    assert len(queries) == 3
+    code = {-2: 2, -3: 3, 0: 1}
+    for (s_, g_), row in zip(((0, 2), (0, 0), (2, 3)), queries):
+        w = orm.query(og, s_, g_)
+        assert int(row[1]) == (0 if w["n"] > 0 else code[w["n"]])
+        if w["n"] > 0:
+            assert float(row[2]) == w["cost"] and [int(v) for v in row[3:]] == list(w["path"])
     idx = [l.split() for l in out if l.startswith("indexed")]
     assert len(idx) == 3 and all(r[1] == r[2] for r in idx) and [int(r[1]) for r in idx] == [int(e[1]) for e in edges]

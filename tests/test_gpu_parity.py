@@ -266,6 +266,29 @@ def test_fk_other_tendon_counts(irt, orc, helpers, n_tendons):
     _fk_check(irt, orc, helpers, robot, states)
 
 
+@pytest.mark.parametrize("n_tendons", [1, 2, 5, 7, 8])
+def test_validity_other_tendon_counts_against_oracle(irt, orc, helpers, n_tendons):
+    """fk_verdict (and its fallback pass) in every instantiated width, with rotation and a rotated environment: verdicts
+    and flags equal the oracle's isValid, state by state."""
+    rng = np.random.default_rng(40 + n_tendons)
+    tendons = [irt.TendonSpecs(C=[2 * np.pi * k / n_tendons, float(rng.uniform(-6, 6))], D=[0.01, float(rng.uniform(-0.01, 0.01))],
+                               max_tension=12.0) for k in range(n_tendons)]
+    robot = irt.TendonRobot(tendons=tendons, specs=irt.BackboneSpecs(dL=0.2 / 128), enable_rotation=True)
+    vox, _ = irt.workloads.reach_environment(seed=5, n_spheres=48)
+    env = irt.VoxelEnvironment()
+    a = -0.7
+    env.inv_rotation = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    chk = irt.VoxelBackboneValidityChecker(robot, env, vox)
+    states = irt.workloads.random_states(robot, 400, seed=9 + n_tendons, tau_max=14.0 / np.sqrt(n_tendons))
+    got = chk.is_valid_detail(states)
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
+    want = [orc.is_valid_state(orb, og, s, env.inv_rotation) for s in states]
+    assert np.array_equal(got["valid"], [w[0] for w in want])
+    assert np.array_equal(got["flags"] & 15, [w[2] for w in want])
+    assert np.abs(got["tips"] - np.array([w[1] for w in want])).max() <= 1e-9
+    assert 0.1 < got["valid"].mean() < 0.95
+
+
 def test_fk_step_not_dividing_length(irt, orc, helpers):
     """L is not a multiple of dL: with dL = 3.5 mm the first interval is 4 mm = 1.14 dL and takes two RK4
     steps (integrate_times); with dL = 3 mm it is 2 mm (one short step).  Both run on the shared-grid
