@@ -279,14 +279,14 @@ def test_validity_other_tendon_counts_against_oracle(irt, orc, helpers, n_tendon
     a = -0.7
     env.inv_rotation = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
     chk = irt.VoxelBackboneValidityChecker(robot, env, vox)
-    states = irt.workloads.random_states(robot, 400, seed=9 + n_tendons, tau_max=14.0 / np.sqrt(n_tendons))
+    states = irt.workloads.random_states(robot, 400, seed=9 + n_tendons, tau_max=22.0 / np.sqrt(n_tendons))
     got = chk.is_valid_detail(states)
     orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, vox)
     want = [orc.is_valid_state(orb, og, s, env.inv_rotation) for s in states]
     assert np.array_equal(got["valid"], [w[0] for w in want])
     assert np.array_equal(got["flags"] & 15, [w[2] for w in want])
     assert np.abs(got["tips"] - np.array([w[1] for w in want])).max() <= 1e-9
-    assert 0.1 < got["valid"].mean() < 0.95
+    assert 0.05 < got["valid"].mean() < 0.99
 
 
 def test_fk_step_not_dividing_length(irt, orc, helpers):
