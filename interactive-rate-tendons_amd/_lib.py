@@ -135,8 +135,11 @@ def source_hash():
 def build(force=False, verbose=False, jobs=None):
     """Compile libtendon_hip.so in-tree for gfx950 if it is missing or older than its sources.
     Objects go to csrc/_obj/ (git-ignored); a unit is recompiled when any source or header is newer."""
-    newest = max(os.path.getmtime(s) for s in _sources())
-    if not force and os.path.exists(LIB_PATH) and newest <= os.path.getmtime(LIB_PATH):
+    # up to date = the library was linked from exactly these sources: their hash is recorded next to it at link time
+    # (modification times do not survive a checkout or a copy to another machine)
+    stamp = LIB_PATH + ".srchash"
+    want = source_hash()
+    if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
     todo = []
@@ -165,6 +168,8 @@ def build(force=False, verbose=False, jobs=None):
     if verbose:
         print(" ".join(link), flush=True)
     subprocess.check_call(link)
+    with open(stamp, "w") as f:
+        f.write(want + "\n")
     return LIB_PATH
 
 
