@@ -105,11 +105,20 @@ def main():
     chk.engine.profile_end()
     n_samples = int(nfk.sum()) - 2 * len(edges) + V          # FK samples actually integrated (vertices once)
     add("edge path (tr_validate_edges_indexed)", units=len(edges), unit="edges", fk_samples=n_samples)
+    # the launches behind the roadmap calls, so that the FK kernels' rows cover ALL of their launches: vertex sampling and
+    # the edge samples run through fk_verdict<4> (the samples also write a 4 P-byte signature row), the voxel caches below
+    # through fk_sweep_fused<4> (stored points)
+    fl4 = isa["rk4_step<4>"]["flops_per_step"] * 128
+    cand = rb.timing["vertices"]["candidates"]
+    add("fk_verdict<4>", bytes=cand * (8 * 4 + 24 + 0.125) + n_samples * (8 * 4 + 4 * 129 + 0.125), flops=(cand + n_samples) * fl4,
+        units=cand + n_samples, unit="checks")
     add("edge_filter", bytes=2.0 * 129 * 4 * (n_samples + len(edges)), units=n_samples + len(edges), unit="interval tests on cell signatures (upper bound: early exit from the tip)")
     e_ok = edges[valid]
     vc = rb.vertex_caches(states)
     ec = rb.edge_caches(states, e_ok)
     add("backbone_voxelize", bytes=(V + n_samples) * (24.0 * 129) + 12.0 * (int(vc["offsets"][-1])), units=V + n_samples, unit="shapes")
+    n_cache_samples = 2 * V + int(ec["n_fk"].sum()) - 2 * len(e_ok)        # vertex caches, then the indexed edge caches (vertices once more)
+    add("fk_sweep_fused<4>", bytes=n_cache_samples * (2 * 24.0 * 129 + 8 * 4 + 4 * 129), flops=n_cache_samples * fl4, units=n_cache_samples, unit="checks")
     add("cache merge (rocPRIM sort + reduce)", units=int(ec["offsets"][-1]), unit="unique edge blocks")
     new_vox, _ = W.reach_environment(seed=7, n_spheres=72)
     prm = irt.VoxelCachedLazyPRM(chk, states, e_ok)
