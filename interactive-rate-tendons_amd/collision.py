@@ -196,6 +196,82 @@ class VoxelOctree:
         ids = np.flatnonzero(self.blocks.reshape(-1)).astype(np.uint32)
         return ids, self.blocks.reshape(-1)[ids].copy()
 
+    # ---- the reference's obstacle-set file formats (collision/VoxelOctree.cpp:1357-1497): what a maintainer hands to
+    # tr_set_grid comes from these files.  .nrrd needs ITK and is not read here. ------------------------------------------
+    def to_json(self):
+        """VoxelOctree::to_json (:1357-1376): {"VoxelOctree": {dimension, x/y/zlimits, data: [[bx, by, bz, block], ...]}}."""
+        Nb = self.Nbx()
+        ids, masks = self.to_sparse()
+        data = [[int(i) // (Nb * Nb), (int(i) // Nb) % Nb, int(i) % Nb, int(m)] for i, m in zip(ids, masks)]
+        return {"VoxelOctree": {"dimension": int(self._N), "xlimits": [self._xmin, self._xmax], "ylimits": [self._ymin, self._ymax],
+                                "zlimits": [self._zmin, self._zmax], "data": data}}
+
+    @classmethod
+    def from_json(cls, obj):
+        """VoxelOctree::from_json (:1378-1394)."""
+        o = obj["VoxelOctree"]
+        v = cls(int(o["dimension"]))
+        v.set_xlim(*o["xlimits"]); v.set_ylim(*o["ylimits"]); v.set_zlim(*o["zlimits"])
+        for bx, by, bz, val in o["data"]:
+            v.set_block(int(bx), int(by), int(bz), int(val))
+        return v
+
+    def to_toml(self):
+        """VoxelOctree::to_toml (:1396-1430) as TOML text: blocks as [bx, by, bz, upper 32 bits, lower 32 bits]."""
+        d = self.to_json()["VoxelOctree"]
+        rows = ",\n  ".join("[%d, %d, %d, %d, %d]" % (bx, by, bz, val >> 32, val & 0xffffffff) for bx, by, bz, val in d["data"])
+        lim = lambda a: "[%r, %r]" % (float(a[0]), float(a[1]))
+        return ("[VoxelOctree]\ndimension = %d\nxlimits = %s\nylimits = %s\nzlimits = %s\ndata = [\n  %s\n]\n"
+                % (d["dimension"], lim(d["xlimits"]), lim(d["ylimits"]), lim(d["zlimits"]), rows))
+
+    @classmethod
+    def from_toml(cls, tbl):
+        """VoxelOctree::from_toml (:1432-1473): `tbl` is the parsed table, with or without the "VoxelOctree" container."""
+        o = tbl.get("VoxelOctree", tbl)
+        v = cls(int(o["dimension"]))
+        v.set_xlim(*o["xlimits"]); v.set_ylim(*o["ylimits"]); v.set_zlim(*o["zlimits"])
+        for bx, by, bz, hi, lo in o["data"]:
+            v.set_block(int(bx), int(by), int(bz), (int(hi) << 32) | int(lo))
+        return v
+
+    def to_file(self, fname):
+        """VoxelOctree::to_file (:1475-1485): .toml[.gz], else the JSON family by extension (util/json_io.cpp: .json,
+        .msgpack, each optionally .gz)."""
+        import gzip
+        import json
+        gz = fname.endswith(".gz")
+        base = fname[:-3] if gz else fname
+        if base.endswith(".nrrd"):
+            raise L.Unsupported(".nrrd needs ITK: not available in this build")
+        if base.endswith(".toml"):
+            raw = self.to_toml().encode()
+        elif base.endswith(".msgpack"):
+            import msgpack
+            raw = msgpack.packb(self.to_json())
+        else:
+            raw = json.dumps(self.to_json()).encode()
+        with (gzip.open(fname, "wb") if gz else open(fname, "wb")) as f:
+            f.write(raw)
+
+    @classmethod
+    def from_file(cls, fname):
+        """VoxelOctree::from_file (:1487-1497)."""
+        import gzip
+        import json
+        gz = fname.endswith(".gz")
+        base = fname[:-3] if gz else fname
+        if base.endswith(".nrrd"):
+            raise L.Unsupported(".nrrd needs ITK: not available in this build")
+        with (gzip.open(fname, "rb") if gz else open(fname, "rb")) as f:
+            raw = f.read()
+        if base.endswith(".toml"):
+            import tomli
+            return cls.from_toml(tomli.loads(raw.decode()))
+        if base.endswith(".msgpack"):
+            import msgpack
+            return cls.from_json(msgpack.unpackb(raw))
+        return cls.from_json(json.loads(raw.decode()))
+
     @classmethod
     def from_sparse(cls, N, limits, ids, masks):
         v = cls(N)

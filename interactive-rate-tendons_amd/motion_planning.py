@@ -47,8 +47,12 @@ class VoxelEnvironment:                    # motion-planning/VoxelEnvironment.h:
         self._obstacle_cache = obstacles
 
     def get_obstacles(self):
+        """VoxelEnvironment::get_obstacles: the cached set, else the file named by `filename` (the reference's JSON /
+        msgpack / TOML layouts, collision/VoxelOctree.cpp:1357-1497; .nrrd images need ITK and are not read here)."""
         if self._obstacle_cache is None:
-            raise L.Unsupported("loading voxel files (nrrd/json/toml) is outside the hot path")
+            if not self.filename:
+                raise L.InvalidArgument("VoxelEnvironment has neither an obstacle cache nor a filename")
+            self._obstacle_cache = VoxelOctree.from_file(self.filename)
         return self._obstacle_cache
 
     def rotate_point(self, p):             # VoxelEnvironment.cpp:125-127

@@ -102,6 +102,33 @@ def test_voxel_octree_matches_oracle_grid(irt, orc):
     assert e.is_empty() and e.limits() == v.limits() and not v.collides(e) and v.collides(v)
 
 
+def test_voxel_octree_file_formats(irt, tmp_path):
+    """The reference's obstacle-set files (collision/VoxelOctree.cpp:1357-1497): JSON object layout, TOML with the block
+    split into two 32-bit halves, msgpack of the same object, each optionally gzipped; VoxelEnvironment loads by name."""
+    import json
+    v = irt.VoxelOctree(32)
+    v.set_xlim(-0.5, 0.25); v.set_ylim(0.0, 1.0); v.set_zlim(-1.0, 1.0)
+    v.add_sphere([0.0, 0.4, 0.1], 0.3)
+    v.set_block(7, 0, 5, (1 << 63) | (1 << 32) | 5)              # exercises the upper half and bit 63
+    j = v.to_json()
+    o = j["VoxelOctree"]
+    assert set(o) == {"dimension", "xlimits", "ylimits", "zlimits", "data"} and o["dimension"] == 32 and o["ylimits"] == [0.0, 1.0]
+    assert [7, 0, 5, (1 << 63) | (1 << 32) | 5] in o["data"] and len(o["data"]) == v.nblocks()
+    assert irt.VoxelOctree.from_json(json.loads(json.dumps(j))) == v
+    assert "[7, 0, 5, %d, 5]" % ((1 << 31) | 1) in v.to_toml()
+    for name in ("a.json", "b.json.gz", "c.msgpack", "d.toml", "e.toml.gz"):
+        path = str(tmp_path / name)
+        v.to_file(path)
+        w = irt.VoxelOctree.from_file(path)
+        assert w == v and w.limits() == v.limits(), name
+    env = irt.VoxelEnvironment(filename=str(tmp_path / "a.json"))
+    assert env.get_obstacles() == v
+    with pytest.raises(irt.Unsupported):
+        irt.VoxelOctree.from_file(str(tmp_path / "x.nrrd"))
+    with pytest.raises(irt.InvalidArgument):
+        irt.VoxelEnvironment().get_obstacles()
+
+
 def test_voxel_octree_errors(irt):
     with pytest.raises(irt.InvalidArgument):
         irt.VoxelOctree(100)
