@@ -72,6 +72,38 @@ class TendonRobot:
         self.residual_threshold = residual_threshold
         self._engines = {}
 
+    # ---- the reference's robot description files (tendon/TendonRobot.cpp:1012-1089, BackboneSpecs.cpp:7-40,
+    # TendonSpecs.cpp:32-54): [tendon_robot], [backbone_specs], [[tendons]] ----------------------------------------------
+    def to_toml(self):
+        f = lambda x: repr(float(x))
+        arr = lambda a: "[" + ", ".join(f(x) for x in a) + "]"
+        s = self.specs
+        out = ["[tendon_robot]", "radius = " + f(self.r), "enable_rotation = " + str(bool(self.enable_rotation)).lower(),
+               "enable_retraction = " + str(bool(self.enable_retraction)).lower(), "residual_threshold = " + f(self.residual_threshold), "",
+               "[backbone_specs]", "length = " + f(s.L), "length_discretization = " + f(s.dL), "ro = " + f(s.ro), "ri = " + f(s.ri),
+               "E = " + f(s.E), "nu = " + f(s.nu), ""]
+        for t in self.tendons:
+            out += ["[[tendons]]", "C = " + arr(t.C), "D = " + arr(t.D), "max_tension = " + f(t.max_tension),
+                    "min_length = " + f(t.min_length), "max_length = " + f(t.max_length), ""]
+        return "\n".join(out)
+
+    @classmethod
+    def from_toml(cls, tbl):
+        """`tbl`: the parsed table (tomli) or a path to a .toml file.  Missing optional keys keep the reference's defaults
+        (TendonRobot.h:53-58); a missing [tendon_robot] / [backbone_specs] entry raises KeyError as cpptoml would throw."""
+        if isinstance(tbl, str):
+            import tomli
+            with open(tbl, "rb") as fh:
+                tbl = tomli.load(fh)
+        rt, bs = tbl["tendon_robot"], tbl["backbone_specs"]
+        specs = BackboneSpecs(L=float(bs["length"]), dL=float(bs["length_discretization"]), ro=float(bs["ro"]), ri=float(bs["ri"]),
+                              E=float(bs["E"]), nu=float(bs["nu"]))
+        tendons = [TendonSpecs(C=[float(x) for x in t["C"]], D=[float(x) for x in t["D"]], max_tension=float(t["max_tension"]),
+                               min_length=float(t["min_length"]), max_length=float(t["max_length"])) for t in tbl.get("tendons", [])]
+        return cls(tendons=tendons, specs=specs, r=float(rt["radius"]), enable_rotation=bool(rt.get("enable_rotation", False)),
+                   enable_retraction=bool(rt.get("enable_retraction", False)),
+                   residual_threshold=float(rt.get("residual_threshold", 5e-6)))
+
     def state_size(self):                  # TendonRobot.h:60-64
         return len(self.tendons) + int(self.enable_rotation) + int(self.enable_retraction)
 

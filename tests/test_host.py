@@ -129,6 +129,28 @@ def test_voxel_octree_file_formats(irt, tmp_path):
         irt.VoxelEnvironment().get_obstacles()
 
 
+def test_robot_toml_roundtrip(irt, tmp_path):
+    """tendon::TendonRobot::to_toml / from_toml (tendon/TendonRobot.cpp:1012-1089): table names and keys as the reference
+    writes them, defaults for the optional keys."""
+    import tomli
+    r = irt.workloads.robot_config3()
+    r.enable_rotation, r.r, r.residual_threshold = True, 0.0125, 1e-6
+    txt = r.to_toml()
+    t = tomli.loads(txt)
+    assert set(t) == {"tendon_robot", "backbone_specs", "tendons"} and len(t["tendons"]) == 4
+    assert t["backbone_specs"]["length_discretization"] == r.specs.dL and t["tendon_robot"]["radius"] == 0.0125
+    path = tmp_path / "robot.toml"
+    path.write_text(txt)
+    q = irt.TendonRobot.from_toml(str(path))
+    assert (q.r, q.enable_rotation, q.enable_retraction, q.residual_threshold) == (0.0125, True, False, 1e-6)
+    assert q.specs == r.specs and q.tendons == r.tendons
+    minimal = tomli.loads("[tendon_robot]\nradius = 0.02\n[backbone_specs]\nlength = 0.1\nlength_discretization = 0.01\nro = 0.01\nri = 0.0\nE = 1e6\nnu = 0.3\n")
+    m = irt.TendonRobot.from_toml(minimal)
+    assert m.tendons == [] and m.residual_threshold == 5e-6 and not m.enable_rotation
+    with pytest.raises(KeyError):
+        irt.TendonRobot.from_toml({"backbone_specs": {}})
+
+
 def test_voxel_octree_errors(irt):
     with pytest.raises(irt.InvalidArgument):
         irt.VoxelOctree(100)
