@@ -362,6 +362,14 @@ int tr_roadmap_solve(tr_roadmap *rm, const int32_t *starts, const int32_t *goals
                      int32_t *status, double *cost, int64_t *path_offsets, tr_roadmap_stats *stats);
 int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capacity);
 
+/* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
+ * of connectionStrategy_(v), `if (!getEdge(v, n)) connectVertices(v, n)`): the undirected edge set of the k-nearest
+ * table -- pairs (lo, hi), lo < hi, each once, ordered by (lo, hi) -- built on the device (sort + unique of the pair
+ * keys); only the edge list crosses PCIe.  k counts the vertex itself, as in tr_knn.  edges: capacity x 2 int32; *n_edges
+ * receives the number of edges (if it exceeds capacity only the first `capacity` are written: at most n (k - 1)). */
+int tr_knn_edges(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_distance, int32_t *edges,
+                 int64_t capacity, int64_t *n_edges);
+
 /* k of the PRM* connection strategy for a roadmap of n_milestones vertices (og::KStarStrategy as installed by
  * setStarConnectionStrategy, motion-planning/VoxelCachedLazyPRM.cpp:1346-1356): ceil((e + e / dim) * ln(n)), dim =
  * state dimension.  createRoadmap connects after all vertices are in place, so this k applies to every vertex of the

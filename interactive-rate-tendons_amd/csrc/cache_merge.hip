@@ -8,6 +8,7 @@
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_reduce_by_key.hpp>
 #include <rocprim/device/device_scan.hpp>
+#include <rocprim/device/device_select.hpp>
 
 namespace trk {
 namespace {
@@ -47,6 +48,22 @@ __global__ __launch_bounds__(256) void merge_finish(const uint64_t *__restrict__
   const uint64_t k = ukeys[i];
   uids[i] = (uint32_t)(k & (((uint64_t)1 << id_bits) - 1));
   atomicAdd(&ecount[k >> id_bits], 1);
+}
+
+__global__ __launch_bounds__(256) void knn_edge_keys(const int32_t *__restrict__ idx, int64_t n, int k, uint64_t *__restrict__ keys) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n * k) return;
+  const int64_t i = t / k;
+  const int64_t j = idx[t];
+  // entries without a neighbour (and the vertex itself) sort to the end and are cut off
+  keys[t] = (j < 0 || j == i) ? ~0ull : ((uint64_t)(i < j ? i : j) << 32) | (uint64_t)(i < j ? j : i);
+}
+
+__global__ __launch_bounds__(256) void knn_edge_unpack(const uint64_t *__restrict__ keys, int64_t m, int32_t *__restrict__ edges) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= m) return;
+  edges[2 * t] = (int32_t)(keys[t] >> 32);
+  edges[2 * t + 1] = (int32_t)(keys[t] & 0xffffffffull);
 }
 
 struct BitOr { __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a | b; } };
@@ -135,6 +152,55 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
   MERGE_TRY(hipMemcpyAsync(sc, ms.scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
   MERGE_TRY(hipStreamSynchronize(stream));
   *n_unique = (int64_t)sc[0];
+  return hipSuccess;
+}
+
+hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int k, int32_t *d_edges, int64_t capacity,
+                         int64_t *n_edges, hipStream_t stream) {
+  *n_edges = 0;
+  const int64_t nnz = n * (int64_t)k;
+  if (nnz <= 0) return hipSuccess;
+  if (ms.cap_nnz < nnz) {
+    const size_t want = (size_t)nnz + (size_t)nnz / 4 + 1024;
+    for (int b = 0; b < 2; b++) { MERGE_TRY(grow(&ms.keys[b], want)); MERGE_TRY(grow(&ms.vals[b], want)); }
+    MERGE_TRY(grow(&ms.ukeys, want));
+    MERGE_TRY(grow(&ms.uvals, want));
+    MERGE_TRY(grow(&ms.uids, want));
+    ms.cap_nnz = (int64_t)want;
+  }
+  if (!ms.scalars) MERGE_TRY(grow(&ms.scalars, 2));
+  auto need_tmp = [&](size_t bytes) -> hipError_t {
+    if (ms.cap_tmp >= bytes) return hipSuccess;
+    MERGE_TRY(grow((char **)&ms.tmp, bytes + bytes / 4));
+    ms.cap_tmp = bytes + bytes / 4;
+    return hipSuccess;
+  };
+  const dim3 b256(256), g((unsigned)((nnz + 255) / 256));
+  hipLaunchKernelGGL(knn_edge_keys, g, b256, 0, stream, d_idx, n, k, ms.keys[0]);
+  MERGE_TRY(hipGetLastError());
+  rocprim::double_buffer<uint64_t> kb(ms.keys[0], ms.keys[1]);
+  size_t bytes = 0;
+  MERGE_TRY(rocprim::radix_sort_keys(nullptr, bytes, kb, (size_t)nnz, 0u, 64u, stream));
+  MERGE_TRY(need_tmp(bytes));
+  MERGE_TRY(rocprim::radix_sort_keys(ms.tmp, bytes, kb, (size_t)nnz, 0u, 64u, stream));
+  bytes = 0;
+  MERGE_TRY(rocprim::unique(nullptr, bytes, kb.current(), ms.ukeys, ms.scalars, (size_t)nnz, rocprim::equal_to<uint64_t>(), stream));
+  MERGE_TRY(need_tmp(bytes));
+  MERGE_TRY(rocprim::unique(ms.tmp, bytes, kb.current(), ms.ukeys, ms.scalars, (size_t)nnz, rocprim::equal_to<uint64_t>(), stream));
+  uint64_t cnt = 0, last = 0;
+  MERGE_TRY(hipMemcpyAsync(&cnt, ms.scalars, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+  MERGE_TRY(hipStreamSynchronize(stream));
+  if (cnt > 0) {                                   // the all-ones key (no neighbour / self), if present, is the last one
+    MERGE_TRY(hipMemcpyAsync(&last, ms.ukeys + (cnt - 1), sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    MERGE_TRY(hipStreamSynchronize(stream));
+    if (last == ~0ull) cnt--;
+  }
+  *n_edges = (int64_t)cnt;
+  const int64_t m = (int64_t)cnt < capacity ? (int64_t)cnt : capacity;
+  if (m > 0) {
+    hipLaunchKernelGGL(knn_edge_unpack, dim3((unsigned)((m + 255) / 256)), b256, 0, stream, ms.ukeys, m, d_edges);
+    MERGE_TRY(hipGetLastError());
+  }
   return hipSuccess;
 }
 

@@ -34,4 +34,11 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
                              int64_t n_edges, int64_t *n_unique, int *overflow, hipStream_t stream);
 void merge_free(MergeScratch &ms);
 
+// Undirected edge list of a k-nearest-neighbour table (connectVertices over every vertex's neighbours with the
+// `if (!getEdge(v, n))` test of VoxelCachedLazyPRM.cpp:1491-1502): the pairs (i, idx[i][p]) with idx >= 0 and idx != i,
+// each once as (lo, hi), ordered by (lo, hi).  d_idx: [n][k] on the device.  d_edges (2 x capacity int32) receives
+// min(count, capacity) pairs; *n_edges the count.
+hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int k, int32_t *d_edges, int64_t capacity,
+                         int64_t *n_edges, hipStream_t stream);
+
 }  // namespace trk

@@ -1473,10 +1473,31 @@ int tr_voxelize_fetch(tr_ctx *c, uint32_t *block_ids, uint64_t *masks, int64_t c
 }
 
 // ---- nearest neighbours ---------------------------------------------------------------------
+}  // extern "C"
+namespace {
+int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist,
+             int32_t *edges, int64_t edge_capacity, int64_t *n_edges);
+}
+extern "C" {
 int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist) {
   if (!c) return TR_ERR_INVALID_ARG;
+  if (n > 0 && (!idx || !dist)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  return knn_impl(c, states, n, k, max_distance, idx, dist, nullptr, 0, nullptr);
+}
+
+int tr_knn_edges(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *edges, int64_t capacity,
+                 int64_t *n_edges) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (!n_edges || capacity < 0 || (capacity > 0 && !edges)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  *n_edges = 0;
+  return knn_impl(c, states, n, k, max_distance, nullptr, nullptr, edges, capacity, n_edges);
+}
+}  // extern "C"
+namespace {
+int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist,
+             int32_t *edges, int64_t edge_capacity, int64_t *n_edges) {
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
-  if (n < 0 || k < 1 || (n > 0 && (!states || !idx || !dist))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  if (n < 0 || k < 1 || (n > 0 && !states)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
   if ((size_t)k * 64 * 12 > 60 * 1024) return fail(c, TR_ERR_INVALID_ARG, "k too large (at most 80)");
   if (n > (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
@@ -1528,8 +1549,21 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
         hipLaunchKernelGGL(trk::knn_merge, dim3((unsigned)qblocks), dim3(64), (size_t)nslice * 64, nullptr, d_pi, d_pd, n, nslice, (int)k, max_distance, d_i, d_d);
     }
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, TR_ERR_HIP, "knn launch failed"); break; }
-    if (hipMemcpy(idx, d_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess ||
-        hipMemcpy(dist, d_d, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+    if (idx && hipMemcpy(idx, d_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+    if (dist && hipMemcpy(dist, d_d, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+    if (n_edges) {
+      // the undirected edge set of the table, deduplicated and ordered on the device (cache_merge.hip); the slice lists are
+      // done with, so the edge pairs are unpacked into that buffer (capacity n k pairs at most)
+      int32_t *d_e = nullptr;
+      const int64_t cap_e = std::min<int64_t>(edge_capacity, n * (int64_t)k);
+      if (cap_e > 0 && hipMalloc((void **)&d_e, (size_t)cap_e * 2 * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+      hipError_t e = trk::knn_edge_list(c->merge, d_i, n, (int)k, d_e, cap_e, n_edges, nullptr);
+      if (e == hipSuccess) e = hipDeviceSynchronize();
+      const int64_t m = std::min<int64_t>(*n_edges, cap_e);
+      if (e == hipSuccess && m > 0) e = hipMemcpy(edges, d_e, (size_t)m * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+      if (d_e) (void)hipFree(d_e);
+      if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn edge list: ") + hipGetErrorString(e)); break; }
+    }
   } while (0);
   if (d_s) (void)hipFree(d_s);
   if (d_d) (void)hipFree(d_d);
@@ -1539,6 +1573,8 @@ int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_dis
   if (d_seed) (void)hipFree(d_seed);
   return rc;
 }
+}  // namespace
+extern "C" {
 
 // KStarStrategy (OMPL 1.5.0 ompl/geometric/planners/prm/ConnectionStrategy.h, installed by setStarConnectionStrategy,
 // motion-planning/VoxelCachedLazyPRM.cpp:1346-1356): k = ceil((e + e / dim) * ln(n)) with n = milestoneCount().  In

@@ -250,6 +250,18 @@ class Engine:
                                            idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dist)))
         return idx, dist
 
+    def knn_edges(self, states, k, max_distance=np.inf):
+        """Undirected edge list (n_edges, 2), lo < hi, ordered, of the k-nearest table (k counts the vertex itself):
+        the connection loop of createRoadmap, deduplicated on the device."""
+        st = self._states(states)
+        n = st.shape[0]
+        cap = max(1, n * max(0, int(k) - 1))
+        e = np.empty((cap, 2), dtype=np.int32)
+        ne = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_knn_edges(self._ctx, _dp(st), n, int(k), float(max_distance),
+                                                 e.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(ne)))
+        return e[: min(cap, ne.value)].copy()
+
     def kstar_k(self, n_milestones):
         """k of og::KStarStrategy for a roadmap of n_milestones vertices (PRM*)."""
         k = self.lib.tr_kstar_k(self._ctx, int(n_milestones))

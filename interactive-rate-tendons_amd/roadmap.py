@@ -60,13 +60,7 @@ class RoadmapBuilder:
         rotation / retraction weights), then the undirected edge set the reference's
         `if (!getEdge(v, n)) connectVertices(v, n)` loop builds (:1491-1502): k counts v itself."""
         t0 = time.perf_counter()
-        idx, dist = self.engine.knn(states, k, max_distance)
-        src = np.repeat(np.arange(len(states), dtype=np.int64), k)
-        dst = idx.reshape(-1).astype(np.int64)
-        keep = (dst >= 0) & (dst != src)
-        lo, hi = np.minimum(src[keep], dst[keep]), np.maximum(src[keep], dst[keep])
-        key = np.unique(lo * len(states) + hi)
-        e = np.stack([key // len(states), key % len(states)], 1)
+        e = self.engine.knn_edges(states, k, max_distance).astype(np.int64)
         self.timing["knn_gpu"] = dict(seconds=time.perf_counter() - t0, edges=len(e))
         return e
 

@@ -98,3 +98,23 @@ def test_kstar_connection_strategy(irt):
     k = chk.engine.kstar_k(len(st))
     e = rb.knn_edges_star(st)
     assert np.array_equal(e, rb.knn_edges(st, k)) and len(e) >= len(st) * k // 2
+
+
+def test_knn_edge_list_on_device_equals_host_dedup(irt):
+    """tr_knn_edges: the undirected, duplicate-free, ordered edge set of the k-nearest table, also with the bounded
+    strategy's distance limit and a robot with rotation + retraction coordinates."""
+    W = irt.workloads
+    robot = W.robot_config2()
+    robot.enable_rotation, robot.enable_retraction = True, True
+    e = robot.engine()
+    st = W.random_states(robot, 5000, seed=84)
+    for md in (np.inf, 6.0):
+        idx, dist = e.knn(st, 8, md)
+        src = np.repeat(np.arange(len(st)), 8)
+        dst = idx.reshape(-1).astype(np.int64)
+        keep = (dst >= 0) & (dst != src)
+        key = np.unique(np.minimum(src[keep], dst[keep]) * len(st) + np.maximum(src[keep], dst[keep]))
+        want = np.stack([key // len(st), key % len(st)], 1)
+        got = e.knn_edges(st, 8, md)
+        assert np.array_equal(got, want) and (md == np.inf or len(want) < 7 * len(st) // 2)
+    assert e.knn_edges(st[:1], 4).shape == (0, 2)
