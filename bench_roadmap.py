@@ -18,15 +18,65 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 
+def config4_single_gpu(irt, args):
+    """Config 4's sizes on one GPU: what each of the 8 ranks does (its shard of the 1M candidates) times 8, plus the edge
+    phase at that roadmap size.  No scaling claim: the collective is exercised elsewhere (tests/test_gpu_distributed.py)."""
+    import torch
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    eng = chk.engine
+    M = 1 << 20
+
+    def validate_local(states):
+        d = torch.from_numpy(states).cuda()
+        bits = torch.zeros((len(states) + 63) // 64, dtype=torch.int64, device="cuda")
+        eng.validate_batch_dev(d, len(states), bits)
+        torch.cuda.synchronize()
+        return bits.cpu().numpy()
+
+    irt.roadmap.gathered_vertex_mask(robot, validate_local, 1 << 16, seed=3, tau_max=None, device="cuda")      # warm-up
+    t0 = time.perf_counter()
+    mask = irt.roadmap.gathered_vertex_mask(robot, validate_local, M, seed=3, tau_max=None, device="cuda")
+    t_mask = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    cand = D.candidate_states(robot, 3, 0, M)
+    t_gen = time.perf_counter() - t0
+    states = np.ascontiguousarray(cand[mask])
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=3)
+    rb.knn_edges_gpu(states[:4096], args.k + 1)
+    t0 = time.perf_counter()
+    edges = rb.knn_edges_gpu(states, args.k + 1)
+    t_knn = time.perf_counter() - t0
+    eng.reserve_edges(len(edges))
+    rb.validate_edges(states, edges[:4096])
+    t0 = time.perf_counter()
+    valid, nfk = rb.validate_edges(states, edges)
+    t_edges = time.perf_counter() - t0
+    out = {"config4_on_one_gpu": {
+        "candidates": M, "accepted_vertices": int(mask.sum()), "mask_seconds_incl_host_candidate_generation": t_mask,
+        "host_candidate_generation_seconds": t_gen, "k": args.k, "edges": int(len(edges)), "knn_edge_list_seconds": t_knn,
+        "pair_distances_per_s": float(len(states)) ** 2 / t_knn, "edge_validation_seconds": t_edges, "edges_per_s": len(edges) / t_edges,
+        "edge_fk_samples_per_s": float(nfk.sum()) / t_edges, "edge_valid_fraction": float(valid.mean()),
+        "note": "one rank's code path with world size 1; at 8 GPUs each rank validates 1/8 of the candidates and of the edge list"}}
+    print(json.dumps(out))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--vertices", type=int, default=100000)
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--queries", type=int, default=10000)
     ap.add_argument("--no-cpu", action="store_true", help="skip the sequential CPU port of the query loop")
+    ap.add_argument("--config4", action="store_true",
+                    help="only BASELINE config 4's workload on ONE GPU: 1M candidate vertices validated as one shard (world size 1, "
+                         "mask all-gather a no-op), then k-NN edges and their validation over the accepted vertices")
     ap.add_argument("--cache-items", type=int, default=200000)
     args = ap.parse_args(argv)
     irt = importlib.import_module("interactive-rate-tendons_amd")
+    if args.config4:
+        return config4_single_gpu(irt, args)
     W = irt.workloads
     robot = W.robot_config3()
     vox, _ = W.reach_environment(seed=7, n_spheres=64)
