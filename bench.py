@@ -319,9 +319,12 @@ def main():
             # PCIe-inclusive rate through the host-buffer entry point (pageable numpy arrays in, bits + tips out);
             # reported for DESIGN.md, never the headline value
             eng.validate_batch(states, True, False)           # first call creates the pinned staging buffers
-            t1 = time.perf_counter()
-            eng.validate_batch(states, True, False)
-            out["pcie_inclusive_checks_per_s"] = n / (time.perf_counter() - t1)
+            best = float("inf")
+            for _ in range(3):
+                t1 = time.perf_counter()
+                eng.validate_batch(states, True, False)
+                best = min(best, time.perf_counter() - t1)
+            out["pcie_inclusive_checks_per_s"] = n / best
             cb, cpu_valid, m = cpu_baseline(irt, robot, vox, states)
             out["cpu_baseline"] = cb
             out["config"]["verdicts_match_cpu_sample"] = bool(np.array_equal(valid[:m], cpu_valid))
