@@ -179,7 +179,16 @@ def main(argv=None):
     rngq = np.random.default_rng(17)
     pairs = rngq.integers(0, len(states), size=(nq, 2))
     prm.set_obstacles(new_vox)
+    prm.prepare(0)
     prm.solveWithRoadmap(pairs[:64, 0], pairs[:64, 1])          # warm-up: thread scratch, device lists
+    prm.clearValidity()
+    t0 = time.perf_counter()
+    plain = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])      # the reference's heuristic alone (state-space distance)
+    t_plain = time.perf_counter() - t0
+    st_plain = dict(prm.stats)
+    t0 = time.perf_counter()
+    prm.prepare(16)                                             # once per roadmap: 16 landmark distance tables
+    t_prepare = time.perf_counter() - t0
     prm.clearValidity()
     chk.engine.profile_begin()
     t0 = time.perf_counter()
@@ -197,9 +206,12 @@ def main(argv=None):
     t_eager = time.perf_counter() - t0
     st_eager = dict(prm.stats)
     assert np.array_equal(lazy["status"], eager["status"]) and np.array_equal(lazy["cost"], eager["cost"])
+    assert np.array_equal(lazy["status"], plain["status"]) and np.array_equal(lazy["cost"], plain["cost"])
+    assert np.array_equal(lazy["path_vertices"], plain["path_vertices"])
     plen = np.diff(lazy["path_offsets"])[lazy["status"] == 0]
     q5 = {"n": nq, "roadmap_vertices": len(states), "roadmap_edges": int(len(e_ok)), "cache_blocks": int(vc_all["offsets"][-1] + ec_all["offsets"][-1]),
-          "cache_upload_s": t_upload,
+          "cache_upload_s": t_upload, "landmark_tables_s": t_prepare,
+          "lazy_reference_heuristic_only": {"queries_per_s": nq / t_plain, "seconds": t_plain, **st_plain},
           "lazy": {"queries_per_s": nq / t_lazy, "seconds": t_lazy, **st_lazy, "k4_launches": k4l["launches"], "k4_ms_total": k4l["total_ms"]},
           "eager": {"queries_per_s_incl_revalidation": nq / (t_eager + t_reval), "revalidate_all_ms": 1e3 * t_reval,
                     "items_per_s_revalidation": (len(states) + len(e_ok)) / t_reval, "search_seconds": t_eager, **st_eager,

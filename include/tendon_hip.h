@@ -348,6 +348,12 @@ int tr_roadmap_set_caches(tr_roadmap *rm, const int64_t *v_offsets, const uint32
                           const uint64_t *e_masks, const uint64_t *e_present_bits);
 /* clearValidity (:1656-1663): everything unknown again, removed items back in the graph -- call it after the
  * obstacle grid of `ctx` changed (tr_set_grid / tr_grid_*). */
+/* Landmark tables for the searches of tr_roadmap_solve: graph distances from n_landmarks extremal vertices over ALL edges
+ * (one Dijkstra each, on n_threads host threads; 0 = the process's CPU share).  They sharpen A*'s heuristic -- the
+ * reference's state-space distance (costHeuristic :2773-2775) -- by lower bounds that stay valid when invalid items leave
+ * the graph, so the returned paths and costs are unchanged and far fewer vertices are expanded.  n_landmarks = 0 searches
+ * with the reference's heuristic alone.  Without this call the first tr_roadmap_solve of >= 64 queries builds 16. */
+int tr_roadmap_prepare(tr_roadmap *rm, int32_t n_landmarks, int32_t n_threads);
 int tr_roadmap_clear_validity(tr_roadmap *rm);
 /* Eager form of the loading loops (:2397-2411, :2486-2526): every cached set against the current grid in one K4
  * launch; afterwards no query finds an unknown item. */

@@ -494,6 +494,8 @@ class VoxelCachedLazyPRM {
                                  vertices.usable.empty() ? nullptr : vp.data(), edges.offsets.data(), edges.block_ids.data(),
                                  edges.masks.data(), edges.usable.empty() ? nullptr : ep.data()));
   }
+  /// landmark lower bounds for the searches (0 = the reference's heuristic alone); paths and costs do not depend on it
+  void prepare(int n_landmarks = 16, int n_threads = 0) { rcheck(tr_roadmap_prepare(rm_, n_landmarks, n_threads)); }
   void clearValidity() { rcheck(tr_roadmap_clear_validity(rm_)); }
   /// every cached set against the checker's current obstacle grid -> (#invalid vertices, #invalid edges)
   std::pair<int64_t, int64_t> revalidate() {

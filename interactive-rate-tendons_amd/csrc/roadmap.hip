@@ -19,6 +19,11 @@
 // shortest path of the graph minus ALL invalid items, whatever subset has been discovered (equal costs; equal vertex
 // sequences unless two paths tie exactly).  What differs is bookkeeping only: every unknown edge of a vertex-clean path
 // is tested in the round (the reference stops at the first invalid one), so the set of DISCOVERED invalid edges is a superset.
+// The searches are the host's share of the loop (latency-bound pointer chasing over a graph that fits the host caches;
+// the device's share is the voxel work).  Their heuristic is the reference's state-space distance, sharpened by landmark
+// lower bounds (tr_roadmap_prepare): distances from a few extremal vertices over the FULL graph; |d(l, v) - d(l, goal)| never
+// exceeds the distance from v to the goal, and stays a lower bound when invalid items leave the graph (distances only
+// grow).  The path A* returns is still the shortest one -- an admissible heuristic only changes how few vertices are expanded.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -55,14 +60,18 @@ int host_threads(int want) {
   return (int)std::max(1u, std::min(n, 64u));
 }
 
+struct Node {                          // A* state of one vertex in one search: 32 B, one cache line touched per visit
+  double g, h;
+  int32_t parent, parent_edge;
+  uint32_t stamp, closed;
+};
 struct Scratch {                       // per host thread, reused across queries: generation-stamped A* state
-  std::vector<double> g;
-  std::vector<int32_t> parent, parent_edge;
-  std::vector<uint32_t> stamp;
-  std::vector<uint8_t> closed;
+  std::vector<Node> node;
   std::vector<std::pair<double, int32_t>> heap;
   uint32_t gen = 0;
 };
+
+struct Arc { int32_t v, e; double w; };   // one adjacency entry: neighbour, edge id, edge weight (16 B: four per cache line)
 
 }  // namespace
 
@@ -78,7 +87,12 @@ struct tr_roadmap {
   std::vector<int32_t> eu, ev;
   std::vector<double> w;
   std::vector<int64_t> adj_off;        // CSR adjacency, both directions
-  std::vector<int32_t> adj_v, adj_e;
+  std::vector<Arc> adj;
+  // landmark lower bounds (tr_roadmap_prepare): lm_d[v * lm_n + l] = graph distance landmark l -> v over all edges, as float
+  // (+inf = not connected); lm_n = 0: none, -1: not built yet (built with the default count by the first solve)
+  int lm_n = -1;
+  std::vector<float> lm_d;
+  std::vector<int32_t> lm_v;
   std::vector<uint8_t> vstat, estat;   // V_*
   std::vector<uint8_t> vpresent, epresent;
   // cached voxel sets in HBM: one CSR, items [0, V) = vertices, [V, V + E) = edges
@@ -121,53 +135,171 @@ inline double state_distance(const tr_roadmap *r, const double *a, const double 
   return dist;
 }
 
+// relative slack that keeps the float-stored landmark distances on the safe side of the true ones (rounding to float is
+// 2^-24 relative per distance; the fp64 path sums behind them differ from A*'s own sums by ~1e-16 per hop)
+constexpr double kLmSlack = 1.0 / (1 << 21);
+
 // astarSearch (:2950-2976): A* with the state-space distance to the goal as heuristic (costHeuristic :2773-2775 ->
 // motionCostHeuristic), edge weights as given; stops when the goal is taken off the open list (AStarGoalVisitor).
 // Vertices / edges known invalid are not part of the graph (the reference has removed them).  Returns false when the
 // goal cannot be reached.  path: goal ... start (vertex ids), path_e: the edges between them.
+// With landmark tables the heuristic is the larger of that distance and the landmark bounds: admissible, so the goal
+// leaves the open list with the same (optimal) cost and, ties apart, the same parents; a vertex whose cost improves after
+// it was expanded is opened again (with the consistent state-space distance alone that never happens).
 bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::vector<int32_t> &path, std::vector<int32_t> &path_e,
            int64_t &expanded) {
-  if (sc.stamp.size() != (size_t)r->V) {
-    sc.g.assign((size_t)r->V, 0.0); sc.parent.assign((size_t)r->V, -1); sc.parent_edge.assign((size_t)r->V, -1);
-    sc.stamp.assign((size_t)r->V, 0u); sc.closed.assign((size_t)r->V, 0); sc.gen = 0;
-  }
-  if (++sc.gen == 0) { std::fill(sc.stamp.begin(), sc.stamp.end(), 0u); sc.gen = 1; }
+  if (sc.node.size() != (size_t)r->V) { sc.node.assign((size_t)r->V, Node{0.0, 0.0, -1, -1, 0u, 0u}); sc.gen = 0; }
+  if (++sc.gen == 0) { for (Node &nd : sc.node) nd.stamp = 0u; sc.gen = 1; }
+  Node *node = sc.node.data();
   const uint32_t gen = sc.gen;
   auto &heap = sc.heap;
   heap.clear();
   const double *sg = &r->states[(size_t)goal * r->S];
+  const int L = r->lm_n > 0 ? r->lm_n : 0;
+  const float *lg = L ? &r->lm_d[(size_t)goal * L] : nullptr;
+  const double inf = std::numeric_limits<double>::infinity();
+  auto heuristic = [&](int32_t v) -> double {
+    double h = state_distance(r, &r->states[(size_t)v * r->S], sg);
+    if (L) {
+      const float *lv = &r->lm_d[(size_t)v * L];
+      float best = 0.0f;
+      bool cut = false;
+      for (int l = 0; l < L; l++) {
+        const float a = lv[l], b = lg[l];
+        const float hi = a > b ? a : b, lo = a > b ? b : a;
+        if (hi == std::numeric_limits<float>::infinity()) { cut |= lo != hi; continue; }   // one side unreachable from l: different components
+        const float t = (hi - lo) - (float)kLmSlack * hi;          // float subtraction of nearby values: error <= 2^-24 hi, inside the slack
+        best = t > best ? t : best;
+      }
+      if (cut) return inf;
+      if ((double)best > h) h = (double)best;
+    }
+    return h;
+  };
   auto cmp = [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; };
-  sc.stamp[start] = gen; sc.g[start] = 0.0; sc.parent[start] = start; sc.parent_edge[start] = -1; sc.closed[start] = 0;
-  heap.emplace_back(state_distance(r, &r->states[(size_t)start * r->S], sg), start);
+  node[start] = Node{0.0, heuristic(start), start, -1, gen, 0u};
+  if (node[start].h == inf) return false;
+  heap.emplace_back(node[start].h, start);
   bool found = false;
   while (!heap.empty()) {
     std::pop_heap(heap.begin(), heap.end(), cmp);
     const int32_t u = heap.back().second;
     heap.pop_back();
-    if (sc.closed[u]) continue;                 // a stale entry of a vertex already expanded with a better cost
-    sc.closed[u] = 1;
+    if (node[u].closed) continue;               // a stale entry of a vertex already expanded with a better cost
+    node[u].closed = 1u;
     expanded++;
     if (u == goal) { found = true; break; }
-    const double gu = sc.g[u];
-    for (int64_t k = r->adj_off[u]; k < r->adj_off[u + 1]; k++) {
-      const int32_t e = r->adj_e[k], v = r->adj_v[k];
+    const double gu = node[u].g;
+    const Arc *arc = r->adj.data() + r->adj_off[u], *end = r->adj.data() + r->adj_off[u + 1];
+    for (; arc != end; ++arc) {
+      const int32_t e = arc->e, v = arc->v;
       if (r->estat[e] == V_INVALID || r->vstat[v] == V_INVALID) continue;
-      const double gv = gu + r->w[e];
-      if (sc.stamp[v] != gen) { sc.stamp[v] = gen; sc.closed[v] = 0; }
-      else if (sc.closed[v] || !(gv < sc.g[v])) continue;
-      sc.g[v] = gv; sc.parent[v] = u; sc.parent_edge[v] = e;
-      heap.emplace_back(gv + state_distance(r, &r->states[(size_t)v * r->S], sg), v);
+      const double gv = gu + arc->w;
+      Node &nv = node[v];
+      if (nv.stamp != gen) { nv.stamp = gen; nv.h = heuristic(v); }     // h(v) is fixed for the query: computed when v is first reached
+      else if (!(gv < nv.g)) continue;
+      nv.g = gv;
+      if (nv.h == inf) { nv.closed = 1u; continue; }
+      nv.parent = u; nv.parent_edge = e; nv.closed = 0u;
+      heap.emplace_back(gv + nv.h, v);
       std::push_heap(heap.begin(), heap.end(), cmp);
     }
   }
   if (!found) return false;
   path.clear(); path_e.clear();
-  for (int32_t v = goal;; v = sc.parent[v]) {
+  for (int32_t v = goal;; v = node[v].parent) {
     path.push_back(v);
     if (v == start) break;
-    path_e.push_back(sc.parent_edge[v]);
+    path_e.push_back(node[v].parent_edge);
   }
   return true;
+}
+
+// Landmark tables: n extremal vertices of the largest component (the corners of the sampled state box first, then fixed
+// pseudo-random directions), one Dijkstra each over ALL edges -- validity plays no part, see the header comment.
+void build_landmarks(tr_roadmap *r, int n, int T) {
+  r->lm_d.clear(); r->lm_v.clear(); r->lm_n = 0;
+  const int64_t V = r->V;
+  const int S = r->S;
+  if (n <= 0 || V < 2 || r->E == 0) return;
+  // largest connected component
+  std::vector<int32_t> comp((size_t)V, -1), stack;
+  int32_t ncomp = 0, big = -1;
+  int64_t big_n = 0;
+  for (int64_t s0 = 0; s0 < V; s0++) {
+    if (comp[(size_t)s0] >= 0) continue;
+    int64_t cnt = 0;
+    stack.assign(1, (int32_t)s0); comp[(size_t)s0] = ncomp;
+    while (!stack.empty()) {
+      const int32_t u = stack.back(); stack.pop_back(); cnt++;
+      for (int64_t k = r->adj_off[u]; k < r->adj_off[u + 1]; k++) {
+        const int32_t v = r->adj[(size_t)k].v;
+        if (comp[(size_t)v] < 0) { comp[(size_t)v] = ncomp; stack.push_back(v); }
+      }
+    }
+    if (cnt > big_n) { big_n = cnt; big = ncomp; }
+    ncomp++;
+  }
+  if (big_n < 2) return;
+  std::vector<double> lo((size_t)S, std::numeric_limits<double>::infinity()), hi((size_t)S, -std::numeric_limits<double>::infinity());
+  for (int64_t v = 0; v < V; v++)
+    for (int i = 0; i < S; i++) { const double x = r->states[(size_t)v * S + i]; lo[(size_t)i] = std::min(lo[(size_t)i], x); hi[(size_t)i] = std::max(hi[(size_t)i], x); }
+  uint64_t lcg = 0x9E3779B97F4A7C15ull;
+  for (int l = 0; l < 4 * n && (int)r->lm_v.size() < n; l++) {
+    std::vector<double> dir((size_t)S);
+    for (int i = 0; i < S; i++) {
+      double c;
+      if (S <= 16 && l < (1 << S)) c = ((l >> i) & 1) ? 1.0 : -1.0;
+      else { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; c = (double)(int64_t)(lcg >> 11) / (double)(1ll << 52) - 1.0; }
+      const double ext = hi[(size_t)i] - lo[(size_t)i];
+      dir[(size_t)i] = ext > 0 ? c / ext : 0.0;
+    }
+    int32_t arg = -1;
+    double best = -std::numeric_limits<double>::infinity();
+    for (int64_t v = 0; v < V; v++) {
+      if (comp[(size_t)v] != big) continue;
+      double d = 0;
+      for (int i = 0; i < S; i++) d += dir[(size_t)i] * r->states[(size_t)v * S + i];
+      if (d > best) { best = d; arg = (int32_t)v; }
+    }
+    if (arg >= 0 && std::find(r->lm_v.begin(), r->lm_v.end(), arg) == r->lm_v.end()) r->lm_v.push_back(arg);
+  }
+  const int L = (int)r->lm_v.size();
+  if (L == 0) return;
+  r->lm_d.assign((size_t)V * L, std::numeric_limits<float>::infinity());
+  std::atomic<int> next{0};
+  auto worker = [&]() {
+    std::vector<double> dist((size_t)V);
+    std::vector<std::pair<double, int32_t>> heap;
+    auto cmp = [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; };
+    for (;;) {
+      const int l = next.fetch_add(1);
+      if (l >= L) break;
+      std::fill(dist.begin(), dist.end(), std::numeric_limits<double>::infinity());
+      heap.clear();
+      dist[(size_t)r->lm_v[(size_t)l]] = 0.0;
+      heap.emplace_back(0.0, r->lm_v[(size_t)l]);
+      while (!heap.empty()) {
+        std::pop_heap(heap.begin(), heap.end(), cmp);
+        const double du = heap.back().first;
+        const int32_t u = heap.back().second;
+        heap.pop_back();
+        if (du > dist[(size_t)u]) continue;
+        for (int64_t k = r->adj_off[u]; k < r->adj_off[u + 1]; k++) {
+          const Arc &a = r->adj[(size_t)k];
+          const double dv = du + a.w;
+          if (dv < dist[(size_t)a.v]) { dist[(size_t)a.v] = dv; heap.emplace_back(dv, a.v); std::push_heap(heap.begin(), heap.end(), cmp); }
+        }
+      }
+      for (int64_t v = 0; v < V; v++) r->lm_d[(size_t)v * L + l] = (float)dist[(size_t)v];
+    }
+  };
+  const int nt = std::max(1, std::min(T, L));
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; t++) th.emplace_back(worker);
+  worker();
+  for (auto &x : th) x.join();
+  r->lm_n = L;
 }
 
 void free_dev(tr_roadmap *r) {
@@ -233,12 +365,12 @@ int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, con
   }
   r->adj_off.assign((size_t)n_vertices + 1, 0);
   for (int64_t v = 0; v < n_vertices; v++) r->adj_off[(size_t)v + 1] = r->adj_off[(size_t)v] + deg[(size_t)v + 1];
-  r->adj_v.resize((size_t)r->adj_off[(size_t)n_vertices]); r->adj_e.resize(r->adj_v.size());
+  r->adj.resize((size_t)r->adj_off[(size_t)n_vertices]);
   std::vector<int64_t> fill(r->adj_off.begin(), r->adj_off.end() - 1);
   for (int64_t e = 0; e < n_edges; e++) {
     const int32_t a = r->eu[(size_t)e], b = r->ev[(size_t)e];
-    r->adj_v[(size_t)fill[(size_t)a]] = b; r->adj_e[(size_t)fill[(size_t)a]++] = (int32_t)e;
-    r->adj_v[(size_t)fill[(size_t)b]] = a; r->adj_e[(size_t)fill[(size_t)b]++] = (int32_t)e;
+    r->adj[(size_t)fill[(size_t)a]++] = Arc{b, (int32_t)e, r->w[(size_t)e]};
+    r->adj[(size_t)fill[(size_t)b]++] = Arc{a, (int32_t)e, r->w[(size_t)e]};
   }
   r->vstat.assign((size_t)n_vertices, V_UNKNOWN); r->estat.assign((size_t)n_edges, V_UNKNOWN);
   r->vpresent.assign((size_t)n_vertices, 1); r->epresent.assign((size_t)n_edges, 1);
@@ -286,6 +418,14 @@ int tr_roadmap_set_caches(tr_roadmap *r, const int64_t *v_offsets, const uint32_
   for (int64_t i = 0; i < r->V; i++) r->vpresent[(size_t)i] = v_present_bits ? (uint8_t)((v_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
   for (int64_t i = 0; i < r->E; i++) r->epresent[(size_t)i] = e_present_bits ? (uint8_t)((e_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
   r->has_caches = true;
+  return TR_OK;
+}
+
+int tr_roadmap_prepare(tr_roadmap *r, int32_t n_landmarks, int32_t n_threads) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  if (n_landmarks < 0 || n_landmarks > 64) return rfail(r, TR_ERR_INVALID_ARG, "landmark count must be in [0, 64]");
+  build_landmarks(r, n_landmarks, host_threads(n_threads));
   return TR_OK;
 }
 
@@ -346,6 +486,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
   const int T = host_threads(n_threads);
   if ((int)r->scratch.size() < T) r->scratch.resize((size_t)T);
+  if (r->lm_n < 0 && n_queries >= 64) build_landmarks(r, 16, T);         // a handful of queries does not repay 16 graph sweeps
   std::vector<std::vector<int32_t>> paths((size_t)n_queries), paths_e((size_t)n_queries);
   std::vector<int32_t> list;
   std::vector<uint8_t> hit;

@@ -223,6 +223,10 @@ class VoxelCachedLazyPRM:
         self.engine.set_grid(voxels.Nx(), voxels.limits(), voxels.blocks, None if env is None else env.inv_rotation)
         self.clearValidity()
 
+    def prepare(self, n_landmarks=16, n_threads=0):
+        """Landmark lower bounds for the searches (tr_roadmap_prepare); 0 = the reference's heuristic alone."""
+        self._check(self.lib.tr_roadmap_prepare(self._rm, int(n_landmarks), int(n_threads)))
+
     def clearValidity(self):
         self._check(self.lib.tr_roadmap_clear_validity(self._rm))
 

@@ -58,6 +58,22 @@ def test_query_loop_matches_oracle_and_paths_are_valid_from_scratch(irt, orc, he
     hit_v = orc.check_cached(og, vc["block_ids"], vc["masks"], vc["offsets"])
     hit_e = orc.check_cached(og, ec["block_ids"], ec["masks"], ec["offsets"])
     assert np.array_equal(v_lazy[v_lazy > 0] == 2, hit_v[v_lazy > 0]) and np.array_equal(e_lazy[e_lazy > 0] == 2, hit_e[e_lazy > 0])
+    # the landmark bounds (built by the first large batch) only change how many vertices the searches expand: with the
+    # reference's heuristic alone -- and with another landmark count -- the same paths, costs and discovered validity
+    for nl in (0, 5):
+        prm0 = irt.VoxelCachedLazyPRM(chk, states, edges)
+        prm0.set_caches(vc, ec)
+        prm0.prepare(nl)
+        plain = prm0.solveWithRoadmap(starts, goals)
+        assert np.array_equal(plain["status"], lazy["status"]) and np.array_equal(plain["cost"], lazy["cost"])
+        assert np.array_equal(plain["path_vertices"], lazy["path_vertices"]) and np.array_equal(plain["path_offsets"], lazy["path_offsets"])
+        v0, e0 = prm0.validity()
+        assert np.array_equal(v0, v_lazy) and np.array_equal(e0, e_lazy)
+        assert prm0.stats["rounds"] == st_lazy["rounds"] and prm0.stats["items_checked"] == st_lazy["items_checked"]
+        if nl == 0:
+            assert prm0.stats["expanded"] > 1.5 * st_lazy["expanded"], (prm0.stats, st_lazy)
+    with pytest.raises(irt.InvalidArgument):
+        prm.prepare(65)
     # eager form: one K4 pass over the whole roadmap, then the same answers in a single round
     prm.clearValidity()
     nv, ne = prm.revalidate()
