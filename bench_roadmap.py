@@ -110,6 +110,12 @@ def main(argv=None):
     nv = min(args.cache_items, len(states))
     ne = min(args.cache_items, len(edges))
     rb.vertex_caches(states[:4096]); rb.edge_caches(states, edges[:4096])        # warm-up: block-list scratch, merge buffers
+    import torch
+    rb.vertex_caches(states[:nv], device=True)                  # lists left in HBM (tr_voxelize_fetch_dev): what the query loop takes
+    t_vc_dev = rb.timing["vertex_caches"]["seconds"]
+    rb.edge_caches(states, edges[:ne], device=True)
+    t_ec_dev = rb.timing["edge_caches"]["seconds"]
+    torch.cuda.empty_cache()
     vc = rb.vertex_caches(states[:nv])
     ec = rb.edge_caches(states, edges[:ne])
     new_vox, _ = W.reach_environment(seed=7, n_spheres=72)
@@ -122,7 +128,6 @@ def main(argv=None):
     for _ in range(reps):
         eh = rb.revalidate(ec, new_vox)
     te = (time.perf_counter() - t0) / reps
-    import torch
     dv, de = irt.roadmap.DeviceCaches(chk.engine, vc), irt.roadmap.DeviceCaches(chk.engine, ec)
     assert np.array_equal(dv.revalidate(new_vox), vh) and np.array_equal(de.revalidate(), eh)
     chk.engine.profile_begin()
@@ -160,6 +165,7 @@ def main(argv=None):
         "vertex_caches_built_per_s": nv / rb.timing["vertex_caches"]["seconds"],
         "edge_cache_items": ne, "edge_cache_blocks": int(ec["offsets"][-1]),
         "edge_caches_built_per_s": ne / rb.timing["edge_caches"]["seconds"],
+        "vertex_caches_built_per_s_lists_left_on_device": nv / t_vc_dev, "edge_caches_built_per_s_lists_left_on_device": ne / t_ec_dev,
         "revalidate_vertex_items_per_s_host_api": nv / tv, "revalidate_edge_items_per_s_host_api": ne / te,
         "vertex_hit_fraction": float(vh.mean()), "edge_hit_fraction": float(eh.mean()),
         "note": "host API: includes set_grid (2 MiB upload + dilation) and CSR upload every call",
@@ -176,6 +182,14 @@ def main(argv=None):
     t0 = time.perf_counter()
     prm.set_caches(vc_all, ec_all)
     t_upload = time.perf_counter() - t0
+    t0 = time.perf_counter()                                    # the same roadmap with the lists never leaving the device
+    vd_all, ed_all = rb.vertex_caches(states, device=True), rb.edge_caches(states, e_ok, device=True)
+    t_build_dev = time.perf_counter() - t0
+    prm_h, prm = prm, irt.VoxelCachedLazyPRM(chk, states, e_ok)   # the queries below run on the device-attached caches
+    t0 = time.perf_counter()
+    prm.set_caches(vd_all, ed_all)
+    t_attach_dev = time.perf_counter() - t0
+    del vd_all, ed_all, prm_h
     rngq = np.random.default_rng(17)
     pairs = rngq.integers(0, len(states), size=(nq, 2))
     prm.set_obstacles(new_vox)
@@ -210,7 +224,8 @@ def main(argv=None):
     assert np.array_equal(lazy["path_vertices"], plain["path_vertices"])
     plen = np.diff(lazy["path_offsets"])[lazy["status"] == 0]
     q5 = {"n": nq, "roadmap_vertices": len(states), "roadmap_edges": int(len(e_ok)), "cache_blocks": int(vc_all["offsets"][-1] + ec_all["offsets"][-1]),
-          "cache_upload_s": t_upload, "landmark_tables_s": t_prepare,
+          "cache_upload_s": t_upload, "caches_built_on_device_s": t_build_dev, "caches_attached_from_device_s": t_attach_dev,
+          "landmark_tables_s": t_prepare,
           "lazy_reference_heuristic_only": {"queries_per_s": nq / t_plain, "seconds": t_plain, **st_plain},
           "lazy": {"queries_per_s": nq / t_lazy, "seconds": t_lazy, **st_lazy, "k4_launches": k4l["launches"], "k4_ms_total": k4l["total_ms"]},
           "eager": {"queries_per_s_incl_revalidation": nq / (t_eager + t_reval), "revalidate_all_ms": 1e3 * t_reval,

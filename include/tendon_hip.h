@@ -291,8 +291,13 @@ int tr_voxelize_edges_indexed(tr_ctx *ctx, const tr_space_params *sp, const doub
                               const int32_t *edges, int64_t n_edges, int64_t *offsets, uint64_t *fully_valid_bits,
                               int32_t *n_fk);
 
-/* Copy the block lists of the last tr_voxelize_* call; capacity must be >= its offsets[n]. */
+/* The block lists of the last tr_voxelize_* call stay in device memory (they are produced there, and their consumers --
+ * tr_check_cached_dev, tr_roadmap_set_caches_dev -- read them there); capacity must be >= its offsets[n] = tr_voxelize_count.
+ * tr_voxelize_fetch copies them to host arrays; tr_voxelize_fetch_dev copies them device to device into arrays the caller
+ * owns (complete when it returns; the next tr_voxelize_* call overwrites the store). */
 int tr_voxelize_fetch(tr_ctx *ctx, uint32_t *block_ids, uint64_t *masks, int64_t capacity);
+int tr_voxelize_fetch_dev(tr_ctx *ctx, uint32_t *d_block_ids, uint64_t *d_masks, int64_t capacity, void *stream);
+int64_t tr_voxelize_count(const tr_ctx *ctx);
 
 /* ---- nearest neighbours in state space ---------------------------- */
 
@@ -346,14 +351,19 @@ const char *tr_roadmap_last_error(const tr_roadmap *rm);
 int tr_roadmap_set_caches(tr_roadmap *rm, const int64_t *v_offsets, const uint32_t *v_block_ids, const uint64_t *v_masks,
                           const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *e_block_ids,
                           const uint64_t *e_masks, const uint64_t *e_present_bits);
-/* clearValidity (:1656-1663): everything unknown again, removed items back in the graph -- call it after the
- * obstacle grid of `ctx` changed (tr_set_grid / tr_grid_*). */
+/* The same with the block ids / masks in device memory (the arrays tr_voxelize_fetch_dev filled): the caches of a roadmap
+ * built on this GPU never cross PCIe.  Offsets and present bits are host arrays as above. */
+int tr_roadmap_set_caches_dev(tr_roadmap *rm, const int64_t *v_offsets, const uint32_t *d_v_block_ids, const uint64_t *d_v_masks,
+                              const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *d_e_block_ids,
+                              const uint64_t *d_e_masks, const uint64_t *e_present_bits);
 /* Landmark tables for the searches of tr_roadmap_solve: graph distances from n_landmarks extremal vertices over ALL edges
  * (one Dijkstra each, on n_threads host threads; 0 = the process's CPU share).  They sharpen A*'s heuristic -- the
  * reference's state-space distance (costHeuristic :2773-2775) -- by lower bounds that stay valid when invalid items leave
  * the graph, so the returned paths and costs are unchanged and far fewer vertices are expanded.  n_landmarks = 0 searches
  * with the reference's heuristic alone.  Without this call the first tr_roadmap_solve of >= 64 queries builds 16. */
 int tr_roadmap_prepare(tr_roadmap *rm, int32_t n_landmarks, int32_t n_threads);
+/* clearValidity (:1656-1663): everything unknown again, removed items back in the graph -- call it after the
+ * obstacle grid of `ctx` changed (tr_set_grid / tr_grid_*). */
 int tr_roadmap_clear_validity(tr_roadmap *rm);
 /* Eager form of the loading loops (:2397-2411, :2486-2526): every cached set against the current grid in one K4
  * launch; afterwards no query finds an unknown item. */

@@ -385,9 +385,11 @@ void tr_roadmap_destroy(tr_roadmap *r) {
   delete r;
 }
 
-int tr_roadmap_set_caches(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *v_ids, const uint64_t *v_masks,
-                          const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *e_ids,
-                          const uint64_t *e_masks, const uint64_t *e_present_bits) {
+}  // extern "C"
+namespace {
+int set_caches_impl(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *v_ids, const uint64_t *v_masks,
+                    const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *e_ids,
+                    const uint64_t *e_masks, const uint64_t *e_present_bits, hipMemcpyKind kind) {
   if (!r) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock_(r->mu);
   if (!v_offsets || !e_offsets) return rfail(r, TR_ERR_INVALID_ARG, "null offsets");
@@ -407,18 +409,32 @@ int tr_roadmap_set_caches(tr_roadmap *r, const int64_t *v_offsets, const uint32_
   RM_HIP(r, hipMalloc((void **)&r->d_off, off.size() * sizeof(int64_t)));
   RM_HIP(r, hipMalloc((void **)&r->d_bits, ((size_t)items / 64 + 1) * sizeof(uint64_t)));
   if (nv) {
-    RM_HIP(r, hipMemcpy(r->d_ids, v_ids, (size_t)nv * sizeof(uint32_t), hipMemcpyHostToDevice));
-    RM_HIP(r, hipMemcpy(r->d_masks, v_masks, (size_t)nv * sizeof(uint64_t), hipMemcpyHostToDevice));
+    RM_HIP(r, hipMemcpy(r->d_ids, v_ids, (size_t)nv * sizeof(uint32_t), kind));
+    RM_HIP(r, hipMemcpy(r->d_masks, v_masks, (size_t)nv * sizeof(uint64_t), kind));
   }
   if (ne) {
-    RM_HIP(r, hipMemcpy(r->d_ids + nv, e_ids, (size_t)ne * sizeof(uint32_t), hipMemcpyHostToDevice));
-    RM_HIP(r, hipMemcpy(r->d_masks + nv, e_masks, (size_t)ne * sizeof(uint64_t), hipMemcpyHostToDevice));
+    RM_HIP(r, hipMemcpy(r->d_ids + nv, e_ids, (size_t)ne * sizeof(uint32_t), kind));
+    RM_HIP(r, hipMemcpy(r->d_masks + nv, e_masks, (size_t)ne * sizeof(uint64_t), kind));
   }
   RM_HIP(r, hipMemcpy(r->d_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   for (int64_t i = 0; i < r->V; i++) r->vpresent[(size_t)i] = v_present_bits ? (uint8_t)((v_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
   for (int64_t i = 0; i < r->E; i++) r->epresent[(size_t)i] = e_present_bits ? (uint8_t)((e_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
   r->has_caches = true;
   return TR_OK;
+}
+}  // namespace
+extern "C" {
+
+int tr_roadmap_set_caches(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *v_ids, const uint64_t *v_masks,
+                          const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *e_ids,
+                          const uint64_t *e_masks, const uint64_t *e_present_bits) {
+  return set_caches_impl(r, v_offsets, v_ids, v_masks, v_present_bits, e_offsets, e_ids, e_masks, e_present_bits, hipMemcpyHostToDevice);
+}
+
+int tr_roadmap_set_caches_dev(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *d_v_ids, const uint64_t *d_v_masks,
+                              const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *d_e_ids,
+                              const uint64_t *d_e_masks, const uint64_t *e_present_bits) {
+  return set_caches_impl(r, v_offsets, d_v_ids, d_v_masks, v_present_bits, e_offsets, d_e_ids, d_e_masks, e_present_bits, hipMemcpyDeviceToDevice);
 }
 
 int tr_roadmap_prepare(tr_roadmap *r, int32_t n_landmarks, int32_t n_threads) {

