@@ -106,7 +106,7 @@ def _units():
     """(object name, source, extra flags): the C ABI + K2..K6, the cache merge, and K1 once per
     (tendon count, kernel: shared grid / retraction / fused with K2) so its 64 instantiations compile in parallel."""
     fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "verdict_kernel.hpp",
-               "sweep_kernel.hpp", "tr_types.hpp"]
+               "sweep_kernel.hpp", "sphere_kernel.hpp", "tr_types.hpp"]
     fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip"]
     main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
     u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),

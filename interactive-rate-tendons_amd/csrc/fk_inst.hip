@@ -14,14 +14,15 @@
 namespace trk {
 
 #if TRK_INST_KIND == 3
-template <bool ROT>
+template <bool ROT, bool SPH>
 static void go(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);
-  hipLaunchKernelGGL((fk_verdict<TRK_INST_N, ROT>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_tab, a.d_steps,
+  hipLaunchKernelGGL((fk_verdict<TRK_INST_N, ROT, SPH>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_tab, a.d_steps,
                      a.n_steps, a.out.tips, va);
 }
-template <> void launch_fk_verdict<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
-  if (a.rotation) go<true>(a, va, lds); else go<false>(a, va, lds);
+template <> void launch_fk_verdict<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres) {
+  if (spheres) { if (a.rotation) go<true, true>(a, va, lds); else go<false, true>(a, va, lds); }
+  else         { if (a.rotation) go<true, false>(a, va, lds); else go<false, false>(a, va, lds); }
 }
 #elif TRK_INST_KIND == 2
 template <bool ROT>

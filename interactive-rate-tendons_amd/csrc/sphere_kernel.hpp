@@ -24,6 +24,42 @@ namespace trk {
 
 #define TRK_EDT_FAR 1e30f
 
+// The exact test for ONE point (wave-uniform sx, sy, sz, already in the voxel frame), served by the whole wave: does an
+// occupied cell have its centre within `radius` of the point?  Each lane takes blocks of add_sphere's block range
+// (nearest_block_idx(c - r) .. nearest_block_idx(c + r), VoxelOctree.cpp:272-283, :446-449), skips empty ones and tests the
+// set bits' centres with the reference's arithmetic.  Returns the same answer in every lane.
+__device__ __forceinline__ bool sphere_scan_wave(double sx, double sy, double sz, double radius, const GridK &g,
+                                                 const uint64_t *__restrict__ grid, int lane) {
+#pragma clang fp contract(off)
+  const int Nb = g.Nb;
+  const double rr = radius * radius;
+  auto blk = [&](double v, double lo, double dd) { int q = (int)((v - lo) / dd); q = q / 4; return q < 0 ? 0 : (q > Nb - 1 ? Nb - 1 : q); };
+  const int lx = blk(sx - radius, g.xmin, g.dx), hx = blk(sx + radius, g.xmin, g.dx);
+  const int ly = blk(sy - radius, g.ymin, g.dy), hy = blk(sy + radius, g.ymin, g.dy);
+  const int lz = blk(sz - radius, g.zmin, g.dz), hz = blk(sz + radius, g.zmin, g.dz);
+  const int ny = hy - ly + 1, nz = hz - lz + 1, total = (hx - lx + 1) * ny * nz;
+  bool found = false;
+  for (int t0 = 0; t0 < total && !__any(found); t0 += 64) {
+    const int t = t0 + lane;
+    if (t < total) {
+      const int bx = lx + t / (ny * nz), by = ly + (t / nz) % ny, bz = lz + t % nz;
+      unsigned long long w = grid[((size_t)bx * Nb + by) * Nb + bz];
+      while (w && !found) {
+        const int bit = __ffsll((long long)w) - 1;
+        w &= w - 1;
+        const double vx = g.xmin + g.dx * ((double)((bx << 2) + (bit >> 4)) + 0.5);
+        const double vy = g.ymin + g.dy * ((double)((by << 2) + ((bit >> 2) & 3)) + 0.5);
+        const double vz = g.zmin + g.dz * ((double)((bz << 2) + (bit & 3)) + 0.5);
+        const double d0 = sx - vx, d1 = sy - vy, d2 = sz - vz;
+        found = d0 * d0 + d1 * d1 + d2 * d2 <= rr;
+      }
+    }
+  }
+  return __any(found) != 0;
+}
+
+#ifndef TRK_DEVICE_BODIES_ONLY      // verdict_kernel.hpp takes sphere_scan_wave only
+
 // pass 1: squared distance (metres^2) along x to the nearest occupied cell within +-R cells.  One wave per
 // block, lane = cell.
 __global__ __launch_bounds__(64) void obstacle_distance_x(const uint64_t *__restrict__ grid, float *__restrict__ out, int Nb, int R, float dx) {
@@ -78,7 +114,6 @@ __global__ __launch_bounds__(64) void spheres_vs_grid(
   bool hit = false;
   const int np = n_points ? n_points[ic] : P;
   const int64_t ib = ic + (int64_t)(P - np) * ld;        // retraction robots: the lane's point j is in row j + (P - np)
-  const double rr = radius * radius;
   const int Nb = g.Nb, N = g.N;
   const float hd = 0.5f * sqrtf((float)(g.dx * g.dx + g.dy * g.dy + g.dz * g.dz));
   const float r_lo = (float)radius - hd - 1e-6f, r_hi = (float)radius + hd + 1e-6f;
@@ -119,30 +154,7 @@ __global__ __launch_bounds__(64) void spheres_vs_grid(
       const int src = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
       const double sx = __shfl(x, src), sy = __shfl(y, src), sz = __shfl(z, src);
-      // block range of add_sphere: nearest_block_idx(c - r) .. nearest_block_idx(c + r) (:272-283, :446-449)
-      auto blk = [&](double v, double lo, double dd) { int q = (int)((v - lo) / dd); q = q / 4; return q < 0 ? 0 : (q > Nb - 1 ? Nb - 1 : q); };
-      const int lx = blk(sx - radius, g.xmin, g.dx), hx = blk(sx + radius, g.xmin, g.dx);
-      const int ly = blk(sy - radius, g.ymin, g.dy), hy = blk(sy + radius, g.ymin, g.dy);
-      const int lz = blk(sz - radius, g.zmin, g.dz), hz = blk(sz + radius, g.zmin, g.dz);
-      const int ny = hy - ly + 1, nz = hz - lz + 1, total = (hx - lx + 1) * ny * nz;
-      bool found = false;
-      for (int t0 = 0; t0 < total && !__any(found); t0 += 64) {
-        const int t = t0 + lane;
-        if (t < total) {
-          const int bx = lx + t / (ny * nz), by = ly + (t / nz) % ny, bz = lz + t % nz;
-          unsigned long long w = grid[((size_t)bx * Nb + by) * Nb + bz];
-          while (w && !found) {
-            const int bit = __ffsll((long long)w) - 1;
-            w &= w - 1;
-            const double vx = g.xmin + g.dx * ((double)((bx << 2) + (bit >> 4)) + 0.5);
-            const double vy = g.ymin + g.dy * ((double)((by << 2) + ((bit >> 2) & 3)) + 0.5);
-            const double vz = g.zmin + g.dz * ((double)((bz << 2) + (bit & 3)) + 0.5);
-            const double d0 = sx - vx, d1 = sy - vy, d2 = sz - vz;
-            found = d0 * d0 + d1 * d1 + d2 * d2 <= rr;
-          }
-        }
-      }
-      if (__any(found) && lane == src) hit = true;
+      if (sphere_scan_wave(sx, sy, sz, radius, g, grid, lane) && lane == src) hit = true;
     }
   }
   const bool ok = alive && !hit;
@@ -150,5 +162,7 @@ __global__ __launch_bounds__(64) void spheres_vs_grid(
   if (lane == 0) valid_bits[(int64_t)blockIdx.x] = m;
   if (flags && ok) flags[i] |= 8u;
 }
+
+#endif  // TRK_DEVICE_BODIES_ONLY
 
 }  // namespace trk

@@ -501,7 +501,7 @@ __device__ __forceinline__ void sweep_body(
         const int k = last ? Kl : j / CH;
         mx[k * 64] = (float)q.x; my[k * 64] = (float)q.y; mz[k * 64] = (float)q.z; ma[k * 64] = dist;
       }
-      if (check_voxels && !hit && !bad) {
+      if (check_voxels == 1 && !hit && !bad) {
         V3 qr;
         if (g.rot_is_identity) { qr = q; }
         else {
@@ -622,7 +622,13 @@ __device__ __forceinline__ void sweep_body(
   bool valid = conv_ok && len_ok;
   if (valid && bad) { fl |= 16u; valid = false; }
   if (valid) { if (!selfhit) fl |= 4u; else valid = false; }
-  if (valid && check_voxels) { if (!hit) fl |= 8u; else valid = false; }
+  if (valid && check_voxels == 1) { if (!hit) fl |= 8u; else valid = false; }
+  if (valid && check_voxels == 2) {
+    // list mode behind fk_verdict<.., SPH>: the sphere test has been made there; its answer is bit 8 of the flags it wrote
+    // (without flags only configurations that passed it are listed)
+    const bool passed = (out_map && flags && live) ? (flags[out_map[i]] & 8u) != 0 : true;
+    if (passed) fl |= 8u; else valid = false;
+  }
 
   if (out_map) {
     // compacted list (the fallback pass of the verdict path): column i is configuration out_map[i]; its verdict bit is

@@ -27,12 +27,12 @@
 #include "tr_types.hpp"
 #include "fk_launch.hpp"
 #include "sweep_kernel.hpp"
+#include "sphere_kernel.hpp"
 #include "verdict_kernel.hpp"
 #include "edge_kernel.hpp"
 #include "knn_kernel.hpp"
 #include "cache_merge.hpp"
 #include "env_kernel.hpp"
-#include "sphere_kernel.hpp"
 
 namespace {
 
@@ -452,11 +452,13 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
 // is stored -- then ONE launch of fk_sweep_fused_list, which integrates again, with stored points, the configurations whose
 // self-collision test needs the exact pairwise sweep (their indices and count stay on the device; with an empty list its
 // blocks return at once).  d_bits / d_flags / d_tips as in tr_validate_batch_dev; n <= 2^31.
+int ensure_sphere_near(tr_ctx *c, hipStream_t s);
 int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_bits, double *d_tips, uint8_t *d_flags, hipStream_t s,
-                   uint32_t *sig = nullptr, int64_t sig_stride = 0) {
+                   uint32_t *sig = nullptr, int64_t sig_stride = 0, bool spheres = false) {
   if (n <= 0) return TR_OK;
   if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   int rc;
+  if (spheres && (rc = ensure_sphere_near(ctx, s))) return rc;
   Workspace &w = ctx->ws;
   if (ctx->fb_list_cap < n) {
     HIP_TRY(ctx, hipDeviceSynchronize());
@@ -489,12 +491,18 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   }
   a.fb_list = ctx->d_fb_list; a.fb_count = ctx->d_fb_count;
   a.sig = sig; a.sig_stride = sig_stride;
+  if (spheres) {                       // the classification thresholds of K8 (sphere_kernel.hpp: spheres_vs_grid), same expressions
+    const GridK &g = ctx->G;
+    const float hd = 0.5f * sqrtf((float)(g.dx * g.dx + g.dy * g.dy + g.dz * g.dz));
+    a.field = ctx->d_sph_near; a.radius = ctx->K.radius;
+    a.r_lo = (float)ctx->K.radius - hd - 1e-6f; a.r_hi = (float)ctx->K.radius + hd + 1e-6f;
+  }
   HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb_count, 0, sizeof(uint32_t), s));
   // the fallback pass sweeps columns of the small point workspace
   trk::SweepIn in{w.px, w.py, w.pz, nullptr, w.Li, w.conv, nullptr, w.acc};
   const trk::FusedSweepArgs *d_fargs; size_t lds_f; int fslot;
-  if ((rc = fused_args_slot(ctx, in, 1, d_bits, d_flags, s, &d_fargs, &lds_f, &fslot))) return rc;
+  if ((rc = fused_args_slot(ctx, in, spheres ? 2 : 1, d_bits, d_flags, s, &d_fargs, &lds_f, &fslot))) return rc;
   const trk::FkOut vout{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_tips, nullptr, nullptr, nullptr};
   const trk::FkLaunch vl{d_states, n, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                          (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, vout, s};
@@ -505,7 +513,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   {
     ProfScope ps(ctx, 5, s);
     switch (ctx->K.n_tendons) {
-#define TRK_CASE(N) case N: trk::launch_fk_verdict<N>(vl, vr.d_slots + vslot, lds_v); break;
+#define TRK_CASE(N) case N: trk::launch_fk_verdict<N>(vl, vr.d_slots + vslot, lds_v, spheres); break;
       TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
       default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
@@ -568,10 +576,10 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
     if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
     if ((rc = ensure_sphere_near(ctx, s))) return rc;
   }
-  if (ctx->fuse == 2 && voxel_test == 1 && points_unused && !ctx->K.enable_retraction && !out.R && !out.L && !out.tips) {
+  if (ctx->fuse == 2 && voxel_test != 0 && points_unused && !ctx->K.enable_retraction && !out.R && !out.L && !out.tips) {
     // nobody reads this launch's backbone points (edge samples of the checkMotion forms: the bisection compares cell
     // signatures): the verdict-only kernel, which stores none
-    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride);
+    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride, voxel_test == 2);
   }
   if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s, sig, sig_stride))) return rc;
@@ -981,7 +989,7 @@ int tr_reserve(tr_ctx *c, int64_t n) {
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
-  if (c->fuse == 2 && !c->K.enable_retraction && c->checker == TR_CHECKER_BACKBONE) {
+  if (c->fuse == 2 && !c->K.enable_retraction) {
     // the verdict path keeps no points: a list of fallback candidates and the fallback pass's small workspace
     if (c->fb_list_cap < n) {
       HIP_TRY(c, hipDeviceSynchronize());
@@ -1166,13 +1174,13 @@ int validate_batch_dev_impl(tr_ctx *c, const double *d_states, int64_t n, uint64
   hipStream_t s = (hipStream_t)stream;
   const int S = c->K.state_size;
   const bool ret = c->K.enable_retraction;
-  if (c->fuse == 2 && !ret && c->checker == TR_CHECKER_BACKBONE) {
-    // verdict-only kernel: nothing but the verdict (and the tips) leaves the chip, no point workspace to size
+  if (c->fuse == 2 && !ret) {
+    // verdict-only kernel (both checkers): nothing but the verdict (and the tips) leaves the chip, no point workspace to size
     const int64_t chunk = (int64_t)1 << 26;                 // list indices are 32-bit; per-launch grid stays far below 2^31 blocks
     for (int64_t off = 0; off < n; off += chunk) {
       const int64_t m = std::min<int64_t>(chunk, n - off);
       if ((rc = launch_verdict(c, d_states + off * S, m, d_valid_bits + off / 64, d_tips ? d_tips + 3 * off : nullptr,
-                               d_flags ? d_flags + off : nullptr, s))) return rc;
+                               d_flags ? d_flags + off : nullptr, s, nullptr, 0, c->checker == TR_CHECKER_SPHERES))) return rc;
     }
     return TR_OK;
   }
@@ -1239,7 +1247,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
     // synchronisation -- the stream only waits for the last *_dev call that may still use this context's workspace.
     // What remains is the kernel itself: one lane integrates its configuration serially (INTEGRATION.md has the numbers).
     const int S = c->K.state_size;
-    const bool verdict = c->fuse == 2 && !c->K.enable_retraction && c->checker == TR_CHECKER_BACKBONE;
+    const bool verdict = c->fuse == 2 && !c->K.enable_retraction;
     if ((rc = ensure_staging(c, n))) return rc;
     if (!verdict && (rc = ensure_workspace(c, n))) return rc;
     Workspace &w = c->ws;
@@ -1257,7 +1265,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
     return TR_OK;
   }
   if ((rc = ensure_staging(c, std::min(n, 2 * CH)))) return rc;
-  if (!(c->fuse == 2 && !c->K.enable_retraction && c->checker == TR_CHECKER_BACKBONE) && (rc = ensure_workspace(c, std::min(n, CH)))) return rc;
+  if (!(c->fuse == 2 && !c->K.enable_retraction) && (rc = ensure_workspace(c, std::min(n, CH)))) return rc;
   HIP_TRY(c, hipDeviceSynchronize());          // earlier work on other streams (e.g. a *_dev call) is finished
   Workspace &w = c->ws;
   const int S = c->K.state_size;

@@ -20,6 +20,7 @@
 #include "fk_kernel.hpp"
 #define TRK_DEVICE_BODIES_ONLY
 #include "sweep_kernel.hpp"
+#include "sphere_kernel.hpp"
 
 namespace trk {
 
@@ -35,6 +36,11 @@ struct VerdictArgs {
   uint32_t *fb_count;
   uint32_t *sig;                  // optional (edge samples): cell signatures [n][sig_stride], see sweep_kernel.hpp
   int64_t sig_stride;
+  // sphere-swept checker (fk_verdict<.., SPH = true>, sphere_kernel.hpp): distance field of the obstacle cells and the two
+  // thresholds of its classification (radius -+ half a cell diagonal, formed on the host as K8 forms them)
+  const float *field;
+  float r_lo, r_hi;
+  double radius;
 };
 
 constexpr int VQ = 128;           // ring of deferred segments per wave
@@ -60,9 +66,12 @@ __host__ __device__ inline size_t verdict_lds_bytes(int NM) { return (size_t)VL_
 #define VL_BARRIER() asm volatile("" ::: "memory")
 
 // The per-point sweep: what sweep_body's pass 1 does with a stored point, done when the point is produced.
+template <bool SPH>
 struct PointSweep {
   const VerdictArgs *va;
   uint64_t near_prev;             // dilated-grid word of the previous point's block (requested one point ahead)
+  float dn_prev;                  // SPH: distance-field value at the previous point's cell (requested one point ahead)
+  uint32_t sph_state;             // SPH: bit 0 = the previous point awaits its classification, bit 1 = it lies inside the closed domain
   int qhead, qcount;              // wave-uniform
   int P, CH, NM, Kl, ms_next, ms_k;   // wave-uniform: point count, milestone spacing / count, last milestone, next milestone row / index
   uint32_t *sig_row;              // this lane's signature row (edge samples), or null
@@ -85,6 +94,29 @@ struct PointSweep {
     const int lane = threadIdx.x;
     __syncthreads();
     const int cnt = qcount < 64 ? qcount : 64;
+    if constexpr (SPH) {
+      // one queued point after the other, each served by the whole wave (as K8 serves its flagged lanes)
+      const GridK &g = a.g;
+      const double radius = a.radius;
+      for (int e = 0; e < cnt; e++) {
+        const int slot = (qhead + e) & (VQ - 1);
+        const double sx = VL_D(VL_QE + 0 * VQ + slot), sy = VL_D(VL_QE + 1 * VQ + slot), sz = VL_D(VL_QE + 2 * VQ + slot);
+        const int owner = (int)VL_U(VL_QOWNER + slot);
+        bool found = false;
+        {
+          // add_point (VoxelOctree.cpp:319-323): the point's own cell, if the point is inside the closed domain
+          const double cx = fmin(fmax(sx, g.xmin), g.xmax), cy = fmin(fmax(sy, g.ymin), g.ymax), cz = fmin(fmax(sz, g.zmin), g.zmax);
+          if (cx == sx && cy == sy && cz == sz) {
+            const int N = g.N;
+            int ix = (int)((cx - g.xmin) / g.dx), iy = (int)((cy - g.ymin) / g.dy), iz = (int)((cz - g.zmin) / g.dz);
+            ix = ix < 0 ? 0 : (ix > N - 1 ? N - 1 : ix); iy = iy < 0 ? 0 : (iy > N - 1 ? N - 1 : iy); iz = iz < 0 ? 0 : (iz > N - 1 ? N - 1 : iz);
+            found = ((a.grid[((size_t)(ix >> 2) * g.Nb + (iy >> 2)) * g.Nb + (iz >> 2)] >> (((ix & 3) << 4) | ((iy & 3) << 2) | (iz & 3))) & 1ull) != 0;
+          }
+        }
+        if (!found) found = sphere_scan_wave(sx, sy, sz, radius, g, a.grid, lane);
+        if (found && lane == 0) atomicOr(&((uint32_t *)vlds)[VL_HIT + owner], 1u);
+      }
+    } else
     if (lane < cnt) {
       const int slot = (qhead + lane) & (VQ - 1);
       const V3 pa = {VL_D(VL_QE + 0 * VQ + slot), VL_D(VL_QE + 1 * VQ + slot), VL_D(VL_QE + 2 * VQ + slot)};
@@ -101,6 +133,62 @@ struct PointSweep {
     qhead = (qhead + cnt) & (VQ - 1);
     qcount -= cnt;
     __syncthreads();
+  }
+
+  // SPH: ask the distance field about point q (as produced; rotated into the voxel frame here): the cell of its projection
+  // onto the domain (nearest_cell, VoxelOctree.cpp:295-307), as K8 forms it
+  __device__ __forceinline__ void request(const VerdictArgs &a, const V3 &q) {
+#pragma clang fp contract(off)
+    const GridK &g = a.g;
+    V3 r = q;
+    if (!g.rot_is_identity) {
+      r.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
+      r.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
+      r.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
+    }
+    if (!(fabs(r.x) < 1e300) || !(fabs(r.y) < 1e300) || !(fabs(r.z) < 1e300)) return;     // non-finite: the chord length settles it
+    const int N = g.N;
+    const double cx = fmin(fmax(r.x, g.xmin), g.xmax), cy = fmin(fmax(r.y, g.ymin), g.ymax), cz = fmin(fmax(r.z, g.zmin), g.zmax);
+    int ix = (int)((cx - g.xmin) / g.dx), iy = (int)((cy - g.ymin) / g.dy), iz = (int)((cz - g.zmin) / g.dz);
+    ix = ix < 0 ? 0 : (ix > N - 1 ? N - 1 : ix); iy = iy < 0 ? 0 : (iy > N - 1 ? N - 1 : iy); iz = iz < 0 ? 0 : (iz > N - 1 ? N - 1 : iz);
+    dn_prev = a.field[((size_t)ix * N + iy) * N + iz];
+    sph_state = 1u | ((cx == r.x && cy == r.y && cz == r.z) ? 2u : 0u);
+  }
+
+  // SPH: the last point's classification (its field value was requested when it was produced), after the RK4 loop
+  __device__ __forceinline__ void finish() {
+#pragma clang fp contract(off)
+    if constexpr (SPH) {
+      VL_BARRIER();
+      const VerdictArgs &a = args();
+      const GridK &g = a.g;
+      const int lane = threadIdx.x;
+      bool need = false;
+      V3 pr = {VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)};
+      if (active && !VL_U(VL_HIT + lane) && (sph_state & 1u)) {
+        if (!g.rot_is_identity) {
+          const V3 pv = pr;
+          pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
+          pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
+          pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
+        }
+        if (dn_prev > a.r_hi) {}
+        else if ((sph_state & 2u) && dn_prev < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+        else need = true;
+      }
+      sph_state = 0;
+      const unsigned long long wm = __ballot(need);
+      if (wm) {
+        if (qcount + __popcll(wm) > VQ) flush();
+        if (need) {
+          const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
+          VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
+          VL_U(VL_QOWNER + slot) = (uint32_t)lane;
+        }
+        qcount += __popcll(wm);
+      }
+      VL_BARRIER();
+    }
   }
 
   // point j of the lane's backbone (j = 0 .. P-1, in order)
@@ -129,6 +217,24 @@ struct PointSweep {
     if (sig_row) sig_row[j] = cell_signature(x, y, z, g);
     bool need = false;
     V3 pr = pv, qr = q;
+    if constexpr (SPH) {
+      if (active && !VL_U(VL_HIT + lane)) {
+        // the previous point's field value has arrived: far from every occupied centre, certainly within r of one, or
+        // in the shell between -- then the point is queued for the exact scan
+        if (sph_state & 1u) {
+          if (!g.rot_is_identity) {
+            pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
+            pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
+            pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
+          }
+          if (dn_prev > a.r_hi) {}
+          else if ((sph_state & 2u) && dn_prev < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+          else need = true;
+        }
+        sph_state = 0;
+        if (!VL_U(VL_HIT + lane)) request(a, q);
+      }
+    } else
     if (active && !VL_U(VL_HIT + lane)) {
       if (!g.rot_is_identity) {
         qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
@@ -162,7 +268,7 @@ struct PointSweep {
       if (need) {
         const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
         VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
-        VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z;
+        if constexpr (!SPH) { VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z; }
         VL_U(VL_QOWNER + slot) = (uint32_t)lane;
       }
       qcount += __popcll(wm);
@@ -172,13 +278,14 @@ struct PointSweep {
   }
 };
 
-template <int N, bool ROT>
+template <int N, bool ROT, bool SPH>
 __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
     const double *__restrict__ states, int64_t n, RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps,
     int nsteps, double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
   const int lane = threadIdx.x;
-  PointSweep ps;
+  PointSweep<SPH> ps;
   ps.va = va;
+  ps.dn_prev = 0.0f; ps.sph_state = 0u;
   ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
   VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
@@ -194,6 +301,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
   fk_uniform_body<N, ROT, false, false>(states, n, 0, K, tab, steps, nsteps, out, ps, nullptr, &fl_);
 
   // ---- what sweep_body does after its pass 1 (comparisons and one subtraction: nothing here can contract) ----
+  ps.finish();
   while (ps.qcount > 0) ps.flush();
   __syncthreads();
   const VerdictArgs a = *va;
@@ -236,6 +344,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
     else valid = false;                                       // hit, flags not wanted
   }
   if (pending) valid = false;                                 // its bit is ORed in by fk_sweep_fused_list
+  if (SPH && pending && !hit) fl |= 8u;                       // ... which takes the sphere test's answer from this bit (sweep_body, check_voxels == 2)
   const uint64_t bits = __ballot(valid && live);
   if (lane == 0 && live) a.valid_bits[i >> 6] = bits;
   if (a.flags && live) a.flags[i] = (uint8_t)fl;

@@ -54,13 +54,13 @@ KERNELS = {
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
 #include "verdict_kernel.hpp"
-template __global__ void trk::fk_verdict<3, false>(const double*, int64_t, RobotK, const double*, const StepK*, int, double*, const trk::VerdictArgs*);
+template __global__ void trk::fk_verdict<3, false, false>(const double*, int64_t, RobotK, const double*, const StepK*, int, double*, const trk::VerdictArgs*);
 ''',
     "fk_verdict<4,false>": r'''
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
 #include "verdict_kernel.hpp"
-template __global__ void trk::fk_verdict<4, false>(const double*, int64_t, RobotK, const double*, const StepK*, int, double*, const trk::VerdictArgs*);
+template __global__ void trk::fk_verdict<4, false, false>(const double*, int64_t, RobotK, const double*, const StepK*, int, double*, const trk::VerdictArgs*);
 ''',
     "fk_sweep_fused<3,false>": r'''
 #include <hip/hip_runtime.h>

@@ -161,3 +161,68 @@ def test_two_checkers_on_one_robot_keep_their_own_environment(irt, orc, helpers)
     wantA, _, _ = orc.validate_batch(orb, helpers.oracle_grid(orc, voxA), states, nthreads=0, lib=orc.omp_lib())
     wantB, _, _ = orc.validate_batch(orb, helpers.oracle_grid(orc, voxB), states, envB.inv_rotation, nthreads=0, lib=orc.omp_lib())
     assert np.array_equal(before, wantA) and np.array_equal(gotB, wantB) and (wantA != wantB).sum() > 50
+
+
+def _with_env(env, fn):
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_sphere_checker_same_bits_in_every_schedule(irt):
+    """The sphere-swept checker through fk_verdict<.., SPH> (no backbone stored; points classified by the distance field as
+    they are produced, the shell between queued for the exact scan) against K1 + K2 + K8 on stored points -- separate
+    launches and fused -- where the rarer branches are busy: self collisions decided by the fallback pass (which takes the
+    sphere test's answer from the flags), length limits, non-converged solves, a rotated environment, a rotating robot,
+    points outside the voxel domain, a coarse grid, and the debug switches."""
+    W = irt.workloads
+    thin = W.robot_config1()
+    thin.specs.dL = 0.2 / 128
+    thin.r = 0.01
+    for t in thin.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 0.08
+    hard = W.robot_config2()
+    for t in hard.tendons:
+        t.max_tension, t.max_length = 60.0, 0.02
+    spin = W.robot_config2()
+    spin.enable_rotation = True
+    a = 0.4
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    big = _env(irt, 21, 90)
+    small = _env(irt, 33, 50, N=64, lim=0.12, rmin=0.01, rmax=0.03)       # the robot reaches out of it; cells of 3.75 mm
+    cases = [(thin, 100.0, None, big, 6000), (hard, 45.0, None, big, 4000), (spin, 12.0, rot, big, 5000),
+             (W.robot_config3(), 20.0, rot, big, 4000), (W.robot_config2(), 14.0, None, small, 5000)]
+    seen = np.zeros(32, int)
+    for robot, tau_max, inv_rot, vox, n in cases:
+        env = irt.VoxelEnvironment()
+        if inv_rot is not None:
+            env.inv_rotation = inv_rot
+        states = W.random_states(robot, n + 21, seed=19, tau_max=tau_max)
+
+        def run(debug=0, detail=True):
+            chk = irt.VoxelValidityChecker(robot, env, vox)
+            chk.engine.set_debug(debug)
+            return chk.is_valid_detail(states) if detail else dict(valid=chk.is_valid(states))
+
+        want = _with_env({"TENDON_HIP_FUSED": "0"}, run)
+        fused = _with_env({"TENDON_HIP_FUSED": "1"}, run)
+        for k in ("valid", "flags"):
+            assert np.array_equal(fused[k], want[k]), k
+        for debug in (0, 2, 3):
+            got = _with_env({"TENDON_HIP_FB_CAP": "64"}, lambda: run(debug))
+            for k in ("valid", "flags"):
+                assert np.array_equal(got[k], want[k]), (k, debug, np.flatnonzero(got[k] != want[k])[:8], got[k][got[k] != want[k]][:8], want[k][got[k] != want[k]][:8])
+            ok = want["flags"] & 1 > 0
+            assert np.abs(got["tips"][ok] - want["tips"][ok]).max() <= 1e-12
+        assert np.array_equal(run(0, detail=False)["valid"], want["valid"])
+        seen += np.bincount(want["flags"], minlength=32)
+    print("flag histogram", seen)
+    assert seen[15] > 0 and seen[7] > 0 and seen[3] > 0 and seen[1] > 0 and seen[0] > 0
