@@ -491,11 +491,9 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   }
   a.fb_list = ctx->d_fb_list; a.fb_count = ctx->d_fb_count;
   a.sig = sig; a.sig_stride = sig_stride;
-  if (spheres) {                       // the classification thresholds of K8 (sphere_kernel.hpp: spheres_vs_grid), same expressions
-    const GridK &g = ctx->G;
-    const float hd = 0.5f * sqrtf((float)(g.dx * g.dx + g.dy * g.dy + g.dz * g.dz));
+  if (spheres) {                       // classification thresholds (verdict_kernel.hpp: PointSweep<true>)
     a.field = ctx->d_sph_near; a.radius = ctx->K.radius;
-    a.r_lo = (float)ctx->K.radius - hd - 1e-6f; a.r_hi = (float)ctx->K.radius + hd + 1e-6f;
+    a.r_lo = (float)ctx->K.radius - 2e-6f; a.r_hi = (float)ctx->K.radius + 2e-6f;
   }
   HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb_count, 0, sizeof(uint32_t), s));

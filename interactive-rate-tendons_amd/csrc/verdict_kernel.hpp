@@ -37,7 +37,8 @@ struct VerdictArgs {
   uint32_t *sig;                  // optional (edge samples): cell signatures [n][sig_stride], see sweep_kernel.hpp
   int64_t sig_stride;
   // sphere-swept checker (fk_verdict<.., SPH = true>, sphere_kernel.hpp): distance field of the obstacle cells and the two
-  // thresholds of its classification (radius -+ half a cell diagonal, formed on the host as K8 forms them)
+  // thresholds of its classification: radius -+ 2e-6 m of slack for the float arithmetic; the distance of the point from
+  // its cell's centre, which K8 bounds by half a cell diagonal, is taken per point here (a thinner undecided shell)
   const float *field;
   float r_lo, r_hi;
   double radius;
@@ -49,12 +50,12 @@ constexpr int VQ = 128;           // ring of deferred segments per wave
 // keeps the accesses in the LDS address space -- ds_read / ds_write -- instead of falling back to flat accesses).
 //   doubles [0, 192)           prev[3][64]     previous point (as produced, before the environment rotation)
 //   doubles [192, 192 + 6 VQ)  qe[6][VQ]       deferred segments: rotated end points a, b
-//   words from 2 * (192 + 6 VQ):  qowner[VQ] | cell[3][64] | inprev[64] | hitflag[64] | dist[64] | milestones float[4][NM][64]
+//   words from 2 * (192 + 6 VQ):  qowner[VQ] | cell[3][64] | inprev[64] | hitflag[64] | dist[64] | delta[64] (SPH) | milestones float[4][NM][64]
 extern __shared__ double vlds[];
 constexpr int VL_QE = 3 * 64;
 constexpr int VL_W0 = 2 * (VL_QE + 6 * VQ);
 constexpr int VL_QOWNER = VL_W0, VL_CELL = VL_QOWNER + VQ, VL_INPREV = VL_CELL + 3 * 64, VL_HIT = VL_INPREV + 64,
-              VL_DIST = VL_HIT + 64, VL_MS = VL_DIST + 64;
+              VL_DIST = VL_HIT + 64, VL_DELTA = VL_DIST + 64, VL_MS = VL_DELTA + 64;
 __host__ __device__ inline size_t verdict_lds_bytes(int NM) { return (size_t)VL_MS * 4 + (size_t)4 * NM * 64 * sizeof(float); }
 
 // (plain accesses: hipcc does not move `volatile` ones into the LDS address space; the compiler barriers at both ends of
@@ -153,6 +154,11 @@ struct PointSweep {
     ix = ix < 0 ? 0 : (ix > N - 1 ? N - 1 : ix); iy = iy < 0 ? 0 : (iy > N - 1 ? N - 1 : iy); iz = iz < 0 ? 0 : (iz > N - 1 ? N - 1 : iz);
     dn_prev = a.field[((size_t)ix * N + iy) * N + iz];
     sph_state = 1u | ((cx == r.x && cy == r.y && cz == r.z) ? 2u : 0u);
+    // how far the looked-up position (the point, or its projection onto the domain) is from the centre of its cell: an
+    // occupied centre is at least field - delta and -- the nearest one -- at most field + delta away from it
+    const float ex = (float)(cx - (g.xmin + g.dx * ((double)ix + 0.5))), ey = (float)(cy - (g.ymin + g.dy * ((double)iy + 0.5))),
+                ez = (float)(cz - (g.zmin + g.dz * ((double)iz + 0.5)));
+    VL_F(VL_DELTA + threadIdx.x) = sqrtf(ex * ex + ey * ey + ez * ez) * 1.000001f;
   }
 
   // SPH: the last point's classification (its field value was requested when it was produced), after the RK4 loop
@@ -172,8 +178,9 @@ struct PointSweep {
           pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
           pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
         }
-        if (dn_prev > a.r_hi) {}
-        else if ((sph_state & 2u) && dn_prev < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+        const float dl = VL_F(VL_DELTA + lane);
+        if (dn_prev - dl > a.r_hi) {}
+        else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(VL_HIT + lane) = 1u;
         else need = true;
       }
       sph_state = 0;
@@ -227,8 +234,9 @@ struct PointSweep {
             pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
             pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
           }
-          if (dn_prev > a.r_hi) {}
-          else if ((sph_state & 2u) && dn_prev < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+          const float dl = VL_F(VL_DELTA + lane);
+          if (dn_prev - dl > a.r_hi) {}
+          else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(VL_HIT + lane) = 1u;
           else need = true;
         }
         sph_state = 0;
