@@ -185,6 +185,13 @@ def main(argv=None):
     t0 = time.perf_counter()                                    # the same roadmap with the lists never leaving the device
     vd_all, ed_all = rb.vertex_caches(states, device=True), rb.edge_caches(states, e_ok, device=True)
     t_build_dev = time.perf_counter() - t0
+    # createRoadmap's edge phase in ONE traversal of the samples: checkMotion on all candidate edges + voxel sets of the accepted
+    rb.connect(states, edges[:4096], device=True)
+    e_conn, ed_conn = rb.connect(states, edges, device=True)
+    t_connect = rb.timing["connect"]["seconds"]
+    import torch
+    assert np.array_equal(e_conn, e_ok) and np.array_equal(ed_conn["offsets"], ed_all["offsets"]) and torch.equal(ed_conn["block_ids"], ed_all["block_ids"])
+    del e_conn, ed_conn
     prm_h, prm = prm, irt.VoxelCachedLazyPRM(chk, states, e_ok)   # the queries below run on the device-attached caches
     t0 = time.perf_counter()
     prm.set_caches(vd_all, ed_all)
@@ -224,7 +231,8 @@ def main(argv=None):
     assert np.array_equal(lazy["path_vertices"], plain["path_vertices"])
     plen = np.diff(lazy["path_offsets"])[lazy["status"] == 0]
     q5 = {"n": nq, "roadmap_vertices": len(states), "roadmap_edges": int(len(e_ok)), "cache_blocks": int(vc_all["offsets"][-1] + ec_all["offsets"][-1]),
-          "cache_upload_s": t_upload, "caches_built_on_device_s": t_build_dev, "caches_attached_from_device_s": t_attach_dev,
+          "cache_upload_s": t_upload, "caches_built_on_device_s": t_build_dev,
+          "connect_all_edges_s": t_connect, "edges_connected_per_s": len(edges) / t_connect, "caches_attached_from_device_s": t_attach_dev,
           "landmark_tables_s": t_prepare,
           "lazy_reference_heuristic_only": {"queries_per_s": nq / t_plain, "seconds": t_plain, **st_plain},
           "lazy": {"queries_per_s": nq / t_lazy, "seconds": t_lazy, **st_lazy, "k4_launches": k4l["launches"], "k4_ms_total": k4l["total_ms"]},

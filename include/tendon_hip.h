@@ -291,6 +291,13 @@ int tr_voxelize_edges_indexed(tr_ctx *ctx, const tr_space_params *sp, const doub
                               const int32_t *edges, int64_t n_edges, int64_t *offsets, uint64_t *fully_valid_bits,
                               int32_t *n_fk);
 
+/* connectVertices and voxelizeEdge in one pass (createRoadmap adds an edge when checkMotion accepts it, :1491-1502, and
+ * voxelises it, :1751-1775 -- two traversals of the same samples): the samples are tested against the obstacle grid as
+ * tr_validate_edges_indexed tests them AND voxelised as tr_voxelize_edges_indexed voxelises them.  valid_bits are
+ * checkMotion's verdicts; a valid edge owns the voxel set tr_voxelize_edges_indexed gives it, an invalid one nothing. */
+int tr_connect_edges_indexed(tr_ctx *ctx, const tr_space_params *sp, const double *states, int64_t n_states,
+                             const int32_t *edges, int64_t n_edges, int64_t *offsets, uint64_t *valid_bits, int32_t *n_fk);
+
 /* The block lists of the last tr_voxelize_* call stay in device memory (they are produced there, and their consumers --
  * tr_check_cached_dev, tr_roadmap_set_caches_dev -- read them there); capacity must be >= its offsets[n] = tr_voxelize_count.
  * tr_voxelize_fetch copies them to host arrays; tr_voxelize_fetch_dev copies them device to device into arrays the caller

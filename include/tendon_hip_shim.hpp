@@ -411,14 +411,18 @@ class VoxelBackboneMotionValidator {
   }
   /// The same for roadmap edges given as index pairs into one vertex array (VoxelCachedLazyPRM.cpp:1751-1775): every
   /// vertex is integrated and voxelised once for all of its edges.
-  VoxelCaches voxelizeIndexed(const std::vector<double> &states, size_t n_states, const std::vector<int32_t> &edges) const {
+  /// `validate`: also checkMotion on the same samples (tr_connect_edges_indexed): `usable` is then checkMotion's verdict and
+  /// only accepted edges own a voxel set -- createRoadmap's connectVertices + voxelizeEdge in one traversal.
+  VoxelCaches voxelizeIndexed(const std::vector<double> &states, size_t n_states, const std::vector<int32_t> &edges,
+                              bool validate = false) const {
     if (states.size() != n_states * vc_.robot().state_size()) throw std::invalid_argument("State is not the right size");
     const size_t n = edges.size() / 2;
     VoxelCaches out;
     out.offsets.assign(n + 1, 0);
     std::vector<uint64_t> bits((n + 63) / 64);
-    check(vc_.context(), tr_voxelize_edges_indexed(vc_.context(), &space, states.data(), (int64_t)n_states, edges.data(), (int64_t)n,
-                                                   out.offsets.data(), bits.data(), nullptr));
+    check(vc_.context(), (validate ? tr_connect_edges_indexed : tr_voxelize_edges_indexed)(
+                             vc_.context(), &space, states.data(), (int64_t)n_states, edges.data(), (int64_t)n,
+                             out.offsets.data(), bits.data(), nullptr));
     out.usable = detail::unpack(bits, n);
     detail::fetch(vc_.context(), out);
     return out;

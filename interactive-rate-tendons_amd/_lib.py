@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "tr_validate_edges_discrete",
     "tr_check_cached", "tr_check_cached_dev", "tr_check_cached_subset_dev", "tr_state_layout", "tr_space_weights", "tr_kstar_k",
     "tr_roadmap_create", "tr_roadmap_destroy", "tr_roadmap_last_error", "tr_roadmap_set_caches", "tr_roadmap_set_caches_dev", "tr_roadmap_prepare", "tr_roadmap_clear_validity",
-    "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_edges_indexed", "tr_voxelize_fetch", "tr_voxelize_fetch_dev", "tr_voxelize_count", "tr_knn", "tr_knn_edges", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
+    "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_edges_indexed", "tr_connect_edges_indexed", "tr_voxelize_fetch", "tr_voxelize_fetch_dev", "tr_voxelize_count", "tr_knn", "tr_knn_edges", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug",
 )
 
@@ -244,6 +244,7 @@ def lib():
     L.tr_voxelize_batch.argtypes = [vp, dp, i64, P(i64), P(C.c_uint64), dp]
     L.tr_voxelize_edges.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(i64), P(C.c_uint64), P(C.c_int32)]
     L.tr_voxelize_edges_indexed.argtypes = [vp, P(TrSpaceParams), dp, i64, P(C.c_int32), i64, P(i64), P(C.c_uint64), P(C.c_int32)]
+    L.tr_connect_edges_indexed.argtypes = L.tr_voxelize_edges_indexed.argtypes
     L.tr_voxelize_fetch.argtypes = [vp, P(C.c_uint32), P(C.c_uint64), i64]
     L.tr_voxelize_fetch_dev.argtypes = [vp, vp, vp, i64, vp]
     L.tr_voxelize_count.argtypes = [vp]

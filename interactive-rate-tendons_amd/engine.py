@@ -316,8 +316,10 @@ class Engine:
         return dict(offsets=offsets, block_ids=ids, masks=masks, fully_valid=unpack_bits(bits, n), n_fk=nfk)
 
     def voxelize_edges_indexed(self, states, edges, min_tension_change=0.02, min_rotation_change=0.01, min_retraction_change=0.0001,
-                               device=False):
-        """voxelizeEdge for roadmap edges given as index pairs: every vertex integrated and voxelised once."""
+                               device=False, validate=False):
+        """voxelizeEdge for roadmap edges given as index pairs: every vertex integrated and voxelised once.  validate=True is
+        tr_connect_edges_indexed: the same samples are also tested against the obstacles (checkMotion), 'fully_valid' is then
+        checkMotion's verdict and only valid edges own a voxel set."""
         st = self._states(states)
         e = np.ascontiguousarray(np.asarray(edges).reshape(-1, 2), dtype=np.int32)
         n = e.shape[0]
@@ -325,7 +327,8 @@ class Engine:
         offsets = np.zeros(n + 1, dtype=np.int64)
         bits = np.zeros((n + 63) // 64, dtype=np.uint64)
         nfk = np.zeros(n, dtype=np.int32)
-        L.check(self._ctx, self.lib.tr_voxelize_edges_indexed(
+        fn = self.lib.tr_connect_edges_indexed if validate else self.lib.tr_voxelize_edges_indexed
+        L.check(self._ctx, fn(
             self._ctx, C.byref(sp), _dp(st), st.shape[0], e.ctypes.data_as(C.POINTER(C.c_int32)), n,
             offsets.ctypes.data_as(C.POINTER(C.c_int64)), bits.ctypes.data_as(C.POINTER(C.c_uint64)),
             nfk.ctypes.data_as(C.POINTER(C.c_int32))))

@@ -101,6 +101,21 @@ class RoadmapBuilder:
         self.timing["vertex_caches"] = dict(seconds=time.perf_counter() - t0, items=len(states), blocks=int(out["offsets"][-1]))
         return out
 
+    def connect(self, states, edges, device=False):
+        """createRoadmap's edge phase in one pass (tr_connect_edges_indexed): checkMotion on every candidate edge and the voxel
+        sets of the accepted ones -> (accepted edges, their caches as CSR over the accepted edges only)."""
+        t0 = time.perf_counter()
+        out = self.engine.voxelize_edges_indexed(states, edges, self.mv.min_tension_change, self.mv.min_rotation_change,
+                                                 self.mv.min_retraction_change, device=device, validate=True)
+        ok = out["fully_valid"]
+        off = out["offsets"]
+        out["offsets"] = np.concatenate([off[:-1][ok], off[-1:]])      # rejected edges own nothing: dropping them leaves the lists as they are
+        out["n_fk"] = out["n_fk"][ok]
+        out["fully_valid"] = np.ones(int(ok.sum()), dtype=bool)
+        e = np.asarray(edges).reshape(-1, 2)
+        self.timing["connect"] = dict(seconds=time.perf_counter() - t0, items=len(e), accepted=int(ok.sum()), blocks=int(off[-1]))
+        return e[ok], out
+
     def edge_caches(self, states, edges, device=False):
         t0 = time.perf_counter()
         out = self.engine.voxelize_edges_indexed(states, edges, self.mv.min_tension_change,

@@ -198,3 +198,39 @@ def test_vertex_sets_are_duplicate_free_and_ordered(irt):
     for i in np.flatnonzero(out["shape_valid"])[:800]:
         ids = out["block_ids"][off[i]:off[i + 1]]
         assert (np.diff(ids.astype(np.int64)) > 0).all() and (out["masks"][off[i]:off[i + 1]] != 0).all()
+
+
+def test_connect_is_check_motion_and_voxelize_edge_in_one_pass(irt):
+    """tr_connect_edges_indexed: verdicts and FK counts of tr_validate_edges_indexed, voxel sets of
+    tr_voxelize_edges_indexed for exactly the accepted edges -- also with a pool so small that chunks are retried and with
+    more vertices than the pool holds (host-gather fallback to the pairwise form)."""
+    import os
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=110)
+    states = W.random_states(robot, 1200, seed=61, tau_max=20.0)
+    near = np.argsort(np.linalg.norm(states[:, None, :] - states[None, :, :], axis=2), axis=1)[:, 1:6]
+    edges = np.stack([np.repeat(np.arange(len(states)), 5), near.reshape(-1)], 1).astype(np.int32)
+
+    def run():
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        mv = irt.VoxelBackboneMotionValidator(chk)
+        rb = irt.RoadmapBuilder(chk, mv, seed=1)
+        return mv.check_motion_indexed(states, edges), chk.engine.voxelize_edges_indexed(states, edges), rb.connect(states, edges)
+
+    for env in ({}, {"TENDON_HIP_EDGE_POOL": "4096"}, {"TENDON_HIP_EDGE_POOL": "1024"}):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
+        try:
+            val, cache, (e_ok, got) = run()
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+        ok = val["valid"]
+        assert 0.2 < ok.mean() < 0.98                             # both outcomes are well represented
+        assert np.array_equal(e_ok, edges[ok]) and np.array_equal(got["n_fk"], val["n_fk"][ok])
+        assert (cache["fully_valid"] | ~ok).all()                 # an edge checkMotion accepts has a valid shape all along
+        off = cache["offsets"]
+        idx = np.concatenate([np.arange(off[e], off[e + 1]) for e in np.flatnonzero(ok)]) if ok.any() else np.zeros(0, int)
+        assert np.array_equal(got["block_ids"], cache["block_ids"][idx]) and np.array_equal(got["masks"], cache["masks"][idx])
+        assert np.array_equal(np.diff(got["offsets"]), np.diff(off)[ok]) and got["offsets"][-1] == len(got["block_ids"])
