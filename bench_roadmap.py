@@ -187,8 +187,10 @@ def main(argv=None):
     t_build_dev = time.perf_counter() - t0
     # createRoadmap's edge phase in ONE traversal of the samples: checkMotion on all candidate edges + voxel sets of the accepted
     rb.connect(states, edges[:4096], device=True)
-    e_conn, ed_conn = rb.connect(states, edges, device=True)
-    t_connect = rb.timing["connect"]["seconds"]
+    t_connect = float("inf")
+    for _ in range(2):
+        e_conn, ed_conn = rb.connect(states, edges, device=True)
+        t_connect = min(t_connect, rb.timing["connect"]["seconds"])
     import torch
     assert np.array_equal(e_conn, e_ok) and np.array_equal(ed_conn["offsets"], ed_all["offsets"]) and torch.equal(ed_conn["block_ids"], ed_all["block_ids"])
     del e_conn, ed_conn
