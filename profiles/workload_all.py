@@ -149,7 +149,20 @@ def main():
     for _ in range(reps):
         sc.engine.validate_batch_dev(st, n, bits)
     torch.cuda.synchronize()
+    # since round 2 the sphere-swept checker runs through the verdict-only kernel too (one distance-field gather per point,
+    # 4 B, from a 64 MiB field that lives in the Infinity Cache: not counted as algorithmic HBM bytes)
+    add("fk_verdict<3> spheres", bytes=reps * n * (8 * 3 + 24 + 0.125), flops=reps * n * isa["rk4_step<3>"]["flops_per_step"] * 128,
+        units=reps * n, unit="checks")
+    # K8 on stored points, as retraction robots still use it
+    sc0 = with_env({"TENDON_HIP_FUSED": "1"}, lambda: irt.VoxelValidityChecker(r2, irt.VoxelEnvironment(), raw))
+    sc0.engine.reserve(n)
+    for _ in range(reps):
+        sc0.engine.validate_batch_dev(st, n, bits)
+    torch.cuda.synchronize()
     add("spheres_vs_grid", bytes=reps * n * (24.0 * 129 + 4 * 129), units=reps * n, unit="shapes")
+    add("fk_sweep_fused<3>", bytes=reps * n * (2 * 24.0 * 129 + 8 * 3 + 8 * 4 + 1.125), flops=reps * n * isa["rk4_step<3>"]["flops_per_step"] * 128,
+        units=reps * n, unit="checks")
+    del sc0
     extra = np.column_stack([rng.uniform(-0.15, 0.15, (8, 3)), np.full(8, 0.02)])
     caps = np.column_stack([rng.uniform(-0.15, 0.15, (8, 3)), rng.uniform(-0.15, 0.15, (8, 3)), np.full(8, 0.01)])
     for _ in range(3):
