@@ -101,8 +101,12 @@ int main(int argc, char **argv) {
     auto rvc = motion_planning::voxelize_states(vc3, flat, states.size());
     auto rec = mv3.voxelizeIndexed(flat, states.size(), redges);
     for (size_t i = 0; i < rec.items(); i++) std::printf("iecache %d %lld\n", (int)rec.usable[i], (long long)(rec.offsets[i + 1] - rec.offsets[i]));
+    // connectVertices + voxelizeEdge in one traversal: checkMotion's verdicts, sets for the accepted edges only
+    auto con = mv3.voxelizeIndexed(flat, states.size(), redges, /*validate=*/true);
+    for (size_t i = 0; i < con.items(); i++) std::printf("connect %d %lld\n", (int)con.usable[i], (long long)(con.offsets[i + 1] - con.offsets[i]));
     motion_planning::VoxelCachedLazyPRM prm(vc3, flat, states.size(), redges);
     prm.setCaches(rvc, rec);
+    prm.prepare(2);                                       // landmark bounds: the answers below do not depend on them
     auto sol = prm.solveWithRoadmap({0, 0, 2}, {2, 0, 3});
     for (size_t q = 0; q < sol.status.size(); q++) {
       std::printf("query %d %.17g", sol.status[q], sol.cost[q]);

@@ -102,6 +102,11 @@ def test_shim_results_match_oracle(tmp_path, irt, orc, helpers):
         w = orc.check_motion(orb, og, S4[a_], S4[b_], want_swept=True)
         assert int(row[1]) == int(w["is_fully_valid"]) and (not w["is_fully_valid"] or int(row[2]) == w["swept"].nblocks())
         ecs.append(w["swept"].export_blocks() if w["is_fully_valid"] else (np.zeros(0, np.uint32), np.zeros(0, np.uint64)))
+    con = [l.split() for l in out if l.startswith("connect")]
+    assert len(con) == 5
+    for (a_, b_), row, irow in zip(redges, con, iec):
+        ok = orc.check_motion(orb, og, S4[a_], S4[b_])["valid"]
+        assert int(row[1]) == int(ok) and int(row[2]) == (int(irow[2]) if ok else 0)
     ref = orc.Grid(256, vox.limits())
     shape_ok = []
     for s in states:
