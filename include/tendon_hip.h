@@ -393,6 +393,15 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
 int tr_knn_edges(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_distance, int32_t *edges,
                  int64_t capacity, int64_t *n_edges);
 
+/* The same neighbour lists for a RANGE of the states as queries (all n states remain the candidates): rows
+ * first_query .. first_query + n_queries - 1 of tr_knn's tables, whatever the range -- one rank's share when the connection
+ * loop of a large roadmap is spread over several GPUs.  idx / dist: n_queries x k. */
+int tr_knn_range(tr_ctx *ctx, const double *states, int64_t n, int64_t first_query, int64_t n_queries, int32_t k,
+                 double max_distance, int32_t *idx, double *dist);
+/* The undirected edge set of a k-nearest table given by the caller (n x k indices, -1 = none; e.g. the ranks' tr_knn_range
+ * rows gathered): what tr_knn_edges builds from its own table, with the same order and capacity rule. */
+int tr_knn_table_edges(tr_ctx *ctx, const int32_t *idx, int64_t n, int32_t k, int32_t *edges, int64_t capacity, int64_t *n_edges);
+
 /* k of the PRM* connection strategy for a roadmap of n_milestones vertices (og::KStarStrategy as installed by
  * setStarConnectionStrategy, motion-planning/VoxelCachedLazyPRM.cpp:1346-1356): ceil((e + e / dim) * ln(n)), dim =
  * state dimension.  createRoadmap connects after all vertices are in place, so this k applies to every vertex of the

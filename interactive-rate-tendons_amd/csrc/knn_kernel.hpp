@@ -35,7 +35,8 @@ constexpr int KNN_SMAX = TRK_MAX_TENDONS + 2;
 // NT tension dimensions and the presence of the rotation / retraction coordinates are compile-time: a chunk is then
 // straight-line code and its scalar loads are issued back to back.
 template <int NT, bool ROT, bool RET>
-__global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ states, int64_t n, KnnMetric m, int k,
+__global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ states, const double *__restrict__ queries, int64_t n,
+                                                     KnnMetric m, int k,
                                                      double max_dist, int64_t slice, int64_t n_cand, const double *__restrict__ seed,
                                                      double *__restrict__ seed_out, int32_t *__restrict__ out_idx,
                                                      double *__restrict__ out_dist) {
@@ -49,7 +50,7 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
   const int S = m.S;
   double x[KNN_SMAX];
 #pragma unroll
-  for (int d = 0; d < KNN_SMAX; d++) x[d] = d < S ? states[qc * S + d] : 0.0;
+  for (int d = 0; d < KNN_SMAX; d++) x[d] = d < S ? queries[qc * S + d] : 0.0;     // the n queries: all of the states, or a range of them
   for (int p = 0; p < k; p++) { bd[p * 64] = 1.0 / 0.0; bi[p * 64] = -1; }
   // `worst`: a candidate must be strictly closer than this to enter the list -- the lane's current k-th entry, or, while
   // the list is not full, the SEED: the k-th smallest distance of the query to a sample of the candidates (a first,

@@ -1521,13 +1521,47 @@ int64_t tr_voxelize_count(const tr_ctx *c) { return c ? c->vstore.n : -1; }
 }  // extern "C"
 namespace {
 int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist,
-             int32_t *edges, int64_t edge_capacity, int64_t *n_edges);
+             int32_t *edges, int64_t edge_capacity, int64_t *n_edges, int64_t q0 = 0, int64_t nq = -1);
 }
 extern "C" {
 int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist) {
   if (!c) return TR_ERR_INVALID_ARG;
   if (n > 0 && (!idx || !dist)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   return knn_impl(c, states, n, k, max_distance, idx, dist, nullptr, 0, nullptr);
+}
+
+int tr_knn_range(tr_ctx *c, const double *states, int64_t n, int64_t first_query, int64_t n_queries, int32_t k, double max_distance,
+                 int32_t *idx, double *dist) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (first_query < 0 || n_queries < 0 || first_query + n_queries > n) return fail(c, TR_ERR_OUT_OF_RANGE, "query range outside the states");
+  if (n_queries > 0 && (!idx || !dist)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  if (n_queries == 0) return TR_OK;
+  return knn_impl(c, states, n, k, max_distance, idx, dist, nullptr, 0, nullptr, first_query, n_queries);
+}
+
+int tr_knn_table_edges(tr_ctx *c, const int32_t *idx, int64_t n, int32_t k, int32_t *edges, int64_t capacity, int64_t *n_edges) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);
+  if (!n_edges || n < 0 || k < 1 || capacity < 0 || (capacity > 0 && !edges) || (n > 0 && !idx)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  *n_edges = 0;
+  if (n == 0) return TR_OK;
+  if (n > (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
+  for (int64_t i = 0; i < n * k; i++)
+    if (idx[i] < -1 || idx[i] >= n) return fail(c, TR_ERR_OUT_OF_RANGE, "neighbour index outside the table");
+  HIP_TRY(c, hipSetDevice(c->device));
+  int32_t *d_i = nullptr, *d_e = nullptr;
+  const int64_t cap_e = std::min<int64_t>(capacity, n * (int64_t)k);
+  hipError_t e = hipMalloc((void **)&d_i, (size_t)n * k * sizeof(int32_t));
+  if (e == hipSuccess && cap_e > 0) e = hipMalloc((void **)&d_e, (size_t)cap_e * 2 * sizeof(int32_t));
+  if (e == hipSuccess) e = hipMemcpy(d_i, idx, (size_t)n * k * sizeof(int32_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = trk::knn_edge_list(c->merge, d_i, n, (int)k, d_e, cap_e, n_edges, nullptr);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  const int64_t m = std::min<int64_t>(*n_edges, cap_e);
+  if (e == hipSuccess && m > 0) e = hipMemcpy(edges, d_e, (size_t)m * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+  if (d_i) (void)hipFree(d_i);
+  if (d_e) (void)hipFree(d_e);
+  if (e != hipSuccess) return fail(c, TR_ERR_HIP, std::string("knn edge list: ") + hipGetErrorString(e));
+  return TR_OK;
 }
 
 int tr_knn_edges(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *edges, int64_t capacity,
@@ -1539,11 +1573,13 @@ int tr_knn_edges(tr_ctx *c, const double *states, int64_t n, int32_t k, double m
 }
 }  // extern "C"
 namespace {
+// queries [q0, q0 + nq) of the n states (nq < 0: all of them) against all n states as candidates
 int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist,
-             int32_t *edges, int64_t edge_capacity, int64_t *n_edges) {
+             int32_t *edges, int64_t edge_capacity, int64_t *n_edges, int64_t q0, int64_t nq) {
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || k < 1 || (n > 0 && !states)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
+  if (nq < 0) { q0 = 0; nq = n; }
   if ((size_t)k * 64 * 12 > 60 * 1024) return fail(c, TR_ERR_INVALID_ARG, "k too large (at most 80)");
   if (n > (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
   HIP_TRY(c, hipSetDevice(c->device));
@@ -1553,7 +1589,7 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   const double ext = std::sqrt(ext2);                         // RealVectorStateSpace::getMaximumExtent
   trk::KnnMetric m{N, c->K.enable_rotation, c->K.enable_retraction, S, ext / (4.0 * M_PI), 2.0 * ext / c->K.L};
   // candidate slices: enough waves to keep ~8 on every SIMD (see knn_kernel.hpp); at most 32 slices of at least 256 candidates
-  const int64_t qblocks = (n + 63) / 64;
+  const int64_t qblocks = (nq + 63) / 64;
   int nslice = (int)std::min<int64_t>(32, std::max<int64_t>(1, (8 * 1024 + qblocks - 1) / qblocks));
   nslice = (int)std::min<int64_t>(nslice, std::max<int64_t>(1, n / 256));
   const int64_t slice = (n + nslice - 1) / nslice;
@@ -1563,12 +1599,12 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   const int64_t n_sample = (nslice > 1 && n >= 8192) ? std::min<int64_t>(16384, std::max<int64_t>(2048, n / 16)) : 0;
   int rc = TR_OK;
   do {
-    if (n_sample && hipMalloc((void **)&d_seed, (size_t)n * sizeof(double)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    if (n_sample && hipMalloc((void **)&d_seed, (size_t)nq * sizeof(double)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
     if (hipMalloc((void **)&d_s, (size_t)n * S * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_d, (size_t)n * k * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_i, (size_t)n * k * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
-    if (nslice > 1 && (hipMalloc((void **)&d_pd, (size_t)n * nslice * k * sizeof(double)) != hipSuccess ||
-                       hipMalloc((void **)&d_pi, (size_t)n * nslice * k * sizeof(int32_t)) != hipSuccess)) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+        hipMalloc((void **)&d_d, (size_t)nq * k * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_i, (size_t)nq * k * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    if (nslice > 1 && (hipMalloc((void **)&d_pd, (size_t)nq * nslice * k * sizeof(double)) != hipSuccess ||
+                       hipMalloc((void **)&d_pi, (size_t)nq * nslice * k * sizeof(int32_t)) != hipSuccess)) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
     if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
@@ -1577,10 +1613,11 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       int32_t *oi = nslice > 1 ? d_pi : d_i;
       double *od = nslice > 1 ? d_pd : d_d;
       const int variant = (c->K.enable_rotation ? 1 : 0) | (c->K.enable_retraction ? 2 : 0);
+      const double *d_q = d_s + (size_t)q0 * S;
 #define TRK_KNN(NT, R, T) do { \
-        if (n_sample) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), dim3((unsigned)qblocks, 1), dim3(64), lds, nullptr, d_s, n, m, (int)k, \
+        if (n_sample) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), dim3((unsigned)qblocks, 1), dim3(64), lds, nullptr, d_s, d_q, nq, m, (int)k, \
                                          max_distance, n_sample, n_sample, (const double *)nullptr, d_seed, (int32_t *)nullptr, (double *)nullptr); \
-        hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), grid, dim3(64), lds, nullptr, d_s, n, m, (int)k, max_distance, slice, n, \
+        hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), grid, dim3(64), lds, nullptr, d_s, d_q, nq, m, (int)k, max_distance, slice, n, \
                            (const double *)d_seed, (double *)nullptr, oi, od); } while (0)
       switch (N) {
 #define TRK_CASE(NT) case NT: if (variant == 0) TRK_KNN(NT, false, false); else if (variant == 1) TRK_KNN(NT, true, false); \
@@ -1591,11 +1628,11 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
         default: break;
       }
       if (nslice > 1)
-        hipLaunchKernelGGL(trk::knn_merge, dim3((unsigned)qblocks), dim3(64), (size_t)nslice * 64, nullptr, d_pi, d_pd, n, nslice, (int)k, max_distance, d_i, d_d);
+        hipLaunchKernelGGL(trk::knn_merge, dim3((unsigned)qblocks), dim3(64), (size_t)nslice * 64, nullptr, d_pi, d_pd, nq, nslice, (int)k, max_distance, d_i, d_d);
     }
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, TR_ERR_HIP, "knn launch failed"); break; }
-    if (idx && hipMemcpy(idx, d_i, (size_t)n * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
-    if (dist && hipMemcpy(dist, d_d, (size_t)n * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+    if (idx && hipMemcpy(idx, d_i, (size_t)nq * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+    if (dist && hipMemcpy(dist, d_d, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
     if (n_edges) {
       // the undirected edge set of the table, deduplicated and ordered on the device (cache_merge.hip); the slice lists are
       // done with, so the edge pairs are unpacked into that buffer (capacity n k pairs at most)

@@ -129,6 +129,36 @@ class ShardedEdgeValidator:
         return allgather_mask(local).cpu().numpy().view(np.uint64)
 
 
+class ShardedNeighbours:
+    """The step between the two: the connection loop (connectionStrategy_(v) for every vertex, :1491-1502) spread over the
+    ranks.  Every rank holds all vertex states (they follow from the gathered mask), computes the k-nearest rows of its
+    contiguous shard of the vertices against ALL vertices and the rows are all-gathered (int32, equal-sized shards,
+    padding rows = -1); the table is then the same on every rank and each derives the same edge list from it.
+
+    knn_local(first, count) -> (count, k) int32 neighbour indices; in production Engine.knn(states, k,
+    query_range=(first, count)) on the rank's GPU, a brute-force numpy table in the CPU tests.
+    """
+
+    def __init__(self, knn_local, k, device="cpu"):
+        self.knn_local, self.k, self.device = knn_local, int(k), device
+
+    def run(self, n, rank=None, world_size=None):
+        import torch
+        import torch.distributed as dist
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_initialized() else 1
+        start, stop, shard = shard_bounds(n, world_size, rank)
+        n_real = max(0, min(stop, n) - start)
+        rows = np.full((shard, self.k), -1, dtype=np.int32)
+        if n_real > 0:
+            rows[:n_real] = np.asarray(self.knn_local(start, n_real), dtype=np.int32).reshape(n_real, self.k)
+        local = torch.from_numpy(rows.reshape(-1)).to(self.device)
+        full = allgather_mask(local).cpu().numpy().reshape(-1, self.k)
+        return full[:n]
+
+
 def pack_bits(mask):
     """bool[n] -> uint64 words, bit i & 63 of word i >> 6 (the layout of every verdict mask here)."""
     mask = np.asarray(mask, dtype=bool)

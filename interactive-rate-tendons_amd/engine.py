@@ -240,15 +240,34 @@ class Engine:
             off.ctypes.data_as(C.POINTER(C.c_int64)), n, bits.ctypes.data_as(C.POINTER(C.c_uint64))))
         return unpack_bits(bits, n)
 
-    def knn(self, states, k, max_distance=np.inf):
-        """k nearest (self included, as OMPL's nearestK on a populated structure) in the state-space metric."""
+    def knn(self, states, k, max_distance=np.inf, query_range=None):
+        """k nearest (self included, as OMPL's nearestK on a populated structure) in the state-space metric.
+        query_range = (first, count): only those rows of the table (all states stay candidates) -- one rank's share."""
         st = self._states(states)
         n = st.shape[0]
-        idx = np.empty((n, k), dtype=np.int32)
-        dist = np.empty((n, k))
-        L.check(self._ctx, self.lib.tr_knn(self._ctx, _dp(st), n, int(k), float(max_distance),
-                                           idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dist)))
+        q0, nq = (0, n) if query_range is None else (int(query_range[0]), int(query_range[1]))
+        idx = np.empty((nq, k), dtype=np.int32)
+        dist = np.empty((nq, k))
+        if query_range is None:
+            L.check(self._ctx, self.lib.tr_knn(self._ctx, _dp(st), n, int(k), float(max_distance),
+                                               idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dist)))
+        else:
+            L.check(self._ctx, self.lib.tr_knn_range(self._ctx, _dp(st), n, q0, nq, int(k), float(max_distance),
+                                                     idx.ctypes.data_as(C.POINTER(C.c_int32)), _dp(dist)))
         return idx, dist
+
+    def edges_from_knn(self, idx):
+        """Undirected, deduplicated, ordered edge list of a k-nearest table given as an (n, k) index array (tr_knn_table_edges)."""
+        t = np.ascontiguousarray(idx, dtype=np.int32)
+        if t.ndim != 2:
+            raise L.InvalidArgument("idx must be (n, k)")
+        n, k = t.shape
+        cap = max(1, n * k)
+        e = np.empty((cap, 2), dtype=np.int32)
+        ne = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_knn_table_edges(self._ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), n, k,
+                                                       e.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(ne)))
+        return e[: min(cap, ne.value)].copy()
 
     def knn_edges(self, states, k, max_distance=np.inf):
         """Undirected edge list (n_edges, 2), lo < hi, ordered, of the k-nearest table (k counts the vertex itself):

@@ -101,6 +101,19 @@ class RoadmapBuilder:
         self.timing["vertex_caches"] = dict(seconds=time.perf_counter() - t0, items=len(states), blocks=int(out["offsets"][-1]))
         return out
 
+    def knn_edges_sharded(self, states, k, device=None):
+        """knn_edges_gpu with the neighbour search spread over the ranks of the default process group (config 4's sizes:
+        10^6 vertices are 10^12 pair distances): this rank's rows of the table (tr_knn_range), one all-gather of the rows,
+        then the edge set from the whole table on every rank (tr_knn_table_edges).  Same edges as knn_edges_gpu."""
+        t0 = time.perf_counter()
+        st = np.ascontiguousarray(states, dtype=np.float64)
+        dev = ("cuda:%d" % self.engine.device) if device is None else device
+        sh = D.ShardedNeighbours(lambda first, count: self.engine.knn(st, k, query_range=(first, count))[0], k, device=dev)
+        table = sh.run(len(st))
+        edges = self.engine.edges_from_knn(table)
+        self.timing["knn_sharded"] = dict(seconds=time.perf_counter() - t0, n=len(st), k=k, edges=len(edges))
+        return edges
+
     def connect(self, states, edges, device=False):
         """createRoadmap's edge phase in one pass (tr_connect_edges_indexed): checkMotion on every candidate edge and the voxel
         sets of the accepted ones -> (accepted edges, their caches as CSR over the accepted edges only)."""

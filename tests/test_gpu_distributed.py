@@ -48,8 +48,13 @@ mv = irt.VoxelBackboneMotionValidator(chk)
 idx = np.flatnonzero(mask)[:261]
 a, b = cand[idx[:-1]], cand[idx[1:]]
 emask = irt.unpack_bits(D.ShardedEdgeValidator(lambda ea, eb: D.pack_bits(mv.check_motion(ea, eb)), device="cuda").run(a, b), len(a))
+# the neighbour phase between them: this rank's rows of the k-nearest table (tr_knn_range), gathered, edges from the table
+rb = irt.RoadmapBuilder(chk, mv, seed=1)
+verts = cand[mask][:3000]
+e_sharded = rb.knn_edges_sharded(verts, 7)
 if dist.get_rank() == 0:
-    np.savez(sys.argv[2], mask=mask, emask=emask, direct=chk.is_valid(cand), edirect=mv.check_motion(a, b))
+    np.savez(sys.argv[2], mask=mask, emask=emask, direct=chk.is_valid(cand), edirect=mv.check_motion(a, b),
+             e_sharded=e_sharded, e_single=rb.knn_edges_gpu(verts, 7))
 dist.barrier()
 dist.destroy_process_group()
 print("nccl-ok")
@@ -72,6 +77,7 @@ def test_nccl_world1_allgather_on_device_tensors(tmp_path, orc, irt, helpers):
     assert p.returncode == 0 and "nccl-ok" in p.stdout, p.stderr[-3000:]
     r = np.load(out)
     assert np.array_equal(r["mask"], r["direct"]) and np.array_equal(r["emask"], r["edirect"])
+    assert len(r["e_single"]) > 9000 and np.array_equal(r["e_sharded"], r["e_single"])
     robot = irt.workloads.robot_config3()
     vox, _ = irt.workloads.reach_environment(seed=7, n_spheres=64)
     cand = irt.distributed.candidate_states(robot, 3, 0, M)

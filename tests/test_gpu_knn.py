@@ -118,3 +118,30 @@ def test_knn_edge_list_on_device_equals_host_dedup(irt):
         got = e.knn_edges(st, 8, md)
         assert np.array_equal(got, want) and (md == np.inf or len(want) < 7 * len(st) // 2)
     assert e.knn_edges(st[:1], 4).shape == (0, 2)
+
+
+def test_query_ranges_are_rows_of_the_whole_table(irt):
+    """tr_knn_range: any range of queries gives exactly those rows of tr_knn's tables (the candidate slicing differs with
+    the number of queries; the merge is order-exact), and tr_knn_table_edges builds tr_knn_edges' edge set from a table
+    handed in by the caller -- the two halves of a connection loop spread over several GPUs."""
+    W = irt.workloads
+    for mk, rot, n in ((W.robot_config3, False, 9000), (W.robot_config2, True, 700)):
+        robot = mk()
+        robot.enable_rotation = rot
+        vox, _ = W.reach_environment(seed=7, n_spheres=8)
+        eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+        st = W.random_states(robot, n, seed=71)
+        st[5] = st[4]                                           # an exact tie
+        idx, dist = eng.knn(st, 9)
+        for first, count in ((0, 64), (0, n), (n // 3, n // 2), (n - 1, 1), (130, 1000 if n > 2000 else 100)):
+            ri, rd = eng.knn(st, 9, query_range=(first, count))
+            assert ri.shape == (count, 9) and np.array_equal(ri, idx[first:first + count]) and np.array_equal(rd, dist[first:first + count])
+        assert eng.knn(st, 9, query_range=(7, 0))[0].shape == (0, 9)
+        for bad in ((-1, 5), (n - 2, 3)):
+            with pytest.raises(irt.OutOfRange):
+                eng.knn(st, 9, query_range=bad)
+        assert np.array_equal(eng.edges_from_knn(idx), eng.knn_edges(st, 9))
+        far = eng.knn(st, 9, max_distance=float(np.median(dist[:, 3])))[0]     # rows with missing neighbours (-1)
+        assert (far < 0).any() and np.array_equal(eng.edges_from_knn(far), eng.knn_edges(st, 9, max_distance=float(np.median(dist[:, 3]))))
+        with pytest.raises(irt.OutOfRange):
+            eng.edges_from_knn(np.full((4, 3), 4, np.int32))

@@ -250,9 +250,16 @@ def edges_local(ea, eb):
     v, _, _ = orc.check_motion_batch(orb, og, ea, eb)
     return D.pack_bits(v)
 emask = D.ShardedEdgeValidator(edges_local).run(a, b)
+# between the two: the connection loop's neighbour table, rows computed per shard and all-gathered (int32)
+def knn_local(first, count):                     # numpy brute force stands in for tr_knn_range
+    d = np.linalg.norm(states[first:first + count, None, :] - states[None, :, :], axis=2)
+    return np.argsort(d, axis=1, kind="stable")[:, :4]
+table = D.ShardedNeighbours(knn_local, 4).run(len(states))
 if rank == 0:
     np.save(sys.argv[2], valid)
     np.save(sys.argv[2] + ".edges.npy", irt.unpack_bits(emask, len(a)))
+    np.save(sys.argv[2] + ".knn.npy", table)
+    np.save(sys.argv[2] + ".knn_want.npy", knn_local(0, len(states)))
 dist.barrier()
 dist.destroy_process_group()
 '''
@@ -277,6 +284,9 @@ def test_sharded_validation_gloo_world2_matches_world1(irt, tmp_path):
     assert 0 < a.sum() < M
     ea, eb = np.load(tmp_path / "w1.npy.edges.npy"), np.load(tmp_path / "w2.npy.edges.npy")
     assert ea.shape == (130,) and np.array_equal(ea, eb) and 0 < ea.sum() < 130      # 130 edges: shards are not whole words
+    for w in ("w1", "w2"):                                                           # 131 vertices: shards of 128 and 3 (+ padding rows)
+        t, want = np.load(tmp_path / (w + ".npy.knn.npy")), np.load(tmp_path / (w + ".npy.knn_want.npy"))
+        assert t.shape == (131, 4) and t.dtype == np.int32 and np.array_equal(t, want)
 
 
 def test_bench_spawns_its_own_ranks_and_relays_failure():
