@@ -120,3 +120,57 @@ def test_zero_tension_known_answer_full_size(irt, setup):
     b, t, f = _bits(setup, d, n)
     assert irt.unpack_bits(b, n).all() and (f == 15).all()
     assert np.abs(t - np.array([0.0, 0.0, 0.2])).max() < 1e-13
+
+
+def test_config4_sizes_on_one_rank(irt):
+    """BASELINE config 4's sizes through one rank's code path (world size 1): the mask of 2^20 candidate vertices from the
+    sharded validator equals direct validation of the same candidate sequence in ragged pieces; two ranks' shares of the
+    neighbour table (tr_knn_range over ~600 k accepted vertices) are the rows a 4 096-query probe of the whole search gives;
+    the edge list derived from gathered rows is symmetric-free, ordered and duplicate-free; a shard of those edges validates
+    the same alone and inside a larger batch."""
+    import torch
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    eng = chk.engine
+    M = 1 << 20
+
+    def validate_local(states):
+        d = torch.from_numpy(states).cuda()
+        bits = torch.zeros((len(states) + 63) // 64, dtype=torch.int64, device="cuda")
+        eng.validate_batch_dev(d, len(states), bits)
+        torch.cuda.synchronize()
+        return bits.cpu().numpy()
+
+    mask = irt.unpack_bits(D.ShardedVertexValidator(robot, validate_local, seed=3, device="cuda").run(M, rank=0, world_size=1), M)
+    cand = D.candidate_states(robot, 3, 0, M)
+    for lo, hi in ((0, 70001), (400000, 470003), (M - 50001, M)):             # ragged pieces, not multiples of 64
+        assert np.array_equal(chk.is_valid(cand[lo:hi]), mask[lo:hi])
+    assert 0.5 < mask.mean() < 0.7
+    verts = np.ascontiguousarray(cand[mask])
+    n = len(verts)
+    k = 11
+    shares = [D.shard_bounds(n, 8, r) for r in (0, 5)]
+    rows = [eng.knn(verts, k, query_range=(s0, min(s1, n) - s0))[0] for s0, s1, _ in shares]
+    for (s0, s1, _), r in zip(shares, rows):
+        assert r.shape == (min(s1, n) - s0, k) and np.array_equal(r[:, 0], np.arange(s0, min(s1, n)))     # every vertex is its own nearest
+        # neighbour lists of a probe inside the share, computed as a small range of their own (other slicing of the candidates)
+        p0 = s0 + 1234
+        probe = eng.knn(verts, k, query_range=(p0, 4096))[0]
+        assert np.array_equal(probe, r[1234:1234 + 4096])
+        d = np.linalg.norm(verts[r[:64, 1:]] - verts[s0:s0 + 64, None, :], axis=2)
+        assert (np.diff(d, axis=1) >= 0).all()                               # ordered by distance
+    table = np.full((n, k), -1, np.int32)
+    for (s0, s1, _), r in zip(shares, rows):
+        table[s0:s0 + len(r)] = r
+    edges = eng.edges_from_knn(table)
+    assert (edges[:, 0] < edges[:, 1]).all()
+    key = edges[:, 0].astype(np.int64) << 32 | edges[:, 1]
+    assert (np.diff(key) > 0).all() and len(edges) > 0.9 * (k - 1) * sum(len(r) for r in rows) * 0.5
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    part = edges[:200000]
+    whole = mv.check_motion_indexed(verts, part)
+    alone = mv.check_motion_indexed(verts, part[70000:90000])
+    assert np.array_equal(whole["valid"][70000:90000], alone["valid"]) and np.array_equal(whole["n_fk"][70000:90000], alone["n_fk"])
+    assert whole["valid"].mean() > 0.9
