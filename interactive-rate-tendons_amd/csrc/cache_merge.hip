@@ -204,4 +204,34 @@ hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int 
   return hipSuccess;
 }
 
+
+namespace {
+__global__ __launch_bounds__(256) void first_coordinate_keys(const double *__restrict__ states, int64_t n, int S, double *__restrict__ keys,
+                                                             int32_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) { keys[i] = states[i * S]; vals[i] = (int32_t)i; }
+}
+__global__ __launch_bounds__(256) void gather_states(const double *__restrict__ states, const int32_t *__restrict__ perm, int64_t n, int S,
+                                                     double *__restrict__ sorted) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t < n * S) { const int64_t j = t / S; sorted[t] = states[(int64_t)perm[j] * S + (t - j * S)]; }
+}
+}  // namespace
+
+hipError_t sort_states_by_first(MergeScratch &ms, const double *d_states, int64_t n, int S, double *d_sorted, double *d_xs,
+                                int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(first_coordinate_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, d_keys_tmp, d_perm_tmp);
+  MERGE_TRY(hipGetLastError());
+  size_t bytes = 0;
+  MERGE_TRY(rocprim::radix_sort_pairs(nullptr, bytes, d_keys_tmp, d_xs, d_perm_tmp, d_perm, (size_t)n, 0u, 64u, stream));
+  if (ms.cap_tmp < bytes) {
+    MERGE_TRY(grow((char **)&ms.tmp, bytes + bytes / 4));
+    ms.cap_tmp = bytes + bytes / 4;
+  }
+  MERGE_TRY(rocprim::radix_sort_pairs(ms.tmp, bytes, d_keys_tmp, d_xs, d_perm_tmp, d_perm, (size_t)n, 0u, 64u, stream));
+  hipLaunchKernelGGL(gather_states, dim3((unsigned)((n * S + 255) / 256)), dim3(256), 0, stream, d_states, d_perm, n, S, d_sorted);
+  return hipGetLastError();
+}
+
 }  // namespace trk

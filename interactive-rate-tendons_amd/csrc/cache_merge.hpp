@@ -41,4 +41,10 @@ void merge_free(MergeScratch &ms);
 hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int k, int32_t *d_edges, int64_t capacity,
                          int64_t *n_edges, hipStream_t stream);
 
+// The states ordered by their first coordinate, for the neighbour search (knn_kernel.hpp): d_sorted [n][S] = the states in
+// ascending order of states[i][0], d_xs [n] those coordinates, d_perm [n] the original index of each (stable: equal
+// coordinates keep their order).  All arrays on the device; d_keys_tmp [n] doubles and d_perm_tmp [n] int32 are scratch.
+hipError_t sort_states_by_first(MergeScratch &ms, const double *d_states, int64_t n, int S, double *d_sorted, double *d_xs,
+                                int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream);
+
 }  // namespace trk

@@ -1581,26 +1581,35 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   if (n == 0) return TR_OK;
   if (nq < 0) { q0 = 0; nq = n; }
   if ((size_t)k * 64 * 12 > 60 * 1024) return fail(c, TR_ERR_INVALID_ARG, "k too large (at most 80)");
-  if (n > (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
+  if (n >= (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
   HIP_TRY(c, hipSetDevice(c->device));
   const int S = c->K.state_size, N = c->K.n_tendons;
   double ext2 = 0;
   for (int i = 0; i < N; i++) ext2 += c->max_tension[i] * c->max_tension[i];
   const double ext = std::sqrt(ext2);                         // RealVectorStateSpace::getMaximumExtent
   trk::KnnMetric m{N, c->K.enable_rotation, c->K.enable_retraction, S, ext / (4.0 * M_PI), 2.0 * ext / c->K.L};
-  // candidate slices: enough waves to keep ~8 on every SIMD (see knn_kernel.hpp); at most 32 slices of at least 256 candidates
+  // candidate slices: enough waves to keep ~8 on every SIMD (see knn_kernel.hpp); at most 32 slices
   const int64_t qblocks = (nq + 63) / 64;
   int nslice = (int)std::min<int64_t>(32, std::max<int64_t>(1, (8 * 1024 + qblocks - 1) / qblocks));
-  nslice = (int)std::min<int64_t>(nslice, std::max<int64_t>(1, n / 256));
-  const int64_t slice = (n + nslice - 1) / nslice;
-  nslice = (int)((n + slice - 1) / slice);
-  double *d_s = nullptr, *d_d = nullptr, *d_pd = nullptr, *d_seed = nullptr; int32_t *d_i = nullptr, *d_pi = nullptr;
-  // seeding pass (knn_kernel.hpp) when the candidates are sliced: the k-th distance to the first n / 16 candidates
-  const int64_t n_sample = (nslice > 1 && n >= 8192) ? std::min<int64_t>(16384, std::max<int64_t>(2048, n / 16)) : 0;
+  nslice = (int)std::min<int64_t>(nslice, std::max<int64_t>(1, n / 2048));
+  // seeding pass (knn_kernel.hpp): the k-th distance to the candidates nearest in sorted order, n / 48 either side.  The
+  // thicker that slab, the closer the seed to the true k-th distance and the narrower the search window of the main pass;
+  // measured flat between n / 32 and n / 64 from 10^5 to 10^6 states (profiles/r02/knn_sorted_v1.txt), and a rougher
+  // first seed for the seeding pass itself gains nothing.
+  int64_t hw_div = 48;
+  if (const char *e = std::getenv("TENDON_HIP_KNN_HW_DIV")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) hw_div = v; }   // tuning only
+  const int64_t half_window = n >= 4096 ? std::min<int64_t>(32768, std::max<int64_t>(1024, n / hw_div)) : 0;
+  double *d_s = nullptr, *d_ss = nullptr, *d_xs = nullptr, *d_kt = nullptr, *d_d = nullptr, *d_pd = nullptr, *d_seed = nullptr;
+  int32_t *d_perm = nullptr, *d_pt = nullptr, *d_ql = nullptr, *d_i = nullptr, *d_pi = nullptr;
   int rc = TR_OK;
   do {
-    if (n_sample && hipMalloc((void **)&d_seed, (size_t)nq * sizeof(double)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    if (half_window && hipMalloc((void **)&d_seed, (size_t)nq * sizeof(double)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
     if (hipMalloc((void **)&d_s, (size_t)n * S * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_ss, (size_t)n * S * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_xs, (size_t)n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_kt, (size_t)n * sizeof(double)) != hipSuccess ||
+        hipMalloc((void **)&d_perm, (size_t)n * sizeof(int32_t)) != hipSuccess ||
+        hipMalloc((void **)&d_pt, (size_t)n * sizeof(int32_t)) != hipSuccess ||
         hipMalloc((void **)&d_d, (size_t)nq * k * sizeof(double)) != hipSuccess ||
         hipMalloc((void **)&d_i, (size_t)nq * k * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
     if (nslice > 1 && (hipMalloc((void **)&d_pd, (size_t)nq * nslice * k * sizeof(double)) != hipSuccess ||
@@ -1608,17 +1617,30 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
     if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
+      const hipError_t e = trk::sort_states_by_first(c->merge, d_s, n, S, d_ss, d_xs, d_perm, d_kt, d_pt, nullptr);
+      if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn sort: ") + hipGetErrorString(e)); break; }
+    }
+    if (nq != n) {
+      // a range of queries: their positions in sorted order, ascending (a wave's 64 queries stay neighbours in the first coordinate)
+      std::vector<int32_t> perm((size_t)n), ql;
+      if (hipMemcpy(perm.data(), d_perm, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+      ql.reserve((size_t)nq);
+      for (int64_t j = 0; j < n; j++) if (perm[(size_t)j] >= q0 && perm[(size_t)j] < q0 + nq) ql.push_back((int32_t)j);
+      if (hipMalloc((void **)&d_ql, (size_t)nq * sizeof(int32_t)) != hipSuccess ||
+          hipMemcpy(d_ql, ql.data(), (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    }
+    {
+      ProfScope ps(c, 3, nullptr);
       const dim3 grid((unsigned)qblocks, (unsigned)nslice);
       const size_t lds = (size_t)k * 64 * 12;
       int32_t *oi = nslice > 1 ? d_pi : d_i;
       double *od = nslice > 1 ? d_pd : d_d;
       const int variant = (c->K.enable_rotation ? 1 : 0) | (c->K.enable_retraction ? 2 : 0);
-      const double *d_q = d_s + (size_t)q0 * S;
 #define TRK_KNN(NT, R, T) do { \
-        if (n_sample) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), dim3((unsigned)qblocks, 1), dim3(64), lds, nullptr, d_s, d_q, nq, m, (int)k, \
-                                         max_distance, n_sample, n_sample, (const double *)nullptr, d_seed, (int32_t *)nullptr, (double *)nullptr); \
-        hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), grid, dim3(64), lds, nullptr, d_s, d_q, nq, m, (int)k, max_distance, slice, n, \
-                           (const double *)d_seed, (double *)nullptr, oi, od); } while (0)
+        if (half_window) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), dim3((unsigned)qblocks, 1), dim3(64), lds, nullptr, d_ss, d_xs, d_perm, d_ql, nq, n, m, \
+                                            (int)k, max_distance, half_window, (const double *)nullptr, d_seed, q0, (int32_t *)nullptr, (double *)nullptr); \
+        hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), grid, dim3(64), lds, nullptr, d_ss, d_xs, d_perm, d_ql, nq, n, m, (int)k, max_distance, \
+                           (int64_t)0, (const double *)d_seed, (double *)nullptr, q0, oi, od); } while (0)
       switch (N) {
 #define TRK_CASE(NT) case NT: if (variant == 0) TRK_KNN(NT, false, false); else if (variant == 1) TRK_KNN(NT, true, false); \
                               else if (variant == 2) TRK_KNN(NT, false, true); else TRK_KNN(NT, true, true); break;
@@ -1634,25 +1656,20 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
     if (idx && hipMemcpy(idx, d_i, (size_t)nq * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
     if (dist && hipMemcpy(dist, d_d, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
     if (n_edges) {
-      // the undirected edge set of the table, deduplicated and ordered on the device (cache_merge.hip); the slice lists are
-      // done with, so the edge pairs are unpacked into that buffer (capacity n k pairs at most)
+      // the undirected edge set of the table, deduplicated and ordered on the device (cache_merge.hip)
       int32_t *d_e = nullptr;
       const int64_t cap_e = std::min<int64_t>(edge_capacity, n * (int64_t)k);
       if (cap_e > 0 && hipMalloc((void **)&d_e, (size_t)cap_e * 2 * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
       hipError_t e = trk::knn_edge_list(c->merge, d_i, n, (int)k, d_e, cap_e, n_edges, nullptr);
       if (e == hipSuccess) e = hipDeviceSynchronize();
-      const int64_t m = std::min<int64_t>(*n_edges, cap_e);
-      if (e == hipSuccess && m > 0) e = hipMemcpy(edges, d_e, (size_t)m * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+      const int64_t mm = std::min<int64_t>(*n_edges, cap_e);
+      if (e == hipSuccess && mm > 0) e = hipMemcpy(edges, d_e, (size_t)mm * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
       if (d_e) (void)hipFree(d_e);
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn edge list: ") + hipGetErrorString(e)); break; }
     }
   } while (0);
-  if (d_s) (void)hipFree(d_s);
-  if (d_d) (void)hipFree(d_d);
-  if (d_i) (void)hipFree(d_i);
-  if (d_pd) (void)hipFree(d_pd);
-  if (d_pi) (void)hipFree(d_pi);
-  if (d_seed) (void)hipFree(d_seed);
+  void *ptrs[] = {d_s, d_ss, d_xs, d_kt, d_d, d_pd, d_seed, d_perm, d_pt, d_ql, d_i, d_pi};
+  for (void *q : ptrs) if (q) (void)hipFree(q);
   return rc;
 }
 }  // namespace
