@@ -314,7 +314,7 @@ int64_t tr_voxelize_count(const tr_ctx *ctx);
  * (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502; KBoundedStrategy :1339 / KStarStrategy :1352).
  * Like nearestK on a structure that already contains v, row i starts with i itself at distance 0.
  * Entries farther than max_distance (KBoundedStrategy's bound; pass INFINITY for none) are -1 / inf.
- * idx, dist: n x k row-major, ascending distance.  Exact (brute force). */
+ * idx, dist: n x k row-major, ascending distance.  Exact: every pair is either computed or excluded by a bound on one coordinate. */
 int tr_knn(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_distance,
            int32_t *idx, double *dist);
 
