@@ -85,6 +85,7 @@ def main(argv=None):
     chk.engine.reserve(1 << 20)
     rb.sample_valid_vertices(2048, batch=4096)                       # warm-up
     states, tips = rb.sample_valid_vertices(args.vertices, batch=1 << 17)
+    rb.knn_edges_gpu(states, args.k + 1)                             # warm-up: sort / merge scratch at this size
     edges = rb.knn_edges_gpu(states, args.k + 1)                     # k counts the vertex itself (nearestK semantics)
     edges_host = rb.knn_edges(states, args.k)
     assert np.array_equal(edges, edges_host)
