@@ -133,6 +133,9 @@ struct tr_ctx {
     bool used[kSlots] = {};
     int next = 0;
   } fused;
+  // scratch of the neighbour search (knn_impl), kept between calls: hipMalloc / hipFree of a dozen buffers per call cost more
+  // than the search itself inside a process that holds large allocations (33 against 10 ms at 10^5 states)
+  struct KnnScratch { void *p[12] = {}; size_t cap[12] = {}; } knn;
   // block lists of the last tr_voxelize_* call, resident on the device (tr_voxelize_fetch / tr_voxelize_fetch_dev copy
   // them out), and the scratch of the kernels that produce them
   struct VoxStore { uint32_t *ids = nullptr; uint64_t *masks = nullptr; int64_t cap = 0, n = 0; } vstore;
@@ -753,6 +756,7 @@ void tr_destroy(tr_ctx *c) {
   if (c->last_dev_ev) (void)hipEventDestroy(c->last_dev_ev);
   if (c->d_item_src) (void)hipFree(c->d_item_src);
   if (c->d_item_edge) (void)hipFree(c->d_item_edge);
+  for (void *q : c->knn.p) if (q) (void)hipFree(q);
   if (c->vstore.ids) (void)hipFree(c->vstore.ids);
   if (c->vstore.masks) (void)hipFree(c->vstore.masks);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
@@ -1602,18 +1606,26 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   double *d_s = nullptr, *d_ss = nullptr, *d_xs = nullptr, *d_kt = nullptr, *d_d = nullptr, *d_pd = nullptr, *d_seed = nullptr;
   int32_t *d_perm = nullptr, *d_pt = nullptr, *d_ql = nullptr, *d_i = nullptr, *d_pi = nullptr;
   int rc = TR_OK;
+  auto scratch = [&](int slot, size_t bytes, auto **out) -> bool {          // grow-only buffers kept in the context
+    tr_ctx::KnnScratch &ks = c->knn;
+    if (ks.cap[slot] < bytes) {
+      if (ks.p[slot]) { (void)hipFree(ks.p[slot]); ks.p[slot] = nullptr; ks.cap[slot] = 0; }
+      const size_t want = bytes + bytes / 8;
+      if (hipMalloc(&ks.p[slot], want) != hipSuccess) return false;
+      ks.cap[slot] = want;
+    }
+    *out = reinterpret_cast<std::remove_reference_t<decltype(**out)> *>(ks.p[slot]);
+    return true;
+  };
   do {
-    if (half_window && hipMalloc((void **)&d_seed, (size_t)nq * sizeof(double)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
-    if (hipMalloc((void **)&d_s, (size_t)n * S * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_ss, (size_t)n * S * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_xs, (size_t)n * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_kt, (size_t)n * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_perm, (size_t)n * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void **)&d_pt, (size_t)n * sizeof(int32_t)) != hipSuccess ||
-        hipMalloc((void **)&d_d, (size_t)nq * k * sizeof(double)) != hipSuccess ||
-        hipMalloc((void **)&d_i, (size_t)nq * k * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
-    if (nslice > 1 && (hipMalloc((void **)&d_pd, (size_t)nq * nslice * k * sizeof(double)) != hipSuccess ||
-                       hipMalloc((void **)&d_pi, (size_t)nq * nslice * k * sizeof(int32_t)) != hipSuccess)) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+    const size_t nn = (size_t)n, qq = (size_t)nq;
+    if (!scratch(0, nn * S * sizeof(double), &d_s) || !scratch(1, nn * S * sizeof(double), &d_ss) || !scratch(2, nn * sizeof(double), &d_xs) ||
+        !scratch(3, nn * sizeof(double), &d_kt) || !scratch(4, nn * sizeof(int32_t), &d_perm) || !scratch(5, nn * sizeof(int32_t), &d_pt) ||
+        !scratch(6, qq * k * sizeof(double), &d_d) || !scratch(7, qq * k * sizeof(int32_t), &d_i) ||
+        (half_window && !scratch(8, qq * sizeof(double), &d_seed)) ||
+        (nslice > 1 && (!scratch(9, qq * nslice * k * sizeof(double), &d_pd) || !scratch(10, qq * nslice * k * sizeof(int32_t), &d_pi)))) {
+      rc = fail(c, TR_ERR_HIP, "hipMalloc failed (neighbour search scratch)"); break;
+    }
     if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
@@ -1626,7 +1638,7 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       if (hipMemcpy(perm.data(), d_perm, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
       ql.reserve((size_t)nq);
       for (int64_t j = 0; j < n; j++) if (perm[(size_t)j] >= q0 && perm[(size_t)j] < q0 + nq) ql.push_back((int32_t)j);
-      if (hipMalloc((void **)&d_ql, (size_t)nq * sizeof(int32_t)) != hipSuccess ||
+      if (!scratch(11, (size_t)nq * sizeof(int32_t), &d_ql) ||
           hipMemcpy(d_ql, ql.data(), (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
     }
     {
@@ -1668,8 +1680,6 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn edge list: ") + hipGetErrorString(e)); break; }
     }
   } while (0);
-  void *ptrs[] = {d_s, d_ss, d_xs, d_kt, d_d, d_pd, d_seed, d_perm, d_pt, d_ql, d_i, d_pi};
-  for (void *q : ptrs) if (q) (void)hipFree(q);
   return rc;
 }
 }  // namespace
