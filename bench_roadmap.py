@@ -265,6 +265,16 @@ def main(argv=None):
         q5["cpu_sequential_port"] = {"queries_per_s": m / (time.perf_counter() - t0), "sample": "first %d queries, 1 thread" % m,
                                      "paths_equal_gpu_batch": bool(agree)}
     out["config5"]["queries"] = q5
+    # createRoadmap as one call (sample, connect with checkMotion, voxel sets, query object), lists kept in HBM
+    rb2 = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
+    chk.engine.set_grid(vox.Nx(), vox.limits(), vox.blocks)
+    prm2, rm2 = rb2.create_roadmap(args.vertices, k=args.k)
+    assert np.array_equal(rm2["states"], states) and np.array_equal(rm2["edges"], e_ok)
+    out["config3"]["create_roadmap"] = {"seconds": rb2.timing["create_roadmap"]["seconds"], "vertices_s": rb2.timing["vertices"]["seconds"],
+                                        "knn_edge_list_s": rb2.timing["knn_gpu"]["seconds"], "connect_s": rb2.timing["connect"]["seconds"],
+                                        "vertex_caches_s": rb2.timing["vertex_caches"]["seconds"],
+                                        "note": "sample + k-NN + checkMotion + voxel sets of all vertices and kept edges + query object with landmark tables"}
+    del prm2, rm2
     # config 1 shape: FK only, 3-tendon linear-routed robot (P = 41), small and large batches
     r1 = W.robot_config1()
     e1 = r1.engine(0)

@@ -129,6 +129,26 @@ class RoadmapBuilder:
         self.timing["connect"] = dict(seconds=time.perf_counter() - t0, items=len(e), accepted=int(ok.sum()), blocks=int(off[-1]))
         return e[ok], out
 
+    def create_roadmap(self, n_vertices, k=None, batch=1 << 17, device=True, n_landmarks=16):
+        """createRoadmap (motion-planning/VoxelCachedLazyPRM.cpp:1431-1560) as one call: n_vertices valid milestones (:1446-1483),
+        the connection loop with k nearest (k = None: the PRM* strategy's k, :1346-1356) keeping the edges checkMotion accepts
+        (:1491-1551), every vertex's and every kept edge's voxel set (:1704-1713, :1751-1775), and the result attached to a
+        VoxelCachedLazyPRM ready for solveWithRoadmap.  device=True keeps the block lists in HBM from the voxelisation to the
+        query loop.  Returns (prm, dict(states, tips, edges, vertex_caches, edge_caches)); self.timing has the phases."""
+        t0 = time.perf_counter()
+        states, tips = self.sample_valid_vertices(n_vertices, batch=batch)
+        kk = (self.engine.kstar_k(len(states)) if k is None else int(k)) + 1            # the tables count the vertex itself
+        cand = self.knn_edges_gpu(states, kk)
+        self.engine.reserve_edges(len(cand))
+        edges, ec = self.connect(states, cand, device=device)
+        vc = self.vertex_caches(states, device=device)
+        prm = VoxelCachedLazyPRM(self.checker, states, edges)
+        prm.set_caches(vc, ec)
+        if n_landmarks:
+            prm.prepare(n_landmarks)
+        self.timing["create_roadmap"] = dict(seconds=time.perf_counter() - t0, vertices=len(states), candidate_edges=len(cand), edges=len(edges))
+        return prm, dict(states=states, tips=tips, edges=edges, vertex_caches=vc, edge_caches=ec)
+
     def edge_caches(self, states, edges, device=False):
         t0 = time.perf_counter()
         out = self.engine.voxelize_edges_indexed(states, edges, self.mv.min_tension_change,

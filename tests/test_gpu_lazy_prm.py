@@ -174,3 +174,45 @@ def test_caches_kept_on_the_device_give_the_same_lists_and_answers(irt):
     with pytest.raises(irt.InvalidArgument):
         chk.engine.lib  # noqa: B018 (keeps the engine alive above)
         chk.engine._fetch_lists(int(ed["offsets"][-1]) - 1, device=True) if ed["offsets"][-1] > 0 else (_ for _ in ()).throw(irt.InvalidArgument("x"))
+
+
+def test_create_roadmap_in_one_call(irt, orc, helpers):
+    """RoadmapBuilder.create_roadmap = sample -> connect (k nearest, checkMotion) -> voxel sets -> query object: the same
+    vertices, edges and caches as the separate calls, and queries on it answer like the oracle's sequential loop."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=90)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    rb = irt.RoadmapBuilder(chk, mv, seed=33)
+    prm, rm = rb.create_roadmap(1200, k=6, batch=4096, device=True)
+    st2, _ = irt.RoadmapBuilder(chk, mv, seed=33).sample_valid_vertices(1200, batch=8192)
+    assert np.array_equal(rm["states"], st2) and chk.is_valid(rm["states"]).all()
+    cand = rb.knn_edges(rm["states"], 6)                               # host cKDTree
+    ok = mv.check_motion_indexed(rm["states"], cand)["valid"]
+    assert np.array_equal(rm["edges"], cand[ok]) and 0 < (~ok).sum()
+    ec_host = rb.edge_caches(rm["states"], rm["edges"])
+    assert np.array_equal(rm["edge_caches"]["offsets"], ec_host["offsets"])
+    assert np.array_equal(rm["edge_caches"]["block_ids"].cpu().numpy().view(np.uint32), ec_host["block_ids"])
+    vc_host = rb.vertex_caches(rm["states"])
+    assert np.array_equal(rm["vertex_caches"]["masks"].cpu().numpy().view(np.uint64), vc_host["masks"])
+    for key in ("vertices", "knn_gpu", "connect", "vertex_caches", "create_roadmap"):
+        assert key in rb.timing
+    # PRM* connection count when k is not given
+    prm_star, rm_star = irt.RoadmapBuilder(chk, mv, seed=33).create_roadmap(300, batch=2048, device=False, n_landmarks=0)
+    assert len(rm_star["edges"]) > len(rm_star["states"]) * 6 and isinstance(rm_star["edge_caches"]["masks"], np.ndarray)
+    # queries in a changed environment against the oracle
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=100)
+    prm.set_obstacles(new_vox)
+    rng = np.random.default_rng(8)
+    starts, goals = rng.integers(0, 1200, 150), rng.integers(0, 1200, 150)
+    got = prm.solveWithRoadmap(starts, goals)
+    orb, og = helpers.oracle_robot(orc, robot), helpers.oracle_grid(orc, new_vox)
+    orm = orc.Roadmap(orb, rm["states"], rm["edges"], None, vc_host, ec_host)
+    code = {-2: 2, -3: 3, 0: 1}
+    for q in range(150):
+        w = orm.query(og, starts[q], goals[q])
+        assert got["status"][q] == (0 if w["n"] > 0 else code[w["n"]])
+        if w["n"] > 0:
+            assert np.array_equal(got["paths"][q], w["path"]) and got["cost"][q] == w["cost"]
+    assert (got["status"] == 0).sum() > 50
