@@ -389,7 +389,7 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
  * of connectionStrategy_(v), `if (!getEdge(v, n)) connectVertices(v, n)`): the undirected edge set of the k-nearest
  * table -- pairs (lo, hi), lo < hi, each once, ordered by (lo, hi) -- built on the device (sort + unique of the pair
  * keys); only the edge list crosses PCIe.  k counts the vertex itself, as in tr_knn.  edges: capacity x 2 int32; *n_edges
- * receives the number of edges (if it exceeds capacity only the first `capacity` are written: at most n (k - 1)). */
+ * receives the number of edges (if it exceeds capacity only the first `capacity` are written: at most n (k - 1) edges exist -- n k when k or more states coincide, a row then need not hold its own vertex). */
 int tr_knn_edges(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_distance, int32_t *edges,
                  int64_t capacity, int64_t *n_edges);
 

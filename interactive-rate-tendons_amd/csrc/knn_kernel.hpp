@@ -101,7 +101,7 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
     j1 = j0 + per < hi ? j0 + per : hi;
     if (j0 > hi) j0 = hi;
   }
-  double gate2 = worst * worst * (1.0 + 4.5e-16);   // plain metric: squared distances at or above this cannot beat `worst`
+  double gate2 = worst * worst * (1.0 + 4.5e-16);   // plain metric: squared distances above this cannot reach `worst`
   constexpr bool plain = !ROT && !RET;
   // Candidates are taken a chunk at a time: their scalar loads are issued together and the wave leaves the chunk at once
   // unless some lane can improve its list -- rare after the first few hundred candidates.  (One candidate per iteration
@@ -146,13 +146,13 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
     double mn = dd[0];
 #pragma unroll
     for (int u = 1; u < CH; u++) mn = fmin(mn, dd[u]);
-    if (!__any(plain ? mn < gate2 : mn <= worst)) return;
+    if (!__any(plain ? mn <= gate2 : mn <= worst)) return;
 #pragma unroll
     for (int u = 0; u < CH; u++) {
       if (!FULL && !(jb + u < j1)) continue;         // a tail chunk's padding
       double dist = dd[u];
       if (plain) {
-        if (!(dist < gate2)) continue;
+        if (!(dist <= gate2)) continue;        // (<=: a zero threshold -- coincident states -- still admits distance 0)
         dist = sqrt(dist);
       }
       if (dist <= worst) {

@@ -274,7 +274,7 @@ class Engine:
         the connection loop of createRoadmap, deduplicated on the device."""
         st = self._states(states)
         n = st.shape[0]
-        cap = max(1, n * max(0, int(k) - 1))
+        cap = max(1, n * int(k))              # n (k - 1) unless k or more states coincide (a row then need not hold its own vertex)
         e = np.empty((cap, 2), dtype=np.int32)
         ne = C.c_int64(0)
         L.check(self._ctx, self.lib.tr_knn_edges(self._ctx, _dp(st), n, int(k), float(max_distance),

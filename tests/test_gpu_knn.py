@@ -145,3 +145,39 @@ def test_query_ranges_are_rows_of_the_whole_table(irt):
         assert (far < 0).any() and np.array_equal(eng.edges_from_knn(far), eng.knn_edges(st, 9, max_distance=float(np.median(dist[:, 3]))))
         with pytest.raises(irt.OutOfRange):
             eng.edges_from_knn(np.full((4, 3), 4, np.int32))
+
+
+def test_degenerate_inputs_of_the_sorted_search(irt):
+    """The neighbour search sorts by the first coordinate and prunes by it: inputs where that coordinate says nothing (all
+    equal), where everything ties (identical states), fewer states than k, a single state, and a large set whose first
+    coordinate takes only two values -- against a stable argsort of the numpy distance matrix."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=8)
+    eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+    rng = np.random.default_rng(5)
+
+    def check(st, k):
+        idx, dist = eng.knn(st, k)
+        D = np.linalg.norm(st[:, None, :] - st[None, :, :], axis=2)
+        order = np.argsort(D, axis=1, kind="stable")[:, :k]
+        n = len(st)
+        kk = min(k, n)
+        assert np.array_equal(idx[:, :kk], order[:, :kk]), np.argwhere(idx[:, :kk] != order[:, :kk])[:5]
+        assert np.allclose(dist[:, :kk], np.take_along_axis(D, order[:, :kk], 1), rtol=0, atol=1e-15)
+        if kk < k:
+            assert (idx[:, kk:] == -1).all() and np.isinf(dist[:, kk:]).all()
+        edges = eng.knn_edges(st, k)
+        want = {(min(i, j), max(i, j)) for i in range(n) for j in order[i, :kk] if i != j}
+        assert {tuple(e) for e in edges} == want
+
+    st = rng.uniform(0, 20, (700, 4))
+    st[:, 0] = 3.0                                             # the sort coordinate carries no information
+    check(st, 9)
+    check(np.tile(rng.uniform(0, 20, (1, 4)), (300, 1)), 7)     # identical states: all distances 0, order by index
+    check(rng.uniform(0, 20, (5, 4)), 9)                        # fewer states than k
+    check(rng.uniform(0, 20, (1, 4)), 3)
+    big = rng.uniform(0, 20, (6000, 4))                         # large enough for the seeding pass and candidate slices
+    big[:, 0] = np.where(rng.random(6000) < 0.5, 1.0, 19.0)
+    big[100:140] = big[99]                                      # a cluster of duplicates
+    check(big, 11)
