@@ -10,7 +10,7 @@ namespace trk {
 
 // Scratch owned by the merge; grows on demand, freed by merge_free.
 struct MergeScratch {
-  int64_t cap_items = 0, cap_nnz = 0;
+  int64_t cap_items = 0, cap_nnz = 0, cap_group_items = 0, cap_group_edges = 0;
   size_t cap_tmp = 0;
   int64_t *cnt = nullptr, *offs = nullptr;        // [items + 1]
   uint64_t *keys[2] = {nullptr, nullptr};         // [nnz] (edge << id_bits) | block id
@@ -21,6 +21,13 @@ struct MergeScratch {
   int64_t cap_edges = 0;
   uint64_t *scalars = nullptr;                    // [0] unique count, [1] overflow flag
   void *tmp = nullptr;
+  // grouping of the items by edge: edge ids as sort keys, item numbers, the rank of every item, entries per edge and
+  // the segment (= edge) offsets of the entry arrays
+  uint32_t *ekey[2] = {nullptr, nullptr};         // [items]
+  int32_t *order[2] = {nullptr, nullptr};         // [items]
+  int32_t *rank = nullptr;                        // [items]
+  unsigned long long *etot = nullptr;             // [edges + 1]
+  unsigned int *seg = nullptr;                    // [edges + 1]
 };
 
 // Per-sample block lists (ids / masks stored as columns [maxB][ld], counts[i] entries, counts < 0 =
