@@ -762,40 +762,44 @@ __global__ __launch_bounds__(64) void dilate2_blocks(const uint64_t *__restrict_
 // K4 `cached_blocks_vs_grid`: sparse cached voxel sets (CSR of (block id, mask)) vs the dense grid:
 // `obstacles.collides(*cached_voxels)` of VoxelCachedLazyPRM.cpp:2397-2411 for every roadmap item.
 // HBM-streaming kernel, bound by the loads it keeps in flight: a roadmap item holds ~40 - 55 blocks, less than one
-// wave-wide iteration, and testing it is a chain of dependent round trips (offsets -> entries -> grid word).  So a wave
-// takes FOUR items at once, 16 lanes each, two entries per lane in flight, and the workgroup (16 waves = the 64 items of
-// one output word) fetches its 65 offsets with one coalesced load up front.  (One item per wave, r02 profile on a 399 MiB
-// working set: 0.27 of the HBM peak with 91 % of the wave cycles waiting.)
-__global__ __launch_bounds__(1024) void cached_blocks_vs_grid(
+// wave-wide iteration, and testing it is a chain of dependent round trips (offsets -> entries -> grid word).  A wave takes
+// FOUR items at once, 16 lanes each, four entries per lane in flight (a typical item's whole list in one round of loads),
+// and is a workgroup of its own: with 16 waves sharing one output word and one offsets fetch the waves of a CU moved
+// through their three phases in step (0.42 of the HBM peak); independent waves spread over them (0.50).  A hit sets the
+// item's bit with an atomic (hit_bits is zeroed by the host).  Measured alternatives, all slower on real caches: one item
+// per wave (0.27), a flat stream of entries with deferred item lookup, and persistent waves that prefetch the
+// next group's entries and the offsets of the one after (0.47: the early exit at an item's first hit wastes the prefetch).
+#ifndef K4_INFLIGHT
+#define K4_INFLIGHT 4
+#endif
+__global__ __launch_bounds__(64) void cached_blocks_vs_grid(
     const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int64_t *__restrict__ offsets,
     int64_t n_items, const uint64_t *__restrict__ grid, uint32_t n_blocks, uint64_t *__restrict__ hit_bits) {
-  __shared__ unsigned long long word;
-  __shared__ int64_t off[65];
-  const int t = threadIdx.x;
-  const int64_t base = (int64_t)blockIdx.x * 64;
-  if (t == 0) word = 0ull;
-  if (t < 65) { const int64_t i = base + t; off[t] = offsets[i <= n_items ? i : n_items]; }
-  __syncthreads();
-  const int lane = t & 63, grp = lane >> 4, sub = lane & 15;
-  const int slot = (t >> 6) * 4 + grp;
+  const int lane = threadIdx.x, grp = lane >> 4, sub = lane & 15;
+  const int64_t item = (int64_t)blockIdx.x * 4 + grp;
   bool hit = false;
-  if (base + slot < n_items) {
-    const int64_t e = off[slot + 1];
-    for (int64_t k = off[slot] + sub; k < e && !hit; k += 32) {
-      const int64_t k2 = k + 16;
-      const uint32_t id0 = ids[k];
-      const uint64_t m0 = masks[k];
-      uint32_t id1 = 0xffffffffu;
-      uint64_t m1 = 0;
-      if (k2 < e) { id1 = ids[k2]; m1 = masks[k2]; }
-      const uint64_t g0 = id0 < n_blocks ? grid[id0] : 0ull, g1 = id1 < n_blocks ? grid[id1] : 0ull;
-      hit = ((g0 & m0) | (g1 & m1)) != 0;
+  if (item < n_items) {
+    const int64_t e = offsets[item + 1];
+    for (int64_t k = offsets[item] + sub; k < e && !hit; k += 16 * K4_INFLIGHT) {
+      uint32_t id[K4_INFLIGHT];
+      uint64_t m[K4_INFLIGHT], g[K4_INFLIGHT];
+#pragma unroll
+      for (int u = 0; u < K4_INFLIGHT; u++) {
+        const int64_t ku = k + 16 * u;
+        const bool in = ku < e;
+        id[u] = in ? ids[ku] : 0xffffffffu;
+        m[u] = in ? masks[ku] : 0ull;
+      }
+#pragma unroll
+      for (int u = 0; u < K4_INFLIGHT; u++) g[u] = id[u] < n_blocks ? grid[id[u]] : 0ull;
+      uint64_t any = 0;
+#pragma unroll
+      for (int u = 0; u < K4_INFLIGHT; u++) any |= g[u] & m[u];
+      hit = any != 0;
     }
   }
   const unsigned long long bal = __ballot(hit);
-  if (sub == 0 && ((bal >> (grp * 16)) & 0xffffull)) atomicOr(&word, 1ull << slot);
-  __syncthreads();
-  if (t == 0) hit_bits[blockIdx.x] = word;
+  if (sub == 0 && ((bal >> (grp * 16)) & 0xffffull)) atomicOr((unsigned long long *)&hit_bits[item >> 6], 1ull << (item & 63));
 }
 
 // K4 on a SUBSET of the cached items: list[q] names an item of the CSR; its verdict goes to hit[q] (one byte).  The lazy query loop (roadmap.hip) validates the unknown vertices / edges of all

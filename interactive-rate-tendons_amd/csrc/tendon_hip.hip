@@ -1319,8 +1319,9 @@ int tr_check_cached_dev(tr_ctx *c, const uint32_t *d_ids, const uint64_t *d_mask
   if (!d_ids || !d_masks || !d_offsets || !d_hit_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
   hipStream_t s = (hipStream_t)stream;
   ProfScope ps(c, 2, s);
-  const unsigned grid = (unsigned)((n_items + 63) / 64);
-  hipLaunchKernelGGL(trk::cached_blocks_vs_grid, dim3(grid), dim3(1024), 0, s, d_ids, d_masks, d_offsets, n_items,
+  const unsigned grid = (unsigned)((n_items + 3) / 4);
+  HIP_TRY(c, hipMemsetAsync(d_hit_bits, 0, (size_t)((n_items + 63) / 64) * sizeof(uint64_t), s));
+  hipLaunchKernelGGL(trk::cached_blocks_vs_grid, dim3(grid), dim3(64), 0, s, d_ids, d_masks, d_offsets, n_items,
                      c->d_grid, c->n_blocks, d_hit_bits);
   HIP_TRY(c, hipGetLastError());
   return TR_OK;
