@@ -128,6 +128,31 @@ def load_isa_counts():
         return {}
 
 
+def secondary_metrics():
+    """BASELINE configs 1, 3 and 5 at full size on this GPU (bench_roadmap.py, without its CPU leg), condensed; never part of
+    `value`, and a failure here must not cost the headline line."""
+    try:
+        import bench_roadmap
+        r = bench_roadmap.run(["--no-cpu"])
+        c3, c5, q = r["config3"], r["config5"], r["config5"]["queries"]
+        return {
+            "config3_100k_vertices_k10": {
+                "valid_vertices_per_s": c3["valid_vertices_per_s"], "knn_edge_list_s": c3["knn_gpu_seconds_incl_pcie_and_dedup"],
+                "edges": c3["edges"], "edges_validated_per_s": c3["edges_per_s"], "edge_fk_samples_per_s": c3["edge_fk_samples_per_s"],
+                "fk_samples_per_edge_mean": c3["fk_samples_per_edge"]["mean"], "connect_all_edges_s": q["connect_all_edges_s"],
+                "create_roadmap_s": c3["create_roadmap"]["seconds"]},
+            "config5_10k_queries": {
+                "queries_per_s_lazy": q["lazy"]["queries_per_s"], "lazy_rounds": q["lazy"]["rounds"], "lazy_items_checked": q["lazy"]["items_checked"],
+                "queries_per_s_eager_incl_revalidation": q["eager"]["queries_per_s_incl_revalidation"],
+                "revalidate_all_cached_sets_ms": q["eager"]["revalidate_all_ms"], "cached_sets": q["roadmap_vertices"] + q["roadmap_edges"],
+                "vertex_caches_built_per_s": c5["vertex_caches_built_per_s"], "edge_caches_built_per_s": c5["edge_caches_built_per_s"],
+                "solved_fraction": q["solved_fraction"]},
+            "config1_fk_only": r["config1"], "sphere_checker_checks_per_s": r["sphere_checker"]["checks_per_s"],
+            "source": "bench_roadmap.py (python bench.py --workload roadmap prints all of it)"}
+    except Exception as e:                                  # noqa: BLE001 -- reported, not raised
+        return {"error": repr(e)[:400]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,6 +160,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch-log2", type=int, default=BATCH_LOG2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics (configs 1, 3, 5 at full size; ~15 s on the GPU)")
     ap.add_argument("--workload", default="config2", choices=["config2", "roadmap"],
                     help="config2 (default): the headline line.  roadmap: BASELINE configs 3 and 5 at full size on one GPU "
                          "(bench_roadmap.py: 100k-vertex PRM, k-NN edges, edge validation with the FK-samples/edge histogram, voxel "
@@ -328,6 +354,8 @@ def main():
             cb, cpu_valid, m = cpu_baseline(irt, robot, vox, states)
             out["cpu_baseline"] = cb
             out["config"]["verdicts_match_cpu_sample"] = bool(np.array_equal(valid[:m], cpu_valid))
+            if not args.no_extras:
+                out["extras"] = secondary_metrics()
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

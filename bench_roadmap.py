@@ -60,10 +60,11 @@ def config4_single_gpu(irt, args):
         "pair_distances_per_s": float(len(states)) ** 2 / t_knn, "edge_validation_seconds": t_edges, "edges_per_s": len(edges) / t_edges,
         "edge_fk_samples_per_s": float(nfk.sum()) / t_edges, "edge_valid_fraction": float(valid.mean()),
         "note": "one rank's code path with world size 1; at 8 GPUs each rank validates 1/8 of the candidates and of the edge list"}}
-    print(json.dumps(out))
+    return out
 
 
-def main(argv=None):
+def run(argv=None):
+    """The measurements as a dict (bench.py folds a selection of them into its line as `extras`)."""
     ap = argparse.ArgumentParser()
     ap.add_argument("--vertices", type=int, default=100000)
     ap.add_argument("--k", type=int, default=10)
@@ -320,7 +321,11 @@ def main(argv=None):
     out["sphere_checker"] = {"checks_per_s": nb / ts, "ms_per_2^20": 1e3 * ts,
                              "valid_fraction": float(irt.unpack_bits(bits.cpu().numpy().view(np.uint64), nb).mean()),
                              "note": "VoxelValidityChecker: 64 raw spheres r = 5 mm, robot radius 15 mm swept as spheres"}
-    print(json.dumps(out))
+    return out
+
+
+def main(argv=None):
+    print(json.dumps(run(argv)))
 
 
 if __name__ == "__main__":
