@@ -253,6 +253,19 @@ def main():
         mine = d_bits.cpu().numpy().view(np.uint64)
         if not np.array_equal(gathered[rank * (n // 64):(rank + 1) * (n // 64)], mine):
             raise SystemExit("rank %d: gathered validity mask does not contain this rank's shard" % rank)
+        # the collective on its own ("report 1/2/4/8 with the all-gather time broken out"): the same K all-gathers
+        # of the same buffers without the kernels, after the timed region
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            if rehearsal:
+                dist.all_gather_into_tensor(h_all, d_bits.cpu())
+            else:
+                dist.all_gather_into_tensor(d_all, d_bits)
+        fence()
+        tg = torch.tensor([(time.perf_counter() - t1) / args.steps], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+        allgather_ms = 1e3 * float(tg.item())
 
     valid_bits = d_bits.cpu().numpy().view(np.uint64)
     valid = irt.unpack_bits(valid_bits, n)
@@ -334,6 +347,8 @@ def main():
                                    "256^3 voxel collision (64 seeded spheres r=0.02 in reach)" % args.batch_log2,
                        "rehearsal_shared_gpu": rehearsal, "batch_per_gpu": n, "parallelism": "shard%d+allgather(bitmask)" % world if use_dist else "single",
                        "collective": ("gloo(host)" if rehearsal else "rccl") if use_dist else None,
+                       "allgather_ms_per_step": allgather_ms if use_dist else None,
+                       "allgather_bytes_per_rank": n // 8 if use_dist else None,
                        "valid_fraction_rank0": float(valid.mean())},
             "roofline": roofline,
             "kernels": {"fk_verdict": {"avg_ms": kv_ms, "launches": kv["launches"], "bytes_per_check": kvb},
