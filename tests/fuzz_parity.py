@@ -1,0 +1,131 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep (opt-in, not collected by pytest): random robots (1-6 tendons, polynomial routings, rotation /
+retraction on or off, radii, step sizes), random voxel environments (grid size, limits, obstacle density, rotated
+environment), both state checkers -- verdicts and flags of the HIP path against the CPU oracle, and edges (verdict +
+reference FK count) against the oracle's depth-first bisection.
+
+    python tests/fuzz_parity.py [n_cases] [seed]        # on the GPU box; prints one line per case, exits non-zero on a mismatch
+"""
+import importlib
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import oracle as orc                                           # noqa: E402
+from tests.conftest import make_oracle_grid, make_oracle_robot             # noqa: E402
+
+
+def random_robot(T, rng):
+    N = int(rng.integers(1, 7))
+    na, nm = int(rng.integers(1, 4)), int(rng.integers(1, 3))
+    tendons = []
+    for k in range(N):
+        C = [2 * np.pi * k / N + rng.uniform(-0.2, 0.2)] + [float(rng.uniform(-6, 6)) * (rng.random() < 0.7) for _ in range(na - 1)]
+        D = [float(rng.uniform(0.006, 0.012))] + [float(rng.uniform(-0.01, 0.01)) for _ in range(nm - 1)]
+        tendons.append(T.TendonSpecs(C=C, D=D, max_tension=float(rng.uniform(8, 40)), min_length=float(rng.uniform(-0.05, -0.01)),
+                                     max_length=float(rng.uniform(0.02, 0.08))))
+    P = int(rng.choice([33, 65, 129]))
+    specs = T.BackboneSpecs(L=0.2, dL=0.2 / (P - 1))
+    robot = T.TendonRobot(tendons=tendons, specs=specs)
+    robot.r = float(rng.uniform(0.004, 0.02))
+    robot.enable_rotation = bool(rng.random() < 0.35)
+    robot.enable_retraction = bool(rng.random() < 0.3)
+    return robot
+
+
+def random_env(irt, rng, dL):
+    # the backbone checker requires dL <= voxel size (VoxelBackboneValidityChecker.h:37-45)
+    N = int(rng.choice([64, 128, 256]))
+    lim = float(rng.uniform(0.15, 0.3))
+    while 2 * lim / N < dL:
+        N //= 2
+    vox = irt.VoxelOctree(max(N, 16))
+    vox.set_xlim(-lim, lim); vox.set_ylim(-lim, lim); vox.set_zlim(-lim * rng.uniform(0.3, 1.0), lim)
+    for _ in range(int(rng.integers(5, 80))):
+        c = rng.uniform(-0.22, 0.22, 3)
+        if np.hypot(c[0], c[1]) < 0.03 and -0.02 < c[2] < 0.06:
+            continue
+        vox.add_sphere(c, float(rng.uniform(0.004, 0.03)))
+    env = irt.VoxelEnvironment()
+    if rng.random() < 0.4:
+        a, b = rng.uniform(-0.6, 0.6, 2)
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+        env.inv_rotation = Rz @ Rx
+    return vox, env
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 12
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    irt = importlib.import_module("interactive-rate-tendons_amd")
+    T = irt.tendon
+    orc.build()
+    bad = 0
+    for case in range(n_cases):
+        rng = np.random.default_rng([seed, case])
+        robot = random_robot(T, rng)
+        vox, env = random_env(irt, rng, robot.specs.dL)
+        n = 1500
+        tm = max(t.max_tension for t in robot.tendons)
+        st = irt.workloads.random_states(robot, n, seed=int(rng.integers(1 << 30)), tau_max=float(rng.uniform(0.3, 1.0)) * tm)
+        if robot.enable_retraction:
+            # [0, L] are the RetractionStateSpace bounds (Problem.cpp:142); beyond L is clamped by the reference (TendonRobot.cpp:359),
+            # below 0 it would integrate a backbone longer than any buffer here holds: the product reports such a state unconverged
+            st[:, -1] = rng.uniform(0.0, 0.21, n) * (rng.random(n) < 0.9)
+        orb, og = make_oracle_robot(orc, robot), make_oracle_grid(orc, vox)
+        t0 = time.perf_counter()
+        msg = []
+        for name, cls, ofn in (("backbone", irt.VoxelBackboneValidityChecker, orc.is_valid_state), ("spheres", irt.VoxelValidityChecker, orc.is_valid_state_spheres)):
+            try:
+                chk = cls(robot, env, vox)
+            except irt.InvalidArgument as e:
+                msg.append("%s: refused (%s)" % (name, str(e)[:40]))
+                continue
+            got = chk.is_valid_detail(st)
+            want = [ofn(orb, og, s, env.inv_rotation) for s in st]
+            wv = np.array([w[0] for w in want]); wf = np.array([w[2] for w in want])
+            ok = np.array_equal(got["valid"], wv) and np.array_equal(got["flags"] & 15, wf & 15)
+            conv = (wf & 1) > 0
+            tip_err = float(np.abs(got["tips"][conv] - np.array([w[1] for w in want])[conv]).max()) if conv.any() else 0.0
+            ok = ok and tip_err < 1e-9
+            msg.append("%s %s valid %.2f tip %.1e" % (name, "ok" if ok else "MISMATCH", wv.mean(), tip_err))
+            if not ok:
+                dv = np.flatnonzero(got["valid"] != wv); df = np.flatnonzero((got["flags"] & 15) != (wf & 15))
+                dt = np.flatnonzero(conv & (np.abs(got["tips"] - np.array([w[1] for w in want])).max(axis=1) >= 1e-9))
+                msg.append("[valid diffs %d, flag diffs %d, tip diffs %d; first: %s]" % (
+                    len(dv), len(df), len(dt),
+                    [(int(i), [round(float(x), 4) for x in st[i]], int(got["flags"][i]), int(wf[i]), [round(float(x), 4) for x in got["tips"][i]],
+                      [round(float(x), 4) for x in want[i][1]]) for i in list(dv[:2]) + list(df[:2]) + list(dt[:2])]))
+            bad += not ok
+            if name == "backbone":
+                # edges between near states
+                m = 300
+                a = st[:m]; b = a + rng.normal(0, 0.03 * tm, a.shape)
+                for j, t_ in enumerate(robot.tendons):
+                    b[:, j] = np.clip(b[:, j], 0, t_.max_tension)
+                if robot.enable_rotation:
+                    b[:, len(robot.tendons)] = a[:, len(robot.tendons)] + rng.normal(0, 0.2, m)
+                if robot.enable_retraction:
+                    b[:, -1] = np.clip(a[:, -1] + rng.normal(0, 0.01, m), 0, 0.2)
+                    a = a.copy(); a[:, -1] = np.clip(a[:, -1], 0, 0.2)
+                mv = irt.VoxelBackboneMotionValidator(chk)
+                ge = mv.check_motion_detail(a, b)
+                we = [orc.check_motion(orb, og, a[i], b[i], None, env.inv_rotation) for i in range(m)]
+                wvalid = np.array([w["valid"] for w in we])
+                eok = np.array_equal(ge["valid"], wvalid) and np.array_equal(ge["n_fk"][wvalid], np.array([w["n_fk"] for w in we])[wvalid])
+                msg.append("edges %s valid %.2f" % ("ok" if eok else "MISMATCH", wvalid.mean()))
+                bad += not eok
+        print("case %d: N=%d P=%d rot=%d ret=%d r=%.3f grid=%d %s | %s | %.1fs" % (
+            case, len(robot.tendons), int(round(0.2 / robot.specs.dL)) + 1, robot.enable_rotation, robot.enable_retraction, robot.r, vox.Nx(),
+            "rotated-env" if not np.allclose(env.inv_rotation, np.eye(3)) else "", "; ".join(msg), time.perf_counter() - t0), flush=True)
+    print("mismatching checks:", bad)
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
