@@ -117,9 +117,73 @@ def main():
                 ge = mv.check_motion_detail(a, b)
                 we = [orc.check_motion(orb, og, a[i], b[i], None, env.inv_rotation) for i in range(m)]
                 wvalid = np.array([w["valid"] for w in we])
+                wdom = np.array([w["domain_error"] for w in we])               # find_cell would throw: the product reports the edge invalid and counts it
                 eok = np.array_equal(ge["valid"], wvalid) and np.array_equal(ge["n_fk"][wvalid], np.array([w["n_fk"] for w in we])[wvalid])
+                eok = eok and (ge["n_domain_errors"] > 0) == bool(wdom.any())
                 msg.append("edges %s valid %.2f" % ("ok" if eok else "MISMATCH", wvalid.mean()))
                 bad += not eok
+                # voxel sets: vertices (add_piecewise_line of the shape) and edges (union over the bisection's samples)
+                mc = 60
+                vcg = chk.engine.voxelize_batch(a[:mc])
+                cok = True
+                why = []
+                ref = og.empty_copy()
+                for i in range(mc):
+                    okv, _, fl = orc.is_valid_state(orb, og, a[i], env.inv_rotation)
+                    shape_ok = (fl & 7) == 7
+                    if bool(vcg["shape_valid"][i]) != bool(shape_ok):
+                        cok = False; why.append(("vshape", i, int(fl)))
+                    if shape_ok:
+                        g_ = ref.empty_copy()
+                        pts = orb.shape(a[i])["p"]
+                        g_.add_piecewise_line(pts @ np.asarray(env.inv_rotation).T if not np.allclose(env.inv_rotation, np.eye(3)) else pts)
+                        wi, wm = g_.export_blocks()
+                        lo, hi = vcg["offsets"][i], vcg["offsets"][i + 1]
+                        if not (np.array_equal(vcg["block_ids"][lo:hi], wi) and np.array_equal(vcg["masks"][lo:hi], wm)):
+                            cok = False; why.append(("vlist", i, int(hi - lo), len(wi)))
+                ecg = chk.engine.voxelize_edges(a[:mc], b[:mc])
+                for i in range(mc):
+                    w = orc.check_motion(orb, og, a[i], b[i], None, env.inv_rotation, want_swept=True)
+                    want_fully = bool(w["is_fully_valid"]) and not w["domain_error"]
+                    if bool(ecg["fully_valid"][i]) != want_fully:
+                        cok = False; why.append(("efully", i, bool(ecg["fully_valid"][i]), want_fully, int(ecg["n_fk"][i]), w["n_fk"]))
+                    elif want_fully:
+                        wi, wm = w["swept"].export_blocks()
+                        lo, hi = ecg["offsets"][i], ecg["offsets"][i + 1]
+                        if not (np.array_equal(ecg["block_ids"][lo:hi], wi) and np.array_equal(ecg["masks"][lo:hi], wm)):
+                            cok = False; why.append(("elist", i, int(hi - lo), len(wi)))
+                msg.append("caches %s %s" % ("ok" if cok else "MISMATCH", why[:4] if why else ""))
+                bad += not cok
+            # the last_valid and discrete forms ask the installed checker about every sample
+            ml = 80
+            a2 = st[:ml].copy(); b2 = st[ml:2 * ml].copy()
+            if robot.enable_retraction:
+                a2[:, -1] = np.clip(a2[:, -1], 0, 0.2); b2[:, -1] = np.clip(b2[:, -1], 0, 0.2)
+            b2 = a2 + 0.25 * (b2 - a2)
+            sph = name == "spheres"
+            mv2 = irt.VoxelBackboneMotionValidator(chk)
+            gv, gt = mv2.check_motion_last_valid(a2, b2)
+            wl = [orc.check_motion_until_invalid(orb, og, a2[i], b2[i], None, env.inv_rotation, vc_spheres=sph) for i in range(ml)]
+            why2 = []
+            wv_ = np.array([w["is_fully_valid"] for w in wl]); wt_ = np.array([w["last_valid_t"] for w in wl])
+            # edges on which the reference's find_cell would throw (a backbone point outside the voxel domain) have no defined
+            # answer: the product reports them invalid; they are left out of the comparison
+            dom = np.array([orc.check_motion(orb, og, a2[i], b2[i], None, env.inv_rotation)["domain_error"] for i in range(ml)])
+            lok = np.array_equal(gv[~dom], wv_[~dom]) and np.array_equal(gt[~dom], wt_[~dom]) and not gv[dom].any()
+            if not lok:
+                j = np.flatnonzero(((gv != wv_) | (gt != wt_)) & ~dom)[:3]
+                why2.append(("last_valid", [(int(i), bool(gv[i]), bool(wv_[i]), float(gt[i]), float(wt_[i])) for i in j]))
+            dv = irt.VoxelBackboneDiscreteMotionValidator(chk)
+            gd = dv.check_motion_detail(a2, b2, last_valid=True)
+            wd = [orc.check_motion_discrete(orb, og, a2[i], b2[i], None, env.inv_rotation, until_invalid=True, vc_spheres=sph) for i in range(ml)]
+            dv_ = np.array([w["is_fully_valid"] for w in wd]); dt_ = np.array([w["last_valid_t"] for w in wd]); dn_ = np.array([w["n_fk"] for w in wd])
+            dok = np.array_equal(gd["valid"], dv_) and np.array_equal(gd["last_valid_t"], dt_) and np.array_equal(gd["n_fk"], dn_)
+            if not dok:
+                j = np.flatnonzero((gd["valid"] != dv_) | (gd["last_valid_t"] != dt_) | (gd["n_fk"] != dn_))[:3]
+                why2.append(("discrete", [(int(i), bool(gd["valid"][i]), bool(dv_[i]), float(gd["last_valid_t"][i]), float(dt_[i]), int(gd["n_fk"][i]), int(dn_[i])) for i in j]))
+            lok &= dok
+            msg.append("last_valid/discrete %s (%.2f) %s" % ("ok" if lok else "MISMATCH", float(np.mean(gv)), why2 if why2 else ""))
+            bad += not lok
         print("case %d: N=%d P=%d rot=%d ret=%d r=%.3f grid=%d %s | %s | %.1fs" % (
             case, len(robot.tendons), int(round(0.2 / robot.specs.dL)) + 1, robot.enable_rotation, robot.enable_retraction, robot.r, vox.Nx(),
             "rotated-env" if not np.allclose(env.inv_rotation, np.eye(3)) else "", "; ".join(msg), time.perf_counter() - t0), flush=True)
