@@ -181,3 +181,36 @@ def test_degenerate_inputs_of_the_sorted_search(irt):
     big[:, 0] = np.where(rng.random(6000) < 0.5, 1.0, 19.0)
     big[100:140] = big[99]                                      # a cluster of duplicates
     check(big, 11)
+
+
+@pytest.mark.parametrize("rot,ret", [(True, False), (False, True), (True, True)])
+def test_windowed_search_with_rotation_and_retraction_metrics(irt, orc, helpers, rot, ret):
+    """The sorted-coordinate search (seeding pass, windows, candidate slices: n >= 4096) under the compound metrics: the first
+    tension still bounds the distance from below, whatever the rotation / retraction terms add.  Sampled query rows against
+    a stable argsort of the oracle's distances to ALL states; the whole table against the search with another window."""
+    import os
+    W = irt.workloads
+    robot = W.robot_config2()
+    robot.enable_rotation, robot.enable_retraction = rot, ret
+    n, k = 6000, 10
+    st = W.random_states(robot, n, seed=83)
+    st[17] = st[16]                                            # an exact tie
+    eng = robot.engine()
+    idx, dist = eng.knn(st, k)
+    orb = helpers.oracle_robot(orc, robot)
+    f = orb.lib.orc_state_distance
+    rng = np.random.default_rng(3)
+    for q in list(rng.integers(0, n, 24)) + [16, 17]:
+        d = np.array([f(C.byref(orb.c), orc._dp(st[q]), orc._dp(st[j])) for j in range(n)])
+        want = np.argsort(d, kind="stable")[:k]
+        assert np.array_equal(idx[q], want), (q, idx[q], want)
+        assert np.abs(dist[q] - d[want]).max() <= 1e-12
+    os.environ["TENDON_HIP_KNN_HW_DIV"] = "4"
+    try:
+        idx2, dist2 = eng.knn(st, k)
+    finally:
+        os.environ.pop("TENDON_HIP_KNN_HW_DIV")
+    assert np.array_equal(idx, idx2) and np.array_equal(dist, dist2)
+    md = float(np.median(dist[:, 5]))
+    idx3, _ = eng.knn(st, k, max_distance=md)
+    assert np.array_equal(idx3 >= 0, dist <= md) and np.array_equal(idx3[idx3 >= 0], idx[dist <= md])
