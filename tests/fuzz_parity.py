@@ -119,7 +119,10 @@ def main():
                 wvalid = np.array([w["valid"] for w in we])
                 wdom = np.array([w["domain_error"] for w in we])               # find_cell would throw: the product reports the edge invalid and counts it
                 eok = np.array_equal(ge["valid"], wvalid) and np.array_equal(ge["n_fk"][wvalid], np.array([w["n_fk"] for w in we])[wvalid])
-                eok = eok and (ge["n_domain_errors"] > 0) == bool(wdom.any())
+                # (the COUNT of domain errors is a diagnostic that depends on the exploration order for edges that are invalid
+                # anyway -- the level-synchronous bisection drops an edge with an invalid end before it looks at cells -- so
+                # only its direction is checked: no domain error reported where the oracle sees none)
+                eok = eok and (ge["n_domain_errors"] == 0 or bool(wdom.any()))
                 msg.append("edges %s valid %.2f" % ("ok" if eok else "MISMATCH", wvalid.mean()))
                 bad += not eok
                 # voxel sets: vertices (add_piecewise_line of the shape) and edges (union over the bisection's samples)
@@ -154,6 +157,25 @@ def main():
                             cok = False; why.append(("elist", i, int(hi - lo), len(wi)))
                 msg.append("caches %s %s" % ("ok" if cok else "MISMATCH", why[:4] if why else ""))
                 bad += not cok
+                # roadmap forms (vertices evaluated once): indexed checkMotion, indexed voxel sets, and connect = both in one
+                # traversal -- against the pairwise forms just compared with the oracle
+                V = np.concatenate([a[:mc], b[:mc]])
+                eidx = np.stack([np.arange(mc), np.arange(mc) + mc], 1).astype(np.int32)
+                eidx = np.concatenate([eidx, eidx[::7, ::-1], [[3, 3]]])                 # + some reversed edges and a == b
+                gi = mv.check_motion_indexed(V, eidx)
+                gp = mv.check_motion_detail(V[eidx[:, 0]], V[eidx[:, 1]])
+                iok = np.array_equal(gi["valid"], gp["valid"]) and np.array_equal(gi["n_fk"], gp["n_fk"])
+                ci = chk.engine.voxelize_edges_indexed(V, eidx)
+                cp_ = chk.engine.voxelize_edges(V[eidx[:, 0]], V[eidx[:, 1]])
+                iok &= all(np.array_equal(ci[k_], cp_[k_]) for k_ in ("offsets", "block_ids", "masks", "fully_valid", "n_fk"))
+                rb = irt.RoadmapBuilder(chk, mv, seed=1)
+                e_ok, cc = rb.connect(V, eidx)
+                okm = gi["valid"]
+                iok &= np.array_equal(e_ok, eidx[okm]) and np.array_equal(cc["n_fk"], gi["n_fk"][okm])
+                sel = np.concatenate([np.arange(ci["offsets"][e], ci["offsets"][e + 1]) for e in np.flatnonzero(okm)]) if okm.any() else np.zeros(0, int)
+                iok &= np.array_equal(cc["block_ids"], ci["block_ids"][sel]) and np.array_equal(cc["masks"], ci["masks"][sel])
+                msg.append("indexed/connect %s" % ("ok" if iok else "MISMATCH"))
+                bad += not iok
             # the last_valid and discrete forms ask the installed checker about every sample
             ml = 80
             a2 = st[:ml].copy(); b2 = st[ml:2 * ml].copy()
