@@ -149,6 +149,27 @@ class RoadmapBuilder:
         self.timing["create_roadmap"] = dict(seconds=time.perf_counter() - t0, vertices=len(states), candidate_edges=len(cand), edges=len(edges))
         return prm, dict(states=states, tips=tips, edges=edges, vertex_caches=vc, edge_caches=ec)
 
+    def save_rmp(self, path, roadmap, weights=None):
+        """Write the dict create_roadmap returns (states, tips, edges, vertex_caches, edge_caches; lists on the host or on the
+        device) as a `.rmp` file the reference's loaders read (rmp.write_rmp)."""
+        from . import rmp
+
+        def host(c):
+            if type(c["block_ids"]).__module__.startswith("torch"):
+                c = dict(c, block_ids=c["block_ids"].cpu().numpy().view(np.uint32), masks=c["masks"].cpu().numpy().view(np.uint64))
+            pres = next((c[k] for k in ("present", "shape_valid", "fully_valid") if k in c and c[k] is not None), None)
+            return dict(offsets=c["offsets"], block_ids=c["block_ids"], masks=c["masks"],
+                        present=np.ones(len(c["offsets"]) - 1, bool) if pres is None else np.asarray(pres, bool))
+        st, e = roadmap["states"], roadmap["edges"]
+        if weights is None:                                  # connectVertices stores the motion cost = state-space distance (:2857-2861)
+            scale = self.state_space_metric_scale()
+            if self.robot.enable_rotation or self.robot.enable_retraction:
+                raise NotImplementedError("pass the edge weights for a space with rotation / retraction")
+            weights = np.linalg.norm((st[e[:, 0]] - st[e[:, 1]]) * scale, axis=1)
+        vox = self.checker._voxels
+        rmp.write_rmp(path, st, roadmap.get("tips"), e, weights, host(roadmap["vertex_caches"]), host(roadmap["edge_caches"]),
+                      N=vox.Nx(), limits=vox.limits())
+
     def edge_caches(self, states, edges, device=False):
         t0 = time.perf_counter()
         out = self.engine.voxelize_edges_indexed(states, edges, self.mv.min_tension_change,
@@ -228,6 +249,20 @@ class VoxelCachedLazyPRM:
             raise L._EXC.get(st, L.TendonHipError)("tr_roadmap_create failed (status %d)" % st)
         self._rm = rm
         self.stats = None
+
+    @classmethod
+    def from_rmp(cls, checker, path, n_landmarks=16):
+        """A roadmap file with voxel caches (`.rmp`, rmp.read_rmp: the layout of RmpStreamer / LazyRmpParser) as a query
+        object: what fromRoadmapParser builds (motion-planning/VoxelCachedLazyPRM.cpp:2357-2580), without the octrees."""
+        from . import rmp
+        d = rmp.read_rmp(path)
+        if d["vertex_caches"] is None or d["edge_caches"] is None:
+            raise ValueError("%s holds no voxel caches" % path)
+        prm = cls(checker, d["states"], d["edges"], weights=d["weights"])
+        prm.set_caches(d["vertex_caches"], d["edge_caches"])
+        if n_landmarks:
+            prm.prepare(n_landmarks)
+        return prm
 
     def _check(self, st):
         if st != self._L.TR_OK:

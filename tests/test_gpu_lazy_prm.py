@@ -270,3 +270,31 @@ def test_landmark_bounds_on_awkward_graphs(irt):
     lone.prepare(16)
     o = lone.solveWithRoadmap(np.arange(10).repeat(8), np.tile(np.arange(8), 10))
     assert ((o["status"] == 0) == (np.arange(10).repeat(8) == np.tile(np.arange(8), 10))).all()
+
+
+def test_roadmap_file_round_trip_into_the_query_loop(irt, tmp_path):
+    """create_roadmap -> .rmp file (rmp.write_rmp: the reference's roadmap file layout) -> VoxelCachedLazyPRM.from_rmp: the
+    loaded roadmap answers a batch of queries in a changed environment exactly like the one it was written from."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=80)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=4)
+    prm, rm = rb.create_roadmap(900, k=5, batch=4096, device=True)
+    path = str(tmp_path / "roadmap.rmp")
+    rb.save_rmp(path, rm)
+    back = irt.rmp.read_rmp(path)
+    assert np.array_equal(back["states"], rm["states"]) and np.array_equal(back["edges"], rm["edges"])
+    assert np.array_equal(back["edge_caches"]["block_ids"], rm["edge_caches"]["block_ids"].cpu().numpy().view(np.uint32))
+    assert np.allclose(back["tips"], rm["tips"], rtol=0, atol=0)
+    loaded = irt.VoxelCachedLazyPRM.from_rmp(chk, path)
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=92)
+    rng = np.random.default_rng(2)
+    starts, goals = rng.integers(0, 900, 200), rng.integers(0, 900, 200)
+    outs = []
+    for p in (prm, loaded):
+        p.set_obstacles(new_vox)
+        outs.append(p.solveWithRoadmap(starts, goals))
+    a, b = outs
+    assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["path_vertices"], b["path_vertices"])
+    assert np.allclose(a["cost"], b["cost"], rtol=1e-15, atol=0) and (a["status"] == 0).sum() > 50
