@@ -378,3 +378,46 @@ def test_error_paths_of_the_batch_entry_points(irt):
     assert out["offsets"].tolist() == [0] and out["block_ids"].size == 0
     # after all that the context still works
     assert eng.validate_batch(st, False, False)["valid"].shape == (8,)
+
+
+def test_contexts_on_concurrent_host_threads(irt):
+    """One context per host thread, every family of call at once (ctypes releases the GIL for the duration of a call): the
+    contexts share nothing -- results equal those of the same work done one thread after the other."""
+    import threading
+    W = irt.workloads
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+
+    def work(t):
+        robot = W.robot_config3() if t % 2 else W.robot_config2()
+        chk = (irt.VoxelValidityChecker if t == 3 else irt.VoxelBackboneValidityChecker)(robot, irt.VoxelEnvironment(), vox)
+        mv = irt.VoxelBackboneMotionValidator(chk)
+        rb = irt.RoadmapBuilder(chk, mv, seed=t)
+        st = W.random_states(robot, 6000, seed=40 + t, tau_max=12.0)
+        out = []
+        for _ in range(3):
+            v = chk.is_valid(st)
+            e = rb.knn_edges_gpu(st, 7)[:6000]
+            ev, nf = rb.validate_edges(st, e)
+            e_ok, ec = rb.connect(st, e[:1500])
+            prm = irt.VoxelCachedLazyPRM(chk, st, e_ok)
+            prm.set_caches(rb.vertex_caches(st), ec)
+            q = prm.solveWithRoadmap(np.arange(100), np.arange(100, 200), n_threads=2)
+            out.append((v.tobytes(), e.tobytes(), ev.tobytes(), nf.tobytes(), e_ok.tobytes(), ec["masks"].tobytes(), q["status"].tobytes(), q["cost"].tobytes()))
+        assert out[0] == out[1] == out[2]
+        return out[0]
+
+    serial = [work(t) for t in range(4)]
+    res, err = [None] * 4, []
+
+    def run(t):
+        try:
+            res[t] = work(t)
+        except Exception as e:                                   # noqa: BLE001
+            err.append((t, repr(e)))
+    ths = [threading.Thread(target=run, args=(t,)) for t in range(4)]
+    for th in ths:
+        th.start()
+    for th in ths:
+        th.join()
+    assert not err, err
+    assert res == serial
