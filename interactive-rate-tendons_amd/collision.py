@@ -182,6 +182,48 @@ class VoxelOctree:
             raise L.InvalidArgument("voxel dimension mismatch (%d != %d)" % (self._N, other._N))
         self.blocks |= other.blocks
 
+    # set operations on whole blocks / voxel sets (VoxelOctree.cpp:224-249, 980-996); the block forms return the OLD value
+    def union_block(self, bx, by, bz, value):
+        old = int(self.blocks[bx, by, bz]); self.blocks[bx, by, bz] = np.uint64(old | int(value)); return old
+
+    def intersect_block(self, bx, by, bz, value):
+        old = int(self.blocks[bx, by, bz]); self.blocks[bx, by, bz] = np.uint64(old & int(value)); return old
+
+    def subtract_block(self, bx, by, bz, value):
+        return self.intersect_block(bx, by, bz, ~int(value) & 0xFFFFFFFFFFFFFFFF)
+
+    def remove_point(self, p):
+        x, y, z = map(float, p)
+        if self.is_in_domain(x, y, z):
+            self.set_cell(*self.nearest_cell(x, y, z), False)
+
+    def _same_size(self, other):
+        if other._N != self._N:
+            raise L.InvalidArgument("voxel dimension mismatch (%d != %d)" % (self._N, other._N))
+
+    def remove_voxels(self, other):
+        self._same_size(other)
+        self.blocks &= ~other.blocks
+
+    def intersect_voxels(self, other):
+        self._same_size(other)
+        self.blocks &= other.blocks
+
+    def visit_leaves(self, visitor):
+        """visitor(bx, by, bz, block) for every non-empty block, in block order (VoxelOctree.cpp:998-1001)."""
+        for bx, by, bz in np.argwhere(self.blocks != 0):
+            visitor(int(bx), int(by), int(bz), int(self.blocks[bx, by, bz]))
+
+    def occupied_voxels(self):
+        """(n, 3) cell indices of the occupied voxels (visit_occupied_voxels, :1013-1017)."""
+        ids = np.argwhere(self.blocks != 0)
+        out = []
+        for bx, by, bz in ids:
+            v = int(self.blocks[bx, by, bz])
+            bits = np.flatnonzero([(v >> k) & 1 for k in range(64)])
+            out.append(np.stack([4 * bx + bits // 16, 4 * by + (bits // 4) % 4, 4 * bz + bits % 4], 1))
+        return np.concatenate(out) if out else np.zeros((0, 3), dtype=np.int64)
+
     def collides(self, other):
         """Host form of VoxelOctree::collides (VoxelOctree.cpp:967-978) for small checks in tests."""
         if isinstance(other, VoxelOctree):

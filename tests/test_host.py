@@ -345,3 +345,31 @@ def test_rmp_byte_layout_and_roundtrip(irt, tmp_path):
     r3 = rmp.read_rmp(str(h))
     assert r3["vertex_caches"] is None and np.array_equal(r3["tips"][1], [0.4, 0.5, 0.6])
     assert h.stat().st_size == 9 + 2 * (8 + 24 + 1 + 24) + 16
+
+
+def test_voxel_octree_set_operations(irt):
+    """union / intersect / subtract_block return the old value; remove_point, remove_voxels, intersect_voxels, the leaf and
+    occupied-voxel visitors (collision/VoxelOctree.cpp:224-249, 980-1017)."""
+    V = irt.VoxelOctree
+    a = V(16); a.set_xlim(-1, 1); a.set_ylim(-1, 1); a.set_zlim(-1, 1)
+    b = a.empty_copy()
+    a.add_sphere([0.1, 0.0, 0.0], 0.4); b.add_sphere([-0.2, 0.1, 0.0], 0.35)
+    both = a.empty_copy(); both.add_voxels(a); both.intersect_voxels(b)
+    only_a = a.empty_copy(); only_a.add_voxels(a); only_a.remove_voxels(b)
+    assert both.ncells() + only_a.ncells() == a.ncells() and 0 < both.ncells() < a.ncells()
+    assert not only_a.collides(b) and both.collides(a) and both.collides(b)
+    old = a.block(1, 1, 1)
+    assert a.union_block(1, 1, 1, 0xF0) == old and a.block(1, 1, 1) == old | 0xF0
+    assert a.intersect_block(1, 1, 1, 0xFF) == old | 0xF0 and a.block(1, 1, 1) == (old | 0xF0) & 0xFF
+    assert a.subtract_block(1, 1, 1, 0x0F) == (old | 0xF0) & 0xFF and a.block(1, 1, 1) == (old | 0xF0) & 0xF0
+    c = a.empty_copy(); c.add_point([0.3, 0.3, 0.3])
+    assert c.ncells() == 1
+    c.remove_point([5.0, 0.0, 0.0]); assert c.ncells() == 1            # outside the domain: ignored
+    c.remove_point([0.3, 0.3, 0.3]); assert c.is_empty()
+    seen = []
+    both.visit_leaves(lambda bx, by, bz, v: seen.append((bx, by, bz, v)))
+    assert len(seen) == both.nblocks() and all(both.block(x, y, z) == v for x, y, z, v in seen)
+    occ = both.occupied_voxels()
+    assert len(occ) == both.ncells() and all(both.cell(*ix) for ix in occ[:50])
+    with pytest.raises(irt.InvalidArgument):
+        a.remove_voxels(V(32))
