@@ -191,6 +191,52 @@ class TendonRobot:
         hi = np.array([t.max_length for t in self.tendons])
         return bool(np.all(~((dl < lo) | (hi < dl))))
 
+    def shape_and_lengths(self, state, home_shape=None, device=0):     # TendonRobot.h:231-247
+        """(shape(state), dl = home L_i - shape L_i): what is_valid compares with the tendons' length limits."""
+        st = np.asarray(state, float).reshape(-1)
+        home = home_shape if home_shape is not None else self.home_shape(float(st[-1]) if self.enable_retraction else 0.0, device)
+        sh = self.shape(st, device)
+        return sh, self.calc_dl(home.L_i, sh.L_i)
+
+    def random_state(self, rng=None):                                  # TendonRobot.cpp:219-246
+        """Uniform in the state space: tensions in [0, max_tension], rotation in [-pi, pi], retraction in [0, L]."""
+        rng = np.random.default_rng() if rng is None else rng
+        st = [rng.uniform(0.0, t.max_tension) for t in self.tendons]
+        if self.enable_rotation:
+            st.append(rng.uniform(-np.pi, np.pi))
+        if self.enable_retraction:
+            st.append(rng.uniform(0.0, self.specs.L))
+        return np.array(st)
+
+    def read_config_csv(self, stream):                                 # TendonRobot.cpp:976-1002
+        """Robot states from a CSV with a header: columns tau_1 .. tau_N (+ theta with rotation, + s_start with retraction),
+        in any order and among other columns -- the input of the reference's batch tools; returns (n, state_size)."""
+        import csv
+        rd = csv.reader(stream)
+        header = [h.strip() for h in next(rd)]
+        names = ["tau_%d" % (i + 1) for i in range(len(self.tendons))]
+        if self.enable_rotation:
+            names.append("theta")
+        if self.enable_retraction:
+            names.append("s_start")
+        try:
+            idx = [header.index(nm) for nm in names]
+        except ValueError as e:
+            raise L.OutOfRange("missing CSV column: %s" % e)
+        rows = [[float(r[i]) for i in idx] for r in rd if r]
+        return np.array(rows, dtype=np.float64).reshape(len(rows), len(names))
+
+    def load_config_csv(self, path):                                   # TendonRobot.cpp:1004-1010
+        with open(path, newline="") as f:
+            return self.read_config_csv(f)
+
+    def __eq__(self, other):                                           # TendonRobot.h:280-286
+        return (isinstance(other, TendonRobot) and self.r == other.r and self.specs == other.specs and self.tendons == other.tendons
+                and self.enable_rotation == other.enable_rotation and self.enable_retraction == other.enable_retraction
+                and self.residual_threshold == other.residual_threshold)
+
+    __hash__ = object.__hash__
+
     # ---- batched API ---------------------------------------------------------------------------
     def shape_batch(self, states, want_R=False, device=0):
         """Batched shape(): dict(p (n,P,3), R, L, L_i, converged, n_points)."""

@@ -373,3 +373,28 @@ def test_voxel_octree_set_operations(irt):
     assert len(occ) == both.ncells() and all(both.cell(*ix) for ix in occ[:50])
     with pytest.raises(irt.InvalidArgument):
         a.remove_voxels(V(32))
+
+
+def test_robot_states_from_csv_and_random_state(irt, tmp_path):
+    """TendonRobot::read_config_csv / load_config_csv (tendon/TendonRobot.cpp:976-1010): the input of the reference's batch FK
+    tools; random_state stays inside the state space; operator==."""
+    import io
+    robot = irt.workloads.robot_config2()
+    robot.enable_rotation = True
+    txt = "i,theta,tau_2,extra,tau_1,tau_3\n0,0.5,2.0,x,1.0,3.0\n1,-1.25,5.5,y,4.5,6.5\n\n"
+    got = robot.read_config_csv(io.StringIO(txt))
+    assert np.array_equal(got, [[1.0, 2.0, 3.0, 0.5], [4.5, 5.5, 6.5, -1.25]])
+    p = tmp_path / "configs.csv"
+    p.write_text(txt)
+    assert np.array_equal(robot.load_config_csv(str(p)), got)
+    with pytest.raises(irt.OutOfRange):
+        robot.read_config_csv(io.StringIO("tau_1,tau_2\n1,2\n"))
+    rng = np.random.default_rng(0)
+    robot.enable_retraction = True
+    st = np.array([robot.random_state(rng) for _ in range(200)])
+    assert st.shape == (200, 5) and (st[:, :3] >= 0).all() and (st[:, :3] <= 20.0).all()
+    assert (np.abs(st[:, 3]) <= np.pi).all() and (st[:, 4] >= 0).all() and (st[:, 4] <= robot.specs.L).all()
+    same = irt.workloads.robot_config2(); other = irt.workloads.robot_config2()
+    assert same == other
+    other.tendons[1].max_tension = 7.0
+    assert same != other
