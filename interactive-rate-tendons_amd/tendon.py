@@ -198,6 +198,34 @@ class TendonRobot:
         sh = self.shape(st, device)
         return sh, self.calc_dl(home.L_i, sh.L_i)
 
+    def collides_self(self, shape, device=0):                          # TendonRobot.h:229, collision/collision.cpp:6-46
+        """collision::collides_self of one shape (a TendonResult or a (P, 3) point array with this robot's point count): the
+        exact capsule sweep of the validity predicate, run on the GPU over the given points (tr_validate_shapes_dev)."""
+        import torch
+        if self.enable_retraction:
+            raise L.Unsupported("collides_self of a given shape: robots with retraction have per-shape point counts (use is_valid)")
+        eng = self.engine(device)
+        P, N = eng.num_points, eng.n_tendons
+        pts = np.asarray(shape.p if hasattr(shape, "p") else shape, dtype=np.float64)
+        if pts.shape != (P, 3):
+            raise L.InvalidArgument("the shape must have this robot's %d backbone points" % P)
+        dev = "cuda:%d" % eng.device
+        planes = torch.zeros((3, P, 64), dtype=torch.float64, device=dev)
+        planes[:, :, 0] = torch.from_numpy(np.ascontiguousarray(pts.T)).to(dev)
+        # tendon lengths that pass the length limits whatever they are, so that the flags report the self-collision test
+        lo = np.array([t.min_length for t in self.tendons]); hi = np.array([t.max_length for t in self.tendons])
+        Li = torch.zeros((N, 64), dtype=torch.float64, device=dev)
+        Li[:, 0] = torch.from_numpy(eng.home_lengths() - np.clip(0.0, lo, hi)).to(dev)
+        conv = torch.ones(64, dtype=torch.uint8, device=dev)
+        bits = torch.zeros(1, dtype=torch.int64, device=dev)
+        flags = torch.zeros(64, dtype=torch.uint8, device=dev)
+        eng.validate_shapes_dev(1, 64, planes[0], planes[1], planes[2], Li, conv, bits, flags, check_voxels=False)
+        torch.cuda.synchronize(eng.device)
+        fl = int(flags[0].item())
+        if not (fl & 2):
+            raise L.TendonHipError("internal: the length limits rejected the stand-in lengths")
+        return not (fl & 4)
+
     def random_state(self, rng=None):                                  # TendonRobot.cpp:219-246
         """Uniform in the state space: tensions in [0, max_tension], rotation in [-pi, pi], retraction in [0, L]."""
         rng = np.random.default_rng() if rng is None else rng

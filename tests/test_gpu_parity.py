@@ -211,6 +211,17 @@ def test_self_collision_cases(irt, orc, helpers):
     conv_len = (got["flags"] & 3) == 3
     assert np.array_equal(got_self[conv_len], want_self[conv_len])
     assert want_self[conv_len].sum() > 20 and (~want_self[conv_len]).sum() > 20
+    # TendonRobot::collides_self(shape) on single shapes, whatever the length limits are
+    for t in robot.tendons:
+        t.min_length, t.max_length = 0.01, 0.02                        # the home lengths themselves would fail these
+    tight = W.robot_config1()
+    tight.specs.dL, tight.r = robot.specs.dL, robot.r
+    for t in tight.tendons:
+        t.min_length, t.max_length = 0.01, 0.02
+    for i in list(np.flatnonzero(want_self & conv_len)[:6]) + list(np.flatnonzero(~want_self & conv_len)[:6]):
+        assert tight.collides_self(fk["p"][i]) == bool(want_self[i])
+    with pytest.raises(irt.InvalidArgument):
+        tight.collides_self(fk["p"][0][:50])
 
 
 def test_empty_and_error_paths(irt):
