@@ -55,6 +55,67 @@ class VoxelEnvironment:                    # motion-planning/VoxelEnvironment.h:
             self._obstacle_cache = VoxelOctree.from_file(self.filename)
         return self._obstacle_cache
 
+    # ---- the [voxel_environment] table of the reference's problem files (VoxelEnvironment.cpp:17-103): filename (or the voxel
+    # set inline), interior_filename, scaling, translation, rotation_quat = (w, x, y, z) of inv_rotation ----------------------
+    @staticmethod
+    def _quat_from_matrix(R):
+        """Unit quaternion (w, x, y, z) of a rotation matrix, largest component first (the branch structure every
+        matrix-to-quaternion conversion uses; q and -q are the same rotation)."""
+        R = np.asarray(R, float)
+        t = R[0, 0] + R[1, 1] + R[2, 2]
+        if t > 0:
+            s = 0.5 / np.sqrt(t + 1.0)
+            q = [0.25 / s, (R[2, 1] - R[1, 2]) * s, (R[0, 2] - R[2, 0]) * s, (R[1, 0] - R[0, 1]) * s]
+        else:
+            i = int(np.argmax([R[0, 0], R[1, 1], R[2, 2]]))
+            j, k = (i + 1) % 3, (i + 2) % 3
+            s = 2.0 * np.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0)
+            v = [0.0, 0.0, 0.0]
+            v[i] = 0.25 * s; v[j] = (R[j, i] + R[i, j]) / s; v[k] = (R[k, i] + R[i, k]) / s
+            q = [(R[k, j] - R[j, k]) / s] + v
+        return np.array(q)
+
+    @staticmethod
+    def _matrix_from_quat(q):
+        w, x, y, z = (float(c) for c in q)
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                         [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+    def to_toml(self):
+        f = lambda x: repr(float(x))
+        arr = lambda a: "[" + ", ".join(f(x) for x in a) + "]"
+        out = ["[voxel_environment]"]
+        inline = ""
+        if not self.filename and self._obstacle_cache is not None:
+            inline = self._obstacle_cache.to_toml()              # the voxel set stored in the file itself (:27-33)
+        else:
+            out.append('filename = "%s"' % self.filename)
+        out += ['interior_filename = "%s"' % self.interior_fname, "scaling = " + f(self.scaling), "translation = " + arr(self.translation),
+                "rotation_quat = " + arr(self._quat_from_matrix(self.inv_rotation)), ""]
+        return "\n".join(out) + ("\n" + inline if inline else "")
+
+    @classmethod
+    def from_toml(cls, tbl):
+        """`tbl`: the parsed table (tomli) or a path; either the top-level table holding [voxel_environment] or that table."""
+        if isinstance(tbl, str):
+            import tomli
+            with open(tbl, "rb") as fh:
+                tbl = tomli.load(fh)
+        top = tbl
+        if "voxel_environment" in tbl:
+            tbl = tbl["voxel_environment"]
+        env = cls()
+        if "filename" in tbl:
+            env.filename = str(tbl["filename"])
+        else:
+            env.set_obstacle_cache(VoxelOctree.from_toml(top))
+        env.scaling = float(tbl["scaling"])
+        env.translation = np.array([float(x) for x in tbl["translation"]])
+        env.inv_rotation = cls._matrix_from_quat(tbl["rotation_quat"])
+        env.interior_fname = str(tbl.get("interior_filename", ""))
+        return env
+
     def rotate_point(self, p):             # VoxelEnvironment.cpp:125-127
         return np.asarray(self.inv_rotation, float) @ np.asarray(p, float)
 

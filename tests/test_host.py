@@ -398,3 +398,30 @@ def test_robot_states_from_csv_and_random_state(irt, tmp_path):
     assert same == other
     other.tendons[1].max_tension = 7.0
     assert same != other
+
+
+def test_voxel_environment_table_round_trip(irt, tmp_path):
+    """[voxel_environment] of the reference's problem files (motion-planning/VoxelEnvironment.cpp:17-103): rotation as a
+    quaternion (w, x, y, z), obstacles by file name or inline."""
+    import tomli
+    a, b, c = 0.7, -0.4, 1.9
+    Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    Ry = np.array([[np.cos(c), 0, np.sin(c)], [0, 1, 0], [-np.sin(c), 0, np.cos(c)]])
+    for R in (np.eye(3), Rz, Rz @ Rx, Ry @ Rz @ Rx, np.diag([1.0, -1.0, -1.0]), np.diag([-1.0, -1.0, 1.0])):
+        env = irt.VoxelEnvironment(filename="obstacles.msgpack", scaling=1.5, translation=np.array([0.1, -0.2, 0.3]), inv_rotation=R,
+                                   interior_fname="inside.nrrd")
+        back = irt.VoxelEnvironment.from_toml(tomli.loads(env.to_toml()))
+        assert back.filename == "obstacles.msgpack" and back.interior_fname == "inside.nrrd" and back.scaling == 1.5
+        assert np.array_equal(back.translation, env.translation) and np.abs(back.inv_rotation - R).max() < 1e-15
+        q = irt.VoxelEnvironment._quat_from_matrix(R)
+        assert abs(np.linalg.norm(q) - 1) < 1e-15
+    vox = irt.VoxelOctree(16)
+    vox.set_xlim(-1, 1); vox.set_ylim(-1, 1); vox.set_zlim(-1, 1)
+    vox.add_sphere([0.2, 0.1, -0.3], 0.4)
+    env = irt.VoxelEnvironment(inv_rotation=Rz)
+    env.set_obstacle_cache(vox)
+    p = tmp_path / "problem.toml"
+    p.write_text(env.to_toml())
+    back = irt.VoxelEnvironment.from_toml(str(p))
+    assert back.filename == "" and back.get_obstacles() == vox and np.abs(back.inv_rotation - Rz).max() < 1e-15
