@@ -15,13 +15,13 @@ from .engine import Engine, unpack_bits
 from .tendon import BackboneSpecs, TendonSpecs, TendonResult, TendonRobot
 from .collision import VoxelOctree
 from .motion_planning import (VoxelEnvironment, VoxelBackboneValidityChecker, VoxelValidityChecker, VoxelBackboneMotionValidator,
-                              VoxelBackboneDiscreteMotionValidator, FunctionTimer)
+                              VoxelBackboneDiscreteMotionValidator, FunctionTimer, Environment, Problem)
 from . import workloads, distributed, roadmap, rmp, tip_control
 from .roadmap import RoadmapBuilder, VoxelCachedLazyPRM
 
 __all__ = [
     "TendonHipError", "InvalidArgument", "OutOfRange", "DomainError", "LengthError", "HipError", "Unsupported",
     "build", "LIB_PATH", "Engine", "unpack_bits", "BackboneSpecs", "TendonSpecs", "TendonResult", "TendonRobot",
-    "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelValidityChecker", "VoxelBackboneMotionValidator", "VoxelBackboneDiscreteMotionValidator",
+    "VoxelOctree", "VoxelEnvironment", "VoxelBackboneValidityChecker", "VoxelValidityChecker", "VoxelBackboneMotionValidator", "VoxelBackboneDiscreteMotionValidator", "Environment", "Problem",
     "FunctionTimer", "workloads", "distributed", "roadmap", "RoadmapBuilder", "VoxelCachedLazyPRM", "tip_control",
 ]

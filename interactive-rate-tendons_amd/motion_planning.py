@@ -265,3 +265,135 @@ class VoxelBackboneDiscreteMotionValidator(VoxelBackboneMotionValidator):
     def check_motion_last_valid(self, a, b):
         d = self.check_motion_detail(a, b, last_valid=True)
         return d["valid"], d["last_valid_t"]
+
+
+class Environment:
+    """motion_planning::Environment (motion-planning/Environment.h): the obstacle primitives of a problem file -- points, spheres
+    (centre, radius), capsules (a, b, radius); meshes are kept as their tables (rasterising them needs FCL / ITK and is out of
+    scope).  `voxelize` is Environment::voxelize (Environment.cpp:62-100): an empty copy of the reference grid with every
+    primitive rasterised -- on the host mirror, or straight into a checker's resident grid."""
+
+    def __init__(self, points=(), spheres=(), capsules=(), meshes=()):
+        self.points = [np.asarray(p, float) for p in points]
+        self.spheres = [(np.asarray(c, float), float(r)) for c, r in spheres]
+        self.capsules = [(np.asarray(a, float), np.asarray(b, float), float(r)) for a, b, r in capsules]
+        self.meshes = list(meshes)
+
+    def to_toml(self):
+        f = lambda x: repr(float(x))
+        arr = lambda a: "[" + ", ".join(f(x) for x in a) + "]"
+        out = ["[environment]", ""]
+        for p in self.points:
+            out += ["[[environment.points]]", "point = " + arr(p), ""]
+        for c, r in self.spheres:
+            out += ["[[environment.spheres]]", "[environment.spheres.sphere]", "radius = " + f(r), "center = " + arr(c), ""]
+        for a, b, r in self.capsules:
+            out += ["[[environment.capsules]]", "[environment.capsules.capsule]", "radius = " + f(r), "a = " + arr(a), "b = " + arr(b), ""]
+        return "\n".join(out)
+
+    @classmethod
+    def from_toml(cls, tbl):
+        if isinstance(tbl, str):
+            import tomli
+            with open(tbl, "rb") as fh:
+                tbl = tomli.load(fh)
+        tbl = tbl.get("environment", tbl)
+        inner = lambda t, key: t.get(key, t)
+        return cls(points=[t["point"] for t in tbl.get("points", [])],
+                   spheres=[(inner(t, "sphere")["center"], inner(t, "sphere")["radius"]) for t in tbl.get("spheres", [])],
+                   capsules=[(inner(t, "capsule")["a"], inner(t, "capsule")["b"], inner(t, "capsule")["radius"]) for t in tbl.get("capsules", [])],
+                   meshes=tbl.get("meshes", []))
+
+    def _rows(self):
+        sph = [list(p) + [0.0] for p in self.points] + [list(c) + [r] for c, r in self.spheres]       # a point is add_point = a sphere of radius 0
+        cap = [list(a) + list(b) + [r] for a, b, r in self.capsules]
+        return np.array(sph, float).reshape(-1, 4), np.array(cap, float).reshape(-1, 7)
+
+    def voxelize(self, reference: VoxelOctree):
+        if self.meshes:
+            raise L.Unsupported("mesh obstacles are not rasterised here")
+        v = reference.empty_copy()
+        for p in self.points:
+            v.add_point(p)
+        for c, r in self.spheres:
+            v.add_sphere(c, r)
+        for a, b, r in self.capsules:
+            v.add_capsule(a, b, r)
+        return v
+
+    def voxelize_into(self, checker, clear=True):
+        """The same on the checker's resident grid (tr_grid_add_spheres / tr_grid_add_capsules)."""
+        if self.meshes:
+            raise L.Unsupported("mesh obstacles are not rasterised here")
+        if clear:
+            vox = checker._voxels
+            checker.engine.set_grid(vox.Nx(), vox.limits(), np.zeros_like(vox.blocks), checker._venv.inv_rotation)
+        sph, cap = self._rows()
+        if len(sph):
+            checker.add_spheres(sph)
+        if len(cap):
+            checker.add_capsules(cap)
+
+
+class Problem:
+    """motion_planning::Problem (motion-planning/Problem.h:41-95, Problem.cpp:420-560): the planner's input file -- robot,
+    obstacle primitives, voxel environment, start and goal, the state-space resolutions of the motion validator."""
+
+    def __init__(self, robot=None, env=None, venv=None, start=(), goal=(), min_tension_change=0.02, min_rotation_change=0.01,
+                 min_retraction_change=0.0001, start_rotation=0.0, start_retraction=0.0, goal_rotation=0.0, goal_retraction=0.0,
+                 sample_like_sphere=True):
+        self.robot = robot if robot is not None else TendonRobot()
+        self.env = env if env is not None else Environment()
+        self.venv = venv if venv is not None else VoxelEnvironment()
+        self.start, self.goal = [float(x) for x in start], [float(x) for x in goal]
+        self.min_tension_change, self.min_rotation_change, self.min_retraction_change = min_tension_change, min_rotation_change, min_retraction_change
+        self.start_rotation, self.start_retraction, self.goal_rotation, self.goal_retraction = start_rotation, start_retraction, goal_rotation, goal_retraction
+        self.sample_like_sphere = sample_like_sphere
+
+    def _state(self, tau, rot, ret):                      # Problem.h:70-83
+        st = list(tau)
+        if self.robot.enable_rotation:
+            st.append(rot)
+        if self.robot.enable_retraction:
+            st.append(ret)
+        return np.array(st, float)
+
+    def start_state(self): return self._state(self.start, self.start_rotation, self.start_retraction)
+    def goal_state(self): return self._state(self.goal, self.goal_rotation, self.goal_retraction)
+
+    def to_toml(self):
+        f = lambda x: repr(float(x))
+        arr = lambda a: "[" + ", ".join(f(x) for x in a) + "]"
+        out = ["[problem]", "start = " + arr(self.start), "goal = " + arr(self.goal), "min_tension_change = " + f(self.min_tension_change),
+               "min_rotation_change = " + f(self.min_rotation_change), "min_retraction_change = " + f(self.min_retraction_change),
+               "start_rotation = " + f(self.start_rotation), "start_retraction = " + f(self.start_retraction),
+               "goal_rotation = " + f(self.goal_rotation), "goal_retraction = " + f(self.goal_retraction),
+               "sample_like_sphere = " + str(bool(self.sample_like_sphere)).lower(), ""]
+        return "\n".join(out) + "\n" + self.robot.to_toml() + "\n" + self.env.to_toml() + "\n" + self.venv.to_toml()
+
+    @classmethod
+    def from_toml(cls, tbl):
+        if isinstance(tbl, str):
+            import tomli
+            with open(tbl, "rb") as fh:
+                tbl = tomli.load(fh)
+        pt = tbl["problem"]
+        robot = TendonRobot.from_toml(tbl)
+        for key, flag in (("start_rotation", robot.enable_rotation), ("goal_rotation", robot.enable_rotation),
+                          ("start_retraction", robot.enable_retraction), ("goal_retraction", robot.enable_retraction)):
+            if flag and key not in pt:
+                raise L.OutOfRange("Must specify %s if %s is enabled" % (key, "rotation" if "rotation" in key else "retraction"))
+        return cls(robot=robot, env=Environment.from_toml(tbl), venv=VoxelEnvironment.from_toml(tbl) if "voxel_environment" in tbl else None,
+                   start=pt["start"], goal=pt["goal"], min_tension_change=float(pt["min_tension_change"]),
+                   min_rotation_change=float(pt.get("min_rotation_change", 0.01)), min_retraction_change=float(pt.get("min_retraction_change", 0.0001)),
+                   start_rotation=float(pt.get("start_rotation", 0.0)), start_retraction=float(pt.get("start_retraction", 0.0)),
+                   goal_rotation=float(pt.get("goal_rotation", 0.0)), goal_retraction=float(pt.get("goal_retraction", 0.0)),
+                   sample_like_sphere=bool(pt.get("sample_like_sphere", True)))
+
+    def voxel_backbone_checker(self, voxels=None, device=0, spheres=False):
+        """Problem::set_voxel_backbone_state_checker / set_voxel_state_checker (Problem.h:175-216): the state checker over the voxel
+        environment's obstacles and the motion validator with this problem's resolutions -> (checker, motion validator)."""
+        vox = voxels if voxels is not None else self.venv.get_obstacles()
+        chk = (VoxelValidityChecker if spheres else VoxelBackboneValidityChecker)(self.robot, self.venv, vox, device)
+        mv = VoxelBackboneMotionValidator(chk, self.min_tension_change, self.min_rotation_change, self.min_retraction_change)
+        return chk, mv

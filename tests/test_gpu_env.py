@@ -133,3 +133,40 @@ def test_environment_edits_on_an_anisotropic_grid(irt, orc):
     g.dilate_sphere(0.02)
     g.remove_interior(False)
     assert np.array_equal(chk.engine.get_grid(), np.asarray(g.blocks()).ravel()) and np.count_nonzero(chk.engine.get_grid()) > 200
+
+
+def test_problem_environment_on_the_device(irt, orc, tmp_path):
+    """A problem file's obstacle primitives rasterised straight into a checker's resident grid (Environment::voxelize,
+    motion-planning/Environment.cpp:62-100) equal the host mirror's grid; Problem.voxel_backbone_checker wires the checker and
+    the motion validator with the file's resolutions."""
+    W = irt.workloads
+    rng = np.random.default_rng(6)
+    env = irt.Environment(points=rng.uniform(-0.2, 0.2, (20, 3)),
+                          spheres=[(rng.uniform(-0.2, 0.2, 3), float(rng.uniform(0.005, 0.03))) for _ in range(15)],
+                          capsules=[(rng.uniform(-0.2, 0.2, 3), rng.uniform(-0.2, 0.2, 3), float(rng.uniform(0.003, 0.02))) for _ in range(10)])
+    vox = irt.VoxelOctree(256)
+    vox.set_xlim(-0.25, 0.25); vox.set_ylim(-0.25, 0.25); vox.set_zlim(-0.25, 0.25)
+    vfile = tmp_path / "empty.msgpack"
+    vox.to_file(str(vfile))
+    pr = irt.Problem(robot=W.robot_config2(), env=env, venv=irt.VoxelEnvironment(filename=str(vfile)), start=[1, 2, 3], goal=[3, 2, 1],
+                     min_tension_change=0.05)
+    pfile = tmp_path / "problem.toml"
+    pfile.write_text(pr.to_toml())
+    back = irt.Problem.from_toml(str(pfile))
+    chk, mv = back.voxel_backbone_checker()
+    assert mv.min_tension_change == 0.05 and chk.engine.get_grid().sum() == 0
+    back.env.voxelize_into(chk)
+    want = back.env.voxelize(vox)
+    assert np.array_equal(chk.engine.get_grid(), want.blocks.ravel()) and want.ncells() > 2000
+    g = _oracle_grid(orc, vox)
+    for p in env.points:
+        g.add_sphere(p, 0.0)
+    for c, r in env.spheres:
+        g.add_sphere(c, r)
+    for a, b, r in env.capsules:
+        g.add_capsule(a, b, r)
+    assert np.array_equal(np.asarray(g.blocks()).ravel(), want.blocks.ravel())
+    st = W.random_states(back.robot, 500, seed=3, tau_max=10.0)
+    chk2 = irt.VoxelBackboneValidityChecker(back.robot, irt.VoxelEnvironment(), want)
+    assert np.array_equal(chk.is_valid(st), chk2.is_valid(st)) and 0 < chk.is_valid(st).mean() < 1
+    assert mv.checkMotion(back.start_state(), back.goal_state()) in (True, False)

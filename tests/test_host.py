@@ -425,3 +425,38 @@ def test_voxel_environment_table_round_trip(irt, tmp_path):
     p.write_text(env.to_toml())
     back = irt.VoxelEnvironment.from_toml(str(p))
     assert back.filename == "" and back.get_obstacles() == vox and np.abs(back.inv_rotation - Rz).max() < 1e-15
+
+
+def test_problem_file_round_trip(irt, tmp_path):
+    """motion_planning::Problem::to_toml / from_toml (motion-planning/Problem.cpp:420-560): robot, obstacle primitives, voxel
+    environment, start / goal and the validator's resolutions in one flattened file; Environment::voxelize on the host mirror."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    robot.enable_rotation = True
+    env = irt.Environment(points=[[0.1, 0.0, 0.05]], spheres=[([0.0, 0.1, 0.1], 0.02), ([0.05, -0.1, 0.12], 0.03)],
+                          capsules=[([0.0, 0.0, 0.15], [0.1, 0.05, 0.15], 0.01)])
+    a = 0.6
+    venv = irt.VoxelEnvironment(filename="env.msgpack", inv_rotation=np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]]))
+    pr = irt.Problem(robot=robot, env=env, venv=venv, start=[1, 2, 3, 4], goal=[4, 3, 2, 1], min_tension_change=0.05, min_rotation_change=0.02,
+                     start_rotation=0.3, goal_rotation=-0.4)
+    path = tmp_path / "problem.toml"
+    path.write_text(pr.to_toml())
+    back = irt.Problem.from_toml(str(path))
+    assert back.robot == robot and back.start == pr.start and back.goal == pr.goal
+    assert (back.min_tension_change, back.min_rotation_change, back.min_retraction_change) == (0.05, 0.02, 0.0001)
+    assert np.array_equal(back.start_state(), [1, 2, 3, 4, 0.3]) and np.array_equal(back.goal_state(), [4, 3, 2, 1, -0.4])
+    assert back.venv.filename == "env.msgpack" and np.abs(back.venv.inv_rotation - venv.inv_rotation).max() < 1e-15
+    assert len(back.env.points) == 1 and len(back.env.spheres) == 2 and len(back.env.capsules) == 1
+    assert back.env.spheres[1][1] == 0.03 and np.array_equal(back.env.capsules[0][1], [0.1, 0.05, 0.15])
+    ref = irt.VoxelOctree(64)
+    ref.set_xlim(-0.25, 0.25); ref.set_ylim(-0.25, 0.25); ref.set_zlim(-0.25, 0.25)
+    v = back.env.voxelize(ref)
+    w = ref.empty_copy()
+    w.add_point([0.1, 0.0, 0.05]); w.add_sphere([0.0, 0.1, 0.1], 0.02); w.add_sphere([0.05, -0.1, 0.12], 0.03)
+    w.add_capsule([0.0, 0.0, 0.15], [0.1, 0.05, 0.15], 0.01)
+    assert v == w and v.ncells() > 50
+    import tomli
+    broken = tomli.loads(pr.to_toml())
+    del broken["problem"]["goal_rotation"]
+    with pytest.raises(irt.OutOfRange):
+        irt.Problem.from_toml(broken)
