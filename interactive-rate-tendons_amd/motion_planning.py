@@ -390,6 +390,47 @@ class Problem:
                    goal_rotation=float(pt.get("goal_rotation", 0.0)), goal_retraction=float(pt.get("goal_retraction", 0.0)),
                    sample_like_sphere=bool(pt.get("sample_like_sphere", True)))
 
+    # ---- plans: the planners' output (Problem.cpp:350-418): CSV with the columns i, tau_1 .. tau_N [, theta] [, s_start] ----------
+    def write_plan(self, stream, plan):
+        names = ["tau_%d" % (i + 1) for i in range(len(self.robot.tendons))]
+        if self.robot.enable_rotation:
+            names.append("theta")
+        if self.robot.enable_retraction:
+            names.append("s_start")
+        plan = np.asarray(plan, float).reshape(-1, len(names))
+        stream.write(",".join(["i"] + names) + "\n")
+        for i, row in enumerate(plan):
+            stream.write(",".join([str(i + 1)] + [repr(float(x)) for x in row]) + "\n")
+
+    def save_plan(self, path, plan):
+        with open(path, "w", newline="") as f:
+            self.write_plan(f, plan)
+
+    @staticmethod
+    def read_plan(stream):
+        """Columns tau_1, tau_2, ... as far as they go, then theta and s_start when present (Problem::read_plan)."""
+        import csv
+        rd = csv.reader(stream)
+        header = [h.strip() for h in next(rd)]
+        idx = []
+        i = 1
+        while "tau_%d" % i in header:
+            idx.append(header.index("tau_%d" % i)); i += 1
+        for nm in ("theta", "s_start"):
+            if nm in header:
+                idx.append(header.index(nm))
+        rows = [[float(r[j]) for j in idx] for r in rd if r]
+        return np.array(rows, float).reshape(len(rows), len(idx))
+
+    @classmethod
+    def load_plan(cls, path):
+        with open(path, newline="") as f:
+            return cls.read_plan(f)
+
+    def plan_from_path(self, states, path_vertices):
+        """The states along a roadmap path (vertex indices, as VoxelCachedLazyPRM.solveWithRoadmap returns them) as a plan."""
+        return np.asarray(states, float)[np.asarray(path_vertices, dtype=np.int64)]
+
     def voxel_backbone_checker(self, voxels=None, device=0, spheres=False):
         """Problem::set_voxel_backbone_state_checker / set_voxel_state_checker (Problem.h:175-216): the state checker over the voxel
         environment's obstacles and the motion validator with this problem's resolutions -> (checker, motion validator)."""

@@ -455,6 +455,13 @@ def test_problem_file_round_trip(irt, tmp_path):
     w.add_point([0.1, 0.0, 0.05]); w.add_sphere([0.0, 0.1, 0.1], 0.02); w.add_sphere([0.05, -0.1, 0.12], 0.03)
     w.add_capsule([0.0, 0.0, 0.15], [0.1, 0.05, 0.15], 0.01)
     assert v == w and v.ncells() > 50
+    # plans (the planners' output CSV)
+    plan = np.array([[1, 2, 3, 4, 0.3], [2, 2.5, 3, 3.5, 0.1], [4, 3, 2, 1, -0.4]])
+    pfile = tmp_path / "plan.csv"
+    back.save_plan(str(pfile), plan)
+    assert pfile.read_text().splitlines()[0] == "i,tau_1,tau_2,tau_3,tau_4,theta" and pfile.read_text().splitlines()[1].startswith("1,1.0,2.0")
+    assert np.array_equal(irt.Problem.load_plan(str(pfile)), plan)
+    assert np.array_equal(back.plan_from_path(plan, [2, 0]), plan[[2, 0]])
     import tomli
     broken = tomli.loads(pr.to_toml())
     del broken["problem"]["goal_rotation"]
