@@ -298,3 +298,39 @@ def test_roadmap_file_round_trip_into_the_query_loop(irt, tmp_path):
     a, b = outs
     assert np.array_equal(a["status"], b["status"]) and np.array_equal(a["path_vertices"], b["path_vertices"])
     assert np.allclose(a["cost"], b["cost"], rtol=1e-15, atol=0) and (a["status"] == 0).sum() > 50
+
+
+def test_planning_flow_from_files(irt, tmp_path):
+    """The flow of INTEGRATION.md: problem file + voxel file + roadmap file -> checker -> query object -> changed environment ->
+    batch of queries -> plan CSV; every state of the plan is valid in the changed environment."""
+    W = irt.workloads
+    vox, _ = W.reach_environment(seed=7, n_spheres=70)
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=80)
+    vox.to_file(str(tmp_path / "env.msgpack")); new_vox.to_file(str(tmp_path / "changed_env.json.gz"))
+    pr = irt.Problem(robot=W.robot_config3(), venv=irt.VoxelEnvironment(filename=str(tmp_path / "env.msgpack")), start=[1, 1, 1, 1], goal=[5, 5, 5, 5])
+    (tmp_path / "problem.toml").write_text(pr.to_toml())
+    # build and store the roadmap
+    problem = irt.Problem.from_toml(str(tmp_path / "problem.toml"))
+    checker, validator = problem.voxel_backbone_checker()
+    rb = irt.RoadmapBuilder(checker, validator, seed=9)
+    _, rm = rb.create_roadmap(800, k=6, batch=4096)
+    rb.save_rmp(str(tmp_path / "roadmap.rmp"), rm)
+    # the interactive side, from the files alone
+    problem = irt.Problem.from_toml(str(tmp_path / "problem.toml"))
+    checker, validator = problem.voxel_backbone_checker()
+    prm = irt.VoxelCachedLazyPRM.from_rmp(checker, str(tmp_path / "roadmap.rmp"))
+    changed = irt.VoxelOctree.from_file(str(tmp_path / "changed_env.json.gz"))
+    prm.set_obstacles(changed)
+    rng = np.random.default_rng(1)
+    starts, goals = rng.integers(0, 800, 60), rng.integers(0, 800, 60)
+    out = prm.solveWithRoadmap(starts, goals)
+    solved = np.flatnonzero(out["status"] == 0)
+    assert len(solved) > 20
+    q = int(solved[np.argmax([len(out["paths"][i]) for i in solved])])
+    plan = problem.plan_from_path(prm.states, out["paths"][q])
+    problem.save_plan(str(tmp_path / "plan.csv"), plan)
+    again = irt.Problem.load_plan(str(tmp_path / "plan.csv"))
+    assert np.array_equal(again, plan) and len(plan) >= 2
+    fresh = irt.VoxelBackboneValidityChecker(problem.robot, problem.venv, changed)
+    assert fresh.is_valid(again).all()
+    assert irt.VoxelBackboneMotionValidator(fresh).check_motion(again[:-1], again[1:]).all()
