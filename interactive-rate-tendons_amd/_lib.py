@@ -104,7 +104,8 @@ OBJ_DIR = os.path.join(SRC_DIR, "_obj")
 
 def _units():
     """(object name, source, extra flags): the C ABI + K2..K6, the cache merge, and K1 once per
-    (tendon count, kernel: shared grid / retraction / fused with K2) so its 64 instantiations compile in parallel."""
+    (tendon count, kernel: shared grid / retraction / fused with K2 / verdict-only / verdict-only with retraction) so its
+    instantiations compile in parallel."""
     fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "verdict_kernel.hpp",
                "sweep_kernel.hpp", "sphere_kernel.hpp", "tr_types.hpp"]
     fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip"]
@@ -113,7 +114,7 @@ def _units():
          ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"]),
          ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", HEADER])]
     for n in range(1, 9):
-        for kind, tag in ((0, "u"), (1, "r"), (2, "f"), (3, "v")):
+        for kind, tag in ((0, "u"), (1, "r"), (2, "f"), (3, "v"), (4, "w")):
             u.append(("fk_%s%d.o" % (tag, n), "fk_inst.hip", ["-DTRK_INST_N=%d" % n, "-DTRK_INST_KIND=%d" % kind], fk_deps))
     return u
 

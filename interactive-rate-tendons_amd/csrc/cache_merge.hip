@@ -322,4 +322,34 @@ hipError_t sort_states_by_first(MergeScratch &ms, const double *d_states, int64_
   return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void retraction_keys(const double *__restrict__ states, int64_t n, int S, double inv_L, uint32_t *__restrict__ keys,
+                                                       int32_t *__restrict__ vals) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  double f = states[i * S + (S - 1)] * inv_L;
+  f = f > 0.0 ? (f < 1.0 ? f : 1.0) : 0.0;          // NaN -> 0
+  keys[i] = (uint32_t)(f * 255.0);
+  vals[i] = (int32_t)i;
+}
+}  // namespace
+
+hipError_t retraction_order(MergeScratch &ms, const double *d_states, int64_t n, int S, double L, uint32_t *const d_keys[2],
+                            int32_t *const d_vals[2], const int32_t **perm_out, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(retraction_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, 1.0 / L, d_keys[0], d_vals[0]);
+  MERGE_TRY(hipGetLastError());
+  rocprim::double_buffer<uint32_t> kb(d_keys[0], d_keys[1]);
+  rocprim::double_buffer<int32_t> vb(d_vals[0], d_vals[1]);
+  size_t bytes = 0;
+  MERGE_TRY(rocprim::radix_sort_pairs(nullptr, bytes, kb, vb, (size_t)n, 0u, 8u, stream));
+  if (ms.cap_tmp < bytes) {
+    MERGE_TRY(grow((char **)&ms.tmp, bytes + bytes / 4));
+    ms.cap_tmp = bytes + bytes / 4;
+  }
+  MERGE_TRY(rocprim::radix_sort_pairs(ms.tmp, bytes, kb, vb, (size_t)n, 0u, 8u, stream));
+  *perm_out = vb.current();
+  return hipSuccess;
+}
+
 }  // namespace trk

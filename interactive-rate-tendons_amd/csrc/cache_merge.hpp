@@ -54,4 +54,13 @@ hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int 
 hipError_t sort_states_by_first(MergeScratch &ms, const double *d_states, int64_t n, int S, double *d_sorted, double *d_xs,
                                 int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream);
 
+// Retraction-enabled robots: the order in which the verdict-only kernel takes a batch.  A wave of the retraction kernel runs
+// from its LONGEST backbone's base to the tip (tip-aligned iterations, fk_retract_kernel.hpp), shorter backbones idling
+// until their rows come up: with retractions ~ U[0, L] in arrival order every wave pays for a full-length backbone and half
+// of its lane-steps are masked off.  d_perm [n] = configuration indices ordered by retraction (state coordinate S - 1,
+// clamped to [0, L], 256 levels: one radix pass), longest first -- a wave then holds backbones of one length.
+// d_keys / d_vals: two scratch arrays of n each; *perm_out points at the one holding the result.
+hipError_t retraction_order(MergeScratch &ms, const double *d_states, int64_t n, int S, double L, uint32_t *const d_keys[2],
+                            int32_t *const d_vals[2], const int32_t **perm_out, hipStream_t stream);
+
 }  // namespace trk

@@ -1,5 +1,5 @@
 // fk_inst.hip -- one K1 instantiation set per object file: compiled once per tendon count and
-// kernel with -DTRK_INST_N=<1..8> -DTRK_INST_KIND=<0 uniform | 1 retract | 2 fused with K2 | 3 verdict-only>
+// kernel with -DTRK_INST_N=<1..8> -DTRK_INST_KIND=<0 uniform | 1 retract | 2 fused with K2 | 3 verdict-only | 4 verdict-only, retraction>
 // (see _lib.py: build()).
 #include "fk_launch.hpp"
 #include "fk_kernel.hpp"
@@ -9,11 +9,36 @@
 #include "fused_kernel.hpp"
 #elif TRK_INST_KIND == 3
 #include "verdict_kernel.hpp"
+#elif TRK_INST_KIND == 4
+#define TRK_WITH_RETRACT_VERDICT
+#include "fk_retract_kernel.hpp"
+#include "verdict_kernel.hpp"
 #endif
 
 namespace trk {
 
-#if TRK_INST_KIND == 3
+#if TRK_INST_KIND == 4
+template <bool ROT, bool SPH>
+static void go(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
+  const unsigned grid = (unsigned)((a.n + 63) / 64);
+  hipLaunchKernelGGL((fk_verdict_retract<TRK_INST_N, ROT, SPH>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_poly,
+                     a.d_tab, a.d_steps, a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.out.tips, va);
+}
+template <> void launch_fk_verdict_retract<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres) {
+  if (spheres) { if (a.rotation) go<true, true>(a, va, lds); else go<false, true>(a, va, lds); }
+  else         { if (a.rotation) go<true, false>(a, va, lds); else go<false, false>(a, va, lds); }
+}
+template <bool ROT>
+static void go_list(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds, const int32_t *list, const uint32_t *count) {
+  const unsigned grid = (unsigned)((a.n + 63) / 64);                       // a.n = columns of the fallback workspace (multiple of 64)
+  hipLaunchKernelGGL((fk_sweep_retract_list<TRK_INST_N, ROT>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.ld, a.K,
+                     a.d_poly, a.d_tab, a.d_steps, a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.out, sweep, list, count);
+}
+template <> void launch_fk_sweep_retract_list<TRK_INST_N>(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds, const int32_t *list,
+                                                          const uint32_t *count) {
+  if (a.rotation) go_list<true>(a, sweep, lds, list, count); else go_list<false>(a, sweep, lds, list, count);
+}
+#elif TRK_INST_KIND == 3
 template <bool ROT, bool SPH>
 static void go(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);

@@ -334,6 +334,7 @@ struct FkLane {
 struct NoPointHook {
   __device__ __forceinline__ void begin(bool) const {}
   __device__ __forceinline__ void operator()(int, double, double, double) const {}
+  __device__ __forceinline__ void tip_point(int, bool, bool, double, double, double) const {}   // retraction kernel
 };
 
 // on_point(j, x, y, z): called for every observed backbone point (after rotate_z), in order j = 0 .. P-1 -- the

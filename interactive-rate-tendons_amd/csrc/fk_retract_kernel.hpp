@@ -93,16 +93,32 @@ __device__ __forceinline__ double home_ldot(const PolyK *__restrict__ pk, int j,
 #ifndef TRK_K1R_TWO_WAVE_MAXN
 #define TRK_K1R_TWO_WAVE_MAXN 3
 #endif
-template <int N, bool ROT, bool WRITE_R>
-__global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_rk4_batch_retract(
-    const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const PolyK *__restrict__ pk,
+
+// What a lane knows about its configuration when the integration ends (the verdict-only kernel continues from here).
+template <int N>
+struct FkLaneR {
+  bool converged;
+  int np;                     // the lane's number of backbone points
+  double Li[N], home_Li[N];
+};
+
+// The body of K1r.  on_point.tip_point(row, on, first, x, y, z) is called in wave-uniform control flow for every observed
+// backbone point (after rotate_z): `row` is the point's tip-aligned row (the lane's point j sits in row j + P - P_lane; it
+// is the lane's own row for its first two points and wave-uniform afterwards), `on` says whether this lane has a point in
+// this call, `first` whether it is the lane's point 0; on_point.begin(converged && live) precedes the first call.
+// row_map (optional): lane i integrates configuration row_map[i] of `states`.
+template <int N, bool ROT, bool WRITE_R, class OnPoint = NoPointHook>
+__device__ __forceinline__ void fk_retract_body(
+    const double *__restrict__ states, int64_t n, int64_t ld, const RobotK &K, const PolyK *__restrict__ pk,
     const double *__restrict__ tab /* K1's routing table of the s_start = 0 grid */, const StepK *__restrict__ steps, int nsteps,
     int k_first /* first step after the grid's own first interval */, const double *__restrict__ tgrid /* [P] shared abscissae */,
-    const double *__restrict__ hl /* [P][N] home-length integrand at the shared abscissae */, FkOut out) {
+    const double *__restrict__ hl /* [P][N] home-length integrand at the shared abscissae */, const FkOut &out,
+    OnPoint &&on_point = NoPointHook(), const int32_t *__restrict__ row_map = nullptr, FkLaneR<N> *lane_out = nullptr) {
 #pragma clang fp contract(fast)
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = i < n;
-  const int64_t ic = live ? i : (n - 1);
+  const int64_t il = live ? i : (n - 1);
+  const int64_t ic = row_map ? (int64_t)row_map[il] : il;
   const int S = K.state_size, Pmax = K.n_points;
   const double L = K.L, dL = K.dL;
   double tau[N];
@@ -159,11 +175,17 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
 #pragma unroll
   for (int j = 0; j < N; j++) Li[j] = 0;
 
-  auto store_point = [&](int j) {
-    const int64_t o = (int64_t)j * ld + i;
+  on_point.begin(conv && live);
+  // `row` may differ from lane to lane (the lane's first two points) or be wave-uniform (the tip-aligned loop); `on`: the
+  // lane has a point here.  The hook runs for the whole wave (it holds ballots and workgroup barriers).
+  auto store_point = [&](int row, bool on, bool is_first) {
     double x = p[0], y = p[1], z = p[2];
-    if (ROT) { const double x2 = rc * x - rs * y, y2 = rs * x + rc * y; x = x2; y = y2; z = r22 * z; }
-    out.px[o] = x; out.py[o] = y; out.pz[o] = z;
+    // rotate_z (tendon/TendonResult.cpp:13-18); explicit FMAs so that every kernel holding this body forms the same bits
+    if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
+    on_point.tip_point(row, on, is_first, x, y, z);
+    if (!(on && live)) return;
+    const int64_t o = (int64_t)row * ld + i;
+    if (out.px) { out.px[o] = x; out.py[o] = y; out.pz[o] = z; }
     if (WRITE_R) {
       const int64_t PS = (int64_t)Pmax * ld;
 #pragma unroll
@@ -174,7 +196,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
       }
     }
   };
-  if (live) store_point(shift);                     // rows are aligned at the tip: the lane's point j goes to row j + shift
+  store_point(shift, true, true);                   // rows are aligned at the tip: the lane's point j goes to row j + shift
 
   // the lane's own first interval: s -> shared grid point shift + 1, steps of min(dL, remaining) while
   // remaining > eps (integrate_times), routing evaluated per lane
@@ -194,7 +216,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
         cur += h;
       }
     }
-    if (first && live) store_point(shift + 1);
+    store_point(shift + 1, first, false);
   }
 
   // tip-aligned: step k of the shared grid ends at its point steps[k].obs = the lane's point obs - shift
@@ -257,8 +279,8 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
       for (int q = 0; q < 9; q++) R[q] = aR[q];
 #pragma unroll
       for (int q = 0; q < 3; q++) { v[q] = av[q]; u[q] = au[q]; }
-      if (live) store_point(obs);
     }
+    store_point(obs, act, false);
   }
 
   // home-shape tendon lengths: home_shape clamps s_start into [0, L] (TendonRobot.cpp:257-258); composite
@@ -295,6 +317,26 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
   }
 
 
+  // home_shape(s_start).L_i (TendonRobot.cpp:249-314)
+  double home[N];
+  if (out.home_Li || lane_out) {
+    double sh = s_raw;
+    if (sh < 0.0) sh = 0.0;
+    if (sh > L) sh = L;
+    const double Lh = L - sh;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      double val;
+      if (sh == L) val = 0.0;
+      else if (pk->home_kind[j] == 0) val = Lh;
+      else if (pk->home_kind[j] == 1) val = Lh * pk->helix_scale[j];
+      else {
+        const double odd = (nint % 2 != 0) ? 0.5 * dL * hodd[j] : 0.0;
+        val = (P_lane < 2) ? 0.0 : ((ne == 0) ? odd : odd + (hsum[j] * dL / 3.0));
+      }
+      home[j] = val;
+    }
+  }
   if (live) {
     if (out.L) out.L[i] = Lb;
     if (out.Li) {
@@ -305,28 +347,28 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_r
     if (out.n_points) out.n_points[i] = P_lane;
     if (out.tips) {
       double x = p[0], y = p[1], z = p[2];
-      if (ROT) { const double x2 = rc * x - rs * y, y2 = rs * x + rc * y; x = x2; y = y2; z = r22 * z; }
-      out.tips[3 * i + 0] = x; out.tips[3 * i + 1] = y; out.tips[3 * i + 2] = z;
+      if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
+      out.tips[3 * ic + 0] = x; out.tips[3 * ic + 1] = y; out.tips[3 * ic + 2] = z;   // (row_map: the configuration's own place)
     }
     if (out.home_Li) {
-      double sh = s_raw;
-      if (sh < 0.0) sh = 0.0;
-      if (sh > L) sh = L;
-      const double Lh = L - sh;
 #pragma unroll
-      for (int j = 0; j < N; j++) {
-        double val;
-        if (sh == L) val = 0.0;
-        else if (pk->home_kind[j] == 0) val = Lh;
-        else if (pk->home_kind[j] == 1) val = Lh * pk->helix_scale[j];
-        else {
-          const double odd = (nint % 2 != 0) ? 0.5 * dL * hodd[j] : 0.0;
-          val = (P_lane < 2) ? 0.0 : ((ne == 0) ? odd : odd + (hsum[j] * dL / 3.0));
-        }
-        out.home_Li[(int64_t)j * ld + i] = val;
-      }
+      for (int j = 0; j < N; j++) out.home_Li[(int64_t)j * ld + i] = home[j];
     }
   }
+  if (lane_out) {
+    lane_out->converged = conv;
+    lane_out->np = P_lane;
+#pragma unroll
+    for (int j = 0; j < N; j++) { lane_out->Li[j] = Li[j]; lane_out->home_Li[j] = home[j]; }
+  }
+}
+
+template <int N, bool ROT, bool WRITE_R>
+__global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_rk4_batch_retract(
+    const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const PolyK *__restrict__ pk,
+    const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid,
+    const double *__restrict__ hl, FkOut out) {
+  fk_retract_body<N, ROT, WRITE_R>(states, n, ld, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out);
 }
 
 }  // namespace trk

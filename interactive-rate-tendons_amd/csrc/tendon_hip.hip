@@ -57,6 +57,7 @@ struct Workspace {
 
 struct EventPair { hipEvent_t a, b; };
 
+constexpr int64_t kRetractSortMin = 8192;   // below this a launch is a few waves per CU at most: ordering them buys nothing
 constexpr int64_t kSmallBatch = 4096;   // tr_validate_batch: up to here the single-stream path without a device-wide sync
 
 // device state of the edge frontier (edge_kernel.hpp / edge_host.inc)
@@ -119,6 +120,10 @@ struct tr_ctx {
   int fuse = 2;
   int64_t fb_cap = 1 << 17;       // columns of the fallback pass's point workspace: one resident round of waves (tr_create), env TENDON_HIP_FB_CAP
   int32_t *d_fb_list = nullptr; uint32_t *d_fb_count = nullptr; int64_t fb_list_cap = 0;
+  // retraction robots: the batch ordered by backbone length for the verdict-only kernel (cache_merge.hpp: retraction_order);
+  // for batches of at least retract_sort_min configurations (TENDON_HIP_RETRACT_SORT=<n>; 0 = never, keep arrival order)
+  uint32_t *d_ro_keys[2] = {nullptr, nullptr}; int32_t *d_ro_vals[2] = {nullptr, nullptr}; int64_t ro_cap = 0;
+  int64_t retract_sort_min = kRetractSortMin;
   struct VerdictRing {
     static constexpr int kSlots = 16;
     trk::VerdictArgs *d_slots = nullptr, *h_slots = nullptr;
@@ -498,23 +503,40 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     a.field = ctx->d_sph_near; a.radius = ctx->K.radius;
     a.r_lo = (float)ctx->K.radius - 2e-6f; a.r_hi = (float)ctx->K.radius + 2e-6f;
   }
+  if (ctx->K.enable_retraction && ctx->retract_sort_min > 0 && n >= ctx->retract_sort_min) {
+    // waves of one backbone length: see retraction_order.  The mask is filled by atomic ORs, so it starts from zero.
+    if (ctx->ro_cap < n) {
+      HIP_TRY(ctx, hipDeviceSynchronize());
+      const int64_t want = round_up(n, 64);
+      for (int q = 0; q < 2; q++) {
+        if ((rc = dev_alloc(ctx, &ctx->d_ro_keys[q], (size_t)want))) return rc;
+        if ((rc = dev_alloc(ctx, &ctx->d_ro_vals[q], (size_t)want))) return rc;
+      }
+      ctx->ro_cap = want;
+    }
+    const hipError_t e = trk::retraction_order(ctx->merge, d_states, n, ctx->K.state_size, ctx->K.L, ctx->d_ro_keys, ctx->d_ro_vals, &a.perm, s);
+    if (e != hipSuccess) return fail(ctx, TR_ERR_HIP, std::string("retraction order: ") + hipGetErrorString(e));
+    HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, (size_t)((n + 63) / 64) * sizeof(uint64_t), s));
+  }
   HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb_count, 0, sizeof(uint32_t), s));
   // the fallback pass sweeps columns of the small point workspace
-  trk::SweepIn in{w.px, w.py, w.pz, nullptr, w.Li, w.conv, nullptr, w.acc};
+  const bool ret = ctx->K.enable_retraction;      // K1r's body in both launches, tip-aligned rows in the fallback workspace
+  trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
   const trk::FusedSweepArgs *d_fargs; size_t lds_f; int fslot;
   if ((rc = fused_args_slot(ctx, in, spheres ? 2 : 1, d_bits, d_flags, s, &d_fargs, &lds_f, &fslot))) return rc;
   const trk::FkOut vout{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_tips, nullptr, nullptr, nullptr};
   const trk::FkLaunch vl{d_states, n, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                          (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, vout, s};
-  const trk::FkOut fout{w.px, w.py, w.pz, nullptr, nullptr, w.Li, nullptr, w.conv, nullptr, nullptr};
+  const trk::FkOut fout{w.px, w.py, w.pz, nullptr, nullptr, w.Li, nullptr, w.conv, ret ? w.np : nullptr, ret ? w.homeLi : nullptr};
   const trk::FkLaunch fl{d_states, cap, w.ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                          (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, fout, s};
   const size_t lds_v = trk::verdict_lds_bytes(a.NM);
   {
     ProfScope ps(ctx, 5, s);
     switch (ctx->K.n_tendons) {
-#define TRK_CASE(N) case N: trk::launch_fk_verdict<N>(vl, vr.d_slots + vslot, lds_v, spheres); break;
+#define TRK_CASE(N) case N: if (ret) trk::launch_fk_verdict_retract<N>(vl, vr.d_slots + vslot, lds_v, spheres); \
+                            else trk::launch_fk_verdict<N>(vl, vr.d_slots + vslot, lds_v, spheres); break;
       TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
       default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
@@ -524,7 +546,8 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   {
     ProfScope ps(ctx, 4, s);
     switch (ctx->K.n_tendons) {
-#define TRK_CASE(N) case N: trk::launch_fk_sweep_fused_list<N>(fl, d_fargs, lds_f, ctx->d_fb_list, ctx->d_fb_count); break;
+#define TRK_CASE(N) case N: if (ret) trk::launch_fk_sweep_retract_list<N>(fl, d_fargs, lds_f, ctx->d_fb_list, ctx->d_fb_count); \
+                            else trk::launch_fk_sweep_fused_list<N>(fl, d_fargs, lds_f, ctx->d_fb_list, ctx->d_fb_count); break;
       TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
       default: break;
@@ -626,6 +649,7 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   tr_ctx *c = new tr_ctx();
   c->device = device;
   if (const char *e = std::getenv("TENDON_HIP_FUSED")) { const int v = std::atoi(e); c->fuse = v < 0 ? 0 : (v > 2 ? 2 : v); }
+  if (const char *e = std::getenv("TENDON_HIP_RETRACT_SORT")) c->retract_sort_min = std::atoll(e);
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
     if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = (int64_t)round_up(v, 64);
@@ -760,6 +784,7 @@ void tr_destroy(tr_ctx *c) {
   if (c->vstore.ids) (void)hipFree(c->vstore.ids);
   if (c->vstore.masks) (void)hipFree(c->vstore.masks);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
+  for (int q = 0; q < 2; q++) { if (c->d_ro_keys[q]) (void)hipFree(c->d_ro_keys[q]); if (c->d_ro_vals[q]) (void)hipFree(c->d_ro_vals[q]); }
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);
   delete c;
 }
@@ -991,7 +1016,7 @@ int tr_reserve(tr_ctx *c, int64_t n) {
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   HIP_TRY(c, hipSetDevice(c->device));
   int rc;
-  if (c->fuse == 2 && !c->K.enable_retraction) {
+  if (c->fuse == 2) {
     // the verdict path keeps no points: a list of fallback candidates and the fallback pass's small workspace
     if (c->fb_list_cap < n) {
       HIP_TRY(c, hipDeviceSynchronize());
@@ -1176,8 +1201,8 @@ int validate_batch_dev_impl(tr_ctx *c, const double *d_states, int64_t n, uint64
   hipStream_t s = (hipStream_t)stream;
   const int S = c->K.state_size;
   const bool ret = c->K.enable_retraction;
-  if (c->fuse == 2 && !ret) {
-    // verdict-only kernel (both checkers): nothing but the verdict (and the tips) leaves the chip, no point workspace to size
+  if (c->fuse == 2) {
+    // verdict-only kernel (both checkers, with or without retraction): nothing but the verdict (and the tips) leaves the chip, no point workspace to size
     const int64_t chunk = (int64_t)1 << 26;                 // list indices are 32-bit; per-launch grid stays far below 2^31 blocks
     for (int64_t off = 0; off < n; off += chunk) {
       const int64_t m = std::min<int64_t>(chunk, n - off);
@@ -1249,7 +1274,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
     // synchronisation -- the stream only waits for the last *_dev call that may still use this context's workspace.
     // What remains is the kernel itself: one lane integrates its configuration serially (INTEGRATION.md has the numbers).
     const int S = c->K.state_size;
-    const bool verdict = c->fuse == 2 && !c->K.enable_retraction;
+    const bool verdict = c->fuse == 2;
     if ((rc = ensure_staging(c, n))) return rc;
     if (!verdict && (rc = ensure_workspace(c, n))) return rc;
     Workspace &w = c->ws;
@@ -1267,7 +1292,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
     return TR_OK;
   }
   if ((rc = ensure_staging(c, std::min(n, 2 * CH)))) return rc;
-  if (!(c->fuse == 2 && !c->K.enable_retraction) && (rc = ensure_workspace(c, std::min(n, CH)))) return rc;
+  if (c->fuse != 2 && (rc = ensure_workspace(c, std::min(n, CH)))) return rc;
   HIP_TRY(c, hipDeviceSynchronize());          // earlier work on other streams (e.g. a *_dev call) is finished
   Workspace &w = c->ws;
   const int S = c->K.state_size;

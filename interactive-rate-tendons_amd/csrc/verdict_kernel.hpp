@@ -42,6 +42,10 @@ struct VerdictArgs {
   const float *field;
   float r_lo, r_hi;
   double radius;
+  // retraction robots (fk_verdict_retract): lane i of the launch takes configuration perm[i] -- the batch ordered by
+  // backbone length (cache_merge.hpp: retraction_order) -- and its outputs go to that configuration's places: the verdict
+  // bit by an atomic OR into the zeroed mask; null = arrival order, bits by ballot
+  const int32_t *perm;
 };
 
 constexpr int VQ = 128;           // ring of deferred segments per wave
@@ -284,6 +288,104 @@ struct PointSweep {
     }
     VL_BARRIER();
   }
+
+  // Retraction robots (fk_retract_kernel.hpp): the wave runs tip-aligned, a lane's point j arrives in row j + (P - P_lane).
+  // `row` is the lane's own for its first two points and wave-uniform afterwards; `on`: the lane has a point in this call;
+  // `first`: it is the lane's point 0.  Same per-point work as operator() -- only the milestones of the self-collision
+  // proof are laid out from the TIP: slot k holds the point k CH rows before the tip row P - 1 (slot 0 = the tip), the
+  // lane's base point closes the list in slot ceil((P - 1 - row) / CH), and the arc positions are stored negated, so they
+  // still grow with the slot index.  milestones_unresolved only looks at spans between slots, chord lengths and arc
+  // differences, none of which depends on the direction the backbone is traversed in.
+  __device__ __forceinline__ void tip_point(int row, bool on, bool first, double x, double y, double z) {
+#pragma clang fp contract(off)
+    VL_BARRIER();
+    const VerdictArgs &a = args();
+    const GridK &g = a.g;
+    const int lane = threadIdx.x;
+    const V3 q = {x, y, z};
+    V3 pv = q;
+    bool need = false;
+    V3 pr = pv, qr = q;
+    if (on) {
+      float d = 0.0f;
+      if (!first) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(VL_DIST + lane); }
+      pr = pv;
+      {
+        const float dx = (float)(q.x - pv.x), dy = (float)(q.y - pv.y), dz = (float)(q.z - pv.z);
+        d += sqrtf(dx * dx + dy * dy + dz * dz);
+        VL_F(VL_DIST + lane) = d;
+      }
+      {
+        // back = rows to the tip; k = back / CH through a float quotient (back < 2^16, CH <= 48: (back + 1/2) / CH is at
+        // least 1 / (2 CH) away from an integer, far beyond the rounding of the product)
+        const int back = P - 1 - row;
+        const int k = (int)(((float)back + 0.5f) * (1.0f / (float)CH));
+        const bool ms_row = (back - k * CH) == 0;
+        if (first || ms_row) {
+          const int slot = (first && !ms_row) ? k + 1 : k;
+          const int o = VL_MS + slot * 64 + lane, pl = NM * 64;
+          VL_F(o) = (float)q.x; VL_F(o + pl) = (float)q.y; VL_F(o + 2 * pl) = (float)q.z; VL_F(o + 3 * pl) = -d;
+        }
+      }
+      VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
+      if constexpr (SPH) {
+        if (active && !VL_U(VL_HIT + lane)) {
+          if (sph_state & 1u) {
+            if (!g.rot_is_identity) {
+              pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
+              pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
+              pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
+            }
+            const float dl = VL_F(VL_DELTA + lane);
+            if (dn_prev - dl > a.r_hi) {}
+            else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+            else need = true;
+          }
+          sph_state = 0;
+          if (!VL_U(VL_HIT + lane)) request(a, q);
+        }
+      } else
+      if (active && !VL_U(VL_HIT + lane)) {
+        if (!g.rot_is_identity) {
+          qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
+          qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
+          qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
+          pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
+          pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
+          pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
+        }
+        const bool in_q = qr.x > a.box[0] && qr.x < a.box[1] && qr.y > a.box[2] && qr.y < a.box[3] && qr.z > a.box[4] && qr.z < a.box[5];
+        const V3 Bq = {(qr.x - g.xmin) * g.inv_dx, (qr.y - g.ymin) * g.inv_dy, (qr.z - g.zmin) * g.inv_dz};
+        const int cqx = (int)Bq.x, cqy = (int)Bq.y, cqz = (int)Bq.z;
+        const bool use_near = a.near_grid != nullptr && !(a.debug & 4u);
+        if (!first) {
+          need = true;
+          if (VL_U(VL_INPREV + lane) && in_q) {
+            const int cpx = VL_I(VL_CELL + lane), cpy = VL_I(VL_CELL + 64 + lane), cpz = VL_I(VL_CELL + 128 + lane);
+            const int ddx = cqx - cpx, ddy = cqy - cpy, ddz = cqz - cpz;
+            const bool nearby = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1;
+            const bool start_free = use_near && !((near_prev >> (((cpx & 3) << 4) | ((cpy & 3) << 2) | (cpz & 3))) & 1ull);
+            need = !(nearby && start_free);
+          }
+        }
+        VL_I(VL_CELL + lane) = cqx; VL_I(VL_CELL + 64 + lane) = cqy; VL_I(VL_CELL + 128 + lane) = cqz;
+        VL_U(VL_INPREV + lane) = in_q ? 1u : 0u;
+        if (use_near && in_q) near_prev = a.near_grid[((size_t)(cqx >> 2) * g.Nb + (cqy >> 2)) * g.Nb + (cqz >> 2)];
+      }
+    }
+    const unsigned long long wm = __ballot(need);
+    if (wm) {
+      if (need) {
+        const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
+        VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
+        if constexpr (!SPH) { VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z; }
+        VL_U(VL_QOWNER + slot) = (uint32_t)lane;
+      }
+      qcount += __popcll(wm);
+      if (qcount >= 64) flush();
+    }
+    VL_BARRIER();
+  }
 };
 
 template <int N, bool ROT, bool SPH>
@@ -364,5 +466,109 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
     if (pending) a.fb_list[base + __popcll(pm & (((unsigned long long)1 << lane) - 1))] = (int32_t)i;
   }
 }
+
+#ifdef TRK_WITH_RETRACT_VERDICT
+// The same for retraction-enabled robots: K1r's body (fk_retract_kernel.hpp: per-lane arc-length grid, tip-aligned
+// iterations) with the sweep in its point hook (PointSweep::tip_point).  What differs after the loop is per lane: the
+// number of points, the last milestone slot and the home-shape tendon lengths.
+template <int N, bool ROT, bool SPH>
+__global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict_retract(
+    const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
+    const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
+    double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
+  const int lane = threadIdx.x;
+  PointSweep<SPH> ps;
+  ps.va = va;
+  ps.dn_prev = 0.0f; ps.sph_state = 0u;
+  ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
+  ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = 0; ps.ms_next = 0; ps.ms_k = 0;
+  ps.sig_row = nullptr;
+  VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
+  __syncthreads();
+
+  FkLaneR<N> fl_;
+  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tips, nullptr, nullptr, nullptr};
+  const int32_t *__restrict__ perm = va->perm;
+  fk_retract_body<N, ROT, false>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, ps, perm, &fl_);
+
+  ps.finish();
+  while (ps.qcount > 0) ps.flush();
+  __syncthreads();
+  const VerdictArgs a = *va;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i < n;
+  const int64_t c = (perm && live) ? (int64_t)perm[i] : i;      // the configuration this lane has integrated
+  const int np = fl_.np;
+  const int Kl = (np - 1 + a.CH - 1) / a.CH;              // this lane's last milestone slot: its base point
+  const bool conv_ok = live && fl_.converged;
+  bool len_ok = false;
+  if (conv_ok) {
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+      const double dl = fl_.home_Li[j] - fl_.Li[j];
+      if (dl < K.min_len[j] || K.max_len[j] < dl) ok = false;
+    }
+    len_ok = ok;
+  }
+  bool alive = conv_ok && len_ok;
+  const uint32_t hf = VL_U(VL_HIT + lane);
+  const bool hit = (hf & 1u) != 0;
+  bool bad = (hf & 2u) != 0;
+  if (alive && !(VL_F(VL_DIST + lane) < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
+  bool need_exact = alive && np > 2;
+  if (!(a.debug & 2u) && __any(need_exact)) {
+    const float *mx = (const float *)vlds + VL_MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
+    need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)K.radius);
+  }
+
+  uint32_t fl = 0;
+  if (conv_ok) fl |= 1u;
+  if (conv_ok && len_ok) fl |= 2u;
+  bool valid = conv_ok && len_ok;
+  if (valid && bad) { fl |= 16u; valid = false; }
+  const bool pending = valid && need_exact && (a.flags != nullptr || !hit);
+  if (valid && !pending) {
+    if (!need_exact) { fl |= 4u; if (!hit) fl |= 8u; else valid = false; }
+    else valid = false;
+  }
+  if (pending) valid = false;                                 // its bit is ORed in by fk_sweep_retract_list
+  if (SPH && pending && !hit) fl |= 8u;
+  if (perm) {
+    if (valid && live) atomicOr((unsigned long long *)&a.valid_bits[c >> 6], 1ull << (c & 63));
+  } else {
+    const uint64_t bits = __ballot(valid && live);
+    if (lane == 0 && live) a.valid_bits[i >> 6] = bits;
+  }
+  if (a.flags && live) a.flags[c] = (uint8_t)fl;
+  const unsigned long long pm = __ballot(pending);
+  if (pm) {
+    uint32_t base = 0;
+    if (lane == 0) base = atomicAdd(a.fb_count, (uint32_t)__popcll(pm));
+    base = __shfl(base, 0, 64);
+    if (pending) a.fb_list[base + __popcll(pm & (((unsigned long long)1 << lane) - 1))] = (int32_t)c;
+  }
+}
+
+// Fallback pass for the configurations whose self-collision test needs every backbone point at once (as
+// fk_sweep_fused_list, fused_kernel.hpp): K1r with stored points on the compacted list, then K2's body on the tip-aligned rows.
+template <int N, bool ROT>
+__global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_sweep_retract_list(
+    const double *__restrict__ states, int64_t cap, int64_t ld, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
+    const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
+    FkOut out, const FusedSweepArgs *__restrict__ sa, const int32_t *__restrict__ list, const uint32_t *__restrict__ count) {
+  const int64_t total = (int64_t)*count;
+  for (int64_t offset = 0; offset < total; offset += cap) {
+    const int64_t left = total - offset;
+    const int64_t m = left < cap ? left : cap;
+    if ((int64_t)blockIdx.x * 64 >= m) break;                     // wave-uniform
+    fk_retract_body<N, ROT, false>(states, m, ld, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, NoPointHook(), list + offset);
+    __syncthreads();
+    const FusedSweepArgs a = *sa;
+    sweep_body<true>(a.in, m, ld, a.P, a.CH, a.NM, K, a.g, a.grid, a.near_grid, a.check_voxels, a.debug, a.valid_bits, a.flags, list + offset);
+    __syncthreads();
+  }
+}
+#endif
 
 }  // namespace trk

@@ -161,8 +161,9 @@ def test_retraction_other_tendon_counts(irt, orc, helpers, n_tendons):
 
 
 def test_device_resident_two_stage_path_with_retraction(irt):
-    """tr_fk_batch_retraction_dev -> tr_validate_shapes_retraction_dev equals tr_validate_batch (same kernels,
-    caller-owned buffers: per-configuration point counts, home lengths, rows aligned at the tip)."""
+    """tr_fk_batch_retraction_dev -> tr_validate_shapes_retraction_dev (K1r, K2 on caller-owned buffers: per-configuration
+    point counts, home lengths, rows aligned at the tip) equals tr_validate_batch (the verdict-only kernel: same RK4 body
+    inside another kernel, tips to rounding)."""
     import torch
     W = irt.workloads
     robot = _robot(irt, "quad")
@@ -188,6 +189,86 @@ def test_device_resident_two_stage_path_with_retraction(irt):
     assert np.array_equal(got, want["valid"]) and np.array_equal(flags.cpu().numpy(), want["flags"])
     # the tip is always in the last row
     tips = np.stack([px.view(P, ld)[P - 1, :n].cpu().numpy(), py.view(P, ld)[P - 1, :n].cpu().numpy(), pz.view(P, ld)[P - 1, :n].cpu().numpy()], 1)
-    assert np.array_equal(tips, want["tips"])
+    assert np.abs(tips - want["tips"]).max() <= 1e-12
     with pytest.raises(irt.Unsupported):
         eng.validate_shapes_dev(n, ld, px, py, pz, Li, conv, bits)
+
+
+def _with_env(env, fn):
+    """Run fn with environment overrides that libtendon_hip reads when a context is created."""
+    import os
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        return fn()
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("checker", ["backbone", "spheres"])
+def test_verdict_only_kernel_with_retraction_all_branches(irt, checker):
+    """fk_verdict_retract (K1r's body with the sweep in its point hook: tip-aligned rows, milestones laid out from the tip,
+    per-lane point counts and home lengths; fallback pass fk_sweep_retract_list) against K1r -> K2 (-> K8) on stored points,
+    where the rarer branches are busy: self collisions through a 64-column fallback workspace, length limits,
+    non-converged solves, one-point and two-point backbones, negative retraction, rotation, a rotated environment, points
+    outside the voxel domain, and the debug switches -- with the batch in arrival order and ordered by backbone length."""
+    W = irt.workloads
+
+    def ret(r, rot=False):
+        r.specs.dL = 0.2 / 128
+        r.enable_retraction = True
+        r.enable_rotation = rot
+        return r
+
+    thin = ret(W.robot_config1())
+    thin.r = 0.01
+    for t in thin.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 0.08
+    hard = ret(W.robot_config2())
+    for t in hard.tendons:
+        t.max_tension, t.max_length = 60.0, 0.02
+    spin = ret(W.robot_config2(), rot=True)
+    quad = ret(W.robot_config3(), rot=True)
+    small, _ = W.sphere_environment(seed=5, n_spheres=40, radius=0.01, N=128, half=0.12, keepout=0.02)   # the robot reaches out of it
+    a = 0.4
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    cases = [(thin, 100.0, None, None, 6000), (hard, 45.0, None, None, 4000), (spin, 12.0, rot, None, 5000), (quad, 20.0, rot, None, 4000),
+             (ret(W.robot_config2()), 14.0, None, small, 5000)]
+    cls = irt.VoxelBackboneValidityChecker if checker == "backbone" else irt.VoxelValidityChecker
+    seen = np.zeros(32, int)
+    for robot, tau_max, inv_rot, vox, n in cases:
+        if vox is None:
+            vox, _ = W.reach_environment(seed=3, n_spheres=48)
+        env = irt.VoxelEnvironment()
+        if inv_rot is not None:
+            env.inv_rotation = inv_rot
+        states = W.random_states(robot, n + 21, seed=23, tau_max=tau_max)
+        L, dL = robot.specs.L, robot.specs.dL
+        special = [0.0, L, L + 0.01, L - dL / 4, L - dL / 2, L - 0.75 * dL, L - 1.25 * dL, L - 1.5 * dL, 0.0975, 0.1, dL / 3,
+                   L - 2.49 * dL, 17 * dL, 17.5 * dL, -0.01, L - 3.2 * dL]
+        states[:len(special), -1] = special
+        states[100:400, -1] *= 0.1                                   # long backbones: most of the self collisions
+
+        def run(debug=0, detail=True):
+            chk = cls(robot, env, vox)
+            chk.engine.set_debug(debug)
+            return chk.is_valid_detail(states) if detail else dict(valid=chk.is_valid(states))
+
+        want = _with_env({"TENDON_HIP_FUSED": "0"}, run)
+        for debug in ((0, 2, 3, 4) if checker == "backbone" else (0, 2, 3)):
+            # in arrival order, and ordered by backbone length (what batches of 8192 or more get by default)
+            for order in ("0", "64"):
+                got = _with_env({"TENDON_HIP_FB_CAP": "64", "TENDON_HIP_RETRACT_SORT": order}, lambda: run(debug))
+                for k in ("valid", "flags"):
+                    assert np.array_equal(got[k], want[k]), (k, debug, order, np.flatnonzero(got[k] != want[k])[:8], got[k][got[k] != want[k]][:8],
+                                                              want[k][got[k] != want[k]][:8])
+                ok = want["flags"] & 1 > 0
+                assert np.abs(got["tips"][ok] - want["tips"][ok]).max() <= 1e-12
+        assert np.array_equal(run(0, detail=False)["valid"], want["valid"])
+        seen += np.bincount(want["flags"], minlength=32)
+    print("flag histogram", seen)
+    assert seen[15] > 0 and seen[7] > 0 and seen[3] > 0 and seen[1] > 0 and seen[0] > 0
