@@ -85,10 +85,21 @@ __device__ inline int cells_differ(const double *__restrict__ px, const double *
 // cells_differ on cell signatures (sweep_kernel.hpp: cell_signature): the whole wave tests ONE pair of samples, lanes
 // over backbone points from the tip down, 64 at a time (two coalesced 256-byte reads); the first event in tip-first
 // order decides, a domain error at a point before a difference at that point -- as the sequential loop does.
-__device__ inline int signatures_differ(const uint32_t *__restrict__ sig, int64_t stride, int P, int64_t sa, int64_t sb) {
+// n_points (retraction robots): the samples' point counts; their rows are aligned at the tip (point j of a backbone of n
+// points sits in row j + P - n), backbones more than one link apart subdivide, otherwise the common prefix of points is
+// compared index by index from the base (VoxelEnvironment.cpp:317-326), as cells_differ does on stored points.
+__device__ inline int signatures_differ(const uint32_t *__restrict__ sig, int64_t stride, int P, const int32_t *__restrict__ n_points,
+                                        int64_t sa, int64_t sb) {
   const int lane = (int)(threadIdx.x & 63);
   const uint32_t *__restrict__ ra = sig + sa * stride, *__restrict__ rb = sig + sb * stride;
-  for (int j0 = P - 1; j0 >= 0; j0 -= 64) {
+  int Pm = P;
+  if (n_points) {
+    const int na = n_points[sa], nb = n_points[sb];
+    if (na + 1 < nb || na > nb + 1) return 1;
+    Pm = na < nb ? na : nb;
+    ra += P - na; rb += P - nb;
+  }
+  for (int j0 = Pm - 1; j0 >= 0; j0 -= 64) {
     const int j = j0 - lane;
     uint32_t va = 0, vb = 0;
     if (j >= 0) { va = ra[j]; vb = rb[j]; }
@@ -247,7 +258,7 @@ __global__ __launch_bounds__(256) void edge_filter(EdgeState st, const EdgeIv *_
     while (todo) {
       const int l = __ffsll((long long)todo) - 1;
       todo &= todo - 1;
-      const int r = signatures_differ(sig, sig_stride, P, __shfl(c.sa, l), __shfl(c.sb, l));
+      const int r = signatures_differ(sig, sig_stride, P, n_points, __shfl(c.sa, l), __shfl(c.sb, l));
       if ((int)(threadIdx.x & 63) == l) f = r;
     }
   } else if (keep) {

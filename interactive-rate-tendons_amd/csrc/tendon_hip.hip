@@ -462,7 +462,7 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
 // blocks return at once).  d_bits / d_flags / d_tips as in tr_validate_batch_dev; n <= 2^31.
 int ensure_sphere_near(tr_ctx *c, hipStream_t s);
 int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_bits, double *d_tips, uint8_t *d_flags, hipStream_t s,
-                   uint32_t *sig = nullptr, int64_t sig_stride = 0, bool spheres = false) {
+                   uint32_t *sig = nullptr, int64_t sig_stride = 0, bool spheres = false, int32_t *np_out = nullptr) {
   if (n <= 0) return TR_OK;
   if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   int rc;
@@ -498,7 +498,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     a.box[4] = g.zmin + 1e-6 * (g.zmax - g.zmin); a.box[5] = g.zmax - 1e-6 * (g.zmax - g.zmin);
   }
   a.fb_list = ctx->d_fb_list; a.fb_count = ctx->d_fb_count;
-  a.sig = sig; a.sig_stride = sig_stride;
+  a.sig = sig; a.sig_stride = sig_stride; a.np_out = np_out;
   if (spheres) {                       // classification thresholds (verdict_kernel.hpp: PointSweep<true>)
     a.field = ctx->d_sph_near; a.radius = ctx->K.radius;
     a.r_lo = (float)ctx->K.radius - 2e-6f; a.r_hi = (float)ctx->K.radius + 2e-6f;
@@ -586,10 +586,15 @@ int ensure_sphere_near(tr_ctx *c, hipStream_t s) {
 // K1 then K2 on one stream: a single fused launch when the robot uses the shared arc-length grid.
 // voxel_test: 0 = is_valid_shape only, 1 = backbone voxels (VoxelBackboneValidityChecker), 2 = sphere-swept
 // robot (VoxelValidityChecker: K2 without the voxel test, then K8 on the survivors).
-// sig (optional, edge samples): the fused launch also writes the samples' cell signatures; use edge_signatures(ctx) to
+// sig (optional, edge samples): the fused launch also writes the samples' cell signatures; use edge_signatures(ctx, ..) to
 // learn whether this context's fused path is active (the separate kernels write none).  points_unused: the caller will not
 // read the points of this launch (out.px .. may then stay unwritten).
-bool edge_signatures(const tr_ctx *ctx) { return ctx->fuse != 0 && !ctx->K.enable_retraction; }
+// with_points: the caller also needs the samples' stored points (voxel caches).  Retraction robots then run K1r -> K2 as
+// separate launches, which write no signatures (the interval test reads the points); without points their samples go
+// through fk_verdict_retract, which does.
+bool edge_signatures(const tr_ctx *ctx, bool with_points) {
+  return ctx->K.enable_retraction ? (ctx->fuse == 2 && !with_points) : ctx->fuse != 0;
+}
 
 int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
                     int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s, uint32_t *sig = nullptr, int64_t sig_stride = 0,
@@ -600,10 +605,10 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
     if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
     if ((rc = ensure_sphere_near(ctx, s))) return rc;
   }
-  if (ctx->fuse == 2 && voxel_test != 0 && points_unused && !ctx->K.enable_retraction && !out.R && !out.L && !out.tips) {
+  if (ctx->fuse == 2 && voxel_test != 0 && points_unused && !out.R && !out.L && !out.tips) {
     // nobody reads this launch's backbone points (edge samples of the checkMotion forms: the bisection compares cell
-    // signatures): the verdict-only kernel, which stores none
-    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride, voxel_test == 2);
+    // signatures -- of tip-aligned rows for retraction robots, hence the point counts): the verdict-only kernel, which stores none
+    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride, voxel_test == 2, sig ? out.n_points : nullptr);
   }
   if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s, sig, sig_stride))) return rc;

@@ -46,6 +46,7 @@ struct VerdictArgs {
   // backbone length (cache_merge.hpp: retraction_order) -- and its outputs go to that configuration's places: the verdict
   // bit by an atomic OR into the zeroed mask; null = arrival order, bits by ballot
   const int32_t *perm;
+  int32_t *np_out;                // optional (edge samples): the configurations' point counts, for the comparison of tip-aligned signature rows
 };
 
 constexpr int VQ = 128;           // ring of deferred segments per wave
@@ -328,6 +329,7 @@ struct PointSweep {
         }
       }
       VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
+      if (sig_row) sig_row[row] = cell_signature(x, y, z, g);        // tip-aligned like the rows of K1r's stored points
       if constexpr (SPH) {
         if (active && !VL_U(VL_HIT + lane)) {
           if (sph_state & 1u) {
@@ -482,13 +484,17 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_v
   ps.dn_prev = 0.0f; ps.sph_state = 0u;
   ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = 0; ps.ms_next = 0; ps.ms_k = 0;
-  ps.sig_row = nullptr;
+  const int32_t *__restrict__ perm = va->perm;
+  {
+    uint32_t *sig = va->sig;
+    const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
+    ps.sig_row = (sig && i0 < n) ? sig + (perm ? (int64_t)perm[i0] : i0) * va->sig_stride : nullptr;
+  }
   VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
   __syncthreads();
 
   FkLaneR<N> fl_;
   FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tips, nullptr, nullptr, nullptr};
-  const int32_t *__restrict__ perm = va->perm;
   fk_retract_body<N, ROT, false>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, ps, perm, &fl_);
 
   ps.finish();
@@ -541,6 +547,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_v
     if (lane == 0 && live) a.valid_bits[i >> 6] = bits;
   }
   if (a.flags && live) a.flags[c] = (uint8_t)fl;
+  if (a.np_out && live) a.np_out[c] = np;
   const unsigned long long pm = __ballot(pending);
   if (pm) {
     uint32_t base = 0;
