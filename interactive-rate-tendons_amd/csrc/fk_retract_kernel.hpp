@@ -88,10 +88,16 @@ __device__ __forceinline__ double home_ldot(const PolyK *__restrict__ pk, int j,
   return sqrt(dd * dd + (d * d) * (cd * cd) + 1);
 }
 
-// Two waves per SIMD up to 3 tendons; from 4 the lane-private bookkeeping on top of K1's budget spills too much
-// (measured, ms per 2^19 configurations, two waves | one wave: N=4 9.0 | 8.4).
+// Waves per SIMD (measured, profiles/r02/retract_widths_v1.txt: ms per 2^18 configurations, s_start ~ U[0, L), rotation and
+// general routing; one wave | two waves).  K1r with stored points: two waves pay up to 4 tendons (N=4 3.31 | 3.15, N=5
+// 3.68 | 3.77, N=6 4.16 | 4.31, N=8 5.93 | 6.37).  The verdict-only form (fk_verdict_retract: no stores, the sweep's loads
+// between the RK4 steps want a second wave to hide behind) is faster with two waves at every width (N=4 1.97 | 1.82, N=5
+// 2.34 | 2.16, N=6 2.58 | 2.36, N=7 3.02 | 2.77, N=8 3.53 | 3.49).
 #ifndef TRK_K1R_TWO_WAVE_MAXN
-#define TRK_K1R_TWO_WAVE_MAXN 3
+#define TRK_K1R_TWO_WAVE_MAXN 4
+#endif
+#ifndef TRK_VR_TWO_WAVE_MAXN
+#define TRK_VR_TWO_WAVE_MAXN 8
 #endif
 
 // What a lane knows about its configuration when the integration ends (the verdict-only kernel continues from here).

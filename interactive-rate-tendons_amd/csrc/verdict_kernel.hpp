@@ -474,7 +474,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
 // iterations) with the sweep in its point hook (PointSweep::tip_point).  What differs after the loop is per lane: the
 // number of points, the last milestone slot and the home-shape tendon lengths.
 template <int N, bool ROT, bool SPH>
-__global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict_retract(
+__global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict_retract(
     const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
     double *__restrict__ tips, const VerdictArgs *__restrict__ va) {

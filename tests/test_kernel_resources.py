@@ -89,6 +89,35 @@ def test_verdict_kernel_register_budget_and_lds_address_space(tmp_path, spheres)
     assert len(re.findall(r"\bflat_(load|store)", asm)) <= (24 if spheres == "true" else 16)   # grid / field words and the epilogue's outputs only
 
 
+VERDICT_RETRACT_TU = r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#define TRK_WITH_RETRACT_VERDICT
+#include "fk_retract_kernel.hpp"
+#include "verdict_kernel.hpp"
+template __global__ void trk::fk_verdict_retract<%d, true, false>(const double*, int64_t, RobotK, const PolyK*, const double*, const StepK*, int, int,
+                                                                  const double*, const double*, double*, const trk::VerdictArgs*);
+'''
+
+
+@pytest.mark.parametrize("n_tendons", [3, 4])
+def test_verdict_retract_kernel_occupancy_and_lds_address_space(tmp_path, n_tendons):
+    """fk_verdict_retract (retraction robots): two waves per SIMD -- measured faster at every width, the sweep's loads hide
+    behind the other wave -- and the point hook's state in LDS.  Its scratch is the lane-private first interval's
+    (per-lane routing), outside the tip-aligned loop."""
+    src = tmp_path / "kvr.hip"
+    src.write_text(VERDICT_RETRACT_TU % n_tendons)
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-I", CSRC, str(src)]
+    out = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "kvr.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    get = lambda key: int(re.search(key + r"[^:]*: (\d+)", out.stderr).group(1))
+    assert get("Occupancy") == 2
+    assert get("ScratchSize") <= (700 if n_tendons == 3 else 1000)
+    assert get("AGPRs") == 0
+    asm = subprocess.run(base + ["-S", "-o", "-"], capture_output=True, text=True).stdout
+    assert asm.count("ds_read") + asm.count("ds_write") >= 30
+
+
 def test_isa_counts_are_current():
     """profiles/isa_counts.json -- the flops per RK4 step bench.py prices the fp64-VALU roofline with -- must be the
     count of THIS source tree's gfx950 assembly (profiles/count_isa.py rewrites it)."""
