@@ -76,7 +76,12 @@ def cpu_baseline(irt, robot, vox, states, budget_s=12.0):
     t0 = time.perf_counter()
     valid, _, used = orc.validate_batch(orb, og, states[:m], nthreads=threads, lib=orc.omp_lib())
     dt = time.perf_counter() - t0
-    return dict(value=m / dt, unit="checks/s", cores=int(used), kind="port",
+    try:
+        model = [l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name")][0]
+    except Exception:
+        model = None
+    return dict(value=m / dt, unit="checks/s", cores=int(used), kind="port", per_core=m / dt / max(1, int(used)), cpu_model=model,
+                build="oracle/tendon_oracle.c, gcc -O3 -march=native -fopenmp",
                 sample="first %d of the %d configurations of rank 0's batch, %.1f s wall, OpenMP schedule(dynamic,1)"
                        % (m, len(states), dt)), valid, m
 
@@ -148,6 +153,8 @@ def secondary_metrics():
                 "vertex_caches_built_per_s": c5["vertex_caches_built_per_s"], "edge_caches_built_per_s": c5["edge_caches_built_per_s"],
                 "solved_fraction": q["solved_fraction"]},
             "config1_fk_only": r["config1"], "sphere_checker_checks_per_s": r["sphere_checker"]["checks_per_s"],
+            "rotation_retraction_robot": {k: r["rotation_retraction_robot"][k] for k in ("robot", "checks_per_s", "edges", "edges_per_s",
+                                                                                         "edge_fk_samples_per_s")},
             "source": "bench_roadmap.py (python bench.py --workload roadmap prints all of it)"}
     except Exception as e:                                  # noqa: BLE001 -- reported, not raised
         return {"error": repr(e)[:400]}

@@ -321,6 +321,39 @@ def run(argv=None):
     out["sphere_checker"] = {"checks_per_s": nb / ts, "ms_per_2^20": 1e3 * ts,
                              "valid_fraction": float(irt.unpack_bits(bits.cpu().numpy().view(np.uint64), nb).mean()),
                              "note": "VoxelValidityChecker: 64 raw spheres r = 5 mm, robot radius 15 mm swept as spheres"}
+    # The planner's full state space (Problem.cpp:101-163): config 3's robot with rotation and retraction enabled, states
+    # sampled over the whole space (retraction ~ U[0, L)): fk_verdict_retract, batch ordered by backbone length
+    r4 = W.robot_config3()
+    r4.enable_rotation = True
+    r4.enable_retraction = True
+    rc = irt.VoxelBackboneValidityChecker(r4, irt.VoxelEnvironment(), vox)
+    nb = 1 << 20
+    st4 = torch.from_numpy(W.random_states(r4, nb, seed=5, tau_max=20.0)).cuda()
+    rc.engine.reserve(nb)
+    for _ in range(2):
+        rc.engine.validate_batch_dev(st4, nb, bits)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        rc.engine.validate_batch_dev(st4, nb, bits)
+    torch.cuda.synchronize()
+    tr_ = (time.perf_counter() - t0) / 5
+    rrb = irt.RoadmapBuilder(rc, irt.VoxelBackboneMotionValidator(rc), seed=13)
+    rstates, _ = rrb.sample_valid_vertices(50000, batch=1 << 16)
+    redges = rrb.knn_edges_gpu(rstates, args.k + 1)
+    rc.engine.reserve_edges(len(redges))
+    rrb.validate_edges(rstates, redges)
+    te = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        rv, rnf = rrb.validate_edges(rstates, redges)
+        te = min(te, time.perf_counter() - t0)
+    out["rotation_retraction_robot"] = {
+        "robot": "config 3's 4 tendons with rotation and retraction enabled (state = 4 tensions, angle, s_start), 256^3 grid, 64 spheres",
+        "checks_per_s": nb / tr_, "ms_per_2^20": 1e3 * tr_, "valid_fraction": float(irt.unpack_bits(bits.cpu().numpy().view(np.uint64), nb).mean()),
+        "vertices": int(len(rstates)), "edges": int(len(redges)), "edges_per_s": len(redges) / te, "edge_fk_samples_per_s": float(rnf.sum()) / te,
+        "edge_valid_fraction": float(rv.mean()),
+        "note": "states ~ U over the whole space incl. s_start ~ U[0, L): fk_verdict_retract, batch ordered by backbone length"}
     return out
 
 

@@ -74,6 +74,10 @@ struct EdgeDev {
   uint32_t *counters = nullptr;
   uint32_t *nd = nullptr; int64_t *cnt = nullptr;      // discrete variant: validSegmentCount, sample offsets [cap/2 + 2]
   uint32_t *sig = nullptr; int64_t sig_stride = 0;     // [cap][sig_stride] cell signatures of the pool samples (sweep_kernel.hpp)
+  // [cap] point counts of the pool samples whose signatures fk_verdict_retract wrote (tip-aligned rows).  NOT the
+  // workspace's n_points: the verdict path's fallback pass re-integrates its few configurations in workspace columns
+  // [0, fb_cap) and would overwrite the counts of the pool's first samples
+  int32_t *sig_np = nullptr;
 };
 
 }  // namespace
@@ -598,7 +602,7 @@ bool edge_signatures(const tr_ctx *ctx, bool with_points) {
 
 int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
                     int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s, uint32_t *sig = nullptr, int64_t sig_stride = 0,
-                    bool points_unused = false) {
+                    bool points_unused = false, int32_t *sig_np = nullptr /* retraction: the samples' point counts, next to sig */) {
   const int check_voxels = voxel_test == 1 ? 1 : 0;
   int rc;
   if (voxel_test == 2) {
@@ -608,7 +612,7 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
   if (ctx->fuse == 2 && voxel_test != 0 && points_unused && !out.R && !out.L && !out.tips) {
     // nobody reads this launch's backbone points (edge samples of the checkMotion forms: the bisection compares cell
     // signatures -- of tip-aligned rows for retraction robots, hence the point counts): the verdict-only kernel, which stores none
-    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride, voxel_test == 2, sig ? out.n_points : nullptr);
+    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride, voxel_test == 2, sig ? sig_np : nullptr);
   }
   if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s, sig, sig_stride))) return rc;
@@ -777,7 +781,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->edge.sig, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->edge.sig, c->edge.sig_np, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }

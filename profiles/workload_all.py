@@ -69,26 +69,31 @@ def main():
                 add("fk_rk4_batch_uniform<%d>" % N, bytes=reps * n * k1b, flops=reps * n * fl_k1, units=reps * n, unit="FK")
                 add("backbone_voxel_sweep", bytes=reps * n * k2b, units=reps * n, unit="shapes")
             del chk
-    # ---- retraction robots: K1r + K2 (tip-aligned rows) ---------------------------------------------------------------
+    # ---- retraction robots, s_start ~ U[0, L) as a planner samples it: K1r + K2 on stored points in arrival order
+    # (TENDON_HIP_FUSED=1), and the verdict-only form on the batch ordered by backbone length (default) -----------------
     for mk, N in ((W.robot_config2, 3), (W.robot_config3, 4)):
         robot = mk()
         robot.enable_retraction = True
         n = 1 << (19 - (4 if small else 0))
         stn = W.random_states(robot, n, seed=4, tau_max=10.0 if N == 3 else 20.0)
-        stn[:, -1] = np.random.default_rng(5).uniform(0.0, 0.1, n)
         st = torch.from_numpy(stn).cuda()
         bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
-        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
-        chk.engine.reserve(n)
-        for _ in range(reps):
-            chk.engine.validate_batch_dev(st, n, bits)
-        torch.cuda.synchronize()
-        # points per configuration ~ 129 * (1 - s/L) on average: count the algorithmic bytes of the mean
+        # points per configuration ~ 129 * (1 - s/L) on average: count the algorithmic bytes and flops of the mean
         pm = float(np.mean(np.ceil((0.2 - stn[:, -1]) / (0.2 / 128)) + 1))
-        add("fk_rk4_batch_retract<%d>" % N, bytes=reps * n * (8 * (N + 1) + 24 * pm + 16 * N + 5), units=reps * n, unit="FK",
-            flops=reps * n * isa["fk_rk4_batch_uniform<%d,false,false>" % N]["flops_per_step"] * (pm - 1))
-        add("backbone_voxel_sweep", bytes=reps * n * (24 * pm + 16 * N + 5), units=reps * n, unit="shapes")
-        del chk
+        for mode in ("1", "2"):
+            chk = with_env({"TENDON_HIP_FUSED": mode}, lambda: irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox))
+            chk.engine.reserve(n)
+            for _ in range(reps):
+                chk.engine.validate_batch_dev(st, n, bits)
+            torch.cuda.synchronize()
+            if mode == "1":
+                add("fk_rk4_batch_retract<%d>" % N, bytes=reps * n * (8 * (N + 1) + 24 * pm + 16 * N + 5), units=reps * n, unit="FK",
+                    flops=reps * n * isa["fk_rk4_batch_uniform<%d,false,false>" % N]["flops_per_step"] * (pm - 1))
+                add("backbone_voxel_sweep", bytes=reps * n * (24 * pm + 16 * N + 5), units=reps * n, unit="shapes")
+            else:
+                add("fk_verdict_retract<%d>" % N, bytes=reps * n * (8 * (N + 1) + 24 + 0.125 + 4), units=reps * n, unit="checks",
+                    flops=reps * n * isa["rk4_step<%d>" % N]["flops_per_step"] * (pm - 1))
+            del chk
     # ---- config 3 roadmap: vertices, k-NN, indexed edges, caches, K4 ---------------------------------------------------
     robot = W.robot_config3()
     chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)

@@ -272,3 +272,35 @@ def test_verdict_only_kernel_with_retraction_all_branches(irt, checker):
         seen += np.bincount(want["flags"], minlength=32)
     print("flag histogram", seen)
     assert seen[15] > 0 and seen[7] > 0 and seen[3] > 0 and seen[1] > 0 and seen[0] > 0
+
+
+def test_edges_with_retraction_where_samples_need_the_fallback_pass(irt, orc, helpers):
+    """Edge samples of retraction robots go through fk_verdict_retract, whose fallback pass (exact self-collision sweep)
+    re-integrates its few configurations in the first columns of the point workspace.  The interval test's per-sample point
+    counts must not live there (they did: the counts of the pool's first samples were overwritten and edge 0 subdivided
+    21 times instead of 8).  A slender robot under high tension curls onto itself, so many samples take the fallback."""
+    W = irt.workloads
+    robot = W.robot_config1()
+    robot.specs.dL = 0.2 / 128
+    robot.r = 0.008
+    robot.enable_retraction = True
+    for t in robot.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 0.12
+    vox, _ = W.reach_environment(seed=3, n_spheres=12)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    mv = irt.VoxelBackboneMotionValidator(chk)
+    rng = np.random.default_rng(71)
+    m = 400
+    a = W.random_states(robot, m, seed=72, tau_max=100.0)
+    a[:, -1] = rng.uniform(0.0, 0.1, m)
+    b = a + rng.normal(0, 1.5, a.shape)
+    b[:, :3] = np.clip(b[:, :3], 0, 100.0)
+    b[:, -1] = np.clip(a[:, -1] + rng.normal(0, 0.01, m), 0, 0.2)
+    det = chk.is_valid_detail(np.concatenate([a, b]))
+    assert ((det["flags"] & 7) == 3).sum() > 60                      # end states in self collision: each one a fallback entry
+    got = mv.check_motion_detail(a, b)
+    want, nfk, _ = orc.check_motion_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), a, b,
+                                          nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(got["valid"], want), np.flatnonzero(got["valid"] != want)[:10]
+    assert np.array_equal(got["n_fk"][want], nfk[want]), np.flatnonzero((got["n_fk"] != nfk) & want)[:10]
+    assert 0.3 < want.mean() < 0.95
