@@ -390,8 +390,14 @@ struct PointSweep {
   }
 };
 
+// Waves per SIMD: K1 with stored points holds two up to 6 tendons (tr_types.hpp); with the sweep in the loop the spills at that
+// budget cost more than the second wave hides from 5 tendons on (measured, profiles/r02/verdict_widths_v1.txt, ms per 2^18
+// configurations, two waves | one: N=4 3.11 | 3.13, N=5 4.01 | 3.52, N=6 5.11 | 4.02; N=7 5.96 | 4.61, N=8 7.08 | 4.92).
+#ifndef TRK_VERDICT_TWO_WAVE_MAXN
+#define TRK_VERDICT_TWO_WAVE_MAXN 4
+#endif
 template <int N, bool ROT, bool SPH>
-__global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
+__global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
     const double *__restrict__ states, int64_t n, RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps,
     int nsteps, double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
   const int lane = threadIdx.x;

@@ -40,8 +40,19 @@ class RoadmapBuilder:
             states.append(cand[take]); tips.append(out["tips"][take])
             have += take.size
             pos += batch
+        states, tips = np.concatenate(states), np.concatenate(tips)
+        if self.robot.enable_retraction:
+            # Milestones are numbered by backbone length.  The numbering of a roadmap's vertices is free (the reference's is the
+            # order of its addMilestone calls), and with this one every later batch over the roadmap is homogeneous wave by
+            # wave: vertex v's neighbours in state space have similar retractions (the retraction term of the metric is the
+            # heaviest, Problem.cpp:144-152), the edge list comes out ordered by vertex number, and the bisection hands its
+            # samples on in groups of 64 neighbours -- so a wave of the retraction kernels (which runs from its LONGEST
+            # backbone's base to the tip, shorter ones idling) holds backbones of one length in the stored-point forms
+            # (voxel caches, connect) too, where no device-side ordering is applied.
+            order = np.argsort(states[:, -1], kind="stable")
+            states, tips = np.ascontiguousarray(states[order]), np.ascontiguousarray(tips[order])
         self.timing["vertices"] = dict(seconds=time.perf_counter() - t0, candidates=tried, accepted=N)
-        return np.concatenate(states), np.concatenate(tips)
+        return states, tips
 
     # ---- phase 3: k nearest neighbours in state space (host) -------------------------------------------
     def state_space_metric_scale(self):
