@@ -415,7 +415,9 @@ int tr_kstar_k(const tr_ctx *ctx, int64_t n_milestones);
  * tr_profile_read returns, per kernel slot, launches and total milliseconds since begin.
  * slots: 0 = fk_rk4_batch, 1 = backbone_voxel_sweep, 2 = cached_blocks_vs_grid, 3 = edge helpers,
  * 4 = fk_sweep_fused (K1 + K2 in one launch over stored points: edge samples, voxel caches, the sphere checker, and the
- *     fallback pass of the verdict path), 5 = fk_verdict (the verdict-only kernel of tr_validate_batch*) */
+ *     fallback pass of the verdict path), 5 = fk_verdict (the verdict-only kernel of tr_validate_batch* and of the edge
+ *     samples; fk_verdict_retract for retraction-enabled robots -- the ordering of its batch by backbone length runs
+ *     outside the slot) */
 #define TR_PROFILE_SLOTS 6
 int tr_profile_begin(tr_ctx *ctx);
 int tr_profile_read(tr_ctx *ctx, int64_t launches[TR_PROFILE_SLOTS], double total_ms[TR_PROFILE_SLOTS]);
