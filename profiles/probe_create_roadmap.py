@@ -20,4 +20,8 @@ for full in (False, True):
         dt = time.perf_counter() - t0
         if best is None or dt < best[0]:
             best = (dt, {k: round(1e3 * v["seconds"], 1) for k, v in rb.timing.items() if "seconds" in v}, len(rm["edges"]))
+    knn = []
+    for _ in range(3):
+        t0 = time.perf_counter(); rb.knn_edges_gpu(rm["states"], 11); knn.append(round(1e3 * (time.perf_counter() - t0), 1))
+    print("  knn_edges_gpu alone, three more calls (ms):", knn)
     print("rotation + retraction" if full else "tensions only", "vertices", V, "edges kept", best[2], "create_roadmap %.1f ms" % (1e3 * best[0]), best[1], flush=True)
