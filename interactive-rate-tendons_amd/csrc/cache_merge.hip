@@ -294,10 +294,10 @@ hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int 
 
 
 namespace {
-__global__ __launch_bounds__(256) void first_coordinate_keys(const double *__restrict__ states, int64_t n, int S, double *__restrict__ keys,
-                                                             int32_t *__restrict__ vals) {
+__global__ __launch_bounds__(256) void key_coordinate_keys(const double *__restrict__ states, int64_t n, int S, int col, double scale,
+                                                           double *__restrict__ keys, int32_t *__restrict__ vals) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n) { keys[i] = states[i * S]; vals[i] = (int32_t)i; }
+  if (i < n) { keys[i] = scale * states[i * S + col]; vals[i] = (int32_t)i; }       // the product the search kernel forms for its queries
 }
 __global__ __launch_bounds__(256) void gather_states(const double *__restrict__ states, const int32_t *__restrict__ perm, int64_t n, int S,
                                                      double *__restrict__ sorted) {
@@ -306,10 +306,11 @@ __global__ __launch_bounds__(256) void gather_states(const double *__restrict__ 
 }
 }  // namespace
 
-hipError_t sort_states_by_first(MergeScratch &ms, const double *d_states, int64_t n, int S, double *d_sorted, double *d_xs,
-                                int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream) {
+hipError_t sort_states_by_key(MergeScratch &ms, const double *d_states, int64_t n, int S, int key_col, double key_scale, double *d_sorted,
+                              double *d_xs, int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
-  hipLaunchKernelGGL(first_coordinate_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, d_keys_tmp, d_perm_tmp);
+  hipLaunchKernelGGL(key_coordinate_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, key_col, key_scale,
+                     d_keys_tmp, d_perm_tmp);
   MERGE_TRY(hipGetLastError());
   size_t bytes = 0;
   MERGE_TRY(rocprim::radix_sort_pairs(nullptr, bytes, d_keys_tmp, d_xs, d_perm_tmp, d_perm, (size_t)n, 0u, 64u, stream));

@@ -48,11 +48,12 @@ void merge_free(MergeScratch &ms);
 hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int k, int32_t *d_edges, int64_t capacity,
                          int64_t *n_edges, hipStream_t stream);
 
-// The states ordered by their first coordinate, for the neighbour search (knn_kernel.hpp): d_sorted [n][S] = the states in
-// ascending order of states[i][0], d_xs [n] those coordinates, d_perm [n] the original index of each (stable: equal
-// coordinates keep their order).  All arrays on the device; d_keys_tmp [n] doubles and d_perm_tmp [n] int32 are scratch.
-hipError_t sort_states_by_first(MergeScratch &ms, const double *d_states, int64_t n, int S, double *d_sorted, double *d_xs,
-                                int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream);
+// The states ordered by one weighted coordinate, for the neighbour search (knn_kernel.hpp): key = key_scale * states[i][key_col]
+// -- a term of the compound metric, so |key difference| <= distance.  d_sorted [n][S] = the states in ascending order of the key,
+// d_xs [n] those keys, d_perm [n] the original index of each (stable: equal keys keep their order).  All arrays on the device;
+// d_keys_tmp [n] doubles and d_perm_tmp [n] int32 are scratch.
+hipError_t sort_states_by_key(MergeScratch &ms, const double *d_states, int64_t n, int S, int key_col, double key_scale, double *d_sorted,
+                              double *d_xs, int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream);
 
 // Retraction-enabled robots: the order in which the verdict-only kernel takes a batch.  A wave of the retraction kernel runs
 // from its LONGEST backbone's base to the tip (tip-aligned iterations, fk_retract_kernel.hpp), shorter backbones idling

@@ -37,7 +37,7 @@ constexpr int KNN_SMAX = TRK_MAX_TENDONS + 2;
 // test on the squared distance (rare once the list has warmed up).
 // NT tension dimensions and the presence of the rotation / retraction coordinates are compile-time: a chunk is then
 // straight-line code and its scalar loads are issued back to back.
-// cand / xs / perm: the states in sorted order, their first coordinates, and the original index of each.  qlist (optional):
+// cand / xs / perm: the states in sorted order, their sort keys (first tension, or w_ret s_start), and the original index of each.  qlist (optional):
 // sorted positions of the queries (ascending; null = every state is a query), nq of them; row_first: original index of
 // the first output row (tr_knn_range).  half_window > 0 marks the seeding pass: candidates = the half_window sorted
 // neighbours either side of the wave's queries, only the k-th distance is written (seed_out, indexed like qlist).
@@ -64,6 +64,7 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
   // or, while the list is not full, the SEED (any index): the k nearest of all candidates are at most that far, so a slice
   // starts by accepting exactly the candidates with distance <= seed instead of filling its list with whatever comes first
   // and shifting it ~k ln(slice / k) times (those insertions, not the distances, were 80 % of the kernel's time).
+  constexpr int SS_KEY = NT + (ROT ? 1 : 0);                 // position of the retraction coordinate, when there is one
   double worst = 1.0 / 0.0;
   if (seed) worst = seed[qc];
   // ---- the wave's candidate range [j0, j1) in sorted order ----
@@ -77,11 +78,13 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
       lo = a - half_window; hi = b + 1 + half_window;
       lo = lo < 0 ? 0 : lo; hi = hi > n_cand ? n_cand : hi;
     } else {
-      // |x0 - c0| <= distance(x, c): a candidate outside [x0 - r, x0 + r] cannot be among the k nearest when k candidates
+      // |key(x) - key(c)| <= distance(x, c) (the key is one term of the metric: the first tension, or w_ret s_start when
+      // the robot retracts): a candidate outside [key - r, key + r] cannot be among the k nearest when k candidates
       // within r exist (the seed).  r is widened by a relative 1e-12: sqrt(fl(t0^2 + ...)) may round an ulp below |t0|.
       double r = worst < max_dist ? worst : max_dist;
       r = r + r * 1e-12;
-      const double xlo = wave_min(x[0] - r), xhi = wave_max(x[0] + r);
+      const double xk = RET ? m.w_ret * x[SS_KEY] : x[0];      // the key the states were sorted by (tr_knn: sort_states_by_key)
+      const double xlo = wave_min(xk - r), xhi = wave_max(xk + r);
       lo = 0; hi = n_cand;
       if (xlo > -1.0 / 0.0 && xlo == xlo) {                       // lower bound: first candidate with xs >= xlo
         int64_t a = 0, b = n_cand;

@@ -1664,7 +1664,10 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
     if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
-      const hipError_t e = trk::sort_states_by_first(c->merge, d_s, n, S, d_ss, d_xs, d_perm, d_kt, d_pt, nullptr);
+      // the coordinate the search is ordered and windowed by: the retraction term of the metric when there is one (its
+      // spread, 2 extent, is several times a tension's), else the first tension
+      const bool by_ret = c->K.enable_retraction != 0;
+      const hipError_t e = trk::sort_states_by_key(c->merge, d_s, n, S, by_ret ? S - 1 : 0, by_ret ? m.w_ret : 1.0, d_ss, d_xs, d_perm, d_kt, d_pt, nullptr);
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn sort: ") + hipGetErrorString(e)); break; }
     }
     if (nq != n) {
@@ -1704,14 +1707,14 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
     if (dist && hipMemcpy(dist, d_d, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
     if (n_edges) {
       // the undirected edge set of the table, deduplicated and ordered on the device (cache_merge.hip)
-      int32_t *d_e = nullptr;
+      int32_t *d_e = nullptr;                 // kept with the rest of the search's scratch: a hipMalloc / hipFree pair per call costs
+                                              // 15 - 30 ms in a process that holds the edge pool (profiles/r02/create_roadmap_v1.txt)
       const int64_t cap_e = std::min<int64_t>(edge_capacity, n * (int64_t)k);
-      if (cap_e > 0 && hipMalloc((void **)&d_e, (size_t)cap_e * 2 * sizeof(int32_t)) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+      if (cap_e > 0 && !scratch(11, (size_t)cap_e * 2 * sizeof(int32_t), &d_e)) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
       hipError_t e = trk::knn_edge_list(c->merge, d_i, n, (int)k, d_e, cap_e, n_edges, nullptr);
       if (e == hipSuccess) e = hipDeviceSynchronize();
       const int64_t mm = std::min<int64_t>(*n_edges, cap_e);
       if (e == hipSuccess && mm > 0) e = hipMemcpy(edges, d_e, (size_t)mm * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
-      if (d_e) (void)hipFree(d_e);
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn edge list: ") + hipGetErrorString(e)); break; }
     }
   } while (0);
