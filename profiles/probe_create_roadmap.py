@@ -13,11 +13,12 @@ for full in (False, True):
     vox, _ = W.reach_environment(seed=7, n_spheres=64)
     chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
     best = None
-    for rep in range(3):
+    for rep in range(5):                                    # the first two also warm the process up (allocations, clocks)
         rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
         t0 = time.perf_counter()
         prm, rm = rb.create_roadmap(V, k=10)
         dt = time.perf_counter() - t0
+        print("  rep", rep, "%.1f ms" % (1e3 * dt), {k: round(1e3 * v["seconds"], 1) for k, v in rb.timing.items() if "seconds" in v}, flush=True)
         if best is None or dt < best[0]:
             best = (dt, {k: round(1e3 * v["seconds"], 1) for k, v in rb.timing.items() if "seconds" in v}, len(rm["edges"]))
     knn = []
