@@ -1591,6 +1591,7 @@ int tr_knn_table_edges(tr_ctx *c, const int32_t *idx, int64_t n, int32_t k, int3
   for (int64_t i = 0; i < n * k; i++)
     if (idx[i] < -1 || idx[i] >= n) return fail(c, TR_ERR_OUT_OF_RANGE, "neighbour index outside the table");
   HIP_TRY(c, hipSetDevice(c->device));
+  if (c->last_dev_used) HIP_TRY(c, hipEventSynchronize(c->last_dev_ev));      // shared sort scratch, see knn_impl
   int32_t *d_i = nullptr, *d_e = nullptr;
   const int64_t cap_e = std::min<int64_t>(capacity, n * (int64_t)k);
   hipError_t e = hipMalloc((void **)&d_i, (size_t)n * k * sizeof(int32_t));
@@ -1625,6 +1626,9 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   if ((size_t)k * 64 * 12 > 60 * 1024) return fail(c, TR_ERR_INVALID_ARG, "k too large (at most 80)");
   if (n >= (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
   HIP_TRY(c, hipSetDevice(c->device));
+  // the sort scratch (tr_ctx::merge) is shared with the ordering pass of a *_dev validity call that may still run on the
+  // caller's stream
+  if (c->last_dev_used) HIP_TRY(c, hipEventSynchronize(c->last_dev_ev));
   const int S = c->K.state_size, N = c->K.n_tendons;
   double ext2 = 0;
   for (int i = 0; i < N; i++) ext2 += c->max_tension[i] * c->max_tension[i];
