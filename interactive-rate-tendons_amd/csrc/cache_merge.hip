@@ -335,8 +335,23 @@ __global__ __launch_bounds__(256) void retraction_keys(const double *__restrict_
 }
 }  // namespace
 
+// wave w of the ordered batch holds sorted positions [64 w, 64 w + 64): its smallest level bounds every retraction in it from below,
+// i.e. its longest backbone from above: s_start >= level / 255 * L (the key is the truncation of s / L * 255).  Rows are spaced dL
+// from the tip, a backbone starting at s has its base in row >= floor(s / dL) - 1 (the first interval is at most 1.5 dL long), and
+// behind the grid's own first interval step k_first + r - 2 ends in row r: nothing of the wave happens before step
+// k_first + floor(s_low / dL) - 3.
+__global__ __launch_bounds__(256) void retraction_wave_begin(const uint32_t *__restrict__ sorted_keys, int64_t n, double L, double dL, int k_first,
+                                                             int32_t *__restrict__ out) {
+  const int64_t w = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (w * 64 >= n) return;
+  const double s_low = (double)sorted_keys[w * 64] * (1.0 / 255.0) * L;       // ascending order: the wave's first key is its smallest
+  const int rows = (int)(s_low / dL) - 3;
+  out[w] = rows > 0 ? k_first + rows : 0;
+}
+
 hipError_t retraction_order(MergeScratch &ms, const double *d_states, int64_t n, int S, double L, uint32_t *const d_keys[2],
-                            int32_t *const d_vals[2], const int32_t **perm_out, hipStream_t stream) {
+                            int32_t *const d_vals[2], const int32_t **perm_out, hipStream_t stream, double dL, int k_first, bool one_step_per_row,
+                            int32_t *d_wave_k_begin) {
   if (n <= 0) return hipSuccess;
   hipLaunchKernelGGL(retraction_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, 1.0 / L, d_keys[0], d_vals[0]);
   MERGE_TRY(hipGetLastError());
@@ -350,6 +365,15 @@ hipError_t retraction_order(MergeScratch &ms, const double *d_states, int64_t n,
   }
   MERGE_TRY(rocprim::radix_sort_pairs(ms.tmp, bytes, kb, vb, (size_t)n, 0u, 8u, stream));
   *perm_out = vb.current();
+  if (d_wave_k_begin) {
+    const int64_t nw = (n + 63) / 64;
+    if (one_step_per_row) {
+      hipLaunchKernelGGL(retraction_wave_begin, dim3((unsigned)((nw + 255) / 256)), dim3(256), 0, stream, kb.current(), n, L, dL, k_first, d_wave_k_begin);
+      MERGE_TRY(hipGetLastError());
+    } else {
+      MERGE_TRY(hipMemsetAsync(d_wave_k_begin, 0, (size_t)nw * sizeof(int32_t), stream));
+    }
+  }
   return hipSuccess;
 }
 

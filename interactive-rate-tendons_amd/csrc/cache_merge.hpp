@@ -61,7 +61,10 @@ hipError_t sort_states_by_key(MergeScratch &ms, const double *d_states, int64_t 
 // of its lane-steps are masked off.  d_perm [n] = configuration indices ordered by retraction (state coordinate S - 1,
 // clamped to [0, L], 256 levels: one radix pass), longest first -- a wave then holds backbones of one length.
 // d_keys / d_vals: two scratch arrays of n each; *perm_out points at the one holding the result.
+// d_wave_k_begin (optional, [ceil(n / 64)]): per wave of the ordered batch a step of the shared grid before which none of its backbones
+// has begun (0 when the grid does not take exactly one step per row behind its first interval: one_step_per_row).
 hipError_t retraction_order(MergeScratch &ms, const double *d_states, int64_t n, int S, double L, uint32_t *const d_keys[2],
-                            int32_t *const d_vals[2], const int32_t **perm_out, hipStream_t stream);
+                            int32_t *const d_vals[2], const int32_t **perm_out, hipStream_t stream, double dL = 0.0, int k_first = 0,
+                            bool one_step_per_row = false, int32_t *d_wave_k_begin = nullptr);
 
 }  // namespace trk

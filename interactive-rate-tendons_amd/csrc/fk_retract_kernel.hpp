@@ -119,7 +119,8 @@ __device__ __forceinline__ void fk_retract_body(
     const double *__restrict__ tab /* K1's routing table of the s_start = 0 grid */, const StepK *__restrict__ steps, int nsteps,
     int k_first /* first step after the grid's own first interval */, const double *__restrict__ tgrid /* [P] shared abscissae */,
     const double *__restrict__ hl /* [P][N] home-length integrand at the shared abscissae */, const FkOut &out,
-    OnPoint &&on_point = NoPointHook(), const int32_t *__restrict__ row_map = nullptr, FkLaneR<N> *lane_out = nullptr) {
+    OnPoint &&on_point = NoPointHook(), const int32_t *__restrict__ row_map = nullptr, FkLaneR<N> *lane_out = nullptr,
+    int k_begin = 0 /* wave-uniform: no lane of this wave has a point in a row that a step before k_begin ends in (0 = unknown) */) {
 #pragma clang fp contract(fast)
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = i < n;
@@ -226,7 +227,7 @@ __device__ __forceinline__ void fk_retract_body(
   }
 
   // tip-aligned: step k of the shared grid ends at its point steps[k].obs = the lane's point obs - shift
-  for (int k = k_first; k < nsteps; k++) {
+  for (int k = (k_begin > k_first ? k_begin : k_first); k < nsteps; k++) {
     const int obs = steps[k].obs;
     const int ipt = obs - shift;
     const bool act = !single && ipt >= 2;

@@ -131,6 +131,9 @@ struct tr_ctx {
   // for batches of at least retract_sort_min configurations (TENDON_HIP_RETRACT_SORT=<n>; 0 = never, keep arrival order)
   uint32_t *d_ro_keys[2] = {nullptr, nullptr}; int32_t *d_ro_vals[2] = {nullptr, nullptr}; int64_t ro_cap = 0;
   int64_t retract_sort_min = kRetractSortMin;
+  int32_t *d_ro_kbegin = nullptr;       // [ro_cap / 64] per wave of the ordered batch: the step its tip-aligned loop may start at
+  bool rows_one_step = false;           // behind the grid's own first interval every RK4 step ends in the next row
+  bool retract_wave_start = true;       // TENDON_HIP_RETRACT_KBEGIN_OFF (A/B switch of profiles/probe_retract.py): +1 - 2 %
   struct VerdictRing {
     static constexpr int kSlots = 16;
     trk::VerdictArgs *d_slots = nullptr, *h_slots = nullptr;
@@ -519,9 +522,12 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
         if ((rc = dev_alloc(ctx, &ctx->d_ro_keys[q], (size_t)want))) return rc;
         if ((rc = dev_alloc(ctx, &ctx->d_ro_vals[q], (size_t)want))) return rc;
       }
+      if ((rc = dev_alloc(ctx, &ctx->d_ro_kbegin, (size_t)want / 64))) return rc;
       ctx->ro_cap = want;
     }
-    const hipError_t e = trk::retraction_order(ctx->merge, d_states, n, ctx->K.state_size, ctx->K.L, ctx->d_ro_keys, ctx->d_ro_vals, &a.perm, s);
+    const hipError_t e = trk::retraction_order(ctx->merge, d_states, n, ctx->K.state_size, ctx->K.L, ctx->d_ro_keys, ctx->d_ro_vals, &a.perm, s,
+                                               ctx->K.dL, ctx->k_first, ctx->rows_one_step, ctx->d_ro_kbegin);
+    a.wave_k_begin = ctx->retract_wave_start ? ctx->d_ro_kbegin : nullptr;
     if (e != hipSuccess) return fail(ctx, TR_ERR_HIP, std::string("retraction order: ") + hipGetErrorString(e));
     HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, (size_t)((n + 63) / 64) * sizeof(uint64_t), s));
   }
@@ -662,6 +668,7 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   c->device = device;
   if (const char *e = std::getenv("TENDON_HIP_FUSED")) { const int v = std::atoi(e); c->fuse = v < 0 ? 0 : (v > 2 ? 2 : v); }
   if (const char *e = std::getenv("TENDON_HIP_RETRACT_SORT")) c->retract_sort_min = std::atoll(e);
+  if (std::getenv("TENDON_HIP_RETRACT_KBEGIN_OFF")) c->retract_wave_start = false;
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
     if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = (int64_t)round_up(v, 64);
@@ -731,6 +738,9 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   // retraction kernel: the step after the grid's own first interval, and the home-length integrand
   // sqrt(rho'^2 + rho^2 theta'^2 + 1) (TendonRobot.cpp:300-307) at every shared abscissa
   for (size_t k = 0; k < c->steps.size(); k++) if (c->steps[k].obs == 1) c->k_first = (int)k + 1;
+  c->rows_one_step = (int)c->steps.size() - c->k_first == K.n_points - 2;
+  for (size_t k = (size_t)c->k_first; k < c->steps.size() && c->rows_one_step; k++)
+    if (c->steps[k].obs != (int)k - c->k_first + 2) c->rows_one_step = false;
   std::vector<double> hl(c->t.size() * (size_t)N);
   for (size_t q = 0; q < c->t.size(); q++)
     for (int j = 0; j < N; j++) {
@@ -797,6 +807,7 @@ void tr_destroy(tr_ctx *c) {
   if (c->vstore.masks) (void)hipFree(c->vstore.masks);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
   for (int q = 0; q < 2; q++) { if (c->d_ro_keys[q]) (void)hipFree(c->d_ro_keys[q]); if (c->d_ro_vals[q]) (void)hipFree(c->d_ro_vals[q]); }
+  if (c->d_ro_kbegin) (void)hipFree(c->d_ro_kbegin);
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);
   delete c;
 }

@@ -47,6 +47,10 @@ struct VerdictArgs {
   // bit by an atomic OR into the zeroed mask; null = arrival order, bits by ballot
   const int32_t *perm;
   int32_t *np_out;                // optional (edge samples): the configurations' point counts, for the comparison of tip-aligned signature rows
+  // with perm: per wave of the ordered batch, a step index before which none of its 64 backbones has begun (from the longest
+  // backbone its retraction level allows, retraction_order): the wave enters the tip-aligned loop there instead of stepping
+  // over ~100 table entries when it was dealt short backbones
+  const int32_t *wave_k_begin;
 };
 
 constexpr int VQ = 128;           // ring of deferred segments per wave
@@ -501,7 +505,8 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
 
   FkLaneR<N> fl_;
   FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tips, nullptr, nullptr, nullptr};
-  fk_retract_body<N, ROT, false>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, ps, perm, &fl_);
+  const int32_t *__restrict__ wkb = va->wave_k_begin;
+  fk_retract_body<N, ROT, false>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, ps, perm, &fl_, wkb ? wkb[blockIdx.x] : 0);
 
   ps.finish();
   while (ps.qcount > 0) ps.flush();

@@ -9,12 +9,15 @@ vox, _ = W.reach_environment(seed=7, n_spheres=64)
 # 1 = stored points (retraction: K1r -> K2)
 # TENDON_HIP_RETRACT_SORT=0: the verdict-only kernel takes the batch in arrival order instead of ordered by backbone length
 for ret, fused, order, smax in ((False, "2", "1", 0.0), (True, "1", "1", 0.1), (True, "2", "0", 0.1), (True, "2", "8192", 0.1),
-                               (True, "1", "1", 0.2), (True, "2", "0", 0.2), (True, "2", "8192", 0.2)):
+                               (True, "1", "1", 0.2), (True, "2", "0", 0.2), (True, "2", "8192", 0.2), (True, "2", "8192/wave start off", 0.2)):
     for mk in (W.robot_config2, W.robot_config3):
         robot = mk()
         robot.enable_retraction = ret
         os.environ["TENDON_HIP_FUSED"] = fused
-        os.environ["TENDON_HIP_RETRACT_SORT"] = order
+        os.environ["TENDON_HIP_RETRACT_SORT"] = order.split("/")[0]
+        os.environ.pop("TENDON_HIP_RETRACT_KBEGIN_OFF", None)
+        if "off" in order:
+            os.environ["TENDON_HIP_RETRACT_KBEGIN_OFF"] = "1"
         chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
         n = 1 << 19
         st = W.random_states(robot, n, seed=1, tau_max=10.0)
