@@ -174,3 +174,54 @@ def test_config4_sizes_on_one_rank(irt):
     alone = mv.check_motion_indexed(verts, part[70000:90000])
     assert np.array_equal(whole["valid"][70000:90000], alone["valid"]) and np.array_equal(whole["n_fk"][70000:90000], alone["n_fk"])
     assert whole["valid"].mean() > 0.9
+
+
+def test_full_size_rotation_retraction_robot_order_invariance(irt, orc, helpers):
+    """The planner's full state space at full size: config 3's robot with rotation and retraction, 2^20 states over the whole
+    space.  A batch this large is integrated in the order of its backbone lengths (fk_verdict_retract); the same states in ragged
+    pieces -- pieces below 8192 states run in arrival order -- and as a permutation must give the same verdict, flags and tip
+    for every configuration, bit for bit (a lane's result does not depend on the wave it runs in), with the device-side
+    ordering switched off as well, and equal to the oracle's on a sample."""
+    import os
+    import torch
+    W = irt.workloads
+    robot = W.robot_config3()
+    robot.enable_rotation = True
+    robot.enable_retraction = True
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    states = W.random_states(robot, N, seed=77, tau_max=20.0)
+    states[:64, -1] = np.linspace(0.0, 0.2, 64)                   # both ends of the range, exactly
+
+    def run(chk, st):
+        n = len(st)
+        d = torch.from_numpy(np.ascontiguousarray(st)).cuda()
+        bits = torch.zeros((n + 63) // 64, dtype=torch.int64, device="cuda")
+        tips = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
+        flags = torch.zeros(n, dtype=torch.uint8, device="cuda")
+        chk.engine.validate_batch_dev(d, n, bits, tips, flags)
+        torch.cuda.synchronize()
+        return irt.unpack_bits(bits.cpu().numpy().view(np.uint64), n), tips.cpu().numpy(), flags.cpu().numpy()
+
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    v, t, f = run(chk, states)
+    assert 0.5 < v.mean() < 0.95 and np.array_equal(v, f == 15)
+    v2, t2, f2 = run(chk, states)
+    assert np.array_equal(v, v2) and np.array_equal(t, t2) and np.array_equal(f, f2)
+    cuts = [0, 1, 64, 1000, 8191, 8192 + 8191, 65537, 300001, N]
+    pv, pt, pf = zip(*[run(chk, states[a:b]) for a, b in zip(cuts[:-1], cuts[1:])])
+    assert np.array_equal(np.concatenate(pv), v) and np.array_equal(np.concatenate(pt), t) and np.array_equal(np.concatenate(pf), f)
+    perm = np.random.default_rng(5).permutation(N)
+    vp, tp, fp = run(chk, states[perm])
+    assert np.array_equal(vp, v[perm]) and np.array_equal(tp, t[perm]) and np.array_equal(fp, f[perm])
+    os.environ["TENDON_HIP_RETRACT_SORT"] = "0"
+    try:
+        va, ta, fa = run(irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox), states)
+    finally:
+        os.environ.pop("TENDON_HIP_RETRACT_SORT", None)
+    assert np.array_equal(va, v) and np.array_equal(ta, t) and np.array_equal(fa, f)
+    idx = np.random.default_rng(6).choice(N, 5000, replace=False)
+    want, tips, _ = orc.validate_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), states[idx],
+                                       nthreads=0, lib=orc.omp_lib())
+    assert np.array_equal(v[idx], want)
+    ok = (f[idx] & 1) > 0
+    assert np.abs(t[idx][ok] - tips[ok]).max() <= 1e-9
