@@ -49,7 +49,9 @@ class RoadmapBuilder:
             # samples on in groups of 64 neighbours -- so a wave of the retraction kernels (which runs from its LONGEST
             # backbone's base to the tip, shorter ones idling) holds backbones of one length in the stored-point forms
             # (voxel caches, connect) too, where no device-side ordering is applied.
-            order = np.argsort(states[:, -1], kind="stable")
+            # (65 536 levels of the retraction range: a radix sort of 16-bit keys, 1 ms per 10^5 against 12 for the doubles)
+            L_ = self.robot.specs.L
+            order = np.argsort(np.clip(states[:, -1] * (65535.0 / L_), 0.0, 65535.0).astype(np.uint16), kind="stable")
             states, tips = np.ascontiguousarray(states[order]), np.ascontiguousarray(tips[order])
         self.timing["vertices"] = dict(seconds=time.perf_counter() - t0, candidates=tried, accepted=N)
         return states, tips
