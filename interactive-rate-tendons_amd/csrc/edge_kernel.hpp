@@ -300,8 +300,8 @@ __global__ __launch_bounds__(256) void edge_open(EdgeState st, EdgeSpaceK sk, co
 
 // partial.t of checkMotion(s1, s2, last_valid): the largest sampled t below the first invalid one
 // (VoxelEnvironment.cpp:403-424)
-__global__ __launch_bounds__(256) void edge_last_valid_t(EdgeState st, int64_t pool) {
-  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(256) void edge_last_valid_t(EdgeState st, int64_t slot_lo, int64_t pool) {     // the run's own slots [slot_lo, pool)
+  const int64_t s = slot_lo + (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (s >= pool) return;
   const int32_t e = st.sample_edge[s];
   if (e < 0) return;

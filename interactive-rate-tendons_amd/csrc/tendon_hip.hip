@@ -127,6 +127,16 @@ struct tr_ctx {
   int fuse = 2;
   int64_t fb_cap = 1 << 17;       // columns of the fallback pass's point workspace: one resident round of waves (tr_create), env TENDON_HIP_FB_CAP
   int32_t *d_fb_list = nullptr; uint32_t *d_fb_count = nullptr; int64_t fb_list_cap = 0;
+  // second lane of the edge bisection (edge_host.inc: EdgeLane): its own fallback list, stream, counters
+  int32_t *d_fb_list1 = nullptr; uint32_t *d_fb_count1 = nullptr; int64_t fb_list1_cap = 0;
+  hipStream_t edge_stream[2] = {nullptr, nullptr};
+  uint32_t *edge_hc[2] = {nullptr, nullptr};      // pinned host images of the lanes' counters
+  uint32_t *d_edge_counters1 = nullptr;
+  int edge_lanes = 2;                             // TENDON_HIP_EDGE_LANES=1: one lane only
+  double edge_rate_seen = 0.0;                    // own samples per edge of this context's last indexed edge call (0 = none yet): sizes
+                                                  // the next call's chunks and lanes (a rotating robot's edges take ~10, not ~4)
+  double edge_lane_guess = 6.0;                   // own samples per edge assumed when a half is given its share of the pool
+                                                  // (TENDON_HIP_EDGE_LANE_GUESS: testing, a small value provokes the overflow path)
   // retraction robots: the batch ordered by backbone length for the verdict-only kernel (cache_merge.hpp: retraction_order);
   // for batches of at least retract_sort_min configurations (TENDON_HIP_RETRACT_SORT=<n>; 0 = never, keep arrival order)
   uint32_t *d_ro_keys[2] = {nullptr, nullptr}; int32_t *d_ro_vals[2] = {nullptr, nullptr}; int64_t ro_cap = 0;
@@ -472,20 +482,26 @@ int launch_fused(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, con
 // blocks return at once).  d_bits / d_flags / d_tips as in tr_validate_batch_dev; n <= 2^31.
 int ensure_sphere_near(tr_ctx *c, hipStream_t s);
 int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_bits, double *d_tips, uint8_t *d_flags, hipStream_t s,
-                   uint32_t *sig = nullptr, int64_t sig_stride = 0, bool spheres = false, int32_t *np_out = nullptr) {
+                   uint32_t *sig = nullptr, int64_t sig_stride = 0, bool spheres = false, int32_t *np_out = nullptr, int lane = 0) {
   if (n <= 0) return TR_OK;
   if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
   int rc;
   if (spheres && (rc = ensure_sphere_near(ctx, s))) return rc;
   Workspace &w = ctx->ws;
-  if (ctx->fb_list_cap < n) {
+  // lane 1 (the second lane of an edge bisection, running concurrently on its own stream): its own list and counter, and the
+  // workspace columns [fb_cap, 2 fb_cap) for its fallback pass
+  int32_t *&fb_list = lane ? ctx->d_fb_list1 : ctx->d_fb_list;
+  uint32_t *&fb_count = lane ? ctx->d_fb_count1 : ctx->d_fb_count;
+  int64_t &fb_list_cap = lane ? ctx->fb_list1_cap : ctx->fb_list_cap;
+  if (fb_list_cap < n) {
     HIP_TRY(ctx, hipDeviceSynchronize());
-    if ((rc = dev_alloc(ctx, &ctx->d_fb_list, (size_t)round_up(n, 64)))) return rc;
-    if (!ctx->d_fb_count && (rc = dev_alloc(ctx, &ctx->d_fb_count, 1))) return rc;
-    ctx->fb_list_cap = round_up(n, 64);
+    if ((rc = dev_alloc(ctx, &fb_list, (size_t)round_up(n, 64)))) return rc;
+    if (!fb_count && (rc = dev_alloc(ctx, &fb_count, 1))) return rc;
+    fb_list_cap = round_up(n, 64);
   }
   const int64_t cap = std::min<int64_t>(ctx->fb_cap, round_up(n, 64));
-  if ((rc = ensure_workspace(ctx, cap))) return rc;
+  if ((rc = ensure_workspace(ctx, lane ? 2 * ctx->fb_cap : cap))) return rc;
+  const int64_t fcol = lane ? ctx->fb_cap : 0;                    // first workspace column of this lane's fallback pass
   tr_ctx::VerdictRing &vr = ctx->vring;
   if (!vr.d_slots) {
     HIP_TRY(ctx, hipMalloc((void **)&vr.d_slots, sizeof(trk::VerdictArgs) * tr_ctx::VerdictRing::kSlots));
@@ -507,7 +523,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     a.box[2] = g.ymin + 1e-6 * (g.ymax - g.ymin); a.box[3] = g.ymax - 1e-6 * (g.ymax - g.ymin);
     a.box[4] = g.zmin + 1e-6 * (g.zmax - g.zmin); a.box[5] = g.zmax - 1e-6 * (g.zmax - g.zmin);
   }
-  a.fb_list = ctx->d_fb_list; a.fb_count = ctx->d_fb_count;
+  a.fb_list = fb_list; a.fb_count = fb_count;
   a.sig = sig; a.sig_stride = sig_stride; a.np_out = np_out;
   if (spheres) {                       // classification thresholds (verdict_kernel.hpp: PointSweep<true>)
     a.field = ctx->d_sph_near; a.radius = ctx->K.radius;
@@ -532,16 +548,18 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, (size_t)((n + 63) / 64) * sizeof(uint64_t), s));
   }
   HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
-  HIP_TRY(ctx, hipMemsetAsync(ctx->d_fb_count, 0, sizeof(uint32_t), s));
+  HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(uint32_t), s));
   // the fallback pass sweeps columns of the small point workspace
   const bool ret = ctx->K.enable_retraction;      // K1r's body in both launches, tip-aligned rows in the fallback workspace
-  trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
+  trk::SweepIn in{w.px + fcol, w.py + fcol, w.pz + fcol, ret ? w.np + fcol : nullptr, w.Li + fcol, w.conv + fcol, ret ? w.homeLi + fcol : nullptr,
+                  w.acc + fcol};
   const trk::FusedSweepArgs *d_fargs; size_t lds_f; int fslot;
   if ((rc = fused_args_slot(ctx, in, spheres ? 2 : 1, d_bits, d_flags, s, &d_fargs, &lds_f, &fslot))) return rc;
   const trk::FkOut vout{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_tips, nullptr, nullptr, nullptr};
   const trk::FkLaunch vl{d_states, n, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                          (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, vout, s};
-  const trk::FkOut fout{w.px, w.py, w.pz, nullptr, nullptr, w.Li, nullptr, w.conv, ret ? w.np : nullptr, ret ? w.homeLi : nullptr};
+  const trk::FkOut fout{w.px + fcol, w.py + fcol, w.pz + fcol, nullptr, nullptr, w.Li + fcol, nullptr, w.conv + fcol, ret ? w.np + fcol : nullptr,
+                        ret ? w.homeLi + fcol : nullptr};
   const trk::FkLaunch fl{d_states, cap, w.ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                          (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, fout, s};
   const size_t lds_v = trk::verdict_lds_bytes(a.NM);
@@ -559,8 +577,8 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   {
     ProfScope ps(ctx, 4, s);
     switch (ctx->K.n_tendons) {
-#define TRK_CASE(N) case N: if (ret) trk::launch_fk_sweep_retract_list<N>(fl, d_fargs, lds_f, ctx->d_fb_list, ctx->d_fb_count); \
-                            else trk::launch_fk_sweep_fused_list<N>(fl, d_fargs, lds_f, ctx->d_fb_list, ctx->d_fb_count); break;
+#define TRK_CASE(N) case N: if (ret) trk::launch_fk_sweep_retract_list<N>(fl, d_fargs, lds_f, fb_list, fb_count); \
+                            else trk::launch_fk_sweep_fused_list<N>(fl, d_fargs, lds_f, fb_list, fb_count); break;
       TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
       default: break;
@@ -611,7 +629,8 @@ bool edge_signatures(const tr_ctx *ctx, bool with_points) {
 
 int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, const trk::SweepIn &in,
                     int voxel_test, uint64_t *d_bits, uint8_t *d_flags, hipStream_t s, uint32_t *sig = nullptr, int64_t sig_stride = 0,
-                    bool points_unused = false, int32_t *sig_np = nullptr /* retraction: the samples' point counts, next to sig */) {
+                    bool points_unused = false, int32_t *sig_np = nullptr /* retraction: the samples' point counts, next to sig */,
+                    int lane = 0) {
   const int check_voxels = voxel_test == 1 ? 1 : 0;
   int rc;
   if (voxel_test == 2) {
@@ -621,7 +640,7 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
   if (ctx->fuse == 2 && voxel_test != 0 && points_unused && !out.R && !out.L && !out.tips) {
     // nobody reads this launch's backbone points (edge samples of the checkMotion forms: the bisection compares cell
     // signatures -- of tip-aligned rows for retraction robots, hence the point counts): the verdict-only kernel, which stores none
-    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride, voxel_test == 2, sig ? sig_np : nullptr);
+    return launch_verdict(ctx, d_states, n, d_bits, nullptr, d_flags, s, sig, sig_stride, voxel_test == 2, sig ? sig_np : nullptr, lane);
   }
   if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s, sig, sig_stride))) return rc;
@@ -669,6 +688,8 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (const char *e = std::getenv("TENDON_HIP_FUSED")) { const int v = std::atoi(e); c->fuse = v < 0 ? 0 : (v > 2 ? 2 : v); }
   if (const char *e = std::getenv("TENDON_HIP_RETRACT_SORT")) c->retract_sort_min = std::atoll(e);
   if (std::getenv("TENDON_HIP_RETRACT_KBEGIN_OFF")) c->retract_wave_start = false;
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_LANES")) c->edge_lanes = std::atoi(e) >= 2 ? 2 : 1;
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_LANE_GUESS")) { const double v = std::atof(e); if (v >= 0.5 && v <= 64.0) c->edge_lane_guess = v; }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
     if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = (int64_t)round_up(v, 64);
@@ -806,6 +827,10 @@ void tr_destroy(tr_ctx *c) {
   if (c->vstore.ids) (void)hipFree(c->vstore.ids);
   if (c->vstore.masks) (void)hipFree(c->vstore.masks);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
+  if (c->d_fb_list1) (void)hipFree(c->d_fb_list1);
+  if (c->d_fb_count1) (void)hipFree(c->d_fb_count1);
+  if (c->d_edge_counters1) (void)hipFree(c->d_edge_counters1);
+  for (int q = 0; q < 2; q++) { if (c->edge_stream[q]) (void)hipStreamDestroy(c->edge_stream[q]); if (c->edge_hc[q]) (void)hipHostFree(c->edge_hc[q]); }
   for (int q = 0; q < 2; q++) { if (c->d_ro_keys[q]) (void)hipFree(c->d_ro_keys[q]); if (c->d_ro_vals[q]) (void)hipFree(c->d_ro_vals[q]); }
   if (c->d_ro_kbegin) (void)hipFree(c->d_ro_kbegin);
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);

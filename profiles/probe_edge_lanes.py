@@ -1,0 +1,29 @@
+"""tr_validate_edges_indexed with one lane and with two (TENDON_HIP_EDGE_LANES, read when a context is created): config 3's robot,
+roadmaps of 25 k / 50 k / 100 k vertices, 10-NN edges, best of five calls each."""
+import importlib, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+irt = importlib.import_module("interactive-rate-tendons_amd")
+W = irt.workloads
+for rot in (False, True):
+    for V in (25000, 50000, 100000):
+        res = {}
+        for lanes in ("1", "2"):
+            os.environ["TENDON_HIP_EDGE_LANES"] = lanes
+            robot = W.robot_config3()
+            robot.enable_rotation = rot
+            vox, _ = W.reach_environment(seed=7, n_spheres=64)
+            chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+            rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
+            states, _ = rb.sample_valid_vertices(V, batch=1 << 17)
+            edges = rb.knn_edges_gpu(states, 11)
+            chk.engine.reserve_edges(len(edges))
+            rb.validate_edges(states, edges)
+            best = 1e9
+            for _ in range(5):
+                t0 = time.perf_counter(); v, nf = rb.validate_edges(states, edges); best = min(best, time.perf_counter() - t0)
+            res[lanes] = (best, int(np.flatnonzero(v).sum()), int(nf.sum()), len(edges))
+        assert res["1"][1:] == res["2"][1:], res
+        print("rotation %s, %d vertices, %d edges: one lane %.2f ms, two lanes %.2f ms (%.1f %%) = %.3g edges/s, %.3g FK samples/s"
+              % (rot, V, res["1"][3], 1e3 * res["1"][0], 1e3 * res["2"][0], 100 * (res["1"][0] - res["2"][0]) / res["1"][0],
+                 res["2"][3] / res["2"][0], res["2"][2] / res["2"][0]), flush=True)

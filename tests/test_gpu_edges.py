@@ -269,3 +269,47 @@ def test_indexed_edges_equal_the_pairwise_form(irt):
         assert 0.05 < got["valid"].mean() < 0.99 and got["n_fk"].max() > 4
     with pytest.raises(irt.OutOfRange):
         irt.VoxelBackboneMotionValidator(irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)).check_motion_indexed(states, [[0, 900]])
+
+
+def test_two_lane_bisection_equals_one_lane(irt, orc, helpers):
+    """tr_validate_edges_indexed bisects the two halves of a roadmap's edge list side by side on two streams (each lane with its
+    half of the sample pool, its own frontier, counters and fallback list; one host thread alternating between them).  Verdicts,
+    FK counts and the domain-error count equal the one-lane path's (TENDON_HIP_EDGE_LANES=1) -- where samples need the fallback
+    pass (a slender robot under high tension, through a 64-column fallback workspace), with a rotating robot in a rotated
+    environment, and with a pool so small that a lane overflows and the call falls back to one lane -- and the oracle's on a
+    sample of the edges."""
+    W = irt.workloads
+    thin = W.robot_config1()
+    thin.specs.dL = 0.2 / 128
+    thin.r = 0.008
+    for t in thin.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 0.12
+    spin = W.robot_config3()
+    spin.enable_rotation = True
+    a = 0.4
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    for robot, tau_max, inv_rot, nv in ((thin, 100.0, None, 1500), (spin, 20.0, rot, 1500)):
+        vox, _ = W.reach_environment(seed=7, n_spheres=48)
+        env = irt.VoxelEnvironment()
+        if inv_rot is not None:
+            env.inv_rotation = inv_rot
+        states = W.random_states(robot, nv, seed=81, tau_max=tau_max)
+        nt = len(robot.tendons)
+        near = np.argsort(np.linalg.norm(states[:, None, :nt] - states[None, :, :nt], axis=2), axis=1)[:, 1:8]
+        edges = np.stack([np.repeat(np.arange(nv), 7), near.reshape(-1)], 1)            # 10 500 edges: above the two-lane threshold
+
+        def run():
+            chk = irt.VoxelBackboneValidityChecker(robot, env, vox)
+            return irt.VoxelBackboneMotionValidator(chk).check_motion_indexed(states, edges)
+
+        want = _with_env(irt, {"TENDON_HIP_EDGE_LANES": "1", "TENDON_HIP_FB_CAP": "64"}, run)
+        for extra in ({}, {"TENDON_HIP_EDGE_POOL": "40000", "TENDON_HIP_EDGE_LANE_GUESS": "1"}):   # the second: lanes overflow their share
+            got = _with_env(irt, dict({"TENDON_HIP_EDGE_LANES": "2", "TENDON_HIP_FB_CAP": "64"}, **extra), run)
+            for k in ("valid", "n_fk", "n_domain_errors"):
+                assert np.array_equal(got[k], want[k]), (k, extra, np.flatnonzero(np.asarray(got[k]) != np.asarray(want[k]))[:8])
+        assert 0.2 < want["valid"].mean() < 0.99 and want["n_fk"].max() > 6
+        idx = np.random.default_rng(82).choice(len(edges), 400, replace=False)
+        ov, onf, _ = orc.check_motion_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), states[edges[idx, 0]],
+                                            states[edges[idx, 1]], inv_rot=np.eye(3) if inv_rot is None else inv_rot, nthreads=0, lib=orc.omp_lib())
+        assert np.array_equal(want["valid"][idx], ov)
+        assert np.array_equal(want["n_fk"][idx][ov], onf[ov])
