@@ -139,9 +139,13 @@ struct tr_ctx {
                                                   // (TENDON_HIP_EDGE_LANE_GUESS: testing, a small value provokes the overflow path)
   // retraction robots: the batch ordered by backbone length for the verdict-only kernel (cache_merge.hpp: retraction_order);
   // for batches of at least retract_sort_min configurations (TENDON_HIP_RETRACT_SORT=<n>; 0 = never, keep arrival order)
-  uint32_t *d_ro_keys[2] = {nullptr, nullptr}; int32_t *d_ro_vals[2] = {nullptr, nullptr}; int64_t ro_cap = 0;
+  // (one set of buffers per lane of the edge bisection, launch_verdict's `lane`)
+  struct RetractOrder {
+    uint32_t *keys[2] = {nullptr, nullptr}; int32_t *vals[2] = {nullptr, nullptr}; int64_t cap = 0;
+    int32_t *kbegin = nullptr;          // [cap / 64] per wave of the ordered batch: the step its tip-aligned loop may start at
+    trk::MergeScratch ms;               // lane 1's radix-sort scratch (lane 0 uses tr_ctx::merge)
+  } ro[2];
   int64_t retract_sort_min = kRetractSortMin;
-  int32_t *d_ro_kbegin = nullptr;       // [ro_cap / 64] per wave of the ordered batch: the step its tip-aligned loop may start at
   bool rows_one_step = false;           // behind the grid's own first interval every RK4 step ends in the next row
   bool retract_wave_start = true;       // TENDON_HIP_RETRACT_KBEGIN_OFF (A/B switch of profiles/probe_retract.py): +1 - 2 %
   struct VerdictRing {
@@ -531,19 +535,20 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   }
   if (ctx->K.enable_retraction && ctx->retract_sort_min > 0 && n >= ctx->retract_sort_min) {
     // waves of one backbone length: see retraction_order.  The mask is filled by atomic ORs, so it starts from zero.
-    if (ctx->ro_cap < n) {
+    tr_ctx::RetractOrder &ro = ctx->ro[lane ? 1 : 0];
+    if (ro.cap < n) {
       HIP_TRY(ctx, hipDeviceSynchronize());
       const int64_t want = round_up(n, 64);
       for (int q = 0; q < 2; q++) {
-        if ((rc = dev_alloc(ctx, &ctx->d_ro_keys[q], (size_t)want))) return rc;
-        if ((rc = dev_alloc(ctx, &ctx->d_ro_vals[q], (size_t)want))) return rc;
+        if ((rc = dev_alloc(ctx, &ro.keys[q], (size_t)want))) return rc;
+        if ((rc = dev_alloc(ctx, &ro.vals[q], (size_t)want))) return rc;
       }
-      if ((rc = dev_alloc(ctx, &ctx->d_ro_kbegin, (size_t)want / 64))) return rc;
-      ctx->ro_cap = want;
+      if ((rc = dev_alloc(ctx, &ro.kbegin, (size_t)want / 64))) return rc;
+      ro.cap = want;
     }
-    const hipError_t e = trk::retraction_order(ctx->merge, d_states, n, ctx->K.state_size, ctx->K.L, ctx->d_ro_keys, ctx->d_ro_vals, &a.perm, s,
-                                               ctx->K.dL, ctx->k_first, ctx->rows_one_step, ctx->d_ro_kbegin);
-    a.wave_k_begin = ctx->retract_wave_start ? ctx->d_ro_kbegin : nullptr;
+    const hipError_t e = trk::retraction_order(lane ? ro.ms : ctx->merge, d_states, n, ctx->K.state_size, ctx->K.L, ro.keys, ro.vals, &a.perm, s,
+                                               ctx->K.dL, ctx->k_first, ctx->rows_one_step, ro.kbegin);
+    a.wave_k_begin = ctx->retract_wave_start ? ro.kbegin : nullptr;
     if (e != hipSuccess) return fail(ctx, TR_ERR_HIP, std::string("retraction order: ") + hipGetErrorString(e));
     HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, (size_t)((n + 63) / 64) * sizeof(uint64_t), s));
   }
@@ -831,8 +836,11 @@ void tr_destroy(tr_ctx *c) {
   if (c->d_fb_count1) (void)hipFree(c->d_fb_count1);
   if (c->d_edge_counters1) (void)hipFree(c->d_edge_counters1);
   for (int q = 0; q < 2; q++) { if (c->edge_stream[q]) (void)hipStreamDestroy(c->edge_stream[q]); if (c->edge_hc[q]) (void)hipHostFree(c->edge_hc[q]); }
-  for (int q = 0; q < 2; q++) { if (c->d_ro_keys[q]) (void)hipFree(c->d_ro_keys[q]); if (c->d_ro_vals[q]) (void)hipFree(c->d_ro_vals[q]); }
-  if (c->d_ro_kbegin) (void)hipFree(c->d_ro_kbegin);
+  for (auto &ro : c->ro) {
+    for (int q = 0; q < 2; q++) { if (ro.keys[q]) (void)hipFree(ro.keys[q]); if (ro.vals[q]) (void)hipFree(ro.vals[q]); }
+    if (ro.kbegin) (void)hipFree(ro.kbegin);
+    trk::merge_free(ro.ms);
+  }
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);
   delete c;
 }

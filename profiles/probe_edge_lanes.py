@@ -5,13 +5,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 irt = importlib.import_module("interactive-rate-tendons_amd")
 W = irt.workloads
-for rot in (False, True):
+for rot in (False, True, "rotation + retraction"):
     for V in (25000, 50000, 100000):
         res = {}
         for lanes in ("1", "2"):
             os.environ["TENDON_HIP_EDGE_LANES"] = lanes
             robot = W.robot_config3()
-            robot.enable_rotation = rot
+            robot.enable_rotation = bool(rot)
+            robot.enable_retraction = rot == "rotation + retraction"
             vox, _ = W.reach_environment(seed=7, n_spheres=64)
             chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
             rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)

@@ -288,12 +288,16 @@ def test_two_lane_bisection_equals_one_lane(irt, orc, helpers):
     spin.enable_rotation = True
     a = 0.4
     rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
-    for robot, tau_max, inv_rot, nv in ((thin, 100.0, None, 1500), (spin, 20.0, rot, 1500)):
+    pull = W.robot_config2()                       # retraction: every lane orders its own launches by backbone length
+    pull.enable_retraction = True
+    for robot, tau_max, inv_rot, nv in ((thin, 100.0, None, 1500), (spin, 20.0, rot, 1500), (pull, 14.0, None, 1500)):
         vox, _ = W.reach_environment(seed=7, n_spheres=48)
         env = irt.VoxelEnvironment()
         if inv_rot is not None:
             env.inv_rotation = inv_rot
         states = W.random_states(robot, nv, seed=81, tau_max=tau_max)
+        if robot.enable_retraction:
+            states[:, -1] = 0.03 + 0.004 * np.random.default_rng(83).random(nv) + 0.1 * (np.arange(nv) % 2)     # two groups of lengths
         nt = len(robot.tendons)
         near = np.argsort(np.linalg.norm(states[:, None, :nt] - states[None, :, :nt], axis=2), axis=1)[:, 1:8]
         edges = np.stack([np.repeat(np.arange(nv), 7), near.reshape(-1)], 1)            # 10 500 edges: above the two-lane threshold
@@ -302,9 +306,14 @@ def test_two_lane_bisection_equals_one_lane(irt, orc, helpers):
             chk = irt.VoxelBackboneValidityChecker(robot, env, vox)
             return irt.VoxelBackboneMotionValidator(chk).check_motion_indexed(states, edges)
 
-        want = _with_env(irt, {"TENDON_HIP_EDGE_LANES": "1", "TENDON_HIP_FB_CAP": "64"}, run)
+        if robot.enable_retraction:                 # neighbours within a group of lengths
+            near = np.stack([np.flatnonzero(np.arange(nv) % 2 == i % 2)[np.argsort(np.linalg.norm(
+                states[np.arange(nv) % 2 == i % 2, :nt] - states[i, :nt], axis=1))[1:8]] for i in range(nv)])
+            edges = np.stack([np.repeat(np.arange(nv), 7), near.reshape(-1)], 1)
+        base_env = {"TENDON_HIP_FB_CAP": "64", "TENDON_HIP_RETRACT_SORT": "64"}          # (launches of 64 samples or more are ordered by length)
+        want = _with_env(irt, dict(base_env, TENDON_HIP_EDGE_LANES="1"), run)
         for extra in ({}, {"TENDON_HIP_EDGE_POOL": "40000", "TENDON_HIP_EDGE_LANE_GUESS": "1"}):   # the second: lanes overflow their share
-            got = _with_env(irt, dict({"TENDON_HIP_EDGE_LANES": "2", "TENDON_HIP_FB_CAP": "64"}, **extra), run)
+            got = _with_env(irt, dict(base_env, TENDON_HIP_EDGE_LANES="2", **extra), run)
             for k in ("valid", "n_fk", "n_domain_errors"):
                 assert np.array_equal(got[k], want[k]), (k, extra, np.flatnonzero(np.asarray(got[k]) != np.asarray(want[k]))[:8])
         assert 0.2 < want["valid"].mean() < 0.99 and want["n_fk"].max() > 6
