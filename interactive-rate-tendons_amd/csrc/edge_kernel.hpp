@@ -298,6 +298,23 @@ __global__ __launch_bounds__(256) void edge_open(EdgeState st, EdgeSpaceK sk, co
   }
 }
 
+// A level's samples re-dealt in the order `perm` (retraction robots, stored-point forms: cache_merge.hpp: retraction_order sorts the
+// level by backbone length, so that a wave of K1r holds backbones of one length).  Slot s0 + j now belongs to what edge_open had
+// put in slot s0 + perm[j]: the interval, its midpoint state, and the slot's edge / t entries (the midpoint t by edge_open's expression).
+__global__ __launch_bounds__(256) void edge_level_gather(EdgeState st, const int32_t *__restrict__ perm, int64_t m, int S, int64_t s0,
+                                                         const EdgeIv *__restrict__ open_in, const double *__restrict__ lvl_in,
+                                                         EdgeIv *__restrict__ open_out, double *__restrict__ lvl_out) {
+#pragma clang fp contract(off)
+  const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j >= m) return;
+  const int64_t i = perm[j];
+  const EdgeIv iv = open_in[i];
+  open_out[j] = iv;
+  for (int d = 0; d < S; d++) lvl_out[j * S + d] = lvl_in[i * S + d];
+  st.sample_edge[s0 + j] = iv.e;
+  st.sample_t[s0 + j] = (iv.ta + iv.tb) / 2;
+}
+
 // partial.t of checkMotion(s1, s2, last_valid): the largest sampled t below the first invalid one
 // (VoxelEnvironment.cpp:403-424)
 __global__ __launch_bounds__(256) void edge_last_valid_t(EdgeState st, int64_t slot_lo, int64_t pool) {     // the run's own slots [slot_lo, pool)

@@ -78,6 +78,9 @@ struct EdgeDev {
   // workspace's n_points: the verdict path's fallback pass re-integrates its few configurations in workspace columns
   // [0, fb_cap) and would overwrite the counts of the pool's first samples
   int32_t *sig_np = nullptr;
+  // second copies of a level's intervals and states: a retraction robot's stored-point levels are re-dealt in the order of their
+  // backbone lengths (edge_level_gather)
+  trk::EdgeIv *open2 = nullptr; double *lvl_states2 = nullptr;
   // indexed forms: the roadmap's vertex states and the edges' index pairs (grow-only)
   double *ix_states = nullptr; int64_t ix_states_cap = 0;
   int32_t *ix_idx = nullptr; int64_t ix_idx_cap = 0;
@@ -820,7 +823,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->edge.sig, c->edge.sig_np, c->edge.ix_states, c->edge.ix_idx, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->edge.sig, c->edge.sig_np, c->edge.ix_states, c->edge.ix_idx, c->edge.open2, c->edge.lvl_states2, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }

@@ -234,3 +234,47 @@ def test_connect_is_check_motion_and_voxelize_edge_in_one_pass(irt):
         idx = np.concatenate([np.arange(off[e], off[e + 1]) for e in np.flatnonzero(ok)]) if ok.any() else np.zeros(0, int)
         assert np.array_equal(got["block_ids"], cache["block_ids"][idx]) and np.array_equal(got["masks"], cache["masks"][idx])
         assert np.array_equal(np.diff(got["offsets"]), np.diff(off)[ok]) and got["offsets"][-1] == len(got["block_ids"])
+
+
+def test_retraction_levels_dealt_by_length_give_the_same_sets(irt):
+    """Stored-point edge forms of a retraction robot (tr_voxelize_edges, the indexed form, connect) re-deal every bisection level
+    of TENDON_HIP_RETRACT_SORT samples or more in the order of the samples' backbone lengths (edge_level_gather), so that K1r's waves
+    are homogeneous.  Which pool slot a sample gets is bookkeeping: per edge the voxel set (block ids and masks), the fully-valid
+    bit, checkMotion's verdict and the FK count are those of arrival order."""
+    import os
+    W = irt.workloads
+    robot = W.robot_config3()
+    robot.enable_rotation = True
+    robot.enable_retraction = True
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    rng = np.random.default_rng(91)
+    nv = 700
+    states = W.random_states(robot, nv, seed=92, tau_max=18.0)
+    states[:, -1] = rng.uniform(0.0, 0.16, nv)
+    nt = len(robot.tendons)
+    scale = np.array([1.0] * nt + [3.0, 400.0])
+    near = np.argsort(np.linalg.norm((states[:, None, :] - states[None, :, :]) * scale, axis=2), axis=1)[:, 1:6]
+    edges = np.stack([np.repeat(np.arange(nv), 5), near.reshape(-1)], 1)
+
+    def run():
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        eng = chk.engine
+        mv = irt.VoxelBackboneMotionValidator(chk)
+        return (eng.voxelize_edges_indexed(states, edges, mv.min_tension_change, mv.min_rotation_change, mv.min_retraction_change),
+                eng.voxelize_edges(states[edges[:400, 0]], states[edges[:400, 1]]),
+                eng.voxelize_edges_indexed(states, edges, mv.min_tension_change, mv.min_rotation_change, mv.min_retraction_change, validate=True))
+
+    def with_sort(v):
+        old = os.environ.get("TENDON_HIP_RETRACT_SORT")
+        os.environ["TENDON_HIP_RETRACT_SORT"] = v
+        try:
+            return run()
+        finally:
+            os.environ.pop("TENDON_HIP_RETRACT_SORT", None) if old is None else os.environ.__setitem__("TENDON_HIP_RETRACT_SORT", old)
+
+    want, got = with_sort("0"), with_sort("64")
+    for w, g in zip(want, got):
+        for k in w:
+            if isinstance(w[k], np.ndarray):
+                assert np.array_equal(w[k], g[k]), k
+    assert want[0]["fully_valid"].sum() > 500 and want[0]["offsets"][-1] > 10000
