@@ -122,6 +122,10 @@ struct tr_ctx {
   trk::MergeScratch merge;       // device-side union of edge voxel caches (cache_merge.hip)
   int64_t max_chunk = 1 << 20;
   int64_t edge_pool_max = 1 << 22; // samples held at once by tr_validate_edges / tr_voxelize_edges
+  // tr_validate_edges_indexed through the verdict-only kernels keeps no backbone points: its pool is the per-sample arrays of
+  // EdgeDev alone (~0.7 KB per sample against 4.1 KB with the point planes) and may be larger than the FK workspace
+  int64_t edge_slots_max = 1 << 24;
+  int64_t edge_slots_now = 0;      // slots of the running indexed call (0: the pool is the workspace, ws.ld)
   double ch_scale = 2.0;          // milestone spacing of K2 in robot radii (env TENDON_HIP_CH_SCALE, tuning only)
   int64_t k1_round = 1 << 17;     // configurations in one resident round of K1 waves (CUs x 4 SIMDs x waves/SIMD x 64)
   // tr_validate_batch*: 2 (default) = verdict-only kernel (verdict_kernel.hpp: no point storage) for the backbone checker
@@ -700,7 +704,7 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (const char *e = std::getenv("TENDON_HIP_EDGE_LANE_GUESS")) { const double v = std::atof(e); if (v >= 0.5 && v <= 64.0) c->edge_lane_guess = v; }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
-    if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = (int64_t)round_up(v, 64);
+    if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = c->edge_slots_max = (int64_t)round_up(v, 64);
   }
   if (const char *e = std::getenv("TENDON_HIP_CH_SCALE")) { const double v = std::atof(e); if (v > 0.05 && v < 50) c->ch_scale = v; }
   if (hipSetDevice(device) != hipSuccess) { delete c; return fail(nullptr, TR_ERR_HIP, "hipSetDevice failed"); }
