@@ -114,6 +114,17 @@ class RoadmapBuilder:
         self.timing["vertex_caches"] = dict(seconds=time.perf_counter() - t0, items=len(states), blocks=int(out["offsets"][-1]))
         return out
 
+    def validate_edges_sharded(self, states, edges, device=None):
+        """checkMotion of the candidate edges over the ranks of the default process group (second phase): this rank
+        validates its contiguous shard of the edge list with the indexed form (every vertex once per rank, two lanes), one
+        all-gather of the verdict words; every rank returns the whole mask."""
+        import torch
+        dev = device if device is not None else ("cuda:%d" % self.engine.device if torch.cuda.is_available() else "cpu")
+        st = np.ascontiguousarray(states, dtype=np.float64)
+        sh = D.ShardedEdgeValidator(lambda s_, e_: D.pack_bits(self.engine.validate_edges_indexed(
+            s_, e_, self.mv.min_tension_change, self.mv.min_rotation_change, self.mv.min_retraction_change)["valid"]), device=dev)
+        return unpack_bits(sh.run_indexed(st, np.asarray(edges)), len(edges))
+
     def knn_edges_sharded(self, states, k, device=None):
         """knn_edges_gpu with the neighbour search spread over the ranks of the default process group (config 4's sizes:
         10^6 vertices are 10^12 pair distances): this rank's rows of the table (tr_knn_range), one all-gather of the rows,

@@ -52,6 +52,10 @@ emask = irt.unpack_bits(D.ShardedEdgeValidator(lambda ea, eb: D.pack_bits(mv.che
 rb = irt.RoadmapBuilder(chk, mv, seed=1)
 verts = cand[mask][:3000]
 e_sharded = rb.knn_edges_sharded(verts, 7)
+# the edge phase in its roadmap form: this rank's shard of the index pairs through tr_validate_edges_indexed, verdict words gathered
+ev_sharded = rb.validate_edges_sharded(verts, e_sharded)
+ev_single, _ = rb.validate_edges(verts, e_sharded)
+assert np.array_equal(ev_sharded, ev_single) and 0 < ev_single.sum() < len(ev_single)
 if dist.get_rank() == 0:
     np.savez(sys.argv[2], mask=mask, emask=emask, direct=chk.is_valid(cand), edirect=mv.check_motion(a, b),
              e_sharded=e_sharded, e_single=rb.knn_edges_gpu(verts, 7))

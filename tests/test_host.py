@@ -250,6 +250,10 @@ def edges_local(ea, eb):
     v, _, _ = orc.check_motion_batch(orb, og, ea, eb)
     return D.pack_bits(v)
 emask = D.ShardedEdgeValidator(edges_local).run(a, b)
+# the roadmap form of the same phase: all vertices on every rank, the rank's shard of the index pairs
+eidx = np.stack([np.arange(len(states) - 1), np.arange(1, len(states))], 1)
+emask_ix = D.ShardedEdgeValidator(lambda st_, e_: edges_local(st_[e_[:, 0]], st_[e_[:, 1]])).run_indexed(states, eidx)
+assert np.array_equal(emask_ix, emask)
 # between the two: the connection loop's neighbour table, rows computed per shard and all-gathered (int32)
 def knn_local(first, count):                     # numpy brute force stands in for tr_knn_range
     d = np.linalg.norm(states[first:first + count, None, :] - states[None, :, :], axis=2)
