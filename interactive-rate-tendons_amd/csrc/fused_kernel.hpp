@@ -19,8 +19,14 @@
 
 namespace trk {
 
+// Waves per SIMD of the stored-point fused kernels, measured per width like the verdict-only ones (profiles/r02/verdict_widths_v1.txt,
+// second table; ms per 2^18 configurations, two waves | one): N=4 3.19 | 3.19, N=5 4.25 | 4.52, N=6 5.29 | 4.91.
+#ifndef TRK_FUSED_TWO_WAVE_MAXN
+#define TRK_FUSED_TWO_WAVE_MAXN 5
+#endif
+
 template <int N, bool ROT>
-__global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_sweep_fused(
+__global__ __launch_bounds__(64, (N <= TRK_FUSED_TWO_WAVE_MAXN ? 2 : 1)) void fk_sweep_fused(
     const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, FkOut out, const FusedSweepArgs *__restrict__ sa) {
   // (the verdict paths never ask for the backbone length)  Edge samples also get their cell signatures, point by point
@@ -43,7 +49,7 @@ __global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_sw
 // configuration list[r cap + 64 b + i] (while that index is below *count) and ORs its verdict bit into the mask.  A block
 // leaves as soon as its slice of the list is exhausted, so with an empty list the launch costs nothing.
 template <int N, bool ROT>
-__global__ __launch_bounds__(64, (N <= TRK_K1_TWO_WAVE_MAXN ? 2 : 1)) void fk_sweep_fused_list(
+__global__ __launch_bounds__(64, (N <= TRK_FUSED_TWO_WAVE_MAXN ? 2 : 1)) void fk_sweep_fused_list(
     const double *__restrict__ states, int64_t cap, int64_t ld, RobotK K, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, FkOut out, const FusedSweepArgs *__restrict__ sa,
     const int32_t *__restrict__ list, const uint32_t *__restrict__ count) {
