@@ -269,13 +269,17 @@ def run(argv=None):
     # createRoadmap as one call (sample, connect with checkMotion, voxel sets, query object), lists kept in HBM
     rb2 = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
     chk.engine.set_grid(vox.Nx(), vox.limits(), vox.blocks)
-    prm2, rm2 = rb2.create_roadmap(args.vertices, k=args.k)
-    assert np.array_equal(rm2["states"], states) and np.array_equal(rm2["edges"], e_ok)
-    out["config3"]["create_roadmap"] = {"seconds": rb2.timing["create_roadmap"]["seconds"], "vertices_s": rb2.timing["vertices"]["seconds"],
-                                        "knn_edge_list_s": rb2.timing["knn_gpu"]["seconds"], "connect_s": rb2.timing["connect"]["seconds"],
-                                        "vertex_caches_s": rb2.timing["vertex_caches"]["seconds"],
-                                        "note": "sample + k-NN + checkMotion + voxel sets of all vertices and kept edges + query object with landmark tables"}
-    del prm2, rm2
+    cr = None
+    for _ in range(2):                                               # the second call: what a warm process pays
+        prm2, rm2 = rb2.create_roadmap(args.vertices, k=args.k)
+        assert np.array_equal(rm2["states"], states) and np.array_equal(rm2["edges"], e_ok)
+        t2 = rb2.timing
+        if cr is None or t2["create_roadmap"]["seconds"] < cr["seconds"]:
+            cr = {"seconds": t2["create_roadmap"]["seconds"], "vertices_s": t2["vertices"]["seconds"], "knn_edge_list_s": t2["knn_gpu"]["seconds"],
+                  "connect_s": t2["connect"]["seconds"], "vertex_caches_s": t2["vertex_caches"]["seconds"]}
+        del prm2, rm2
+    out["config3"]["create_roadmap"] = dict(cr, note="sample + k-NN + checkMotion + voxel sets of all vertices and kept edges + query object with "
+                                                     "landmark tables; the faster of two calls")
     # config 1 shape: FK only, 3-tendon linear-routed robot (P = 41), small and large batches
     r1 = W.robot_config1()
     e1 = r1.engine(0)
