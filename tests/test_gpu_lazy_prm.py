@@ -334,3 +334,37 @@ def test_planning_flow_from_files(irt, tmp_path):
     fresh = irt.VoxelBackboneValidityChecker(problem.robot, problem.venv, changed)
     assert fresh.is_valid(again).all()
     assert irt.VoxelBackboneMotionValidator(fresh).check_motion(again[:-1], again[1:]).all()
+
+
+def test_landmark_distances_on_the_device_equal_the_hosts(irt):
+    """tr_roadmap_prepare computes the landmark tables on the device (every sweep relaxes all arcs for all landmarks, to the fixed
+    point) instead of one Dijkstra per landmark on the host threads.  TENDON_HIP_LANDMARKS=check builds both and fails the call
+    if a single bit differs: a real roadmap, random geometric graphs with several components, zero-weight edges and isolated
+    vertices, landmark counts from 1 to 64."""
+    import os
+    robot, vox, chk, states, edges, vc, ec = _roadmap(irt, 3000, 6, seed=31)
+    rng = np.random.default_rng(32)
+    cases = [(states, edges)]
+    for n, k, gap in ((4000, 5, 0.0), (1500, 3, 30.0), (200, 2, 50.0)):
+        st = rng.uniform(0, 20, (n, states.shape[1]))
+        st[n // 2:, 0] += gap                                       # two clusters when gap > 0
+        st[5] = st[4]                                               # a zero-weight edge
+        d = np.linalg.norm(st[:, None, :] - st[None, :, :], axis=2) if n <= 1500 else None
+        if d is None:
+            from scipy.spatial import cKDTree
+            nb = cKDTree(st).query(st, k + 1)[1][:, 1:]
+        else:
+            nb = np.argsort(d, axis=1, kind="stable")[:, 1:k + 1]
+        e = np.unique(np.sort(np.stack([np.repeat(np.arange(n), k), nb.reshape(-1)], 1), axis=1), axis=0)
+        e = e[e[:, 0] != e[:, 1]]
+        e = e[~np.isin(e, np.arange(n - 7, n)).any(axis=1)]         # the last seven vertices stay isolated
+        cases.append((st, np.concatenate([e, [[4, 5]]]).astype(np.int32)))
+    old = os.environ.get("TENDON_HIP_LANDMARKS")
+    os.environ["TENDON_HIP_LANDMARKS"] = "check"
+    try:
+        for st, e in cases:
+            for nl in (1, 5, 16, 64):
+                prm = irt.VoxelCachedLazyPRM(chk, st, e)
+                prm.prepare(nl)                                     # raises if the device's table differs from the host's
+    finally:
+        os.environ.pop("TENDON_HIP_LANDMARKS", None) if old is None else os.environ.__setitem__("TENDON_HIP_LANDMARKS", old)
