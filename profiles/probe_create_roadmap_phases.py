@@ -1,9 +1,11 @@
+"""createRoadmap phase by phase (the calls RoadmapBuilder.create_roadmap makes), config 3's robot; `full` adds rotation + retraction."""
 import importlib, os, sys, time
 sys.path.insert(0, "/root/repo")
 import numpy as np
 irt = importlib.import_module("interactive-rate-tendons_amd")
 W = irt.workloads
 robot = W.robot_config3()
+robot.enable_rotation = robot.enable_retraction = len(sys.argv) > 1 and sys.argv[1] == "full"      # "full": rotation + retraction
 vox, _ = W.reach_environment(seed=7, n_spheres=64)
 chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
 rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
