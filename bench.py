@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py -- FK+collision checks/sec (3-tendon helical robot, 256^3 voxel environment).
 
-One "step" = one pass of the hot path (K1 fk_rk4_batch -> K2 backbone_voxel_sweep, plus for N>1
+One "step" = one pass of the hot path (fk_verdict: Cosserat-rod FK by RK4 with the whole validity predicate -- length limits,
+self collision, backbone against the voxel grid -- in one launch, plus its fallback launch; for N>1 also
 the all-gather of the validity bitmask) over one batch of 2^20 synthetic configurations PER GPU
 (weak scaling), inputs resident in HBM before the timed region.  Workload = BASELINE.json
 configs[1] as specified in BASELINE.md section 2 (seeded, synthetic).
