@@ -143,12 +143,23 @@ def build(force=False, verbose=False, jobs=None):
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
-    todo = []
+    import hashlib
+    todo, stamps = [], []
     for obj, src, extra, deps in _units():
         o = os.path.join(OBJ_DIR, obj)
-        dep_t = max(os.path.getmtime(os.path.join(SRC_DIR, f)) for f in deps)
-        if force or not os.path.exists(o) or os.path.getmtime(o) < dep_t:
+        # an object is current when it was compiled from exactly these dependencies with exactly these flags: the hash of
+        # both is kept next to it (modification times lie after a copy or a checkout)
+        h = hashlib.sha1(" ".join(HIPCC_FLAGS + extra + [src]).encode())
+        for f in sorted(set(deps)):
+            h.update(os.path.basename(f).encode())
+            h.update(open(os.path.join(SRC_DIR, f), "rb").read())
+        key = h.hexdigest()
+        okey = o + ".dephash"
+        if force or not os.path.exists(o) or not os.path.exists(okey) or open(okey).read().strip() != key:
+            if os.path.exists(okey):
+                os.remove(okey)
             todo.append(["hipcc"] + HIPCC_FLAGS + extra + ["-c", os.path.join(SRC_DIR, src), "-o", o])
+            stamps.append((okey, key))
     jobs = jobs or max(1, min(len(todo), os.cpu_count() or 1))
     running, failed = [], None
     while (todo or running) and failed is None:
@@ -164,6 +175,9 @@ def build(force=False, verbose=False, jobs=None):
         p.wait()
     if failed is not None:
         raise subprocess.CalledProcessError(1, failed)
+    for okey, key in stamps:
+        with open(okey, "w") as f:
+            f.write(key + "\n")
     link = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-pthread", "-o", LIB_PATH] + \
            [os.path.join(OBJ_DIR, u[0]) for u in _units()]
     if verbose:

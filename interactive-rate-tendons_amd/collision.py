@@ -12,6 +12,19 @@ from . import _lib as L
 _SUPPORTED = (4, 8, 16, 32, 64, 128, 256, 512)
 
 
+def leaf_order_of(block_ids, Nb):
+    """Permutation that puts dense block ids ((bx * Nb + by) * Nb + bz) into the order `TreeNode::visit_leaves` reaches
+    them (collision/detail/TreeNode.hxx:176-190: per octree level bx outermost, then by, then bz, i.e. ascending by the key
+    that interleaves the bits of bx, by, bz from the top, bx first).  It is the order of the "data" array of the voxel
+    files (VoxelOctree.cpp:1357-1363) and of a roadmap file's block records (VoxelCachedLazyPRM.cpp:633-642)."""
+    ids = np.asarray(block_ids, dtype=np.int64)
+    bx, by, bz = ids // (Nb * Nb), (ids // Nb) % Nb, ids % Nb
+    key = np.zeros(len(ids), dtype=np.int64)
+    for bit in range(max(int(Nb).bit_length() - 1, 0)):
+        key |= (((bx >> bit) & 1) << (3 * bit + 2)) | (((by >> bit) & 1) << (3 * bit + 1)) | (((bz >> bit) & 1) << (3 * bit))
+    return np.argsort(key, kind="stable")
+
+
 class VoxelOctree:
     def __init__(self, Ndim=4):
         if Ndim not in _SUPPORTED:                         # VoxelOctree.cpp:98-116
@@ -210,9 +223,12 @@ class VoxelOctree:
         self.blocks &= other.blocks
 
     def visit_leaves(self, visitor):
-        """visitor(bx, by, bz, block) for every non-empty block, in block order (VoxelOctree.cpp:998-1001)."""
-        for bx, by, bz in np.argwhere(self.blocks != 0):
-            visitor(int(bx), int(by), int(bz), int(self.blocks[bx, by, bz]))
+        """visitor(bx, by, bz, block) for every non-empty block in the reference's traversal order
+        (VoxelOctree.cpp:998-1001 -> detail/TreeNode.hxx:176-190; pinned by tests/golden/treenode_*.npz)."""
+        ids, masks = self.to_sparse(leaf_order=True)
+        Nb = self.Nbx()
+        for i, m in zip(ids.tolist(), masks.tolist()):
+            visitor(i // (Nb * Nb), (i // Nb) % Nb, i % Nb, int(m))
 
     def occupied_voxels(self):
         """(n, 3) cell indices of the occupied voxels (visit_occupied_voxels, :1013-1017)."""
@@ -234,8 +250,12 @@ class VoxelOctree:
         return self.is_in_domain(x, y, z) and self.cell(*self.nearest_cell(x, y, z))
 
     # sparse export: what a roadmap voxel cache stores (VoxelCachedLazyPRM.cpp:986-1114 .rmp blocks) ---
-    def to_sparse(self):
+    def to_sparse(self, leaf_order=False):
+        """(dense block ids, masks) of the non-empty blocks, ascending by id -- or, with leaf_order, in the order the
+        reference visits (and serialises) them."""
         ids = np.flatnonzero(self.blocks.reshape(-1)).astype(np.uint32)
+        if leaf_order:
+            ids = ids[leaf_order_of(ids, self.Nbx())]
         return ids, self.blocks.reshape(-1)[ids].copy()
 
     # ---- the reference's obstacle-set file formats (collision/VoxelOctree.cpp:1357-1497): what a maintainer hands to
@@ -243,7 +263,7 @@ class VoxelOctree:
     def to_json(self):
         """VoxelOctree::to_json (:1357-1376): {"VoxelOctree": {dimension, x/y/zlimits, data: [[bx, by, bz, block], ...]}}."""
         Nb = self.Nbx()
-        ids, masks = self.to_sparse()
+        ids, masks = self.to_sparse(leaf_order=True)
         data = [[int(i) // (Nb * Nb), (int(i) // Nb) % Nb, int(i) % Nb, int(m)] for i, m in zip(ids, masks)]
         return {"VoxelOctree": {"dimension": int(self._N), "xlimits": [self._xmin, self._xmax], "ylimits": [self._ymin, self._ymax],
                                 "zlimits": [self._zmin, self._zmax], "data": data}}

@@ -14,6 +14,8 @@ import struct
 
 import numpy as np
 
+from .collision import leaf_order_of
+
 _BLOCK = np.dtype([("bx", "u1"), ("by", "u1"), ("bz", "u1"), ("mask", "<u8")])     # 11 bytes, packed
 
 
@@ -27,9 +29,11 @@ def _pack_voxels(out, caches, i, Nb):
     if not has:
         return
     ids = np.asarray(caches["block_ids"][a:b], dtype=np.int64)
+    order = leaf_order_of(ids, Nb)          # serialize_inner writes visit_leaves order (:633-642), not ascending ids
+    ids = ids[order]
     rec = np.empty(b - a, dtype=_BLOCK)
     rec["bx"], rec["by"], rec["bz"] = ids // (Nb * Nb), (ids // Nb) % Nb, ids % Nb
-    rec["mask"] = caches["masks"][a:b]
+    rec["mask"] = np.asarray(caches["masks"][a:b])[order]
     out.append(struct.pack("<I", b - a))
     out.append(rec.tobytes())
 

@@ -199,6 +199,14 @@ def _load(kind="strict"):
                                      P(C.c_uint8)]
     lib.orc_grid_export_blocks.argtypes = [P(OrcGrid), P(C.c_uint32), P(C.c_uint64), C.c_long]
     lib.orc_grid_export_blocks.restype = C.c_long
+    lib.orc_grid_export_blocks_leaf_order.argtypes = [P(OrcGrid), P(C.c_uint32), P(C.c_uint64), C.c_long]
+    lib.orc_grid_export_blocks_leaf_order.restype = C.c_long
+    lib.orc_grid_block.argtypes = [P(OrcGrid), C.c_int, C.c_int, C.c_int]
+    lib.orc_grid_block.restype = C.c_uint64
+    lib.orc_grid_set_block.argtypes = [P(OrcGrid), C.c_int, C.c_int, C.c_int, C.c_uint64]
+    lib.orc_grid_set_block.restype = None
+    lib.orc_grid_union_block.argtypes = [P(OrcGrid), C.c_int, C.c_int, C.c_int, C.c_uint64]
+    lib.orc_grid_union_block.restype = C.c_uint64
     lib.orc_max_threads.restype = C.c_int
     _libs[kind] = lib
     return lib
@@ -439,12 +447,23 @@ class Grid:
     def ncells(self):
         return int(self.lib.orc_grid_ncells(self.ptr))
 
-    def export_blocks(self):
-        n = self.lib.orc_grid_export_blocks(self.ptr, None, None, 0)
+    def export_blocks(self, leaf_order=False):
+        """Non-zero blocks as (dense block id, mask); leaf_order=True gives them in the reference's visit_leaves
+        order (the order its files are written in) instead of ascending block id."""
+        f = self.lib.orc_grid_export_blocks_leaf_order if leaf_order else self.lib.orc_grid_export_blocks
+        n = f(self.ptr, None, None, 0)
         ids, masks = np.empty(n, dtype=np.uint32), np.empty(n, dtype=np.uint64)
-        self.lib.orc_grid_export_blocks(self.ptr, ids.ctypes.data_as(C.POINTER(C.c_uint32)),
-                                        masks.ctypes.data_as(C.POINTER(C.c_uint64)), n)
+        f(self.ptr, ids.ctypes.data_as(C.POINTER(C.c_uint32)), masks.ctypes.data_as(C.POINTER(C.c_uint64)), n)
         return ids, masks
+
+    def block(self, bx, by, bz):
+        return int(self.lib.orc_grid_block(self.ptr, int(bx), int(by), int(bz)))
+
+    def set_block(self, bx, by, bz, value):
+        self.lib.orc_grid_set_block(self.ptr, int(bx), int(by), int(bz), int(value))
+
+    def union_block(self, bx, by, bz, value):
+        return int(self.lib.orc_grid_union_block(self.ptr, int(bx), int(by), int(bz), int(value)))
 
 
 IDENTITY = np.eye(3).reshape(9)

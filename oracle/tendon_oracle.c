@@ -978,6 +978,46 @@ long orc_grid_export_blocks(const orc_grid *g, uint32_t *ids, uint64_t *masks, l
   return c;
 }
 
+/* collision/detail/TreeNode.hxx:176-190 visit_leaves_impl: at every level the eight children are visited with bx outermost,
+ * then by, then bz (child index 4*(bx half) + 2*(by half) + (bz half), TreeNode.h:68-70), absent children skipped, down to
+ * the TreeNode<4> leaves (:271-273).  On a dense grid that is: non-zero blocks in ascending order of the key that takes one
+ * bit of bx, by, bz per level from the top (bx the most significant of each triple).  This is the order in which
+ * VoxelOctree::to_json (collision/VoxelOctree.cpp:1357-1363) and the roadmap files' serialize_inner
+ * (motion-planning/VoxelCachedLazyPRM.cpp:633-642) write a voxel set.  Pinned against the reference's own TreeNode
+ * (oracle/_ref, tests/golden/treenode_*.npz). */
+static void leaf_order_rec(const orc_grid *g, int bx0, int by0, int bz0, int size,
+                           uint32_t *ids, uint64_t *masks, long cap, long *c) {
+  if (size == 1) {
+    size_t i = block_index(g, bx0, by0, bz0);
+    if (g->blocks[i]) {
+      if (ids && masks && *c < cap) { ids[*c] = (uint32_t)i; masks[*c] = g->blocks[i]; }
+      (*c)++;
+    }
+    return;
+  }
+  int h = size / 2;
+  for (int x = 0; x < 2; x++)
+    for (int y = 0; y < 2; y++)
+      for (int z = 0; z < 2; z++)
+        leaf_order_rec(g, bx0 + x * h, by0 + y * h, bz0 + z * h, h, ids, masks, cap, c);
+}
+long orc_grid_export_blocks_leaf_order(const orc_grid *g, uint32_t *ids, uint64_t *masks, long cap) {
+  long c = 0;
+  leaf_order_rec(g, 0, 0, 0, g->Nb, ids, masks, cap, &c);
+  return c;
+}
+
+/* collision/VoxelOctree.cpp:211-242 block / set_block / union_block (-> TreeNode.hxx:74-95,140-148; leaf :255-259,267):
+ * union_block returns the block's value BEFORE the OR. */
+uint64_t orc_grid_block(const orc_grid *g, int bx, int by, int bz) { return g->blocks[block_index(g, bx, by, bz)]; }
+void orc_grid_set_block(orc_grid *g, int bx, int by, int bz, uint64_t value) { g->blocks[block_index(g, bx, by, bz)] = value; }
+uint64_t orc_grid_union_block(orc_grid *g, int bx, int by, int bz, uint64_t value) {
+  size_t i = block_index(g, bx, by, bz);
+  uint64_t prev = g->blocks[i];
+  g->blocks[i] = prev | value;
+  return prev;
+}
+
 /* motion-planning/VoxelEnvironment.cpp:129-131: p <- inv_rotation * p (inv_rot row-major 3x3) */
 void orc_rotate_points(const double inv_rot[9], double *pts, int n) {
   for (int j = 0; j < n; j++) {

@@ -186,6 +186,10 @@ void orc_check_cached(const orc_grid *obstacles, const uint32_t *block_ids, cons
                       const int64_t *offsets, long n_items, uint8_t *hit);
 /* export occupied blocks of g: returns count; ids/masks may be NULL to count only */
 long orc_grid_export_blocks(const orc_grid *g, uint32_t *ids, uint64_t *masks, long cap);
+long orc_grid_export_blocks_leaf_order(const orc_grid *g, uint32_t *ids, uint64_t *masks, long cap);   /* TreeNode.hxx:176-190 */
+uint64_t orc_grid_block(const orc_grid *g, int bx, int by, int bz);
+void orc_grid_set_block(orc_grid *g, int bx, int by, int bz, uint64_t value);
+uint64_t orc_grid_union_block(orc_grid *g, int bx, int by, int bz, uint64_t value);
 
 int  orc_max_threads(void);
 
