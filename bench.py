@@ -219,8 +219,14 @@ def main():
     n = 1 << args.batch_log2
     S, P, N = eng.state_size, eng.num_points, eng.n_tendons
     # every rank validates its own shard of the global candidate sequence (weak scaling)
+    # ... generated in HBM by the library's counter-based generator (tr_candidate_states_dev; nothing is uploaded); the host
+    # mirror of the same sequence feeds the CPU baseline and the verdict comparison below
+    box = irt.distributed.sampling_box(robot, tau_max=10.0)
+    d_states = torch.empty(n * S, dtype=torch.float64, device="cuda")
+    eng.candidate_states_dev(2024, rank * n, n, d_states, box=box)
     states = irt.distributed.candidate_states(robot, seed=2024, start=rank * n, count=n, tau_max=10.0)
-    d_states = torch.from_numpy(states).cuda()
+    if not np.array_equal(d_states[: 4096 * S].cpu().numpy().reshape(4096, S), states[:4096]):
+        raise SystemExit("rank %d: device candidate generator differs from its host mirror" % rank)
     d_bits = torch.zeros(n // 64, dtype=torch.int64, device="cuda")
     d_tips = torch.zeros(n, 3, dtype=torch.float64, device="cuda")
     d_all = torch.zeros(world * (n // 64), dtype=torch.int64, device="cuda") if use_dist else None

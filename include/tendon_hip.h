@@ -15,6 +15,13 @@
  *     (tendon/TendonRobot.h:105-115, motion-planning/AbstractValidityChecker.cpp:50-78).
  *   - *_dev entry points take DEVICE pointers and a hipStream_t (as void*); they enqueue work and
  *     return without synchronising.  The host-pointer forms copy in/out and synchronise.
+ *   - one context = one workspace (fallback list, point columns, ordering buffers, argument slots are
+ *     per context).  Entry points serialise on a per-context mutex, and the *_dev calls that touch that
+ *     workspace execute in ISSUE ORDER whichever streams they name: a call arriving on a different
+ *     stream than the previous one first makes its stream wait (hipStreamWaitEvent) for that call's
+ *     work.  So two caller streams never share the scratch concurrently, and there is no concurrency
+ *     to gain from several streams on ONE context -- use one context per concurrent stream
+ *     (contexts share nothing but the device).  Caller buffers are the caller's to order.
  *   - validity bitmasks: bit (i & 63) of word (i >> 6) is configuration i; padding bits are 0.
  *   - non-convergence / NaN in a lane is not an error: that configuration is simply invalid.
  */
@@ -183,6 +190,47 @@ int tr_validate_batch(tr_ctx *ctx, const double *states, int64_t n,
                       uint64_t *valid_bits, double *tips, uint8_t *flags);
 int tr_validate_batch_dev(tr_ctx *ctx, const double *d_states, int64_t n,
                           uint64_t *d_valid_bits, double *d_tips, uint8_t *d_flags, void *stream);
+
+/* ---- createRoadmap phase 1 on the device: rejection sampling of valid vertices ------------- */
+
+/* The reference's vertex phase (motion-planning/VoxelCachedLazyPRM.cpp:1415-1455) draws every new milestone in a loop
+ *   sampleUniform -> fk -> is_valid_shape -> voxelize -> collides   until a state is accepted (:1441-1444),
+ * from thread-local OMPL generators (not reproducible).  Here the candidates form ONE sequence that is a pure function of
+ * (seed, candidate index): Philox-4x32-10 with counter (index, coordinate pair) and key = seed gives 53-bit uniforms u,
+ * state[d] = lo[d] + u * (hi[d] - lo[d]) (product and sum rounded separately).  lo / hi: S doubles each, or both NULL for the
+ * planner's state-space bounds (Problem.cpp:101-163: tension [0, max_tension_i], rotation [-pi, pi), retraction [0, L]).
+ * The same candidates come out for every batch size, every GPU count (rank g takes a contiguous index range) and from the
+ * host mirror (interactive-rate-tendons_amd/distributed.py: candidate_states).  States are generated in HBM and never
+ * uploaded. */
+int tr_candidate_states(tr_ctx *ctx, uint64_t seed, uint64_t first, int64_t count, const double *lo, const double *hi,
+                        double *states /* count x S, host */);
+int tr_candidate_states_dev(tr_ctx *ctx, uint64_t seed, uint64_t first, int64_t count, const double *lo, const double *hi,
+                            double *d_states /* count x S */, void *stream);
+
+/* tr_validate_batch_dev on candidates [first, first + count) of the sequence, generated on the device (first % 64 == 0 so
+ * that shards are whole mask words).  The shard form of config 4: the mask stays on the device for the all-gather. */
+int tr_validate_candidates_dev(tr_ctx *ctx, uint64_t seed, uint64_t first, int64_t count, const double *lo, const double *hi,
+                               uint64_t *d_valid_bits, double *d_tips, uint8_t *d_flags, void *stream);
+
+/* Order-preserving compaction on the device: rows i of d_rows (row_doubles doubles each) whose mask bit is set go, in
+ * ascending i, to d_rows_out (at most `capacity` rows); d_index_out (optional) receives their i.  *n_out = number of set
+ * bits among the first `count` (rows written = min(*n_out, capacity)).  With the gathered vertex mask and the regenerated
+ * candidates this yields the same vertex array on every rank.  Synchronises `stream` (one counter read-back). */
+int tr_compact_rows_dev(tr_ctx *ctx, const uint64_t *d_mask, int64_t count, const double *d_rows, int32_t row_doubles,
+                        int64_t capacity, double *d_rows_out, int64_t *d_index_out, int64_t *n_out, void *stream);
+
+/* The whole loop: candidates first_candidate, first_candidate + 1, ... are validated batch by batch (fk_verdict; batch sizes
+ * follow the acceptance rate seen so far) and the first n_want VALID ones are returned in candidate order -- the accepted set
+ * does not depend on the batch sizes.  One 32-byte counter read-back per batch is the only host traffic of the _dev form.
+ *   states  n_want x S     tips  n_want x 3 (optional)     index  n_want (optional): candidate index of each vertex
+ *   *n_accepted  vertices returned (< n_want only when max_candidates candidates did not yield enough; 0 = the default
+ *                64 n_want + 2^20)        *n_tried  candidates consumed up to and including the last accepted one         */
+int tr_sample_valid_vertices(tr_ctx *ctx, uint64_t seed, uint64_t first_candidate, const double *lo, const double *hi,
+                             int64_t n_want, int64_t max_candidates, double *states, double *tips, int64_t *index,
+                             int64_t *n_accepted, int64_t *n_tried);
+int tr_sample_valid_vertices_dev(tr_ctx *ctx, uint64_t seed, uint64_t first_candidate, const double *lo, const double *hi,
+                                 int64_t n_want, int64_t max_candidates, double *d_states, double *d_tips, int64_t *d_index,
+                                 int64_t *n_accepted, int64_t *n_tried, void *stream);
 
 /* The second stage alone, on caller-supplied backbone shapes (is_valid_shape + voxelize +
  * collides on given TendonResults: AbstractValidityChecker.cpp:99-122).  Device pointers, SoA as

@@ -34,6 +34,8 @@ ABI_SYMBOLS = (
     "tr_roadmap_create", "tr_roadmap_destroy", "tr_roadmap_last_error", "tr_roadmap_set_caches", "tr_roadmap_set_caches_dev", "tr_roadmap_prepare", "tr_roadmap_clear_validity",
     "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_edges_indexed", "tr_connect_edges_indexed", "tr_voxelize_fetch", "tr_voxelize_fetch_dev", "tr_voxelize_count", "tr_knn", "tr_knn_range", "tr_knn_table_edges", "tr_knn_edges", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug",
+    "tr_candidate_states", "tr_candidate_states_dev", "tr_validate_candidates_dev", "tr_compact_rows_dev",
+    "tr_sample_valid_vertices", "tr_sample_valid_vertices_dev",
 )
 
 
@@ -108,11 +110,12 @@ def _units():
     instantiations compile in parallel."""
     fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "verdict_kernel.hpp",
                "sweep_kernel.hpp", "sphere_kernel.hpp", "tr_types.hpp"]
-    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip"]
+    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip", "sample.hip"]
     main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
     u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),
          ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"]),
-         ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", HEADER])]
+         ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", HEADER]),
+         ("sample.o", "sample.hip", [], ["sample.hip", "sample.hpp", "tr_types.hpp"])]
     for n in range(1, 9):
         for kind, tag in ((0, "u"), (1, "r"), (2, "f"), (3, "v"), (4, "w")):
             u.append(("fk_%s%d.o" % (tag, n), "fk_inst.hip", ["-DTRK_INST_N=%d" % n, "-DTRK_INST_KIND=%d" % kind], fk_deps))
@@ -268,6 +271,13 @@ def lib():
     L.tr_knn_edges.argtypes = [vp, dp, i64, C.c_int32, C.c_double, P(C.c_int32), i64, P(i64)]
     L.tr_knn_range.argtypes = [vp, dp, i64, i64, i64, C.c_int32, C.c_double, P(C.c_int32), dp]
     L.tr_knn_table_edges.argtypes = [vp, P(C.c_int32), i64, C.c_int32, P(C.c_int32), i64, P(i64)]
+    u64 = C.c_uint64
+    L.tr_candidate_states.argtypes = [vp, u64, u64, i64, dp, dp, dp]
+    L.tr_candidate_states_dev.argtypes = [vp, u64, u64, i64, dp, dp, vp, vp]
+    L.tr_validate_candidates_dev.argtypes = [vp, u64, u64, i64, dp, dp, vp, vp, vp, vp]
+    L.tr_compact_rows_dev.argtypes = [vp, vp, i64, vp, C.c_int32, i64, vp, vp, P(i64), vp]
+    L.tr_sample_valid_vertices.argtypes = [vp, u64, u64, dp, dp, i64, i64, dp, dp, P(i64), P(i64), P(i64)]
+    L.tr_sample_valid_vertices_dev.argtypes = [vp, u64, u64, dp, dp, i64, i64, vp, vp, vp, P(i64), P(i64), vp]
     L.tr_profile_begin.argtypes = [vp]
     L.tr_profile_read.argtypes = [vp, P(i64), dp]
     L.tr_profile_end.argtypes = [vp]

@@ -33,6 +33,7 @@
 #include "knn_kernel.hpp"
 #include "cache_merge.hpp"
 #include "env_kernel.hpp"
+#include "sample.hpp"
 
 namespace {
 
@@ -192,6 +193,18 @@ struct tr_ctx {
   // stream instead of synchronising the whole device
   hipEvent_t last_dev_ev = nullptr;
   bool last_dev_used = false;
+  hipStream_t last_dev_stream = nullptr;   // stream of that work: a *_dev call on ANOTHER stream first waits for it (begin_dev_work)
+  // createRoadmap's vertex phase on the device (sample_host.inc): one batch of candidates (states, verdict bits, tips), the
+  // compaction's scratch and counters, the accepted set when the caller wants host arrays
+  struct Sampler {
+    int64_t cap = 0;
+    double *states = nullptr; uint64_t *bits = nullptr; double *tips = nullptr; uint32_t *wprefix = nullptr;
+    uint32_t *wprefix2 = nullptr; int64_t wp2_cap = 0;       // tr_compact_rows_dev's own scan scratch
+    trk::SampleCounters *d_ctr = nullptr, *h_ctr = nullptr;  // device block and its pinned host image
+    int64_t out_cap = 0;
+    double *out_states = nullptr, *out_tips = nullptr; int64_t *out_index = nullptr;
+    double rate_seen = 0.0;                                  // acceptance rate of this context's last run (sizes the first batch)
+  } samp;
   // instrumentation
   bool profiling = false;
   std::vector<EventPair> events[TR_PROFILE_SLOTS];
@@ -384,11 +397,21 @@ struct ProfScope {
   }
 };
 
-// *_dev entry points call this after enqueueing their work
+// The *_dev entry points that use per-context scratch (fallback list and counter, workspace columns, ordering buffers, argument
+// rings, the sampler's batch) bracket their work with these two.  Calls on ONE stream are ordered by the stream; a call that
+// arrives on a DIFFERENT stream than the previous one first makes its stream wait for that call's work (a device-side
+// dependency, no host synchronisation), so two caller streams can never run on the shared scratch at once -- calls on one
+// context execute in the order they were issued, whichever streams they name.
+int begin_dev_work(tr_ctx *ctx, hipStream_t s) {
+  if (ctx->last_dev_used && ctx->last_dev_stream != s) HIP_TRY(ctx, hipStreamWaitEvent(s, ctx->last_dev_ev, 0));
+  return TR_OK;
+}
+// ... and this after enqueueing their work
 int note_dev_work(tr_ctx *ctx, hipStream_t s) {
   if (!ctx->last_dev_ev) HIP_TRY(ctx, hipEventCreateWithFlags(&ctx->last_dev_ev, hipEventDisableTiming));
   HIP_TRY(ctx, hipEventRecord(ctx->last_dev_ev, s));
   ctx->last_dev_used = true;
+  ctx->last_dev_stream = s;
   return TR_OK;
 }
 
@@ -833,6 +856,12 @@ void tr_destroy(tr_ctx *c) {
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
   if (c->vring.d_slots) { (void)hipFree(c->vring.d_slots); (void)hipHostFree(c->vring.h_slots); for (auto &e : c->vring.ev) (void)hipEventDestroy(e); }
   if (c->last_dev_ev) (void)hipEventDestroy(c->last_dev_ev);
+  {
+    tr_ctx::Sampler &sm = c->samp;
+    void *sp[] = {sm.states, sm.bits, sm.tips, sm.wprefix, sm.wprefix2, sm.d_ctr, sm.out_states, sm.out_tips, sm.out_index};
+    for (void *q : sp) if (q) (void)hipFree(q);
+    if (sm.h_ctr) (void)hipHostFree(sm.h_ctr);
+  }
   if (c->d_item_src) (void)hipFree(c->d_item_src);
   if (c->d_item_edge) (void)hipFree(c->d_item_edge);
   for (void *q : c->knn.p) if (q) (void)hipFree(q);
@@ -1210,6 +1239,7 @@ int tr_validate_shapes_dev(tr_ctx *c, int64_t n, int64_t ld, const double *d_px,
     if ((rc = ensure_workspace(c, ld))) return rc;
   }
   (void)d_n_points;                     // every configuration of a robot without retraction has all P points
+  if ((rc = begin_dev_work(c, (hipStream_t)stream))) return rc;
   trk::SweepIn in{d_px, d_py, d_pz, nullptr, d_Li, d_converged, nullptr, c->ws.acc};
   // acc scratch is laid out [P][ws.ld]; the kernel indexes it with ld, which is <= ws.ld: fine as
   // long as P*ld <= P*ws.ld (it only needs P*ld doubles).
@@ -1234,6 +1264,7 @@ int tr_validate_shapes_retraction_dev(tr_ctx *c, int64_t n, int64_t ld, const do
     if ((rc = ensure_workspace(c, ld))) return rc;
   }
   trk::SweepIn in{d_px, d_py, d_pz, d_n_points, d_Li, d_converged, d_home_Li, c->ws.acc};
+  if ((rc = begin_dev_work(c, (hipStream_t)stream))) return rc;
   if ((rc = launch_sweep(c, in, n, ld, check_voxels, d_valid_bits, d_flags, (hipStream_t)stream))) return rc;
   return note_dev_work(c, (hipStream_t)stream);
 }
@@ -1248,7 +1279,9 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
                           double *d_tips, uint8_t *d_flags, void *stream) {
   if (!c) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
-  const int rc = validate_batch_dev_impl(c, d_states, n, d_valid_bits, d_tips, d_flags, stream);
+  int rc;
+  if ((rc = begin_dev_work(c, (hipStream_t)stream))) return rc;
+  rc = validate_batch_dev_impl(c, d_states, n, d_valid_bits, d_tips, d_flags, stream);
   if (rc == TR_OK && n > 0) return note_dev_work(c, (hipStream_t)stream);
   return rc;
 }
@@ -1341,7 +1374,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
     if ((rc = ensure_staging(c, n))) return rc;
     if (!verdict && (rc = ensure_workspace(c, n))) return rc;
     Workspace &w = c->ws;
-    if (c->last_dev_used) HIP_TRY(c, hipStreamWaitEvent(p.s_comp, c->last_dev_ev, 0));
+    if ((rc = begin_dev_work(c, p.s_comp))) return rc;
     std::memcpy(p.h_states[0], states, (size_t)n * S * sizeof(double));
     HIP_TRY(c, hipMemcpyAsync(w.states, p.h_states[0], (size_t)n * S * sizeof(double), hipMemcpyHostToDevice, p.s_comp));
     if ((rc = validate_batch_dev_impl(c, w.states, n, w.bits, tips ? w.tips : nullptr, flags ? w.flags : nullptr, p.s_comp))) return rc;
@@ -1349,6 +1382,7 @@ int tr_validate_batch(tr_ctx *c, const double *states, int64_t n, uint64_t *vali
     if (tips) HIP_TRY(c, hipMemcpyAsync(p.h_tips[0], w.tips, (size_t)n * 3 * sizeof(double), hipMemcpyDeviceToHost, p.s_comp));
     if (flags) HIP_TRY(c, hipMemcpyAsync(p.h_flags[0], w.flags, (size_t)n, hipMemcpyDeviceToHost, p.s_comp));
     HIP_TRY(c, hipStreamSynchronize(p.s_comp));
+    c->last_dev_used = false;                      // everything enqueued on this context so far has finished
     std::memcpy(valid_bits, p.h_bits[0], (size_t)((n + 63) / 64) * sizeof(uint64_t));
     if (tips) std::memcpy(tips, p.h_tips[0], (size_t)n * 3 * sizeof(double));
     if (flags) std::memcpy(flags, p.h_flags[0], (size_t)n);
@@ -1828,3 +1862,4 @@ int tr_profile_end(tr_ctx *c) {
 }  // extern "C"
 
 #include "edge_host.inc"
+#include "sample_host.inc"

@@ -5,13 +5,13 @@ host connects edges -- the exchange step the reference's single-process createRo
 free from shared memory (motion-planning/VoxelCachedLazyPRM.cpp:1446-1483: parallel vertex
 validation, then serial addMilestone over ALL vertices).
 
-Candidate vertices come from a counter-keyed generator (chunk index -> stream), so the candidate
-set and therefore the gathered mask are identical for every world size.
+Candidate vertices come from a counter-based generator keyed by (seed, global candidate index) -- Philox-4x32-10, the same
+function on the device (csrc/sample.hip) and here -- so the candidate set and therefore the gathered mask are identical for
+every world size and every batch size.
 """
 import numpy as np
 
 WORD = 64
-RNG_CHUNK = 1 << 16
 
 
 def shard_bounds(M, world_size, rank):
@@ -25,29 +25,56 @@ def shard_bounds(M, world_size, rank):
     return start, start + shard, shard
 
 
-def candidate_states(robot, seed, start, count, tau_max=None):
-    """States [start, start+count) of the global candidate sequence keyed by (seed, chunk)."""
-    S = robot.state_size()
-    out = np.empty((count, S))
-    pos = start
-    while pos < start + count:
-        chunk = pos // RNG_CHUNK
-        lo = chunk * RNG_CHUNK
-        rng = np.random.default_rng([int(seed), int(chunk)])
-        block = np.empty((RNG_CHUNK, S))
-        k = 0
-        for t in robot.tendons:
-            block[:, k] = rng.uniform(0.0, t.max_tension if tau_max is None else tau_max, RNG_CHUNK)
-            k += 1
-        if robot.enable_rotation:
-            block[:, k] = rng.uniform(-np.pi, np.pi, RNG_CHUNK)
-            k += 1
-        if robot.enable_retraction:
-            block[:, k] = rng.uniform(0.0, robot.specs.L, RNG_CHUNK)
-        a = pos - lo
-        b = min(RNG_CHUNK, start + count - lo)
-        out[pos - start: pos - start + (b - a)] = block[a:b]
-        pos += b - a
+_PHILOX_M0, _PHILOX_M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_PHILOX_W0, _PHILOX_W1 = 0x9E3779B9, 0xBB67AE85
+_M32 = np.uint64(0xFFFFFFFF)
+
+
+def philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Philox-4x32-10 (Salmon et al., SC'11) on arrays of 32-bit counter words held in uint64; key words are Python ints.
+    The device generator (csrc/sample.hip) is the same function; tests hold the paper's known-answer vectors."""
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) & _M32 for x in (c0, c1, c2, c3))
+    k0, k1 = int(k0) & 0xFFFFFFFF, int(k1) & 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = _PHILOX_M0 * c0, _PHILOX_M1 * c2                      # 32 x 32 -> 64 bit products
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ np.uint64(k0)
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ np.uint64(k1)
+        c0, c1, c2, c3 = n0, p1 & _M32, n2, p0 & _M32
+        k0, k1 = (k0 + _PHILOX_W0) & 0xFFFFFFFF, (k1 + _PHILOX_W1) & 0xFFFFFFFF
+    return c0, c1, c2, c3
+
+
+def sampling_box(robot, tau_max=None):
+    """(lo, hi) of the planner's state space (motion-planning/Problem.cpp:101-163): tensions [0, max_tension] (or a common
+    tau_max), rotation [-pi, pi), retraction [0, L]."""
+    lo = [0.0] * len(robot.tendons)
+    hi = [float(t.max_tension if tau_max is None else tau_max) for t in robot.tendons]
+    if robot.enable_rotation:
+        lo.append(-np.pi); hi.append(np.pi)
+    if robot.enable_retraction:
+        lo.append(0.0); hi.append(float(robot.specs.L))
+    return np.array(lo), np.array(hi)
+
+
+def candidate_states(robot, seed, start, count, tau_max=None, box=None):
+    """States [start, start + count) of the global candidate sequence: a pure function of (seed, candidate index) -- the host
+    mirror of the device generator (tr_candidate_states / tr_sample_valid_vertices, include/tendon_hip.h): Philox counter
+    (index lo, index hi, coordinate pair, 0), key (seed lo, seed hi); 53-bit uniforms u, state[d] = lo[d] + u * (hi[d] - lo[d])
+    with the product and the sum rounded separately.  Bit-identical to the device (tests/test_gpu_sampling.py)."""
+    lo, hi = box if box is not None else sampling_box(robot, tau_max)
+    S = len(lo)
+    span = hi - lo
+    idx = np.uint64(int(start)) + np.arange(int(count), dtype=np.uint64)
+    out = np.empty((int(count), S))
+    seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    for j in range((S + 1) // 2):
+        r0, r1, r2, r3 = philox4x32_10(idx & _M32, idx >> np.uint64(32), np.full(len(idx), j, dtype=np.uint64), 0,
+                                       seed & 0xFFFFFFFF, seed >> 32)
+        ua = (((r0 << np.uint64(32)) | r1) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+        out[:, 2 * j] = lo[2 * j] + ua * span[2 * j]
+        if 2 * j + 1 < S:
+            ub = (((r2 << np.uint64(32)) | r3) >> np.uint64(11)).astype(np.float64) * 2.0 ** -53
+            out[:, 2 * j + 1] = lo[2 * j + 1] + ub * span[2 * j + 1]
     return out
 
 
@@ -66,16 +93,18 @@ def allgather_mask(local_words, group=None):
 class ShardedVertexValidator:
     """Validate M candidate vertices across the ranks of the default process group.
 
-    validate_local(states) -> uint64/int64 mask words for that shard (bit i&63 of word i>>6).
-    In production this is Engine.validate_batch_dev on the rank's GPU; the CPU tests plug in the
-    oracle to exercise the sharding and the collective with the `gloo` backend.
+    Production (one rank per GPU): `validate_candidates(first, count, n_words)` -> int64 tensor of n_words mask words ON THE
+    DEVICE for candidates [first, first + count) -- `device_candidate_validator(engine, seed, box)` builds it from
+    Engine.validate_candidates_dev, which generates the candidates in HBM, so neither states nor mask touch the host before
+    the all-gather.  CPU tests (gloo): `validate_local(states)` -> uint64/int64 mask words for host states from the host
+    mirror of the generator (the oracle plugs in there).  Bit i & 63 of word i >> 6; padding bits zero.
     """
 
-    def __init__(self, robot, validate_local, seed=0, tau_max=None, device="cpu"):
-        self.robot, self.validate_local = robot, validate_local
-        self.seed, self.tau_max, self.device = seed, tau_max, device
+    def __init__(self, robot, validate_local=None, seed=0, tau_max=None, device="cpu", validate_candidates=None, box=None):
+        self.robot, self.validate_local, self.validate_candidates = robot, validate_local, validate_candidates
+        self.seed, self.tau_max, self.device, self.box = seed, tau_max, device, box
 
-    def run(self, M, rank=None, world_size=None):
+    def run(self, M, rank=None, world_size=None, keep_on_device=False):
         import torch
         import torch.distributed as dist
         if rank is None:
@@ -84,17 +113,51 @@ class ShardedVertexValidator:
             world_size = dist.get_world_size() if dist.is_initialized() else 1
         start, stop, shard = shard_bounds(M, world_size, rank)
         n_real = max(0, min(stop, M) - start)
-        words = np.zeros(shard // WORD, dtype=np.uint64)
-        if n_real > 0:
-            states = candidate_states(self.robot, self.seed, start, n_real, self.tau_max)
-            w = np.asarray(self.validate_local(states)).view(np.uint64)
-            words[: w.size] = w
-            if n_real % WORD:                              # padding bits stay zero
-                words[n_real // WORD] &= np.uint64((1 << (n_real % WORD)) - 1)
-        local = torch.from_numpy(words.view(np.int64)).to(self.device)
+        if self.validate_candidates is not None:
+            local = self.validate_candidates(start, n_real, shard // WORD)
+        else:
+            words = np.zeros(shard // WORD, dtype=np.uint64)
+            if n_real > 0:
+                states = candidate_states(self.robot, self.seed, start, n_real, self.tau_max, box=self.box)
+                w = np.asarray(self.validate_local(states)).view(np.uint64)
+                words[: w.size] = w
+                if n_real % WORD:                              # padding bits stay zero
+                    words[n_real // WORD] &= np.uint64((1 << (n_real % WORD)) - 1)
+            local = torch.from_numpy(words.view(np.int64)).to(self.device)
         full = allgather_mask(local)
         # world_size * shard/64 words; bits of items >= M are zero.  unpack_bits(words, M) is the mask.
-        return full.cpu().numpy().view(np.uint64)
+        return full if keep_on_device else full.cpu().numpy().view(np.uint64)
+
+
+def device_candidate_validator(engine, seed, box=None, tips=None):
+    """validate_candidates for ShardedVertexValidator on `engine`'s GPU (tr_validate_candidates_dev).  tips (optional): a
+    dict that receives the shard's tip tensor under "tips" (n x 3, on the device)."""
+    def validate(first, count, n_words):
+        import torch
+        dev = "cuda:%d" % engine.device
+        bits = torch.zeros(n_words, dtype=torch.int64, device=dev)
+        if count > 0:
+            d_tips = torch.empty(count * 3, dtype=torch.float64, device=dev) if tips is not None else None
+            engine.validate_candidates_dev(seed, first, count, bits, d_tips=d_tips, box=box)
+            if tips is not None:
+                tips["tips"] = d_tips.view(count, 3)
+        return bits
+    return validate
+
+
+def gather_valid_vertices_dev(engine, seed, M, d_mask, box=None):
+    """Every rank's copy of the accepted vertices after the all-gather: the M candidates are regenerated in HBM
+    (tr_candidate_states_dev, ~10 us per 10^6) and compacted by the gathered mask in candidate order (tr_compact_rows_dev).
+    Returns (states tensor [n_valid, S] on the device, candidate indices [n_valid])."""
+    import torch
+    dev = "cuda:%d" % engine.device
+    S = engine.state_size
+    cand = torch.empty(M * S, dtype=torch.float64, device=dev)
+    engine.candidate_states_dev(seed, 0, M, cand, box=box)
+    out = torch.empty(M * S, dtype=torch.float64, device=dev)
+    idx = torch.empty(M, dtype=torch.int64, device=dev)
+    n = engine.compact_rows_dev(d_mask, M, cand, S, out, M, d_index_out=idx)
+    return out[: n * S].view(n, S), idx[:n]
 
 
 class ShardedEdgeValidator:

@@ -281,6 +281,35 @@ class Engine:
                                                  e.ctypes.data_as(C.POINTER(C.c_int32)), cap, C.byref(ne)))
         return e[: min(cap, ne.value)].copy()
 
+    def space_weights(self):
+        """(w_rotation, w_retraction) of the planner's compound state space (tr_space_weights; Problem.cpp:131-152)."""
+        wr, ws = C.c_double(0), C.c_double(0)
+        L.check(self._ctx, self.lib.tr_space_weights(self._ctx, C.byref(wr), C.byref(ws)))
+        return wr.value, ws.value
+
+    def state_distance(self, a, b):
+        """OMPL's CompoundStateSpace::distance for rows of a and b as Problem.cpp:101-163 wires it: Euclidean norm of the
+        tensions (weight 1) + w_rotation x shortest SO2 arc + w_retraction x |delta s| -- the cost connectVertices stores on an
+        edge (VoxelCachedLazyPRM.cpp:2857-2861) and the metric of tr_knn."""
+        a, b = _f64(a).reshape(-1, self.state_size), _f64(b).reshape(-1, self.state_size)
+        n = self.n_tendons
+        _, rot, ret = self.state_layout()
+        wr, ws = self.space_weights()
+        d = np.sqrt(((a[:, :n] - b[:, :n]) ** 2).sum(axis=1))
+        k = n
+        if rot:
+            arc = np.abs(a[:, k] - b[:, k])
+            d = d + wr * np.where(arc > np.pi, 2.0 * np.pi - arc, arc)
+            k += 1
+        if ret:
+            d = d + ws * np.abs(a[:, k] - b[:, k])
+        return d
+
+    def state_layout(self):
+        n, rot, ret = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        L.check(self._ctx, self.lib.tr_state_layout(self._ctx, C.byref(n), C.byref(rot), C.byref(ret)))
+        return n.value, bool(rot.value), bool(ret.value)
+
     def kstar_k(self, n_milestones):
         """k of og::KStarStrategy for a roadmap of n_milestones vertices (PRM*)."""
         k = self.lib.tr_kstar_k(self._ctx, int(n_milestones))
@@ -376,6 +405,77 @@ class Engine:
         pt = self._check_dev(d_tips, torch.float64, 3 * n, "d_tips") if d_tips is not None else None
         pf = self._check_dev(d_flags, torch.uint8, n, "d_flags") if d_flags is not None else None
         L.check(self._ctx, self.lib.tr_validate_batch_dev(self._ctx, ps, int(n), pb, pt, pf, self._stream_ptr(stream)))
+
+    # ---- createRoadmap phase 1 on the device (tr_sample_valid_vertices & co, include/tendon_hip.h) ----------------------
+    @staticmethod
+    def _box(box):
+        if box is None:
+            return None, None, None
+        lo, hi = _f64(box[0]), _f64(box[1])
+        return (lo, hi), _dp(lo), _dp(hi)
+
+    def candidate_states(self, seed, first, count, box=None):
+        """Candidates [first, first + count) of the sequence `seed`, generated on the device, as a host array."""
+        keep, plo, phi = self._box(box)
+        out = np.empty((int(count), self.state_size))
+        L.check(self._ctx, self.lib.tr_candidate_states(self._ctx, int(seed), int(first), int(count), plo, phi, _dp(out)))
+        return out
+
+    def candidate_states_dev(self, seed, first, count, d_states, box=None, stream=None):
+        keep, plo, phi = self._box(box)
+        ps = self._check_dev(d_states, _torch().float64, count * self.state_size, "d_states")
+        L.check(self._ctx, self.lib.tr_candidate_states_dev(self._ctx, int(seed), int(first), int(count), plo, phi, ps, self._stream_ptr(stream)))
+
+    def validate_candidates_dev(self, seed, first, count, d_bits, d_tips=None, d_flags=None, box=None, stream=None):
+        """tr_validate_batch_dev on device-generated candidates [first, first + count): nothing is uploaded, the mask stays in HBM."""
+        torch = _torch()
+        keep, plo, phi = self._box(box)
+        pb = self._check_dev(d_bits, torch.int64, (count + 63) // 64, "d_bits")
+        pt = self._check_dev(d_tips, torch.float64, 3 * count, "d_tips") if d_tips is not None else None
+        pf = self._check_dev(d_flags, torch.uint8, count, "d_flags") if d_flags is not None else None
+        L.check(self._ctx, self.lib.tr_validate_candidates_dev(self._ctx, int(seed), int(first), int(count), plo, phi, pb, pt, pf,
+                                                               self._stream_ptr(stream)))
+
+    def compact_rows_dev(self, d_mask, count, d_rows, row_doubles, d_rows_out, capacity, d_index_out=None, stream=None):
+        """Rows of d_rows whose mask bit is set, in order, into d_rows_out (at most capacity); returns the number of set bits."""
+        torch = _torch()
+        pm = self._check_dev(d_mask, torch.int64, (count + 63) // 64, "d_mask")
+        pr = self._check_dev(d_rows, torch.float64, count * row_doubles, "d_rows") if row_doubles else None
+        po = self._check_dev(d_rows_out, torch.float64, capacity * row_doubles, "d_rows_out") if row_doubles else None
+        pi = self._check_dev(d_index_out, torch.int64, capacity, "d_index_out") if d_index_out is not None else None
+        n_out = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_compact_rows_dev(self._ctx, pm, int(count), pr, int(row_doubles), int(capacity), po, pi, C.byref(n_out),
+                                                        self._stream_ptr(stream)))
+        return n_out.value
+
+    def sample_valid_vertices(self, n_want, seed=0, first_candidate=0, box=None, max_candidates=0, want_tips=True, want_index=False):
+        """The first n_want valid candidates of the sequence, in candidate order: generated, validated and compacted on the GPU."""
+        keep, plo, phi = self._box(box)
+        n_want = int(n_want)
+        states = np.empty((n_want, self.state_size))
+        tips = np.empty((n_want, 3)) if want_tips else None
+        index = np.empty(n_want, dtype=np.int64) if want_index else None
+        n_acc, n_tried = C.c_int64(0), C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_sample_valid_vertices(
+            self._ctx, int(seed), int(first_candidate), plo, phi, n_want, int(max_candidates), _dp(states),
+            _dp(tips) if want_tips else None, index.ctypes.data_as(C.POINTER(C.c_int64)) if want_index else None,
+            C.byref(n_acc), C.byref(n_tried)))
+        k = n_acc.value
+        return dict(states=states[:k], tips=tips[:k] if want_tips else None, index=index[:k] if want_index else None,
+                    accepted=k, tried=n_tried.value)
+
+    def sample_valid_vertices_dev(self, n_want, d_states, d_tips=None, d_index=None, seed=0, first_candidate=0, box=None,
+                                  max_candidates=0, stream=None):
+        torch = _torch()
+        keep, plo, phi = self._box(box)
+        ps = self._check_dev(d_states, torch.float64, n_want * self.state_size, "d_states")
+        pt = self._check_dev(d_tips, torch.float64, 3 * n_want, "d_tips") if d_tips is not None else None
+        pi = self._check_dev(d_index, torch.int64, n_want, "d_index") if d_index is not None else None
+        n_acc, n_tried = C.c_int64(0), C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_sample_valid_vertices_dev(self._ctx, int(seed), int(first_candidate), plo, phi, int(n_want),
+                                                                 int(max_candidates), ps, pt, pi, C.byref(n_acc), C.byref(n_tried),
+                                                                 self._stream_ptr(stream)))
+        return n_acc.value, n_tried.value
 
     def fk_batch_dev(self, d_states, n, ld, d_px, d_py, d_pz, d_L=None, d_Li=None, d_conv=None, d_R=None,
                      d_npts=None, stream=None):

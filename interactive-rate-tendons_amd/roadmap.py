@@ -21,26 +21,16 @@ class RoadmapBuilder:
         self.timing = {}
 
     # ---- createRoadmap phase 1: rejection sampling until N valid vertices ----------------------------
-    def sample_valid_vertices(self, N, batch=1 << 16):
-        """Candidates come from the counter-keyed sequence of distributed.candidate_states, so the
-        accepted set is a deterministic prefix-filter of it (independent of batch size)."""
+    def sample_valid_vertices(self, N, batch=None):
+        """createRoadmap's vertex phase on the device (tr_sample_valid_vertices): the candidates are a counter-based sequence
+        keyed by (seed, candidate index) -- distributed.candidate_states is its host mirror -- generated in HBM, validated by
+        fk_verdict and compacted in candidate order on the GPU; only the accepted states and tips come back.  The accepted set
+        is a deterministic prefix-filter of the sequence (independent of the batch sizes; `batch` is accepted and ignored)."""
         t0 = time.perf_counter()
-        states, tips, pos, tried = [], [], 0, 0
-        have = 0
-        while have < N:
-            cand = D.candidate_states(self.robot, self.seed, pos, batch, self.tau_max)
-            out = self.engine.validate_batch(cand, True, False)
-            ok = out["valid"]
-            take = np.flatnonzero(ok)
-            if have + take.size > N:
-                take = take[: N - have]
-                tried += int(take[-1]) + 1
-            else:
-                tried += batch
-            states.append(cand[take]); tips.append(out["tips"][take])
-            have += take.size
-            pos += batch
-        states, tips = np.concatenate(states), np.concatenate(tips)
+        out = self.engine.sample_valid_vertices(N, seed=self.seed, box=D.sampling_box(self.robot, self.tau_max))
+        if out["accepted"] < N:
+            raise RuntimeError("only %d of %d valid vertices after %d candidates" % (out["accepted"], N, out["tried"]))
+        states, tips, tried = out["states"], out["tips"], out["tried"]
         if self.robot.enable_retraction:
             # Milestones are numbered by backbone length.  The numbering of a roadmap's vertices is free (the reference's is the
             # order of its addMilestone calls), and with this one every later batch over the roadmap is homogeneous wave by
@@ -186,10 +176,7 @@ class RoadmapBuilder:
                         present=np.ones(len(c["offsets"]) - 1, bool) if pres is None else np.asarray(pres, bool))
         st, e = roadmap["states"], roadmap["edges"]
         if weights is None:                                  # connectVertices stores the motion cost = state-space distance (:2857-2861)
-            scale = self.state_space_metric_scale()
-            if self.robot.enable_rotation or self.robot.enable_retraction:
-                raise NotImplementedError("pass the edge weights for a space with rotation / retraction")
-            weights = np.linalg.norm((st[e[:, 0]] - st[e[:, 1]]) * scale, axis=1)
+            weights = self.engine.state_distance(st[e[:, 0]], st[e[:, 1]])
         vox = self.checker._voxels
         rmp.write_rmp(path, st, roadmap.get("tips"), e, weights, host(roadmap["vertex_caches"]), host(roadmap["edge_caches"]),
                       N=vox.Nx(), limits=vox.limits())

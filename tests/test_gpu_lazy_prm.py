@@ -285,7 +285,16 @@ def test_roadmap_file_round_trip_into_the_query_loop(irt, tmp_path):
     rb.save_rmp(path, rm)
     back = irt.rmp.read_rmp(path)
     assert np.array_equal(back["states"], rm["states"]) and np.array_equal(back["edges"], rm["edges"])
-    assert np.array_equal(back["edge_caches"]["block_ids"], rm["edge_caches"]["block_ids"].cpu().numpy().view(np.uint32))
+    # the file holds every voxel set in the reference's serialisation order (visit_leaves, tests/test_treenode_pin.py); as
+    # SETS they are the caches the roadmap was built with
+    ec, eo = rm["edge_caches"], rm["edge_caches"]["offsets"]
+    want_ids, want_masks = ec["block_ids"].cpu().numpy().view(np.uint32), ec["masks"].cpu().numpy().view(np.uint64)
+    assert np.array_equal(back["edge_caches"]["offsets"], eo)
+    for i in range(0, len(eo) - 1, 37):
+        o = np.argsort(back["edge_caches"]["block_ids"][eo[i]:eo[i + 1]])
+        assert np.array_equal(back["edge_caches"]["block_ids"][eo[i]:eo[i + 1]][o], np.sort(want_ids[eo[i]:eo[i + 1]]))
+        assert np.array_equal(back["edge_caches"]["masks"][eo[i]:eo[i + 1]][o], want_masks[eo[i]:eo[i + 1]][np.argsort(want_ids[eo[i]:eo[i + 1]])])
+    assert np.array_equal(np.sort(back["edge_caches"]["block_ids"]), np.sort(want_ids))
     assert np.allclose(back["tips"], rm["tips"], rtol=0, atol=0)
     loaded = irt.VoxelCachedLazyPRM.from_rmp(chk, path)
     new_vox, _ = W.reach_environment(seed=7, n_spheres=92)
@@ -368,3 +377,29 @@ def test_landmark_distances_on_the_device_equal_the_hosts(irt):
                 prm.prepare(nl)                                     # raises if the device's table differs from the host's
     finally:
         os.environ.pop("TENDON_HIP_LANDMARKS", None) if old is None else os.environ.__setitem__("TENDON_HIP_LANDMARKS", old)
+
+
+def test_rmp_edge_weights_in_the_full_state_space(irt, orc, helpers, tmp_path):
+    """save_rmp without explicit weights on a robot with rotation and retraction: every edge carries OMPL's compound-space
+    distance (connectVertices, VoxelCachedLazyPRM.cpp:2857-2861) -- the oracle's orc_state_distance -- computed with the
+    library's subspace weights (tr_space_weights)."""
+    import ctypes as C
+    W = irt.workloads
+    robot = W.robot_config3()
+    robot.enable_rotation = robot.enable_retraction = True
+    vox, _ = W.reach_environment(seed=7, n_spheres=40)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=6)
+    prm, rm = rb.create_roadmap(300, k=4, device=True)
+    path = str(tmp_path / "full.rmp")
+    rb.save_rmp(path, rm)
+    back = irt.rmp.read_rmp(path)
+    orb = helpers.oracle_robot(orc, robot)
+    f = orb.lib.orc_state_distance
+    st, e = rm["states"], rm["edges"]
+    want = np.array([f(C.byref(orb.c), orc._dp(st[a]), orc._dp(st[b])) for a, b in e])
+    assert len(e) > 200 and np.allclose(back["weights"], want, rtol=1e-14, atol=0)
+    loaded = irt.VoxelCachedLazyPRM.from_rmp(chk, path)
+    o1 = prm.solveWithRoadmap(np.arange(40), np.arange(40)[::-1].copy())
+    o2 = loaded.solveWithRoadmap(np.arange(40), np.arange(40)[::-1].copy())
+    assert np.array_equal(o1["status"], o2["status"]) and np.allclose(o1["cost"], o2["cost"], rtol=1e-13, atol=0)

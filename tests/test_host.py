@@ -202,6 +202,33 @@ def test_candidate_states_do_not_depend_on_the_split(irt):
     for start, count in ((0, 1), (65535, 3), (65536, 70000), (131071, 2), (199000, 1000)):
         assert np.array_equal(D.candidate_states(r, 9, start, count), whole[start:start + count])
     assert whole.min() >= 0 and whole.max() < 20.0
+    assert not np.array_equal(D.candidate_states(r, 10, 0, 64), whole[:64])          # the seed is the key
+    assert abs(whole.mean() - 10.0) < 0.05 and np.abs(np.corrcoef(whole.T) - np.eye(4)).max() < 0.01
+
+
+def test_philox_known_answers_and_generator_layout(irt):
+    """The candidate generator is Philox-4x32-10 (Salmon et al., SC'11; the Random123 distribution's known-answer vectors
+    for philox4x32, 10 rounds) with counter (index lo, index hi, coordinate pair, 0) and key = seed; csrc/sample.hip is the
+    same function (compared bit for bit in tests/test_gpu_sampling.py)."""
+    D = irt.distributed
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        got = D.philox4x32_10(*[[c] for c in ctr], *key)
+        assert tuple(int(g[0]) for g in got) == want
+    r = irt.workloads.robot_config3()
+    r.enable_rotation = r.enable_retraction = True                 # S = 6: three Philox blocks per candidate
+    lo, hi = D.sampling_box(r)
+    assert lo.tolist() == [0, 0, 0, 0, -np.pi, 0] and hi.tolist() == [20, 20, 20, 20, np.pi, r.specs.L]
+    seed, idx = (5 << 32) | 77, (1 << 33) + 12345
+    st = D.candidate_states(r, seed, idx, 1)[0]
+    for j in range(3):
+        w = [int(x[0]) for x in D.philox4x32_10([idx & 0xffffffff], [idx >> 32], [j], [0], 77, 5)]
+        for half in range(2):
+            u = (((w[2 * half] << 32) | w[2 * half + 1]) >> 11) * 2.0 ** -53
+            d = 2 * j + half
+            assert st[d] == lo[d] + u * (hi[d] - lo[d])
 
 
 def test_shard_bounds(irt):
