@@ -161,28 +161,8 @@ def secondary_metrics():
         return {"error": repr(e)[:400]}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch-log2", type=int, default=BATCH_LOG2)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics (configs 1, 3, 5 at full size; ~15 s on the GPU)")
-    ap.add_argument("--workload", default="config2", choices=["config2", "roadmap"],
-                    help="config2 (default): the headline line.  roadmap: BASELINE configs 3 and 5 at full size on one GPU "
-                         "(bench_roadmap.py: 100k-vertex PRM, k-NN edges, edge validation with the FK-samples/edge histogram, voxel "
-                         "caches, 10k lazy queries) -- prints that script's JSON object instead of the headline line")
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
-                    help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
-    args = ap.parse_args()
-
-    if args.workload == "roadmap":
-        import bench_roadmap
-        return bench_roadmap.main([] if not args.no_cpu_baseline else ["--no-cpu"])
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus))
-
+def setup_ranks(args):
+    """One process per GPU: device selection and the process group (RCCL; gloo through host memory in rehearsal mode)."""
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -209,6 +189,158 @@ def main():
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    return torch, dist, world, rank, local_rank, dev_index, rehearsal, use_dist
+
+
+def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
+    """BASELINE configs[3]: the PRM build at 2^20 candidate vertices with every phase sharded over the ranks (strong scaling:
+    the job is fixed, ranks divide it) --
+      1. vertex phase: rank g validates candidates [g M/G, (g+1) M/G) of the counter-based sequence, generated in HBM
+         (tr_validate_candidates_dev), and the mask words are all-gathered as device tensors (RCCL);
+      2. every rank regenerates the M candidates and compacts them by the gathered mask (tr_candidate_states_dev,
+         tr_compact_rows_dev): the same vertex array everywhere, no states on the wire;
+      3. connection loop: the rank's rows of the exact k-nearest table against all vertices (tr_knn_range), all-gather of the
+         int32 rows, the deduplicated edge list from the whole table on every rank (tr_knn_table_edges);
+      4. edge phase: the rank's contiguous shard of the edge list through tr_validate_edges_indexed, all-gather of the verdict
+         words.
+    One step = the whole pipeline.  `value` = candidates through the vertex phase per second of vertex-phase time (the
+    metric's FK+collision checks, whole job); the other phases are reported beside it, each as the max over ranks, with the
+    collectives timed on their own afterwards."""
+    import zlib
+    irt = importlib.import_module("interactive-rate-tendons_amd")
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    checker = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox, device=dev_index)
+    mv = irt.VoxelBackboneMotionValidator(checker)
+    eng = checker.engine
+    rb = irt.RoadmapBuilder(checker, mv, seed=3)
+    M, k, seed = 1 << args.config4_log2, args.config4_k, 3
+    dev = "cuda:%d" % dev_index
+    box = D.sampling_box(robot)
+    vv = D.ShardedVertexValidator(robot, seed=seed, device=dev, box=box, validate_candidates=D.device_candidate_validator(eng, seed, box))
+
+    def fence():
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def pipeline():
+        t = [time.perf_counter()]
+        mask = vv.run(M, keep_on_device=True)
+        torch.cuda.synchronize(); t.append(time.perf_counter())
+        verts_dev, _ = D.gather_valid_vertices_dev(eng, seed, M, mask, box=box)
+        verts = verts_dev.cpu().numpy()
+        t.append(time.perf_counter())
+        edges = rb.knn_edges_sharded(verts, k + 1, device=dev)                  # k neighbours + the vertex itself, as nearestK returns
+        t.append(time.perf_counter())
+        ev = rb.validate_edges_sharded(verts, edges, device=dev)
+        t.append(time.perf_counter())
+        return mask, verts, edges, ev, np.diff(t)
+
+    for _ in range(args.warmup):
+        pipeline()
+    fence()
+    eng.profile_begin()
+    t0 = time.perf_counter()
+    phase = np.zeros(4)
+    for _ in range(args.steps):
+        mask, verts, edges, ev, dt = pipeline()
+        phase += dt
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = eng.profile_read()
+    eng.profile_end()
+    phase /= args.steps
+    mask_words = mask.cpu().numpy().view(np.uint64)
+    sums = np.array([zlib.crc32(mask_words[: (M + 63) // 64].tobytes()), len(verts), len(edges), int(ev.sum()), zlib.crc32(edges.tobytes())],
+                    dtype=np.int64)
+    coll = {}
+    if use_dist:
+        cdev = "cpu" if rehearsal else dev
+        tt = torch.tensor(np.concatenate([[elapsed], phase]), dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed, phase = float(tt[0]), tt[1:].cpu().numpy()
+        lo, hi = torch.tensor(sums, device=cdev), torch.tensor(sums, device=cdev)
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN); dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        if not torch.equal(lo, hi):
+            raise SystemExit("rank %d: the ranks disagree on the gathered mask / vertices / edge list / verdicts" % rank)
+        # the three collectives on their own, same buffers and sizes
+        _, _, vshard = D.shard_bounds(M, world, rank)
+        _, _, nshard = D.shard_bounds(len(verts), world, rank)
+        _, _, eshard = D.shard_bounds(len(edges), world, rank)
+        bufs = {"vertex_mask": torch.zeros(vshard // 64, dtype=torch.int64, device=dev),
+                "knn_rows": torch.zeros(nshard * (k + 1), dtype=torch.int32, device=dev),
+                "edge_mask": torch.zeros(eshard // 64, dtype=torch.int64, device=dev)}
+        for name, b in bufs.items():
+            D.allgather_mask(b)
+            fence()
+            t1 = time.perf_counter()
+            for _ in range(10):
+                D.allgather_mask(b)
+            fence()
+            tg = torch.tensor([(time.perf_counter() - t1) / 10], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tg, op=dist.ReduceOp.MAX)
+            coll[name] = {"ms": 1e3 * float(tg.item()), "bytes_per_rank": b.numel() * b.element_size()}
+    if rank == 0:
+        out = {
+            "metric": "FK+collision checks/sec (4-tendon PRM vertex phase, 256^3 voxel env)",
+            "value": M / phase[0], "unit": "checks/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[3]: PRM roadmap, 2^%d candidate vertices (4-tendon quadratic-routed robot, tau~U[0,20)^4, 256^3 grid, "
+                                   "64 spheres) sharded over the ranks: vertex mask all-gather -> %d-NN rows all-gather -> edge verdicts "
+                                   "all-gather" % (args.config4_log2, k),
+                       "ranks_seen": dist.get_world_size() if use_dist else 1, "rehearsal_shared_gpu": rehearsal,
+                       "collective": ("gloo(host)" if rehearsal else "rccl") if use_dist else None,
+                       "candidates": M, "valid_vertices": int(len(verts)), "candidate_edges": int(len(edges)), "valid_edges": int(ev.sum()),
+                       "vertex_mask_crc32": int(sums[0]), "edge_list_crc32": int(sums[4]),
+                       "phases_ms": {"vertices_incl_allgather": 1e3 * phase[0], "regenerate_compact_download": 1e3 * phase[1],
+                                     "knn_rows_incl_allgather_and_edge_list": 1e3 * phase[2], "edges_incl_allgather": 1e3 * phase[3]},
+                       "collectives_alone": coll,
+                       "rates": {"valid_vertices_per_s": len(verts) / phase[0], "edges_validated_per_s": len(edges) / phase[3]}},
+            "kernels": {name: {"launches": v["launches"], "total_ms": v["total_ms"]} for name, v in prof.items()},
+        }
+        print(json.dumps(out), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch-log2", type=int, default=BATCH_LOG2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary metrics (configs 1, 3, 5 at full size; ~15 s on the GPU)")
+    ap.add_argument("--config4-log2", type=int, default=20, help="--workload config4: log2 of the candidate vertices (whole job)")
+    ap.add_argument("--config4-k", type=int, default=10, help="--workload config4: neighbours per vertex")
+    ap.add_argument("--workload", default="config2", choices=["config2", "roadmap", "config4"],
+                    help="config2 (default): the headline line.  roadmap: BASELINE configs 3 and 5 at full size on one GPU "
+                         "(bench_roadmap.py: 100k-vertex PRM, k-NN edges, edge validation with the FK-samples/edge histogram, voxel "
+                         "caches, 10k lazy queries) -- prints that script's JSON object instead of the headline line.  config4: "
+                         "BASELINE configs[3], the PRM build at 2^20 candidates with vertices, neighbour rows and edges sharded over "
+                         "--gpus N ranks (strong scaling), one JSON line with per-phase and per-collective times")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
+                    help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
+    args = ap.parse_args()
+
+    if args.workload == "roadmap":
+        import bench_roadmap
+        return bench_roadmap.main([] if not args.no_cpu_baseline else ["--no-cpu"])
+    if args.workload == "config4" and args.steps == 20 and args.warmup == 3:
+        args.steps, args.warmup = 3, 1                      # a step is the whole roadmap build
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # build once here: N ranks compiling into the same object directory at once would race (hipcc only; no GPU call)
+        importlib.import_module("interactive-rate-tendons_amd._lib").build()
+        sys.exit(spawn_ranks(args.gpus))
+
+    torch, dist, world, rank, local_rank, dev_index, rehearsal, use_dist = setup_ranks(args)
+    if args.workload == "config4":
+        return run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist)
 
     irt = importlib.import_module("interactive-rate-tendons_amd")
     W = irt.workloads

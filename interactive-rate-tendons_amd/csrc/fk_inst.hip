@@ -18,15 +18,19 @@
 namespace trk {
 
 #if TRK_INST_KIND == 4
-template <bool ROT, bool SPH>
+template <bool ROT, bool SPH, bool SIG>
 static void go(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);
-  hipLaunchKernelGGL((fk_verdict_retract<TRK_INST_N, ROT, SPH>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_poly,
+  hipLaunchKernelGGL((fk_verdict_retract<TRK_INST_N, ROT, SPH, SIG>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_poly,
                      a.d_tab, a.d_steps, a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.out.tips, va);
 }
-template <> void launch_fk_verdict_retract<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres) {
-  if (spheres) { if (a.rotation) go<true, true>(a, va, lds); else go<false, true>(a, va, lds); }
-  else         { if (a.rotation) go<true, false>(a, va, lds); else go<false, false>(a, va, lds); }
+template <bool SPH, bool SIG>
+static void go_rot(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
+  if (a.rotation) go<true, SPH, SIG>(a, va, lds); else go<false, SPH, SIG>(a, va, lds);
+}
+template <> void launch_fk_verdict_retract<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres, bool with_sig) {
+  if (spheres) { if (with_sig) go_rot<true, true>(a, va, lds); else go_rot<true, false>(a, va, lds); }
+  else         { if (with_sig) go_rot<false, true>(a, va, lds); else go_rot<false, false>(a, va, lds); }
 }
 template <bool ROT>
 static void go_list(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds, const int32_t *list, const uint32_t *count) {
@@ -39,15 +43,19 @@ template <> void launch_fk_sweep_retract_list<TRK_INST_N>(const FkLaunch &a, con
   if (a.rotation) go_list<true>(a, sweep, lds, list, count); else go_list<false>(a, sweep, lds, list, count);
 }
 #elif TRK_INST_KIND == 3
-template <bool ROT, bool SPH>
+template <bool ROT, bool SPH, bool SIG>
 static void go(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);
-  hipLaunchKernelGGL((fk_verdict<TRK_INST_N, ROT, SPH>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_tab, a.d_steps,
+  hipLaunchKernelGGL((fk_verdict<TRK_INST_N, ROT, SPH, SIG>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_tab, a.d_steps,
                      a.n_steps, a.out.tips, va);
 }
-template <> void launch_fk_verdict<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres) {
-  if (spheres) { if (a.rotation) go<true, true>(a, va, lds); else go<false, true>(a, va, lds); }
-  else         { if (a.rotation) go<true, false>(a, va, lds); else go<false, false>(a, va, lds); }
+template <bool SPH, bool SIG>
+static void go_rot(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
+  if (a.rotation) go<true, SPH, SIG>(a, va, lds); else go<false, SPH, SIG>(a, va, lds);
+}
+template <> void launch_fk_verdict<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres, bool with_sig) {
+  if (spheres) { if (with_sig) go_rot<true, true>(a, va, lds); else go_rot<true, false>(a, va, lds); }
+  else         { if (with_sig) go_rot<false, true>(a, va, lds); else go_rot<false, false>(a, va, lds); }
 }
 #elif TRK_INST_KIND == 2
 template <bool ROT>

@@ -329,12 +329,13 @@ template <int N>
 struct FkLane {
   bool converged;
   double Li[N];
+  double tip[3];              // the last backbone point (after rotate_z)
 };
 
 struct NoPointHook {
   __device__ __forceinline__ void begin(bool) const {}
   __device__ __forceinline__ void operator()(int, double, double, double) const {}
-  __device__ __forceinline__ void tip_point(int, bool, bool, double, double, double) const {}   // retraction kernel
+  __device__ __forceinline__ void tip_point(int, bool, bool, double, double, double, bool = true) const {}   // retraction kernel
 };
 
 // on_point(j, x, y, z): called for every observed backbone point (after rotate_z), in order j = 0 .. P-1 -- the
@@ -474,6 +475,9 @@ __device__ __forceinline__ void fk_uniform_body(
     lane_out->converged = conv;
 #pragma unroll
     for (int j = 0; j < N; j++) lane_out->Li[j] = Li[j];
+    double x = p[0], y = p[1], z = p[2];
+    if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
+    lane_out->tip[0] = x; lane_out->tip[1] = y; lane_out->tip[2] = z;
   }
 }
 

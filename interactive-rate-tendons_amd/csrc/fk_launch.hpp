@@ -28,18 +28,19 @@ template <int N> void launch_fk_sweep_fused(const FkLaunch &a, const FusedSweepA
 template <int N> void launch_fk_sweep_fused_list(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds, const int32_t *list,
                                                  const uint32_t *count);
 // verdict-only kernel (verdict_kernel.hpp): no point storage; `va` is a device pointer, `lds` its dynamic LDS bytes
-template <int N> void launch_fk_verdict(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres);
+// (with_sig: the launch writes cell signatures, va->sig != null; lds then includes the signature tile)
+template <int N> void launch_fk_verdict(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres, bool with_sig);
 template <int N> void launch_fk_retract(const FkLaunch &a);
 // the verdict-only kernel and its fallback pass for retraction-enabled robots (verdict_kernel.hpp, TRK_WITH_RETRACT_VERDICT)
-template <int N> void launch_fk_verdict_retract(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres);
+template <int N> void launch_fk_verdict_retract(const FkLaunch &a, const VerdictArgs *va, size_t lds, bool spheres, bool with_sig);
 template <int N> void launch_fk_sweep_retract_list(const FkLaunch &a, const FusedSweepArgs *sweep, size_t lds, const int32_t *list,
                                                    const uint32_t *count);
 
 #define TRK_DECL_FK(N) template <> void launch_fk_uniform<N>(const FkLaunch &); template <> void launch_fk_retract<N>(const FkLaunch &); \
   template <> void launch_fk_sweep_fused<N>(const FkLaunch &, const FusedSweepArgs *, size_t); \
   template <> void launch_fk_sweep_fused_list<N>(const FkLaunch &, const FusedSweepArgs *, size_t, const int32_t *, const uint32_t *); \
-  template <> void launch_fk_verdict<N>(const FkLaunch &, const VerdictArgs *, size_t, bool); \
-  template <> void launch_fk_verdict_retract<N>(const FkLaunch &, const VerdictArgs *, size_t, bool); \
+  template <> void launch_fk_verdict<N>(const FkLaunch &, const VerdictArgs *, size_t, bool, bool); \
+  template <> void launch_fk_verdict_retract<N>(const FkLaunch &, const VerdictArgs *, size_t, bool, bool); \
   template <> void launch_fk_sweep_retract_list<N>(const FkLaunch &, const FusedSweepArgs *, size_t, const int32_t *, const uint32_t *);
 TRK_DECL_FK(1) TRK_DECL_FK(2) TRK_DECL_FK(3) TRK_DECL_FK(4) TRK_DECL_FK(5) TRK_DECL_FK(6) TRK_DECL_FK(7) TRK_DECL_FK(8)
 #undef TRK_DECL_FK

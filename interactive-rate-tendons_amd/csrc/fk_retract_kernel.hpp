@@ -185,11 +185,11 @@ __device__ __forceinline__ void fk_retract_body(
   on_point.begin(conv && live);
   // `row` may differ from lane to lane (the lane's first two points) or be wave-uniform (the tip-aligned loop); `on`: the
   // lane has a point here.  The hook runs for the whole wave (it holds ballots and workgroup barriers).
-  auto store_point = [&](int row, bool on, bool is_first) {
+  auto store_point = [&](int row, bool on, bool is_first, bool wave_row = false) {
     double x = p[0], y = p[1], z = p[2];
     // rotate_z (tendon/TendonResult.cpp:13-18); explicit FMAs so that every kernel holding this body forms the same bits
     if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
-    on_point.tip_point(row, on, is_first, x, y, z);
+    on_point.tip_point(row, on, is_first, x, y, z, wave_row);
     if (!(on && live)) return;
     const int64_t o = (int64_t)row * ld + i;
     if (out.px) { out.px[o] = x; out.py[o] = y; out.pz[o] = z; }
@@ -227,7 +227,13 @@ __device__ __forceinline__ void fk_retract_body(
   }
 
   // tip-aligned: step k of the shared grid ends at its point steps[k].obs = the lane's point obs - shift
-  for (int k = (k_begin > k_first ? k_begin : k_first); k < nsteps; k++) {
+  // (k_begin reaches this function through a pointer that was itself loaded from memory -- a flat pointer, whose loads the
+  // compiler must treat as lane-dependent.  Left like that, the loop counter lived in a VGPR, the loop ran under an exec mask
+  // and every step's three routing-table rows were fetched with per-lane vector loads into ~108 VGPRs, spilling the
+  // integrator's state around them: 470 - 550 B of scratch per lane, whose write-backs showed up as 1 - 4 KB of HBM
+  // traffic per check (profiles/r03/traffic_split_v1.json).  It IS wave-uniform: say so.)
+  const int k_start = __builtin_amdgcn_readfirstlane(k_begin > k_first ? k_begin : k_first);
+  for (int k = k_start; k < nsteps; k++) {
     const int obs = steps[k].obs;
     const int ipt = obs - shift;
     const bool act = !single && ipt >= 2;
@@ -287,7 +293,7 @@ __device__ __forceinline__ void fk_retract_body(
 #pragma unroll
       for (int q = 0; q < 3; q++) { v[q] = av[q]; u[q] = au[q]; }
     }
-    store_point(obs, act, false);
+    store_point(obs, act, false, true);
   }
 
   // home-shape tendon lengths: home_shape clamps s_start into [0, L] (TendonRobot.cpp:257-258); composite

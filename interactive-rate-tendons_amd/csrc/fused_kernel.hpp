@@ -30,13 +30,10 @@ __global__ __launch_bounds__(64, (N <= TRK_FUSED_TWO_WAVE_MAXN ? 2 : 1)) void fk
     const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, FkOut out, const FusedSweepArgs *__restrict__ sa) {
   // (the verdict paths never ask for the backbone length)  Edge samples also get their cell signatures, point by point
-  SignatureHook hook{sa, nullptr};
-  {
-    uint32_t *sig = sa->sig;
-    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-    if (sig && i < n) hook.row = sig + i * sa->sig_stride;
-  }
+  SignatureHook hook{sa, n, sa->sig != nullptr, {}};
+  hook.st.init();
   fk_uniform_body<N, ROT, false, false>(states, n, ld, K, tab, steps, nsteps, out, hook);
+  hook.finish();
   __syncthreads();
   const FusedSweepArgs a = *sa;
   sweep_body<false>(a.in, n, ld, a.P, a.CH, a.NM, K, a.g, a.grid, a.near_grid, a.check_voxels, a.debug, a.valid_bits, a.flags);

@@ -279,18 +279,71 @@ __device__ __forceinline__ uint32_t cell_signature(double x, double y, double z,
   return (cx & 1023u) | ((cy & 1023u) << 10) | ((cz & 1023u) << 20);
 }
 
-// fk_uniform_body's point hook of the stored-point fused kernel: writes the signature of every observed point when the
-// launch asks for them (edge samples).  The arguments are re-read per point through an index the optimiser cannot
-// hoist (as in verdict_kernel.hpp), so they hold no SGPRs across the RK4 loop.
+// How the signature rows leave the FK kernels.  The rows are sample-major ([sample][sig_stride]: edge_filter reads one pair
+// of rows with the whole wave), but a wave produces ONE point of 64 different samples at a time: stored as they come, every
+// 4-byte word opened a 32/64-byte write of its own (measured r03: 4.9 KB written per edge sample for a 516-byte row,
+// profiles/r03/traffic_split_v1.json).  So a wave collects SIG_T consecutive points of its 64 samples in an LDS tile
+// ([SIG_T][SIG_LDS_STRIDE] words, written lane-contiguous, conflict-free) and flushes it transposed: one store instruction =
+// 8 rows x 32 contiguous, 32-byte-aligned bytes (rows are 64-byte aligned: sig_stride is a multiple of 16).
+// `W(i)` gives the i-th 32-bit word of the wave's tile in LDS (a lambda over the kernel's own __shared__ symbol, so the
+// accesses stay ds_read / ds_write).  row_of: the sample whose row this lane's points belong to (-1: none); first_row: the
+// first point index this lane contributes through the tile (0, or a retraction robot's third point: its first two arrive in
+// rows of their own and are stored directly).  cur / mask are wave-uniform.
+constexpr int SIG_T = 8, SIG_LDS_STRIDE = 72, SIG_LDS_WORDS = SIG_T * SIG_LDS_STRIDE;
+struct SigStage {
+  int cur, mask;                 // wave-uniform: the tile being filled (point index / SIG_T, -1 = none), which of its words are in
+  __device__ __forceinline__ void init() { cur = -1; mask = 0; }
+  // row_of: the sample whose row this lane's points belong to (-1: none); first_row: the first point index this lane
+  // contributes through the tile
+  template <class Word>
+  __device__ __forceinline__ void flush(Word &&W, uint32_t *__restrict__ sig, int64_t stride, int row_of, int first_row) {
+    if (cur < 0) return;
+    __syncthreads();                                   // one wave per workgroup: orders the tile's writes before the reads below
+    const int lane = threadIdx.x, w = lane & (SIG_T - 1), sub = lane >> 3;
+    const int j = cur * SIG_T + w;
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int r = it * 8 + sub;                      // the lane whose sample's row this store serves
+      const int ro = __shfl(row_of, r, 64), fr = __shfl(first_row, r, 64);
+      const uint32_t v = W(w * SIG_LDS_STRIDE + r);
+      if (((mask >> w) & 1) && ro >= 0 && j >= fr) sig[(int64_t)ro * stride + j] = v;
+    }
+    __syncthreads();
+    cur = -1; mask = 0;
+  }
+  // point `row` (wave-uniform) of every lane that has one (`on`)
+  template <class Word>
+  __device__ __forceinline__ void put(Word &&W, uint32_t *__restrict__ sig, int64_t stride, int row_of, int first_row, int row, bool on,
+                                      uint32_t value) {
+    const int tile = row >> 3;
+    if (tile != cur) { flush(W, sig, stride, row_of, first_row); cur = tile; }
+    if (on) W((row & (SIG_T - 1)) * SIG_LDS_STRIDE + (int)threadIdx.x) = value;
+    mask |= 1 << (row & (SIG_T - 1));
+  }
+};
+
+// fk_uniform_body's point hook of the stored-point fused kernel: collects the signature of every observed point when the
+// launch asks for them (edge samples); the tile sits at the start of the sweep's LDS image, which nothing else uses before
+// sweep_body starts.  The arguments are re-read per point through an index the optimiser cannot hoist (as in
+// verdict_kernel.hpp), so they hold no SGPRs across the RK4 loop.
 struct SignatureHook {
   const FusedSweepArgs *sa;
-  uint32_t *row;                 // this lane's signature row, or null
+  int64_t n;                     // configurations of the launch
+  bool any;                      // wave-uniform: this launch wants signatures
+  SigStage st;
+  __device__ __forceinline__ static uint32_t &word(int i) { extern __shared__ float lds[]; return ((uint32_t *)lds)[i]; }
+  __device__ __forceinline__ int row_of() const { const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; return i < n ? (int)i : -1; }
   __device__ __forceinline__ void begin(bool) const {}
-  __device__ __forceinline__ void operator()(int j, double x, double y, double z) const {
-    if (!row) return;
+  __device__ __forceinline__ void operator()(int j, double x, double y, double z) {
+    if (!any) return;
     int zero = 0;
     asm volatile("" : "+s"(zero));
-    row[j] = cell_signature(x, y, z, sa[zero].g);
+    const FusedSweepArgs &a = sa[zero];
+    st.put([](int i) -> uint32_t & { return word(i); }, a.sig, a.sig_stride, row_of(), 0, j, true, cell_signature(x, y, z, a.g));
+  }
+  __device__ __forceinline__ void finish() {
+    if (!any) return;
+    st.flush([](int i) -> uint32_t & { return word(i); }, sa->sig, sa->sig_stride, row_of(), 0);
   }
 };
 

@@ -477,6 +477,7 @@ int fused_args_slot(tr_ctx *ctx, const trk::SweepIn &in, int check_voxels, uint6
   a = trk::FusedSweepArgs{};
   a.in = in;
   sweep_geometry(ctx, a.CH, a.NM, *lds);
+  if (sig) *lds = std::max(*lds, (size_t)trk::SIG_LDS_WORDS * 4);       // the signature tile shares the sweep's image (sweep_kernel.hpp: SigStage)
   a.P = ctx->K.n_points; a.check_voxels = check_voxels; a.debug = ctx->debug;
   a.g = ctx->G; a.grid = ctx->d_grid; a.near_grid = ctx->d_near; a.valid_bits = d_bits; a.flags = d_flags;
   a.sig = sig; a.sig_stride = sig_stride;
@@ -597,12 +598,12 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
                         ret ? w.homeLi + fcol : nullptr};
   const trk::FkLaunch fl{d_states, cap, w.ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                          (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, fout, s};
-  const size_t lds_v = trk::verdict_lds_bytes(a.NM);
+  const size_t lds_v = trk::verdict_lds_bytes(a.NM, sig != nullptr);
   {
     ProfScope ps(ctx, 5, s);
     switch (ctx->K.n_tendons) {
-#define TRK_CASE(N) case N: if (ret) trk::launch_fk_verdict_retract<N>(vl, vr.d_slots + vslot, lds_v, spheres); \
-                            else trk::launch_fk_verdict<N>(vl, vr.d_slots + vslot, lds_v, spheres); break;
+#define TRK_CASE(N) case N: if (ret) trk::launch_fk_verdict_retract<N>(vl, vr.d_slots + vslot, lds_v, spheres, sig != nullptr); \
+                            else trk::launch_fk_verdict<N>(vl, vr.d_slots + vslot, lds_v, spheres, sig != nullptr); break;
       TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
       default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");

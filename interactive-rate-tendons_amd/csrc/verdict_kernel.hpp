@@ -65,7 +65,11 @@ constexpr int VL_QE = 3 * 64;
 constexpr int VL_W0 = 2 * (VL_QE + 6 * VQ);
 constexpr int VL_QOWNER = VL_W0, VL_CELL = VL_QOWNER + VQ, VL_INPREV = VL_CELL + 3 * 64, VL_HIT = VL_INPREV + 64,
               VL_DIST = VL_HIT + 64, VL_DELTA = VL_DIST + 64, VL_MS = VL_DELTA + 64;
-__host__ __device__ inline size_t verdict_lds_bytes(int NM) { return (size_t)VL_MS * 4 + (size_t)4 * NM * 64 * sizeof(float); }
+// with signatures (edge samples) the tile of SigStage (sweep_kernel.hpp) follows the milestones: 18 176 + 2 304 B = exactly
+// 20 KiB per wave at NM = 8, eight waves per CU still fit the 160 KiB
+__host__ __device__ inline size_t verdict_lds_bytes(int NM, bool with_sig = false) {
+  return (size_t)VL_MS * 4 + (size_t)4 * NM * 64 * sizeof(float) + (with_sig ? (size_t)SIG_LDS_WORDS * 4 : 0);
+}
 
 // (plain accesses: hipcc does not move `volatile` ones into the LDS address space; the compiler barriers at both ends of
 // the per-point code keep it from promoting this state to registers across the RK4 loop)
@@ -76,7 +80,9 @@ __host__ __device__ inline size_t verdict_lds_bytes(int NM) { return (size_t)VL_
 #define VL_BARRIER() asm volatile("" ::: "memory")
 
 // The per-point sweep: what sweep_body's pass 1 does with a stored point, done when the point is produced.
-template <bool SPH>
+// SIG: the launch also writes the samples' cell signatures (edge samples); a compile-time switch so that the plain
+// verdict kernels carry none of it.
+template <bool SPH, bool SIG = false>
 struct PointSweep {
   const VerdictArgs *va;
   uint64_t near_prev;             // dilated-grid word of the previous point's block (requested one point ahead)
@@ -84,8 +90,28 @@ struct PointSweep {
   uint32_t sph_state;             // SPH: bit 0 = the previous point awaits its classification, bit 1 = it lies inside the closed domain
   int qhead, qcount;              // wave-uniform
   int P, CH, NM, Kl, ms_next, ms_k;   // wave-uniform: point count, milestone spacing / count, last milestone, next milestone row / index
-  uint32_t *sig_row;              // this lane's signature row (edge samples), or null
+  SigStage sigst;                 // ... through this LDS tile (words [VL_MS + 4 NM 64, + SIG_LDS_WORDS) of the wave's image)
+  // the sample whose row this lane writes (-1: none) and its first point that goes through the tile: lane-private for the
+  // retraction kernel (a permuted batch, the first two points in rows of the lane's own); the shared-grid kernel forms them
+  // from sig_n on the fly
+  int sig_row_of, sig_first_row;
+  int64_t sig_n;                  // wave-uniform: configurations of the launch (shared-grid kernel)
   bool active;                    // live && converged: only these lanes test voxels
+
+  __device__ __forceinline__ int sig_own_row() const { const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; return i < sig_n ? (int)i : -1; }
+  __device__ __forceinline__ void sig_put(const VerdictArgs &a, int row, bool on, uint32_t value, int row_of, int first_row) {
+    const int base = VL_MS + 4 * NM * 64;
+    sigst.put([base](int i) -> uint32_t & { return VL_U(base + i); }, a.sig, a.sig_stride, row_of, first_row, row, on, value);
+  }
+  template <bool RETRACT>
+  __device__ __forceinline__ void sig_finish() {
+    if constexpr (SIG) {
+      const VerdictArgs &a = args();
+      const int base = VL_MS + 4 * NM * 64;
+      sigst.flush([base](int i) -> uint32_t & { return VL_U(base + i); }, a.sig, a.sig_stride, RETRACT ? sig_row_of : sig_own_row(),
+                  RETRACT ? sig_first_row : 0);
+    }
+  }
 
   __device__ __forceinline__ void begin(bool on) { active = on; }
 
@@ -230,7 +256,7 @@ struct PointSweep {
       if (j == ms_next) { ms_next += CH; ms_k++; }
     }
     VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
-    if (sig_row) sig_row[j] = cell_signature(x, y, z, g);
+    if constexpr (SIG) sig_put(a, j, true, cell_signature(x, y, z, g), sig_own_row(), 0);
     bool need = false;
     V3 pr = pv, qr = q;
     if constexpr (SPH) {
@@ -301,7 +327,7 @@ struct PointSweep {
   // lane's base point closes the list in slot ceil((P - 1 - row) / CH), and the arc positions are stored negated, so they
   // still grow with the slot index.  milestones_unresolved only looks at spans between slots, chord lengths and arc
   // differences, none of which depends on the direction the backbone is traversed in.
-  __device__ __forceinline__ void tip_point(int row, bool on, bool first, double x, double y, double z) {
+  __device__ __forceinline__ void tip_point(int row, bool on, bool first, double x, double y, double z, bool wave_row = true) {
 #pragma clang fp contract(off)
     VL_BARRIER();
     const VerdictArgs &a = args();
@@ -311,6 +337,17 @@ struct PointSweep {
     V3 pv = q;
     bool need = false;
     V3 pr = pv, qr = q;
+    if constexpr (SIG) {
+      // signatures sit in tip-aligned rows like the rows of K1r's stored points.  A lane's first two points come in rows of
+      // its own (wave_row false): stored directly, two words per lane; from its third point on the row is the wave's and
+      // the words go through the tile (SigStage::first_row = the lane's base row + 2 keeps stale tile words of earlier rows
+      // from reaching this lane's row)
+      const uint32_t sg = on ? cell_signature(x, y, z, g) : 0u;
+      if (!wave_row) {
+        if (on && sig_row_of >= 0) a.sig[(int64_t)sig_row_of * a.sig_stride + row] = sg;
+        if (first) sig_first_row = row + 2;
+      } else sig_put(a, row, on, sg, sig_row_of, sig_first_row);
+    }
     if (on) {
       float d = 0.0f;
       if (!first) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(VL_DIST + lane); }
@@ -333,7 +370,6 @@ struct PointSweep {
         }
       }
       VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
-      if (sig_row) sig_row[row] = cell_signature(x, y, z, g);        // tip-aligned like the rows of K1r's stored points
       if constexpr (SPH) {
         if (active && !VL_U(VL_HIT + lane)) {
           if (sph_state & 1u) {
@@ -400,32 +436,47 @@ struct PointSweep {
 #ifndef TRK_VERDICT_TWO_WAVE_MAXN
 #define TRK_VERDICT_TWO_WAVE_MAXN 4
 #endif
-template <int N, bool ROT, bool SPH>
+template <int N, bool ROT, bool SPH, bool SIG = false>
 __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
     const double *__restrict__ states, int64_t n, RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps,
     int nsteps, double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
   const int lane = threadIdx.x;
-  PointSweep<SPH> ps;
+  PointSweep<SPH, SIG> ps;
   ps.va = va;
   ps.dn_prev = 0.0f; ps.sph_state = 0u;
   ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
   VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
   {
-    uint32_t *sig = va->sig;
     const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
-    ps.sig_row = (sig && i0 < n) ? sig + i0 * va->sig_stride : nullptr;
+    ps.sigst.init(); ps.sig_row_of = -1; ps.sig_first_row = 0; ps.sig_n = n;
   }
   __syncthreads();
 
   FkLane<N> fl_;
-  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tips, nullptr, nullptr, nullptr};
+  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   fk_uniform_body<N, ROT, false, false>(states, n, 0, K, tab, steps, nsteps, out, ps, nullptr, &fl_);
 
   // ---- what sweep_body does after its pass 1 (comparisons and one subtraction: nothing here can contract) ----
+  ps.template sig_finish<false>();
   ps.finish();
   while (ps.qcount > 0) ps.flush();
   __syncthreads();
+  if (tips) {
+    // the wave's 64 tips are 1 536 contiguous bytes: through LDS (the previous-point slots, free now) so that each of the
+    // three store instructions writes 512 contiguous bytes -- lane by lane (x, y, z at a stride of 24 bytes) every
+    // instruction touched every 32-byte sector of the block and the block was written three times over (measured: 70 B per
+    // check against the 24 the tips are)
+    VL_D(lane) = fl_.tip[0]; VL_D(64 + lane) = fl_.tip[1]; VL_D(128 + lane) = fl_.tip[2];
+    __syncthreads();
+    const int64_t e0 = (int64_t)blockIdx.x * 192, etot = 3 * n;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int e = q * 64 + lane;                 // element e of the block = coordinate e % 3 of configuration e / 3
+      if (e0 + e < etot) tips[e0 + e] = VL_D((e % 3) * 64 + e / 3);
+    }
+    __syncthreads();
+  }
   const VerdictArgs a = *va;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const bool live = i < n;
@@ -483,22 +534,21 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
 // The same for retraction-enabled robots: K1r's body (fk_retract_kernel.hpp: per-lane arc-length grid, tip-aligned
 // iterations) with the sweep in its point hook (PointSweep::tip_point).  What differs after the loop is per lane: the
 // number of points, the last milestone slot and the home-shape tendon lengths.
-template <int N, bool ROT, bool SPH>
+template <int N, bool ROT, bool SPH, bool SIG = false>
 __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict_retract(
     const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
     double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
   const int lane = threadIdx.x;
-  PointSweep<SPH> ps;
+  PointSweep<SPH, SIG> ps;
   ps.va = va;
   ps.dn_prev = 0.0f; ps.sph_state = 0u;
   ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = 0; ps.ms_next = 0; ps.ms_k = 0;
   const int32_t *__restrict__ perm = va->perm;
   {
-    uint32_t *sig = va->sig;
     const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
-    ps.sig_row = (sig && i0 < n) ? sig + (perm ? (int64_t)perm[i0] : i0) * va->sig_stride : nullptr;
+    ps.sigst.init(); ps.sig_row_of = i0 < n ? (perm ? perm[i0] : (int)i0) : -1; ps.sig_first_row = 0; ps.sig_n = n;
   }
   VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
   __syncthreads();
@@ -508,6 +558,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
   const int32_t *__restrict__ wkb = va->wave_k_begin;
   fk_retract_body<N, ROT, false>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, ps, perm, &fl_, wkb ? wkb[blockIdx.x] : 0);
 
+  ps.template sig_finish<true>();
   ps.finish();
   while (ps.qcount > 0) ps.flush();
   __syncthreads();

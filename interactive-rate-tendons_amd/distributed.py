@@ -85,6 +85,11 @@ def allgather_mask(local_words, group=None):
     if not (dist.is_available() and dist.is_initialized()):
         return local_words.clone()
     world = dist.get_world_size(group)
+    if local_words.is_cuda and dist.get_backend(group) == "gloo":
+        # rehearsal only (several ranks sharing one GPU, bench.py TENDON_BENCH_SHARED_GPU=1): gloo gathers through host memory
+        out = torch.empty(world * local_words.numel(), dtype=local_words.dtype)
+        dist.all_gather_into_tensor(out, local_words.cpu().contiguous(), group=group)
+        return out.to(local_words.device)
     out = torch.empty(world * local_words.numel(), dtype=local_words.dtype, device=local_words.device)
     dist.all_gather_into_tensor(out, local_words.contiguous(), group=group)
     return out

@@ -23,7 +23,7 @@ def key_of(name):
     """'void trk::fk_verdict<3, false>(...)' -> 'fk_verdict<3>'; rocPRIM kernels -> 'cache merge (rocPRIM sort + reduce)'."""
     if "rocprim" in name:
         return "cache merge (rocPRIM sort + reduce)"
-    m = re.search(r"trk::fk_verdict<(\d+), (?:true|false), true>", name)
+    m = re.search(r"trk::fk_verdict<(\d+), (?:true|false), true[,>]", name)
     if m:
         return "fk_verdict<%s> spheres" % m.group(1)              # the sphere-swept checker's variant (SPH = true)
     m = re.search(r"trk::([A-Za-z0-9_]+)(?:<(\d+))?", name)

@@ -119,3 +119,24 @@ def test_bench_gpus2_from_a_bare_command_shared_gpu():
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak" and out["config"]["rehearsal_shared_gpu"] is True
+
+
+def test_config4_workload_world1_rccl_and_world2_rehearsal_agree():
+    """`bench.py --workload config4`: the PRM build with vertices, neighbour rows and edges sharded over the ranks.  World
+    size 1 runs the RCCL form (device-tensor all-gathers); world size 2 rehearses the N > 1 control flow with both ranks on
+    cuda:0 (gloo).  The gathered vertex mask, the vertex count, the edge list and the verdict count must be the same for both
+    world sizes ("gathered mask identical for G = 1, 2, 4, 8")."""
+    common = ["--workload", "config4", "--config4-log2", "15", "--config4-k", "6", "--steps", "1", "--warmup", "1"]
+    one = _bench(["--gpus", "1"] + common, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    assert one["n_gpus"] == 1 and one["config"]["collective"] == "rccl" and one["config"]["ranks_seen"] == 1
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + common,
+                       env=dict(env, TENDON_BENCH_SHARED_GPU="1"), capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stderr[-3000:]
+    two = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert two["n_gpus"] == 2 and two["config"]["ranks_seen"] == 2 and two["scaling"] == "strong"
+    for key in ("candidates", "valid_vertices", "candidate_edges", "valid_edges", "vertex_mask_crc32", "edge_list_crc32"):
+        assert one["config"][key] == two["config"][key], key
+    assert 0 < one["config"]["valid_vertices"] < 1 << 15 and 0 < one["config"]["valid_edges"] <= one["config"]["candidate_edges"]
+    assert set(two["config"]["collectives_alone"]) == {"vertex_mask", "knn_rows", "edge_mask"}
+    assert all(v > 0 for v in two["config"]["phases_ms"].values()) and two["value"] > 0
