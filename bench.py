@@ -41,6 +41,23 @@ def algorithmic_bytes_per_check(S, P, N):
     return k1, k2
 
 
+def algorithmic_flops_per_rk4_step(N):
+    """Hand count of one RK4 step of the RESTRUCTURED right-hand side (csrc/fk_kernel.hpp: strain_rates_routed + the stage
+    updates of fk_uniform_body), every +, -, x one flop, an FMA two, a reciprocal (square root) seed one plus its Newton step
+    as written -- independent of what the compiler emits, so that executing more instructions cannot raise the fraction:
+      per tendon and evaluation   128   (pd 10, |pd|^2 5, rsqrt + Newton 7, c / q / sdot 7, A 12 + 1, e / g 8, B 18, H 12,
+                                         Q / P 10, w 13, pd.w 5, a_i 12, b 8)
+      tendon-independent          272   (rhat / rhat^2 folds 5, K u / K (v - e3) 7, c 24, d 12, M11 5, its adjugate 18,
+                                         1 / det 10, M11^-1 6, y 15, T = B M11^-1 45, Schur complement 43, rhs 18, adjugate 18,
+                                         1 / det 10, u' 18, v' 18)
+      per stage                   78 + 2 N   (p quadrature 21, L_i 2 N, R' = R u^ 27, accumulators 30), + 30 stage state x 3
+      per step                    4 (128 N + 272 + 78 + 2 N) + 90 + 3
+    = 3 053 (N = 3), 3 573 (N = 4); the gfx950 ISA of the same source executes 3 089 / 3 621 (profiles/isa_counts.json).
+    DESIGN.md section 5 carries the derivation; SURVEY 8(d)'s 1.1 Mflop per check is the reference's formulation as written
+    (dense 3x3 products, two general inverses), which this kernel does not execute."""
+    return 4 * (128 * N + 272 + 78 + 2 * N) + 93
+
+
 def host_core_share(omp_max):
     """Host cores this process may actually use: the cgroup CPU quota when there is one (a GPU box grants a
     share of the host to each job; running 256 threads on a 16-core quota was 30 % SLOWER than 16), else the
@@ -463,6 +480,7 @@ def main():
         hbm = {"achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                "algorithmic_bytes_per_check": dom_bytes}
         valu = None
+        flops_alg = algorithmic_flops_per_rk4_step(N) * (P - 1)
         if flops_per_check:
             tf = flops_per_check * units_per_launch / (dom_ms * 1e-3) / 1e12
             valu = {"achieved": tf, "peak": FP64_VALU_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP64_VALU_PEAK_TF,
@@ -470,9 +488,14 @@ def main():
                     "flops_source": "profiles/isa_counts.json[%s]" % isa_key}
         # the roofline that binds the kernel is the one it sits closest to; the other is kept beside it
         if valu and valu["frac"] >= hbm["frac"]:
-            roofline = dict(bound="fp64_valu", kernel=dom_name, achieved=valu["achieved"], peak=valu["peak"], unit=valu["unit"],
-                            frac=valu["frac"], traffic=traffic, traffic_source=traffic_source, avg_launch_ms=dom_ms,
-                            flops_per_check=flops_per_check, flops_source=valu["flops_source"], hbm=hbm)
+            # `frac` prices the launch with the ALGORITHMIC flop count (hand count of the restructured right-hand side:
+            # algorithmic_flops_per_rk4_step); the executed count of the compiled kernel is kept beside it
+            tf_alg = flops_alg * units_per_launch / (dom_ms * 1e-3) / 1e12
+            roofline = dict(bound="fp64_valu", kernel=dom_name, achieved=tf_alg, peak=valu["peak"], unit=valu["unit"],
+                            frac=tf_alg / valu["peak"], traffic=traffic, traffic_source=traffic_source, avg_launch_ms=dom_ms,
+                            flops_per_check_algorithmic=flops_alg, flops_algorithmic_source="bench.py: algorithmic_flops_per_rk4_step (hand count, DESIGN.md section 5)",
+                            flops_per_check=flops_per_check, flops_source=valu["flops_source"],
+                            executed={"achieved": valu["achieved"], "frac": valu["frac"]}, hbm=hbm)
         else:
             roofline = dict(bound="hbm", kernel=dom_name, achieved=hbm["achieved"], peak=hbm["peak"], unit=hbm["unit"],
                             frac=hbm["frac"], traffic=traffic, traffic_source=traffic_source, avg_launch_ms=dom_ms,

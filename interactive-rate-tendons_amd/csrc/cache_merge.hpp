@@ -55,6 +55,28 @@ hipError_t knn_edge_list(MergeScratch &ms, const int32_t *d_idx, int64_t n, int 
 hipError_t sort_states_by_key(MergeScratch &ms, const double *d_states, int64_t n, int S, int key_col, double key_scale, double *d_sorted,
                               double *d_xs, int32_t *d_perm, double *d_keys_tmp, int32_t *d_perm_tmp, hipStream_t stream);
 
+// The neighbour search's cell grid (knn_kernel.hpp): two coordinates of the state, each scaled to a TERM of the compound metric
+// (a tension as it is, the retraction times its weight), so that |key difference| <= distance on either of them; C x B cells of
+// uniform width over the keys' ranges.  knn_cell_of is monotone non-decreasing in the key, so every candidate whose key lies in
+// [lo, hi] has its cell index in [cell(lo), cell(hi)]: the search visits exactly those cells.
+struct KnnCells {
+  int32_t col0, col1;           // state columns of the two keys (col1 = -1: one key only)
+  int32_t C, B;                 // cells along key 0 / key 1
+  double scale0, scale1;        // key = scale * state[col]
+  double lo0, inv0, lo1, inv1;  // cell = clamp((int)((key - lo) * inv), 0, cells - 1)
+};
+__host__ __device__ inline int knn_cell_of(double key, double lo, double inv, int cells) {
+  const double t = (key - lo) * inv;
+  int c = t > 0.0 ? (t < (double)cells ? (int)t : cells - 1) : 0;      // NaN -> 0
+  return c < cells - 1 ? c : cells - 1;
+}
+// d_sorted [n][S] = the states ordered by cell id (key-0 cell major), d_perm [n] the original index of each, d_cellstart [C B + 1]
+// the first sorted position of every cell.  g comes in with col / scale set; C, B (cells of about cell_width along each key's
+// range in the data, at most max_cells; 1 along a key without spread), lo and inv are filled in.  d_keys: two scratch arrays of
+// n uint32, d_perm_tmp n int32, d_cellstart max_cells^2 + 1 int32.  Synchronises `stream` once (the key ranges).
+hipError_t sort_states_by_cells(MergeScratch &ms, const double *d_states, int64_t n, int S, KnnCells &g, double cell_width, int max_cells, double *d_sorted,
+                                int32_t *d_perm, int32_t *d_cellstart, uint32_t *d_keys[2], int32_t *d_perm_tmp, hipStream_t stream);
+
 // Retraction-enabled robots: the order in which the verdict-only kernel takes a batch.  A wave of the retraction kernel runs
 // from its LONGEST backbone's base to the tip (tip-aligned iterations, fk_retract_kernel.hpp), shorter backbones idling
 // until their rows come up: with retractions ~ U[0, L] in arrival order every wave pays for a full-length backbone and half

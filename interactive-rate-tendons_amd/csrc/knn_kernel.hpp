@@ -5,17 +5,20 @@
 //   |d tau|_2  +  (extent / 4 pi) * arc(d theta)  +  (2 extent / L) * |d s_start|.
 // One lane per query vertex; the candidate index is wave-uniform, so candidates arrive through scalar
 // loads and feed the fp64 FMAs as SGPR operands; each lane keeps its k best in an LDS column (sorted
-// insertion; insertions become rare once the list has warmed up).  Exact, and no tree: the states are sorted by their
-// first coordinate (rocPRIM radix sort, cache_merge.hip) and a wave -- 64 queries that are neighbours in that order --
-// only visits the candidates whose first coordinate lies within its queries' search radius of theirs (every term of the
-// metric is non-negative, so |d tau_0| <= distance): the radius is the SEED, the k-th distance to the candidates nearest
-// in sorted order (a first, short pass).  At 10^5 uniform 4-D states that is ~1/6 of the candidates, at 10^6 ~1/12.
+// insertion; insertions become rare once the list has warmed up).  Exact, and no tree: the states are ordered by the cells
+// of a uniform 2-D grid over two key coordinates (one rocPRIM radix pass on the cell ids, cache_merge.hip:
+// sort_states_by_cells) and a wave -- 64 queries that are neighbours in that order, i.e. of one or two cells -- only visits
+// the cells its queries' search radii reach in BOTH keys (every term of the metric is non-negative, so |d key| <= distance on
+// each): the radius is the SEED, the k-th distance to the candidates nearest in sorted order (a first, short pass).
+// Round 2 windowed one sorted coordinate (~1/6 of the candidates at 10^5 uniform 4-D states, ~1/12 at 10^6); the second key
+// squares that.
 // Like nearestK on a structure that already holds v, the result includes v itself (distance 0), which connectVertices
 // then skips (:2848).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include "tr_types.hpp"
+#include "cache_merge.hpp"
 
 namespace trk {
 
@@ -37,12 +40,15 @@ constexpr int KNN_SMAX = TRK_MAX_TENDONS + 2;
 // test on the squared distance (rare once the list has warmed up).
 // NT tension dimensions and the presence of the rotation / retraction coordinates are compile-time: a chunk is then
 // straight-line code and its scalar loads are issued back to back.
-// cand / xs / perm: the states in sorted order, their sort keys (first tension, or w_ret s_start), and the original index of each.  qlist (optional):
+// cand / perm: the states in cell order and the original index of each; cg / cellstart: the grid and the first sorted position of
+// every cell.  qlist (optional):
 // sorted positions of the queries (ascending; null = every state is a query), nq of them; row_first: original index of
 // the first output row (tr_knn_range).  half_window > 0 marks the seeding pass: candidates = the half_window sorted
 // neighbours either side of the wave's queries, only the k-th distance is written (seed_out, indexed like qlist).
-template <int NT, bool ROT, bool RET>
-__global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ cand, const double *__restrict__ xs,
+// KCAP > 0: the list lives in REGISTERS (k <= KCAP entries; the rest are inert), an insertion is straight-line selects with no
+// LDS round trip; KCAP = 0: in the lane's LDS column, any k.
+template <int NT, bool ROT, bool RET, int KCAP = 0>
+__global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ cand, KnnCells cg, const int32_t *__restrict__ cellstart,
                                                      const int32_t *__restrict__ perm, const int32_t *__restrict__ qlist, int64_t nq,
                                                      int64_t n_cand, KnnMetric m, int k, double max_dist, int64_t half_window,
                                                      const double *__restrict__ seed, double *__restrict__ seed_out,
@@ -59,51 +65,42 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
   double x[KNN_SMAX];
 #pragma unroll
   for (int d = 0; d < KNN_SMAX; d++) x[d] = d < S ? cand[js * S + d] : 0.0;
-  for (int p = 0; p < k; p++) { bd[p * 64] = 1.0 / 0.0; bi[p * 64] = -1; }
+  constexpr int RC = KCAP > 0 ? KCAP : 1;
+  double rd[RC];
+  int32_t ri[RC];
+  if constexpr (KCAP > 0) {
+    // entries beyond k hold (-inf, 0): never the largest, never replaced
+#pragma unroll
+    for (int e = 0; e < KCAP; e++) { rd[e] = e < k ? 1.0 / 0.0 : -1.0 / 0.0; ri[e] = e < k ? -1 : 0; }
+  } else {
+    for (int p = 0; p < k; p++) { bd[p * 64] = 1.0 / 0.0; bi[p * 64] = -1; }
+  }
   // `worst`: a candidate enters the list when it sorts before this by (distance, index) -- the lane's current k-th entry,
   // or, while the list is not full, the SEED (any index): the k nearest of all candidates are at most that far, so a slice
   // starts by accepting exactly the candidates with distance <= seed instead of filling its list with whatever comes first
   // and shifting it ~k ln(slice / k) times (those insertions, not the distances, were 80 % of the kernel's time).
   constexpr int SS_KEY = NT + (ROT ? 1 : 0);                 // position of the retraction coordinate, when there is one
   double worst = 1.0 / 0.0;
-  if (seed) worst = seed[qc];
-  // ---- the wave's candidate range [j0, j1) in sorted order ----
-  int64_t j0, j1;
-  {
-    auto wave_min = [](double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64)); return v; };
-    auto wave_max = [](double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; };
-    int64_t lo, hi;
-    if (half_window > 0) {
-      const int64_t a = (int64_t)wave_min((double)js), b = (int64_t)wave_max((double)js);      // exact: positions < 2^53
-      lo = a - half_window; hi = b + 1 + half_window;
-      lo = lo < 0 ? 0 : lo; hi = hi > n_cand ? n_cand : hi;
-    } else {
-      // |key(x) - key(c)| <= distance(x, c) (the key is one term of the metric: the first tension, or w_ret s_start when
-      // the robot retracts): a candidate outside [key - r, key + r] cannot be among the k nearest when k candidates
-      // within r exist (the seed).  r is widened by a relative 1e-12: sqrt(fl(t0^2 + ...)) may round an ulp below |t0|.
-      double r = worst < max_dist ? worst : max_dist;
-      r = r + r * 1e-12;
-      const double xk = RET ? m.w_ret * x[SS_KEY] : x[0];      // the key the states were sorted by (tr_knn: sort_states_by_key)
-      const double xlo = wave_min(xk - r), xhi = wave_max(xk + r);
-      lo = 0; hi = n_cand;
-      if (xlo > -1.0 / 0.0 && xlo == xlo) {                       // lower bound: first candidate with xs >= xlo
-        int64_t a = 0, b = n_cand;
-        while (a < b) { const int64_t mid = (a + b) >> 1; if (xs[mid] < xlo) a = mid + 1; else b = mid; }
-        lo = a;
-      }
-      if (xhi < 1.0 / 0.0 && xhi == xhi) {                        // upper bound: first candidate with xs > xhi
-        int64_t a = lo, b = n_cand;
-        while (a < b) { const int64_t mid = (a + b) >> 1; if (xs[mid] <= xhi) a = mid + 1; else b = mid; }
-        hi = a;
-      }
-    }
-    lo = __builtin_amdgcn_readfirstlane((int)lo); hi = __builtin_amdgcn_readfirstlane((int)hi);     // wave-uniform by construction; n_cand < 2^31
-    const int64_t len = hi - lo, ny = gridDim.y;
-    const int64_t per = (len + ny - 1) / ny;
-    j0 = lo + (int64_t)blockIdx.y * per;
-    j1 = j0 + per < hi ? j0 + per : hi;
-    if (j0 > hi) j0 = hi;
-  }
+  if (seed) worst = seed[qc];                                  // (an optional upper bound of the k-th distance; the expanding search needs none)
+  int32_t worst_i = -1;                                        // original index of the list's largest entry (-1: the list is not full yet)
+  int wpos = 0;                                                // ... and its position: the entry the next accepted candidate replaces
+  // ---- the wave's candidates: an EXPANDING search over the cells of the 2-D grid ----
+  // The states are ordered by the cells of a uniform grid over two key coordinates, each a TERM of the metric -- the first two
+  // tensions, or the weighted retraction and the first tension -- so |key difference| <= distance on either: once a lane holds k
+  // candidates, nothing outside [key - worst, key + worst] in either key can improve its list.  The wave scans the cells its own
+  // queries lie in, then keeps growing that box of cells by one ring towards the window its lanes' CURRENT thresholds still ask
+  // for, until the box covers the window (thresholds only shrink, so the window only shrinks).  Near candidates come first:
+  // the thresholds are almost final after the first ring and few later candidates enter a list -- list insertions, not
+  // distances, were what the one-coordinate window of round 2 spent most of its time on (its seeding pass started from empty
+  // lists: 30 of 80 ms at 6 x 10^5 states).  r is widened by a relative 1e-12: sqrt(fl(t0^2 + ...)) may round an ulp below
+  // |t0|.  Cells are a monotone function of the key (cache_merge.hpp: knn_cell_of), so the cells of an interval's end points
+  // bracket the cells of everything inside it.
+  constexpr int K1 = RET ? 0 : (NT >= 2 ? 1 : -1);            // the second key's coordinate (none for a single tension)
+  const double k0 = RET ? m.w_ret * x[SS_KEY] : x[0];         // the products sort_states_by_cells formed (cg.scale x coordinate)
+  const double k1 = K1 >= 0 ? x[K1 >= 0 ? K1 : 0] : 0.0;
+  auto wave_min = [](double v) { for (int o = 32; o > 0; o >>= 1) v = fmin(v, __shfl_xor(v, o, 64)); return v; };
+  auto wave_max = [](double v) { for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o, 64)); return v; };
+  int64_t j1 = 0;                                             // end of the run being scanned (do_chunk masks a tail chunk against it)
   double gate2 = worst * worst * (1.0 + 4.5e-16);   // plain metric: squared distances above this cannot reach `worst`
   constexpr bool plain = !ROT && !RET;
   // Candidates are taken a chunk at a time: their scalar loads are issued together and the wave leaves the chunk at once
@@ -159,36 +156,105 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
         dist = sqrt(dist);
       }
       if (dist <= worst) {
-        // Sorted insertion by (distance, original index) without a data-dependent loop: entry e becomes its left
-        // neighbour when that one sorts after the candidate (shift), the candidate when the entry itself is the first one
-        // that does, else it stays.  Every entry is a function of two OLD entries, so the LDS reads do not wait for one
-        // another (the shifting while-loop paid a full LDS round trip per step: ~900 cycles per insertion against ~500
-        // for a chunk's distances).  Candidates arrive in sorted-coordinate order, so equal distances are ordered here by
-        // the original index -- the order of a stable sort of the query's distance row.  A candidate that ties with the
-        // k-th entry and has the larger index changes nothing.
+        // The list is kept UNSORTED with its largest entry tracked (value, original index, position): a candidate that sorts
+        // before that entry by (distance, original index) replaces it -- one LDS write pair at the lane's own position -- and
+        // the new largest entry is found by one pass over the k entries.  (Round 2 kept the list sorted and shifted it on
+        // every insertion: 4 k LDS operations and ~10 k VALU instructions per event, and with 64 lanes sharing the branch a
+        // wave runs an event whenever ANY lane inserts; the search was spending most of its time there: 9.5 ms at k = 2
+        // against 34 ms at k = 11 and 285 ms at k = 41 for 6 x 10^5 states.)  The list is sorted once, at the end.
+        // Equal distances are ordered by the original index -- the order of a stable sort of the query's distance row; empty
+        // entries (index < 0) sort last.
         const int32_t cj = perm[jb + u];
-        auto after = [&](double d, int32_t i) { return d > dist || (d == dist && (i > cj || i < 0)); };
-        double right = bd[(k - 1) * 64];
-        int32_t righti = bi[(k - 1) * 64];
-        for (int e = k - 1; e > 0; e--) {
-          const double left = bd[(e - 1) * 64];
-          const int32_t lefti = bi[(e - 1) * 64];
-          const bool shift = after(left, lefti), take = after(right, righti);
-          bd[e * 64] = shift ? left : (take ? dist : right);
-          bi[e * 64] = shift ? lefti : (take ? cj : righti);
-          right = left; righti = lefti;
+        if (dist < worst || worst_i < 0 || cj < worst_i) {
+          double md;
+          int32_t mi;
+          int mp = 0;
+          if constexpr (KCAP > 0) {
+#pragma unroll
+            for (int e = 0; e < KCAP; e++) { const bool hit = e == wpos; rd[e] = hit ? dist : rd[e]; ri[e] = hit ? cj : ri[e]; }
+            md = rd[0]; mi = ri[0];
+#pragma unroll
+            for (int e = 1; e < KCAP; e++) {
+              const double d = rd[e];
+              const int32_t i = ri[e];
+              const bool later = mi >= 0 && (i < 0 || d > md || (d == md && i > mi));     // entry e sorts after the largest so far
+              md = later ? d : md; mi = later ? i : mi; mp = later ? e : mp;
+            }
+          } else {
+            bd[wpos * 64] = dist; bi[wpos * 64] = cj;
+            md = bd[0]; mi = bi[0];
+            for (int e = 1; e < k; e++) {
+              const double d = bd[e * 64];
+              const int32_t i = bi[e * 64];
+              const bool later = mi >= 0 && (i < 0 || d > md || (d == md && i > mi));
+              md = later ? d : md; mi = later ? i : mi; mp = later ? e : mp;
+            }
+          }
+          worst_i = mi; wpos = mp;
+          if (mi >= 0) worst = md;                    // (an unfilled list keeps its threshold: infinity, or the seed)
         }
-        if (after(right, righti)) { bd[0] = dist; bi[0] = cj; }
-        const double kth = bd[(k - 1) * 64];
-        if (kth < worst) worst = kth;               // (an unfilled list keeps the seed as its threshold)
         // sqrt(s2) <= worst needs s2 <= worst^2 (1 + 2^-51): beyond that the correctly rounded root is > worst
         gate2 = worst * worst * (1.0 + 4.5e-16);
       }
     }
   };
-  int64_t jb = j0;
-  for (; jb + CH <= j1; jb += CH) do_chunk(std::true_type{}, jb);
-  if (jb < j1) do_chunk(std::false_type{}, jb);
+  // a run [a, b) of sorted positions
+  auto scan = [&](int64_t a, int64_t b) {
+    int64_t jb = a;
+    j1 = b;
+    for (; jb + CH <= j1; jb += CH) do_chunk(std::true_type{}, jb);
+    if (jb < j1) do_chunk(std::false_type{}, jb);
+  };
+  // rows [y0, y1] of column cx: consecutive in sorted order
+  auto scan_cells = [&](int cx, int y0, int y1) {
+    if (y0 <= y1) scan((int64_t)cellstart[cx * cg.B + y0], (int64_t)cellstart[cx * cg.B + y1 + 1]);
+  };
+  {
+    // the box of cells the wave's own queries lie in (NaN keys: cell 0)
+    const double q0lo = wave_min(k0), q0hi = wave_max(k0), q1lo = wave_min(k1), q1hi = wave_max(k1);
+    int sx0 = __builtin_amdgcn_readfirstlane(knn_cell_of(q0lo, cg.lo0, cg.inv0, cg.C)), sx1 = __builtin_amdgcn_readfirstlane(knn_cell_of(q0hi, cg.lo0, cg.inv0, cg.C));
+    int sy0 = __builtin_amdgcn_readfirstlane(knn_cell_of(q1lo, cg.lo1, cg.inv1, cg.B)), sy1 = __builtin_amdgcn_readfirstlane(knn_cell_of(q1hi, cg.lo1, cg.inv1, cg.B));
+    if (sx1 < sx0) sx1 = sx0;
+    if (sy1 < sy0) sy1 = sy0;
+    for (int cx = sx0; cx <= sx1; cx++) scan_cells(cx, sy0, sy1);
+    for (;;) {
+      // the window the lanes' thresholds still ask for (an unfilled list: everything)
+      double r = worst < max_dist ? worst : max_dist;
+      r = r + r * 1e-12;
+      const int nx0 = __builtin_amdgcn_readfirstlane(knn_cell_of(wave_min(k0 - r), cg.lo0, cg.inv0, cg.C));
+      const int nx1 = __builtin_amdgcn_readfirstlane(knn_cell_of(wave_max(k0 + r), cg.lo0, cg.inv0, cg.C));
+      const int ny0 = __builtin_amdgcn_readfirstlane(knn_cell_of(wave_min(k1 - r), cg.lo1, cg.inv1, cg.B));
+      const int ny1 = __builtin_amdgcn_readfirstlane(knn_cell_of(wave_max(k1 + r), cg.lo1, cg.inv1, cg.B));
+      if (nx0 >= sx0 && nx1 <= sx1 && ny0 >= sy0 && ny1 <= sy1) break;
+      // one ring towards it: new rows of the old columns first, then the new columns over all rows of the grown box
+      const int tx0 = nx0 < sx0 ? sx0 - 1 : sx0, tx1 = nx1 > sx1 ? sx1 + 1 : sx1;
+      const int ty0 = ny0 < sy0 ? sy0 - 1 : sy0, ty1 = ny1 > sy1 ? sy1 + 1 : sy1;
+      for (int cx = sx0; cx <= sx1; cx++) { scan_cells(cx, ty0, sy0 - 1); scan_cells(cx, sy1 + 1, ty1); }
+      if (tx0 < sx0) scan_cells(tx0, ty0, ty1);
+      if (tx1 > sx1) scan_cells(tx1, ty0, ty1);
+      sx0 = tx0; sx1 = tx1; sy0 = ty0; sy1 = ty1;
+    }
+  }
+  if constexpr (KCAP > 0) {
+#pragma unroll
+    for (int e = 0; e < KCAP; e++) if (e < k) { bd[e * 64] = rd[e]; bi[e * 64] = ri[e]; }
+  }
+  // order the list by (distance, original index), empty entries last: a selection sort over the lane's LDS column, once
+  for (int p = 0; p + 1 < k; p++) {
+    double md = bd[p * 64];
+    int32_t mi = bi[p * 64];
+    int mp = p;
+    for (int e = p + 1; e < k; e++) {
+      const double d = bd[e * 64];
+      const int32_t i = bi[e * 64];
+      const bool earlier = i >= 0 && (mi < 0 || d < md || (d == md && i < mi));
+      md = earlier ? d : md; mi = earlier ? i : mi; mp = earlier ? e : mp;
+    }
+    const double d0 = bd[p * 64];
+    const int32_t i0 = bi[p * 64];
+    bd[mp * 64] = d0; bi[mp * 64] = i0;
+    bd[p * 64] = md; bi[p * 64] = mi;
+  }
   if (seed_out) {                                   // seeding pass: only the k-th distance is wanted
     if (live) seed_out[q] = bd[(k - 1) * 64];
     return;

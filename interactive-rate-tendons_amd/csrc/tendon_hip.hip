@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <limits>
 #include <mutex>
 #include <string>
@@ -560,6 +561,8 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   }
   a.fb_list = fb_list; a.fb_count = fb_count;
   a.sig = sig; a.sig_stride = sig_stride; a.np_out = np_out;
+  a.radius = ctx->K.radius;
+  for (int j = 0; j < TRK_MAX_TENDONS; j++) { a.home_Li[j] = ctx->K.home_Li[j]; a.min_len[j] = ctx->K.min_len[j]; a.max_len[j] = ctx->K.max_len[j]; }
   if (spheres) {                       // classification thresholds (verdict_kernel.hpp: PointSweep<true>)
     a.field = ctx->d_sph_near; a.radius = ctx->K.radius;
     a.r_lo = (float)ctx->K.radius - 2e-6f; a.r_hi = (float)ctx->K.radius + 2e-6f;
@@ -1722,17 +1725,15 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   trk::KnnMetric m{N, c->K.enable_rotation, c->K.enable_retraction, S, ext / (4.0 * M_PI), 2.0 * ext / c->K.L};
   // candidate slices: enough waves to keep ~8 on every SIMD (see knn_kernel.hpp); at most 32 slices
   const int64_t qblocks = (nq + 63) / 64;
-  int nslice = (int)std::min<int64_t>(32, std::max<int64_t>(1, (8 * 1024 + qblocks - 1) / qblocks));
-  nslice = (int)std::min<int64_t>(nslice, std::max<int64_t>(1, n / 2048));
-  // seeding pass (knn_kernel.hpp): the k-th distance to the candidates nearest in sorted order, n / 48 either side.  The
-  // thicker that slab, the closer the seed to the true k-th distance and the narrower the search window of the main pass;
-  // measured flat between n / 32 and n / 64 from 10^5 to 10^6 states (profiles/r02/knn_sorted_v1.txt), and a rougher
-  // first seed for the seeding pass itself gains nothing.
-  int64_t hw_div = 48;
-  if (const char *e = std::getenv("TENDON_HIP_KNN_HW_DIV")) { const int v = std::atoi(e); if (v >= 1 && v <= 4096) hw_div = v; }   // tuning only
-  const int64_t half_window = n >= 4096 ? std::min<int64_t>(32768, std::max<int64_t>(1024, n / hw_div)) : 0;
-  double *d_s = nullptr, *d_ss = nullptr, *d_xs = nullptr, *d_kt = nullptr, *d_d = nullptr, *d_pd = nullptr, *d_seed = nullptr;
-  int32_t *d_perm = nullptr, *d_pt = nullptr, *d_ql = nullptr, *d_i = nullptr, *d_pi = nullptr;
+  // (round 2 sliced the candidate range over blockIdx.y and merged the slices' lists, and ran a seeding pass first; the
+  // expanding cell search of round 3 needs neither: a wave's candidates are a few thousand, nearest first)
+  const int nslice = 1;
+  const int64_t half_window = 0;                 // (no seeding pass)
+  double *d_s = nullptr, *d_ss = nullptr, *d_d = nullptr, *d_pd = nullptr, *d_seed = nullptr;
+  uint32_t *d_ck[2] = {nullptr, nullptr};
+  int32_t *d_perm = nullptr, *d_pt = nullptr, *d_ql = nullptr, *d_i = nullptr, *d_pi = nullptr, *d_cs = nullptr;
+  trk::KnnCells cg{};
+  constexpr int kMaxCells = 64;
   int rc = TR_OK;
   auto scratch = [&](int slot, size_t bytes, auto **out) -> bool {          // grow-only buffers kept in the context
     tr_ctx::KnnScratch &ks = c->knn;
@@ -1747,20 +1748,36 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   };
   do {
     const size_t nn = (size_t)n, qq = (size_t)nq;
-    if (!scratch(0, nn * S * sizeof(double), &d_s) || !scratch(1, nn * S * sizeof(double), &d_ss) || !scratch(2, nn * sizeof(double), &d_xs) ||
-        !scratch(3, nn * sizeof(double), &d_kt) || !scratch(4, nn * sizeof(int32_t), &d_perm) || !scratch(5, nn * sizeof(int32_t), &d_pt) ||
+    // (slot 2: the two cell-id arrays of the sort; slot 3: the cells' first positions)
+    uint32_t *ck = nullptr;
+    if (!scratch(0, nn * S * sizeof(double), &d_s) || !scratch(1, nn * S * sizeof(double), &d_ss) || !scratch(2, 2 * nn * sizeof(uint32_t), &ck) ||
+        !scratch(3, ((size_t)kMaxCells * kMaxCells + 1) * sizeof(int32_t), &d_cs) || !scratch(4, nn * sizeof(int32_t), &d_perm) || !scratch(5, nn * sizeof(int32_t), &d_pt) ||
         !scratch(6, qq * k * sizeof(double), &d_d) || !scratch(7, qq * k * sizeof(int32_t), &d_i) ||
         (half_window && !scratch(8, qq * sizeof(double), &d_seed)) ||
         (nslice > 1 && (!scratch(9, qq * nslice * k * sizeof(double), &d_pd) || !scratch(10, qq * nslice * k * sizeof(int32_t), &d_pi)))) {
       rc = fail(c, TR_ERR_HIP, "hipMalloc failed (neighbour search scratch)"); break;
     }
+    d_ck[0] = ck; d_ck[1] = ck + nn;
     if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
-      // the coordinate the search is ordered and windowed by: the retraction term of the metric when there is one (its
-      // spread, 2 extent, is several times a tension's), else the first tension
+      // the two coordinates the search is ordered and windowed by (knn_kernel.hpp): the retraction term of the metric when there
+      // is one (its spread, 2 extent, is several times a tension's) and the first tension, else the first two tensions.  Cells
+      // about a quarter of the expected k-th neighbour distance wide: for n points spread over the d metric dimensions with ranges R_i
+      // that distance is ~ (k / (n V_d))^(1/d) (prod R_i)^(1/d), V_d^(1/d) ~ 1.5 for d = 2 .. 6.  The estimate only sizes the
+      // grid: any cell width gives the same neighbours.
       const bool by_ret = c->K.enable_retraction != 0;
-      const hipError_t e = trk::sort_states_by_key(c->merge, d_s, n, S, by_ret ? S - 1 : 0, by_ret ? m.w_ret : 1.0, d_ss, d_xs, d_perm, d_kt, d_pt, nullptr);
+      cg.col0 = by_ret ? S - 1 : 0; cg.scale0 = by_ret ? m.w_ret : 1.0;
+      cg.col1 = by_ret ? 0 : (N >= 2 ? 1 : -1); cg.scale1 = 1.0;
+      double logprod = 0.0;
+      for (int i = 0; i < N; i++) logprod += std::log(std::max(c->max_tension[i], 1e-12));
+      if (c->K.enable_rotation) logprod += std::log(m.w_rot * 2.0 * M_PI);
+      if (c->K.enable_retraction) logprod += std::log(m.w_ret * c->K.L);
+      const double r_est = std::pow((double)k / (double)n, 1.0 / S) * std::exp(logprod / S) / 1.5;
+      double width = 0.25 * r_est;                  // measured at 10^5 and 6 x 10^5 states: 0.25 r (or the 64-cell cap) 6.2 / 27 ms, 0.5 r 7.3 / 31 ms, r 13 / 51 ms
+      if (const char *e = std::getenv("TENDON_HIP_KNN_CELL")) { const double v = std::atof(e); if (v > 0) width *= v; }      // tuning only
+      const int max_cells = n >= 4096 ? (int)std::min<int64_t>(kMaxCells, std::max<int64_t>(1, (int64_t)std::sqrt((double)n / 64.0))) : 1;
+      const hipError_t e = trk::sort_states_by_cells(c->merge, d_s, n, S, cg, width, max_cells, d_ss, d_perm, d_cs, d_ck, d_pt, nullptr);
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn sort: ") + hipGetErrorString(e)); break; }
     }
     if (nq != n) {
@@ -1779,17 +1796,18 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       int32_t *oi = nslice > 1 ? d_pi : d_i;
       double *od = nslice > 1 ? d_pd : d_d;
       const int variant = (c->K.enable_rotation ? 1 : 0) | (c->K.enable_retraction ? 2 : 0);
-#define TRK_KNN(NT, R, T) do { \
-        if (half_window) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), dim3((unsigned)qblocks, 1), dim3(64), lds, nullptr, d_ss, d_xs, d_perm, d_ql, nq, n, m, \
-                                            (int)k, max_distance, half_window, (const double *)nullptr, d_seed, q0, (int32_t *)nullptr, (double *)nullptr); \
-        hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T>), grid, dim3(64), lds, nullptr, d_ss, d_xs, d_perm, d_ql, nq, n, m, (int)k, max_distance, \
-                           (int64_t)0, (const double *)d_seed, (double *)nullptr, q0, oi, od); } while (0)
+#define TRK_KNN_K(NT, R, T, KC) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T, KC>), grid, dim3(64), lds, nullptr, d_ss, cg, d_cs, d_perm, d_ql, nq, n, m, (int)k, \
+                                                  max_distance, (int64_t)0, (const double *)nullptr, (double *)nullptr, q0, oi, od)
+      // (KCAP = 16 / 32 -- the list in registers -- measured SLOWER than the LDS column at every k: 29.9 against 27.4 ms at k = 11,
+      // 416 against 57 ms at k = 21 for 6 x 10^5 states; the instantiations are not built)
+#define TRK_KNN(NT, R, T) TRK_KNN_K(NT, R, T, 0)
       switch (N) {
 #define TRK_CASE(NT) case NT: if (variant == 0) TRK_KNN(NT, false, false); else if (variant == 1) TRK_KNN(NT, true, false); \
                               else if (variant == 2) TRK_KNN(NT, false, true); else TRK_KNN(NT, true, true); break;
         TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
 #undef TRK_CASE
 #undef TRK_KNN
+#undef TRK_KNN_K
         default: break;
       }
       if (nslice > 1)

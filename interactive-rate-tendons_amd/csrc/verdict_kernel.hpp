@@ -51,6 +51,9 @@ struct VerdictArgs {
   // backbone its retraction level allows, retraction_order): the wave enters the tip-aligned loop there instead of stepping
   // over ~100 table entries when it was dealt short backbones
   const int32_t *wave_k_begin;
+  // the robot's length limits and home lengths (RobotK's): read here after the loop, so that the kernel's RobotK argument
+  // keeps nothing but the stiffness constants live across it
+  double home_Li[TRK_MAX_TENDONS], min_len[TRK_MAX_TENDONS], max_len[TRK_MAX_TENDONS];
 };
 
 constexpr int VQ = 128;           // ring of deferred segments per wave
@@ -249,11 +252,12 @@ struct PointSweep {
       d += sqrtf(dx * dx + dy * dy + dz * dz);
       VL_F(VL_DIST + lane) = d;
     }
-    if (j == ms_next || j == P - 1) {                       // wave-uniform: every CH-th point and the tip
-      const int k = (j == P - 1) ? Kl : ms_k;
-      const int o = VL_MS + k * 64 + lane, pl = NM * 64;
+    if (j == ms_next || j == a.P - 1) {                     // wave-uniform: every CH-th point and the tip
+      const int CH_ = a.CH, P_ = a.P;                       // (from the argument block: they hold no registers between milestones)
+      const int k = (j == P_ - 1) ? (P_ - 1 + CH_ - 1) / CH_ : ms_k;
+      const int o = VL_MS + k * 64 + lane, pl = a.NM * 64;
       VL_F(o) = (float)q.x; VL_F(o + pl) = (float)q.y; VL_F(o + 2 * pl) = (float)q.z; VL_F(o + 3 * pl) = d;
-      if (j == ms_next) { ms_next += CH; ms_k++; }
+      if (j == ms_next) { ms_next += CH_; ms_k++; }
     }
     VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
     if constexpr (SIG) sig_put(a, j, true, cell_signature(x, y, z, g), sig_own_row(), 0);
@@ -488,8 +492,8 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     bool ok = true;
 #pragma unroll
     for (int j = 0; j < N; j++) {
-      const double dl = K.home_Li[j] - fl_.Li[j];
-      if (dl < K.min_len[j] || K.max_len[j] < dl) ok = false;
+      const double dl = a.home_Li[j] - fl_.Li[j];
+      if (dl < a.min_len[j] || a.max_len[j] < dl) ok = false;
     }
     len_ok = ok;
   }
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
   bool need_exact = alive && P > 2;
   if (!(a.debug & 2u) && __any(need_exact)) {
     const float *mx = (const float *)vlds + VL_MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
-    need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)K.radius);
+    need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)a.radius);
   }
 
   uint32_t fl = 0;
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
 #pragma unroll
     for (int j = 0; j < N; j++) {
       const double dl = fl_.home_Li[j] - fl_.Li[j];
-      if (dl < K.min_len[j] || K.max_len[j] < dl) ok = false;
+      if (dl < a.min_len[j] || a.max_len[j] < dl) ok = false;
     }
     len_ok = ok;
   }
@@ -587,7 +591,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
   bool need_exact = alive && np > 2;
   if (!(a.debug & 2u) && __any(need_exact)) {
     const float *mx = (const float *)vlds + VL_MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
-    need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)K.radius);
+    need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)a.radius);
   }
 
   uint32_t fl = 0;

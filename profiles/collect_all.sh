@@ -25,7 +25,7 @@ echo "sq done"
 rocprofv3 --pmc GRBM_GUI_ACTIVE --output-format csv -d "$O/grbm" -- python3 profiles/workload_all.py "$O/u_grbm" > "$O/grbm.log" 2>&1
 echo "grbm done"
 # keep what travels back small: the per-dispatch CSVs are condensed here
-python3 profiles/summarize_all.py "$O" "$O/summary" "$TAG" > "$O/summary.log" 2>&1 || true
+python3 profiles/summarize_all.py "$O" "$O/summary" "$TAG" > "$O/summary.log" 2>&1 || true   # (also condenses the trace into first_launch.json)
 rm -rf "$O"/pmc_fetch "$O"/pmc_write "$O"/sq "$O"/grbm
 find "$O/stats" -name "*kernel_trace.csv" -delete
 tail -3 "$O/summary.log"
