@@ -298,6 +298,10 @@ __device__ __forceinline__ uint32_t cell_signature(double x, double y, double z,
 // accesses stay ds_read / ds_write).  row_of: the sample whose row this lane's points belong to (-1: none); first_row: the
 // first point index this lane contributes through the tile (0, or a retraction robot's third point: its first two arrive in
 // rows of their own and are stored directly).  cur / mask are wave-uniform.
+// (the flush loop stays rolled: unrolled eight times inside the RK4 loop's hook it cost fk_verdict<4, .., SIG> 13 more scratch loads per step)
+#ifndef TRK_SIG_FLUSH_UNROLL
+#define TRK_SIG_FLUSH_UNROLL 1
+#endif
 constexpr int SIG_T = 8, SIG_LDS_STRIDE = 72, SIG_LDS_WORDS = SIG_T * SIG_LDS_STRIDE;
 struct SigStage {
   int cur, mask;                 // wave-uniform: the tile being filled (point index / SIG_T, -1 = none), which of its words are in
@@ -310,7 +314,7 @@ struct SigStage {
     __syncthreads();                                   // one wave per workgroup: orders the tile's writes before the reads below
     const int lane = threadIdx.x, w = lane & (SIG_T - 1), sub = lane >> 3;
     const int j = cur * SIG_T + w;
-#pragma unroll
+#pragma unroll TRK_SIG_FLUSH_UNROLL
     for (int it = 0; it < 8; it++) {
       const int r = it * 8 + sub;                      // the lane whose sample's row this store serves
       const int ro = __shfl(row_of, r, 64), fr = __shfl(first_row, r, 64);

@@ -144,6 +144,7 @@ struct tr_ctx {
   int edge_lanes = 2;                             // TENDON_HIP_EDGE_LANES=1: one lane only
   double edge_rate_seen = 0.0;                    // own samples per edge of this context's last indexed edge call (0 = none yet): sizes
                                                   // the next call's chunks and lanes (a rotating robot's edges take ~10, not ~4)
+  bool edge_lane_guess_forced = false;            // TENDON_HIP_EDGE_LANE_GUESS was given: it overrides the rate this context has seen
   double edge_lane_guess = 6.0;                   // own samples per edge assumed when a half is given its share of the pool
                                                   // (TENDON_HIP_EDGE_LANE_GUESS: testing, a small value provokes the overflow path)
   // retraction robots: the batch ordered by backbone length for the verdict-only kernel (cache_merge.hpp: retraction_order);
@@ -728,7 +729,7 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (const char *e = std::getenv("TENDON_HIP_RETRACT_SORT")) c->retract_sort_min = std::atoll(e);
   if (std::getenv("TENDON_HIP_RETRACT_KBEGIN_OFF")) c->retract_wave_start = false;
   if (const char *e = std::getenv("TENDON_HIP_EDGE_LANES")) c->edge_lanes = std::atoi(e) >= 2 ? 2 : 1;
-  if (const char *e = std::getenv("TENDON_HIP_EDGE_LANE_GUESS")) { const double v = std::atof(e); if (v >= 0.5 && v <= 64.0) c->edge_lane_guess = v; }
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_LANE_GUESS")) { const double v = std::atof(e); if (v >= 0.5 && v <= 64.0) { c->edge_lane_guess = v; c->edge_lane_guess_forced = true; } }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
     if (v >= 256 && v <= (1ll << 24)) c->edge_pool_max = c->edge_slots_max = (int64_t)round_up(v, 64);

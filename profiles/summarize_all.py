@@ -23,9 +23,11 @@ def key_of(name):
     """'void trk::fk_verdict<3, false>(...)' -> 'fk_verdict<3>'; rocPRIM kernels -> 'cache merge (rocPRIM sort + reduce)'."""
     if "rocprim" in name:
         return "cache merge (rocPRIM sort + reduce)"
-    m = re.search(r"trk::fk_verdict<(\d+), (?:true|false), true[,>]", name)
-    if m:
-        return "fk_verdict<%s> spheres" % m.group(1)              # the sphere-swept checker's variant (SPH = true)
+    name = name.replace("(anonymous namespace)::", "")
+    name = name.split("(")[0]                                    # the function's own name, not its argument types
+    m = re.search(r"trk::(fk_verdict(?:_retract)?)<(\d+), (?:true|false), (true|false)(?:, (true|false))?>", name)
+    if m:                                                         # SPH = true: the sphere-swept checker; SIG = true: edge samples (signature rows)
+        return "%s<%s>%s%s" % (m.group(1), m.group(2), " spheres" if m.group(3) == "true" else "", " +sig" if m.group(4) == "true" else "")
     m = re.search(r"trk::([A-Za-z0-9_]+)(?:<(\d+))?", name)
     if not m:
         return None

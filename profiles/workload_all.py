@@ -104,7 +104,7 @@ def main():
     edges = rb.knn_edges_gpu(states, k + 1)
     # since the search runs on sorted states a wave visits only the candidates within its seed radius: V^2 pairs are DECIDED,
     # about a fifth of them computed -- no flop or byte figure is claimed for the row
-    add("knn_bruteforce<4>", units=float(V) * V, unit="pair distances decided (seeding pass + main pass)")
+    add("knn_bruteforce<4>", units=float(V) * V, unit="pair distances decided (expanding cell search: a few thousand computed per query)")
     chk.engine.reserve_edges(len(edges))
     chk.engine.profile_begin()
     valid, nfk = rb.validate_edges(states, edges)
@@ -117,8 +117,10 @@ def main():
     # through fk_sweep_fused<4> (stored points)
     fl4 = isa["rk4_step<4>"]["flops_per_step"] * 128
     cand = rb.timing["vertices"]["candidates"]
-    add("fk_verdict<4>", bytes=cand * (8 * 4 + 24 + 0.125) + n_samples * (8 * 4 + 4 * 129 + 0.125), flops=(cand + n_samples) * fl4,
-        units=cand + n_samples, unit="checks")
+    add("fk_verdict<4>", bytes=(cand + V) * (8 * 4 + 24 + 0.125), flops=(cand + V) * fl4, units=cand + V, unit="checks")   # vertex sampling + the edge call's vertex pass? no: see below
+    # the edge call evaluates its V vertices and its own samples through the SIG variant (a 4 P-byte signature row per sample)
+    units["fk_verdict<4>"]["bytes"] -= V * (8 * 4 + 24 + 0.125); units["fk_verdict<4>"]["flops"] -= V * fl4; units["fk_verdict<4>"]["units"] -= V
+    add("fk_verdict<4> +sig", bytes=n_samples * (8 * 4 + 4 * 129 + 0.125), flops=n_samples * fl4, units=n_samples, unit="edge samples")
     add("edge_filter", bytes=2.0 * 129 * 4 * (n_samples + len(edges)), units=n_samples + len(edges), unit="interval tests on cell signatures (upper bound: early exit from the tip)")
     e_ok = edges[valid]
     vc = rb.vertex_caches(states)
