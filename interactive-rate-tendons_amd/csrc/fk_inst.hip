@@ -21,8 +21,11 @@ namespace trk {
 template <bool ROT, bool SPH, bool SIG>
 static void go(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);
+  const RetractHandoff ho{a.d_handoff, a.handoff_ld};
+  hipLaunchKernelGGL((fk_retract_prologue<TRK_INST_N, ROT>), dim3(grid), dim3(64), 0, a.stream, a.d_states, a.n, a.K, a.d_poly, a.d_tab, a.d_steps,
+                     a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.d_perm, ho);
   hipLaunchKernelGGL((fk_verdict_retract<TRK_INST_N, ROT, SPH, SIG>), dim3(grid), dim3(64), lds, a.stream, a.d_states, a.n, a.K, a.d_poly,
-                     a.d_tab, a.d_steps, a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.out.tips, va);
+                     a.d_tab, a.d_steps, a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.out.tips, va, ho);
 }
 template <bool SPH, bool SIG>
 static void go_rot(const FkLaunch &a, const VerdictArgs *va, size_t lds) {

@@ -17,6 +17,8 @@ struct FkLaunch {
   const PolyK *d_poly; int k_first; const double *d_tgrid, *d_hl;
   FkOut out;
   hipStream_t stream;
+  // retraction robots' verdict path: the prologue kernel's hand-over planes ([19 + N][handoff_ld] doubles) and the batch order
+  double *d_handoff = nullptr; int64_t handoff_ld = 0; const int32_t *d_perm = nullptr;
 };
 
 struct FusedSweepArgs;

@@ -108,19 +108,34 @@ struct FkLaneR {
   double Li[N], home_Li[N];
 };
 
+// What the prologue kernel hands to the tip-aligned kernel (PHASE 1 -> PHASE 2 of fk_retract_body): the integrator's state at
+// the end of the lane's own first interval, plane by plane, [field][ld] with ld = the launch's lane count rounded to 64 -- lane i
+// of both launches is the same configuration, so both sides are coalesced.  Fields: R 0-8, v 9-11, u 12-14, p 15-17, L_i 18 ..
+// 18 + N - 1, converged (as 0.0 / 1.0), then the configuration's S state coordinates (so that the second kernel does not gather
+// them once more through the batch order: 40 scattered bytes cost a 128-byte line each).
+struct RetractHandoff {
+  double *data;
+  int64_t ld;
+};
+
 // The body of K1r.  on_point.tip_point(row, on, first, x, y, z) is called in wave-uniform control flow for every observed
 // backbone point (after rotate_z): `row` is the point's tip-aligned row (the lane's point j sits in row j + P - P_lane; it
 // is the lane's own row for its first two points and wave-uniform afterwards), `on` says whether this lane has a point in
 // this call, `first` whether it is the lane's point 0; on_point.begin(converged && live) precedes the first call.
 // row_map (optional): lane i integrates configuration row_map[i] of `states`.
-template <int N, bool ROT, bool WRITE_R, class OnPoint = NoPointHook>
+// PHASE 0: everything.  PHASE 1: up to the end of the lane's own first interval (initial bending, per-lane routing) -- the part
+// whose register demand spills -- then the state goes to `ho` and the body returns; no hook is called, nothing else is written.
+// PHASE 2: the state comes from `ho`, the hook sees points 0 and 1, and the tip-aligned loop and the epilogue follow: this kernel
+// holds neither the per-lane routing nor the fixed-point solve.
+template <int N, bool ROT, bool WRITE_R, class OnPoint = NoPointHook, int PHASE = 0>
 __device__ __forceinline__ void fk_retract_body(
     const double *__restrict__ states, int64_t n, int64_t ld, const RobotK &K, const PolyK *__restrict__ pk,
     const double *__restrict__ tab /* K1's routing table of the s_start = 0 grid */, const StepK *__restrict__ steps, int nsteps,
     int k_first /* first step after the grid's own first interval */, const double *__restrict__ tgrid /* [P] shared abscissae */,
     const double *__restrict__ hl /* [P][N] home-length integrand at the shared abscissae */, const FkOut &out,
     OnPoint &&on_point = NoPointHook(), const int32_t *__restrict__ row_map = nullptr, FkLaneR<N> *lane_out = nullptr,
-    int k_begin = 0 /* wave-uniform: no lane of this wave has a point in a row that a step before k_begin ends in (0 = unknown) */) {
+    int k_begin = 0 /* wave-uniform: no lane of this wave has a point in a row that a step before k_begin ends in (0 = unknown) */,
+    const RetractHandoff *ho = nullptr) {
 #pragma clang fp contract(fast)
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = i < n;
@@ -128,16 +143,21 @@ __device__ __forceinline__ void fk_retract_body(
   const int64_t ic = row_map ? (int64_t)row_map[il] : il;
   const int S = K.state_size, Pmax = K.n_points;
   const double L = K.L, dL = K.dL;
+  // the state: from the caller's array (through the batch order), or -- PHASE 2 -- from the hand-over planes, coalesced
+  auto state_at = [&](int d) -> double {
+    if constexpr (PHASE == 2) return ho->data[(int64_t)(19 + N + d) * ho->ld + (live ? i : n - 1)];
+    else return states[ic * S + d];
+  };
   double tau[N];
 #pragma unroll
-  for (int j = 0; j < N; j++) tau[j] = states[ic * S + j];
+  for (int j = 0; j < N; j++) tau[j] = state_at(j);
   double rc = 1.0, rs = 0.0, r22 = 1.0;
   if (ROT) {
-    const double th = states[ic * S + N];
+    const double th = state_at(N);
     rs = sin(th); rc = cos(th);
     r22 = (1.0 - rc) + rc;
   }
-  const double s_raw = states[ic * S + (S - 1)];
+  const double s_raw = state_at(S - 1);
   // s_start below 0 lies outside the RetractionStateSpace bounds [0, L] (Problem.cpp:142); the
   // reference would integrate a longer backbone than any buffer here holds -> reported unconverged.
   const bool negative = s_raw < 0.0;
@@ -159,10 +179,10 @@ __device__ __forceinline__ void fk_retract_body(
   const int shift = Pmax - P_lane;                   // lane point i = shared grid point i + shift (i >= 1)
 
   RouteCarry<N> rcy;
-  route_anchor<N>(pk, K.n_a, s, rcy);
   double v[3], u[3];
-  bool conv;
-  {
+  bool conv = true;
+  if constexpr (PHASE != 2) {
+    route_anchor<N>(pk, K.n_a, s, rcy);
     double rloc[N * 6];
 #pragma unroll
     for (int j = 0; j < N; j++) {
@@ -172,8 +192,8 @@ __device__ __forceinline__ void fk_retract_body(
       for (int q = 0; q < 6; q++) rloc[6 * j + q] = r6[q];
     }
     initial_bending<N>(tau, rloc, K, v, u, conv);
+    if (single) { conv = !negative; }                // early return keeps the default converged = true
   }
-  if (single) { conv = !negative; }                  // early return keeps the default converged = true
 
   double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
   double p[3] = {0, 0, 0};
@@ -181,8 +201,20 @@ __device__ __forceinline__ void fk_retract_body(
   double Li[N];
 #pragma unroll
   for (int j = 0; j < N; j++) Li[j] = 0;
+  double p1[3] = {0, 0, 0};                          // PHASE 2: the lane's point 1 (the end of its own first interval)
+  if constexpr (PHASE == 2) {
+    const double *__restrict__ h = ho->data + (live ? i : n - 1);
+    const int64_t hl = ho->ld;
+#pragma unroll
+    for (int q = 0; q < 9; q++) R[q] = h[q * hl];
+#pragma unroll
+    for (int q = 0; q < 3; q++) { v[q] = h[(9 + q) * hl]; u[q] = h[(12 + q) * hl]; p1[q] = h[(15 + q) * hl]; }
+#pragma unroll
+    for (int j = 0; j < N; j++) Li[j] = h[(18 + j) * hl];
+    conv = h[(18 + N) * hl] != 0.0;
+  }
 
-  on_point.begin(conv && live);
+  if constexpr (PHASE != 1) on_point.begin(conv && live);
   // `row` may differ from lane to lane (the lane's first two points) or be wave-uniform (the tip-aligned loop); `on`: the
   // lane has a point here.  The hook runs for the whole wave (it holds ballots and workgroup barriers).
   auto store_point = [&](int row, bool on, bool is_first, bool wave_row = false) {
@@ -203,27 +235,50 @@ __device__ __forceinline__ void fk_retract_body(
       }
     }
   };
-  store_point(shift, true, true);                   // rows are aligned at the tip: the lane's point j goes to row j + shift
+  if constexpr (PHASE != 1) store_point(shift, true, true);    // rows are aligned at the tip: the lane's point j goes to row j + shift
 
   // the lane's own first interval: s -> shared grid point shift + 1, steps of min(dL, remaining) while
   // remaining > eps (integrate_times), routing evaluated per lane
   // (s_start within dL/2 of L gives a one-point backbone that is not the `single` early return: no interval at all)
   const bool first = !single && P_lane >= 2;
   if (__any(first)) {
-    double cur = L - (L - s);                        // t[0]: the mirrored `end` sample of t_range
-    double tn = cur;
-    if (first) tn = tgrid[shift + 1];
-    for (int sub = 0; sub < 4; sub++) {
-      const bool go = first && (tn - cur > 2.220446049250313e-16);
-      if (!__any(go)) break;
-      if (go) {
-        const double h = (dL < tn - cur) ? dL : (tn - cur);
-        rk4_step_routed<N>(R, v, u, p, Lb, Li, tau, K, cur, h,
-                           [&](double tt, int j, double (&r6)[6]) { route_tendon<N>(pk, K.n_a, K.n_m, j, tt, rcy, r6); });
-        cur += h;
+    if constexpr (PHASE != 2) {
+      double cur = L - (L - s);                      // t[0]: the mirrored `end` sample of t_range
+      double tn = cur;
+      if (first) tn = tgrid[shift + 1];
+      for (int sub = 0; sub < 4; sub++) {
+        const bool go = first && (tn - cur > 2.220446049250313e-16);
+        if (!__any(go)) break;
+        if (go) {
+          const double h = (dL < tn - cur) ? dL : (tn - cur);
+          rk4_step_routed<N>(R, v, u, p, Lb, Li, tau, K, cur, h,
+                             [&](double tt, int j, double (&r6)[6]) { route_tendon<N>(pk, K.n_a, K.n_m, j, tt, rcy, r6); });
+          cur += h;
+        }
       }
+    } else {
+      p[0] = p1[0]; p[1] = p1[1]; p[2] = p1[2];
     }
-    store_point(shift + 1, first, false);
+    if constexpr (PHASE != 1) store_point(shift + 1, first, false);
+  }
+  if constexpr (PHASE == 1) {
+    // hand the state over and stop (the quadrature of the backbone length is not carried: no verdict path asks for L)
+    if (live) {
+      double *__restrict__ h = ho->data + i;
+      const int64_t hl = ho->ld;
+#pragma unroll
+      for (int q = 0; q < 9; q++) h[q * hl] = R[q];
+#pragma unroll
+      for (int q = 0; q < 3; q++) { h[(9 + q) * hl] = v[q]; h[(12 + q) * hl] = u[q]; h[(15 + q) * hl] = p[q]; }
+#pragma unroll
+      for (int j = 0; j < N; j++) h[(18 + j) * hl] = Li[j];
+      h[(18 + N) * hl] = conv ? 1.0 : 0.0;
+#pragma unroll
+      for (int j = 0; j < N; j++) h[(19 + N + j) * hl] = tau[j];
+      if (ROT) h[(19 + N + N) * hl] = states[ic * S + N];
+      h[(19 + N + S - 1) * hl] = s_raw;
+    }
+    return;
   }
 
   // tip-aligned: step k of the shared grid ends at its point steps[k].obs = the lane's point obs - shift

@@ -153,6 +153,7 @@ struct tr_ctx {
   struct RetractOrder {
     uint32_t *keys[2] = {nullptr, nullptr}; int32_t *vals[2] = {nullptr, nullptr}; int64_t cap = 0;
     int32_t *kbegin = nullptr;          // [cap / 64] per wave of the ordered batch: the step its tip-aligned loop may start at
+    double *handoff = nullptr; int64_t handoff_cap = 0;   // [19 + N + S][cap]: fk_retract_prologue -> fk_verdict_retract
     trk::MergeScratch ms;               // lane 1's radix-sort scratch (lane 0 uses tr_ctx::merge)
   } ro[2];
   int64_t retract_sort_min = kRetractSortMin;
@@ -596,8 +597,20 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   const trk::FusedSweepArgs *d_fargs; size_t lds_f; int fslot;
   if ((rc = fused_args_slot(ctx, in, spheres ? 2 : 1, d_bits, d_flags, s, &d_fargs, &lds_f, &fslot))) return rc;
   const trk::FkOut vout{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, d_tips, nullptr, nullptr, nullptr};
-  const trk::FkLaunch vl{d_states, n, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
-                         (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, vout, s};
+  trk::FkLaunch vl{d_states, n, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
+                   (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, vout, s};
+  if (ctx->K.enable_retraction) {
+    // the prologue kernel's hand-over planes (fk_retract_prologue -> fk_verdict_retract), one set per lane of the edge bisection
+    tr_ctx::RetractOrder &ro = ctx->ro[lane ? 1 : 0];
+    const int64_t hld = round_up(n, 64);
+    if (ro.handoff_cap < hld) {
+      HIP_TRY(ctx, hipDeviceSynchronize());
+      const int64_t want = hld + hld / 8;
+      if ((rc = dev_alloc(ctx, &ro.handoff, (size_t)want * (19 + 2 * TRK_MAX_TENDONS + 2)))) return rc;     // R, v, u, p | L_i | converged | state
+      ro.handoff_cap = want;
+    }
+    vl.d_handoff = ro.handoff; vl.handoff_ld = hld; vl.d_perm = a.perm;
+  }
   const trk::FkOut fout{w.px + fcol, w.py + fcol, w.pz + fcol, nullptr, nullptr, w.Li + fcol, nullptr, w.conv + fcol, ret ? w.np + fcol : nullptr,
                         ret ? w.homeLi + fcol : nullptr};
   const trk::FkLaunch fl{d_states, cap, w.ld, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
@@ -880,6 +893,7 @@ void tr_destroy(tr_ctx *c) {
   for (auto &ro : c->ro) {
     for (int q = 0; q < 2; q++) { if (ro.keys[q]) (void)hipFree(ro.keys[q]); if (ro.vals[q]) (void)hipFree(ro.vals[q]); }
     if (ro.kbegin) (void)hipFree(ro.kbegin);
+    if (ro.handoff) (void)hipFree(ro.handoff);
     trk::merge_free(ro.ms);
   }
   if (c->d_fb_count) (void)hipFree(c->d_fb_count);

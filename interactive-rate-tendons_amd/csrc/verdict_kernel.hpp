@@ -538,11 +538,26 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
 // The same for retraction-enabled robots: K1r's body (fk_retract_kernel.hpp: per-lane arc-length grid, tip-aligned
 // iterations) with the sweep in its point hook (PointSweep::tip_point).  What differs after the loop is per lane: the
 // number of points, the last milestone slot and the home-shape tendon lengths.
+// The lane's own first interval -- fixed-point solve of the base strains, per-lane routing, up to two RK4 steps that evaluate the
+// routing polynomials per stage -- needs more than the 256 registers the two-wave budget of the kernel below allows: inside it the
+// first interval spilled 450 - 650 B per lane, and with 8 waves x 32 CUs x 64 lanes of that per XCD the frames did not stay in
+// the 4 MiB L2 (1.3 - 2.5 KB of HBM traffic per check for 68 algorithmic bytes, profiles/r03/traffic_split_v2.json).  So it runs
+// here, ONE wave per SIMD with the whole register file, and hands the integrator's state over (18 + N + 1 doubles per
+// configuration, written and read coalesced).
+template <int N, bool ROT>
+__global__ __launch_bounds__(64, 1) void fk_retract_prologue(
+    const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
+    const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
+    const int32_t *__restrict__ perm, RetractHandoff ho) {
+  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  fk_retract_body<N, ROT, false, NoPointHook, 1>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, NoPointHook(), perm, nullptr, 0, &ho);
+}
+
 template <int N, bool ROT, bool SPH, bool SIG = false>
 __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict_retract(
     const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
-    double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
+    double *__restrict__ tips, const VerdictArgs *__restrict__ va, RetractHandoff ho) {
   const int lane = threadIdx.x;
   PointSweep<SPH, SIG> ps;
   ps.va = va;
@@ -560,7 +575,8 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
   FkLaneR<N> fl_;
   FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, tips, nullptr, nullptr, nullptr};
   const int32_t *__restrict__ wkb = va->wave_k_begin;
-  fk_retract_body<N, ROT, false>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, ps, perm, &fl_, wkb ? wkb[blockIdx.x] : 0);
+  fk_retract_body<N, ROT, false, PointSweep<SPH, SIG> &, 2>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, ps, perm, &fl_,
+                                                            wkb ? wkb[blockIdx.x] : 0, &ho);
 
   ps.template sig_finish<true>();
   ps.finish();

@@ -84,14 +84,21 @@ def summarize(src, out):
                     continue
                 m = re.search(r"trk::(fk_verdict\w*)<(\d+), (true|false), (true|false)", r["Kernel_Name"])
                 if not m:
+                    # the retraction robots' prologue kernel belongs to the same check (its hand-over planes are part of the path's traffic)
+                    m = re.search(r"trk::(fk_retract_prologue)<(\d+), (true|false)()", r["Kernel_Name"])
+                if not m:
                     continue
                 grid = int(r["Grid_Size"])
                 p = by_grid.get(grid)
                 label = p["label"] if p else "verdict4_edges" if m.group(1) == "fk_verdict" and m.group(2) == "4" else "other"
-                e = res.setdefault(label, {"kernel": "%s<%s>" % (m.group(1), m.group(2)), "launches": {"FETCH_SIZE": 0, "WRITE_SIZE": 0},
+                e = res.setdefault(label, {"kernel": "%s<%s>" % (m.group(1).replace("fk_retract_prologue", "fk_verdict_retract"), m.group(2)),
+                                           "launches": {"FETCH_SIZE": 0, "WRITE_SIZE": 0},
                                            "bytes": {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0}, "lanes": {"FETCH_SIZE": 0, "WRITE_SIZE": 0}})
-                e["launches"][counter] += 1
                 e["bytes"][counter] += float(r["Counter_Value"]) * scale
+                if m.group(1) == "fk_retract_prologue":
+                    e.setdefault("prologue_bytes", {"FETCH_SIZE": 0.0, "WRITE_SIZE": 0.0})[counter] += float(r["Counter_Value"]) * scale
+                    continue                                   # same lanes as the main kernel's launch: counted once
+                e["launches"][counter] += 1
                 e["lanes"][counter] += grid
     for label, e in res.items():
         e["fetch_bytes_per_lane"] = e["bytes"]["FETCH_SIZE"] / max(1, e["lanes"]["FETCH_SIZE"])

@@ -98,7 +98,9 @@ VERDICT_RETRACT_TU = r'''
 #include "fk_retract_kernel.hpp"
 #include "verdict_kernel.hpp"
 template __global__ void trk::fk_verdict_retract<%d, true, false>(const double*, int64_t, RobotK, const PolyK*, const double*, const StepK*, int, int,
-                                                                  const double*, const double*, double*, const trk::VerdictArgs*);
+                                                                  const double*, const double*, double*, const trk::VerdictArgs*, trk::RetractHandoff);
+template __global__ void trk::fk_retract_prologue<%d, true>(const double*, int64_t, RobotK, const PolyK*, const double*, const StepK*, int, int,
+                                                            const double*, const double*, const int32_t*, trk::RetractHandoff);
 '''
 
 
@@ -108,7 +110,7 @@ def test_verdict_retract_kernel_occupancy_and_lds_address_space(tmp_path, n_tend
     behind the other wave -- and the point hook's state in LDS.  Its scratch is the lane-private first interval's
     (per-lane routing), outside the tip-aligned loop."""
     src = tmp_path / "kvr.hip"
-    src.write_text(VERDICT_RETRACT_TU % n_tendons)
+    src.write_text(VERDICT_RETRACT_TU % (n_tendons, n_tendons))
     base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-I", CSRC, str(src)]
     out = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "kvr.o")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
