@@ -151,6 +151,40 @@ def load_isa_counts():
         return {}
 
 
+def config4_one_gpu_extras():
+    """configs[3] at full size (2^20 candidates) through ONE rank's code path of `--workload config4`: what every phase costs
+    before it is divided over ranks.  Two builds, the faster reported."""
+    try:
+        import torch
+        irt = importlib.import_module("interactive-rate-tendons_amd")
+        W, D = irt.workloads, irt.distributed
+        robot = W.robot_config3()
+        vox, _ = W.reach_environment(seed=7, n_spheres=64)
+        checker = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        eng = checker.engine
+        rb = irt.RoadmapBuilder(checker, irt.VoxelBackboneMotionValidator(checker), seed=3)
+        M, k, seed = 1 << 20, 10, 3
+        box = D.sampling_box(robot)
+        vv = D.ShardedVertexValidator(robot, seed=seed, device="cuda", box=box, validate_candidates=D.device_candidate_validator(eng, seed, box))
+        best = None
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = [time.perf_counter()]
+            mask = vv.run(M, rank=0, world_size=1, keep_on_device=True); torch.cuda.synchronize(); t.append(time.perf_counter())
+            verts = D.gather_valid_vertices_dev(eng, seed, M, mask, box=box)[0].cpu().numpy(); t.append(time.perf_counter())
+            edges = rb.knn_edges_gpu(verts, k + 1); t.append(time.perf_counter())
+            ev, nfk = rb.validate_edges(verts, edges); t.append(time.perf_counter())
+            d = np.diff(t)
+            if best is None or d.sum() < best[0].sum():
+                best = (d, len(verts), len(edges), int(ev.sum()), int(nfk.sum()))
+        d, nv, ne, nok, nfk = best
+        return {"candidates": M, "valid_vertices": nv, "candidate_edges": ne, "valid_edges": nok, "build_s": float(d.sum()),
+                "vertex_phase_checks_per_s": M / d[0], "valid_vertices_per_s": nv / d[0], "compact_and_download_s": float(d[1]),
+                "knn_edge_list_s": float(d[2]), "edges_validated_per_s": ne / d[3], "edge_fk_samples_per_s": nfk / d[3]}
+    except Exception as e:                                  # noqa: BLE001 -- reported, not raised
+        return {"error": repr(e)[:300]}
+
+
 def secondary_metrics():
     """BASELINE configs 1, 3 and 5 at full size on this GPU (bench_roadmap.py, without its CPU leg), condensed; never part of
     `value`, and a failure here must not cost the headline line."""
@@ -170,6 +204,7 @@ def secondary_metrics():
                 "revalidate_all_cached_sets_ms": q["eager"]["revalidate_all_ms"], "cached_sets": q["roadmap_vertices"] + q["roadmap_edges"],
                 "vertex_caches_built_per_s": c5["vertex_caches_built_per_s"], "edge_caches_built_per_s": c5["edge_caches_built_per_s"],
                 "solved_fraction": q["solved_fraction"]},
+            "config4_on_one_gpu": config4_one_gpu_extras(),
             "config1_fk_only": r["config1"], "sphere_checker_checks_per_s": r["sphere_checker"]["checks_per_s"],
             "rotation_retraction_robot": {k: r["rotation_retraction_robot"][k] for k in ("robot", "checks_per_s", "edges", "edges_per_s",
                                                                                          "edge_fk_samples_per_s")},
