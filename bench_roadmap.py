@@ -190,9 +190,12 @@ def run(argv=None):
     vd_all, ed_all = rb.vertex_caches(states, device=True), rb.edge_caches(states, e_ok, device=True)
     t_build_dev = time.perf_counter() - t0
     # createRoadmap's edge phase in ONE traversal of the samples: checkMotion on all candidate edges + voxel sets of the accepted
+    chk.engine.reserve_edges(len(edges))                        # (what create_roadmap does before its connect: both lanes' pools in one go)
     rb.connect(states, edges[:4096], device=True)
     t_connect = float("inf")
-    for _ in range(2):
+    e_conn = ed_conn = None
+    for _ in range(3):
+        e_conn = ed_conn = None                                 # the last result's device lists go back to torch's pool first: a fresh 375 MB hipMalloc is 20 ms
         e_conn, ed_conn = rb.connect(states, edges, device=True)
         t_connect = min(t_connect, rb.timing["connect"]["seconds"])
     import torch

@@ -28,10 +28,13 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -40,6 +43,31 @@
 #include "../../include/tendon_hip.h"
 
 namespace {
+
+// TENDON_HIP_ROADMAP_TIMING=1: the host phases of tr_roadmap_create / tr_roadmap_prepare on stderr (profiles/probe_query_object.py)
+struct Laps {
+  bool on = std::getenv("TENDON_HIP_ROADMAP_TIMING") != nullptr;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  const char *what;
+  explicit Laps(const char *w) : what(w) { if (on) std::fprintf(stderr, "[%s]", what); }
+  void lap(const char *name) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, " %s %.2f ms", name, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+  ~Laps() { if (on) std::fprintf(stderr, "\n"); }
+};
+
+// fn(t) for t = 0 .. T-1 on T host threads (the caller's included)
+template <class F> void on_threads(int T, F &&fn) {
+  if (T <= 1) { fn(0); return; }
+  std::vector<std::thread> th;
+  th.reserve((size_t)T - 1);
+  for (int t = 1; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
+  fn(0);
+  for (auto &x : th) x.join();
+}
 
 enum : uint8_t { V_UNKNOWN = 0, V_VALID = 1, V_INVALID = 2 };   // VALIDITY_UNKNOWN / VALIDITY_TRUE / removed from the graph
 
@@ -75,6 +103,19 @@ struct Arc { int32_t v, e; double w; };   // one adjacency entry: neighbour, edg
 
 }  // namespace
 
+// A heap array that is NOT zeroed when sized (std::vector would touch all of it on the calling thread: for the 19 MB of arcs of a
+// 100 k-vertex roadmap the page faults of that pass cost more than filling them): the pages are first touched by the threads that fill them.
+template <class T> struct RawArray {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  void resize_uninit(size_t m) { p.reset(new T[m]); n = m; }
+  size_t size() const { return n; }
+  T *data() { return p.get(); }
+  const T *data() const { return p.get(); }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
+
 struct tr_roadmap {
   std::mutex mu;
   tr_ctx *ctx = nullptr;
@@ -84,10 +125,10 @@ struct tr_roadmap {
   double w_rot = 0, w_ret = 0;
   int64_t V = 0, E = 0;
   std::vector<double> states;
-  std::vector<int32_t> eu, ev;
-  std::vector<double> w;
+  RawArray<int32_t> eu, ev;
+  RawArray<double> w;
   std::vector<int64_t> adj_off;        // CSR adjacency, both directions
-  std::vector<Arc> adj;
+  RawArray<Arc> adj;
   // landmark lower bounds (tr_roadmap_prepare): lm_d[v * lm_n + l] = graph distance landmark l -> v over all edges, as float
   // (+inf = not connected); lm_n = 0: none, -1: not built yet (built with the default count by the first solve)
   int lm_n = -1;
@@ -282,23 +323,40 @@ __global__ __launch_bounds__(256) void landmark_to_float(const unsigned long lon
   if (t < n) out[t] = (float)__longlong_as_double((long long)dist[t]);
 }
 
+__global__ __launch_bounds__(256) void landmark_init(unsigned long long *__restrict__ dist, int64_t n, const int32_t *__restrict__ lm_v, int L) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int64_t u = t / L;
+  const int l = (int)(t - u * L);
+  dist[t] = (lm_v[l] == (int32_t)u) ? 0ull : 0x7FF0000000000000ull;          // 0 at the landmark itself, +inf elsewhere
+}
+
 bool landmark_distances_device(tr_roadmap *r) {
   const int64_t V = r->V;
   const int L = (int)r->lm_v.size();
   if (hipSetDevice(tr_device(r->ctx)) != hipSuccess) return false;
-  int64_t *d_off = nullptr; Arc *d_adj = nullptr; unsigned long long *d_dist = nullptr; uint32_t *d_changed = nullptr; float *d_out = nullptr;
   constexpr int BATCH = 8;                                     // sweeps between two looks at the flags
-  std::vector<unsigned long long> init((size_t)V * L, 0x7FF0000000000000ull);          // +inf
-  for (int l = 0; l < L; l++) init[(size_t)r->lm_v[(size_t)l] * L + l] = 0ull;
-  bool ok = hipMalloc((void **)&d_off, (size_t)(V + 1) * sizeof(int64_t)) == hipSuccess &&
-            hipMalloc((void **)&d_adj, std::max<size_t>(1, r->adj.size()) * sizeof(Arc)) == hipSuccess &&
-            hipMalloc((void **)&d_dist, init.size() * sizeof(unsigned long long)) == hipSuccess &&
-            hipMalloc((void **)&d_changed, BATCH * sizeof(uint32_t)) == hipSuccess &&
-            hipMalloc((void **)&d_out, init.size() * sizeof(float)) == hipSuccess &&
-            hipMemcpy(d_off, r->adj_off.data(), (size_t)(V + 1) * sizeof(int64_t), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(d_adj, r->adj.data(), r->adj.size() * sizeof(Arc), hipMemcpyHostToDevice) == hipSuccess &&
-            hipMemcpy(d_dist, init.data(), init.size() * sizeof(unsigned long long), hipMemcpyHostToDevice) == hipSuccess;
+  // one allocation: offsets | arcs | distances (as ordered bit patterns) | float table | landmark vertices | flags
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_off = up((size_t)(V + 1) * sizeof(int64_t)), b_adj = up(std::max<size_t>(1, r->adj.size()) * sizeof(Arc)),
+               b_dist = up((size_t)V * L * sizeof(unsigned long long)), b_out = up((size_t)V * L * sizeof(float)),
+               b_lm = up((size_t)L * sizeof(int32_t)), b_flags = up(BATCH * sizeof(uint32_t));
+  char *arena = nullptr;
+  if (hipMalloc((void **)&arena, b_off + b_adj + b_dist + b_out + b_lm + b_flags) != hipSuccess) return false;
+  int64_t *d_off = (int64_t *)arena;
+  Arc *d_adj = (Arc *)(arena + b_off);
+  unsigned long long *d_dist = (unsigned long long *)(arena + b_off + b_adj);
+  float *d_out = (float *)(arena + b_off + b_adj + b_dist);
+  int32_t *d_lm = (int32_t *)(arena + b_off + b_adj + b_dist + b_out);
+  uint32_t *d_changed = (uint32_t *)(arena + b_off + b_adj + b_dist + b_out + b_lm);
   const unsigned grid = (unsigned)((V * L + 255) / 256);
+  bool ok = hipMemcpyAsync(d_lm, r->lm_v.data(), (size_t)L * sizeof(int32_t), hipMemcpyHostToDevice, nullptr) == hipSuccess;
+  if (ok) {
+    hipLaunchKernelGGL(landmark_init, dim3(grid), dim3(256), 0, nullptr, d_dist, V * L, d_lm, L);
+    ok = hipGetLastError() == hipSuccess;
+  }
+  ok = ok && hipMemcpyAsync(d_off, r->adj_off.data(), (size_t)(V + 1) * sizeof(int64_t), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       hipMemcpyAsync(d_adj, r->adj.data(), r->adj.size() * sizeof(Arc), hipMemcpyHostToDevice, nullptr) == hipSuccess;
   bool converged = false;
   for (int64_t sweeps = 0; ok && !converged && sweeps < 4 * V + BATCH; sweeps += BATCH) {     // (V - 1 sweeps always suffice)
     uint32_t flags[BATCH];
@@ -315,8 +373,7 @@ bool landmark_distances_device(tr_roadmap *r) {
     ok = hipGetLastError() == hipSuccess &&
          hipMemcpy(r->lm_d.data(), d_out, (size_t)V * L * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
   }
-  void *ptrs[] = {d_off, d_adj, d_dist, d_changed, d_out};
-  for (void *q : ptrs) if (q) (void)hipFree(q);
+  (void)hipFree(arena);
   return ok && converged;
 }
 
@@ -327,50 +384,70 @@ void build_landmarks(tr_roadmap *r, int n, int T) {
   const int64_t V = r->V;
   const int S = r->S;
   if (n <= 0 || V < 2 || r->E == 0) return;
-  // largest connected component
-  std::vector<int32_t> comp((size_t)V, -1), stack;
-  int32_t ncomp = 0, big = -1;
+  Laps laps("build_landmarks");
+  // largest connected component: union-find over the edge list (sequential reads; the parent array stays in cache -- a graph
+  // traversal would take one cache miss per vertex into the 16-byte arcs)
+  std::vector<int32_t> comp((size_t)V);
+  int32_t big = -1;
   int64_t big_n = 0;
-  for (int64_t s0 = 0; s0 < V; s0++) {
-    if (comp[(size_t)s0] >= 0) continue;
-    int64_t cnt = 0;
-    stack.assign(1, (int32_t)s0); comp[(size_t)s0] = ncomp;
-    while (!stack.empty()) {
-      const int32_t u = stack.back(); stack.pop_back(); cnt++;
-      for (int64_t k = r->adj_off[u]; k < r->adj_off[u + 1]; k++) {
-        const int32_t v = r->adj[(size_t)k].v;
-        if (comp[(size_t)v] < 0) { comp[(size_t)v] = ncomp; stack.push_back(v); }
-      }
+  {
+    std::vector<int32_t> &par = comp;
+    for (int64_t v = 0; v < V; v++) par[(size_t)v] = (int32_t)v;
+    auto root = [&par](int32_t x) {
+      while (par[(size_t)x] != x) { par[(size_t)x] = par[(size_t)par[(size_t)x]]; x = par[(size_t)x]; }     // path halving
+      return x;
+    };
+    for (int64_t e = 0; e < r->E; e++) {
+      const int32_t a = root(r->eu[(size_t)e]), b = root(r->ev[(size_t)e]);
+      if (a != b) par[(size_t)std::max(a, b)] = std::min(a, b);          // the smaller index becomes the root
     }
-    if (cnt > big_n) { big_n = cnt; big = ncomp; }
-    ncomp++;
+    std::vector<int32_t> cnt((size_t)V, 0);
+    for (int64_t v = 0; v < V; v++) { const int32_t c = root((int32_t)v); par[(size_t)v] = c; cnt[(size_t)c]++; }   // comp[v] = its root
+    for (int64_t v = 0; v < V; v++) if (cnt[(size_t)v] > big_n) { big_n = cnt[(size_t)v]; big = (int32_t)v; }       // ties: the smallest root
   }
   if (big_n < 2) return;
+  laps.lap("components");
   std::vector<double> lo((size_t)S, std::numeric_limits<double>::infinity()), hi((size_t)S, -std::numeric_limits<double>::infinity());
   for (int64_t v = 0; v < V; v++)
     for (int i = 0; i < S; i++) { const double x = r->states[(size_t)v * S + i]; lo[(size_t)i] = std::min(lo[(size_t)i], x); hi[(size_t)i] = std::max(hi[(size_t)i], x); }
-  uint64_t lcg = 0x9E3779B97F4A7C15ull;
-  for (int l = 0; l < 4 * n && (int)r->lm_v.size() < n; l++) {
-    std::vector<double> dir((size_t)S);
-    for (int i = 0; i < S; i++) {
-      double c;
-      if (S <= 16 && l < (1 << S)) c = ((l >> i) & 1) ? 1.0 : -1.0;
-      else { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; c = (double)(int64_t)(lcg >> 11) / (double)(1ll << 52) - 1.0; }
-      const double ext = hi[(size_t)i] - lo[(size_t)i];
-      dir[(size_t)i] = ext > 0 ? c / ext : 0.0;
-    }
+  // the directions, in their fixed order; the vertex furthest along each of the first n on the host threads, any further one
+  // (needed only when two directions pick the same vertex) when its turn comes
+  std::vector<double> dirs((size_t)4 * n * S);
+  {
+    uint64_t lcg = 0x9E3779B97F4A7C15ull;
+    for (int l = 0; l < 4 * n; l++)
+      for (int i = 0; i < S; i++) {
+        double c;
+        if (S <= 16 && l < (1 << S)) c = ((l >> i) & 1) ? 1.0 : -1.0;
+        else { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; c = (double)(int64_t)(lcg >> 11) / (double)(1ll << 52) - 1.0; }
+        const double ext = hi[(size_t)i] - lo[(size_t)i];
+        dirs[(size_t)l * S + i] = ext > 0 ? c / ext : 0.0;
+      }
+  }
+  auto furthest = [&](int l) {
+    const double *dir = &dirs[(size_t)l * S];
     int32_t arg = -1;
     double best = -std::numeric_limits<double>::infinity();
     for (int64_t v = 0; v < V; v++) {
       if (comp[(size_t)v] != big) continue;
       double d = 0;
-      for (int i = 0; i < S; i++) d += dir[(size_t)i] * r->states[(size_t)v * S + i];
+      for (int i = 0; i < S; i++) d += dir[i] * r->states[(size_t)v * S + i];
       if (d > best) { best = d; arg = (int32_t)v; }
     }
+    return arg;
+  };
+  std::vector<int32_t> first((size_t)n, -1);
+  {
+    const int Tn = std::max(1, std::min(T, n));
+    on_threads(Tn, [&](int t) { for (int l = t; l < n; l += Tn) first[(size_t)l] = furthest(l); });
+  }
+  for (int l = 0; l < 4 * n && (int)r->lm_v.size() < n; l++) {
+    const int32_t arg = l < n ? first[(size_t)l] : furthest(l);
     if (arg >= 0 && std::find(r->lm_v.begin(), r->lm_v.end(), arg) == r->lm_v.end()) r->lm_v.push_back(arg);
   }
   const int L = (int)r->lm_v.size();
   if (L == 0) return;
+  laps.lap("extremal vertices");
   r->lm_d.assign((size_t)V * L, std::numeric_limits<float>::infinity());
   // the distances: on the device (landmark_distances_device), or L Dijkstras on the host threads (TENDON_HIP_LANDMARKS=host, or when
   // the device path fails); TENDON_HIP_LANDMARKS=check builds both and keeps the host's if they differ in any bit
@@ -378,6 +455,7 @@ void build_landmarks(tr_roadmap *r, int n, int T) {
   const bool host_only = mode && std::strcmp(mode, "host") == 0, check = mode && std::strcmp(mode, "check") == 0;
   bool done = false;
   if (!host_only) done = landmark_distances_device(r);
+  laps.lap("distances");
   if (!done || check) {
     std::vector<float> dev;
     if (done) dev = r->lm_d;
@@ -436,27 +514,49 @@ int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, con
     tr_state_layout(ctx, &nt, &rot, &ret);
     r->NT = nt; r->rot = rot != 0; r->ret = ret != 0;
   }
+  Laps laps("tr_roadmap_create");
   r->states.assign(states, states + (size_t)n_vertices * r->S);
-  r->eu.resize((size_t)n_edges); r->ev.resize((size_t)n_edges); r->w.resize((size_t)n_edges);
-  std::vector<int64_t> deg((size_t)n_vertices + 1, 0);
-  for (int64_t e = 0; e < n_edges; e++) {
-    const int32_t a = edges[2 * e], b = edges[2 * e + 1];
-    if (a < 0 || a >= n_vertices || b < 0 || b >= n_vertices) { delete r; return TR_ERR_OUT_OF_RANGE; }
-    r->eu[(size_t)e] = a; r->ev[(size_t)e] = b;
-    // edge cost = opt_->motionCost = si->distance(a, b) unless the file supplies one (weightProperty_, :2598-2603)
-    r->w[(size_t)e] = weights ? weights[e] : state_distance(r, &r->states[(size_t)a * r->S], &r->states[(size_t)b * r->S]);
-    if (!(r->w[(size_t)e] >= 0)) { delete r; return TR_ERR_INVALID_ARG; }
-    deg[(size_t)a + 1]++; deg[(size_t)b + 1]++;
-  }
+  r->eu.resize_uninit((size_t)n_edges); r->ev.resize_uninit((size_t)n_edges); r->w.resize_uninit((size_t)n_edges);
+  // the edge arrays on T threads by edge ranges, the CSR adjacency by VERTEX ranges: every thread scans all edges in order and
+  // takes the arcs that leave its vertices, so a vertex's arcs keep the edge order whatever T is
+  const int T = n_edges >= (1 << 16) ? std::min(host_threads(0), 16) : 1;
+  std::atomic<int> bad{TR_OK};
+  on_threads(T, [&](int t) {
+    const int64_t lo = n_edges * t / T, hi = n_edges * (t + 1) / T;
+    for (int64_t e = lo; e < hi; e++) {
+      const int32_t a = edges[2 * e], b = edges[2 * e + 1];
+      if (a < 0 || a >= n_vertices || b < 0 || b >= n_vertices) { bad = TR_ERR_OUT_OF_RANGE; return; }
+      r->eu[(size_t)e] = a; r->ev[(size_t)e] = b;
+      // edge cost = opt_->motionCost = si->distance(a, b) unless the file supplies one (weightProperty_, :2598-2603)
+      r->w[(size_t)e] = weights ? weights[e] : state_distance(r, &r->states[(size_t)a * r->S], &r->states[(size_t)b * r->S]);
+      if (!(r->w[(size_t)e] >= 0)) { int want = TR_OK; bad.compare_exchange_strong(want, TR_ERR_INVALID_ARG); return; }
+    }
+  });
+  if (bad != TR_OK) { const int rc = bad; delete r; return rc; }
+  laps.lap("edges");
   r->adj_off.assign((size_t)n_vertices + 1, 0);
-  for (int64_t v = 0; v < n_vertices; v++) r->adj_off[(size_t)v + 1] = r->adj_off[(size_t)v] + deg[(size_t)v + 1];
-  r->adj.resize((size_t)r->adj_off[(size_t)n_vertices]);
-  std::vector<int64_t> fill(r->adj_off.begin(), r->adj_off.end() - 1);
-  for (int64_t e = 0; e < n_edges; e++) {
-    const int32_t a = r->eu[(size_t)e], b = r->ev[(size_t)e];
-    r->adj[(size_t)fill[(size_t)a]++] = Arc{b, (int32_t)e, r->w[(size_t)e]};
-    r->adj[(size_t)fill[(size_t)b]++] = Arc{a, (int32_t)e, r->w[(size_t)e]};
-  }
+  on_threads(T, [&](int t) {
+    const int32_t vlo = (int32_t)(n_vertices * t / T), vhi = (int32_t)(n_vertices * (t + 1) / T);
+    for (int64_t e = 0; e < n_edges; e++) {
+      const int32_t a = r->eu[(size_t)e], b = r->ev[(size_t)e];
+      if (a >= vlo && a < vhi) r->adj_off[(size_t)a + 1]++;
+      if (b >= vlo && b < vhi) r->adj_off[(size_t)b + 1]++;
+    }
+  });
+  for (int64_t v = 0; v < n_vertices; v++) r->adj_off[(size_t)v + 1] += r->adj_off[(size_t)v];
+  r->adj.resize_uninit((size_t)r->adj_off[(size_t)n_vertices]);
+  laps.lap("degrees");
+  on_threads(T, [&](int t) {
+    const int32_t vlo = (int32_t)(n_vertices * t / T), vhi = (int32_t)(n_vertices * (t + 1) / T);
+    if (vlo == vhi) return;
+    std::vector<int64_t> fill(r->adj_off.begin() + vlo, r->adj_off.begin() + vhi);
+    for (int64_t e = 0; e < n_edges; e++) {
+      const int32_t a = r->eu[(size_t)e], b = r->ev[(size_t)e];
+      if (a >= vlo && a < vhi) r->adj[(size_t)fill[(size_t)(a - vlo)]++] = Arc{b, (int32_t)e, r->w[(size_t)e]};
+      if (b >= vlo && b < vhi) r->adj[(size_t)fill[(size_t)(b - vlo)]++] = Arc{a, (int32_t)e, r->w[(size_t)e]};
+    }
+  });
+  laps.lap("adjacency");
   r->vstat.assign((size_t)n_vertices, V_UNKNOWN); r->estat.assign((size_t)n_edges, V_UNKNOWN);
   r->vpresent.assign((size_t)n_vertices, 1); r->epresent.assign((size_t)n_edges, 1);
   *out = r;

@@ -588,6 +588,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     if (e != hipSuccess) return fail(ctx, TR_ERR_HIP, std::string("retraction order: ") + hipGetErrorString(e));
     HIP_TRY(ctx, hipMemsetAsync(d_bits, 0, (size_t)((n + 63) / 64) * sizeof(uint64_t), s));
   }
+  a.finish_hot();
   HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
   HIP_TRY(ctx, hipMemsetAsync(fb_count, 0, sizeof(uint32_t), s));
   // the fallback pass sweeps columns of the small point workspace

@@ -24,7 +24,20 @@
 
 namespace trk {
 
-struct VerdictArgs {
+// What EVERY observed point reads, in one 128-byte block at the head of the argument block: two wide scalar loads per
+// point instead of a dozen narrow ones with a wait each (finish_hot() fills it from the fields below, on the host).
+struct VerdictHot {
+  double box[6];                  // VerdictArgs::box
+  double org[3], inv_d[3];        // g.xmin, g.ymin, g.zmin; g.inv_dx, g.inv_dy, g.inv_dz
+  const uint64_t *near_grid;      // always a readable grid of Nb^3 words (the obstacle grid itself when use_near is 0)
+  int32_t Nb, rot_is_identity, P, CH;
+  int32_t use_near;               // 0: no dilated grid, or debug bit 2 (the fast path of the voxel walk is off)
+  int32_t pad_;
+};
+static_assert(sizeof(VerdictHot) == 128, "one 128-byte block");
+
+struct alignas(128) VerdictArgs {
+  VerdictHot hot;
   int P, CH, NM, pad0_;
   uint32_t debug, pad1_;
   double box[6];                  // the margin box of sweep_body: {x0, x1, y0, y1, z0, z1} = limits -+ 1e-6 of the extent (same expressions, formed on the host)
@@ -54,6 +67,15 @@ struct VerdictArgs {
   // the robot's length limits and home lengths (RobotK's): read here after the loop, so that the kernel's RobotK argument
   // keeps nothing but the stiffness constants live across it
   double home_Li[TRK_MAX_TENDONS], min_len[TRK_MAX_TENDONS], max_len[TRK_MAX_TENDONS];
+
+  __host__ void finish_hot() {
+    for (int q = 0; q < 6; q++) hot.box[q] = box[q];
+    hot.org[0] = g.xmin; hot.org[1] = g.ymin; hot.org[2] = g.zmin;
+    hot.inv_d[0] = g.inv_dx; hot.inv_d[1] = g.inv_dy; hot.inv_d[2] = g.inv_dz;
+    hot.use_near = (near_grid != nullptr && !(debug & 4u)) ? 1 : 0;
+    hot.near_grid = hot.use_near ? near_grid : grid;
+    hot.Nb = g.Nb; hot.rot_is_identity = g.rot_is_identity; hot.P = P; hot.CH = CH;
+  }
 };
 
 constexpr int VQ = 128;           // ring of deferred segments per wave
@@ -62,12 +84,14 @@ constexpr int VQ = 128;           // ring of deferred segments per wave
 // keeps the accesses in the LDS address space -- ds_read / ds_write -- instead of falling back to flat accesses).
 //   doubles [0, 192)           prev[3][64]     previous point (as produced, before the environment rotation)
 //   doubles [192, 192 + 6 VQ)  qe[6][VQ]       deferred segments: rotated end points a, b
-//   words from 2 * (192 + 6 VQ):  qowner[VQ] | cell[3][64] | inprev[64] | hitflag[64] | dist[64] | delta[64] (SPH) | milestones float[4][NM][64]
+//   words from 2 * (192 + 6 VQ):  qowner[VQ] | cell[3][64] | inprev[64] | hitflag[64] | dist[64] | delta[64] (SPH) / nearw[64] | milestones float[4][NM][64]
 extern __shared__ double vlds[];
 constexpr int VL_QE = 3 * 64;
 constexpr int VL_W0 = 2 * (VL_QE + 6 * VQ);
 constexpr int VL_QOWNER = VL_W0, VL_CELL = VL_QOWNER + VQ, VL_INPREV = VL_CELL + 3 * 64, VL_HIT = VL_INPREV + 64,
               VL_DIST = VL_HIT + 64, VL_DELTA = VL_DIST + 64, VL_MS = VL_DELTA + 64;
+// voxel checker: delta[] is unused and holds the requested half of the dilated-grid word of the previous point's block instead
+constexpr int VL_NEARW = VL_DELTA;
 // with signatures (edge samples) the tile of SigStage (sweep_kernel.hpp) follows the milestones: 18 176 + 2 304 B = exactly
 // 20 KiB per wave at NM = 8, eight waves per CU still fit the 160 KiB
 __host__ __device__ inline size_t verdict_lds_bytes(int NM, bool with_sig = false) {
@@ -88,7 +112,6 @@ __host__ __device__ inline size_t verdict_lds_bytes(int NM, bool with_sig = fals
 template <bool SPH, bool SIG = false>
 struct PointSweep {
   const VerdictArgs *va;
-  uint64_t near_prev;             // dilated-grid word of the previous point's block (requested one point ahead)
   float dn_prev;                  // SPH: distance-field value at the previous point's cell (requested one point ahead)
   uint32_t sph_state;             // SPH: bit 0 = the previous point awaits its classification, bit 1 = it lies inside the closed domain
   int qhead, qcount;              // wave-uniform
@@ -199,7 +222,7 @@ struct PointSweep {
     VL_F(VL_DELTA + threadIdx.x) = sqrtf(ex * ex + ey * ey + ez * ez) * 1.000001f;
   }
 
-  // SPH: the last point's classification (its field value was requested when it was produced), after the RK4 loop
+  // after the RK4 loop.  SPH: the last point's classification (its field value was requested when it was produced)
   __device__ __forceinline__ void finish() {
 #pragma clang fp contract(off)
     if constexpr (SPH) {
@@ -233,7 +256,88 @@ struct PointSweep {
         qcount += __popcll(wm);
       }
       VL_BARRIER();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the last point's request (voxel_test) must have landed in LDS before the wave moves on
     }
+  }
+
+  // Point q in the voxel frame (qr), whether it lies strictly inside the margin box, its voxel coordinates t and its cell c by
+  // truncation (inside the box the coordinates are in (0, N): floor == truncation, no range checks).  Straight-line code from
+  // the hot block -- no short-circuit chains, whose every link costs a scalar load and a wait.  For ALL lanes: the cell also
+  // serves the point's signature.
+  __device__ __forceinline__ void point_cell(const VerdictArgs &a, const V3 &q, V3 &qr, bool &in_q, int (&c)[3], double (&t)[3]) const {
+#pragma clang fp contract(off)
+    const VerdictHot &h = a.hot;
+    qr = q;
+    if (!h.rot_is_identity) {
+      const GridK &g = a.g;
+      qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
+      qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
+      qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
+    }
+    in_q = (qr.x > h.box[0]) & (qr.x < h.box[1]) & (qr.y > h.box[2]) & (qr.y < h.box[3]) & (qr.z > h.box[4]) & (qr.z < h.box[5]);
+    t[0] = (qr.x - h.org[0]) * h.inv_d[0]; t[1] = (qr.y - h.org[1]) * h.inv_d[1]; t[2] = (qr.z - h.org[2]) * h.inv_d[2];
+    c[0] = (int)t[0]; c[1] = (int)t[1]; c[2] = (int)t[2];
+  }
+
+  // cell_signature(x, y, z) from what point_cell has formed: inside the margin box the point is inside the closed domain and
+  // finite, t is cell_signature's product with the rounded reciprocal and c its truncation -- the same fast path, decided by
+  // the same test (no voxel coordinate within 1e-9 of an integer); every other point takes the function itself.
+  __device__ __forceinline__ uint32_t signature_of(const VerdictArgs &a, bool in_q, const int (&c)[3], const double (&t)[3],
+                                                   double x, double y, double z) const {
+#pragma clang fp contract(off)
+    const double fx = t[0] - (double)c[0], fy = t[1] - (double)c[1], fz = t[2] - (double)c[2];
+    const double lo = 1e-9, hi = 1.0 - 1e-9;
+    const bool plain = in_q & (fx > lo) & (fx < hi) & (fy > lo) & (fy < hi) & (fz > lo) & (fz < hi);
+    uint32_t sg = ((uint32_t)c[0] & 1023u) | (((uint32_t)c[1] & 1023u) << 10) | (((uint32_t)c[2] & 1023u) << 20);
+    if (!plain) sg = cell_signature(x, y, z, a.g);
+    return sg;
+  }
+
+  // The voxel test of the segment that ends in the point of cell c: "the end cells differ by at most one per axis and the
+  // START cell is free in the dilated grid" -- then the segment cannot touch an occupied cell -- and the request for the
+  // dilated word of c's block (consumed one point later).  Returns true when the segment needs the full reference walk
+  // (queued by the caller).  `first`: the lane's point 0 (nothing to test; the LDS words read are then stale and unused).
+  __device__ __forceinline__ bool voxel_test(const VerdictHot &h, bool first, bool in_q, const int (&c)[3]) {
+    const int lane = threadIdx.x;
+    const int cqx = c[0], cqy = c[1], cqz = c[2];
+    const bool use_near = h.use_near != 0;
+    const uint32_t was_in = VL_U(VL_INPREV + lane);
+    const int cpx = VL_I(VL_CELL + lane), cpy = VL_I(VL_CELL + 64 + lane), cpz = VL_I(VL_CELL + 128 + lane);
+    const uint32_t ex = (uint32_t)(cqx - cpx + 1), ey = (uint32_t)(cqy - cpy + 1), ez = (uint32_t)(cqz - cpz + 1);   // 0, 1, 2: neighbours
+    const uint32_t emax = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
+    // the half of the dilated-grid word of the previous point's block that holds its cell's bit: requested when that point
+    // was produced, delivered straight into LDS (no register lives across the RK4 step for it)
+    const uint32_t bit = (uint32_t)(((cpx & 1) << 4) | ((cpy & 3) << 2) | (cpz & 3));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the compiler does not order LDS reads after loads into LDS; a whole RK4 step has passed)
+    uint32_t near_bit = (VL_U(VL_NEARW + lane) >> bit) & 1u;
+    const bool start_free = use_near & (near_bit == 0u);
+    // otherwise (also at the domain boundary): the full reference path, in the flush
+    const bool need = !first & !((was_in != 0u) & in_q & (emax <= 2u) & start_free);
+    VL_I(VL_CELL + lane) = cqx; VL_I(VL_CELL + 64 + lane) = cqy; VL_I(VL_CELL + 128 + lane) = cqz;
+    VL_U(VL_INPREV + lane) = in_q ? 1u : 0u;
+    {
+      // request the half word of q's block for the next point: a global load whose destination is LDS word nearw[lane]
+      // (global_load_lds_dword; counted by vmcnt, no destination register), half word 0 for lanes outside the box, whose
+      // next segment takes the full path anyway.  The empty asm orders it after the read of the old word above.
+      const uint32_t nb = (uint32_t)h.Nb;
+      uint32_t w = (((uint32_t)cqx >> 2) * nb + ((uint32_t)cqy >> 2)) * nb + ((uint32_t)cqz >> 2);
+      w = in_q ? 2u * w + (((uint32_t)cqx >> 1) & 1u) : 0u;
+      asm volatile("" : "+v"(w) : "v"(near_bit));
+      typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)h.near_grid + w,
+                                       (lds_u32_ptr)((uint32_t *)vlds + VL_NEARW), 4, 0, 0);
+    }
+    return need;
+  }
+
+  // the previous point in the voxel frame, for a segment that is queued (rare: the rotation is not spent on every point)
+  __device__ __forceinline__ V3 to_voxel_frame(const VerdictArgs &a, const V3 &p) const {
+#pragma clang fp contract(off)
+    if (a.hot.rot_is_identity) return p;
+    const GridK &g = a.g;
+    return V3{g.inv_rot[0] * p.x + g.inv_rot[1] * p.y + g.inv_rot[2] * p.z, g.inv_rot[3] * p.x + g.inv_rot[4] * p.y + g.inv_rot[5] * p.z,
+              g.inv_rot[6] * p.x + g.inv_rot[7] * p.y + g.inv_rot[8] * p.z};
   }
 
   // point j of the lane's backbone (j = 0 .. P-1, in order)
@@ -249,20 +353,28 @@ struct PointSweep {
     if (j > 0) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(VL_DIST + lane); }
     {
       const float dx = (float)(q.x - pv.x), dy = (float)(q.y - pv.y), dz = (float)(q.z - pv.z);
-      d += sqrtf(dx * dx + dy * dy + dz * dz);
+      d += __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);   // v_sqrt_f32 (1 ulp): the proof keeps 1e-6 m of slack over ~1e-8 m of rounding
       VL_F(VL_DIST + lane) = d;
     }
-    if (j == ms_next || j == a.P - 1) {                     // wave-uniform: every CH-th point and the tip
-      const int CH_ = a.CH, P_ = a.P;                       // (from the argument block: they hold no registers between milestones)
-      const int k = (j == P_ - 1) ? (P_ - 1 + CH_ - 1) / CH_ : ms_k;
-      const int o = VL_MS + k * 64 + lane, pl = a.NM * 64;
+    if (j == ms_next) {                                     // wave-uniform: every CH-th point and the tip (ms_next = min(k CH, P - 1))
+      const int CH_ = a.hot.CH, P_ = a.hot.P;               // (from the argument block: they hold no registers between milestones)
+      const int o = VL_MS + ms_k * 64 + lane, pl = a.NM * 64;     // the tip's slot: ceil((P - 1) / CH) = the count of milestones before it
       VL_F(o) = (float)q.x; VL_F(o + pl) = (float)q.y; VL_F(o + 2 * pl) = (float)q.z; VL_F(o + 3 * pl) = d;
-      if (j == ms_next) { ms_next += CH_; ms_k++; }
+      ms_next = (ms_next + CH_ < P_ - 1) ? ms_next + CH_ : P_ - 1;
+      ms_k++;
     }
     VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
-    if constexpr (SIG) sig_put(a, j, true, cell_signature(x, y, z, g), sig_own_row(), 0);
     bool need = false;
     V3 pr = pv, qr = q;
+    bool in_q = false;
+    int cq[3] = {0, 0, 0};
+    if constexpr (!SPH) {
+      double tq[3];
+      point_cell(a, q, qr, in_q, cq, tq);
+      if constexpr (SIG) sig_put(a, j, true, signature_of(a, in_q, cq, tq, x, y, z), sig_own_row(), 0);
+    } else {
+      if constexpr (SIG) sig_put(a, j, true, cell_signature(x, y, z, g), sig_own_row(), 0);
+    }
     if constexpr (SPH) {
       if (active && !VL_U(VL_HIT + lane)) {
         // the previous point's field value has arrived: far from every occupied centre, certainly within r of one, or
@@ -282,37 +394,11 @@ struct PointSweep {
         if (!VL_U(VL_HIT + lane)) request(a, q);
       }
     } else
-    if (active && !VL_U(VL_HIT + lane)) {
-      if (!g.rot_is_identity) {
-        qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
-        qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
-        qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
-        pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
-        pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
-        pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
-      }
-      const bool in_q = qr.x > a.box[0] && qr.x < a.box[1] && qr.y > a.box[2] && qr.y < a.box[3] && qr.z > a.box[4] && qr.z < a.box[5];
-      const V3 Bq = {(qr.x - g.xmin) * g.inv_dx, (qr.y - g.ymin) * g.inv_dy, (qr.z - g.zmin) * g.inv_dz};
-      // inside the margin box the voxel coordinates are in (0, N): floor == truncation, no range checks
-      const int cqx = (int)Bq.x, cqy = (int)Bq.y, cqz = (int)Bq.z;
-      const bool use_near = a.near_grid != nullptr && !(a.debug & 4u);
-      if (j > 0) {
-        need = true;                                        // at the domain boundary: the full reference path, in the flush
-        if (VL_U(VL_INPREV + lane) && in_q) {
-          const int cpx = VL_I(VL_CELL + lane), cpy = VL_I(VL_CELL + 64 + lane), cpz = VL_I(VL_CELL + 128 + lane);
-          const int ddx = cqx - cpx, ddy = cqy - cpy, ddz = cqz - cpz;
-          const bool nearby = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1;
-          const bool start_free = use_near && !((near_prev >> (((cpx & 3) << 4) | ((cpy & 3) << 2) | (cpz & 3))) & 1ull);
-          need = !(nearby && start_free);
-        }
-      }
-      VL_I(VL_CELL + lane) = cqx; VL_I(VL_CELL + 64 + lane) = cqy; VL_I(VL_CELL + 128 + lane) = cqz;
-      VL_U(VL_INPREV + lane) = in_q ? 1u : 0u;
-      if (use_near && in_q) near_prev = a.near_grid[((size_t)(cqx >> 2) * g.Nb + (cqy >> 2)) * g.Nb + (cqz >> 2)];
-    }
+    if (active && !VL_U(VL_HIT + lane)) need = voxel_test(a.hot, j == 0, in_q, cq);
     const unsigned long long wm = __ballot(need);
     if (wm) {
       if (need) {
+        if constexpr (!SPH) pr = to_voxel_frame(a, pv);
         const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
         VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
         if constexpr (!SPH) { VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z; }
@@ -341,12 +427,18 @@ struct PointSweep {
     V3 pv = q;
     bool need = false;
     V3 pr = pv, qr = q;
+    bool in_q = false;
+    int cq[3] = {0, 0, 0};
+    double tq[3] = {0.0, 0.0, 0.0};
+    if constexpr (!SPH) point_cell(a, q, qr, in_q, cq, tq);          // (idle lanes: whatever their registers hold -- every use is under `on`)
     if constexpr (SIG) {
       // signatures sit in tip-aligned rows like the rows of K1r's stored points.  A lane's first two points come in rows of
       // its own (wave_row false): stored directly, two words per lane; from its third point on the row is the wave's and
       // the words go through the tile (SigStage::first_row = the lane's base row + 2 keeps stale tile words of earlier rows
       // from reaching this lane's row)
-      const uint32_t sg = on ? cell_signature(x, y, z, g) : 0u;
+      uint32_t sg = 0u;
+      if constexpr (!SPH) sg = on ? signature_of(a, in_q, cq, tq, x, y, z) : 0u;
+      else sg = on ? cell_signature(x, y, z, g) : 0u;
       if (!wave_row) {
         if (on && sig_row_of >= 0) a.sig[(int64_t)sig_row_of * a.sig_stride + row] = sg;
         if (first) sig_first_row = row + 2;
@@ -358,7 +450,7 @@ struct PointSweep {
       pr = pv;
       {
         const float dx = (float)(q.x - pv.x), dy = (float)(q.y - pv.y), dz = (float)(q.z - pv.z);
-        d += sqrtf(dx * dx + dy * dy + dz * dz);
+        d += __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);   // v_sqrt_f32 (1 ulp): the proof keeps 1e-6 m of slack over ~1e-8 m of rounding
         VL_F(VL_DIST + lane) = d;
       }
       {
@@ -391,37 +483,12 @@ struct PointSweep {
           if (!VL_U(VL_HIT + lane)) request(a, q);
         }
       } else
-      if (active && !VL_U(VL_HIT + lane)) {
-        if (!g.rot_is_identity) {
-          qr.x = g.inv_rot[0] * q.x + g.inv_rot[1] * q.y + g.inv_rot[2] * q.z;
-          qr.y = g.inv_rot[3] * q.x + g.inv_rot[4] * q.y + g.inv_rot[5] * q.z;
-          qr.z = g.inv_rot[6] * q.x + g.inv_rot[7] * q.y + g.inv_rot[8] * q.z;
-          pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
-          pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
-          pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
-        }
-        const bool in_q = qr.x > a.box[0] && qr.x < a.box[1] && qr.y > a.box[2] && qr.y < a.box[3] && qr.z > a.box[4] && qr.z < a.box[5];
-        const V3 Bq = {(qr.x - g.xmin) * g.inv_dx, (qr.y - g.ymin) * g.inv_dy, (qr.z - g.zmin) * g.inv_dz};
-        const int cqx = (int)Bq.x, cqy = (int)Bq.y, cqz = (int)Bq.z;
-        const bool use_near = a.near_grid != nullptr && !(a.debug & 4u);
-        if (!first) {
-          need = true;
-          if (VL_U(VL_INPREV + lane) && in_q) {
-            const int cpx = VL_I(VL_CELL + lane), cpy = VL_I(VL_CELL + 64 + lane), cpz = VL_I(VL_CELL + 128 + lane);
-            const int ddx = cqx - cpx, ddy = cqy - cpy, ddz = cqz - cpz;
-            const bool nearby = ddx >= -1 && ddx <= 1 && ddy >= -1 && ddy <= 1 && ddz >= -1 && ddz <= 1;
-            const bool start_free = use_near && !((near_prev >> (((cpx & 3) << 4) | ((cpy & 3) << 2) | (cpz & 3))) & 1ull);
-            need = !(nearby && start_free);
-          }
-        }
-        VL_I(VL_CELL + lane) = cqx; VL_I(VL_CELL + 64 + lane) = cqy; VL_I(VL_CELL + 128 + lane) = cqz;
-        VL_U(VL_INPREV + lane) = in_q ? 1u : 0u;
-        if (use_near && in_q) near_prev = a.near_grid[((size_t)(cqx >> 2) * g.Nb + (cqy >> 2)) * g.Nb + (cqz >> 2)];
-      }
+      if (active && !VL_U(VL_HIT + lane)) need = voxel_test(a.hot, first, in_q, cq);
     }
     const unsigned long long wm = __ballot(need);
     if (wm) {
       if (need) {
+        if constexpr (!SPH) pr = to_voxel_frame(a, pv);
         const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
         VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
         if constexpr (!SPH) { VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z; }
@@ -448,7 +515,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
   PointSweep<SPH, SIG> ps;
   ps.va = va;
   ps.dn_prev = 0.0f; ps.sph_state = 0u;
-  ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
+  ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
   VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
   {
@@ -562,7 +629,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
   PointSweep<SPH, SIG> ps;
   ps.va = va;
   ps.dn_prev = 0.0f; ps.sph_state = 0u;
-  ps.near_prev = 0; ps.qhead = 0; ps.qcount = 0; ps.active = false;
+  ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = 0; ps.ms_next = 0; ps.ms_k = 0;
   const int32_t *__restrict__ perm = va->perm;
   {

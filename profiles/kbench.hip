@@ -18,6 +18,11 @@
 #include "fk_kernel.hpp"
 #ifdef KB_VERDICT
 #include "verdict_kernel.hpp"     // -DKB_VERDICT: time fk_verdict<N> (the per-point sweep hook in the loop) against an EMPTY 256^3 grid
+#ifdef KB_SIG                     // -DKB_VERDICT -DKB_SIG: the edge samples' form, which also writes every point's cell signature
+constexpr bool kSig = true;
+#else
+constexpr bool kSig = false;
+#endif
 #endif
 
 #ifndef KB_N
@@ -81,7 +86,11 @@ int main() {
     steps.push_back(StepK{dL, k + 1, 0});
     for (int q = 0; q < 3; q++) routing_at(N, C, D, tk + 0.5 * q * dL, &tab[(size_t)(1 + 3 * k + q) * N * 6]);
   }
+#ifdef KB_COUNT                   // -DKB_COUNT=<n>: a launch that is not a whole number of rounds of the chip's 2048 wave slots
+  const int64_t n = KB_COUNT;
+#else
   const int64_t n = (int64_t)1 << KB_LOG2;
+#endif
   std::vector<double> st((size_t)n * N);
   unsigned long long lcg = 88172645463325252ull;
   const double tmax = N == 3 ? 10.0 : 20.0;
@@ -101,20 +110,23 @@ int main() {
   for (int q = 0; q < 3; q++) { va.box[2 * q] = -0.25 + 1e-6 * 0.5; va.box[2 * q + 1] = 0.25 - 1e-6 * 0.5; }
   uint64_t *d_grid, *d_bits; int32_t *d_fb; uint32_t *d_fbc; trk::VerdictArgs *d_va;
   CK(hipMalloc(&d_grid, (size_t)64 * 64 * 64 * 8 * 2)); CK(hipMemset(d_grid, 0, (size_t)64 * 64 * 64 * 8 * 2));
-  CK(hipMalloc(&d_bits, (size_t)n / 8)); CK(hipMalloc(&d_fb, (size_t)n * 4)); CK(hipMalloc(&d_fbc, 4)); CK(hipMemset(d_fbc, 0, 4));
+  CK(hipMalloc(&d_bits, (size_t)((n + 63) / 64) * 8)); CK(hipMalloc(&d_fb, (size_t)n * 4)); CK(hipMalloc(&d_fbc, 4)); CK(hipMemset(d_fbc, 0, 4));
   va.grid = d_grid; va.near_grid = d_grid + 64 * 64 * 64; va.valid_bits = d_bits; va.fb_list = d_fb; va.fb_count = d_fbc;
   va.radius = K.radius;
+  uint32_t *d_sig = nullptr;
+  if (kSig) { va.sig_stride = (129 + 15) / 16 * 16; CK(hipMalloc(&d_sig, (size_t)n * va.sig_stride * 4)); va.sig = d_sig; }
   for (int j = 0; j < N; j++) { va.min_len[j] = K.min_len[j] = -1.0; va.max_len[j] = K.max_len[j] = 1.0; va.home_Li[j] = K.home_Li[j] = L; }
+  va.finish_hot();
   CK(hipMalloc(&d_va, sizeof(va))); CK(hipMemcpy(d_va, &va, sizeof(va), hipMemcpyHostToDevice));
-  const size_t lds = trk::verdict_lds_bytes(va.NM);
+  const size_t lds = trk::verdict_lds_bytes(va.NM, kSig);
 #endif
   std::vector<float> ms;
   for (int r = 0; r < KB_REPS + 2; r++) {
     CK(hipEventRecord(a));
 #ifdef KB_VERDICT
-    hipLaunchKernelGGL((trk::fk_verdict<N, false, false, false>), dim3((unsigned)(n / 64)), dim3(64), lds, nullptr, d_st, n, K, d_tab, d_steps, 128, d_tips, d_va);
+    hipLaunchKernelGGL((trk::fk_verdict<N, false, false, kSig>), dim3((unsigned)((n + 63) / 64)), dim3(64), lds, nullptr, d_st, n, K, d_tab, d_steps, 128, d_tips, d_va);
 #else
-    hipLaunchKernelGGL((trk::rk4_only<N>), dim3((unsigned)(n / 64)), dim3(64), 0, nullptr, d_st, n, K, d_tab, d_steps, 128, d_tips);
+    hipLaunchKernelGGL((trk::rk4_only<N>), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, nullptr, d_st, n, K, d_tab, d_steps, 128, d_tips);
 #endif
     CK(hipEventRecord(b)); CK(hipEventSynchronize(b));
     float t; CK(hipEventElapsedTime(&t, a, b));
@@ -126,9 +138,9 @@ int main() {
   std::sort(ms.begin(), ms.end());
   hipFuncAttributes fa;
 #ifdef KB_VERDICT
-  CK(hipFuncGetAttributes(&fa, (const void *)trk::fk_verdict<N, false, false, false>));
+  CK(hipFuncGetAttributes(&fa, (const void *)trk::fk_verdict<N, false, false, kSig>));
   {
-    std::vector<uint64_t> bits((size_t)n / 64);
+    std::vector<uint64_t> bits((size_t)((n + 63) / 64));
     CK(hipMemcpy(bits.data(), d_bits, bits.size() * 8, hipMemcpyDeviceToHost));
     uint32_t fbc = 0; CK(hipMemcpy(&fbc, d_fbc, 4, hipMemcpyDeviceToHost));
     long valid = 0; for (uint64_t w : bits) valid += __builtin_popcountll(w);
@@ -137,7 +149,7 @@ int main() {
 #else
   CK(hipFuncGetAttributes(&fa, (const void *)trk::rk4_only<N>));
 #endif
-  std::printf("N=%d n=2^%d waves/SIMD<=%d: best %.3f ms  median %.3f ms  -> %.4g FK/s   regs %d  scratch %zu B   tips sum %.17g abs %.17g\n", N, KB_LOG2, KB_WAVES,
+  std::printf("N=%d n=%ld (2^%d unless KB_COUNT) waves/SIMD<=%d: best %.3f ms  median %.3f ms  -> %.4g FK/s   regs %d  scratch %zu B   tips sum %.17g abs %.17g\n", N, (long)n, KB_LOG2, KB_WAVES,
               ms.front(), ms[ms.size() / 2], (double)n / (ms.front() * 1e-3), fa.numRegs, (size_t)fa.localSizeBytes, sum, asum);
   return 0;
 }
