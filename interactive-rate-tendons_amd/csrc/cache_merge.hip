@@ -4,6 +4,7 @@
 // HBM-bound integer work: ~16 B per entry per sort pass, (id_bits + edge_bits) / 8 passes.
 #include "cache_merge.hpp"
 
+#include <cstdlib>
 #include <cstring>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_segmented_radix_sort.hpp>
@@ -30,12 +31,16 @@ __global__ __launch_bounds__(256) void merge_item_keys(const int32_t *__restrict
 __global__ __launch_bounds__(256) void merge_counts(const int32_t *__restrict__ counts, const int32_t *__restrict__ src,
                                                     const uint32_t *__restrict__ ekey, const int32_t *__restrict__ order,
                                                     int64_t n_items, int64_t *__restrict__ cnt, int32_t *__restrict__ rank,
-                                                    unsigned long long *__restrict__ etot, uint64_t *__restrict__ scalars) {
+                                                    unsigned long long *__restrict__ etot, uint64_t *__restrict__ scalars,
+                                                    int32_t *__restrict__ ibeg, int32_t *__restrict__ iend) {
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= n_items) return;
   const int32_t i = order[p];
   rank[i] = (int32_t)p;
   if ((int32_t)ekey[p] < 0) { cnt[p] = 0; return; }
+  // the edge's run of grouped positions [ibeg, iend) (both zeroed by the host: an edge without items keeps an empty run)
+  if (p == 0 || ekey[p - 1] != ekey[p]) ibeg[ekey[p]] = (int32_t)p;
+  if (p == n_items - 1 || ekey[p + 1] != ekey[p]) iend[ekey[p]] = (int32_t)(p + 1);
   const int c = counts[src ? src[i] : i];
   if (c < 0) scalars[1] = 1;
   cnt[p] = c > 0 ? c : 0;
@@ -121,6 +126,101 @@ __global__ __launch_bounds__(256) void knn_edge_unpack(const uint64_t *__restric
   edges[2 * t + 1] = (int32_t)(keys[t] & 0xffffffffull);
 }
 
+
+// The union of an edge's block lists in ONE kernel, a wave per edge: every (block id, mask) entry of the edge's items goes
+// into an open-addressing hash table in LDS (compare-and-swap claims the slot of a block id, an atomic OR adds the mask),
+// the occupied slots are gathered, ordered by block id with a bitonic sort in LDS and written as the edge's list into its
+// segment of the entry arrays (the segment holds all its entries, so the duplicate-free list fits).  It replaces the gather
+// of the entries into segments, the segmented radix sort and the reduce-by-key (~11 ms of a 588 k-edge roadmap's 17 ms of
+// voxelise-and-merge; the sort path below stays as the fallback for an edge with more than EU_MAXLOAD distinct blocks).
+constexpr int EU_SLOTS = 512, EU_MAXLOAD = 384;
+constexpr uint32_t EU_EMPTY = 0xffffffffu;          // no block has this id (ids < Nb^3 <= 2^30)
+
+__global__ __launch_bounds__(64) void edge_union(const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int32_t *__restrict__ counts,
+                                                 const int32_t *__restrict__ src, const int32_t *__restrict__ ibeg, const int32_t *__restrict__ iend,
+                                                 const int32_t *__restrict__ order, int64_t ld, const unsigned long long *__restrict__ eoff_in, uint32_t *__restrict__ tmp_ids,
+                                                 uint64_t *__restrict__ tmp_masks, int32_t *__restrict__ ecount, uint64_t *__restrict__ scalars) {
+  __shared__ uint32_t tkey[EU_SLOTS];
+  __shared__ unsigned long long tmask[EU_SLOTS];
+  __shared__ uint32_t lid[EU_SLOTS];
+  __shared__ unsigned long long lmask[EU_SLOTS];
+  __shared__ int s_unique, s_ovf;
+  const int64_t e = blockIdx.x;
+  const int lane = threadIdx.x;
+  for (int s = lane; s < EU_SLOTS; s += 64) { tkey[s] = EU_EMPTY; tmask[s] = 0ull; }
+  if (lane == 0) { s_unique = 0; s_ovf = 0; }
+  __syncthreads();
+  const int64_t p0 = ibeg[e], p1 = iend[e];         // (a binary search of the grouped keys here was most of the kernel: 44 dependent loads per wave)
+  // eight items at a time, eight lanes each (an item holds ~35 entries: eight lanes waste few turns on its last round, and
+  // the items of an edge are mostly neighbouring pool slots -- neighbouring columns, so one row of eight items is one 32-byte read)
+  const int grp = lane >> 3, gl = lane & 7;
+  for (int64_t p = p0 + grp; p < p1; p += 8) {
+    const int32_t i = order[p];
+    const int64_t col = src ? src[i] : i;
+    const int c = counts[col];
+    for (int k = gl; k < c; k += 8) {
+      const uint32_t id = ids[(int64_t)k * ld + col];
+      const unsigned long long m = masks[(int64_t)k * ld + col];
+      uint32_t h = (id * 2654435761u) >> 23;                       // 9 bits
+      int probe = 0;
+      for (; probe < EU_SLOTS; probe++) {
+        const uint32_t old = atomicCAS(&tkey[h], EU_EMPTY, id);
+        if (old == EU_EMPTY) atomicAdd(&s_unique, 1);
+        if (old == EU_EMPTY || old == id) { atomicOr(&tmask[h], m); break; }
+        h = (h + 1) & (EU_SLOTS - 1);
+      }
+      if (probe == EU_SLOTS) s_ovf = 1;                             // the table is full
+    }
+  }
+  __syncthreads();
+  if (s_ovf != 0 || s_unique > EU_MAXLOAD) {
+    if (lane == 0) { ecount[e] = 0; atomicOr((unsigned long long *)&scalars[1], 2ull); }
+    return;
+  }
+  // the occupied slots, densely
+  int n = 0;
+  for (int s0 = 0; s0 < EU_SLOTS; s0 += 64) {
+    const uint32_t key = tkey[s0 + lane];
+    const bool occ = key != EU_EMPTY;
+    const unsigned long long b = __ballot(occ);
+    if (occ) {
+      const int pos = n + __popcll(b & (((unsigned long long)1 << lane) - 1));
+      lid[pos] = key; lmask[pos] = tmask[s0 + lane];
+    }
+    n += __popcll(b);
+  }
+  int np2 = 1;
+  while (np2 < n) np2 <<= 1;
+  for (int t = n + lane; t < np2; t += 64) lid[t] = EU_EMPTY;        // padding sorts to the end
+  __syncthreads();
+  for (int k = 2; k <= np2; k <<= 1)
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int t = lane; t < (np2 >> 1); t += 64) {
+        const int a = ((t & ~(j - 1)) << 1) | (t & (j - 1)), b = a | j;
+        const bool up = (a & k) == 0;
+        const uint32_t ia = lid[a], ib = lid[b];
+        if ((ia > ib) == up) {
+          const unsigned long long ma = lmask[a], mb = lmask[b];
+          lid[a] = ib; lid[b] = ia; lmask[a] = mb; lmask[b] = ma;
+        }
+      }
+      __syncthreads();
+    }
+  const int64_t base = (int64_t)eoff_in[e];
+  for (int t = lane; t < n; t += 64) { tmp_ids[base + t] = lid[t]; tmp_masks[base + t] = lmask[t]; }
+  if (lane == 0) ecount[e] = n;
+}
+
+// the edges' lists from their segments to their final, contiguous places: a wave per edge
+__global__ __launch_bounds__(64) void edge_union_compact(const uint32_t *__restrict__ tmp_ids, const uint64_t *__restrict__ tmp_masks,
+                                                         const unsigned long long *__restrict__ eoff_in, const int32_t *__restrict__ ecount,
+                                                         const int64_t *__restrict__ eoff_out, uint32_t *__restrict__ uids, uint64_t *__restrict__ uvals) {
+  const int64_t e = blockIdx.x;
+  const int n = ecount[e];
+  const int64_t from = (int64_t)eoff_in[e], to = eoff_out[e];
+  for (int t = threadIdx.x; t < n; t += 64) { uids[to + t] = tmp_ids[from + t]; uvals[to + t] = tmp_masks[from + t]; }
+}
+
 struct BitOr { __host__ __device__ uint64_t operator()(uint64_t a, uint64_t b) const { return a | b; } };
 
 int bits_for(uint64_t n) { int b = 1; while (((uint64_t)1 << b) < n) b++; return b; }
@@ -137,7 +237,7 @@ hipError_t grow(T **p, size_t count) {
 
 void merge_free(MergeScratch &ms) {
   void *ptrs[] = {ms.cnt, ms.offs, ms.keys[0], ms.keys[1], ms.vals[0], ms.vals[1], ms.ukeys, ms.uvals, ms.uids, ms.ecount, ms.scalars, ms.tmp,
-                  ms.ekey[0], ms.ekey[1], ms.order[0], ms.order[1], ms.rank, ms.etot, ms.seg};
+                  ms.ekey[0], ms.ekey[1], ms.order[0], ms.order[1], ms.rank, ms.etot, ms.seg, ms.ibeg, ms.iend};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   ms = MergeScratch{};
 }
@@ -154,7 +254,7 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
     MERGE_TRY(grow(&ms.offs, (size_t)pool + 1));
     ms.cap_items = pool + 1;
   }
-  if (ms.cap_edges < n_edges) { MERGE_TRY(grow(&ms.ecount, (size_t)n_edges)); ms.cap_edges = n_edges; }
+  if (ms.cap_edges < n_edges + 1) { MERGE_TRY(grow(&ms.ecount, (size_t)n_edges + 1)); ms.cap_edges = n_edges + 1; }
   if (!ms.scalars) MERGE_TRY(grow(&ms.scalars, 2));
   auto need_tmp = [&](size_t bytes) -> hipError_t {
     if (ms.cap_tmp >= bytes) return hipSuccess;
@@ -171,6 +271,8 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
   if (ms.cap_group_edges < n_edges + 1) {
     MERGE_TRY(grow(&ms.etot, (size_t)n_edges + 1));
     MERGE_TRY(grow(&ms.seg, (size_t)n_edges + 1));
+    MERGE_TRY(grow(&ms.ibeg, (size_t)n_edges + 1));
+    MERGE_TRY(grow(&ms.iend, (size_t)n_edges + 1));
     ms.cap_group_edges = n_edges + 1;
   }
 
@@ -178,6 +280,8 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
   MERGE_TRY(hipMemsetAsync(ms.ecount, 0, (size_t)n_edges * sizeof(int32_t), stream));
   MERGE_TRY(hipMemsetAsync(ms.cnt + pool, 0, sizeof(int64_t), stream));
   MERGE_TRY(hipMemsetAsync(ms.etot, 0, ((size_t)n_edges + 1) * sizeof(unsigned long long), stream));
+  MERGE_TRY(hipMemsetAsync(ms.ibeg, 0, (size_t)n_edges * sizeof(int32_t), stream));
+  MERGE_TRY(hipMemsetAsync(ms.iend, 0, (size_t)n_edges * sizeof(int32_t), stream));
   // group the items by edge
   hipLaunchKernelGGL(merge_item_keys, gp, b256, 0, stream, d_sample_edge, pool, ms.ekey[0], ms.order[0]);
   MERGE_TRY(hipGetLastError());
@@ -188,7 +292,7 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
   MERGE_TRY(need_tmp(bytes));
   MERGE_TRY(rocprim::radix_sort_pairs(ms.tmp, bytes, ekb, orb, (size_t)pool, 0u, 32u, stream));
   hipLaunchKernelGGL(merge_counts, gp, b256, 0, stream, d_counts, d_item_src, ekb.current(), orb.current(), pool, ms.cnt, ms.rank, ms.etot,
-                     ms.scalars);
+                     ms.scalars, ms.ibeg, ms.iend);
   MERGE_TRY(hipGetLastError());
   bytes = 0;
   MERGE_TRY(rocprim::exclusive_scan(nullptr, bytes, ms.cnt, ms.offs, (int64_t)0, (size_t)pool + 1, rocprim::plus<int64_t>(), stream));
@@ -215,6 +319,41 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
     MERGE_TRY(grow(&ms.uvals, want));
     MERGE_TRY(grow(&ms.uids, want));
     ms.cap_nnz = (int64_t)want;
+  }
+  // the union kernel (TENDON_HIP_MERGE=sort: the sort path only; it also takes over when an edge overflows the kernel's table)
+  const char *merge_mode = std::getenv("TENDON_HIP_MERGE");          // (read per call: the tests switch between the two paths)
+  const bool sort_only = merge_mode && std::strcmp(merge_mode, "sort") == 0;
+  if (!sort_only && n_edges < ((int64_t)1 << 31) && pool + 1 >= n_edges + 1) {
+    uint32_t *tmp_ids = (uint32_t *)ms.keys[0];
+    uint64_t *tmp_masks = ms.vals[0];
+    hipLaunchKernelGGL(edge_union, dim3((unsigned)n_edges), dim3(64), 0, stream, d_ids, d_masks, d_counts, d_item_src, ms.ibeg, ms.iend, orb.current(),
+                       ld, ms.etot, tmp_ids, tmp_masks, ms.ecount, ms.scalars);
+    MERGE_TRY(hipGetLastError());
+    // final offsets of the edges' lists (ms.cnt is free again: [pool + 1] >= [n_edges + 1]; its element n_edges is the total)
+    MERGE_TRY(hipMemsetAsync(ms.ecount + n_edges, 0, sizeof(int32_t), stream));
+    bytes = 0;
+    MERGE_TRY(rocprim::exclusive_scan(nullptr, bytes, ms.ecount, ms.cnt, (int64_t)0, (size_t)n_edges + 1, rocprim::plus<int64_t>(), stream));
+    MERGE_TRY(need_tmp(bytes));
+    MERGE_TRY(rocprim::exclusive_scan(ms.tmp, bytes, ms.ecount, ms.cnt, (int64_t)0, (size_t)n_edges + 1, rocprim::plus<int64_t>(), stream));
+    hipLaunchKernelGGL(edge_union_compact, dim3((unsigned)n_edges), dim3(64), 0, stream, tmp_ids, tmp_masks, ms.etot, ms.ecount, ms.cnt, ms.uids, ms.uvals);
+    MERGE_TRY(hipGetLastError());
+    int64_t total = 0;
+    MERGE_TRY(hipMemcpyAsync(&total, ms.cnt + n_edges, sizeof(int64_t), hipMemcpyDeviceToHost, stream));
+    MERGE_TRY(hipMemcpyAsync(sc, ms.scalars, sizeof(sc), hipMemcpyDeviceToHost, stream));
+    MERGE_TRY(hipStreamSynchronize(stream));
+    if (!(sc[1] & 2ull)) { *n_unique = total; return hipSuccess; }
+    // an edge with more distinct blocks than the table takes: everything again on the sort path (ms.cnt is rebuilt below)
+    MERGE_TRY(hipMemsetAsync(ms.scalars, 0, 2 * sizeof(uint64_t), stream));
+    MERGE_TRY(hipMemsetAsync(ms.ecount, 0, (size_t)n_edges * sizeof(int32_t), stream));
+    MERGE_TRY(hipMemsetAsync(ms.etot, 0, ((size_t)n_edges + 1) * sizeof(unsigned long long), stream));
+    hipLaunchKernelGGL(merge_counts, gp, b256, 0, stream, d_counts, d_item_src, ekb.current(), orb.current(), pool, ms.cnt, ms.rank, ms.etot, ms.scalars,
+                       ms.ibeg, ms.iend);
+    MERGE_TRY(hipGetLastError());
+    MERGE_TRY(hipMemsetAsync(ms.cnt + pool, 0, sizeof(int64_t), stream));
+    bytes = 0;
+    MERGE_TRY(rocprim::exclusive_scan(nullptr, bytes, ms.etot, ms.etot, 0ull, (size_t)n_edges + 1, rocprim::plus<unsigned long long>(), stream));
+    MERGE_TRY(need_tmp(bytes));
+    MERGE_TRY(rocprim::exclusive_scan(ms.tmp, bytes, ms.etot, ms.etot, 0ull, (size_t)n_edges + 1, rocprim::plus<unsigned long long>(), stream));
   }
   hipLaunchKernelGGL(merge_keys, dim3((unsigned)((pool + 63) / 64)), b256, 0, stream, d_ids, d_masks, ms.cnt, ms.offs, ms.rank, d_item_src,
                      d_sample_edge, pool, ld, id_bits, ms.keys[0], ms.vals[0]);

@@ -28,6 +28,7 @@ struct MergeScratch {
   int32_t *rank = nullptr;                        // [items]
   unsigned long long *etot = nullptr;             // [edges + 1]
   unsigned int *seg = nullptr;                    // [edges + 1]
+  int32_t *ibeg = nullptr, *iend = nullptr;       // [edges] every edge's run of grouped positions
 };
 
 // Per-sample block lists (ids / masks stored as columns [maxB][ld], counts[i] entries, counts < 0 =

@@ -785,6 +785,11 @@ __global__ __launch_bounds__(64) void backbone_voxelize(
   counts[i] = (overflow || bad) ? -1 : cnt;
 }
 
+// n 8-byte words from `src` to `dst`: upload_staged's copy out of pinned host memory (tendon_hip.hip), grid-stride
+__global__ __launch_bounds__(256) void copy_words(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) dst[i] = src[i];
+}
+
 __global__ __launch_bounds__(256) void iota_i32(int32_t *__restrict__ out, int64_t n) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i < n) out[i] = (int32_t)i;

@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <ctime>
 #include <limits>
 #include <mutex>
@@ -208,6 +209,8 @@ struct tr_ctx {
     double *out_states = nullptr, *out_tips = nullptr; int64_t *out_index = nullptr;
     double rate_seen = 0.0;                                  // acceptance rate of this context's last run (sizes the first batch)
   } samp;
+  // pinned staging for host arrays that are uploaded by a synchronous call (upload_staged)
+  void *h_stage = nullptr; size_t h_stage_cap = 0;
   // instrumentation
   bool profiling = false;
   std::vector<EventPair> events[TR_PROFILE_SLOTS];
@@ -383,6 +386,30 @@ int ensure_staging(tr_ctx *ctx, int64_t n) {
   if ((rc = dev_alloc(ctx, &w.L, (size_t)want))) return rc;
   if ((rc = dev_alloc(ctx, &w.npts, (size_t)want))) return rc;
   w.st_cap = want;
+  return TR_OK;
+}
+
+// Host array -> device through a pinned buffer of the context (grow-only): memcpy, then a KERNEL that reads the pinned memory
+// over the bus (hipHostMalloc memory is mapped into the device's address space).  Measured in create_roadmap (the sampled states
+// going back up for their voxel sets, right after the connect call): the runtime's DMA copy of these 3.2 MB -- from the
+// pageable array or from this pinned buffer, on the null stream or on another -- completed after 13 - 25 ms, and after 0.06 ms
+// once any kernel had run on the stream first (profiles/r03/vox_timing_v*.txt); the kernel copy takes no such chances.
+// `bytes` must be a multiple of 8 (arrays of doubles / int64).
+int upload_staged(tr_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return TR_OK;
+  if (bytes % 8) return fail(c, TR_ERR_INVALID_ARG, "upload_staged: whole 8-byte words only");
+  if (c->h_stage_cap < bytes) {
+    if (c->h_stage) { HIP_TRY(c, hipDeviceSynchronize()); (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
+    const size_t want = bytes + bytes / 4;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+    c->h_stage_cap = want;
+  }
+  std::memcpy(c->h_stage, h_src, bytes);
+  const int64_t words = (int64_t)(bytes / 8);
+  hipLaunchKernelGGL(trk::copy_words, dim3((unsigned)std::min<int64_t>((words + 255) / 256, 2048)), dim3(256), 0, s, (uint64_t *)d_dst,
+                     (const uint64_t *)c->h_stage, words);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(s));                  // the buffer is free for the next call
   return TR_OK;
 }
 
@@ -891,6 +918,7 @@ void tr_destroy(tr_ctx *c) {
   if (c->d_fb_count1) (void)hipFree(c->d_fb_count1);
   if (c->d_edge_counters1) (void)hipFree(c->d_edge_counters1);
   for (int q = 0; q < 2; q++) { if (c->edge_stream[q]) (void)hipStreamDestroy(c->edge_stream[q]); if (c->edge_hc[q]) (void)hipHostFree(c->edge_hc[q]); }
+  if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto &ro : c->ro) {
     for (int q = 0; q < 2; q++) { if (ro.keys[q]) (void)hipFree(ro.keys[q]); if (ro.vals[q]) (void)hipFree(ro.vals[q]); }
     if (ro.kbegin) (void)hipFree(ro.kbegin);
@@ -1605,28 +1633,45 @@ int tr_voxelize_batch(tr_ctx *c, const double *states, int64_t n, int64_t *offse
   if (offsets) offsets[0] = 0;
   if (n == 0) return TR_OK;
   if (!c->has_grid) return fail(c, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  // TENDON_HIP_VOX_TIMING=1: where this call's time goes (stderr; tuning only -- every lap synchronises the device)
+  const bool vt = std::getenv("TENDON_HIP_VOX_TIMING") != nullptr;
+  auto vt0 = std::chrono::steady_clock::now();
+  auto vlap = [&](const char *what) {
+    if (!vt) return;
+    (void)hipDeviceSynchronize();
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[voxelize_batch] %-28s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - vt0).count());
+    vt0 = t1;
+  };
   HIP_TRY(c, hipSetDevice(c->device));
   HIP_TRY(c, hipDeviceSynchronize());
+  vlap("entry (device drained)");
   const int64_t chunk = std::min<int64_t>(c->max_chunk, 1 << 18);   // block-list scratch: 12 B x (2P + 16) per configuration
   int rc;
   if ((rc = ensure_workspace(c, std::min(n, chunk)))) return rc;
+  vlap("ensure_workspace");
   if ((rc = ensure_staging(c, std::min(n, chunk)))) return rc;
+  vlap("ensure_staging");
   Workspace &w = c->ws;
   const int S = c->K.state_size;
   const bool ret = c->K.enable_retraction;
   std::vector<int32_t> counts; std::vector<int64_t> offs;
   for (int64_t off = 0; off < n; off += chunk) {
     const int64_t m = std::min(chunk, n - off);
-    HIP_TRY(c, hipMemcpy(w.states, states + off * S, (size_t)m * S * sizeof(double), hipMemcpyHostToDevice));
+    if ((rc = upload_staged(c, w.states, states + off * S, (size_t)m * S * sizeof(double), nullptr))) return rc;
     trk::FkOut out{w.px, w.py, w.pz, nullptr, nullptr, w.Li, tips ? w.tips : nullptr, w.conv, ret ? w.np : nullptr,
                    ret ? w.homeLi : nullptr};
     trk::SweepIn in{w.px, w.py, w.pz, ret ? w.np : nullptr, w.Li, w.conv, ret ? w.homeLi : nullptr, w.acc};
+    vlap("upload");
     if ((rc = launch_fk_sweep(c, w.states, m, w.ld, out, in, 0, w.bits, nullptr, nullptr))) return rc;     // is_valid_shape only
+    vlap("FK + shape test");
     const int64_t base = c->vstore.n;
     if ((rc = voxelize_samples(c, m, w.ld, ret ? w.np : nullptr, w.bits, counts, offs))) return rc;
+    vlap("voxelise + merge + store");
     HIP_TRY(c, hipMemcpy(shape_valid_bits + off / 64, w.bits, (size_t)((m + 63) / 64) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (tips) HIP_TRY(c, hipMemcpy(tips + 3 * off, w.tips, (size_t)m * 3 * sizeof(double), hipMemcpyDeviceToHost));
     for (int64_t i = 0; i < m; i++) offsets[off + i + 1] = base + offs[(size_t)i + 1];
+    vlap("downloads + offsets");
   }
   return TR_OK;
 }

@@ -89,3 +89,38 @@ def test_config4_sharded_mask_single_rank(irt, orc, helpers):
     want, _, _ = orc.validate_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), cand,
                                     nthreads=0, lib=orc.omp_lib())
     assert np.array_equal(mask, want)
+
+
+def test_union_kernel_and_sort_path_build_the_same_caches(irt, monkeypatch):
+    """The block lists of vertices, edges (voxelizeEdge) and connected edges from the wave-per-edge union kernel
+    (cache_merge.hip: edge_union) are, entry for entry, those of the sort + reduce-by-key path it replaces."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    rb, chk = _builder(irt, robot, vox, seed=21)
+    states, _ = rb.sample_valid_vertices(3000, batch=8192)
+    edges = rb.knn_edges_gpu(states, 7)
+    got = {}
+    for mode in ("union", "sort"):
+        if mode == "sort":
+            monkeypatch.setenv("TENDON_HIP_MERGE", "sort")
+        else:
+            monkeypatch.delenv("TENDON_HIP_MERGE", raising=False)
+        vc = rb.vertex_caches(states)
+        ec = rb.edge_caches(states, edges)
+        e_ok, cc = rb.connect(states, edges)
+        got[mode] = (vc, ec, e_ok, cc)
+    for a, b in zip(got["union"], got["sort"]):
+        if isinstance(a, dict):
+            for key in ("offsets", "block_ids", "masks"):
+                assert np.array_equal(a[key], b[key]), key
+        else:
+            assert np.array_equal(a, b)
+    vc, ec, e_ok, cc = got["union"]
+    assert int(vc["offsets"][-1]) > 20 * len(states) and int(ec["offsets"][-1]) > 20 * int(ec["fully_valid"].sum()) and len(e_ok) > 0
+    # ordered by block id, no block twice
+    for c in (vc, ec, cc):
+        off, ids = c["offsets"], c["block_ids"].astype(np.int64)
+        inner = np.ones(len(ids), bool)
+        inner[off[:-1][off[:-1] < len(ids)]] = False            # first entry of every list
+        assert (np.diff(ids)[inner[1:]] > 0).all()
