@@ -104,6 +104,9 @@ def summarize(src, out):
           (marks["what"], marks["wall_ms"], res["between_markers_ms"], res["first_to_last_kernel_ms"], res["any_kernel_busy_ms"],
            res["fk_kernels_busy_ms"], res["idle_before_first_kernel_ms"], res["idle_after_last_kernel_ms"]))
     print("  largest idle gaps (ms @ ms into the call):", ", ".join("%.2f@%.1f" % g for g in gaps[:10]))
+    for s_, e_, n in call:
+        if n.startswith("fk_") and (e_ - s_) > 2e5:              # every FK launch longer than 0.2 ms: start within the call, duration
+            print("  %-22s t = %7.2f ms   %7.3f ms" % (n, (s_ - t0) / 1e6, (e_ - s_) / 1e6))
     for n, d in sorted(per.items(), key=lambda kv: -kv[1]["sum_ms"])[:18]:
         print("  %-36s %4d launches %8.3f ms" % (n, d["launches"], d["sum_ms"]))
 
