@@ -146,6 +146,17 @@ def build(force=False, verbose=False, jobs=None):
     if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
         return LIB_PATH
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # one builder at a time: the ranks of a `torch.distributed.run` launch all arrive here when the library is stale, and
+    # would compile and link into the same files (bench.py's own launcher builds once in the parent; this covers the rest)
+    import fcntl
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and os.path.exists(LIB_PATH) and os.path.exists(stamp) and open(stamp).read().strip() == want:
+            return LIB_PATH                                      # another process built it while this one waited
+        return _build_locked(force, verbose, jobs, stamp, want)
+
+
+def _build_locked(force, verbose, jobs, stamp, want):
     import hashlib
     todo, stamps = [], []
     for obj, src, extra, deps in _units():
