@@ -534,18 +534,21 @@ int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, con
   });
   if (bad != TR_OK) { const int rc = bad; delete r; return rc; }
   laps.lap("edges");
+  // CSR adjacency: degrees by edge ranges (atomic increments)
   r->adj_off.assign((size_t)n_vertices + 1, 0);
   on_threads(T, [&](int t) {
-    const int32_t vlo = (int32_t)(n_vertices * t / T), vhi = (int32_t)(n_vertices * (t + 1) / T);
-    for (int64_t e = 0; e < n_edges; e++) {
-      const int32_t a = r->eu[(size_t)e], b = r->ev[(size_t)e];
-      if (a >= vlo && a < vhi) r->adj_off[(size_t)a + 1]++;
-      if (b >= vlo && b < vhi) r->adj_off[(size_t)b + 1]++;
+    const int64_t lo = n_edges * t / T, hi = n_edges * (t + 1) / T;
+    for (int64_t e = lo; e < hi; e++) {
+      __atomic_fetch_add(&r->adj_off[(size_t)r->eu[(size_t)e] + 1], (int64_t)1, __ATOMIC_RELAXED);
+      __atomic_fetch_add(&r->adj_off[(size_t)r->ev[(size_t)e] + 1], (int64_t)1, __ATOMIC_RELAXED);
     }
   });
   for (int64_t v = 0; v < n_vertices; v++) r->adj_off[(size_t)v + 1] += r->adj_off[(size_t)v];
   r->adj.resize_uninit((size_t)r->adj_off[(size_t)n_vertices]);
   laps.lap("degrees");
+  // the arcs by VERTEX ranges: every thread scans all edges in order and takes the arcs that leave its vertices, so a vertex's
+  // arcs keep the edge order whatever T is (atomic cursors + a per-vertex sort were slower: 5.6 against 3.0 ms, scattered
+  // first touches of the 19 MB)
   on_threads(T, [&](int t) {
     const int32_t vlo = (int32_t)(n_vertices * t / T), vhi = (int32_t)(n_vertices * (t + 1) / T);
     if (vlo == vhi) return;
