@@ -517,39 +517,45 @@ int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, con
   Laps laps("tr_roadmap_create");
   r->states.assign(states, states + (size_t)n_vertices * r->S);
   r->eu.resize_uninit((size_t)n_edges); r->ev.resize_uninit((size_t)n_edges); r->w.resize_uninit((size_t)n_edges);
-  // the edge arrays on T threads by edge ranges, the CSR adjacency by VERTEX ranges: every thread scans all edges in order and
-  // takes the arcs that leave its vertices, so a vertex's arcs keep the edge order whatever T is
+  // One team of T threads, three phases with a barrier between them (a team per phase cost ~1 ms each in thread starts):
+  //   1. the edge arrays by edge ranges (end points, weights);  2. degrees by edge ranges (atomic increments), then thread 0 turns
+  //   them into offsets and sizes the arc array;  3. the arcs by VERTEX ranges: every thread scans all edges in order and takes the
+  //   arcs that leave its vertices, so a vertex's arcs keep the edge order whatever T is (atomic cursors + a per-vertex sort were
+  //   slower: 5.6 against 3.0 ms, scattered first touches of the 19 MB).
   const int T = n_edges >= (1 << 16) ? std::min(host_threads(0), 16) : 1;
   std::atomic<int> bad{TR_OK};
+  r->adj_off.assign((size_t)n_vertices + 1, 0);
+  struct Barrier {
+    const int n; std::atomic<int> arrived{0}, phase{0};
+    explicit Barrier(int n_) : n(n_) {}
+    void wait() {
+      const int ph = phase.load(std::memory_order_acquire);
+      if (arrived.fetch_add(1, std::memory_order_acq_rel) + 1 == n) { arrived.store(0, std::memory_order_relaxed); phase.store(ph + 1, std::memory_order_release); }
+      else while (phase.load(std::memory_order_acquire) == ph) std::this_thread::yield();
+    }
+  } barrier(T);
   on_threads(T, [&](int t) {
     const int64_t lo = n_edges * t / T, hi = n_edges * (t + 1) / T;
     for (int64_t e = lo; e < hi; e++) {
       const int32_t a = edges[2 * e], b = edges[2 * e + 1];
-      if (a < 0 || a >= n_vertices || b < 0 || b >= n_vertices) { bad = TR_ERR_OUT_OF_RANGE; return; }
+      if (a < 0 || a >= n_vertices || b < 0 || b >= n_vertices) { bad = TR_ERR_OUT_OF_RANGE; break; }
       r->eu[(size_t)e] = a; r->ev[(size_t)e] = b;
       // edge cost = opt_->motionCost = si->distance(a, b) unless the file supplies one (weightProperty_, :2598-2603)
       r->w[(size_t)e] = weights ? weights[e] : state_distance(r, &r->states[(size_t)a * r->S], &r->states[(size_t)b * r->S]);
-      if (!(r->w[(size_t)e] >= 0)) { int want = TR_OK; bad.compare_exchange_strong(want, TR_ERR_INVALID_ARG); return; }
+      if (!(r->w[(size_t)e] >= 0)) { int want = TR_OK; bad.compare_exchange_strong(want, TR_ERR_INVALID_ARG); break; }
     }
-  });
-  if (bad != TR_OK) { const int rc = bad; delete r; return rc; }
-  laps.lap("edges");
-  // CSR adjacency: degrees by edge ranges (atomic increments)
-  r->adj_off.assign((size_t)n_vertices + 1, 0);
-  on_threads(T, [&](int t) {
-    const int64_t lo = n_edges * t / T, hi = n_edges * (t + 1) / T;
+    barrier.wait();
+    if (bad != TR_OK) return;                                   // (every thread sees the same value after the barrier)
     for (int64_t e = lo; e < hi; e++) {
       __atomic_fetch_add(&r->adj_off[(size_t)r->eu[(size_t)e] + 1], (int64_t)1, __ATOMIC_RELAXED);
       __atomic_fetch_add(&r->adj_off[(size_t)r->ev[(size_t)e] + 1], (int64_t)1, __ATOMIC_RELAXED);
     }
-  });
-  for (int64_t v = 0; v < n_vertices; v++) r->adj_off[(size_t)v + 1] += r->adj_off[(size_t)v];
-  r->adj.resize_uninit((size_t)r->adj_off[(size_t)n_vertices]);
-  laps.lap("degrees");
-  // the arcs by VERTEX ranges: every thread scans all edges in order and takes the arcs that leave its vertices, so a vertex's
-  // arcs keep the edge order whatever T is (atomic cursors + a per-vertex sort were slower: 5.6 against 3.0 ms, scattered
-  // first touches of the 19 MB)
-  on_threads(T, [&](int t) {
+    barrier.wait();
+    if (t == 0) {
+      for (int64_t v = 0; v < n_vertices; v++) r->adj_off[(size_t)v + 1] += r->adj_off[(size_t)v];
+      r->adj.resize_uninit((size_t)r->adj_off[(size_t)n_vertices]);
+    }
+    barrier.wait();
     const int32_t vlo = (int32_t)(n_vertices * t / T), vhi = (int32_t)(n_vertices * (t + 1) / T);
     if (vlo == vhi) return;
     std::vector<int64_t> fill(r->adj_off.begin() + vlo, r->adj_off.begin() + vhi);
@@ -559,7 +565,8 @@ int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, con
       if (b >= vlo && b < vhi) r->adj[(size_t)fill[(size_t)(b - vlo)]++] = Arc{a, (int32_t)e, r->w[(size_t)e]};
     }
   });
-  laps.lap("adjacency");
+  if (bad != TR_OK) { const int rc = bad; delete r; return rc; }
+  laps.lap("edges + degrees + adjacency");
   r->vstat.assign((size_t)n_vertices, V_UNKNOWN); r->estat.assign((size_t)n_edges, V_UNKNOWN);
   r->vpresent.assign((size_t)n_vertices, 1); r->epresent.assign((size_t)n_edges, 1);
   *out = r;
