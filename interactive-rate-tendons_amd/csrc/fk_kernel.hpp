@@ -25,6 +25,7 @@
 // tip position <= 1e-9 m, see tests/); the bit-exact integer/predicate stage lives in
 // sweep_kernel.hpp and is compiled without contraction.
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include "tr_types.hpp"
 
@@ -338,6 +339,14 @@ struct NoPointHook {
   __device__ __forceinline__ void tip_point(int, bool, bool, double, double, double, bool = true) const {}   // retraction kernel
 };
 
+// A hook may ask for the tendon-length quadratures in LDS (`static constexpr bool kLiInLds = true`, verdict_kernel.hpp: PointSweep);
+// granted where it pays: four tendons, the widest robot that still runs two waves per SIMD with a sweep in its loop.
+template <class H, class = void> struct HookLiInLds { static constexpr bool value = false; };
+template <class H> struct HookLiInLds<H, std::void_t<decltype(H::kLiInLds)>> { static constexpr bool value = H::kLiInLds; };
+template <class OnPoint> __host__ __device__ constexpr bool li_in_lds(int N) {
+  return HookLiInLds<std::remove_cv_t<std::remove_reference_t<OnPoint>>>::value && N == 4;
+}
+
 // on_point(j, x, y, z): called for every observed backbone point (after rotate_z), in order j = 0 .. P-1 -- the
 // verdict-only kernel sweeps the point there instead of storing it; on_point.begin(converged && live) precedes point 0.  row_map (optional): lane i integrates
 // configuration row_map[i] of `states` (the fallback pass of the verdict path works on a compacted list).
@@ -355,6 +364,18 @@ __device__ __forceinline__ void fk_uniform_body(
   double tau[N];
 #pragma unroll
   for (int j = 0; j < N; j++) tau[j] = states[ic * S + j];
+  // Four tendons at two waves per SIMD with a per-point sweep in the loop: the N tendon-length quadratures -- written four times
+  // a step, read once after the loop -- live in LDS (N x 512 B per wave) instead of 2 N registers.  Measured on fk_verdict<4>:
+  // VGPR spills 25 -> 2 dwords (76 -> 12 B of scratch per lane, which every wave wrote back to HBM once: 2.4x -> 1.2x the
+  // algorithmic traffic), 5.26 -> 5.19 ms per 2^19 (profiles/r03/kbench_v8_li_in_lds.txt; with 2.5 KB instead of 2 the wave count per CU drops to seven: -11 %, kbench_v7).  The tensions themselves in LDS changed nothing.
+  constexpr bool kLiLds = li_in_lds<OnPoint>(N);
+  double *li_lds = nullptr;
+  if constexpr (kLiLds) {
+    __shared__ double li_lds_store[N * 64];
+    li_lds = li_lds_store;
+#pragma unroll
+    for (int j = 0; j < N; j++) li_lds[j * 64 + threadIdx.x] = 0.0;
+  }
   double rc = 1.0, rs = 0.0, r22 = 1.0;
   if (ROT) {
     const double th = states[ic * S + N];
@@ -428,8 +449,13 @@ __device__ __forceinline__ void fk_uniform_body(
         const double v2 = sv[0] * sv[0] + sv[1] * sv[1] + sv[2] * sv[2];
         Lb += bw * (v2 * fast_rsqrt(v2));
       }
+      if constexpr (kLiLds) {
 #pragma unroll
-      for (int j = 0; j < N; j++) Li[j] += bw * sd[j];
+        for (int j = 0; j < N; j++) li_lds[j * 64 + threadIdx.x] += bw * sd[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < N; j++) Li[j] += bw * sd[j];
+      }
       // R' = R uhat : col0 = R1*uz - R2*uy ; col1 = R2*ux - R0*uz ; col2 = R0*uy - R1*ux
       double dR[9];
 #pragma unroll
@@ -457,6 +483,10 @@ __device__ __forceinline__ void fk_uniform_body(
     if (obs >= 0) store_point(obs);
   }
 
+  if constexpr (kLiLds) {
+#pragma unroll
+    for (int j = 0; j < N; j++) Li[j] = li_lds[j * 64 + threadIdx.x];
+  }
   if (live) {
     if (out.L) out.L[i] = Lb;
     if (out.Li) {

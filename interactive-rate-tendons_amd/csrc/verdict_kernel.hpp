@@ -93,7 +93,8 @@ constexpr int VL_QOWNER = VL_W0, VL_CELL = VL_QOWNER + VQ, VL_INPREV = VL_CELL +
 // voxel checker: delta[] is unused and holds the requested half of the dilated-grid word of the previous point's block instead
 constexpr int VL_NEARW = VL_DELTA;
 // with signatures (edge samples) the tile of SigStage (sweep_kernel.hpp) follows the milestones: 18 176 + 2 304 B = exactly
-// 20 KiB per wave at NM = 8, eight waves per CU still fit the 160 KiB
+// 20 KiB per wave at NM = 8, eight waves per CU still fit the 160 KiB (the plain 4-tendon kernels add 2 KiB of static LDS for
+// their tendon-length quadratures: 19.75 KiB)
 __host__ __device__ inline size_t verdict_lds_bytes(int NM, bool with_sig = false) {
   return (size_t)VL_MS * 4 + (size_t)4 * NM * 64 * sizeof(float) + (with_sig ? (size_t)SIG_LDS_WORDS * 4 : 0);
 }
@@ -111,6 +112,11 @@ __host__ __device__ inline size_t verdict_lds_bytes(int NM, bool with_sig = fals
 // verdict kernels carry none of it.
 template <bool SPH, bool SIG = false>
 struct PointSweep {
+  // fk_uniform_body keeps the 4-tendon robots' tendon-length quadratures in LDS when this hook sits in its loop (fk_kernel.hpp:
+  // li_in_lds).  Not with signatures: that kernel's LDS image is exactly an eighth of the CU's at 8 milestones (below), and a
+  // ninth 2 KB would cost it a wave per CU -- measured -11 % (a ring of 64 deferred segments, emptied BEFORE a push that would
+  // not fit, would make the room, but the second flush site spills 20 more registers in every variant).
+  static constexpr bool kLiInLds = !SIG;
   const VerdictArgs *va;
   float dn_prev;                  // SPH: distance-field value at the previous point's cell (requested one point ahead)
   uint32_t sph_state;             // SPH: bit 0 = the previous point awaits its classification, bit 1 = it lies inside the closed domain
