@@ -339,12 +339,13 @@ struct NoPointHook {
   __device__ __forceinline__ void tip_point(int, bool, bool, double, double, double, bool = true) const {}   // retraction kernel
 };
 
-// A hook may ask for the tendon-length quadratures in LDS (`static constexpr bool kLiInLds = true`, verdict_kernel.hpp: PointSweep);
-// granted where it pays: four tendons, the widest robot that still runs two waves per SIMD with a sweep in its loop.
-template <class H, class = void> struct HookLiInLds { static constexpr bool value = false; };
-template <class H> struct HookLiInLds<H, std::void_t<decltype(H::kLiInLds)>> { static constexpr bool value = H::kLiInLds; };
+// A hook may ask for the tendon-length quadratures in LDS from some tendon count on (`static constexpr int kLiInLdsFrom = 3`;
+// verdict_kernel.hpp: PointSweep, sweep_kernel.hpp: SignatureHook); granted up to four tendons, the widest robot that runs two
+// waves per SIMD with a sweep in (or behind) its loop.
+template <class H, class = void> struct HookLiInLds { static constexpr int from = 1 << 30; };
+template <class H> struct HookLiInLds<H, std::void_t<decltype(H::kLiInLdsFrom)>> { static constexpr int from = H::kLiInLdsFrom; };
 template <class OnPoint> __host__ __device__ constexpr bool li_in_lds(int N) {
-  return HookLiInLds<std::remove_cv_t<std::remove_reference_t<OnPoint>>>::value && N == 4;
+  return N >= HookLiInLds<std::remove_cv_t<std::remove_reference_t<OnPoint>>>::from && N <= 4;
 }
 
 // on_point(j, x, y, z): called for every observed backbone point (after rotate_z), in order j = 0 .. P-1 -- the

@@ -340,6 +340,7 @@ struct SigStage {
 // sweep_body starts.  The arguments are re-read per point through an index the optimiser cannot hoist (as in
 // verdict_kernel.hpp), so they hold no SGPRs across the RK4 loop.
 struct SignatureHook {
+  static constexpr int kLiInLdsFrom = 3;     // fk_kernel.hpp: li_in_lds (the fused kernels' LDS image leaves room: 10.3 of 20 KiB per wave)
   const FusedSweepArgs *sa;
   int64_t n;                     // configurations of the launch
   bool any;                      // wave-uniform: this launch wants signatures

@@ -116,7 +116,7 @@ struct PointSweep {
   // li_in_lds).  Not with signatures: that kernel's LDS image is exactly an eighth of the CU's at 8 milestones (below), and a
   // ninth 2 KB would cost it a wave per CU -- measured -11 % (a ring of 64 deferred segments, emptied BEFORE a push that would
   // not fit, would make the room, but the second flush site spills 20 more registers in every variant).
-  static constexpr bool kLiInLds = !SIG;
+  static constexpr int kLiInLdsFrom = SIG ? (1 << 30) : 4;   // (3 tendons: 2 spilled dwords, nothing to gain)
   const VerdictArgs *va;
   float dn_prev;                  // SPH: distance-field value at the previous point's cell (requested one point ahead)
   uint32_t sph_state;             // SPH: bit 0 = the previous point awaits its classification, bit 1 = it lies inside the closed domain
