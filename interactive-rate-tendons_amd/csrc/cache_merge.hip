@@ -139,7 +139,8 @@ constexpr uint32_t EU_EMPTY = 0xffffffffu;          // no block has this id (ids
 __global__ __launch_bounds__(64) void edge_union(const uint32_t *__restrict__ ids, const uint64_t *__restrict__ masks, const int32_t *__restrict__ counts,
                                                  const int32_t *__restrict__ src, const int32_t *__restrict__ ibeg, const int32_t *__restrict__ iend,
                                                  const int32_t *__restrict__ order, int64_t ld, const unsigned long long *__restrict__ eoff_in, uint32_t *__restrict__ tmp_ids,
-                                                 uint64_t *__restrict__ tmp_masks, int32_t *__restrict__ ecount, uint64_t *__restrict__ scalars) {
+                                                 uint64_t *__restrict__ tmp_masks, int32_t *__restrict__ ecount, uint64_t *__restrict__ scalars,
+                                                 int max_load) {
   __shared__ uint32_t tkey[EU_SLOTS];
   __shared__ unsigned long long tmask[EU_SLOTS];
   __shared__ uint32_t lid[EU_SLOTS];
@@ -173,7 +174,7 @@ __global__ __launch_bounds__(64) void edge_union(const uint32_t *__restrict__ id
     }
   }
   __syncthreads();
-  if (s_ovf != 0 || s_unique > EU_MAXLOAD) {
+  if (s_ovf != 0 || s_unique > max_load) {
     if (lane == 0) { ecount[e] = 0; atomicOr((unsigned long long *)&scalars[1], 2ull); }
     return;
   }
@@ -326,8 +327,13 @@ hipError_t merge_edge_caches(MergeScratch &ms, const uint32_t *d_ids, const uint
   if (!sort_only && n_edges < ((int64_t)1 << 31) && pool + 1 >= n_edges + 1) {
     uint32_t *tmp_ids = (uint32_t *)ms.keys[0];
     uint64_t *tmp_masks = ms.vals[0];
+    int max_load = EU_MAXLOAD;
+    if (const char *e = std::getenv("TENDON_HIP_MERGE_MAXLOAD")) {     // (tests: a small value sends the call through the overflow fallback)
+      const int v = std::atoi(e);
+      if (v >= 1 && v < EU_MAXLOAD) max_load = v;
+    }
     hipLaunchKernelGGL(edge_union, dim3((unsigned)n_edges), dim3(64), 0, stream, d_ids, d_masks, d_counts, d_item_src, ms.ibeg, ms.iend, orb.current(),
-                       ld, ms.etot, tmp_ids, tmp_masks, ms.ecount, ms.scalars);
+                       ld, ms.etot, tmp_ids, tmp_masks, ms.ecount, ms.scalars, max_load);
     MERGE_TRY(hipGetLastError());
     // final offsets of the edges' lists (ms.cnt is free again: [pool + 1] >= [n_edges + 1]; its element n_edges is the total)
     MERGE_TRY(hipMemsetAsync(ms.ecount + n_edges, 0, sizeof(int32_t), stream));

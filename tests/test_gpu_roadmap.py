@@ -101,21 +101,26 @@ def test_union_kernel_and_sort_path_build_the_same_caches(irt, monkeypatch):
     states, _ = rb.sample_valid_vertices(3000, batch=8192)
     edges = rb.knn_edges_gpu(states, 7)
     got = {}
-    for mode in ("union", "sort"):
+    # "overflow": the union kernel gives up on every edge with more than 20 distinct blocks (all of them), the call falls back to
+    # the sort path half way -- the route an edge with more than 384 blocks takes
+    for mode in ("union", "sort", "overflow"):
+        monkeypatch.delenv("TENDON_HIP_MERGE", raising=False)
+        monkeypatch.delenv("TENDON_HIP_MERGE_MAXLOAD", raising=False)
         if mode == "sort":
             monkeypatch.setenv("TENDON_HIP_MERGE", "sort")
-        else:
-            monkeypatch.delenv("TENDON_HIP_MERGE", raising=False)
+        if mode == "overflow":
+            monkeypatch.setenv("TENDON_HIP_MERGE_MAXLOAD", "20")
         vc = rb.vertex_caches(states)
         ec = rb.edge_caches(states, edges)
         e_ok, cc = rb.connect(states, edges)
         got[mode] = (vc, ec, e_ok, cc)
-    for a, b in zip(got["union"], got["sort"]):
-        if isinstance(a, dict):
-            for key in ("offsets", "block_ids", "masks"):
-                assert np.array_equal(a[key], b[key]), key
-        else:
-            assert np.array_equal(a, b)
+    for other in ("sort", "overflow"):
+        for a, b in zip(got["union"], got[other]):
+            if isinstance(a, dict):
+                for key in ("offsets", "block_ids", "masks"):
+                    assert np.array_equal(a[key], b[key]), (other, key)
+            else:
+                assert np.array_equal(a, b), other
     vc, ec, e_ok, cc = got["union"]
     assert int(vc["offsets"][-1]) > 20 * len(states) and int(ec["offsets"][-1]) > 20 * int(ec["fully_valid"].sum()) and len(e_ok) > 0
     # ordered by block id, no block twice
