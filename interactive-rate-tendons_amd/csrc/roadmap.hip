@@ -38,6 +38,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tendon_hip.h"
@@ -68,6 +69,58 @@ template <class F> void on_threads(int T, F &&fn) {
   fn(0);
   for (auto &x : th) x.join();
 }
+
+// Device buffers of the query objects come from a small per-process cache instead of hipMalloc / hipFree: a roadmap build attaches
+// and later drops ~0.45 GB of them (block lists, offsets, the landmark arena), six allocations and frees of 0.1 - 1 ms each
+// (set_caches 2.8 -> 2.2 ms, prepare 6.1 -> 5.7 ms).  A freed buffer is kept (up to kCacheMaxBytes / kCacheMaxEntries per
+// process) and handed to the next request of at least half its size; a failed hipMalloc empties the cache and tries again.
+struct DevCache {
+  struct Buf { void *p; size_t bytes; int dev; };
+  std::mutex mu;
+  std::vector<Buf> idle;
+  std::unordered_map<void *, Buf> live;
+  size_t idle_bytes = 0;
+  static constexpr size_t kCacheMaxBytes = (size_t)3 << 30, kCacheMaxEntries = 48;
+  hipError_t alloc(int dev, void **out, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    std::lock_guard<std::mutex> lock(mu);
+    size_t best = idle.size();
+    for (size_t i = 0; i < idle.size(); i++)
+      if (idle[i].dev == dev && idle[i].bytes >= bytes && idle[i].bytes <= 2 * bytes + ((size_t)1 << 20) &&
+          (best == idle.size() || idle[i].bytes < idle[best].bytes)) best = i;
+    if (best < idle.size()) {
+      const Buf b = idle[best];
+      idle.erase(idle.begin() + (long)best);
+      idle_bytes -= b.bytes;
+      live[b.p] = b;
+      *out = b.p;
+      return hipSuccess;
+    }
+    const size_t cap = (bytes + ((size_t)1 << 16) - 1) & ~(((size_t)1 << 16) - 1);
+    void *p = nullptr;
+    hipError_t e = hipMalloc(&p, cap);
+    if (e != hipSuccess && !idle.empty()) {                     // out of memory with buffers parked here: give them back and try again
+      for (const Buf &b : idle) (void)hipFree(b.p);
+      idle.clear(); idle_bytes = 0;
+      e = hipMalloc(&p, cap);
+    }
+    if (e != hipSuccess) return e;
+    live[p] = Buf{p, cap, dev};
+    *out = p;
+    return hipSuccess;
+  }
+  void release(void *p) {
+    if (!p) return;
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = live.find(p);
+    if (it == live.end()) { (void)hipFree(p); return; }
+    const Buf b = it->second;
+    live.erase(it);
+    if (idle.size() < kCacheMaxEntries && idle_bytes + b.bytes <= kCacheMaxBytes) { idle.push_back(b); idle_bytes += b.bytes; }
+    else (void)hipFree(b.p);
+  }
+};
+DevCache &dev_cache() { static DevCache c; return c; }
 
 enum : uint8_t { V_UNKNOWN = 0, V_VALID = 1, V_INVALID = 2 };   // VALIDITY_UNKNOWN / VALIDITY_TRUE / removed from the graph
 
@@ -342,7 +395,7 @@ bool landmark_distances_device(tr_roadmap *r) {
                b_dist = up((size_t)V * L * sizeof(unsigned long long)), b_out = up((size_t)V * L * sizeof(float)),
                b_lm = up((size_t)L * sizeof(int32_t)), b_flags = up(BATCH * sizeof(uint32_t));
   char *arena = nullptr;
-  if (hipMalloc((void **)&arena, b_off + b_adj + b_dist + b_out + b_lm + b_flags) != hipSuccess) return false;
+  if (dev_cache().alloc(tr_device(r->ctx), (void **)&arena, b_off + b_adj + b_dist + b_out + b_lm + b_flags) != hipSuccess) return false;
   int64_t *d_off = (int64_t *)arena;
   Arc *d_adj = (Arc *)(arena + b_off);
   unsigned long long *d_dist = (unsigned long long *)(arena + b_off + b_adj);
@@ -373,7 +426,7 @@ bool landmark_distances_device(tr_roadmap *r) {
     ok = hipGetLastError() == hipSuccess &&
          hipMemcpy(r->lm_d.data(), d_out, (size_t)V * L * sizeof(float), hipMemcpyDeviceToHost) == hipSuccess;
   }
-  (void)hipFree(arena);
+  dev_cache().release(arena);
   return ok && converged;
 }
 
@@ -467,7 +520,7 @@ void build_landmarks(tr_roadmap *r, int n, int T) {
 
 void free_dev(tr_roadmap *r) {
   void *p[] = {r->d_ids, r->d_masks, r->d_off, r->d_list, r->d_hit, r->d_bits};
-  for (void *q : p) if (q) (void)hipFree(q);
+  for (void *q : p) if (q) dev_cache().release(q);
   r->d_ids = nullptr; r->d_masks = nullptr; r->d_off = nullptr; r->d_list = nullptr; r->d_hit = nullptr; r->d_bits = nullptr;
   r->list_cap = 0; r->has_caches = false;
 }
@@ -479,12 +532,12 @@ int check_items(tr_roadmap *r, const std::vector<int32_t> &list, std::vector<uin
   if (!r->has_caches) return rfail(r, TR_ERR_INVALID_ARG, "no voxel caches attached (tr_roadmap_set_caches)");
   const int64_t n = (int64_t)list.size();
   if (n > r->list_cap) {
-    if (r->d_list) (void)hipFree(r->d_list);
-    if (r->d_hit) (void)hipFree(r->d_hit);
+    if (r->d_list) dev_cache().release(r->d_list);
+    if (r->d_hit) dev_cache().release(r->d_hit);
     r->d_list = nullptr; r->d_hit = nullptr;
     r->list_cap = std::max<int64_t>(n + n / 2, 1 << 14);
-    RM_HIP(r, hipMalloc((void **)&r->d_list, (size_t)r->list_cap * sizeof(int32_t)));
-    RM_HIP(r, hipMalloc((void **)&r->d_hit, (size_t)r->list_cap));
+    RM_HIP(r, dev_cache().alloc(tr_device(r->ctx), (void **)&r->d_list, (size_t)r->list_cap * sizeof(int32_t)));
+    RM_HIP(r, dev_cache().alloc(tr_device(r->ctx), (void **)&r->d_hit, (size_t)r->list_cap));
   }
   RM_HIP(r, hipMemcpy(r->d_list, list.data(), (size_t)n * sizeof(int32_t), hipMemcpyHostToDevice));
   const int rc = tr_check_cached_subset_dev(r->ctx, r->d_ids, r->d_masks, r->d_off, r->V + r->E, r->d_list, n, r->d_hit, nullptr);
@@ -599,10 +652,11 @@ int set_caches_impl(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *v_i
   std::vector<int64_t> off((size_t)items + 1);
   for (int64_t i = 0; i <= r->V; i++) off[(size_t)i] = v_offsets[i];
   for (int64_t i = 0; i <= r->E; i++) off[(size_t)(r->V + i)] = nv + e_offsets[i];
-  RM_HIP(r, hipMalloc((void **)&r->d_ids, std::max<size_t>(1, (size_t)r->nnz) * sizeof(uint32_t)));
-  RM_HIP(r, hipMalloc((void **)&r->d_masks, std::max<size_t>(1, (size_t)r->nnz) * sizeof(uint64_t)));
-  RM_HIP(r, hipMalloc((void **)&r->d_off, off.size() * sizeof(int64_t)));
-  RM_HIP(r, hipMalloc((void **)&r->d_bits, ((size_t)items / 64 + 1) * sizeof(uint64_t)));
+  const int dev = tr_device(r->ctx);
+  RM_HIP(r, dev_cache().alloc(dev, (void **)&r->d_ids, std::max<size_t>(1, (size_t)r->nnz) * sizeof(uint32_t)));
+  RM_HIP(r, dev_cache().alloc(dev, (void **)&r->d_masks, std::max<size_t>(1, (size_t)r->nnz) * sizeof(uint64_t)));
+  RM_HIP(r, dev_cache().alloc(dev, (void **)&r->d_off, off.size() * sizeof(int64_t)));
+  RM_HIP(r, dev_cache().alloc(dev, (void **)&r->d_bits, ((size_t)items / 64 + 1) * sizeof(uint64_t)));
   if (nv) {
     RM_HIP(r, hipMemcpy(r->d_ids, v_ids, (size_t)nv * sizeof(uint32_t), kind));
     RM_HIP(r, hipMemcpy(r->d_masks, v_masks, (size_t)nv * sizeof(uint64_t), kind));

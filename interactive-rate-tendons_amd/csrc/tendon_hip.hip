@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <thread>
 #include <ctime>
 #include <limits>
 #include <mutex>
@@ -390,11 +391,14 @@ int ensure_staging(tr_ctx *ctx, int64_t n) {
 }
 
 // Host array -> device through a pinned buffer of the context (grow-only): memcpy, then a KERNEL that reads the pinned memory
-// over the bus (hipHostMalloc memory is mapped into the device's address space).  Measured in create_roadmap (the sampled states
-// going back up for their voxel sets, right after the connect call): the runtime's DMA copy of these 3.2 MB -- from the
-// pageable array or from this pinned buffer, on the null stream or on another -- completed after 13 - 25 ms, and after 0.06 ms
-// once any kernel had run on the stream first (profiles/r03/vox_timing_v*.txt); the kernel copy takes no such chances.
-// `bytes` must be a multiple of 8 (arrays of doubles / int64).
+// over the bus (hipHostMalloc memory is mapped into the device's address space): the same cost as the runtime's staged copy
+// without its choice between staging and pinning the caller's pages.  `bytes` must be a multiple of 8 (doubles / int64).
+// (How this came about: inside create_roadmap the upload of the 3.2 MB of vertices sometimes completed only after 10 - 35 ms.
+// It is not the copy: the FIRST submission of any kind after some calls -- a 2 KB device-to-device kernel on any stream -- can
+// take that long, a second one 0.02 ms, and after a 40 ms sleep the first one is fast too: something outside this library keeps
+// the device from taking the process's work for a while.  It happens in ~3 - 13 % of the calls of a loop with or without query
+// objects, allocation churn, munmap or user-page pinning (profiles/probe_prm_churn.py, probe_after_connect.py, r03/stalls_v1.txt)
+// on this pool's shared hosts; medians and minima are what the tables quote.)
 int upload_staged(tr_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipStream_t s) {
   if (bytes == 0) return TR_OK;
   if (bytes % 8) return fail(c, TR_ERR_INVALID_ARG, "upload_staged: whole 8-byte words only");

@@ -134,14 +134,18 @@ class RoadmapBuilder:
         t0 = time.perf_counter()
         out = self.engine.voxelize_edges_indexed(states, edges, self.mv.min_tension_change, self.mv.min_rotation_change,
                                                  self.mv.min_retraction_change, device=device, validate=True)
-        ok = out["fully_valid"]
+        keep = np.flatnonzero(out["fully_valid"])                      # (one index list for all four selections: boolean masks re-scan per use)
         off = out["offsets"]
-        out["offsets"] = np.concatenate([off[:-1][ok], off[-1:]])      # rejected edges own nothing: dropping them leaves the lists as they are
-        out["n_fk"] = out["n_fk"][ok]
-        out["fully_valid"] = np.ones(int(ok.sum()), dtype=bool)
+        new_off = np.empty(len(keep) + 1, dtype=off.dtype)              # rejected edges own nothing: dropping them leaves the lists as they are
+        np.take(off, keep, out=new_off[:-1])
+        new_off[-1] = off[-1]
+        out["offsets"] = new_off
+        out["n_fk"] = np.take(out["n_fk"], keep)
+        out["fully_valid"] = np.ones(len(keep), dtype=bool)
         e = np.asarray(edges).reshape(-1, 2)
-        self.timing["connect"] = dict(seconds=time.perf_counter() - t0, items=len(e), accepted=int(ok.sum()), blocks=int(off[-1]))
-        return e[ok], out
+        kept = np.take(e, keep, axis=0)
+        self.timing["connect"] = dict(seconds=time.perf_counter() - t0, items=len(e), accepted=len(keep), blocks=int(off[-1]))
+        return kept, out
 
     def create_roadmap(self, n_vertices, k=None, batch=1 << 17, device=True, n_landmarks=16):
         """createRoadmap (motion-planning/VoxelCachedLazyPRM.cpp:1431-1560) as one call: n_vertices valid milestones (:1446-1483),
