@@ -397,6 +397,8 @@ typedef struct {
  * edge weights (weightProperty_; NULL = state-space distance, what connectVertices stores :2857-2861). */
 int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, const int32_t *edges,
                       const double *weights, int64_t n_edges, tr_roadmap **out);
+/* Device buffers of a destroyed (or re-attached) roadmap are parked in a per-process cache for the next one -- at most 3 GiB /
+ * 48 buffers; a failed allocation empties it first -- so free device memory does not return to its earlier level at once. */
 void tr_roadmap_destroy(tr_roadmap *rm);
 const char *tr_roadmap_last_error(const tr_roadmap *rm);
 /* Upload the cached voxel sets (vertexVoxelsProperty_ / edgeVoxelsProperty_) as CSR block lists -- the output of
