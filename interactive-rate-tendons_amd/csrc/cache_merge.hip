@@ -481,23 +481,24 @@ __host__ __device__ __forceinline__ double from_ordered_bits(unsigned long long 
   __builtin_memcpy(&v, &b, 8);
   return v;
 }
-// min / max of the two key coordinates over all states (NaN keys are skipped: they land in cell 0 and are never within a radius)
-__global__ __launch_bounds__(256) void key_ranges(const double *__restrict__ states, int64_t n, int S, int col0, double scale0, int col1, double scale1,
-                                                  unsigned long long *__restrict__ mm /* [4]: min0, max0, min1, max1 as ordered bits */) {
+// min / max of the key coordinates over all states (NaN keys are skipped: they land in cell 0 and are never within a radius)
+__global__ __launch_bounds__(256) void key_ranges(const double *__restrict__ states, int64_t n, int S, KnnCells g,
+                                                  unsigned long long *__restrict__ mm /* [6]: min0, max0, min1, max1, min2, max2 as ordered bits */) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  double a = 1.0 / 0.0, b = -1.0 / 0.0, c = 1.0 / 0.0, d = -1.0 / 0.0;
+  double lo[3] = {1.0 / 0.0, 1.0 / 0.0, 1.0 / 0.0}, hi[3] = {-1.0 / 0.0, -1.0 / 0.0, -1.0 / 0.0};
   if (i < n) {
-    const double k0 = scale0 * states[i * S + col0];
-    if (k0 == k0) { a = k0; b = k0; }
-    if (col1 >= 0) { const double k1 = scale1 * states[i * S + col1]; if (k1 == k1) { c = k1; d = k1; } }
+    const int col[3] = {g.col0, g.col1, g.col2};
+    const double sc[3] = {g.scale0, g.scale1, g.scale2};
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+      if (col[a] >= 0) { const double kx = sc[a] * states[i * S + col[a]]; if (kx == kx) { lo[a] = kx; hi[a] = kx; } }
   }
-  for (int o = 32; o > 0; o >>= 1) {
-    a = fmin(a, __shfl_xor(a, o, 64)); b = fmax(b, __shfl_xor(b, o, 64));
-    c = fmin(c, __shfl_xor(c, o, 64)); d = fmax(d, __shfl_xor(d, o, 64));
-  }
+#pragma unroll
+  for (int a = 0; a < 3; a++)
+    for (int o = 32; o > 0; o >>= 1) { lo[a] = fmin(lo[a], __shfl_xor(lo[a], o, 64)); hi[a] = fmax(hi[a], __shfl_xor(hi[a], o, 64)); }
   if ((threadIdx.x & 63) == 0) {
-    atomicMin(&mm[0], ordered_bits(a)); atomicMax(&mm[1], ordered_bits(b));
-    atomicMin(&mm[2], ordered_bits(c)); atomicMax(&mm[3], ordered_bits(d));
+#pragma unroll
+    for (int a = 0; a < 3; a++) { atomicMin(&mm[2 * a], ordered_bits(lo[a])); atomicMax(&mm[2 * a + 1], ordered_bits(hi[a])); }
   }
 }
 __global__ __launch_bounds__(256) void cell_keys(const double *__restrict__ states, int64_t n, int S, KnnCells g, uint32_t *__restrict__ keys,
@@ -506,10 +507,11 @@ __global__ __launch_bounds__(256) void cell_keys(const double *__restrict__ stat
   if (i >= n) return;
   const double k0 = g.scale0 * states[i * S + g.col0];
   const double k1 = g.col1 >= 0 ? g.scale1 * states[i * S + g.col1] : 0.0;
-  keys[i] = (uint32_t)(knn_cell_of(k0, g.lo0, g.inv0, g.C) * g.B + knn_cell_of(k1, g.lo1, g.inv1, g.B));
+  const double k2 = g.col2 >= 0 ? g.scale2 * states[i * S + g.col2] : 0.0;
+  keys[i] = (uint32_t)((knn_cell_of(k0, g.lo0, g.inv0, g.C) * g.B + knn_cell_of(k1, g.lo1, g.inv1, g.B)) * g.A + knn_cell_of(k2, g.lo2, g.inv2, g.A));
   vals[i] = (int32_t)i;
 }
-// cellstart[c] = first sorted position whose cell id is >= c (c = 0 .. C B)
+// cellstart[c] = first sorted position whose cell id is >= c (c = 0 .. C B A)
 __global__ __launch_bounds__(256) void cell_starts(const uint32_t *__restrict__ sorted_keys, int64_t n, int n_cells, int32_t *__restrict__ cellstart) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   if (c > n_cells) return;
@@ -523,21 +525,22 @@ hipError_t sort_states_by_cells(MergeScratch &ms, const double *d_states, int64_
                                 int32_t *d_perm, int32_t *d_cellstart, uint32_t *d_keys[2], int32_t *d_perm_tmp, hipStream_t stream) {
   if (n <= 0) return hipSuccess;
   if (!ms.scalars) MERGE_TRY(grow(&ms.scalars, 2));
-  // key ranges: four ordered-bit words in a scratch of their own (the merge's scalars hold only two)
+  // key ranges: six ordered-bit words in a scratch of their own (the merge's scalars hold only two)
   unsigned long long *mm = nullptr;
-  MERGE_TRY(hipMalloc((void **)&mm, 4 * sizeof(unsigned long long)));
-  const unsigned long long init[4] = {~0ull, 0ull, ~0ull, 0ull};
+  MERGE_TRY(hipMalloc((void **)&mm, 6 * sizeof(unsigned long long)));
+  const unsigned long long init[6] = {~0ull, 0ull, ~0ull, 0ull, ~0ull, 0ull};
   hipError_t e = hipMemcpyAsync(mm, init, sizeof(init), hipMemcpyHostToDevice, stream);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(key_ranges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, g.col0, g.scale0, g.col1, g.scale1, mm);
+    hipLaunchKernelGGL(key_ranges, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, g, mm);
     e = hipGetLastError();
   }
-  unsigned long long got[4];
+  unsigned long long got[6];
   if (e == hipSuccess) e = hipMemcpyAsync(got, mm, sizeof(got), hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
   (void)hipFree(mm);
   MERGE_TRY(e);
   const double a0 = from_ordered_bits(got[0]), b0 = from_ordered_bits(got[1]), a1 = from_ordered_bits(got[2]), b1 = from_ordered_bits(got[3]);
+  const double a2 = from_ordered_bits(got[4]), b2 = from_ordered_bits(got[5]);
   auto cells = [&](double lo, double hi) {
     if (!(hi > lo) || !(cell_width > 0.0)) return 1;
     const double c = std::ceil((hi - lo) / cell_width);
@@ -545,12 +548,14 @@ hipError_t sort_states_by_cells(MergeScratch &ms, const double *d_states, int64_
   };
   g.C = cells(a0, b0);
   g.B = g.col1 >= 0 ? cells(a1, b1) : 1;
+  g.A = g.col2 >= 0 ? cells(a2, b2) : 1;
   g.lo0 = (b0 >= a0) ? a0 : 0.0; g.inv0 = g.C > 1 ? (double)g.C / (b0 - a0) : 0.0;
   g.lo1 = (b1 >= a1) ? a1 : 0.0; g.inv1 = g.B > 1 ? (double)g.B / (b1 - a1) : 0.0;
+  g.lo2 = (b2 >= a2) ? a2 : 0.0; g.inv2 = g.A > 1 ? (double)g.A / (b2 - a2) : 0.0;
   hipLaunchKernelGGL(cell_keys, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, d_states, n, S, g, d_keys[0], d_perm_tmp);
   MERGE_TRY(hipGetLastError());
   int bits = 1;
-  while ((1 << bits) < g.C * g.B) bits++;
+  while ((1 << bits) < g.C * g.B * g.A) bits++;
   size_t bytes = 0;
   MERGE_TRY(rocprim::radix_sort_pairs(nullptr, bytes, d_keys[0], d_keys[1], d_perm_tmp, d_perm, (size_t)n, 0u, (unsigned)bits, stream));
   if (ms.cap_tmp < bytes) {
@@ -558,7 +563,7 @@ hipError_t sort_states_by_cells(MergeScratch &ms, const double *d_states, int64_
     ms.cap_tmp = bytes + bytes / 4;
   }
   MERGE_TRY(rocprim::radix_sort_pairs(ms.tmp, bytes, d_keys[0], d_keys[1], d_perm_tmp, d_perm, (size_t)n, 0u, (unsigned)bits, stream));
-  hipLaunchKernelGGL(cell_starts, dim3((unsigned)((g.C * g.B + 1 + 255) / 256)), dim3(256), 0, stream, d_keys[1], n, g.C * g.B, d_cellstart);
+  hipLaunchKernelGGL(cell_starts, dim3((unsigned)((g.C * g.B * g.A + 1 + 255) / 256)), dim3(256), 0, stream, d_keys[1], n, g.C * g.B * g.A, d_cellstart);
   hipLaunchKernelGGL(gather_states, dim3((unsigned)((n * S + 255) / 256)), dim3(256), 0, stream, d_states, d_perm, n, S, d_sorted);
   return hipGetLastError();
 }

@@ -61,10 +61,13 @@ hipError_t sort_states_by_key(MergeScratch &ms, const double *d_states, int64_t 
 // uniform width over the keys' ranges.  knn_cell_of is monotone non-decreasing in the key, so every candidate whose key lies in
 // [lo, hi] has its cell index in [cell(lo), cell(hi)]: the search visits exactly those cells.
 struct KnnCells {
-  int32_t col0, col1;           // state columns of the two keys (col1 = -1: one key only)
+  int32_t col0, col1;           // state columns of the first two keys (col1 = -1: one key only)
   int32_t C, B;                 // cells along key 0 / key 1
   double scale0, scale1;        // key = scale * state[col]
   double lo0, inv0, lo1, inv1;  // cell = clamp((int)((key - lo) * inv), 0, cells - 1)
+  // an optional third key (the wave-per-query search, knn_kernel.hpp: knn_wave_query): cell id = (c0 B + c1) A + c2; col2 = -1, A = 1: none
+  int32_t col2, A;
+  double scale2, lo2, inv2;
 };
 __host__ __device__ inline int knn_cell_of(double key, double lo, double inv, int cells) {
   const double t = (key - lo) * inv;
@@ -74,7 +77,7 @@ __host__ __device__ inline int knn_cell_of(double key, double lo, double inv, in
 // d_sorted [n][S] = the states ordered by cell id (key-0 cell major), d_perm [n] the original index of each, d_cellstart [C B + 1]
 // the first sorted position of every cell.  g comes in with col / scale set; C, B (cells of about cell_width along each key's
 // range in the data, at most max_cells; 1 along a key without spread), lo and inv are filled in.  d_keys: two scratch arrays of
-// n uint32, d_perm_tmp n int32, d_cellstart max_cells^2 + 1 int32.  Synchronises `stream` once (the key ranges).
+// n uint32, d_perm_tmp n int32, d_cellstart C B A + 1 <= max_cells^3 + 1 int32 (max_cells^2 + 1 without a third key).  Synchronises `stream` once (the key ranges).
 hipError_t sort_states_by_cells(MergeScratch &ms, const double *d_states, int64_t n, int S, KnnCells &g, double cell_width, int max_cells, double *d_sorted,
                                 int32_t *d_perm, int32_t *d_cellstart, uint32_t *d_keys[2], int32_t *d_perm_tmp, hipStream_t stream);
 

@@ -272,6 +272,197 @@ __global__ __launch_bounds__(64) void knn_bruteforce(const double *__restrict__ 
   }
 }
 
+// K6, wave-per-query form (k <= 64): a WAVE serves Q query vertices that are neighbours in sorted order, its 64 lanes each taking
+// one candidate of a tile (a coalesced read of 64 consecutive sorted states).  No divergence between queries: the lane-per-query
+// form above spends most of its time in list insertions that every lane of the wave sits through whenever ANY of its 64 queries
+// inserts (issue utilisation 0.10, r03).  Per query the k best live one per lane, in order (lanes >= k hold an inert entry), the
+// threshold (the list's last entry by (distance, original index)) is wave-uniform, a tile's candidates that pass it are taken
+// one by one (ballot), each shifting the entries behind it one lane up.  Q queries per
+// tile: a candidate fetched once is measured against Q queries -- with one query per wave the 6 x 10^5-vertex table re-read its
+// 19 MB of states ~5 000 times (94 GB, 16.5 ms); the search box is the union of the Q queries' own.  Same arithmetic for the
+// distances, same acceptance rule, same expanding cell search, same output order as knn_bruteforce: identical tables.
+template <int NT, bool ROT, bool RET, int Q, int G>
+__global__ __launch_bounds__(256) void knn_wave_query(const double *__restrict__ cand, KnnCells cg, const int32_t *__restrict__ cellstart,
+                                                      const int32_t *__restrict__ perm, const int32_t *__restrict__ qlist, int64_t nq,
+                                                      KnnMetric m, int k, double max_dist, int64_t row_first,
+                                                      int32_t *__restrict__ out_idx, double *__restrict__ out_dist) {
+#pragma clang fp contract(off)
+  const int lane = threadIdx.x & 63;
+  const int64_t q0 = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * Q;
+  if (q0 >= nq) return;                                                 // wave-uniform
+  constexpr int SS = NT + (ROT ? 1 : 0) + (RET ? 1 : 0);
+  constexpr int SS_KEY = NT + (ROT ? 1 : 0);
+  constexpr bool plain = !ROT && !RET;
+  constexpr int K1 = RET ? 0 : (NT >= 2 ? 1 : -1);
+  auto uniform = [](double v) {
+    return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+  };
+  auto lane_value = [](double v, int src) {                             // src wave-uniform
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), src), __builtin_amdgcn_readlane(__double2loint(v), src));
+  };
+  int64_t js[Q];                                                        // the queries' positions in sorted order (a query beyond nq repeats the last one)
+  double x[Q][SS];
+  // the lists: lane e < k holds one entry per query, +inf / -1 while empty; lanes >= k hold (-inf, 0): never the largest, never replaced
+  double ld[Q], worst[Q], gate2[Q];
+  int32_t li[Q], worst_i[Q];
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    const int64_t qi = q0 + q < nq ? q0 + q : nq - 1;
+    js[q] = qlist ? (int64_t)qlist[qi] : qi;
+#pragma unroll
+    for (int d = 0; d < SS; d++) x[q][d] = uniform(cand[js[q] * SS + d]);
+    ld[q] = lane < k ? 1.0 / 0.0 : -1.0 / 0.0;
+    li[q] = lane < k ? -1 : 0;
+    worst[q] = 1.0 / 0.0;                                               // wave-uniform: the threshold
+    worst_i[q] = -1;                                                    // original index of the largest entry (-1: the list is not full)
+    gate2[q] = worst[q] * worst[q] * (1.0 + 4.5e-16);
+  }
+  // The list is kept ORDERED across the lanes (lane e: the e-th entry by (distance, index), empty entries -- +inf, -1 -- last):
+  // an accepted candidate shifts the entries that sort after it one lane up, the last one falls out, and the threshold is
+  // whatever lane k - 1 then holds (+inf / -1 while the list is not full).  ~25 instructions per insertion; finding the new
+  // largest entry of an unordered list by a butterfly reduction was ~100, and with ~80 insertions per query most of the kernel.
+  auto insert = [&](double &ldq, int32_t &liq, double cd, int32_t ci, double &worstq, int32_t &worst_iq, double &gate2q) {
+    const bool after = lane < k && (liq < 0 || cd < ldq || (cd == ldq && ci < liq));       // my entry sorts after the new one
+    const int prev_after = __shfl_up((int)after, 1, 64);
+    const double pd = __shfl_up(ldq, 1, 64);
+    const int32_t pi = __shfl_up(liq, 1, 64);
+    if (after) {
+      const bool from_prev = lane > 0 && prev_after != 0;
+      ldq = from_prev ? pd : cd;
+      liq = from_prev ? pi : ci;
+    }
+    worstq = lane_value(ldq, k - 1);
+    worst_iq = __builtin_amdgcn_readlane(liq, k - 1);
+    gate2q = worstq * worstq * (1.0 + 4.5e-16);
+  };
+  // one tile: the lane's candidate c (position jl, `have`: it exists) against the Q queries
+  auto tile = [&](const double (&c)[SS], int64_t jl, bool have) {
+    double dist[Q];
+    unsigned long long mask[Q], any = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      double s2 = 0.0;
+#pragma unroll
+      for (int d = 0; d < NT; d++) { const double t = x[q][d] - c[d]; s2 += t * t; }
+      bool pass = have;
+      if constexpr (plain) {
+        // the root only of a squared distance that can still matter (the IEEE square root is ~20 instructions; a wave leaves
+        // the branch unless one of its 64 candidates passes)
+        pass = pass && s2 <= gate2[q];
+        dist[q] = 1.0 / 0.0;
+        if (pass) dist[q] = sqrt(s2);
+      } else {
+        dist[q] = sqrt(s2);
+        if constexpr (ROT) {                                  // SO2StateSpace::distance
+          double a_ = fabs(x[q][NT] - c[NT]);
+          a_ = (a_ > 3.14159265358979323846) ? 2.0 * 3.14159265358979323846 - a_ : a_;
+          dist[q] += m.w_rot * a_;
+        }
+        if constexpr (RET) {
+          const double t = x[q][SS - 1] - c[SS - 1];
+          dist[q] += m.w_ret * sqrt(t * t);
+        }
+      }
+      pass = pass && dist[q] <= worst[q];
+      mask[q] = __ballot(pass);
+      any |= mask[q];
+    }
+    if (!any) return;
+    const int32_t cj = perm[jl];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      unsigned long long mk = mask[q];
+      while (mk) {
+        const int src = __builtin_ctzll(mk);
+        mk &= mk - 1;
+        const double cd = lane_value(dist[q], src);
+        const int32_t ci = __builtin_amdgcn_readlane(cj, src);
+        // the acceptance rule of knn_bruteforce, against the CURRENT threshold (it moves with every replacement)
+        if (cd <= worst[q] && (cd < worst[q] || worst_i[q] < 0 || ci < worst_i[q])) insert(ld[q], li[q], cd, ci, worst[q], worst_i[q], gate2[q]);
+      }
+    }
+  };
+  // a run [a, b) of sorted positions, G tiles at a time: their reads are issued together (a wave with one tile in flight spent
+  // ~3 us per tile waiting for it: 16.5 ms per 6 x 10^5 queries, whatever Q)
+  auto scan = [&](int64_t a, int64_t b) {
+    for (int64_t jt = a; jt < b; jt += 64 * G) {
+      double c[G][SS];
+      int64_t jl[G];
+      bool have[G];
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        const int64_t j = jt + 64 * g + lane;
+        have[g] = j < b;
+        jl[g] = have[g] ? j : b - 1;
+#pragma unroll
+        for (int d = 0; d < SS; d++) c[g][d] = cand[jl[g] * SS + d];
+      }
+#pragma unroll
+      for (int g = 0; g < G; g++) {
+        if (jt + 64 * g >= b) break;                                    // wave-uniform
+        tile(c[g], jl[g], have[g]);
+      }
+    }
+  };
+  // cells (cx, cy, z0 .. z1): consecutive in sorted order
+  auto scan_cells = [&](int cx, int cy, int z0, int z1) {
+    if (z0 <= z1) { const int base = (cx * cg.B + cy) * cg.A; scan((int64_t)cellstart[base + z0], (int64_t)cellstart[base + z1 + 1]); }
+  };
+  {
+    // Three keys, each a TERM of the metric (|key difference| <= distance): a box of cells around the queries' own, grown ring by
+    // ring towards the window the current thresholds still ask for, until it covers that window.  (Two keys left ~5 000 of 6 x 10^5
+    // uniform 4-D states inside the window of a 10-neighbour search, three leave ~900.)
+    constexpr int K2 = RET ? (NT >= 2 ? 1 : -1) : (NT >= 3 ? 2 : -1);   // the third key's coordinate (cache_merge.hpp: KnnCells::col2)
+    double k0[Q], k1[Q], k2[Q];
+    int sx0 = 1 << 30, sx1 = -1, sy0 = 1 << 30, sy1 = -1, sz0 = 1 << 30, sz1 = -1;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+      k0[q] = RET ? m.w_ret * x[q][SS_KEY] : x[q][0];                   // the products sort_states_by_cells formed (cg.scale x coordinate)
+      k1[q] = K1 >= 0 ? x[q][K1 >= 0 ? K1 : 0] : 0.0;
+      k2[q] = (K2 >= 0 && cg.col2 >= 0) ? x[q][K2 >= 0 ? K2 : 0] : 0.0;
+      const int cx = knn_cell_of(k0[q], cg.lo0, cg.inv0, cg.C), cy = knn_cell_of(k1[q], cg.lo1, cg.inv1, cg.B), cz = knn_cell_of(k2[q], cg.lo2, cg.inv2, cg.A);
+      sx0 = cx < sx0 ? cx : sx0; sx1 = cx > sx1 ? cx : sx1; sy0 = cy < sy0 ? cy : sy0; sy1 = cy > sy1 ? cy : sy1; sz0 = cz < sz0 ? cz : sz0; sz1 = cz > sz1 ? cz : sz1;
+    }
+    for (int cx = sx0; cx <= sx1; cx++)
+      for (int cy = sy0; cy <= sy1; cy++) scan_cells(cx, cy, sz0, sz1);
+    for (;;) {
+      // the window the queries' thresholds still ask for (an unfilled list: everything)
+      int nx0 = 1 << 30, nx1 = -1, ny0 = 1 << 30, ny1 = -1, nz0 = 1 << 30, nz1 = -1;
+#pragma unroll
+      for (int q = 0; q < Q; q++) {
+        double r = worst[q] < max_dist ? worst[q] : max_dist;
+        r = r + r * 1e-12;
+        const int a0 = knn_cell_of(k0[q] - r, cg.lo0, cg.inv0, cg.C), a1 = knn_cell_of(k0[q] + r, cg.lo0, cg.inv0, cg.C);
+        const int b0 = knn_cell_of(k1[q] - r, cg.lo1, cg.inv1, cg.B), b1 = knn_cell_of(k1[q] + r, cg.lo1, cg.inv1, cg.B);
+        const int c0 = knn_cell_of(k2[q] - r, cg.lo2, cg.inv2, cg.A), c1 = knn_cell_of(k2[q] + r, cg.lo2, cg.inv2, cg.A);
+        nx0 = a0 < nx0 ? a0 : nx0; nx1 = a1 > nx1 ? a1 : nx1; ny0 = b0 < ny0 ? b0 : ny0; ny1 = b1 > ny1 ? b1 : ny1;
+        nz0 = c0 < nz0 ? c0 : nz0; nz1 = c1 > nz1 ? c1 : nz1;
+      }
+      if (nx0 >= sx0 && nx1 <= sx1 && ny0 >= sy0 && ny1 <= sy1 && nz0 >= sz0 && nz1 <= sz1) break;
+      // one ring towards it: every column (cx, cy) of the grown box takes the rows it has not been through
+      const int tx0 = nx0 < sx0 ? sx0 - 1 : sx0, tx1 = nx1 > sx1 ? sx1 + 1 : sx1;
+      const int ty0 = ny0 < sy0 ? sy0 - 1 : sy0, ty1 = ny1 > sy1 ? sy1 + 1 : sy1;
+      const int tz0 = nz0 < sz0 ? sz0 - 1 : sz0, tz1 = nz1 > sz1 ? sz1 + 1 : sz1;
+      for (int cx = tx0; cx <= tx1; cx++)
+        for (int cy = ty0; cy <= ty1; cy++) {
+          if (cx >= sx0 && cx <= sx1 && cy >= sy0 && cy <= sy1) { scan_cells(cx, cy, tz0, sz0 - 1); scan_cells(cx, cy, sz1 + 1, tz1); }
+          else scan_cells(cx, cy, tz0, tz1);
+        }
+      sx0 = tx0; sx1 = tx1; sy0 = ty0; sy1 = ty1; sz0 = tz0; sz1 = tz1;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < Q; q++) {
+    if (q0 + q >= nq) break;                                            // (a repeated last query: nothing to write)
+    if (lane < k) {
+      const int64_t o = ((int64_t)perm[js[q]] - row_first) * k + lane;       // (the list is in order)
+      const bool ok = li[q] >= 0 && !(ld[q] > max_dist);
+      out_idx[o] = ok ? li[q] : -1;
+      out_dist[o] = ok ? ld[q] : 1.0 / 0.0;
+    }
+  }
+}
+
 // Merge the per-slice lists of a query (each ordered by (distance, original index)) into its k nearest: smallest head
 // first, ties to the lower index -- the order of a stable sort of all distances.
 __global__ __launch_bounds__(64) void knn_merge(const int32_t *__restrict__ part_idx, const double *__restrict__ part_dist, int64_t n,

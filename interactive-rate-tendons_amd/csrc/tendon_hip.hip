@@ -1799,6 +1799,10 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
   int32_t *d_perm = nullptr, *d_pt = nullptr, *d_ql = nullptr, *d_i = nullptr, *d_pi = nullptr, *d_cs = nullptr;
   trk::KnnCells cg{};
   constexpr int kMaxCells = 64;
+  // k <= 64: a wave per query over a THREE-key cell grid (knn_kernel.hpp: knn_wave_query); larger k (or TENDON_HIP_KNN=lanes, read
+  // per call: tests and A/B timing): a lane per query over two keys with the list in an LDS column
+  const char *knn_mode = std::getenv("TENDON_HIP_KNN");
+  const bool wave_form = k <= 64 && !(knn_mode && std::strcmp(knn_mode, "lanes") == 0);
   int rc = TR_OK;
   auto scratch = [&](int slot, size_t bytes, auto **out) -> bool {          // grow-only buffers kept in the context
     tr_ctx::KnnScratch &ks = c->knn;
@@ -1816,7 +1820,7 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
     // (slot 2: the two cell-id arrays of the sort; slot 3: the cells' first positions)
     uint32_t *ck = nullptr;
     if (!scratch(0, nn * S * sizeof(double), &d_s) || !scratch(1, nn * S * sizeof(double), &d_ss) || !scratch(2, 2 * nn * sizeof(uint32_t), &ck) ||
-        !scratch(3, ((size_t)kMaxCells * kMaxCells + 1) * sizeof(int32_t), &d_cs) || !scratch(4, nn * sizeof(int32_t), &d_perm) || !scratch(5, nn * sizeof(int32_t), &d_pt) ||
+        !scratch(3, ((size_t)kMaxCells * kMaxCells * kMaxCells + 1) * sizeof(int32_t), &d_cs) || !scratch(4, nn * sizeof(int32_t), &d_perm) || !scratch(5, nn * sizeof(int32_t), &d_pt) ||
         !scratch(6, qq * k * sizeof(double), &d_d) || !scratch(7, qq * k * sizeof(int32_t), &d_i) ||
         (half_window && !scratch(8, qq * sizeof(double), &d_seed)) ||
         (nslice > 1 && (!scratch(9, qq * nslice * k * sizeof(double), &d_pd) || !scratch(10, qq * nslice * k * sizeof(int32_t), &d_pi)))) {
@@ -1834,6 +1838,7 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       const bool by_ret = c->K.enable_retraction != 0;
       cg.col0 = by_ret ? S - 1 : 0; cg.scale0 = by_ret ? m.w_ret : 1.0;
       cg.col1 = by_ret ? 0 : (N >= 2 ? 1 : -1); cg.scale1 = 1.0;
+      cg.col2 = wave_form ? (by_ret ? (N >= 2 ? 1 : -1) : (N >= 3 ? 2 : -1)) : -1; cg.scale2 = 1.0; cg.A = 1;
       double logprod = 0.0;
       for (int i = 0; i < N; i++) logprod += std::log(std::max(c->max_tension[i], 1e-12));
       if (c->K.enable_rotation) logprod += std::log(m.w_rot * 2.0 * M_PI);
@@ -1841,7 +1846,13 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       const double r_est = std::pow((double)k / (double)n, 1.0 / S) * std::exp(logprod / S) / 1.5;
       double width = 0.25 * r_est;                  // measured at 10^5 and 6 x 10^5 states: 0.25 r (or the 64-cell cap) 6.2 / 27 ms, 0.5 r 7.3 / 31 ms, r 13 / 51 ms
       if (const char *e = std::getenv("TENDON_HIP_KNN_CELL")) { const double v = std::atof(e); if (v > 0) width *= v; }      // tuning only
-      const int max_cells = n >= 4096 ? (int)std::min<int64_t>(kMaxCells, std::max<int64_t>(1, (int64_t)std::sqrt((double)n / 64.0))) : 1;
+      int max_cells = n >= 4096 ? (int)std::min<int64_t>(kMaxCells, std::max<int64_t>(1, (int64_t)std::sqrt((double)n / 64.0))) : 1;
+      if (cg.col2 >= 0) {
+        // three keys, one query per wave: ~12 states per cell (a run of a column's cells inside the search box is then about one
+        // 64-candidate tile), cells about half the expected k-th distance wide
+        max_cells = n >= 512 ? (int)std::min<int64_t>(kMaxCells, std::max<int64_t>(1, (int64_t)std::cbrt((double)n / 12.0))) : 1;
+        width = 2.0 * width;
+      }
       const hipError_t e = trk::sort_states_by_cells(c->merge, d_s, n, S, cg, width, max_cells, d_ss, d_perm, d_cs, d_ck, d_pt, nullptr);
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn sort: ") + hipGetErrorString(e)); break; }
     }
@@ -1861,8 +1872,12 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       int32_t *oi = nslice > 1 ? d_pi : d_i;
       double *od = nslice > 1 ? d_pd : d_d;
       const int variant = (c->K.enable_rotation ? 1 : 0) | (c->K.enable_retraction ? 2 : 0);
-#define TRK_KNN_K(NT, R, T, KC) hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T, KC>), grid, dim3(64), lds, nullptr, d_ss, cg, d_cs, d_perm, d_ql, nq, n, m, (int)k, \
-                                                  max_distance, (int64_t)0, (const double *)nullptr, (double *)nullptr, q0, oi, od)
+      constexpr int kWaveQ = 1, kWaveG = 1;                       // queries per wave, tiles in flight (measured: knn_kernel.hpp)
+      const dim3 wgrid((unsigned)((nq + 4 * kWaveQ - 1) / (4 * kWaveQ)));
+#define TRK_KNN_K(NT, R, T, KC) do { if (wave_form) hipLaunchKernelGGL((trk::knn_wave_query<NT, R, T, kWaveQ, kWaveG>), wgrid, dim3(256), 0, nullptr, d_ss, cg, d_cs, d_perm, d_ql, nq, m, \
+                                                  (int)k, max_distance, q0, oi, od); \
+                                     else hipLaunchKernelGGL((trk::knn_bruteforce<NT, R, T, KC>), grid, dim3(64), lds, nullptr, d_ss, cg, d_cs, d_perm, d_ql, nq, n, m, (int)k, \
+                                                  max_distance, (int64_t)0, (const double *)nullptr, (double *)nullptr, q0, oi, od); } while (0)
       // (KCAP = 16 / 32 -- the list in registers -- measured SLOWER than the LDS column at every k: 29.9 against 27.4 ms at k = 11,
       // 416 against 57 ms at k = 21 for 6 x 10^5 states; the instantiations are not built)
 #define TRK_KNN(NT, R, T) TRK_KNN_K(NT, R, T, 0)
