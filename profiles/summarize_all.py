@@ -36,7 +36,7 @@ def key_of(name):
         return "cache merge (rocPRIM sort + reduce)"
     if base in ("grid_add_spheres", "grid_add_capsules", "grid_dilate_step", "grid_remove_interior", "dilate2_blocks", "grid_embed", "grid_extract"):
         return "environment edits (grid_add_spheres / grid_add_capsules / grid_dilate_step / grid_remove_interior / dilate2_blocks)"
-    if base.startswith("fk_") or base == "knn_bruteforce":
+    if base.startswith("fk_") or base in ("knn_bruteforce", "knn_wave_query"):
         return "%s<%s>" % (base, n) if n else base
     return base
 

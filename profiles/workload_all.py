@@ -104,7 +104,7 @@ def main():
     edges = rb.knn_edges_gpu(states, k + 1)
     # since the search runs on sorted states a wave visits only the candidates within its seed radius: V^2 pairs are DECIDED,
     # about a fifth of them computed -- no flop or byte figure is claimed for the row
-    add("knn_bruteforce<4>", units=float(V) * V, unit="pair distances decided (expanding cell search: a few thousand computed per query)")
+    add("knn_wave_query<4>", units=float(V) * V, unit="pair distances decided (a wave per query, three-key cell grid: ~10^3 computed per query)")
     chk.engine.reserve_edges(len(edges))
     chk.engine.profile_begin()
     valid, nfk = rb.validate_edges(states, edges)
