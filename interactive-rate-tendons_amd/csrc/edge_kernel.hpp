@@ -326,6 +326,13 @@ __global__ __launch_bounds__(256) void edge_last_valid_t(EdgeState st, int64_t s
   if (t < __longlong_as_double((long long)st.first_inv[e])) atomicMax(&st.last_t[e], (unsigned long long)__double_as_longlong(t));
 }
 
+// bit e = edge e of the run is valid: the run's verdicts as the words of the caller's mask (E bits from bit 0 of out[0])
+__global__ __launch_bounds__(256) void edge_ok_bits(const uint32_t *__restrict__ edge_ok, int64_t E, uint64_t *__restrict__ out) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const unsigned long long m = __ballot(e < E && edge_ok[e] != 0u);
+  if ((threadIdx.x & 63) == 0 && e < E) out[e >> 6] = m;
+}
+
 // bit s = pool sample s belongs to a fully valid edge (its backbone joins the edge's voxel cache)
 __global__ __launch_bounds__(256) void edge_sample_bits(EdgeState st, int64_t pool, uint64_t *__restrict__ out) {
   const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
