@@ -214,3 +214,33 @@ def test_windowed_search_with_rotation_and_retraction_metrics(irt, orc, helpers,
     md = float(np.median(dist[:, 5]))
     idx3, _ = eng.knn(st, k, max_distance=md)
     assert np.array_equal(idx3 >= 0, dist <= md) and np.array_equal(idx3[idx3 >= 0], idx[dist <= md])
+
+
+def test_wave_per_query_and_lane_per_query_kernels_give_the_same_tables(irt, monkeypatch):
+    """k <= 64 runs a wave per query over a three-key cell grid (knn_wave_query), larger k -- or TENDON_HIP_KNN=lanes -- a lane per
+    query over two keys (knn_bruteforce): identical tables, entry for entry, at small k, at the 64 / 65 boundary, with a distance
+    bound, with duplicates and with fewer states than k."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=8)
+    eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+    rng = np.random.default_rng(23)
+    st = rng.uniform(0, 20, (9000, 4))
+    st[500:540] = st[499]                                       # ties
+    small = rng.uniform(0, 20, (40, 4))
+
+    def table(states, k, max_distance=np.inf, lanes=False):
+        if lanes:
+            monkeypatch.setenv("TENDON_HIP_KNN", "lanes")
+        else:
+            monkeypatch.delenv("TENDON_HIP_KNN", raising=False)
+        return eng.knn(states, k, max_distance)
+
+    for states, k, md in ((st, 11, np.inf), (st, 64, np.inf), (st, 3, 2.5), (small, 64, np.inf), (st[:3000], 33, 6.0)):
+        a, b = table(states, k, md), table(states, k, md, lanes=True)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), (k, md)
+    # k = 65 always takes the lane-per-query kernel; its first 64 columns are the k = 64 table
+    monkeypatch.delenv("TENDON_HIP_KNN", raising=False)
+    i65, d65 = eng.knn(st[:4000], 65)
+    i64, d64 = eng.knn(st[:4000], 64)
+    assert np.array_equal(i65[:, :64], i64) and np.array_equal(d65[:, :64], d64)
