@@ -442,6 +442,18 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
  * receives the number of edges (if it exceeds capacity only the first `capacity` are written: at most n (k - 1) edges exist -- n k when k or more states coincide, a row then need not hold its own vertex). */
 int tr_knn_edges(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double max_distance, int32_t *edges,
                  int64_t capacity, int64_t *n_edges);
+/* Device-resident form of the connection loop and of the edge checks after it: d_states (n x state_size doubles) and d_edges
+ * (capacity x 2 int32) are device arrays on the context's GPU, so a roadmap whose vertices were produced there (sampled or
+ * filtered on the device) is connected and validated without its states or its edge list crossing PCIe -- only *n_edges, and
+ * from tr_validate_edges_indexed_dev the mask words (d_valid_bits: (n_edges + 63) / 64 words; d_n_fk: n_edges counts or NULL),
+ * which are device arrays too.  Same results, order and error codes as tr_knn_edges / tr_validate_edges_indexed; both calls
+ * synchronise.  tr_validate_edges_indexed_dev returns TR_ERR_UNSUPPORTED where the host form would fall back to gathering the
+ * end states on the host (more vertices than half the sample pool). */
+int tr_knn_edges_dev(tr_ctx *ctx, const double *d_states, int64_t n, int32_t k, double max_distance, int32_t *d_edges,
+                     int64_t capacity, int64_t *n_edges);
+int tr_validate_edges_indexed_dev(tr_ctx *ctx, const tr_space_params *sp, const double *d_states, int64_t n_states,
+                                  const int32_t *d_edges, int64_t n_edges, uint64_t *d_valid_bits, int32_t *d_n_fk,
+                                  int64_t *n_domain_errors);
 
 /* The same neighbour lists for a RANGE of the states as queries (all n states remain the candidates): rows
  * first_query .. first_query + n_queries - 1 of tr_knn's tables, whatever the range -- one rank's share when the connection

@@ -326,6 +326,12 @@ __global__ __launch_bounds__(256) void edge_last_valid_t(EdgeState st, int64_t s
   if (t < __longlong_as_double((long long)st.first_inv[e])) atomicMax(&st.last_t[e], (unsigned long long)__double_as_longlong(t));
 }
 
+// *flag != 0 afterwards: some index is outside [0, limit)
+__global__ __launch_bounds__(256) void index_range_check(const int32_t *__restrict__ idx, int64_t n, int32_t limit, uint32_t *__restrict__ flag) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n && (uint32_t)idx[i] >= (uint32_t)limit) *flag = 1u;
+}
+
 // bit e = edge e of the run is valid: the run's verdicts as the words of the caller's mask (E bits from bit 0 of out[0])
 __global__ __launch_bounds__(256) void edge_ok_bits(const uint32_t *__restrict__ edge_ok, int64_t E, uint64_t *__restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -1717,7 +1717,7 @@ int64_t tr_voxelize_count(const tr_ctx *c) { return c ? c->vstore.n : -1; }
 }  // extern "C"
 namespace {
 int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist,
-             int32_t *edges, int64_t edge_capacity, int64_t *n_edges, int64_t q0 = 0, int64_t nq = -1);
+             int32_t *edges, int64_t edge_capacity, int64_t *n_edges, int64_t q0 = 0, int64_t nq = -1, bool dev = false);
 }
 extern "C" {
 int tr_knn(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist) {
@@ -1768,11 +1768,21 @@ int tr_knn_edges(tr_ctx *c, const double *states, int64_t n, int32_t k, double m
   *n_edges = 0;
   return knn_impl(c, states, n, k, max_distance, nullptr, nullptr, edges, capacity, n_edges);
 }
+
+// The same with the states in HBM and the edge list left there (for tr_validate_edges_indexed_dev): only *n_edges comes back.
+int tr_knn_edges_dev(tr_ctx *c, const double *d_states, int64_t n, int32_t k, double max_distance, int32_t *d_edges, int64_t capacity,
+                     int64_t *n_edges) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (!n_edges || capacity < 0 || (capacity > 0 && !d_edges)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  *n_edges = 0;
+  return knn_impl(c, d_states, n, k, max_distance, nullptr, nullptr, d_edges, capacity, n_edges, 0, -1, true);
+}
 }  // extern "C"
 namespace {
 // queries [q0, q0 + nq) of the n states (nq < 0: all of them) against all n states as candidates
 int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist,
-             int32_t *edges, int64_t edge_capacity, int64_t *n_edges, int64_t q0, int64_t nq) {
+             int32_t *edges, int64_t edge_capacity, int64_t *n_edges, int64_t q0, int64_t nq, bool dev) {
+  // dev: `states` and `edges` are device arrays (tr_knn_edges_dev)
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || k < 1 || (n > 0 && !states)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
@@ -1827,7 +1837,7 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       rc = fail(c, TR_ERR_HIP, "hipMalloc failed (neighbour search scratch)"); break;
     }
     d_ck[0] = ck; d_ck[1] = ck + nn;
-    if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
+    if (hipMemcpy(d_s, states, (size_t)n * S * sizeof(double), dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMemcpy failed"); break; }
     {
       ProfScope ps(c, 3, nullptr);
       // the two coordinates the search is ordered and windowed by (knn_kernel.hpp): the retraction term of the metric when there
@@ -1905,7 +1915,7 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       hipError_t e = trk::knn_edge_list(c->merge, d_i, n, (int)k, d_e, cap_e, n_edges, nullptr);
       if (e == hipSuccess) e = hipDeviceSynchronize();
       const int64_t mm = std::min<int64_t>(*n_edges, cap_e);
-      if (e == hipSuccess && mm > 0) e = hipMemcpy(edges, d_e, (size_t)mm * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
+      if (e == hipSuccess && mm > 0) e = hipMemcpy(edges, d_e, (size_t)mm * 2 * sizeof(int32_t), dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost);
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn edge list: ") + hipGetErrorString(e)); break; }
     }
   } while (0);

@@ -436,6 +436,30 @@ class Engine:
         L.check(self._ctx, self.lib.tr_validate_candidates_dev(self._ctx, int(seed), int(first), int(count), plo, phi, pb, pt, pf,
                                                                self._stream_ptr(stream)))
 
+    def knn_edges_dev(self, d_states, n, k, d_edges, max_distance=np.inf):
+        """tr_knn_edges with the states in HBM and the edge list left there (d_edges: int32 tensor, capacity x 2): returns n_edges."""
+        torch = _torch()
+        ps = self._check_dev(d_states, torch.float64, n * self.state_size, "d_states")
+        cap = d_edges.numel() // 2
+        pe = self._check_dev(d_edges, torch.int32, 2 * cap, "d_edges")
+        ne = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_knn_edges_dev(self._ctx, ps, int(n), int(k), float(max_distance), pe, cap, C.byref(ne)))
+        return int(ne.value)
+
+    def validate_edges_indexed_dev(self, d_states, n_states, d_edges, n_edges, d_bits, d_n_fk=None, min_tension_change=0.02,
+                                   min_rotation_change=0.01, min_retraction_change=0.0001):
+        """tr_validate_edges_indexed on device arrays (vertex states, index pairs, mask words, optional FK counts): returns the
+        number of domain errors."""
+        torch = _torch()
+        ps = self._check_dev(d_states, torch.float64, n_states * self.state_size, "d_states")
+        pe = self._check_dev(d_edges, torch.int32, 2 * n_edges, "d_edges")
+        pb = self._check_dev(d_bits, torch.int64, (n_edges + 63) // 64, "d_bits")
+        pn = self._check_dev(d_n_fk, torch.int32, n_edges, "d_n_fk") if d_n_fk is not None else None
+        sp = L.TrSpaceParams(min_tension_change, min_rotation_change, min_retraction_change)
+        nd = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_validate_edges_indexed_dev(self._ctx, C.byref(sp), ps, int(n_states), pe, int(n_edges), pb, pn, C.byref(nd)))
+        return int(nd.value)
+
     def compact_rows_dev(self, d_mask, count, d_rows, row_doubles, d_rows_out, capacity, d_index_out=None, stream=None):
         """Rows of d_rows whose mask bit is set, in order, into d_rows_out (at most capacity); returns the number of set bits."""
         torch = _torch()

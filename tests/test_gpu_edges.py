@@ -322,3 +322,57 @@ def test_two_lane_bisection_equals_one_lane(irt, orc, helpers):
                                             states[edges[idx, 1]], inv_rot=np.eye(3) if inv_rot is None else inv_rot, nthreads=0, lib=orc.omp_lib())
         assert np.array_equal(want["valid"][idx], ov)
         assert np.array_equal(want["n_fk"][idx][ov], onf[ov])
+
+
+def test_device_resident_connect_and_validate_equal_the_host_forms(irt):
+    """tr_knn_edges_dev + tr_validate_edges_indexed_dev (vertex states, edge list, mask and FK counts all in HBM) give the edge list,
+    verdicts, FK counts and domain-error count of tr_knn_edges + tr_validate_edges_indexed -- on one lane and on two, with and
+    without the FK counts -- and the same errors: an index outside the vertex array, a pool too small for the vertex block."""
+    import torch
+    W = irt.workloads
+    for mk, rot, nv, k in ((W.robot_config3, False, 700, 6), (W.robot_config2, True, 2600, 8)):
+        robot = mk()
+        robot.enable_rotation = rot
+        vox, _ = W.reach_environment(seed=7, n_spheres=64)
+        states = W.random_states(robot, nv, seed=145)
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        eng = chk.engine
+        edges = eng.knn_edges(states, k)
+        want = eng.validate_edges_indexed(states, edges)
+        d_states = torch.from_numpy(states).cuda()
+        d_edges = torch.full((nv * k, 2), -7, dtype=torch.int32, device="cuda")
+        ne = eng.knn_edges_dev(d_states, nv, k, d_edges)
+        assert ne == len(edges) and np.array_equal(d_edges[:ne].cpu().numpy(), edges)
+        assert (d_edges[ne:] == -7).all()                                  # nothing written past the list
+        d_bits = torch.zeros((ne + 63) // 64, dtype=torch.int64, device="cuda")
+        d_nfk = torch.zeros(ne, dtype=torch.int32, device="cuda")
+        nd = eng.validate_edges_indexed_dev(d_states, nv, d_edges, ne, d_bits, d_nfk)
+        bits = d_bits.cpu().numpy().view(np.uint64)
+        assert np.array_equal(irt.unpack_bits(bits, ne), want["valid"])
+        assert np.array_equal(d_nfk.cpu().numpy(), want["n_fk"]) and nd == want["n_domain_errors"]
+        d_bits.zero_()
+        assert eng.validate_edges_indexed_dev(d_states, nv, d_edges, ne, d_bits) == nd        # without the counts
+        assert np.array_equal(d_bits.cpu().numpy().view(np.uint64), bits)
+        assert 0.05 < want["valid"].mean() < 0.99 and (nv < 2000 or ne >= 8192)          # (the second case runs on two lanes)
+        # the edge list truncated at the capacity: the count is still the whole list's
+        d_few = torch.zeros((10, 2), dtype=torch.int32, device="cuda")
+        assert eng.knn_edges_dev(d_states, nv, k, d_few) == ne and np.array_equal(d_few.cpu().numpy(), edges[:10])
+        bad = d_edges[:ne].clone()
+        bad[ne // 2, 1] = nv
+        with pytest.raises(irt.OutOfRange):
+            eng.validate_edges_indexed_dev(d_states, nv, bad, ne, d_bits)
+        bad[ne // 2, 1] = -1
+        with pytest.raises(irt.OutOfRange):
+            eng.validate_edges_indexed_dev(d_states, nv, bad, ne, d_bits)
+        assert eng.validate_edges_indexed_dev(d_states, nv, d_edges, ne, d_bits) == nd        # and the context is usable afterwards
+        assert np.array_equal(d_bits.cpu().numpy().view(np.uint64), bits)
+        with pytest.raises(irt.InvalidArgument):
+            eng.validate_edges_indexed_dev(d_states.cpu(), nv, d_edges, ne, d_bits)
+
+    def small_pool():
+        c2 = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        with pytest.raises(irt.Unsupported) as ei:
+            c2.engine.validate_edges_indexed_dev(d_states, nv, d_edges, ne, d_bits)
+        return str(ei.value)
+
+    assert "host form" in _with_env(irt, {"TENDON_HIP_EDGE_POOL": "1024"}, small_pool)
