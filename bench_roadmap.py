@@ -93,8 +93,16 @@ def run(argv=None):
     edges_host = rb.knn_edges(states, args.k)
     assert np.array_equal(edges, edges_host)
     chk.engine.reserve_edges(len(edges))
+    # "edges_per_s" is the FIRST full-size call of the context (pools reserved; the lanes' streams and lists, the kernels' code
+    # objects and the sample rate the pool shares are sized by come with it); "edges_per_s_repeat" the fastest of three more --
+    # a planner's second roadmap on the same context
     valid, nfk = rb.validate_edges(states, edges)
-    t = rb.timing
+    t = dict(rb.timing)
+    t_edges_repeat = float("inf")
+    for _ in range(3):
+        v2, nfk2 = rb.validate_edges(states, edges)
+        t_edges_repeat = min(t_edges_repeat, rb.timing["edges"]["seconds"])
+        assert np.array_equal(v2, valid) and np.array_equal(nfk2, nfk)
     out = {
         "config3": {
             "robot": "4-tendon quadratic-routed (workloads.robot_config3), 256^3 grid, 64 spheres",
@@ -103,7 +111,7 @@ def run(argv=None):
             "valid_vertices_per_s": args.vertices / t["vertices"]["seconds"],
             "vertex_checks_per_s": t["vertices"]["candidates"] / t["vertices"]["seconds"],
             "knn_host_seconds": t["knn"]["seconds"], "knn_gpu_seconds_incl_pcie_and_dedup": t_knn_gpu,
-            "edges_per_s": len(edges) / t["edges"]["seconds"],
+            "edges_per_s": len(edges) / t["edges"]["seconds"], "edges_per_s_repeat": len(edges) / t_edges_repeat,
             "edge_fk_samples_per_s": t["edges"]["fk_samples"] / t["edges"]["seconds"],
             "edge_valid_fraction": float(valid.mean()),
             "fk_samples_per_edge": {"mean": float(nfk.mean()), "p50": float(np.median(nfk)), "max": int(nfk.max()),

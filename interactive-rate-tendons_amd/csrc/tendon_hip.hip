@@ -11,6 +11,7 @@
 //   * home-shape tendon lengths (home_shape, TendonRobot.cpp:249-314),
 //   * device workspace, launches, optional HIP-event timing per kernel.
 #include <hip/hip_runtime.h>
+#include <sched.h>
 
 #include <algorithm>
 #include <cfloat>
@@ -139,11 +140,13 @@ struct tr_ctx {
   int64_t fb_cap = 1 << 17;       // columns of the fallback pass's point workspace: one resident round of waves (tr_create), env TENDON_HIP_FB_CAP
   int32_t *d_fb_list = nullptr; uint32_t *d_fb_count = nullptr; int64_t fb_list_cap = 0;
   // second lane of the edge bisection (edge_host.inc: EdgeLane): its own fallback list, stream, counters
-  int32_t *d_fb_list1 = nullptr; uint32_t *d_fb_count1 = nullptr; int64_t fb_list1_cap = 0;
-  hipStream_t edge_stream[2] = {nullptr, nullptr};
-  uint32_t *edge_hc[2] = {nullptr, nullptr};      // pinned host images of the lanes' counters
-  uint32_t *d_edge_counters1 = nullptr;
-  int edge_lanes = 2;                             // TENDON_HIP_EDGE_LANES=1: one lane only
+  static constexpr int kMaxLanes = 4;             // lanes of an edge bisection (edge_host.inc): streams, counters, fallback lists, ordering buffers
+  int32_t *d_fb_list1[kMaxLanes - 1] = {}; uint32_t *d_fb_count1[kMaxLanes - 1] = {}; int64_t fb_list1_cap[kMaxLanes - 1] = {};   // lanes 1 ..
+  hipStream_t edge_stream[kMaxLanes] = {};
+  uint32_t *edge_hc[kMaxLanes] = {};              // pinned host images of the lanes' counters
+  uint32_t *d_edge_counters1[kMaxLanes - 1] = {}; // lanes 1 .. (lane 0: EdgeDev::counters)
+  int edge_lanes = kMaxLanes;                     // TENDON_HIP_EDGE_LANES=1 .. 4: exactly that many lanes (1: one lane only); default: by the edge count
+  bool edge_lanes_fixed = false;
   double edge_rate_seen = 0.0;                    // own samples per edge of this context's last indexed edge call (0 = none yet): sizes
                                                   // the next call's chunks and lanes (a rotating robot's edges take ~10, not ~4)
   bool edge_lane_guess_forced = false;            // TENDON_HIP_EDGE_LANE_GUESS was given: it overrides the rate this context has seen
@@ -156,8 +159,8 @@ struct tr_ctx {
     uint32_t *keys[2] = {nullptr, nullptr}; int32_t *vals[2] = {nullptr, nullptr}; int64_t cap = 0;
     int32_t *kbegin = nullptr;          // [cap / 64] per wave of the ordered batch: the step its tip-aligned loop may start at
     double *handoff = nullptr; int64_t handoff_cap = 0;   // [19 + N + S][cap]: fk_retract_prologue -> fk_verdict_retract
-    trk::MergeScratch ms;               // lane 1's radix-sort scratch (lane 0 uses tr_ctx::merge)
-  } ro[2];
+    trk::MergeScratch ms;               // radix-sort scratch of lanes 1 .. (lane 0 uses tr_ctx::merge)
+  } ro[kMaxLanes];
   int64_t retract_sort_min = kRetractSortMin;
   bool rows_one_step = false;           // behind the grid's own first interval every RK4 step ends in the next row
   bool retract_wave_start = true;       // TENDON_HIP_RETRACT_KBEGIN_OFF (A/B switch of profiles/probe_retract.py): +1 - 2 %
@@ -557,11 +560,12 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   int rc;
   if (spheres && (rc = ensure_sphere_near(ctx, s))) return rc;
   Workspace &w = ctx->ws;
-  // lane 1 (the second lane of an edge bisection, running concurrently on its own stream): its own list and counter, and the
-  // workspace columns [fb_cap, 2 fb_cap) for its fallback pass
-  int32_t *&fb_list = lane ? ctx->d_fb_list1 : ctx->d_fb_list;
-  uint32_t *&fb_count = lane ? ctx->d_fb_count1 : ctx->d_fb_count;
-  int64_t &fb_list_cap = lane ? ctx->fb_list1_cap : ctx->fb_list_cap;
+  // lanes 1 .. (the further lanes of an edge bisection, running concurrently on their own streams): their own list and counter, and
+  // the workspace columns [lane fb_cap, (lane + 1) fb_cap) for their fallback pass
+  if (lane < 0 || lane >= tr_ctx::kMaxLanes) return fail(ctx, TR_ERR_RUNTIME, "bad lane");
+  int32_t *&fb_list = lane ? ctx->d_fb_list1[lane - 1] : ctx->d_fb_list;
+  uint32_t *&fb_count = lane ? ctx->d_fb_count1[lane - 1] : ctx->d_fb_count;
+  int64_t &fb_list_cap = lane ? ctx->fb_list1_cap[lane - 1] : ctx->fb_list_cap;
   if (fb_list_cap < n) {
     HIP_TRY(ctx, hipDeviceSynchronize());
     if ((rc = dev_alloc(ctx, &fb_list, (size_t)round_up(n, 64)))) return rc;
@@ -569,8 +573,8 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     fb_list_cap = round_up(n, 64);
   }
   const int64_t cap = std::min<int64_t>(ctx->fb_cap, round_up(n, 64));
-  if ((rc = ensure_workspace(ctx, lane ? 2 * ctx->fb_cap : cap))) return rc;
-  const int64_t fcol = lane ? ctx->fb_cap : 0;                    // first workspace column of this lane's fallback pass
+  if ((rc = ensure_workspace(ctx, lane ? (lane + 1) * ctx->fb_cap : cap))) return rc;
+  const int64_t fcol = lane * ctx->fb_cap;                        // first workspace column of this lane's fallback pass
   tr_ctx::VerdictRing &vr = ctx->vring;
   if (!vr.d_slots) {
     HIP_TRY(ctx, hipMalloc((void **)&vr.d_slots, sizeof(trk::VerdictArgs) * tr_ctx::VerdictRing::kSlots));
@@ -602,7 +606,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   }
   if (ctx->K.enable_retraction && ctx->retract_sort_min > 0 && n >= ctx->retract_sort_min) {
     // waves of one backbone length: see retraction_order.  The mask is filled by atomic ORs, so it starts from zero.
-    tr_ctx::RetractOrder &ro = ctx->ro[lane ? 1 : 0];
+    tr_ctx::RetractOrder &ro = ctx->ro[lane];
     if (ro.cap < n) {
       HIP_TRY(ctx, hipDeviceSynchronize());
       const int64_t want = round_up(n, 64);
@@ -633,7 +637,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
                    (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, vout, s};
   if (ctx->K.enable_retraction) {
     // the prologue kernel's hand-over planes (fk_retract_prologue -> fk_verdict_retract), one set per lane of the edge bisection
-    tr_ctx::RetractOrder &ro = ctx->ro[lane ? 1 : 0];
+    tr_ctx::RetractOrder &ro = ctx->ro[lane];
     const int64_t hld = round_up(n, 64);
     if (ro.handoff_cap < hld) {
       HIP_TRY(ctx, hipDeviceSynchronize());
@@ -773,7 +777,7 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (const char *e = std::getenv("TENDON_HIP_FUSED")) { const int v = std::atoi(e); c->fuse = v < 0 ? 0 : (v > 2 ? 2 : v); }
   if (const char *e = std::getenv("TENDON_HIP_RETRACT_SORT")) c->retract_sort_min = std::atoll(e);
   if (std::getenv("TENDON_HIP_RETRACT_KBEGIN_OFF")) c->retract_wave_start = false;
-  if (const char *e = std::getenv("TENDON_HIP_EDGE_LANES")) c->edge_lanes = std::atoi(e) >= 2 ? 2 : 1;
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_LANES")) { c->edge_lanes = std::max(1, std::min(tr_ctx::kMaxLanes, std::atoi(e))); c->edge_lanes_fixed = true; }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_LANE_GUESS")) { const double v = std::atof(e); if (v >= 0.5 && v <= 64.0) { c->edge_lane_guess = v; c->edge_lane_guess_forced = true; } }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
@@ -918,10 +922,12 @@ void tr_destroy(tr_ctx *c) {
   if (c->vstore.ids) (void)hipFree(c->vstore.ids);
   if (c->vstore.masks) (void)hipFree(c->vstore.masks);
   if (c->d_fb_list) (void)hipFree(c->d_fb_list);
-  if (c->d_fb_list1) (void)hipFree(c->d_fb_list1);
-  if (c->d_fb_count1) (void)hipFree(c->d_fb_count1);
-  if (c->d_edge_counters1) (void)hipFree(c->d_edge_counters1);
-  for (int q = 0; q < 2; q++) { if (c->edge_stream[q]) (void)hipStreamDestroy(c->edge_stream[q]); if (c->edge_hc[q]) (void)hipHostFree(c->edge_hc[q]); }
+  for (int q = 0; q < tr_ctx::kMaxLanes - 1; q++) {
+    if (c->d_fb_list1[q]) (void)hipFree(c->d_fb_list1[q]);
+    if (c->d_fb_count1[q]) (void)hipFree(c->d_fb_count1[q]);
+    if (c->d_edge_counters1[q]) (void)hipFree(c->d_edge_counters1[q]);
+  }
+  for (int q = 0; q < tr_ctx::kMaxLanes; q++) { if (c->edge_stream[q]) (void)hipStreamDestroy(c->edge_stream[q]); if (c->edge_hc[q]) (void)hipHostFree(c->edge_hc[q]); }
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto &ro : c->ro) {
     for (int q = 0; q < 2; q++) { if (ro.keys[q]) (void)hipFree(ro.keys[q]); if (ro.vals[q]) (void)hipFree(ro.vals[q]); }

@@ -272,8 +272,8 @@ def test_indexed_edges_equal_the_pairwise_form(irt):
 
 
 def test_two_lane_bisection_equals_one_lane(irt, orc, helpers):
-    """tr_validate_edges_indexed bisects the two halves of a roadmap's edge list side by side on two streams (each lane with its
-    half of the sample pool, its own frontier, counters and fallback list; one host thread alternating between them).  Verdicts,
+    """tr_validate_edges_indexed bisects the parts of a roadmap's edge list side by side on two to four streams (each lane with its
+    share of the sample pool, its own frontier, counters and fallback list; one host thread alternating between them).  Verdicts,
     FK counts and the domain-error count equal the one-lane path's (TENDON_HIP_EDGE_LANES=1) -- where samples need the fallback
     pass (a slender robot under high tension, through a 64-column fallback workspace), with a rotating robot in a rotated
     environment, and with a pool so small that a lane overflows and the call falls back to one lane -- and the oracle's on a
@@ -312,10 +312,12 @@ def test_two_lane_bisection_equals_one_lane(irt, orc, helpers):
             edges = np.stack([np.repeat(np.arange(nv), 7), near.reshape(-1)], 1)
         base_env = {"TENDON_HIP_FB_CAP": "64", "TENDON_HIP_RETRACT_SORT": "64"}          # (launches of 64 samples or more are ordered by length)
         want = _with_env(irt, dict(base_env, TENDON_HIP_EDGE_LANES="1"), run)
-        for extra in ({}, {"TENDON_HIP_EDGE_POOL": "40000", "TENDON_HIP_EDGE_LANE_GUESS": "1"}):   # the second: lanes overflow their share
-            got = _with_env(irt, dict(base_env, TENDON_HIP_EDGE_LANES="2", **extra), run)
+        for lanes, extra in (("2", {}), ("3", {}), ("4", {}),
+                             ("2", {"TENDON_HIP_EDGE_POOL": "40000", "TENDON_HIP_EDGE_LANE_GUESS": "1"}),    # lanes overflow their share
+                             ("4", {"TENDON_HIP_EDGE_POOL": "40000", "TENDON_HIP_EDGE_LANE_GUESS": "1"})):
+            got = _with_env(irt, dict(base_env, TENDON_HIP_EDGE_LANES=lanes, **extra), run)
             for k in ("valid", "n_fk", "n_domain_errors"):
-                assert np.array_equal(got[k], want[k]), (k, extra, np.flatnonzero(np.asarray(got[k]) != np.asarray(want[k]))[:8])
+                assert np.array_equal(got[k], want[k]), (k, lanes, extra, np.flatnonzero(np.asarray(got[k]) != np.asarray(want[k]))[:8])
         assert 0.2 < want["valid"].mean() < 0.99 and want["n_fk"].max() > 6
         idx = np.random.default_rng(82).choice(len(edges), 400, replace=False)
         ov, onf, _ = orc.check_motion_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), states[edges[idx, 0]],
