@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Opt-in stress of the two-lane edge bisection (not collected by pytest): the same roadmap's edges validated over and over on two
-streams -- verdicts, FK counts and domain-error counts must be those of the first call and of the one-lane path every time (a race
+"""Opt-in stress of the multi-lane edge bisection (not collected by pytest): the same roadmap's edges validated over and over on two
+and on four streams -- verdicts, FK counts and domain-error counts must be those of the first call and of the one-lane path every time (a race
 between the lanes would show up as a changing result), for a tension-only, a rotating and a rotating + retracting robot, with
 state batches and cached-set checks interleaved between the edge calls.
 
@@ -26,14 +26,14 @@ def main():
         robot.enable_rotation, robot.enable_retraction = rot, ret
         vox, _ = W.reach_environment(seed=7, n_spheres=64)
         res = {}
-        for lanes in ("1", "2"):
+        for lanes in ("1", "2", "4"):
             os.environ["TENDON_HIP_EDGE_LANES"] = lanes
             chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
             rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
             states, _ = rb.sample_valid_vertices(30000, batch=1 << 16)
             edges = rb.knn_edges_gpu(states, 9)
             first = None
-            for it in range(iters if lanes == "2" else 3):
+            for it in range(iters if lanes != "1" else 3):
                 out = chk.engine.validate_edges_indexed(states, edges, rb.mv.min_tension_change, rb.mv.min_rotation_change, rb.mv.min_retraction_change)
                 key = (out["valid"].tobytes(), out["n_fk"].tobytes(), out["n_domain_errors"])
                 if first is None:
@@ -44,9 +44,9 @@ def main():
                 if it % 3 == 0:                     # other work of the context between the edge calls
                     chk.is_valid(states[: 20000 + 97 * it])
             res[lanes] = first
-        same = res["1"] == res["2"]
+        same = res["1"] == res["2"] == res["4"]
         bad += not same
-        print("rotation %s retraction %s: %d edges, %d two-lane calls identical, equal to one lane: %s" % (rot, ret, len(edges), iters, same), flush=True)
+        print("rotation %s retraction %s: %d edges, %d two-lane and %d four-lane calls identical, equal to one lane: %s" % (rot, ret, len(edges), iters, iters, same), flush=True)
     print("differences:", bad)
     sys.exit(1 if bad else 0)
 
