@@ -1781,6 +1781,8 @@ int tr_knn_edges_dev(tr_ctx *c, const double *d_states, int64_t n, int32_t k, do
   if (!c) return TR_ERR_INVALID_ARG;
   if (!n_edges || capacity < 0 || (capacity > 0 && !d_edges)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   *n_edges = 0;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());                  // d_states may have been written on any stream of the caller
   return knn_impl(c, d_states, n, k, max_distance, nullptr, nullptr, d_edges, capacity, n_edges, 0, -1, true);
 }
 }  // extern "C"
