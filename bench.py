@@ -166,7 +166,7 @@ def config4_one_gpu_extras():
         M, k, seed = 1 << 20, 10, 3
         box = D.sampling_box(robot)
         vv = D.ShardedVertexValidator(robot, seed=seed, device="cuda", box=box, validate_candidates=D.device_candidate_validator(eng, seed, box))
-        best, dev_s, same, d_edges, d_bits = None, float("inf"), True, None, None
+        best, dev_s, sig_s, same, d_edges, d_bits, d_sig = None, float("inf"), float("inf"), True, None, None, None
         for _ in range(3):
             torch.cuda.synchronize()
             t = [time.perf_counter()]
@@ -193,9 +193,32 @@ def config4_one_gpu_extras():
             torch.cuda.synchronize()
             dev_s = min(dev_s, time.perf_counter() - t0)
             same = same and ned == len(edges) and bool(np.array_equal(irt.unpack_bits(d_bits.cpu().numpy().view(np.uint64), ned), ev))
+            # ... and with the vertices' signatures handed from the vertex phase to the edge call (tr_validate_candidates_sig_dev ->
+            # tr_validate_edges_indexed_sig_dev): the accepted vertices are not integrated a second time
+            sw = eng.signature_words()
+            if sw:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                if d_sig is None:
+                    d_sig = torch.empty((M, sw), dtype=torch.int32, device="cuda")
+                    d_vsig = torch.empty((M, sw), dtype=torch.int32, device="cuda")
+                    d_mask2 = torch.empty((M + 63) // 64, dtype=torch.int64, device="cuda")
+                    d_cand = torch.empty(M * eng.state_size, dtype=torch.float64, device="cuda")
+                    d_vs = torch.empty(M * eng.state_size, dtype=torch.float64, device="cuda")
+                eng.validate_candidates_sig_dev(seed, 0, M, d_mask2, d_sig, box=box)
+                eng.candidate_states_dev(seed, 0, M, d_cand, box=box)
+                nv2 = eng.compact_rows_dev(d_mask2, M, d_cand, eng.state_size, d_vs, M)
+                eng.compact_rows_dev(d_mask2, M, d_sig.view(torch.float64).reshape(-1), sw // 2, d_vsig.view(torch.float64).reshape(-1), M)
+                ne2 = eng.knn_edges_dev(d_vs, nv2, k + 1, d_edges)
+                eng.validate_edges_indexed_dev(d_vs, nv2, d_edges, ne2, d_bits, None, rb.mv.min_tension_change, rb.mv.min_rotation_change,
+                                               rb.mv.min_retraction_change, d_vertex_sig=d_vsig)
+                torch.cuda.synchronize()
+                sig_s = min(sig_s, time.perf_counter() - t0)
+                same = same and ne2 == len(edges) and bool(np.array_equal(irt.unpack_bits(d_bits.cpu().numpy().view(np.uint64), ne2), ev))
         d, nv, ne, nok, nfk = best
         return {"candidates": M, "valid_vertices": nv, "candidate_edges": ne, "valid_edges": nok, "build_s": float(d.sum()),
-                "build_device_resident_s": float(dev_s), "device_resident_verdicts_equal": same,
+                "build_device_resident_s": float(dev_s), "build_device_resident_signatures_handed_over_s": float(sig_s) if sig_s < float("inf") else None,
+                "device_resident_verdicts_equal": same,
                 "vertex_phase_checks_per_s": M / d[0], "valid_vertices_per_s": nv / d[0], "compact_and_download_s": float(d[1]),
                 "knn_edge_list_s": float(d[2]), "edges_validated_per_s": ne / d[3], "edge_fk_samples_per_s": nfk / d[3]}
     except Exception as e:                                  # noqa: BLE001 -- reported, not raised

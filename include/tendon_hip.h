@@ -455,6 +455,20 @@ int tr_knn_edges_dev(tr_ctx *ctx, const double *d_states, int64_t n, int32_t k, 
 int tr_validate_edges_indexed_dev(tr_ctx *ctx, const tr_space_params *sp, const double *d_states, int64_t n_states,
                                   const int32_t *d_edges, int64_t n_edges, uint64_t *d_valid_bits, int32_t *d_n_fk,
                                   int64_t *n_domain_errors);
+/* Vertices that have just passed the vertex phase need not be integrated again by the edge call (every indexed edge call otherwise
+ * evaluates each vertex once for its signature: 1.4 ms per 10^5 vertices, and the same on every rank when the edge list is sharded):
+ * tr_validate_candidates_sig_dev is tr_validate_candidates_dev that also writes each candidate's backbone cell signature, a row of
+ * tr_signature_words(ctx) uint32 (an even number; meaningful where the candidate's bit is set); compact the rows of the accepted
+ * candidates like their states (tr_compact_rows_dev with row_doubles = tr_signature_words / 2) and pass them as d_vertex_sig
+ * (n_states rows) to tr_validate_edges_indexed_sig_dev, which then treats every vertex as valid and gives the verdicts, counts and
+ * errors of tr_validate_edges_indexed_dev.  tr_signature_words returns 0 -- and the two calls TR_ERR_UNSUPPORTED -- for retraction
+ * robots, under TR_CHECKER_SPHERES and on schedules other than the default verdict-only one. */
+int tr_signature_words(const tr_ctx *ctx);
+int tr_validate_candidates_sig_dev(tr_ctx *ctx, uint64_t seed, uint64_t first, int64_t count, const double *lo, const double *hi,
+                                   uint64_t *d_valid_bits, double *d_tips, uint32_t *d_sig, void *stream);
+int tr_validate_edges_indexed_sig_dev(tr_ctx *ctx, const tr_space_params *sp, const double *d_states, int64_t n_states,
+                                      const uint32_t *d_vertex_sig, const int32_t *d_edges, int64_t n_edges,
+                                      uint64_t *d_valid_bits, int32_t *d_n_fk, int64_t *n_domain_errors);
 
 /* The same neighbour lists for a RANGE of the states as queries (all n states remain the candidates): rows
  * first_query .. first_query + n_queries - 1 of tr_knn's tables, whatever the range -- one rank's share when the connection

@@ -1330,7 +1330,7 @@ int tr_validate_shapes_retraction_dev(tr_ctx *c, int64_t n, int64_t ld, const do
 }  // extern "C"
 namespace {
 int validate_batch_dev_impl(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
-                            double *d_tips, uint8_t *d_flags, void *stream);
+                            double *d_tips, uint8_t *d_flags, void *stream, uint32_t *d_sig = nullptr);
 }
 extern "C" {
 int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
@@ -1345,8 +1345,9 @@ int tr_validate_batch_dev(tr_ctx *c, const double *d_states, int64_t n, uint64_t
 }
 }  // extern "C"
 namespace {
+// d_sig: [n][tr_signature_words] cell signatures of the backbones (the rows tr_validate_edges_indexed_sig_dev takes for the vertices)
 int validate_batch_dev_impl(tr_ctx *c, const double *d_states, int64_t n, uint64_t *d_valid_bits,
-                            double *d_tips, uint8_t *d_flags, void *stream) {
+                            double *d_tips, uint8_t *d_flags, void *stream, uint32_t *d_sig) {
   if (n < 0) return fail(c, TR_ERR_INVALID_ARG, "negative batch size");
   if (n == 0) return TR_OK;
   if (!d_states || !d_valid_bits) return fail(c, TR_ERR_INVALID_ARG, "null device pointer");
@@ -1355,13 +1356,16 @@ int validate_batch_dev_impl(tr_ctx *c, const double *d_states, int64_t n, uint64
   hipStream_t s = (hipStream_t)stream;
   const int S = c->K.state_size;
   const bool ret = c->K.enable_retraction;
+  const int64_t sig_words = round_up(c->K.n_points, 16);
+  if (d_sig && (c->fuse != 2 || ret || c->checker == TR_CHECKER_SPHERES)) return fail(c, TR_ERR_UNSUPPORTED, "signatures: backbone checker, no retraction, verdict-only schedule");
   if (c->fuse == 2) {
     // verdict-only kernel (both checkers, with or without retraction): nothing but the verdict (and the tips) leaves the chip, no point workspace to size
     const int64_t chunk = (int64_t)1 << 26;                 // list indices are 32-bit; per-launch grid stays far below 2^31 blocks
     for (int64_t off = 0; off < n; off += chunk) {
       const int64_t m = std::min<int64_t>(chunk, n - off);
       if ((rc = launch_verdict(c, d_states + off * S, m, d_valid_bits + off / 64, d_tips ? d_tips + 3 * off : nullptr,
-                               d_flags ? d_flags + off : nullptr, s, nullptr, 0, c->checker == TR_CHECKER_SPHERES))) return rc;
+                               d_flags ? d_flags + off : nullptr, s, d_sig ? d_sig + off * sig_words : nullptr, d_sig ? sig_words : 0,
+                               c->checker == TR_CHECKER_SPHERES))) return rc;
     }
     return TR_OK;
   }

@@ -436,6 +436,21 @@ class Engine:
         L.check(self._ctx, self.lib.tr_validate_candidates_dev(self._ctx, int(seed), int(first), int(count), plo, phi, pb, pt, pf,
                                                                self._stream_ptr(stream)))
 
+    def signature_words(self):
+        """uint32 words per row of the vertex signature arrays (tr_signature_words); 0: this context cannot hand signatures over."""
+        return int(self.lib.tr_signature_words(self._ctx))
+
+    def validate_candidates_sig_dev(self, seed, first, count, d_bits, d_sig, d_tips=None, box=None, stream=None):
+        """validate_candidates_dev that also writes every candidate's backbone cell signature (d_sig: int32 tensor, count x
+        signature_words()): compacted like the accepted states, the rows spare validate_edges_indexed_dev its vertex pass."""
+        torch = _torch()
+        keep, plo, phi = self._box(box)
+        pb = self._check_dev(d_bits, torch.int64, (count + 63) // 64, "d_bits")
+        pt = self._check_dev(d_tips, torch.float64, 3 * count, "d_tips") if d_tips is not None else None
+        psig = self._check_dev(d_sig, torch.int32, count * max(1, self.signature_words()), "d_sig")
+        L.check(self._ctx, self.lib.tr_validate_candidates_sig_dev(self._ctx, int(seed), int(first), int(count), plo, phi, pb, pt, psig,
+                                                                   self._stream_ptr(stream)))
+
     def knn_edges_dev(self, d_states, n, k, d_edges, max_distance=np.inf):
         """tr_knn_edges with the states in HBM and the edge list left there (d_edges: int32 tensor, capacity x 2): returns n_edges."""
         torch = _torch()
@@ -447,9 +462,10 @@ class Engine:
         return int(ne.value)
 
     def validate_edges_indexed_dev(self, d_states, n_states, d_edges, n_edges, d_bits, d_n_fk=None, min_tension_change=0.02,
-                                   min_rotation_change=0.01, min_retraction_change=0.0001):
+                                   min_rotation_change=0.01, min_retraction_change=0.0001, d_vertex_sig=None):
         """tr_validate_edges_indexed on device arrays (vertex states, index pairs, mask words, optional FK counts): returns the
-        number of domain errors."""
+        number of domain errors.  d_vertex_sig (int32, n_states x signature_words()): the vertices' signature rows from
+        validate_candidates_sig_dev -- every vertex is then taken to be valid and none is integrated again."""
         torch = _torch()
         ps = self._check_dev(d_states, torch.float64, n_states * self.state_size, "d_states")
         pe = self._check_dev(d_edges, torch.int32, 2 * n_edges, "d_edges")
@@ -457,7 +473,11 @@ class Engine:
         pn = self._check_dev(d_n_fk, torch.int32, n_edges, "d_n_fk") if d_n_fk is not None else None
         sp = L.TrSpaceParams(min_tension_change, min_rotation_change, min_retraction_change)
         nd = C.c_int64(0)
-        L.check(self._ctx, self.lib.tr_validate_edges_indexed_dev(self._ctx, C.byref(sp), ps, int(n_states), pe, int(n_edges), pb, pn, C.byref(nd)))
+        if d_vertex_sig is not None:
+            pv = self._check_dev(d_vertex_sig, torch.int32, n_states * max(1, self.signature_words()), "d_vertex_sig")
+            L.check(self._ctx, self.lib.tr_validate_edges_indexed_sig_dev(self._ctx, C.byref(sp), ps, int(n_states), pv, pe, int(n_edges), pb, pn, C.byref(nd)))
+        else:
+            L.check(self._ctx, self.lib.tr_validate_edges_indexed_dev(self._ctx, C.byref(sp), ps, int(n_states), pe, int(n_edges), pb, pn, C.byref(nd)))
         return int(nd.value)
 
     def compact_rows_dev(self, d_mask, count, d_rows, row_doubles, d_rows_out, capacity, d_index_out=None, stream=None):

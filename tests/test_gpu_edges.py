@@ -378,3 +378,55 @@ def test_device_resident_connect_and_validate_equal_the_host_forms(irt):
         return str(ei.value)
 
     assert "host form" in _with_env(irt, {"TENDON_HIP_EDGE_POOL": "1024"}, small_pool)
+
+
+def test_vertex_signatures_handed_over_from_the_vertex_phase(irt):
+    """tr_validate_candidates_sig_dev writes each candidate's backbone signature next to its verdict; the accepted candidates' rows,
+    compacted like their states, let tr_validate_edges_indexed_sig_dev skip its vertex pass: same mask as the plain candidate call,
+    same verdicts, FK counts and domain-error count as tr_validate_edges_indexed_dev (one lane and several), and the rows are the ones the
+    edge call computes for itself.  Contexts that cannot hand signatures over say so."""
+    import torch
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    eng = chk.engine
+    sw = eng.signature_words()
+    assert sw > 0 and sw % 2 == 0 and sw >= eng.num_points
+    box = D.sampling_box(robot)
+    S = eng.state_size
+    for M, k in ((1536, 6), (6016, 9)):                                   # the second: two lanes
+        seed = 17
+        d_bits0 = torch.zeros((M + 63) // 64, dtype=torch.int64, device="cuda")
+        d_bits = torch.zeros_like(d_bits0)
+        d_sig = torch.full((M, sw), -1, dtype=torch.int32, device="cuda")
+        d_tips0, d_tips = torch.zeros(3 * M, dtype=torch.float64, device="cuda"), torch.zeros(3 * M, dtype=torch.float64, device="cuda")
+        eng.validate_candidates_dev(seed, 0, M, d_bits0, d_tips0, box=box)
+        eng.validate_candidates_sig_dev(seed, 0, M, d_bits, d_sig, d_tips, box=box)
+        torch.cuda.synchronize()
+        assert torch.equal(d_bits, d_bits0) and torch.equal(d_tips, d_tips0)
+        cand = torch.empty(M * S, dtype=torch.float64, device="cuda")
+        eng.candidate_states_dev(seed, 0, M, cand, box=box)
+        d_verts = torch.empty(M * S, dtype=torch.float64, device="cuda")
+        nv = eng.compact_rows_dev(d_bits, M, cand, S, d_verts, M)
+        d_vsig = torch.empty((M, sw), dtype=torch.int32, device="cuda")
+        assert eng.compact_rows_dev(d_bits, M, d_sig.view(torch.float64).reshape(-1), sw // 2, d_vsig.view(torch.float64).reshape(-1), M) == nv
+        assert 0.3 * M < nv < M
+        d_verts, d_vsig = d_verts[: nv * S], d_vsig[:nv].contiguous()
+        d_edges = torch.empty((nv * k, 2), dtype=torch.int32, device="cuda")
+        ne = eng.knn_edges_dev(d_verts, nv, k, d_edges)
+        assert (M < 2000) == (ne < 8192)
+        want_bits = torch.zeros((ne + 63) // 64, dtype=torch.int64, device="cuda")
+        want_nfk = torch.zeros(ne, dtype=torch.int32, device="cuda")
+        want_nd = eng.validate_edges_indexed_dev(d_verts, nv, d_edges, ne, want_bits, want_nfk)
+        got_bits, got_nfk = torch.zeros_like(want_bits), torch.zeros_like(want_nfk)
+        got_nd = eng.validate_edges_indexed_dev(d_verts, nv, d_edges, ne, got_bits, got_nfk, d_vertex_sig=d_vsig)
+        assert torch.equal(got_bits, want_bits) and torch.equal(got_nfk, want_nfk) and got_nd == want_nd
+        assert 0.05 < irt.unpack_bits(want_bits.cpu().numpy().view(np.uint64), ne).mean() < 0.999
+    # a retraction robot's context has no signatures to hand over
+    pull = W.robot_config2()
+    pull.enable_retraction = True
+    e2 = irt.VoxelBackboneValidityChecker(pull, irt.VoxelEnvironment(), vox).engine
+    assert e2.signature_words() == 0
+    with pytest.raises(irt.Unsupported):
+        e2.validate_candidates_sig_dev(1, 0, 64, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(64 * 160, dtype=torch.int32, device="cuda"))
