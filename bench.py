@@ -289,13 +289,14 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
     """BASELINE configs[3]: the PRM build at 2^20 candidate vertices with every phase sharded over the ranks (strong scaling:
     the job is fixed, ranks divide it) --
       1. vertex phase: rank g validates candidates [g M/G, (g+1) M/G) of the counter-based sequence, generated in HBM
-         (tr_validate_candidates_dev), and the mask words are all-gathered as device tensors (RCCL);
+         (tr_validate_candidates_sig_dev), and the mask words -- and the accepted candidates' signature rows, which the edge phase
+         would otherwise recompute for ALL vertices on every rank -- are all-gathered as device tensors (RCCL);
       2. every rank regenerates the M candidates and compacts them by the gathered mask (tr_candidate_states_dev,
          tr_compact_rows_dev): the same vertex array everywhere, no states on the wire;
       3. connection loop: the rank's rows of the exact k-nearest table against all vertices (tr_knn_range), all-gather of the
          int32 rows, the deduplicated edge list from the whole table on every rank (tr_knn_table_edges);
-      4. edge phase: the rank's contiguous shard of the edge list through tr_validate_edges_indexed, all-gather of the verdict
-         words.
+      4. edge phase: the rank's contiguous shard of the edge list through tr_validate_edges_indexed_sig_dev, all-gather of the
+         verdict words.
     One step = the whole pipeline.  `value` = candidates through the vertex phase per second of vertex-phase time (the
     metric's FK+collision checks, whole job); the other phases are reported beside it, each as the max over ranks, with the
     collectives timed on their own afterwards."""
@@ -311,7 +312,12 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
     M, k, seed = 1 << args.config4_log2, args.config4_k, 3
     dev = "cuda:%d" % dev_index
     box = D.sampling_box(robot)
-    vv = D.ShardedVertexValidator(robot, seed=seed, device=dev, box=box, validate_candidates=D.device_candidate_validator(eng, seed, box))
+    # the accepted candidates' backbone signatures travel with the mask (one more all-gather), so that no rank integrates the whole
+    # vertex set again for its shard of the edges; TENDON_BENCH_NO_SIGNATURES=1: without (every rank's edge call does its vertex pass)
+    hand_over = eng.signature_words() > 0 and not os.environ.get("TENDON_BENCH_NO_SIGNATURES")
+    vv = D.ShardedVertexValidator(robot, seed=seed, device=dev, box=box,
+                                  validate_candidates=D.device_candidate_validator(eng, seed, box, signatures=hand_over))
+    compact = D.device_row_compactor(eng)
 
     def fence():
         if use_dist:
@@ -320,14 +326,18 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
 
     def pipeline():
         t = [time.perf_counter()]
-        mask = vv.run(M, keep_on_device=True)
+        vsig = None
+        if hand_over:
+            mask, vsig = vv.run_with_rows(M, compact)
+        else:
+            mask = vv.run(M, keep_on_device=True)
         torch.cuda.synchronize(); t.append(time.perf_counter())
         verts_dev, _ = D.gather_valid_vertices_dev(eng, seed, M, mask, box=box)
         verts = verts_dev.cpu().numpy()
         t.append(time.perf_counter())
         edges = rb.knn_edges_sharded(verts, k + 1, device=dev)                  # k neighbours + the vertex itself, as nearestK returns
         t.append(time.perf_counter())
-        ev = rb.validate_edges_sharded(verts, edges, device=dev)
+        ev = rb.validate_edges_sharded(verts, edges, device=dev, d_states=verts_dev if hand_over else None, d_vertex_sig=vsig)
         t.append(time.perf_counter())
         return mask, verts, edges, ev, np.diff(t)
 
@@ -365,6 +375,8 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
         bufs = {"vertex_mask": torch.zeros(vshard // 64, dtype=torch.int64, device=dev),
                 "knn_rows": torch.zeros(nshard * (k + 1), dtype=torch.int32, device=dev),
                 "edge_mask": torch.zeros(eshard // 64, dtype=torch.int64, device=dev)}
+        if hand_over:                   # (padded to the largest shard's accepted count; about the same on every rank)
+            bufs["vertex_signatures"] = torch.zeros((len(verts) + world - 1) // world * eng.signature_words(), dtype=torch.int32, device=dev)
         for name, b in bufs.items():
             D.allgather_mask(b)
             fence()
@@ -386,6 +398,7 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
                                    "all-gather" % (args.config4_log2, k),
                        "ranks_seen": dist.get_world_size() if use_dist else 1, "rehearsal_shared_gpu": rehearsal,
                        "collective": ("gloo(host)" if rehearsal else "rccl") if use_dist else None,
+                       "vertex_signatures_handed_over": bool(hand_over),
                        "candidates": M, "valid_vertices": int(len(verts)), "candidate_edges": int(len(edges)), "valid_edges": int(ev.sum()),
                        "vertex_mask_crc32": int(sums[0]), "edge_list_crc32": int(sums[4]),
                        "phases_ms": {"vertices_incl_allgather": 1e3 * phase[0], "regenerate_compact_download": 1e3 * phase[1],

@@ -95,6 +95,24 @@ def allgather_mask(local_words, group=None):
     return out
 
 
+def allgather_rows(local_rows, counts, group=None):
+    """All-gather row blocks of different lengths: rank r contributes counts[r] rows (counts is known to every rank, e.g. from
+    an all-gathered mask); shorter blocks are padded to the longest for the collective.  Returns the rows in rank order."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return local_rows
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    assert len(counts) == world and local_rows.shape[0] == counts[rank]
+    w = int(np.prod(local_rows.shape[1:])) if local_rows.dim() > 1 else 1
+    most = int(max(counts))
+    buf = torch.zeros(most * w, dtype=local_rows.dtype, device=local_rows.device)
+    buf[: counts[rank] * w] = local_rows.reshape(-1)
+    full = allgather_mask(buf, group=group)
+    parts = [full[r * most * w: r * most * w + int(counts[r]) * w] for r in range(world)]
+    return torch.cat(parts).reshape((-1,) + tuple(local_rows.shape[1:]))
+
+
 class ShardedVertexValidator:
     """Validate M candidate vertices across the ranks of the default process group.
 
@@ -133,14 +151,40 @@ class ShardedVertexValidator:
         # world_size * shard/64 words; bits of items >= M are zero.  unpack_bits(words, M) is the mask.
         return full if keep_on_device else full.cpu().numpy().view(np.uint64)
 
+    def run_with_rows(self, M, compact, rank=None, world_size=None):
+        """run(), and a row of data per ACCEPTED candidate gathered with the mask: validate_candidates(first, count, n_words) returns
+        (mask words, rows [count, w]) here -- device_candidate_validator(..., signatures=True): the candidates' backbone signatures,
+        which tr_validate_edges_indexed_sig_dev takes instead of integrating the vertices again on every rank -- and
+        compact(mask words, count, rows) -> the accepted candidates' rows in order.  Returns (mask words tensor, rows of all
+        accepted candidates in candidate order, the same on every rank)."""
+        import torch.distributed as dist
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world_size is None:
+            world_size = dist.get_world_size() if dist.is_initialized() else 1
+        start, stop, shard = shard_bounds(M, world_size, rank)
+        n_real = max(0, min(stop, M) - start)
+        local, rows = self.validate_candidates(start, n_real, shard // WORD)
+        full = allgather_mask(local)
+        words = full.cpu().numpy().view(np.uint64).reshape(world_size, shard // WORD)
+        counts = [int(np.unpackbits(words[r].view(np.uint8)).sum()) for r in range(world_size)]
+        mine = compact(local, n_real, rows)
+        return full, allgather_rows(mine, counts)
 
-def device_candidate_validator(engine, seed, box=None, tips=None):
+
+def device_candidate_validator(engine, seed, box=None, tips=None, signatures=False):
     """validate_candidates for ShardedVertexValidator on `engine`'s GPU (tr_validate_candidates_dev).  tips (optional): a
-    dict that receives the shard's tip tensor under "tips" (n x 3, on the device)."""
+    dict that receives the shard's tip tensor under "tips" (n x 3, on the device).  signatures: (mask, signature rows) for
+    run_with_rows (tr_validate_candidates_sig_dev)."""
     def validate(first, count, n_words):
         import torch
         dev = "cuda:%d" % engine.device
         bits = torch.zeros(n_words, dtype=torch.int64, device=dev)
+        if signatures:
+            sig = torch.empty((max(count, 0), engine.signature_words()), dtype=torch.int32, device=dev)
+            if count > 0:
+                engine.validate_candidates_sig_dev(seed, first, count, bits, sig, box=box)
+            return bits, sig
         if count > 0:
             d_tips = torch.empty(count * 3, dtype=torch.float64, device=dev) if tips is not None else None
             engine.validate_candidates_dev(seed, first, count, bits, d_tips=d_tips, box=box)
@@ -148,6 +192,20 @@ def device_candidate_validator(engine, seed, box=None, tips=None):
                 tips["tips"] = d_tips.view(count, 3)
         return bits
     return validate
+
+
+def device_row_compactor(engine):
+    """compact for ShardedVertexValidator.run_with_rows on `engine`'s GPU: int32 rows of an even number of words
+    (tr_compact_rows_dev on them as doubles)."""
+    def compact(d_mask, count, rows):
+        import torch
+        w = rows.shape[1]
+        out = torch.empty((max(count, 1), w), dtype=torch.int32, device=rows.device)
+        if count == 0:
+            return out[:0]
+        n = engine.compact_rows_dev(d_mask, count, rows.view(torch.float64).reshape(-1), w // 2, out.view(torch.float64).reshape(-1), count)
+        return out[:n]
+    return compact
 
 
 def gather_valid_vertices_dev(engine, seed, M, d_mask, box=None):

@@ -104,15 +104,28 @@ class RoadmapBuilder:
         self.timing["vertex_caches"] = dict(seconds=time.perf_counter() - t0, items=len(states), blocks=int(out["offsets"][-1]))
         return out
 
-    def validate_edges_sharded(self, states, edges, device=None):
+    def validate_edges_sharded(self, states, edges, device=None, d_states=None, d_vertex_sig=None):
         """checkMotion of the candidate edges over the ranks of the default process group (second phase): this rank
-        validates its contiguous shard of the edge list with the indexed form (every vertex once per rank, two lanes), one
-        all-gather of the verdict words; every rank returns the whole mask."""
+        validates its contiguous shard of the edge list with the indexed form (every vertex once per rank, two to four lanes), one
+        all-gather of the verdict words; every rank returns the whole mask.  d_states (the vertex array already on this rank's GPU)
+        and d_vertex_sig (the vertices' signature rows gathered with the vertex mask, ShardedVertexValidator.run_with_rows) select
+        the device-resident form: with the signatures no rank integrates the vertices again."""
         import torch
         dev = device if device is not None else ("cuda:%d" % self.engine.device if torch.cuda.is_available() else "cpu")
+        mv = self.mv
+        if d_states is not None:
+            nv = d_states.shape[0]
+
+            def local(_, e_):
+                d_e = torch.from_numpy(np.ascontiguousarray(e_, dtype=np.int32)).to(d_states.device)
+                d_bits = torch.zeros((len(e_) + 63) // 64, dtype=torch.int64, device=d_states.device)
+                self.engine.validate_edges_indexed_dev(d_states, nv, d_e, len(e_), d_bits, None, mv.min_tension_change, mv.min_rotation_change,
+                                                       mv.min_retraction_change, d_vertex_sig=d_vertex_sig)
+                return d_bits.cpu().numpy().view(np.uint64)
+            return unpack_bits(D.ShardedEdgeValidator(local, device=dev).run_indexed(None, np.asarray(edges)), len(edges))
         st = np.ascontiguousarray(states, dtype=np.float64)
         sh = D.ShardedEdgeValidator(lambda s_, e_: D.pack_bits(self.engine.validate_edges_indexed(
-            s_, e_, self.mv.min_tension_change, self.mv.min_rotation_change, self.mv.min_retraction_change)["valid"]), device=dev)
+            s_, e_, mv.min_tension_change, mv.min_rotation_change, mv.min_retraction_change)["valid"]), device=dev)
         return unpack_bits(sh.run_indexed(st, np.asarray(edges)), len(edges))
 
     def knn_edges_sharded(self, states, k, device=None):

@@ -286,6 +286,23 @@ def knn_local(first, count):                     # numpy brute force stands in f
     d = np.linalg.norm(states[first:first + count, None, :] - states[None, :, :], axis=2)
     return np.argsort(d, axis=1, kind="stable")[:, :4]
 table = D.ShardedNeighbours(knn_local, 4).run(len(states))
+# the vertex phase with a row of data per ACCEPTED candidate gathered next to the mask (in production the backbone signatures the edge
+# phase would otherwise recompute on every rank): here the row is (candidate index, 7 x index), compacted with numpy
+import torch
+def validate_with_rows(first, count, n_words):
+    words = np.zeros(n_words, dtype=np.uint64)
+    if count > 0:
+        w = np.asarray(validate_local(D.candidate_states(robot, 3, first, count))).view(np.uint64)
+        words[: w.size] = w
+        if count %% 64:
+            words[count // 64] &= np.uint64((1 << (count %% 64)) - 1)
+    idx = np.arange(first, first + count, dtype=np.int32)
+    return torch.from_numpy(words.view(np.int64)), torch.from_numpy(np.stack([idx, 7 * idx], 1))
+def compact(mask_words, count, rows):
+    return rows[torch.from_numpy(irt.unpack_bits(mask_words.numpy().view(np.uint64), count))]
+full, rows = D.ShardedVertexValidator(robot, seed=3, validate_candidates=validate_with_rows).run_with_rows(M, compact)
+assert np.array_equal(irt.unpack_bits(full.numpy().view(np.uint64), M), valid)
+assert np.array_equal(rows.numpy()[:, 0], np.flatnonzero(valid)) and np.array_equal(rows.numpy()[:, 1], 7 * np.flatnonzero(valid))
 if rank == 0:
     np.save(sys.argv[2], valid)
     np.save(sys.argv[2] + ".edges.npy", irt.unpack_bits(emask, len(a)))
