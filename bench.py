@@ -312,12 +312,16 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
     M, k, seed = 1 << args.config4_log2, args.config4_k, 3
     dev = "cuda:%d" % dev_index
     box = D.sampling_box(robot)
-    # the accepted candidates' backbone signatures travel with the mask (one more all-gather), so that no rank integrates the whole
+    # Between the phases everything stays in HBM (vertices, neighbour rows, edge list, verdict words: tr_knn_range_dev,
+    # tr_knn_table_edges_dev, tr_validate_edges_indexed_dev); TENDON_BENCH_HOST_ARRAYS=1: the host-array forms of round 2.
+    # The accepted candidates' backbone signatures travel with the mask (one more all-gather), so that no rank integrates the whole
     # vertex set again for its shard of the edges; TENDON_BENCH_NO_SIGNATURES=1: without (every rank's edge call does its vertex pass)
-    hand_over = eng.signature_words() > 0 and not os.environ.get("TENDON_BENCH_NO_SIGNATURES")
+    resident = not os.environ.get("TENDON_BENCH_HOST_ARRAYS")
+    hand_over = resident and eng.signature_words() > 0 and not os.environ.get("TENDON_BENCH_NO_SIGNATURES")
     vv = D.ShardedVertexValidator(robot, seed=seed, device=dev, box=box,
                                   validate_candidates=D.device_candidate_validator(eng, seed, box, signatures=hand_over))
     compact = D.device_row_compactor(eng)
+    space = (mv.min_tension_change, mv.min_rotation_change, mv.min_retraction_change)
 
     def fence():
         if use_dist:
@@ -333,11 +337,19 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
             mask = vv.run(M, keep_on_device=True)
         torch.cuda.synchronize(); t.append(time.perf_counter())
         verts_dev, _ = D.gather_valid_vertices_dev(eng, seed, M, mask, box=box)
+        if resident:
+            torch.cuda.synchronize(); t.append(time.perf_counter())
+            d_edges = torch.empty((max(1, verts_dev.shape[0] * (k + 1)), 2), dtype=torch.int32, device=dev)
+            ne = D.sharded_knn_edges_dev(eng, verts_dev, k + 1, d_edges)         # k neighbours + the vertex itself, as nearestK returns
+            t.append(time.perf_counter())
+            words = D.sharded_edge_verdicts_dev(eng, verts_dev, d_edges, ne, space, d_vertex_sig=vsig)
+            torch.cuda.synchronize(); t.append(time.perf_counter())
+            return mask, verts_dev, d_edges[:ne], words, np.diff(t)
         verts = verts_dev.cpu().numpy()
         t.append(time.perf_counter())
         edges = rb.knn_edges_sharded(verts, k + 1, device=dev)                  # k neighbours + the vertex itself, as nearestK returns
         t.append(time.perf_counter())
-        ev = rb.validate_edges_sharded(verts, edges, device=dev, d_states=verts_dev if hand_over else None, d_vertex_sig=vsig)
+        ev = rb.validate_edges_sharded(verts, edges, device=dev)
         t.append(time.perf_counter())
         return mask, verts, edges, ev, np.diff(t)
 
@@ -355,6 +367,9 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
     prof = eng.profile_read()
     eng.profile_end()
     phase /= args.steps
+    if resident:                        # (to the host for the checksums only, outside the timed region)
+        verts, edges = verts.cpu().numpy(), edges.cpu().numpy()
+        ev = irt.unpack_bits(ev.cpu().numpy().view(np.uint64), len(edges))
     mask_words = mask.cpu().numpy().view(np.uint64)
     sums = np.array([zlib.crc32(mask_words[: (M + 63) // 64].tobytes()), len(verts), len(edges), int(ev.sum()), zlib.crc32(edges.tobytes())],
                     dtype=np.int64)
@@ -398,7 +413,7 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
                                    "all-gather" % (args.config4_log2, k),
                        "ranks_seen": dist.get_world_size() if use_dist else 1, "rehearsal_shared_gpu": rehearsal,
                        "collective": ("gloo(host)" if rehearsal else "rccl") if use_dist else None,
-                       "vertex_signatures_handed_over": bool(hand_over),
+                       "device_resident_between_phases": bool(resident), "vertex_signatures_handed_over": bool(hand_over),
                        "candidates": M, "valid_vertices": int(len(verts)), "candidate_edges": int(len(edges)), "valid_edges": int(ev.sum()),
                        "vertex_mask_crc32": int(sums[0]), "edge_list_crc32": int(sums[4]),
                        "phases_ms": {"vertices_incl_allgather": 1e3 * phase[0], "regenerate_compact_download": 1e3 * phase[1],

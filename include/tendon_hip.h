@@ -478,6 +478,13 @@ int tr_knn_range(tr_ctx *ctx, const double *states, int64_t n, int64_t first_que
 /* The undirected edge set of a k-nearest table given by the caller (n x k indices, -1 = none; e.g. the ranks' tr_knn_range
  * rows gathered): what tr_knn_edges builds from its own table, with the same order and capacity rule. */
 int tr_knn_table_edges(tr_ctx *ctx, const int32_t *idx, int64_t n, int32_t k, int32_t *edges, int64_t capacity, int64_t *n_edges);
+/* Device-resident forms of the two calls above, for the sharded connection loop of a roadmap whose vertices are in HBM: the rank's rows
+ * go to a device array (all-gathered there), the gathered table's edge list is written straight into d_edges.  Same rows, edges,
+ * order and error codes; both synchronise with the device on entry and before they return. */
+int tr_knn_range_dev(tr_ctx *ctx, const double *d_states, int64_t n, int64_t first_query, int64_t n_queries, int32_t k,
+                     double max_distance, int32_t *d_idx);
+int tr_knn_table_edges_dev(tr_ctx *ctx, const int32_t *d_idx, int64_t n, int32_t k, int32_t *d_edges, int64_t capacity,
+                           int64_t *n_edges);
 
 /* k of the PRM* connection strategy for a roadmap of n_milestones vertices (og::KStarStrategy as installed by
  * setStarConnectionStrategy, motion-planning/VoxelCachedLazyPRM.cpp:1346-1356): ceil((e + e / dim) * ln(n)), dim =

@@ -327,9 +327,10 @@ __global__ __launch_bounds__(256) void edge_last_valid_t(EdgeState st, int64_t s
 }
 
 // *flag != 0 afterwards: some index is outside [0, limit)
-__global__ __launch_bounds__(256) void index_range_check(const int32_t *__restrict__ idx, int64_t n, int32_t limit, uint32_t *__restrict__ flag) {
+// (below = 1: -1, "none", is allowed as well)
+__global__ __launch_bounds__(256) void index_range_check(const int32_t *__restrict__ idx, int64_t n, int32_t limit, uint32_t *__restrict__ flag, int below = 0) {
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (i < n && (uint32_t)idx[i] >= (uint32_t)limit) *flag = 1u;
+  if (i < n && (uint32_t)(idx[i] + below) >= (uint32_t)limit + (uint32_t)below) *flag = 1u;
 }
 
 // bit e = edge e of the run is valid: the run's verdicts as the words of the caller's mask (E bits from bit 0 of out[0])

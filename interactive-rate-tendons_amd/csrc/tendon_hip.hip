@@ -180,7 +180,7 @@ struct tr_ctx {
   } fused;
   // scratch of the neighbour search (knn_impl), kept between calls: hipMalloc / hipFree of a dozen buffers per call cost more
   // than the search itself inside a process that holds large allocations (33 against 10 ms at 10^5 states)
-  struct KnnScratch { void *p[12] = {}; size_t cap[12] = {}; } knn;
+  struct KnnScratch { void *p[13] = {}; size_t cap[13] = {}; } knn;
   // block lists of the last tr_voxelize_* call, resident on the device (tr_voxelize_fetch / tr_voxelize_fetch_dev copy
   // them out), and the scratch of the kernels that produce them
   struct VoxStore { uint32_t *ids = nullptr; uint64_t *masks = nullptr; int64_t cap = 0, n = 0; } vstore;
@@ -1745,30 +1745,80 @@ int tr_knn_range(tr_ctx *c, const double *states, int64_t n, int64_t first_query
   return knn_impl(c, states, n, k, max_distance, idx, dist, nullptr, 0, nullptr, first_query, n_queries);
 }
 
-int tr_knn_table_edges(tr_ctx *c, const int32_t *idx, int64_t n, int32_t k, int32_t *edges, int64_t capacity, int64_t *n_edges) {
+static int knn_table_edges_impl(tr_ctx *c, const int32_t *idx, int64_t n, int32_t k, int32_t *edges, int64_t capacity, int64_t *n_edges, bool dev) {
   if (!c) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (!n_edges || n < 0 || k < 1 || capacity < 0 || (capacity > 0 && !edges) || (n > 0 && !idx)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   *n_edges = 0;
   if (n == 0) return TR_OK;
   if (n > (int64_t)1 << 31) return fail(c, TR_ERR_INVALID_ARG, "too many states");
-  for (int64_t i = 0; i < n * k; i++)
-    if (idx[i] < -1 || idx[i] >= n) return fail(c, TR_ERR_OUT_OF_RANGE, "neighbour index outside the table");
+  if (!dev)
+    for (int64_t i = 0; i < n * k; i++)
+      if (idx[i] < -1 || idx[i] >= n) return fail(c, TR_ERR_OUT_OF_RANGE, "neighbour index outside the table");
   HIP_TRY(c, hipSetDevice(c->device));
+  if (dev) HIP_TRY(c, hipDeviceSynchronize());                                 // the table may have been written on any stream of the caller
   if (c->last_dev_used) HIP_TRY(c, hipEventSynchronize(c->last_dev_ev));      // shared sort scratch, see knn_impl
-  int32_t *d_i = nullptr, *d_e = nullptr;
+  // the table and the list in the grow-only scratch of the neighbour search (a hipMalloc / hipFree pair per call costs 15 - 30 ms in a
+  // process that holds the edge pool); device callers' arrays are used where they lie
+  tr_ctx::KnnScratch &ks = c->knn;
+  auto scratch = [&](int slot, size_t bytes) -> void * {
+    if (ks.cap[slot] < bytes) {
+      if (ks.p[slot]) { (void)hipFree(ks.p[slot]); ks.p[slot] = nullptr; ks.cap[slot] = 0; }
+      const size_t want = bytes + bytes / 8;
+      if (hipMalloc(&ks.p[slot], want) != hipSuccess) return nullptr;
+      ks.cap[slot] = want;
+    }
+    return ks.p[slot];
+  };
   const int64_t cap_e = std::min<int64_t>(capacity, n * (int64_t)k);
-  hipError_t e = hipMalloc((void **)&d_i, (size_t)n * k * sizeof(int32_t));
-  if (e == hipSuccess && cap_e > 0) e = hipMalloc((void **)&d_e, (size_t)cap_e * 2 * sizeof(int32_t));
-  if (e == hipSuccess) e = hipMemcpy(d_i, idx, (size_t)n * k * sizeof(int32_t), hipMemcpyHostToDevice);
+  const int32_t *d_i = idx;
+  int32_t *d_e = edges;
+  hipError_t e = hipSuccess;
+  if (!dev) {
+    int32_t *up = (int32_t *)scratch(7, (size_t)n * k * sizeof(int32_t));
+    d_e = cap_e > 0 ? (int32_t *)scratch(11, (size_t)cap_e * 2 * sizeof(int32_t)) : nullptr;
+    if (!up || (cap_e > 0 && !d_e)) return fail(c, TR_ERR_HIP, "hipMalloc failed (neighbour table)");
+    e = hipMemcpy(up, idx, (size_t)n * k * sizeof(int32_t), hipMemcpyHostToDevice);
+    d_i = up;
+  } else {
+    uint32_t *flag = (uint32_t *)scratch(12, sizeof(uint32_t));
+    if (!flag) return fail(c, TR_ERR_HIP, "hipMalloc failed (neighbour table)");
+    uint32_t bad = 0;
+    e = hipMemsetAsync(flag, 0, sizeof(uint32_t), nullptr);
+    if (e == hipSuccess) {
+      // -1 (no neighbour) .. n - 1
+      hipLaunchKernelGGL(trk::index_range_check, dim3((unsigned)((n * k + 255) / 256)), dim3(256), 0, nullptr, d_i, n * (int64_t)k, (int32_t)n, flag, 1);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpy(&bad, flag, sizeof(bad), hipMemcpyDeviceToHost);
+    if (e == hipSuccess && bad) return fail(c, TR_ERR_OUT_OF_RANGE, "neighbour index outside the table");
+  }
   if (e == hipSuccess) e = trk::knn_edge_list(c->merge, d_i, n, (int)k, d_e, cap_e, n_edges, nullptr);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   const int64_t m = std::min<int64_t>(*n_edges, cap_e);
-  if (e == hipSuccess && m > 0) e = hipMemcpy(edges, d_e, (size_t)m * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
-  if (d_i) (void)hipFree(d_i);
-  if (d_e) (void)hipFree(d_e);
+  if (e == hipSuccess && m > 0 && !dev) e = hipMemcpy(edges, d_e, (size_t)m * 2 * sizeof(int32_t), hipMemcpyDeviceToHost);
   if (e != hipSuccess) return fail(c, TR_ERR_HIP, std::string("knn edge list: ") + hipGetErrorString(e));
   return TR_OK;
+}
+
+int tr_knn_table_edges(tr_ctx *c, const int32_t *idx, int64_t n, int32_t k, int32_t *edges, int64_t capacity, int64_t *n_edges) {
+  return knn_table_edges_impl(c, idx, n, k, edges, capacity, n_edges, false);
+}
+
+// Device-resident forms of the sharded connection loop: a rank's rows of the table from vertices in HBM into a device array (to be
+// all-gathered there), and the edge list of a gathered table written straight into the caller's device array.
+int tr_knn_range_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t first_query, int64_t n_queries, int32_t k, double max_distance,
+                     int32_t *d_idx) {
+  if (!c) return TR_ERR_INVALID_ARG;
+  if (first_query < 0 || n_queries < 0 || first_query + n_queries > n) return fail(c, TR_ERR_OUT_OF_RANGE, "query range outside the states");
+  if (n_queries > 0 && !d_idx) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
+  if (n_queries == 0) return TR_OK;
+  HIP_TRY(c, hipSetDevice(c->device));
+  HIP_TRY(c, hipDeviceSynchronize());                  // d_states may have been written on any stream of the caller
+  return knn_impl(c, d_states, n, k, max_distance, d_idx, nullptr, nullptr, 0, nullptr, first_query, n_queries, true);
+}
+int tr_knn_table_edges_dev(tr_ctx *c, const int32_t *d_idx, int64_t n, int32_t k, int32_t *d_edges, int64_t capacity, int64_t *n_edges) {
+  return knn_table_edges_impl(c, d_idx, n, k, d_edges, capacity, n_edges, true);
 }
 
 int tr_knn_edges(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *edges, int64_t capacity,
@@ -1794,7 +1844,7 @@ namespace {
 // queries [q0, q0 + nq) of the n states (nq < 0: all of them) against all n states as candidates
 int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_distance, int32_t *idx, double *dist,
              int32_t *edges, int64_t edge_capacity, int64_t *n_edges, int64_t q0, int64_t nq, bool dev) {
-  // dev: `states` and `edges` are device arrays (tr_knn_edges_dev)
+  // dev: `states`, `idx`, `dist` and `edges` are device arrays (tr_knn_edges_dev, tr_knn_range_dev)
   std::lock_guard<std::recursive_mutex> lock_(c->mu);
   if (n < 0 || k < 1 || (n > 0 && !states)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n == 0) return TR_OK;
@@ -1916,8 +1966,9 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
         hipLaunchKernelGGL(trk::knn_merge, dim3((unsigned)qblocks), dim3(64), (size_t)nslice * 64, nullptr, d_pi, d_pd, nq, nslice, (int)k, max_distance, d_i, d_d);
     }
     if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = fail(c, TR_ERR_HIP, "knn launch failed"); break; }
-    if (idx && hipMemcpy(idx, d_i, (size_t)nq * k * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
-    if (dist && hipMemcpy(dist, d_d, (size_t)nq * k * sizeof(double), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+    const hipMemcpyKind down = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (idx && hipMemcpy(idx, d_i, (size_t)nq * k * sizeof(int32_t), down) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
+    if (dist && hipMemcpy(dist, d_d, (size_t)nq * k * sizeof(double), down) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
     if (n_edges) {
       // the undirected edge set of the table, deduplicated and ordered on the device (cache_merge.hip)
       int32_t *d_e = nullptr;                 // kept with the rest of the search's scratch: a hipMalloc / hipFree pair per call costs

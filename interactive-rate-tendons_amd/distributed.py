@@ -309,6 +309,47 @@ class ShardedNeighbours:
         return full[:n]
 
 
+def sharded_knn_edges_dev(engine, d_states, k, d_edges, rank=None, world_size=None):
+    """ShardedNeighbours with everything in HBM: this rank's rows of the k-nearest table (tr_knn_range_dev) into a device tensor, one
+    all-gather of the int32 rows (equal shards, padding rows -1), the edge list of the whole table into d_edges (int32, capacity x 2;
+    tr_knn_table_edges_dev) on every rank.  Returns the number of edges."""
+    import torch
+    import torch.distributed as dist
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    n = d_states.shape[0]
+    start, stop, shard = shard_bounds(n, world_size, rank)
+    n_real = max(0, min(stop, n) - start)
+    rows = torch.full((shard, int(k)), -1, dtype=torch.int32, device=d_states.device)
+    if n_real > 0:
+        engine.knn_range_dev(d_states, n, start, n_real, k, rows)           # (the first n_real rows of the shard's block)
+    table = allgather_mask(rows.reshape(-1))[: n * int(k)].contiguous()
+    return engine.edges_from_knn_dev(table, n, k, d_edges)
+
+
+def sharded_edge_verdicts_dev(engine, d_states, d_edges, n_edges, space_params, d_vertex_sig=None, rank=None, world_size=None):
+    """ShardedEdgeValidator.run_indexed with the vertices and the edge list in HBM: this rank's contiguous shard of d_edges through
+    tr_validate_edges_indexed_dev (with d_vertex_sig: _sig_dev, no vertex pass), the verdict words all-gathered as device tensors.
+    Returns the mask words (int64 tensor on the device; unpack_bits(words, n_edges) is the mask)."""
+    import torch
+    import torch.distributed as dist
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    start, stop, shard = shard_bounds(n_edges, world_size, rank)
+    n_real = max(0, min(stop, n_edges) - start)
+    words = torch.zeros(shard // WORD, dtype=torch.int64, device=d_states.device)
+    if n_real > 0:
+        engine.validate_edges_indexed_dev(d_states, d_states.shape[0], d_edges[start:start + n_real], n_real, words, None, *space_params,
+                                          d_vertex_sig=d_vertex_sig)
+        if n_real % WORD:                                  # padding bits stay zero
+            words[n_real // WORD] &= (1 << (n_real % WORD)) - 1
+    return allgather_mask(words)
+
+
 def pack_bits(mask):
     """bool[n] -> uint64 words, bit i & 63 of word i >> 6 (the layout of every verdict mask here)."""
     mask = np.asarray(mask, dtype=bool)

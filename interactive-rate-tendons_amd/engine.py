@@ -461,6 +461,23 @@ class Engine:
         L.check(self._ctx, self.lib.tr_knn_edges_dev(self._ctx, ps, int(n), int(k), float(max_distance), pe, cap, C.byref(ne)))
         return int(ne.value)
 
+    def knn_range_dev(self, d_states, n, first_query, n_queries, k, d_idx, max_distance=np.inf):
+        """tr_knn_range with the states in HBM: rows first_query .. of the k-nearest table into d_idx (int32, n_queries x k, device)."""
+        torch = _torch()
+        ps = self._check_dev(d_states, torch.float64, n * self.state_size, "d_states")
+        pi = self._check_dev(d_idx, torch.int32, n_queries * int(k), "d_idx")
+        L.check(self._ctx, self.lib.tr_knn_range_dev(self._ctx, ps, int(n), int(first_query), int(n_queries), int(k), float(max_distance), pi))
+
+    def edges_from_knn_dev(self, d_table, n, k, d_edges):
+        """tr_knn_table_edges on a table in HBM (int32, n x k), the edge list written into d_edges (int32, capacity x 2): returns n_edges."""
+        torch = _torch()
+        pt = self._check_dev(d_table, torch.int32, n * int(k), "d_table")
+        cap = d_edges.numel() // 2
+        pe = self._check_dev(d_edges, torch.int32, 2 * cap, "d_edges")
+        ne = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_knn_table_edges_dev(self._ctx, pt, int(n), int(k), pe, cap, C.byref(ne)))
+        return int(ne.value)
+
     def validate_edges_indexed_dev(self, d_states, n_states, d_edges, n_edges, d_bits, d_n_fk=None, min_tension_change=0.02,
                                    min_rotation_change=0.01, min_retraction_change=0.0001, d_vertex_sig=None):
         """tr_validate_edges_indexed on device arrays (vertex states, index pairs, mask words, optional FK counts): returns the

@@ -141,8 +141,12 @@ def test_config4_workload_world1_rccl_and_world2_rehearsal_agree():
     assert set(two["config"]["collectives_alone"]) == {"vertex_mask", "knn_rows", "edge_mask", "vertex_signatures"}
     assert one["config"]["vertex_signatures_handed_over"] and two["config"]["vertex_signatures_handed_over"]
     # ... and without the signature hand-over (every rank's edge call integrates the vertices itself): the same build
+    # ... and through the host-array forms of every phase (tr_knn_range / tr_knn_table_edges / tr_validate_edges_indexed): the same build
     plain = _bench(["--gpus", "1"] + common, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TENDON_BENCH_NO_SIGNATURES="1")
-    assert not plain["config"]["vertex_signatures_handed_over"]
-    for key in ("valid_vertices", "candidate_edges", "valid_edges", "vertex_mask_crc32", "edge_list_crc32"):
-        assert one["config"][key] == plain["config"][key], key
+    host = _bench(["--gpus", "1"] + common, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TENDON_BENCH_HOST_ARRAYS="1")
+    assert one["config"]["device_resident_between_phases"] and plain["config"]["device_resident_between_phases"]
+    assert not plain["config"]["vertex_signatures_handed_over"] and not host["config"]["device_resident_between_phases"]
+    for other in (plain, host):
+        for key in ("valid_vertices", "candidate_edges", "valid_edges", "vertex_mask_crc32", "edge_list_crc32"):
+            assert one["config"][key] == other["config"][key], key
     assert all(v > 0 for v in two["config"]["phases_ms"].values()) and two["value"] > 0

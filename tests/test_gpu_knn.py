@@ -244,3 +244,49 @@ def test_wave_per_query_and_lane_per_query_kernels_give_the_same_tables(irt, mon
     i65, d65 = eng.knn(st[:4000], 65)
     i64, d64 = eng.knn(st[:4000], 64)
     assert np.array_equal(i65[:, :64], i64) and np.array_equal(d65[:, :64], d64)
+
+
+def test_device_resident_range_and_table_forms(irt):
+    """tr_knn_range_dev / tr_knn_table_edges_dev (states, rows and edge list in HBM) give the rows of tr_knn_range and the edge list of
+    tr_knn_table_edges -- ranges that are not whole shards, a table with -1 padding entries, a truncating capacity -- and the same errors."""
+    import torch
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=16)
+    eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+    n, k = 5000, 9
+    states = W.random_states(robot, n, seed=77)
+    d_states = torch.from_numpy(states).cuda()
+    table, _ = eng.knn(states, k)
+    d_table = torch.full((n, k), -5, dtype=torch.int32, device="cuda")
+    for first, count in ((0, 1700), (1700, 1601), (3301, 1699)):
+        rows = torch.full((count, k), -5, dtype=torch.int32, device="cuda")
+        eng.knn_range_dev(d_states, n, first, count, k, rows)
+        assert np.array_equal(rows.cpu().numpy(), table[first:first + count])
+        d_table[first:first + count] = rows
+    want = eng.edges_from_knn(table)
+    d_edges = torch.full((n * k, 2), -7, dtype=torch.int32, device="cuda")
+    ne = eng.edges_from_knn_dev(d_table, n, k, d_edges)
+    assert ne == len(want) and np.array_equal(d_edges[:ne].cpu().numpy(), want) and (d_edges[ne:] == -7).all()
+    holes = table.copy()
+    holes[::7, 3:] = -1                                                         # rows with fewer neighbours (a bounded search)
+    assert np.array_equal(_edges_dev(eng, holes, n, k), eng.edges_from_knn(holes))
+    few = torch.zeros((100, 2), dtype=torch.int32, device="cuda")
+    assert eng.edges_from_knn_dev(d_table, n, k, few) == ne and np.array_equal(few.cpu().numpy(), want[:100])
+    bad = d_table.clone()
+    bad[17, 2] = n
+    with pytest.raises(irt.OutOfRange):
+        eng.edges_from_knn_dev(bad, n, k, d_edges)
+    bad[17, 2] = -2
+    with pytest.raises(irt.OutOfRange):
+        eng.edges_from_knn_dev(bad, n, k, d_edges)
+    with pytest.raises(irt.OutOfRange):
+        eng.knn_range_dev(d_states, n, n - 10, 11, k, torch.zeros((11, k), dtype=torch.int32, device="cuda"))
+    assert eng.edges_from_knn_dev(d_table, n, k, d_edges) == ne                  # the context is usable afterwards
+
+
+def _edges_dev(eng, table, n, k):
+    import torch
+    d_e = torch.empty((n * k, 2), dtype=torch.int32, device="cuda")
+    m = eng.edges_from_knn_dev(torch.from_numpy(np.ascontiguousarray(table, dtype=np.int32)).cuda(), n, k, d_e)
+    return d_e[:m].cpu().numpy()
