@@ -147,6 +147,7 @@ struct tr_ctx {
   uint32_t *d_edge_counters1[kMaxLanes - 1] = {}; // lanes 1 .. (lane 0: EdgeDev::counters)
   int edge_lanes = kMaxLanes;                     // TENDON_HIP_EDGE_LANES=1 .. 4: exactly that many lanes (1: one lane only); default: by the edge count
   bool edge_lanes_fixed = false;
+  bool edge_kernels_loaded = false;               // tr_reserve_edges has launched every kernel of the indexed edge path once
   double edge_rate_seen = 0.0;                    // own samples per edge of this context's last indexed edge call (0 = none yet): sizes
                                                   // the next call's chunks and lanes (a rotating robot's edges take ~10, not ~4)
   bool edge_lane_guess_forced = false;            // TENDON_HIP_EDGE_LANE_GUESS was given: it overrides the rate this context has seen
