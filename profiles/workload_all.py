@@ -120,7 +120,8 @@ def main():
     add("fk_verdict<4>", bytes=(cand + V) * (8 * 4 + 24 + 0.125), flops=(cand + V) * fl4, units=cand + V, unit="checks")   # vertex sampling + the edge call's vertex pass? no: see below
     # the edge call evaluates its V vertices and its own samples through the SIG variant (a 4 P-byte signature row per sample)
     units["fk_verdict<4>"]["bytes"] -= V * (8 * 4 + 24 + 0.125); units["fk_verdict<4>"]["flops"] -= V * fl4; units["fk_verdict<4>"]["units"] -= V
-    add("fk_verdict<4> +sig", bytes=n_samples * (8 * 4 + 4 * 129 + 0.125), flops=n_samples * fl4, units=n_samples, unit="edge samples")
+    add("fk_verdict<4> +sig", bytes=n_samples * (8 * 4 + 4 * 129 + 0.125), flops=n_samples * fl4, units=n_samples,
+        unit="edge samples (up to four lanes' launches share the GPU, so the per-launch durations this row sums overlap: the call as a whole integrates 8.6e7 samples/s, r03/edge_timeline_v2.txt)")
     add("edge_filter", bytes=2.0 * 129 * 4 * (n_samples + len(edges)), units=n_samples + len(edges), unit="interval tests on cell signatures (upper bound: early exit from the tip)")
     e_ok = edges[valid]
     vc = rb.vertex_caches(states)
