@@ -323,12 +323,14 @@ def _run_world(world, M, out, tmp_path):
         assert p.wait(timeout=600) == 0
 
 
-def test_sharded_validation_gloo_world2_matches_world1(irt, tmp_path):
+def test_sharded_validation_gloo_world2_and_3_match_world1(irt, tmp_path):
     M = 700                                        # not a multiple of 64: exercises padding bits
     _run_world(1, M, str(tmp_path / "w1.npy"), tmp_path)
     _run_world(2, M, str(tmp_path / "w2.npy"), tmp_path)
+    _run_world(3, M, str(tmp_path / "w3.npy"), tmp_path)          # shards of 256, 256 and 188 candidates; row blocks of three lengths
     a, b = np.load(tmp_path / "w1.npy"), np.load(tmp_path / "w2.npy")
-    assert a.shape == (M,) and np.array_equal(a, b)
+    assert a.shape == (M,) and np.array_equal(a, b) and np.array_equal(a, np.load(tmp_path / "w3.npy"))
+    assert np.array_equal(np.load(tmp_path / "w1.npy.edges.npy"), np.load(tmp_path / "w3.npy.edges.npy"))
     assert 0 < a.sum() < M
     ea, eb = np.load(tmp_path / "w1.npy.edges.npy"), np.load(tmp_path / "w2.npy.edges.npy")
     assert ea.shape == (130,) and np.array_equal(ea, eb) and 0 < ea.sum() < 130      # 130 edges: shards are not whole words
