@@ -101,6 +101,29 @@ def run(argv=None):
         v2, nfk2 = rb.validate_edges(states, edges)
         t_edges_repeat = min(t_edges_repeat, rb.timing["edges"]["seconds"])
         assert np.array_equal(v2, valid) and np.array_equal(nfk2, nfk)
+    # the same edge phase as a build that stays in HBM runs it: vertices from the device sampler WITH their signature rows
+    # (tr_sample_valid_vertices_sig_dev), edge list on the device, the edge call told that its vertices are valid and what their
+    # signatures are (tr_validate_edges_indexed_sig_dev) -- it does not integrate them a second time.  Fastest of three; same verdicts.
+    import torch
+    eng = chk.engine
+    t_edges_sig = None
+    if eng.signature_words():
+        nv, S, sw = len(states), eng.state_size, eng.signature_words()
+        d_st = torch.empty(nv * S, dtype=torch.float64, device="cuda")
+        d_sig = torch.empty((nv, sw), dtype=torch.int32, device="cuda")
+        acc, _ = eng.sample_valid_vertices_dev(nv, d_st, seed=rb.seed, box=irt.distributed.sampling_box(robot, rb.tau_max), d_sig=d_sig)
+        assert acc == nv and np.array_equal(d_st.cpu().numpy().reshape(nv, S), states)
+        d_ed = torch.empty((nv * (args.k + 1), 2), dtype=torch.int32, device="cuda")
+        ne = eng.knn_edges_dev(d_st, nv, args.k + 1, d_ed)
+        d_bits = torch.empty((ne + 63) // 64, dtype=torch.int64, device="cuda")
+        t_edges_sig = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            eng.validate_edges_indexed_dev(d_st, nv, d_ed, ne, d_bits, None, rb.mv.min_tension_change, rb.mv.min_rotation_change,
+                                           rb.mv.min_retraction_change, d_vertex_sig=d_sig)
+            torch.cuda.synchronize(); t_edges_sig = min(t_edges_sig, time.perf_counter() - t0)
+        assert ne == len(edges) and np.array_equal(irt.unpack_bits(d_bits.cpu().numpy().view(np.uint64), ne), valid)
+        del d_st, d_sig, d_ed, d_bits
     # the host's exact search as the check of the edge list (0.8 s of cKDTree: after the timed calls, so that the edge phase follows the
     # neighbour search as it does in a build and not a second of GPU idle)
     edges_host = rb.knn_edges(states, args.k)
@@ -115,6 +138,7 @@ def run(argv=None):
             "vertex_checks_per_s": t["vertices"]["candidates"] / t["vertices"]["seconds"],
             "knn_host_seconds": t["knn"]["seconds"], "knn_gpu_seconds_incl_pcie_and_dedup": t_knn_gpu,
             "edges_per_s": len(edges) / t["edges"]["seconds"], "edges_per_s_repeat": len(edges) / t_edges_repeat,
+            "edges_per_s_device_resident_signatures_handed_over": (len(edges) / t_edges_sig) if t_edges_sig else None,
             "edge_fk_samples_per_s": t["edges"]["fk_samples"] / t["edges"]["seconds"],
             "edge_valid_fraction": float(valid.mean()),
             "fk_samples_per_edge": {"mean": float(nfk.mean()), "p50": float(np.median(nfk)), "max": int(nfk.max()),

@@ -464,6 +464,11 @@ int tr_validate_edges_indexed_dev(tr_ctx *ctx, const tr_space_params *sp, const 
  * errors of tr_validate_edges_indexed_dev.  tr_signature_words returns 0 -- and the two calls TR_ERR_UNSUPPORTED -- for retraction
  * robots, under TR_CHECKER_SPHERES and on schedules other than the default verdict-only one. */
 int tr_signature_words(const tr_ctx *ctx);
+/* ... and tr_sample_valid_vertices_dev that also returns the accepted vertices' rows (d_sig: n_want x tr_signature_words uint32, row i
+ * belongs to d_states row i): createRoadmap's "sample until N are valid" feeding the edge phase directly. */
+int tr_sample_valid_vertices_sig_dev(tr_ctx *ctx, uint64_t seed, uint64_t first_candidate, const double *lo, const double *hi,
+                                     int64_t n_want, int64_t max_candidates, double *d_states, double *d_tips, int64_t *d_index,
+                                     uint32_t *d_sig, int64_t *n_accepted, int64_t *n_tried, void *stream);
 int tr_validate_candidates_sig_dev(tr_ctx *ctx, uint64_t seed, uint64_t first, int64_t count, const double *lo, const double *hi,
                                    uint64_t *d_valid_bits, double *d_tips, uint32_t *d_sig, void *stream);
 int tr_validate_edges_indexed_sig_dev(tr_ctx *ctx, const tr_space_params *sp, const double *d_states, int64_t n_states,

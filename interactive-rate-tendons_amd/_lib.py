@@ -35,7 +35,7 @@ ABI_SYMBOLS = (
     "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_edges_indexed", "tr_connect_edges_indexed", "tr_voxelize_fetch", "tr_voxelize_fetch_dev", "tr_voxelize_count", "tr_knn", "tr_knn_range", "tr_knn_table_edges", "tr_knn_edges", "tr_knn_edges_dev", "tr_knn_range_dev", "tr_knn_table_edges_dev", "tr_validate_edges_indexed_dev", "tr_signature_words", "tr_validate_candidates_sig_dev", "tr_validate_edges_indexed_sig_dev", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug",
     "tr_candidate_states", "tr_candidate_states_dev", "tr_validate_candidates_dev", "tr_compact_rows_dev",
-    "tr_sample_valid_vertices", "tr_sample_valid_vertices_dev",
+    "tr_sample_valid_vertices", "tr_sample_valid_vertices_dev", "tr_sample_valid_vertices_sig_dev",
 )
 
 
@@ -296,6 +296,7 @@ def lib():
     L.tr_compact_rows_dev.argtypes = [vp, vp, i64, vp, C.c_int32, i64, vp, vp, P(i64), vp]
     L.tr_sample_valid_vertices.argtypes = [vp, u64, u64, dp, dp, i64, i64, dp, dp, P(i64), P(i64), P(i64)]
     L.tr_sample_valid_vertices_dev.argtypes = [vp, u64, u64, dp, dp, i64, i64, vp, vp, vp, P(i64), P(i64), vp]
+    L.tr_sample_valid_vertices_sig_dev.argtypes = [vp, u64, u64, dp, dp, i64, i64, vp, vp, vp, vp, P(i64), P(i64), vp]
     L.tr_profile_begin.argtypes = [vp]
     L.tr_profile_read.argtypes = [vp, P(i64), dp]
     L.tr_profile_end.argtypes = [vp]

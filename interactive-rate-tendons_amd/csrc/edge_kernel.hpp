@@ -333,6 +333,15 @@ __global__ __launch_bounds__(256) void index_range_check(const int32_t *__restri
   if (i < n && (uint32_t)(idx[i] + below) >= (uint32_t)limit + (uint32_t)below) *flag = 1u;
 }
 
+// rows of a batch's signature array picked by candidate index (the vertex sampler: accepted candidates' rows, in acceptance order)
+__global__ __launch_bounds__(256) void gather_signature_rows(const uint32_t *__restrict__ sig, int64_t words, const int64_t *__restrict__ index, int64_t rows,
+                                                             int64_t index_base, uint32_t *__restrict__ out) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= rows * words) return;
+  const int64_t r = t / words, w = t - r * words;
+  out[t] = sig[(index[r] - index_base) * words + w];
+}
+
 // bit e = edge e of the run is valid: the run's verdicts as the words of the caller's mask (E bits from bit 0 of out[0])
 __global__ __launch_bounds__(256) void edge_ok_bits(const uint32_t *__restrict__ edge_ok, int64_t E, uint64_t *__restrict__ out) {
   const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;

@@ -213,6 +213,8 @@ struct tr_ctx {
     int64_t out_cap = 0;
     double *out_states = nullptr, *out_tips = nullptr; int64_t *out_index = nullptr;
     double rate_seen = 0.0;                                  // acceptance rate of this context's last run (sizes the first batch)
+    uint32_t *sig = nullptr; int64_t sig_cap = 0;            // [batch][tr_signature_words]: the candidates' signature rows of one batch
+    int64_t *sig_index = nullptr; int64_t sig_index_cap = 0; // accepted candidates' indices when the caller keeps none
   } samp;
   // pinned staging for host arrays that are uploaded by a synchronous call (upload_staged)
   void *h_stage = nullptr; size_t h_stage_cap = 0;
@@ -913,7 +915,7 @@ void tr_destroy(tr_ctx *c) {
   if (c->last_dev_ev) (void)hipEventDestroy(c->last_dev_ev);
   {
     tr_ctx::Sampler &sm = c->samp;
-    void *sp[] = {sm.states, sm.bits, sm.tips, sm.wprefix, sm.wprefix2, sm.d_ctr, sm.out_states, sm.out_tips, sm.out_index};
+    void *sp[] = {sm.states, sm.bits, sm.tips, sm.wprefix, sm.wprefix2, sm.d_ctr, sm.out_states, sm.out_tips, sm.out_index, sm.sig, sm.sig_index};
     for (void *q : sp) if (q) (void)hipFree(q);
     if (sm.h_ctr) (void)hipHostFree(sm.h_ctr);
   }

@@ -526,13 +526,21 @@ class Engine:
                     accepted=k, tried=n_tried.value)
 
     def sample_valid_vertices_dev(self, n_want, d_states, d_tips=None, d_index=None, seed=0, first_candidate=0, box=None,
-                                  max_candidates=0, stream=None):
+                                  max_candidates=0, stream=None, d_sig=None):
+        """tr_sample_valid_vertices_dev; with d_sig (int32, n_want x signature_words()) also the accepted vertices' signature rows
+        (tr_sample_valid_vertices_sig_dev), which validate_edges_indexed_dev takes as d_vertex_sig."""
         torch = _torch()
         keep, plo, phi = self._box(box)
         ps = self._check_dev(d_states, torch.float64, n_want * self.state_size, "d_states")
         pt = self._check_dev(d_tips, torch.float64, 3 * n_want, "d_tips") if d_tips is not None else None
         pi = self._check_dev(d_index, torch.int64, n_want, "d_index") if d_index is not None else None
         n_acc, n_tried = C.c_int64(0), C.c_int64(0)
+        if d_sig is not None:
+            psig = self._check_dev(d_sig, torch.int32, n_want * max(1, self.signature_words()), "d_sig")
+            L.check(self._ctx, self.lib.tr_sample_valid_vertices_sig_dev(self._ctx, int(seed), int(first_candidate), plo, phi, int(n_want),
+                                                                         int(max_candidates), ps, pt, pi, psig, C.byref(n_acc), C.byref(n_tried),
+                                                                         self._stream_ptr(stream)))
+            return n_acc.value, n_tried.value
         L.check(self._ctx, self.lib.tr_sample_valid_vertices_dev(self._ctx, int(seed), int(first_candidate), plo, phi, int(n_want),
                                                                  int(max_candidates), ps, pt, pi, C.byref(n_acc), C.byref(n_tried),
                                                                  self._stream_ptr(stream)))

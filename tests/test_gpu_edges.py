@@ -430,3 +430,50 @@ def test_vertex_signatures_handed_over_from_the_vertex_phase(irt):
     assert e2.signature_words() == 0
     with pytest.raises(irt.Unsupported):
         e2.validate_candidates_sig_dev(1, 0, 64, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(64 * 160, dtype=torch.int32, device="cuda"))
+
+
+def test_sampler_returns_the_signature_rows_of_its_vertices(irt):
+    """tr_sample_valid_vertices_sig_dev: the rejection loop's accepted vertices come with their signature rows -- the rows
+    tr_validate_candidates_sig_dev writes for those candidates, whatever the batch sizes and whether or not the caller keeps the
+    candidate indices -- and the edge call that takes them gives the verdicts of the one that integrates the vertices itself."""
+    import torch
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+    sw, S, box, seed, n_want = eng.signature_words(), eng.state_size, D.sampling_box(robot), 23, 3000
+    d_states = torch.zeros(n_want * S, dtype=torch.float64, device="cuda")
+    d_index = torch.zeros(n_want, dtype=torch.int64, device="cuda")
+    d_sig = torch.full((n_want, sw), -1, dtype=torch.int32, device="cuda")
+    acc, tried = eng.sample_valid_vertices_dev(n_want, d_states, d_index=d_index, seed=seed, box=box, d_sig=d_sig)
+    torch.cuda.synchronize()
+    assert acc == n_want and tried > n_want
+    plain = torch.zeros_like(d_states)
+    assert eng.sample_valid_vertices_dev(n_want, plain, seed=seed, box=box) == (acc, tried) and torch.equal(plain, d_states)
+    # the candidates' rows from the batch call, picked by the accepted indices
+    M = (tried + 63) // 64 * 64
+    d_bits = torch.zeros(M // 64, dtype=torch.int64, device="cuda")
+    d_all = torch.zeros((M, sw), dtype=torch.int32, device="cuda")
+    eng.validate_candidates_sig_dev(seed, 0, M, d_bits, d_all, box=box)
+    torch.cuda.synchronize()
+    P = eng.num_points
+    assert torch.equal(d_sig[:, :P], d_all[d_index][:, :P])
+    # several small batches (a cap on the candidates per call) and no index array: the same rows
+    d_states2, d_sig2 = torch.zeros_like(d_states), torch.full((n_want, sw), -1, dtype=torch.int32, device="cuda")
+    got, first = 0, 0
+    while got < n_want:                                                  # calls capped at 1024 candidates each, run after run
+        a, t = eng.sample_valid_vertices_dev(n_want - got, d_states2[got * S:], seed=seed, first_candidate=first, box=box, max_candidates=1024,
+                                             d_sig=d_sig2[got:])
+        assert 0 < a and t <= 1024
+        got, first = got + a, first + 1024
+    torch.cuda.synchronize()
+    assert got == n_want and torch.equal(d_states2, d_states)            # the same candidates in the same order, so the same vertices
+    assert torch.equal(d_sig2[:, :P], d_sig[:, :P])
+    k = 7
+    for st, sg in ((d_states, d_sig), (d_states2, d_sig2)):
+        d_edges = torch.empty((n_want * k, 2), dtype=torch.int32, device="cuda")
+        ne = eng.knn_edges_dev(st, n_want, k, d_edges)
+        want, got_b = torch.zeros((ne + 63) // 64, dtype=torch.int64, device="cuda"), torch.zeros((ne + 63) // 64, dtype=torch.int64, device="cuda")
+        wn, gn = torch.zeros(ne, dtype=torch.int32, device="cuda"), torch.zeros(ne, dtype=torch.int32, device="cuda")
+        assert eng.validate_edges_indexed_dev(st, n_want, d_edges, ne, want, wn) == eng.validate_edges_indexed_dev(st, n_want, d_edges, ne, got_b, gn, d_vertex_sig=sg)
+        assert torch.equal(want, got_b) and torch.equal(wn, gn) and ne >= 8192
