@@ -67,6 +67,32 @@ class RoadmapBuilder:
         self.timing["knn_gpu"] = dict(seconds=time.perf_counter() - t0, edges=len(e))
         return e
 
+    def build_on_device(self, n_vertices, k, max_distance=np.inf):
+        """createRoadmap's phases 1 - 3 without leaving HBM (:1431-1560): n_vertices valid vertices from the device sampler, with their
+        backbone signatures where the context can hand them over (tr_sample_valid_vertices_sig_dev), the k-nearest edge list
+        (tr_knn_edges_dev; k counts the vertex itself) and checkMotion on every candidate edge (tr_validate_edges_indexed_sig_dev /
+        _dev) -- only counts cross PCIe.  Returns torch tensors on the engine's GPU: d_states [n, S], d_edges [n_edges, 2] int32,
+        d_valid_bits (int64 words; unpack_bits(words, n_edges)), and n_domain_errors, candidates_tried.  Same vertices, edges and
+        verdicts as sample_valid_vertices -> knn_edges_gpu -> validate_edges."""
+        import torch
+        t0 = time.perf_counter()
+        eng, dev = self.engine, "cuda:%d" % self.engine.device
+        n, S, sw = int(n_vertices), eng.state_size, eng.signature_words()
+        d_states = torch.empty(n * S, dtype=torch.float64, device=dev)
+        d_sig = torch.empty((n, sw), dtype=torch.int32, device=dev) if sw else None
+        acc, tried = eng.sample_valid_vertices_dev(n, d_states, seed=self.seed, box=D.sampling_box(self.robot, self.tau_max), d_sig=d_sig)
+        if acc < n:
+            raise RuntimeError("only %d of %d valid vertices after %d candidates" % (acc, n, tried))
+        d_edges = torch.empty((max(1, n * int(k)), 2), dtype=torch.int32, device=dev)
+        ne = eng.knn_edges_dev(d_states, n, k, d_edges, max_distance)
+        d_bits = torch.zeros((ne + 63) // 64, dtype=torch.int64, device=dev)
+        nd = eng.validate_edges_indexed_dev(d_states, n, d_edges, ne, d_bits, None, self.mv.min_tension_change, self.mv.min_rotation_change,
+                                            self.mv.min_retraction_change, d_vertex_sig=d_sig) if ne else 0
+        torch.cuda.synchronize()
+        self.timing["build_on_device"] = dict(seconds=time.perf_counter() - t0, vertices=n, edges=ne, candidates=tried)
+        return dict(d_states=d_states.view(n, S), d_edges=d_edges[:ne], d_valid_bits=d_bits, n_edges=ne, n_domain_errors=nd,
+                    candidates_tried=tried, signatures_handed_over=bool(sw))
+
     def knn_edges_star(self, states):
         """The PRM* connection strategy (setStarConnectionStrategy, VoxelCachedLazyPRM.cpp:1346-1356): k grows with the
         roadmap, k = ceil((e + e/dim) ln n); in createRoadmap all n vertices are in place before connecting."""

@@ -129,3 +129,32 @@ def test_union_kernel_and_sort_path_build_the_same_caches(irt, monkeypatch):
         inner = np.ones(len(ids), bool)
         inner[off[:-1][off[:-1] < len(ids)]] = False            # first entry of every list
         assert (np.diff(ids)[inner[1:]] > 0).all()
+
+
+def test_build_on_device_equals_the_host_array_pipeline(irt):
+    """RoadmapBuilder.build_on_device (sampler with signature rows -> tr_knn_edges_dev -> tr_validate_edges_indexed_sig_dev, nothing
+    but counts over PCIe) gives the vertices, the edge list and the verdicts of sample_valid_vertices -> knn_edges_gpu ->
+    validate_edges -- for the tension-only robot and a rotating one (signatures handed over), and for a retraction robot, whose
+    context has no signatures to hand over (the edge call integrates its vertices itself) and whose host builder numbers the
+    vertices by backbone length: there the edge and verdict COUNTS are compared."""
+    W = irt.workloads
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    for rot, ret in ((False, False), (True, False), (False, True)):
+        robot = W.robot_config3()
+        robot.enable_rotation, robot.enable_retraction = rot, ret
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=29)
+        n, k = 4000, 8
+        out = rb.build_on_device(n, k)
+        states, _ = rb.sample_valid_vertices(n)
+        edges = rb.knn_edges_gpu(states, k)
+        valid, _ = rb.validate_edges(states, edges)
+        got_valid = irt.unpack_bits(out["d_valid_bits"].cpu().numpy().view(np.uint64), out["n_edges"])
+        assert out["signatures_handed_over"] == (not ret) == (chk.engine.signature_words() > 0)
+        assert out["n_edges"] == len(edges) >= 8192 and got_valid.sum() == valid.sum() and 0.2 < valid.mean() < 0.9999
+        if ret:
+            order = np.lexsort(states.T[::-1])
+            assert np.array_equal(out["d_states"].cpu().numpy()[np.lexsort(out["d_states"].cpu().numpy().T[::-1])], states[order])
+        else:
+            assert np.array_equal(out["d_states"].cpu().numpy(), states) and np.array_equal(out["d_edges"].cpu().numpy(), edges)
+            assert np.array_equal(got_valid, valid)
