@@ -228,17 +228,19 @@ def test_full_size_rotation_retraction_robot_order_invariance(irt, orc, helpers)
 
 
 def test_full_size_roadmap_edges_two_lanes_equal_one(irt, orc, helpers):
-    """Config 3 at full size: 100 k valid milestones, their 10-NN edge list (~588 k edges) validated by tr_validate_edges_indexed on two
-    lanes (the default: two halves of the edge list on two streams, pool of 2^24 per-sample slots without point planes) and on one lane
-    (TENDON_HIP_EDGE_LANES=1): verdicts, FK counts and domain-error counts are equal edge for edge, and the oracle's on a sample."""
+    """Config 3 at full size: 100 k valid milestones, their 10-NN edge list (~588 k edges) validated by tr_validate_edges_indexed on the
+    default number of lanes (four at this size: parts of the edge list on as many streams, pool of 2^24 per-sample slots without point
+    planes), on two and on one lane (TENDON_HIP_EDGE_LANES): verdicts, FK counts and domain-error counts are equal edge for edge, and the oracle's on a sample."""
     import os
     W = irt.workloads
     robot = W.robot_config3()
     vox, _ = W.reach_environment(seed=7, n_spheres=64)
     res = {}
-    for lanes in ("1", "2"):
+    for lanes in ("1", "2", "default"):                 # default: by the edge count, four lanes at this size
         old = os.environ.get("TENDON_HIP_EDGE_LANES")
-        os.environ["TENDON_HIP_EDGE_LANES"] = lanes
+        os.environ.pop("TENDON_HIP_EDGE_LANES", None)
+        if lanes != "default":
+            os.environ["TENDON_HIP_EDGE_LANES"] = lanes
         try:
             chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
         finally:
@@ -252,6 +254,7 @@ def test_full_size_roadmap_edges_two_lanes_equal_one(irt, orc, helpers):
     assert len(edges) > 500000
     for k in ("valid", "n_fk", "n_domain_errors"):
         assert np.array_equal(res["1"][k], res["2"][k]) and np.array_equal(res["2"][k], res["2again"][k]) and np.array_equal(res["1"][k], res["1again"][k]), k
+        assert np.array_equal(res["1"][k], res["default"][k]) and np.array_equal(res["1"][k], res["defaultagain"][k]), k
     assert 0.9 < res["2"]["valid"].mean() < 1.0 and res["2"]["n_fk"].max() > 10
     idx = np.random.default_rng(8).choice(len(edges), 3000, replace=False)
     ov, onf, _ = orc.check_motion_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), states[edges[idx, 0]],
