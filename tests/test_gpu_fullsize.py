@@ -260,3 +260,38 @@ def test_full_size_roadmap_edges_two_lanes_equal_one(irt, orc, helpers):
     ov, onf, _ = orc.check_motion_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), states[edges[idx, 0]],
                                         states[edges[idx, 1]], nthreads=0, lib=orc.omp_lib())
     assert np.array_equal(res["2"]["valid"][idx], ov) and np.array_equal(res["2"]["n_fk"][idx][ov], onf[ov])
+
+
+def test_full_size_config4_stays_in_hbm_and_agrees_with_the_host_forms(irt):
+    """Config 4 at full size on one GPU: 2^20 candidates validated with signature output, the ~6 x 10^5 accepted vertices and their rows
+    compacted in HBM, the 10-NN edge list (~3.5 M edges) built there and validated with and without the signature hand-over: the two
+    masks are the same words, and the same as the host-array forms' (tr_knn_edges + tr_validate_edges_indexed on downloaded vertices)."""
+    import torch
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    eng, mv = chk.engine, irt.VoxelBackboneMotionValidator(chk)
+    M, k, seed, S, sw, box = 1 << 20, 11, 3, eng.state_size, eng.signature_words(), D.sampling_box(robot)
+    d_mask = torch.zeros(M // 64, dtype=torch.int64, device="cuda")
+    d_sig = torch.empty((M, sw), dtype=torch.int32, device="cuda")
+    eng.validate_candidates_sig_dev(seed, 0, M, d_mask, d_sig, box=box)
+    d_verts, _ = D.gather_valid_vertices_dev(eng, seed, M, d_mask, box=box)
+    nv = d_verts.shape[0]
+    d_vsig = D.device_row_compactor(eng)(d_mask, M, d_sig)
+    del d_sig
+    assert d_vsig.shape == (nv, sw) and 500000 < nv < 700000
+    d_edges = torch.empty((nv * k, 2), dtype=torch.int32, device="cuda")
+    ne = eng.knn_edges_dev(d_verts, nv, k, d_edges)
+    space = (mv.min_tension_change, mv.min_rotation_change, mv.min_retraction_change)
+    words = {}
+    for name, sig in (("integrated", None), ("handed over", d_vsig)):
+        words[name] = torch.zeros((ne + 63) // 64, dtype=torch.int64, device="cuda")
+        assert eng.validate_edges_indexed_dev(d_verts, nv, d_edges, ne, words[name], None, *space, d_vertex_sig=sig) == 0
+    assert torch.equal(words["integrated"], words["handed over"])
+    verts = d_verts.cpu().numpy()
+    edges = eng.knn_edges(verts, k)
+    assert len(edges) == ne > 3000000 and np.array_equal(d_edges[:ne].cpu().numpy(), edges)
+    host = eng.validate_edges_indexed(verts, edges, *space)
+    got = irt.unpack_bits(words["handed over"].cpu().numpy().view(np.uint64), ne)
+    assert np.array_equal(got, host["valid"]) and 0.98 < got.mean() < 1.0 and host["n_domain_errors"] == 0
