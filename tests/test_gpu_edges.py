@@ -477,3 +477,37 @@ def test_sampler_returns_the_signature_rows_of_its_vertices(irt):
         wn, gn = torch.zeros(ne, dtype=torch.int32, device="cuda"), torch.zeros(ne, dtype=torch.int32, device="cuda")
         assert eng.validate_edges_indexed_dev(st, n_want, d_edges, ne, want, wn) == eng.validate_edges_indexed_dev(st, n_want, d_edges, ne, got_b, gn, d_vertex_sig=sg)
         assert torch.equal(want, got_b) and torch.equal(wn, gn) and ne >= 8192
+
+
+def test_device_resident_entry_points_reject_bad_arguments(irt):
+    """The C entry points added for the device-resident build return the reference's error kinds for null / inconsistent arguments
+    (through the raw ctypes functions: the Python wrappers never pass these)."""
+    import ctypes as C
+    import torch
+    L = irt._lib
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=16)
+    eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+    lib, ctx = eng.lib, eng._ctx
+    sp = L.TrSpaceParams(0.02, 0.01, 0.0001)
+    n64 = C.c_int64(0)
+    d = torch.zeros(4096, dtype=torch.float64, device="cuda")
+    p = C.c_void_p(d.data_ptr())
+    INV, OOR = L.TR_ERR_INVALID_ARG, L.TR_ERR_OUT_OF_RANGE
+    assert lib.tr_knn_edges_dev(ctx, p, 10, 3, 1e300, None, 5, C.byref(n64)) == INV            # capacity without an array
+    assert lib.tr_knn_edges_dev(ctx, p, 10, 3, 1e300, p, 5, None) == INV
+    assert lib.tr_knn_range_dev(ctx, p, 10, 8, 3, 3, 1e300, p) == OOR                           # queries beyond the states
+    assert lib.tr_knn_range_dev(ctx, p, 10, 0, 3, 3, 1e300, None) == INV
+    assert lib.tr_knn_table_edges_dev(ctx, None, 10, 3, p, 30, C.byref(n64)) == INV
+    assert lib.tr_validate_edges_indexed_dev(ctx, C.byref(sp), p, 10, p, 5, None, None, C.byref(n64)) == INV
+    assert lib.tr_validate_edges_indexed_sig_dev(ctx, C.byref(sp), p, 10, None, p, 5, p, None, C.byref(n64)) == INV
+    assert lib.tr_validate_candidates_sig_dev(ctx, 1, 0, 64, None, None, p, None, None, None) == INV
+    assert lib.tr_validate_candidates_sig_dev(ctx, 1, 32, 64, None, None, p, None, p, None) == INV     # first candidate not a multiple of 64
+    assert lib.tr_sample_valid_vertices_sig_dev(ctx, 1, 0, None, None, 8, 0, p, None, None, None, C.byref(n64), C.byref(n64), None) == INV
+    assert lib.tr_signature_words(None) == 0
+    for f in (lib.tr_knn_edges_dev, lib.tr_knn_table_edges_dev):
+        assert f(None, p, 10, 3, *((1e300,) if f is lib.tr_knn_edges_dev else ()), p, 5, C.byref(n64)) == INV
+    # zero sizes are no-ops
+    assert lib.tr_validate_edges_indexed_dev(ctx, C.byref(sp), None, 0, None, 0, None, None, C.byref(n64)) == 0
+    assert lib.tr_knn_range_dev(ctx, p, 10, 4, 0, 3, 1e300, None) == 0
