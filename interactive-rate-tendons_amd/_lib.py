@@ -106,19 +106,21 @@ OBJ_DIR = os.path.join(SRC_DIR, "_obj")
 
 def _units():
     """(object name, source, extra flags): the C ABI + K2..K6, the cache merge, and K1 once per
-    (tendon count, kernel: shared grid / retraction / fused with K2 / verdict-only / verdict-only with retraction) so its
+    (tendon count, kernel: shared grid / retraction / fused with K2 / verdict-only / verdict-only with retraction / edge queue) so its
     instantiations compile in parallel."""
     fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "verdict_kernel.hpp",
                "sweep_kernel.hpp", "sphere_kernel.hpp", "tr_types.hpp"]
-    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip", "sample.hip"]
+    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip", "sample.hip", "edge_queue_kernel.hpp"]
     main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
     u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),
          ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"]),
          ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", HEADER]),
          ("sample.o", "sample.hip", [], ["sample.hip", "sample.hpp", "tr_types.hpp"])]
+    q_deps = fk_deps + ["edge_queue_kernel.hpp", "edge_kernel.hpp"]
     for n in range(1, 9):
-        for kind, tag in ((0, "u"), (1, "r"), (2, "f"), (3, "v"), (4, "w")):
-            u.append(("fk_%s%d.o" % (tag, n), "fk_inst.hip", ["-DTRK_INST_N=%d" % n, "-DTRK_INST_KIND=%d" % kind], fk_deps))
+        for kind, tag in ((0, "u"), (1, "r"), (2, "f"), (3, "v"), (4, "w"), (5, "q")):
+            u.append(("fk_%s%d.o" % (tag, n), "fk_inst.hip", ["-DTRK_INST_N=%d" % n, "-DTRK_INST_KIND=%d" % kind],
+                      q_deps if kind == 5 else fk_deps))
     return u
 
 

@@ -175,6 +175,67 @@ __device__ inline void interpolate_state_dev(const EdgeSpaceK &sk, const double 
   }
 }
 
+// ---- the edge queue (edge_queue_kernel.hpp: fk_edge_queue) --------------------------------------------------------------
+// The bisection without level barriers: the pool is a queue of FK samples in push order.  Persistent waves take samples
+// from its head, integrate them (the verdict-only body with cell signatures), fold the verdicts into their edges, and the wave
+// that folds the LAST outstanding sample of an edge's level runs should_subdivide on that level's signature rows and pushes the
+// edge's next level at the tail.  An edge waits for nothing but its own samples: first_invalid_t is per edge
+// (VoxelEnvironment.cpp:357-398), so the sample set of every edge -- and with it the verdict AND the count of FK calls -- is what
+// the level-synchronous schedule (edge_host.inc) evaluates.
+// Control words (uint32, zeroed by the host; head, tail and done on 128-byte lines of their own).  All three count pool slots from
+// the run's first own slot: [head, tail) waits for a wave (head may run ahead of tail: waves hold tickets for slots not pushed yet),
+// done - first = samples folded so far; done == tail <=> nothing is in flight and nothing can be pushed any more.
+enum { EQ_HEAD = 0, EQ_TAIL = 32, EQ_DONE = 64, EQ_FLAGS = 96, EQ_DOMAIN = 97, EQ_PENDING = 98, EQ_FIRST = 99, EQ_BATCHES = 100, EQ_FINISHED = 101,
+       EQ_CAND = 102,
+       // where the waves' time went, summed over all rounds in ticks of the 100 MHz wall clock (64-bit words; TENDON_HIP_EDGE_TIMING prints them):
+       // claiming a batch (incl. idling), waiting for its records, integrating, the exact sweep, folding + finishing levels + publishing
+       EQ_T_CLAIM = 104, EQ_T_READY = 106, EQ_T_FK = 108, EQ_T_EXACT = 110, EQ_T_FOLD = 112,
+       // ... and inside "folding": release + decrement | acquire + level records | candidates' verdicts | allocation + records | release + publish
+       EQ_T_F0 = 114, EQ_T_F1 = 116, EQ_T_F2 = 118, EQ_T_F3 = 120, EQ_T_F4 = 122, EQ_WORDS = 128 };
+enum { EQF_OVERFLOW = 1u, EQF_STUCK = 2u, EQF_DEEP = 4u };      // pool too small | a wait made no progress | a level of more than 2048 intervals
+constexpr int EQ_MAX_CAND = 4096;        // candidates (two per interval) of one edge level the finishing wave can hold
+
+struct EdgeQueueArgs {
+  uint32_t *ctl;                  // [EQ_WORDS]
+  int32_t slot_hi;                // the run's pool slots end here
+  int32_t P;                      // backbone points = words of a signature row in use
+  EdgeSpaceK sk;
+  const double *A, *B;            // [E][S] end states
+  const double *rel;              // [E] 1 / validSegmentCount
+  uint32_t *edge_ok;              // [E]
+  int32_t *nfk;                   // [E]
+  int32_t *remaining;             // [E] samples of the edge's current level not folded yet
+  int32_t *lvl_base, *lvl_cnt;    // [E] the current level's samples: pool slots [base, base + cnt)
+  EdgeIv *iv;                     // [cap] per pool slot: the interval whose midpoint the sample is
+  double *states;                 // [cap][S] per pool slot: the sample's state
+  int32_t *sample_edge;           // [cap] per pool slot: its edge; -1 until the slot's record is complete (the ready flag)
+  const uint32_t *sig;            // [cap][sig_stride] signature rows (written by the queue's own waves through VerdictArgs::sig)
+  int64_t sig_stride;
+  // the wave's own columns of the point workspace (column = blockIdx.x * 64 + lane, fb_ld >= 64 gridDim.x): a sample whose
+  // self-collision test needs the exact pairwise sweep is integrated again by the wave that found it, with stored points
+  FkOut fb_out; SweepIn fb_in; int64_t fb_ld;
+};
+
+#ifndef TRK_EDGE_DEVICE_ONLY
+// After level 0 (edge_init* / edge_filter<true> / edge_open into per-slot positions): every open interval is a whole edge whose
+// midpoint is pool sample s0 + q; seeds the per-edge level records and the queue's control words.
+__global__ __launch_bounds__(256) void edge_queue_seed(EdgeState st, const EdgeIv *__restrict__ iv /* [slot] */, int64_t s0, int64_t slot_hi,
+                                                       int32_t *__restrict__ remaining, int32_t *__restrict__ lvl_base, int32_t *__restrict__ lvl_cnt,
+                                                       uint32_t *__restrict__ ctl) {
+  const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t m = st.counters[EC_OPEN];
+  const bool fits = s0 + m <= slot_hi;
+  if (q == 0) {
+    ctl[EQ_HEAD] = (uint32_t)s0; ctl[EQ_DONE] = (uint32_t)s0; ctl[EQ_FIRST] = (uint32_t)s0;
+    ctl[EQ_TAIL] = (uint32_t)(fits ? s0 + m : s0);
+    if (!fits) ctl[EQ_FLAGS] = EQF_OVERFLOW;
+  }
+  if (q >= m || !fits) return;
+  const int32_t e = iv[s0 + q].e;
+  remaining[e] = 1; lvl_base[e] = (int32_t)(s0 + q); lvl_cnt[e] = 1;
+  st.nfk[e] += 1;
+}
+
 // level 0: both end states of every edge become pool samples 2k, 2k + 1
 __global__ __launch_bounds__(256) void edge_init(EdgeState st, EdgeSpaceK sk, int64_t E, double *__restrict__ lvl_states) {
 #pragma clang fp contract(off)
@@ -434,5 +495,7 @@ __global__ __launch_bounds__(256) void discrete_finish(EdgeState st, const uint3
   const double t = ok ? 1.0 : (fb <= 1 ? 0.0 : (double)(fb - 1) / (double)nd[e]);
   st.last_t[e] = (unsigned long long)__double_as_longlong(t);
 }
+
+#endif  // TRK_EDGE_DEVICE_ONLY
 
 }  // namespace trk

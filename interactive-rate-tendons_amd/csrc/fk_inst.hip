@@ -1,5 +1,5 @@
 // fk_inst.hip -- one K1 instantiation set per object file: compiled once per tendon count and
-// kernel with -DTRK_INST_N=<1..8> -DTRK_INST_KIND=<0 uniform | 1 retract | 2 fused with K2 | 3 verdict-only | 4 verdict-only, retraction>
+// kernel with -DTRK_INST_N=<1..8> -DTRK_INST_KIND=<0 uniform | 1 retract | 2 fused with K2 | 3 verdict-only | 4 verdict-only, retraction | 5 edge queue>
 // (see _lib.py: build()).
 #include "fk_launch.hpp"
 #include "fk_kernel.hpp"
@@ -13,11 +13,30 @@
 #define TRK_WITH_RETRACT_VERDICT
 #include "fk_retract_kernel.hpp"
 #include "verdict_kernel.hpp"
+#elif TRK_INST_KIND == 5
+#include "edge_queue_kernel.hpp"
 #endif
 
 namespace trk {
 
-#if TRK_INST_KIND == 4
+#if TRK_INST_KIND == 5
+template <> void launch_fk_edge_queue<TRK_INST_N>(const FkLaunch &a, const VerdictArgs *va, size_t lds, const EdgeQueueArgs *qa,
+                                                  const FusedSweepArgs *sweep, unsigned waves) {
+  if (a.rotation)
+    hipLaunchKernelGGL((fk_edge_queue<TRK_INST_N, true>), dim3(waves), dim3(64), lds, a.stream, a.K, a.d_tab, a.d_steps, a.n_steps, va, qa, sweep);
+  else
+    hipLaunchKernelGGL((fk_edge_queue<TRK_INST_N, false>), dim3(waves), dim3(64), lds, a.stream, a.K, a.d_tab, a.d_steps, a.n_steps, va, qa, sweep);
+}
+template <> int fk_edge_queue_waves_per_cu<TRK_INST_N>(bool rotation, size_t lds) {
+  int nb = 0;
+  const hipError_t e = rotation ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fk_edge_queue<TRK_INST_N, true>, 64, lds)
+                                : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fk_edge_queue<TRK_INST_N, false>, 64, lds);
+  return e == hipSuccess ? nb : 0;
+}
+#endif
+
+#if TRK_INST_KIND == 5
+#elif TRK_INST_KIND == 4
 template <bool ROT, bool SPH, bool SIG>
 static void go(const FkLaunch &a, const VerdictArgs *va, size_t lds) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);

@@ -486,14 +486,14 @@ __device__ __forceinline__ bool milestones_unresolved(const float *__restrict__ 
 // cleared falls back to pass 3, the exact pairwise sweep -- rare (tight curls only).
 //   debug bit0: brute-force pairs in pass 3;  bit1: skip pass 2 (every lane takes pass 3);
 //         bit2: disable the dilated-grid fast path of the voxel walk.
-// out_map (optional): see the end of the function.
+// out_map (optional): see the end of the function.  lane_valid (optional): the lane's verdict is returned there instead of written.
 // TIPROWS (retraction robots, in.n_points set): K1r stores a lane's point j in row j + (P - n_points), i.e. rows
 // are aligned at the tip like K1r's iterations, so that its stores -- and the loads here -- stay coalesced.
 template <bool TIPROWS>
 __device__ __forceinline__ void sweep_body(
     const SweepIn &in, int64_t n, int64_t ld, int P, int CH, int NM, const RobotK &K, const GridK &g, const uint64_t *__restrict__ grid,
     const uint64_t *__restrict__ near_grid, int check_voxels, uint32_t debug, uint64_t *__restrict__ valid_bits,
-    uint8_t *__restrict__ flags, const int32_t *__restrict__ out_map = nullptr) {
+    uint8_t *__restrict__ flags, const int32_t *__restrict__ out_map = nullptr, bool *lane_valid = nullptr) {
 #pragma clang fp contract(off)
   extern __shared__ float lds[];
   const int lane = threadIdx.x;
@@ -697,6 +697,7 @@ __device__ __forceinline__ void sweep_body(
     if (passed) fl |= 8u; else valid = false;
   }
 
+  if (lane_valid) { *lane_valid = valid && live; return; }   // the caller folds the verdict itself (edge_queue_kernel.hpp): nothing is written
   if (out_map) {
     // compacted list (the fallback pass of the verdict path): column i is configuration out_map[i]; its verdict bit is
     // still 0 in the mask, its flags are overwritten

@@ -86,6 +86,10 @@ struct EdgeDev {
   // second copies of a level's intervals and states: a retraction robot's stored-point levels are re-dealt in the order of their
   // backbone lengths (edge_level_gather)
   trk::EdgeIv *open2 = nullptr; double *lvl_states2 = nullptr;
+  // the edge queue (edge_queue_kernel.hpp): per-edge level records [cap/2 + 1], control words, the arguments' device copy and pinned image
+  int32_t *q_remaining = nullptr, *q_lvl_base = nullptr, *q_lvl_cnt = nullptr;
+  uint32_t *q_ctl = nullptr, *q_hctl = nullptr;
+  trk::EdgeQueueArgs *q_args = nullptr, *q_hargs = nullptr;
   // indexed forms: the roadmap's vertex states and the edges' index pairs (grow-only)
   double *ix_states = nullptr; int64_t ix_states_cap = 0;
   int32_t *ix_idx = nullptr; int64_t ix_idx_cap = 0;
@@ -148,6 +152,12 @@ struct tr_ctx {
   int edge_lanes = kMaxLanes;                     // TENDON_HIP_EDGE_LANES=1 .. 4: exactly that many lanes (1: one lane only); default: by the edge count
   bool edge_lanes_fixed = false;
   bool edge_kernels_loaded = false;               // tr_reserve_edges has launched every kernel of the indexed edge path once
+  // The indexed edge check as ONE persistent launch over a device work queue (edge_queue_kernel.hpp) instead of level-synchronous
+  // launches on lanes: the default where it applies (backbone checker, no retraction, verdict-only schedule); TENDON_HIP_EDGE_QUEUE=0
+  // keeps the lanes (A/B, tests).  edge_queue_waves: workgroups of that launch (0 = what the device holds at once)
+  bool edge_queue = true;
+  int edge_queue_waves = 0;
+  uint32_t edge_queue_last[4] = {0, 0, 0, 0};     // the last queue run: samples, rounds (wave batches), samples through the exact sweep, flags
   double edge_rate_seen = 0.0;                    // own samples per edge of this context's last indexed edge call (0 = none yet): sizes
                                                   // the next call's chunks and lanes (a rotating robot's edges take ~10, not ~4)
   bool edge_lane_guess_forced = false;            // TENDON_HIP_EDGE_LANE_GUESS was given: it overrides the rate this context has seen
@@ -684,6 +694,83 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
   return TR_OK;
 }
 
+// The edge queue's launch (edge_queue_kernel.hpp: fk_edge_queue): the verdict-only body's arguments as launch_verdict forms them
+// (backbone checker, signature rows into `sig`), the in-wave fallback's sweep arguments over the waves' own workspace columns, and
+// `waves` persistent workgroups.  qa: the queue's arguments, already on the device.  The workspace must hold 64 x waves columns.
+int launch_edge_queue(tr_ctx *ctx, hipStream_t s, uint32_t *sig, int64_t sig_stride, const trk::EdgeQueueArgs *qa, unsigned waves) {
+  if (!ctx->has_grid) return fail(ctx, TR_ERR_INVALID_ARG, "no obstacle grid set (tr_set_grid)");
+  Workspace &w = ctx->ws;
+  if (w.ld < (int64_t)waves * 64) return fail(ctx, TR_ERR_RUNTIME, "edge queue: workspace smaller than the launch");
+  tr_ctx::VerdictRing &vr = ctx->vring;
+  if (!vr.d_slots) {
+    HIP_TRY(ctx, hipMalloc((void **)&vr.d_slots, sizeof(trk::VerdictArgs) * tr_ctx::VerdictRing::kSlots));
+    HIP_TRY(ctx, hipHostMalloc((void **)&vr.h_slots, sizeof(trk::VerdictArgs) * tr_ctx::VerdictRing::kSlots, hipHostMallocDefault));
+    for (auto &e : vr.ev) HIP_TRY(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+  }
+  const int vslot = vr.next;
+  vr.next = (vr.next + 1) % tr_ctx::VerdictRing::kSlots;
+  if (vr.used[vslot]) HIP_TRY(ctx, hipEventSynchronize(vr.ev[vslot]));
+  trk::VerdictArgs &a = vr.h_slots[vslot];
+  a = trk::VerdictArgs{};
+  size_t lds_k2;
+  sweep_geometry(ctx, a.CH, a.NM, lds_k2);
+  a.P = ctx->K.n_points; a.debug = ctx->debug;
+  a.g = ctx->G; a.grid = ctx->d_grid; a.near_grid = ctx->d_near;
+  {
+    const GridK &g = ctx->G;            // sweep_body's margin box, same expressions (this file is compiled without contraction)
+    a.box[0] = g.xmin + 1e-6 * (g.xmax - g.xmin); a.box[1] = g.xmax - 1e-6 * (g.xmax - g.xmin);
+    a.box[2] = g.ymin + 1e-6 * (g.ymax - g.ymin); a.box[3] = g.ymax - 1e-6 * (g.ymax - g.ymin);
+    a.box[4] = g.zmin + 1e-6 * (g.zmax - g.zmin); a.box[5] = g.zmax - 1e-6 * (g.zmax - g.zmin);
+  }
+  a.sig = sig; a.sig_stride = sig_stride;
+  a.radius = ctx->K.radius;
+  for (int j = 0; j < TRK_MAX_TENDONS; j++) { a.home_Li[j] = ctx->K.home_Li[j]; a.min_len[j] = ctx->K.min_len[j]; a.max_len[j] = ctx->K.max_len[j]; }
+  a.finish_hot();
+  HIP_TRY(ctx, hipMemcpyAsync(vr.d_slots + vslot, &a, sizeof(a), hipMemcpyHostToDevice, s));
+  int rc;
+  trk::SweepIn in{w.px, w.py, w.pz, nullptr, w.Li, w.conv, nullptr, w.acc};
+  const trk::FusedSweepArgs *d_fargs; size_t lds_f; int fslot;
+  if ((rc = fused_args_slot(ctx, in, 1, nullptr, nullptr, s, &d_fargs, &lds_f, &fslot))) return rc;
+  const size_t lds_v = std::max(trk::verdict_lds_bytes(a.NM, true), lds_f);
+  const trk::FkOut none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  const trk::FkLaunch fl{nullptr, 0, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
+                         (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, none, s};
+  {
+    ProfScope ps(ctx, 5, s);
+    switch (ctx->K.n_tendons) {
+#define TRK_CASE(N) case N: trk::launch_fk_edge_queue<N>(fl, vr.d_slots + vslot, lds_v, qa, d_fargs, waves); break;
+      TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
+#undef TRK_CASE
+      default: return fail(ctx, TR_ERR_OUT_OF_RANGE, "n_tendons out of range");
+    }
+    HIP_TRY(ctx, hipGetLastError());
+  }
+  HIP_TRY(ctx, hipEventRecord(vr.ev[vslot], s));
+  vr.used[vslot] = true;
+  HIP_TRY(ctx, hipEventRecord(ctx->fused.ev[fslot], s));
+  ctx->fused.used[fslot] = true;
+  return TR_OK;
+}
+
+// persistent workgroups of the edge queue's launch: what the device holds at once (occupancy x CUs)
+int edge_queue_waves(tr_ctx *ctx) {
+  if (ctx->edge_queue_waves > 0) return ctx->edge_queue_waves;
+  int CH, NM; size_t lds_k2;
+  sweep_geometry(ctx, CH, NM, lds_k2);
+  const size_t lds_v = std::max(trk::verdict_lds_bytes(NM, true), lds_k2);
+  int per_cu = 0;
+  switch (ctx->K.n_tendons) {
+#define TRK_CASE(N) case N: per_cu = trk::fk_edge_queue_waves_per_cu<N>((bool)ctx->K.enable_rotation, lds_v); break;
+    TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
+#undef TRK_CASE
+    default: break;
+  }
+  hipDeviceProp_t prop;
+  if (per_cu <= 0 || hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return 0;
+  ctx->edge_queue_waves = per_cu * prop.multiProcessorCount;
+  return ctx->edge_queue_waves;
+}
+
 // Distance from every cell centre to the nearest occupied cell centre, exact within the window that matters
 // (r + a cell diagonal), TRK_EDT_FAR beyond: three separable min-plus passes (x on the bit grid, then y, z).
 int ensure_sphere_near(tr_ctx *c, hipStream_t s) {
@@ -781,6 +868,8 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (const char *e = std::getenv("TENDON_HIP_RETRACT_SORT")) c->retract_sort_min = std::atoll(e);
   if (std::getenv("TENDON_HIP_RETRACT_KBEGIN_OFF")) c->retract_wave_start = false;
   if (const char *e = std::getenv("TENDON_HIP_EDGE_LANES")) { c->edge_lanes = std::max(1, std::min(tr_ctx::kMaxLanes, std::atoi(e))); c->edge_lanes_fixed = true; }
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_QUEUE")) c->edge_queue = std::atoi(e) != 0;
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_QUEUE_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) c->edge_queue_waves = v; }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_LANE_GUESS")) { const double v = std::atof(e); if (v >= 0.5 && v <= 64.0) { c->edge_lane_guess = v; c->edge_lane_guess_forced = true; } }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path
     const long long v = std::atoll(e);
@@ -907,7 +996,7 @@ void tr_destroy(tr_ctx *c) {
                   c->d_vbits, w.px, w.py, w.pz, w.acc, w.Li, w.conv,
                   w.states, w.bits, w.tips, w.flags, w.L, w.npts,
                   c->edge.lvl_states, c->edge.bits, c->edge.sample_edge, c->edge.sample_t, c->edge.open, c->edge.frontier,
-                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->edge.sig, c->edge.sig_np, c->edge.ix_states, c->edge.ix_idx, c->edge.open2, c->edge.lvl_states2, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
+                  c->edge.A, c->edge.B, c->edge.rel, c->edge.edge_ok, c->edge.nfk, c->edge.first_inv, c->edge.last_t, c->edge.counters, c->edge.nd, c->edge.cnt, c->edge.sig, c->edge.sig_np, c->edge.ix_states, c->edge.ix_idx, c->edge.open2, c->edge.lvl_states2, c->edge.q_remaining, c->edge.q_lvl_base, c->edge.q_lvl_cnt, c->edge.q_ctl, c->edge.q_args, c->d_envw[0], c->d_envw[1], c->d_sph_near, c->d_sph_tmp};
   for (void *p : ptrs) if (p) (void)hipFree(p);
   trk::merge_free(c->merge);
   if (c->fused.d_slots) { (void)hipFree(c->fused.d_slots); (void)hipHostFree(c->fused.h_slots); for (auto &e : c->fused.ev) (void)hipEventDestroy(e); }
@@ -931,6 +1020,8 @@ void tr_destroy(tr_ctx *c) {
     if (c->d_edge_counters1[q]) (void)hipFree(c->d_edge_counters1[q]);
   }
   for (int q = 0; q < tr_ctx::kMaxLanes; q++) { if (c->edge_stream[q]) (void)hipStreamDestroy(c->edge_stream[q]); if (c->edge_hc[q]) (void)hipHostFree(c->edge_hc[q]); }
+  if (c->edge.q_hctl) (void)hipHostFree(c->edge.q_hctl);
+  if (c->edge.q_hargs) (void)hipHostFree(c->edge.q_hargs);
   if (c->h_stage) (void)hipHostFree(c->h_stage);
   for (auto &ro : c->ro) {
     for (int q = 0; q < 2; q++) { if (ro.keys[q]) (void)hipFree(ro.keys[q]); if (ro.vals[q]) (void)hipFree(ro.vals[q]); }

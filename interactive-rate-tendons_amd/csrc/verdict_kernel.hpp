@@ -127,10 +127,16 @@ struct PointSweep {
   // retraction kernel (a permuted batch, the first two points in rows of the lane's own); the shared-grid kernel forms them
   // from sig_n on the fly
   int sig_row_of, sig_first_row;
-  int64_t sig_n;                  // wave-uniform: configurations of the launch (shared-grid kernel)
+  int sig_row0, sig_cnt;          // wave-uniform (shared-grid kernels): lane l < sig_cnt writes signature row sig_row0 + l -- the wave's 64
+                                  // configurations of a launch, or the pool slots a wave of the edge queue has claimed (edge_queue_kernel.hpp)
   bool active;                    // live && converged: only these lanes test voxels
 
-  __device__ __forceinline__ int sig_own_row() const { const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x; return i < sig_n ? (int)i : -1; }
+  __device__ __forceinline__ int sig_own_row() const { const int l = (int)threadIdx.x; return l < sig_cnt ? sig_row0 + l : -1; }
+  // the rows of the wave's 64 lanes in a launch over n configurations, one lane each
+  __device__ __forceinline__ void sig_rows_of_launch(int64_t n) {
+    const int64_t r0 = (int64_t)blockIdx.x * 64, left = n - r0;
+    sig_row0 = (int)r0; sig_cnt = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
+  }
   __device__ __forceinline__ void sig_put(const VerdictArgs &a, int row, bool on, uint32_t value, int row_of, int first_row) {
     const int base = VL_MS + 4 * NM * 64;
     sigst.put([base](int i) -> uint32_t & { return VL_U(base + i); }, a.sig, a.sig_stride, row_of, first_row, row, on, value);
@@ -507,56 +513,13 @@ struct PointSweep {
   }
 };
 
-// Waves per SIMD: K1 with stored points holds two up to 6 tendons (tr_types.hpp); with the sweep in the loop the spills at that
-// budget cost more than the second wave hides from 5 tendons on (measured, profiles/r02/verdict_widths_v1.txt, ms per 2^18
-// configurations, two waves | one: N=4 3.11 | 3.13, N=5 4.01 | 3.52, N=6 5.11 | 4.02; N=7 5.96 | 4.61, N=8 7.08 | 4.92).
-#ifndef TRK_VERDICT_TWO_WAVE_MAXN
-#define TRK_VERDICT_TWO_WAVE_MAXN 4
-#endif
-template <int N, bool ROT, bool SPH, bool SIG = false>
-__global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
-    const double *__restrict__ states, int64_t n, RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps,
-    int nsteps, double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
+// What a lane of the shared-grid verdict kernels concludes when its integration and the per-point sweep have ended (what sweep_body
+// does after its pass 1; comparisons and one subtraction: nothing here can contract).  pending: only the exact pairwise
+// self-collision sweep can decide the configuration (its bit is then left 0 and the fallback pass ORs it in).
+struct LaneVerdict { bool valid, pending; uint32_t fl; };
+template <int N, bool SPH>
+__device__ __forceinline__ LaneVerdict verdict_decide(const VerdictArgs &a, const FkLane<N> &fl_, bool live) {
   const int lane = threadIdx.x;
-  PointSweep<SPH, SIG> ps;
-  ps.va = va;
-  ps.dn_prev = 0.0f; ps.sph_state = 0u;
-  ps.qhead = 0; ps.qcount = 0; ps.active = false;
-  ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
-  VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
-  {
-    const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
-    ps.sigst.init(); ps.sig_row_of = -1; ps.sig_first_row = 0; ps.sig_n = n;
-  }
-  __syncthreads();
-
-  FkLane<N> fl_;
-  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  fk_uniform_body<N, ROT, false, false>(states, n, 0, K, tab, steps, nsteps, out, ps, nullptr, &fl_);
-
-  // ---- what sweep_body does after its pass 1 (comparisons and one subtraction: nothing here can contract) ----
-  ps.template sig_finish<false>();
-  ps.finish();
-  while (ps.qcount > 0) ps.flush();
-  __syncthreads();
-  if (tips) {
-    // the wave's 64 tips are 1 536 contiguous bytes: through LDS (the previous-point slots, free now) so that each of the
-    // three store instructions writes 512 contiguous bytes -- lane by lane (x, y, z at a stride of 24 bytes) every
-    // instruction touched every 32-byte sector of the block and the block was written three times over (measured: 70 B per
-    // check against the 24 the tips are)
-    VL_D(lane) = fl_.tip[0]; VL_D(64 + lane) = fl_.tip[1]; VL_D(128 + lane) = fl_.tip[2];
-    __syncthreads();
-    const int64_t e0 = (int64_t)blockIdx.x * 192, etot = 3 * n;
-#pragma unroll
-    for (int q = 0; q < 3; q++) {
-      const int e = q * 64 + lane;                 // element e of the block = coordinate e % 3 of configuration e / 3
-      if (e0 + e < etot) tips[e0 + e] = VL_D((e % 3) * 64 + e / 3);
-    }
-    __syncthreads();
-  }
-  const VerdictArgs a = *va;
-  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
-  const bool live = i < n;
   const int P = a.P;
   const int Kl = (P - 1 + a.CH - 1) / a.CH;
   const bool conv_ok = live && fl_.converged;
@@ -595,6 +558,62 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
   }
   if (pending) valid = false;                                 // its bit is ORed in by fk_sweep_fused_list
   if (SPH && pending && !hit) fl |= 8u;                       // ... which takes the sphere test's answer from this bit (sweep_body, check_voxels == 2)
+  return LaneVerdict{valid, pending, fl};
+}
+
+// Waves per SIMD: K1 with stored points holds two up to 6 tendons (tr_types.hpp); with the sweep in the loop the spills at that
+// budget cost more than the second wave hides from 5 tendons on (measured, profiles/r02/verdict_widths_v1.txt, ms per 2^18
+// configurations, two waves | one: N=4 3.11 | 3.13, N=5 4.01 | 3.52, N=6 5.11 | 4.02; N=7 5.96 | 4.61, N=8 7.08 | 4.92).
+#ifndef TRK_VERDICT_TWO_WAVE_MAXN
+#define TRK_VERDICT_TWO_WAVE_MAXN 4
+#endif
+template <int N, bool ROT, bool SPH, bool SIG = false>
+__global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
+    const double *__restrict__ states, int64_t n, RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps,
+    int nsteps, double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
+  const int lane = threadIdx.x;
+  PointSweep<SPH, SIG> ps;
+  ps.va = va;
+  ps.dn_prev = 0.0f; ps.sph_state = 0u;
+  ps.qhead = 0; ps.qcount = 0; ps.active = false;
+  ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
+  VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
+  {
+    const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
+    ps.sigst.init(); ps.sig_row_of = -1; ps.sig_first_row = 0; ps.sig_rows_of_launch(n);
+  }
+  __syncthreads();
+
+  FkLane<N> fl_;
+  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  fk_uniform_body<N, ROT, false, false>(states, n, 0, K, tab, steps, nsteps, out, ps, nullptr, &fl_);
+
+  // ---- what sweep_body does after its pass 1 (comparisons and one subtraction: nothing here can contract) ----
+  ps.template sig_finish<false>();
+  ps.finish();
+  while (ps.qcount > 0) ps.flush();
+  __syncthreads();
+  if (tips) {
+    // the wave's 64 tips are 1 536 contiguous bytes: through LDS (the previous-point slots, free now) so that each of the
+    // three store instructions writes 512 contiguous bytes -- lane by lane (x, y, z at a stride of 24 bytes) every
+    // instruction touched every 32-byte sector of the block and the block was written three times over (measured: 70 B per
+    // check against the 24 the tips are)
+    VL_D(lane) = fl_.tip[0]; VL_D(64 + lane) = fl_.tip[1]; VL_D(128 + lane) = fl_.tip[2];
+    __syncthreads();
+    const int64_t e0 = (int64_t)blockIdx.x * 192, etot = 3 * n;
+#pragma unroll
+    for (int q = 0; q < 3; q++) {
+      const int e = q * 64 + lane;                 // element e of the block = coordinate e % 3 of configuration e / 3
+      if (e0 + e < etot) tips[e0 + e] = VL_D((e % 3) * 64 + e / 3);
+    }
+    __syncthreads();
+  }
+  const VerdictArgs a = *va;
+  const int64_t i = (int64_t)blockIdx.x * 64 + lane;
+  const bool live = i < n;
+  const LaneVerdict lv = verdict_decide<N, SPH>(a, fl_, live);
+  const bool valid = lv.valid, pending = lv.pending;
+  const uint32_t fl = lv.fl;
   const uint64_t bits = __ballot(valid && live);
   if (lane == 0 && live) a.valid_bits[i >> 6] = bits;
   if (a.flags && live) a.flags[i] = (uint8_t)fl;
@@ -640,7 +659,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
   const int32_t *__restrict__ perm = va->perm;
   {
     const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
-    ps.sigst.init(); ps.sig_row_of = i0 < n ? (perm ? perm[i0] : (int)i0) : -1; ps.sig_first_row = 0; ps.sig_n = n;
+    ps.sigst.init(); ps.sig_row_of = i0 < n ? (perm ? perm[i0] : (int)i0) : -1; ps.sig_first_row = 0; ps.sig_row0 = 0; ps.sig_cnt = 0;
   }
   VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
   __syncthreads();
