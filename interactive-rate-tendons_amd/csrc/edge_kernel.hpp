@@ -182,16 +182,22 @@ __device__ inline void interpolate_state_dev(const EdgeSpaceK &sk, const double 
 // edge's next level at the tail.  An edge waits for nothing but its own samples: first_invalid_t is per edge
 // (VoxelEnvironment.cpp:357-398), so the sample set of every edge -- and with it the verdict AND the count of FK calls -- is what
 // the level-synchronous schedule (edge_host.inc) evaluates.
-// Control words (uint32, zeroed by the host; head, tail and done on 128-byte lines of their own).  All three count pool slots from
-// the run's first own slot: [head, tail) waits for a wave (head may run ahead of tail: waves hold tickets for slots not pushed yet),
-// done - first = samples folded so far; done == tail <=> nothing is in flight and nothing can be pushed any more.
+// The queue is the pool in push order: slots [first, tail), the edges' first midpoints seeded before the launch in the order of
+// the edge list (neighbouring edges share end vertices: their rows stay close in memory; ordering the seeds by edge length, longest
+// first, was measured -- it shortens the tail and costs more than that in scattered row reads), then everything the waves push.  EQ_AVAIL counts the published samples nobody has taken yet (a
+// semaphore: a wave subtracts what it wants and gives back what was not there), EQ_HEAD hands out their positions.  The launch
+// ends when done == tail: `done` counts folded samples from `first`, and it is read BEFORE `tail`, so equality means that nothing
+// was in flight at that moment.
+// Control words (uint32, zeroed by the host; the hot ones on 128-byte lines of their own).
 enum { EQ_HEAD = 0, EQ_TAIL = 32, EQ_DONE = 64, EQ_FLAGS = 96, EQ_DOMAIN = 97, EQ_PENDING = 98, EQ_FIRST = 99, EQ_BATCHES = 100, EQ_FINISHED = 101,
        EQ_CAND = 102,
        // where the waves' time went, summed over all rounds in ticks of the 100 MHz wall clock (64-bit words; TENDON_HIP_EDGE_TIMING prints them):
        // claiming a batch (incl. idling), waiting for its records, integrating, the exact sweep, folding + finishing levels + publishing
        EQ_T_CLAIM = 104, EQ_T_READY = 106, EQ_T_FK = 108, EQ_T_EXACT = 110, EQ_T_FOLD = 112,
        // ... and inside "folding": release + decrement | acquire + level records | candidates' verdicts | allocation + records | release + publish
-       EQ_T_F0 = 114, EQ_T_F1 = 116, EQ_T_F2 = 118, EQ_T_F3 = 120, EQ_T_F4 = 122, EQ_WORDS = 128 };
+       EQ_T_F0 = 114, EQ_T_F1 = 116, EQ_T_F2 = 118, EQ_T_F3 = 120, EQ_T_F4 = 122,
+       EQ_SIZES = 124,              // rounds of 64 | 32..63 | 2..31 | 1 samples
+       EQ_AVAIL = 128, EQ_WORDS = 160 };
 enum { EQF_OVERFLOW = 1u, EQF_STUCK = 2u, EQF_DEEP = 4u };      // pool too small | a wait made no progress | a level of more than 2048 intervals
 constexpr int EQ_MAX_CAND = 4096;        // candidates (two per interval) of one edge level the finishing wave can hold
 
@@ -217,8 +223,8 @@ struct EdgeQueueArgs {
 };
 
 #ifndef TRK_EDGE_DEVICE_ONLY
-// After level 0 (edge_init* / edge_filter<true> / edge_open into per-slot positions): every open interval is a whole edge whose
-// midpoint is pool sample s0 + q; seeds the per-edge level records and the queue's control words.
+// After level 0 (edge_init* / edge_filter<true> / edge_open into per-slot positions): every open interval is a
+// whole edge whose midpoint is pool sample s0 + q; seeds the per-edge level records and the queue's control words.
 __global__ __launch_bounds__(256) void edge_queue_seed(EdgeState st, const EdgeIv *__restrict__ iv /* [slot] */, int64_t s0, int64_t slot_hi,
                                                        int32_t *__restrict__ remaining, int32_t *__restrict__ lvl_base, int32_t *__restrict__ lvl_cnt,
                                                        uint32_t *__restrict__ ctl) {
@@ -226,8 +232,8 @@ __global__ __launch_bounds__(256) void edge_queue_seed(EdgeState st, const EdgeI
   const int64_t m = st.counters[EC_OPEN];
   const bool fits = s0 + m <= slot_hi;
   if (q == 0) {
-    ctl[EQ_HEAD] = (uint32_t)s0; ctl[EQ_DONE] = (uint32_t)s0; ctl[EQ_FIRST] = (uint32_t)s0;
-    ctl[EQ_TAIL] = (uint32_t)(fits ? s0 + m : s0);
+    ctl[EQ_FIRST] = (uint32_t)s0; ctl[EQ_DONE] = (uint32_t)s0; ctl[EQ_HEAD] = (uint32_t)s0;
+    ctl[EQ_TAIL] = (uint32_t)(fits ? s0 + m : s0); ctl[EQ_AVAIL] = (uint32_t)(fits ? m : 0);
     if (!fits) ctl[EQ_FLAGS] = EQF_OVERFLOW;
   }
   if (q >= m || !fits) return;

@@ -4,19 +4,21 @@
 // one per level of all edges (edge_kernel.hpp: "the edge queue" states the scheme and why the results are those of the
 // level-synchronous schedule).
 //
-// A wave's round: take up to 64 pool slots at the queue's head -> integrate their states with the verdict-only body and its
-// per-point sweep (verdict_kernel.hpp: fk_uniform_body + PointSweep<.., SIG>, the signature rows go to the slots' rows) -> fold
-// the verdicts into the edges -> for every edge whose level this wave completed: should_subdivide on both halves of the level's
-// intervals (signatures_differ, the whole wave on one pair of rows), the survivors become the edge's next level at the queue's
-// tail -> publish -> count the round's samples as done.
+// A wave's round: take up to 64 pool slots at the queue's head (push order: shallow levels first -- the samples with the longest
+// chains of levels still ahead of them; taking pushed samples before the seeds was measured: 10 % longer) -> integrate their
+// states with the verdict-only body and its per-point sweep (verdict_kernel.hpp: fk_uniform_body + PointSweep<.., SIG>, the
+// signature rows go to the slots' rows) -> fold the verdicts into the edges -> for every edge whose level this wave completed:
+// should_subdivide on both halves of the level's intervals, one candidate per lane (signatures_differ_lane), the survivors
+// become the edge's next level at the queue's tail -> publish -> count the round's samples as done.
 //
 // Hand-offs between waves (MI355X: per-XCD L2s, a CU's vector L1 is never refreshed by another CU's stores): every record a wave
 // leaves for others -- signature rows, edge_ok, the level records, the pushed slots' intervals and states -- is written with plain
 // stores, then `s_waitcnt vmcnt(0)` -> agent-scope release fence -> `s_waitcnt vmcnt(0)` -> the agent-scope atomic that
 // hands it over (the edge's `remaining` counter, the slot's ready flag); the wave that receives it -- its decrement returned 1, its
 // poll of the ready flag matched -- runs an agent-scope acquire fence and `s_waitcnt vmcnt(0)` before its first load.
-// No wave ever waits for a wave that has not started: a wave holds a ticket for slots, waits only while slots it holds are being
-// written by a wave inside its push, and leaves when done == tail.  Every wait is bounded (EQF_STUCK ends the launch).
+// No wave ever waits for a wave that has not started: a wave takes only samples that are published (the semaphore) or seeded, waits
+// only while a slot it has taken is being written by a wave inside its push, and leaves when done == tail.  Every wait is
+// bounded (EQF_STUCK ends the launch).
 #pragma once
 #include "verdict_kernel.hpp"
 #define TRK_EDGE_DEVICE_ONLY
@@ -48,80 +50,90 @@ struct EqClock {
 };
 
 // LDS scratch of the finishing stage: the head of the wave's image (state of the per-point sweep, dead between two
-// integrations): the survivors' mask (one bit per candidate of a group), then per owner lane: its first candidate, edge, level base,
+// integrations): the survivors' masks (two words per 64 intervals of a group: proximal, distal), then per owner lane: its first interval, edge, level base,
 // survivor count, domain flag, the new level's first slot and fill count, 1 / validSegmentCount
-constexpr int EQ_GROUP_CAND = 2 * EQ_MAX_CAND;                 // candidates of one group of finished levels
+constexpr int EQ_GROUP_IV = EQ_MAX_CAND;                       // intervals (two candidates each) of one group of finished levels
 #define EQ_MASK(i) (((unsigned long long *)vlds)[(i)])
 #define EQ_I(i) (((int32_t *)vlds)[(i)])
 #define EQ_U(i) (((uint32_t *)vlds)[(i)])
-constexpr int EQ_PRE = EQ_GROUP_CAND / 32, EQ_EOF = EQ_PRE + 64, EQ_BASEOF = EQ_EOF + 64, EQ_CNT = EQ_BASEOF + 64, EQ_DOM = EQ_CNT + 64,
+constexpr int EQ_PRE = 2 * EQ_GROUP_IV / 32, EQ_EOF = EQ_PRE + 64, EQ_BASEOF = EQ_EOF + 64, EQ_CNT = EQ_BASEOF + 64, EQ_DOM = EQ_CNT + 64,
               EQ_NBASE = EQ_DOM + 64, EQ_FILL = EQ_NBASE + 64, EQ_RELW = EQ_FILL + 64;     // (word offsets)
 #define EQ_REL(i) (((double *)vlds)[EQ_RELW / 2 + (i)])
 
-// signatures_differ (edge_kernel.hpp) by ONE lane: the lane's own pair of rows from the tip down, four points per 16-byte load,
-// 24 loads in flight; the first event in tip-first order decides, a domain error at a point before a difference at that point
-__device__ __forceinline__ int signatures_differ_lane(const uint32_t *__restrict__ ra, const uint32_t *__restrict__ rb, int P) {
-  constexpr int U = 12;                 // 24 loads in flight per lane: a 129-point row in three rounds of the memory latency (4: nine)
-  for (int k = (P - 1) >> 2; k >= 0; k -= U) {
-    uint4 va[U], vb[U];
+// signatures_differ (edge_kernel.hpp) for BOTH halves of one interval by ONE lane: the rows of the interval's ends (ra, rb) and of its
+// midpoint (rm) from the tip down, four points per 16-byte load, 18 loads in flight; for each half the first event in tip-first
+// order decides, a domain error at a point before a difference at that point.  fp: proximal half (ra, rm), fd: distal half (rm, rb).
+__device__ __forceinline__ void signatures_differ_lane2(const uint32_t *__restrict__ ra, const uint32_t *__restrict__ rm,
+                                                        const uint32_t *__restrict__ rb, int P, int &fp, int &fd) {
+  constexpr int U = 6;
+  fp = 0; fd = 0;
+  bool open_p = true, open_d = true;
+  for (int k = (P - 1) >> 2; k >= 0 && (open_p || open_d); k -= U) {
+    uint4 va[U], vm[U], vb[U];
 #pragma unroll
     for (int u = 0; u < U; u++) {
       const int kk = k - u >= 0 ? k - u : 0;
       va[u] = *reinterpret_cast<const uint4 *>(ra + 4 * kk);
+      vm[u] = *reinterpret_cast<const uint4 *>(rm + 4 * kk);
       vb[u] = *reinterpret_cast<const uint4 *>(rb + 4 * kk);
     }
 #pragma unroll
     for (int u = 0; u < U; u++) {
       if (k - u < 0) break;
-      const uint32_t wa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, wb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+      const uint32_t wa[4] = {va[u].x, va[u].y, va[u].z, va[u].w}, wm[4] = {vm[u].x, vm[u].y, vm[u].z, vm[u].w},
+                     wb[4] = {vb[u].x, vb[u].y, vb[u].z, vb[u].w};
 #pragma unroll
       for (int w = 3; w >= 0; w--) {
         if (4 * (k - u) + w >= P) continue;                    // (words of the row's padding)
-        const uint32_t a = wa[w], b = wb[w];
-        if ((a | b) & SIG_BAD) return 2;
-        const int dx = (int)(a & 1023u) - (int)(b & 1023u), dy = (int)((a >> 10) & 1023u) - (int)((b >> 10) & 1023u),
-                  dz = (int)((a >> 20) & 1023u) - (int)((b >> 20) & 1023u);
-        if (dx > 1 || dx < -1 || dy > 1 || dy < -1 || dz > 1 || dz < -1) return 1;
+        const uint32_t a = wa[w], m = wm[w], b = wb[w];
+        const uint32_t mx = m & 1023u, my = (m >> 10) & 1023u, mz = (m >> 20) & 1023u;
+        // d + 1 in {0, 1, 2} <=> the cells are at most one apart
+        const uint32_t px = (a & 1023u) + 1u - mx, py = ((a >> 10) & 1023u) + 1u - my, pz = ((a >> 20) & 1023u) + 1u - mz;
+        const uint32_t dx = mx + 1u - (b & 1023u), dy = my + 1u - ((b >> 10) & 1023u), dz = mz + 1u - ((b >> 20) & 1023u);
+        const int ep = ((a | m) & SIG_BAD) ? 2 : ((px > 2u || py > 2u || pz > 2u) ? 1 : 0);
+        const int ed = ((m | b) & SIG_BAD) ? 2 : ((dx > 2u || dy > 2u || dz > 2u) ? 1 : 0);
+        if (open_p && ep) { fp = ep; open_p = false; }
+        if (open_d && ed) { fd = ed; open_d = false; }
       }
     }
   }
-  return 0;
 }
 
-// Take the wave's next samples: slots [h, h + cnt) of the pool.  own_lo / own_hi: the ticket the wave holds.  false: leave.
-__device__ __forceinline__ bool eq_claim(const EdgeQueueArgs &q, int &own_lo, int &own_hi, int &h, int &cnt) {
+// Take the wave's next samples: pool slots [pos, pos + n).  false: leave.
+__device__ __forceinline__ bool eq_claim(const EdgeQueueArgs &q, int &pos, int &n) {
   const int lane = threadIdx.x;
   uint32_t *ctl = q.ctl;
   uint32_t seen = 0xffffffffu;          // done + tail at the last look: a wait that sees them unchanged for too long gives up
   unsigned idle = 0;
+  int patience = 0;                     // (lane 0's)
   for (;;) {
-    uint32_t fl = 0, d = 0, t = 0;
+    int r_fl = 0, r_pos = 0, r_n = 0, r_end = 0, r_wait = 0;
+    uint32_t d = 0, t = 0;
     if (lane == 0) {
-      fl = eq_load(ctl + EQ_FLAGS);
+      r_fl = (int)eq_load(ctl + EQ_FLAGS);
       d = eq_load(ctl + EQ_DONE);
       eq_wait_vm();                     // `done` is read BEFORE `tail`: done == tail then means that nothing was in flight at that moment
       t = eq_load(ctl + EQ_TAIL);
+      const int avail = (int)eq_load(ctl + EQ_AVAIL);
+      // whole waves while work is plenty, single samples when it runs dry (an FK costs a wave the same 128 serial steps whatever
+      // its lane count: the last samples finish soonest one per idle wave).  "Plenty" counts what is outstanding anywhere -- waiting
+      // or being integrated (its children are pushed within a round): a wave that finds less than it wants waits a few
+      // microseconds for the pushes in progress instead of running half empty
+      const int out = (int)(t - d);
+      const int want = out >= 4096 ? 64 : (out < 128 ? 1 : out >> 6);
+      if (!r_fl && avail > 0 && avail < want && patience < 24) { patience++; r_wait = 1; }
+      else if (!r_fl && avail > 0) {
+        const int old = (int)__hip_atomic_fetch_add((int *)(ctl + EQ_AVAIL), -want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int got = old >= want ? want : (old > 0 ? old : 0);
+        if (got < want) __hip_atomic_fetch_add((int *)(ctl + EQ_AVAIL), want - got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (got > 0) { r_pos = (int)__hip_atomic_fetch_add(ctl + EQ_HEAD, (uint32_t)got, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); r_n = got; }
+      } else if (!r_fl && d == t) r_end = 1;
     }
-    fl = (uint32_t)eq_bcast((int)fl); d = (uint32_t)eq_bcast((int)d); t = (uint32_t)eq_bcast((int)t);
-    if (fl) return false;
-    if (own_lo == own_hi) {
-      // a ticket sized by the queue's depth: whole waves while it is deep, single samples when it runs dry (an FK costs a wave
-      // the same 128 serial steps whatever its lane count: the last samples finish soonest one per idle wave)
-      int lo = 0, size = 0;
-      if (lane == 0) {
-        const int depth = (int)(t - eq_load(ctl + EQ_HEAD));
-        size = depth >= 4096 ? 64 : (depth < 128 ? 1 : depth >> 6);
-        lo = (int)__hip_atomic_fetch_add(ctl + EQ_HEAD, (uint32_t)size, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-      own_lo = eq_bcast(lo); own_hi = own_lo + eq_bcast(size);
-    }
-    if ((int)t > own_lo) {
-      h = own_lo;
-      cnt = ((int)t < own_hi ? (int)t : own_hi) - own_lo;
-      own_lo += cnt;
-      return true;
-    }
-    if (d == t) return false;
+    if (eq_bcast(r_fl) || eq_bcast(r_end)) return false;
+    if (eq_bcast(r_wait)) { __builtin_amdgcn_s_sleep(16); continue; }
+    n = eq_bcast(r_n);
+    if (n > 0) { pos = eq_bcast(r_pos); return true; }
+    d = (uint32_t)eq_bcast((int)d); t = (uint32_t)eq_bcast((int)t);
     if (d + t != seen) { seen = d + t; idle = 0; }
     else if (++idle > (1u << 19)) {     // ~ seconds without a sample finishing anywhere
       if (lane == 0) __hip_atomic_fetch_or(ctl + EQ_FLAGS, EQF_STUCK, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -138,7 +150,6 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps,
     const VerdictArgs *__restrict__ va, const EdgeQueueArgs *__restrict__ qa, const FusedSweepArgs *__restrict__ sa) {
   const int lane = threadIdx.x;
-  int own_lo = 0, own_hi = 0;
   EqClock clk;
   clk.start();
   for (;;) {
@@ -146,15 +157,16 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     asm volatile("" : "+s"(zero));      // (as PointSweep::args: the queue's arguments are re-read when needed, not held across the RK4 loop)
     const EdgeQueueArgs &q = qa[zero];
     int h = 0, cnt = 0;
-    if (!eq_claim(q, own_lo, own_hi, h, cnt)) break;
+    if (!eq_claim(q, h, cnt)) break;
     clk.lap(q.ctl, EQ_T_CLAIM);
     const bool live = lane < cnt;
+    const int slot = h + lane;
     // ---- the slots' records: written by a wave that is inside its push right now, or long ago ----
     int e_lane = -1;
     {
       bool bail = false;
       if (live) {
-        const uint32_t *flag = (const uint32_t *)q.sample_edge + h + lane;
+        const uint32_t *flag = (const uint32_t *)q.sample_edge + slot;
         unsigned spins = 0;
         while ((e_lane = (int)eq_load(flag)) < 0) {
           if (eq_load(q.ctl + EQ_FLAGS) != 0u) { bail = true; break; }
@@ -233,14 +245,15 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
         const uint32_t nfin = (uint32_t)__popcll(__ballot(fin));
         if (lane == 0) __hip_atomic_fetch_add(q2.ctl + EQ_FINISHED, nfin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      // ---- finish the levels: should_subdivide on both halves of every interval, ONE CANDIDATE PER LANE ----
-      // candidates 2 i, 2 i + 1 of an edge: the distal (:387-390) and the proximal (:393-396) half of its interval i, whose midpoint
-      // is pool slot base + i.  A finisher lane owns its edge's 2 cnt candidates; the wave deals all of them out 64 at a time.
+      // ---- finish the levels: should_subdivide on both halves of every interval, ONE INTERVAL PER LANE ----
+      // interval i of an edge's level has its midpoint in pool slot base + i; its distal half (:387-390) and its proximal half
+      // (:393-396) are the candidates for the next level.  A finisher lane owns its edge's cnt intervals; the wave deals all of
+      // them out 64 at a time.
       int base_l = 0, ncand_l = 0;
       double rel_l = 0.0;
       if (fin && q2.edge_ok[e_lane] != 0u) {                  // (an invalid sample decides the edge: nothing to open)
-        base_l = q2.lvl_base[e_lane]; ncand_l = 2 * q2.lvl_cnt[e_lane]; rel_l = q2.rel[e_lane];
-        if (ncand_l > EQ_MAX_CAND) {
+        base_l = q2.lvl_base[e_lane]; ncand_l = q2.lvl_cnt[e_lane]; rel_l = q2.rel[e_lane];
+        if (2 * ncand_l > EQ_MAX_CAND) {
           __hip_atomic_fetch_or(q2.ctl + EQ_FLAGS, EQF_DEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ncand_l = 0; stop = true;
         }
@@ -251,56 +264,55 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
       const int P = q2.P;
       const int S2 = q2.sk.S;
       while (todo && !stop) {
-        // a group of owner lanes, in lane order, whose candidates fit the emit mask (EQ_GROUP_CAND bits; one level is at most half of it)
+        // a group of owner lanes, in lane order, whose intervals fit the emit masks (EQ_GROUP_IV intervals; one level is at most half of it)
         const bool mine = (todo >> lane) & 1ull;
         int pre = mine ? ncand_l : 0;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(pre, o, 64); if (lane >= o) pre += v; }     // inclusive prefix
-        const bool in_group = mine && pre <= EQ_GROUP_CAND;
+        const bool in_group = mine && pre <= EQ_GROUP_IV;
         const unsigned long long gm = __ballot(in_group);
         todo &= ~gm;
         const int n_g = in_group ? ncand_l : 0;
         int ex = n_g;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) { const int v = __shfl_up(ex, o, 64); if (lane >= o) ex += v; }
-        const int T = __shfl(ex, 63, 64);                      // the group's candidates
-        ex -= n_g;                                             // exclusive prefix: the lane's first candidate
+        const int T = __shfl(ex, 63, 64);                      // the group's intervals
+        ex -= n_g;                                             // exclusive prefix: the lane's first interval
         __syncthreads();
         EQ_I(EQ_PRE + lane) = ex; EQ_I(EQ_EOF + lane) = e_lane; EQ_I(EQ_BASEOF + lane) = base_l;
         EQ_I(EQ_CNT + lane) = 0; EQ_I(EQ_DOM + lane) = 0; EQ_I(EQ_FILL + lane) = 0;
         EQ_REL(lane) = rel_l;
         __syncthreads();
-        if (lane == 0) __hip_atomic_fetch_add(q2.ctl + EQ_CAND, (uint32_t)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // candidate g of the group -> its owner lane (the last lane whose first candidate is <= g), the edge's candidate index
+        if (lane == 0) __hip_atomic_fetch_add(q2.ctl + EQ_CAND, (uint32_t)(2 * T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // interval g of the group -> its owner lane: the last lane whose first interval is <= g
         auto owner_of = [&](int g) {
           int lo = 0;
 #pragma unroll
           for (int st = 32; st > 0; st >>= 1) if (EQ_I(EQ_PRE + lo + st) <= g) lo += st;
           return lo;
         };
-        auto candidate = [&](int ow, int c, int &sa, int &sb, double &ta, double &tb) {
-#pragma clang fp contract(off)
-          const int sm = EQ_I(EQ_BASEOF + ow) + (c >> 1);
-          const EdgeIv iv = q2.iv[sm];
-          const double tm = (iv.ta + iv.tb) / 2;               // :382
-          if (c & 1) { sa = iv.sa; sb = sm; ta = iv.ta; tb = tm; } else { sa = sm; sb = iv.sb; ta = tm; tb = iv.tb; }
-        };
-        // pass 1: the verdict of every candidate, survivors counted per owner
+        // pass 1: the verdicts of every interval's two halves, survivors counted per owner
         for (int g0 = 0; g0 < T; g0 += 64) {
           const int g = g0 + lane;
-          bool emit = false;
+          bool emit_p = false, emit_d = false;
           if (g < T) {
 #pragma clang fp contract(off)
             const int ow = owner_of(g);
-            int sa, sb; double ta, tb;
-            candidate(ow, g - EQ_I(EQ_PRE + ow), sa, sb, ta, tb);
-            const int f = signatures_differ_lane(q2.sig + (int64_t)sa * q2.sig_stride, q2.sig + (int64_t)sb * q2.sig_stride, P);
-            if (f == 2) atomicOr(&EQ_U(EQ_DOM + ow), 1u);      // std::domain_error in the reference: the edge is invalid
-            emit = f == 1 && (tb - ta) > EQ_REL(ow);           // width rule of :369-372, applied at push time
-            if (emit) atomicAdd(&EQ_U(EQ_CNT + ow), 1u);
+            const int sm = EQ_I(EQ_BASEOF + ow) + (g - EQ_I(EQ_PRE + ow));
+            const EdgeIv iv = q2.iv[sm];
+            const double tm = (iv.ta + iv.tb) / 2;             // :382
+            int fp, fd;
+            signatures_differ_lane2(q2.sig + (int64_t)iv.sa * q2.sig_stride, q2.sig + (int64_t)sm * q2.sig_stride,
+                                    q2.sig + (int64_t)iv.sb * q2.sig_stride, P, fp, fd);
+            if (fp == 2 || fd == 2) atomicOr(&EQ_U(EQ_DOM + ow), 1u);    // std::domain_error in the reference: the edge is invalid
+            const double relv = EQ_REL(ow);
+            emit_p = fp == 1 && (tm - iv.ta) > relv;           // width rule of :369-372, applied at push time
+            emit_d = fd == 1 && (iv.tb - tm) > relv;
+            const uint32_t k = (emit_p ? 1u : 0u) + (emit_d ? 1u : 0u);
+            if (k) atomicAdd(&EQ_U(EQ_CNT + ow), k);
           }
-          const unsigned long long m = __ballot(emit);
-          if (lane == 0) EQ_MASK(g0 >> 6) = m;
+          const unsigned long long mp = __ballot(emit_p), md = __ballot(emit_d);
+          if (lane == 0) { EQ_MASK(2 * (g0 >> 6)) = mp; EQ_MASK(2 * (g0 >> 6) + 1) = md; }
         }
         __syncthreads();
         sub.lap(q2.ctl, EQ_T_F2);
@@ -333,28 +345,40 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
         __syncthreads();
         // pass 2: the survivors' records at their slots
         for (int g0 = 0; g0 < T; g0 += 64) {
-          const unsigned long long m = EQ_MASK(g0 >> 6);
-          if ((m >> lane) & 1ull) {
+          const unsigned long long mp = EQ_MASK(2 * (g0 >> 6)), md = EQ_MASK(2 * (g0 >> 6) + 1);
+          const bool ep = (mp >> lane) & 1ull, ed = (md >> lane) & 1ull;
+          if (ep || ed) {
 #pragma clang fp contract(off)
             const int g = g0 + lane;
             const int ow = owner_of(g);
             if (!EQ_I(EQ_DOM + ow)) {
-              int sa, sb; double ta, tb;
-              candidate(ow, g - EQ_I(EQ_PRE + ow), sa, sb, ta, tb);
-              const int slot = EQ_I(EQ_NBASE + ow) + (int)atomicAdd(&EQ_U(EQ_FILL + ow), 1u);
+              const int sm = EQ_I(EQ_BASEOF + ow) + (g - EQ_I(EQ_PRE + ow));
+              const EdgeIv iv = q2.iv[sm];
+              const double tm = (iv.ta + iv.tb) / 2;           // :382
               const int e = EQ_I(EQ_EOF + ow);
-              q2.iv[slot] = EdgeIv{e, sa, sb, 0, ta, tb};
-              const double tm = (ta + tb) / 2;                 // edge_open's expression
-              interpolate_state_dev(q2.sk, q2.A + (int64_t)e * S2, q2.B + (int64_t)e * S2, tm, q2.states + (int64_t)slot * S2);
+              int ns = EQ_I(EQ_NBASE + ow) + (int)atomicAdd(&EQ_U(EQ_FILL + ow), (ep ? 1u : 0u) + (ed ? 1u : 0u));
+              if (ed) {                                        // the distal half [tm, tb] between the midpoint and the far end
+                q2.iv[ns] = EdgeIv{e, sm, iv.sb, 0, tm, iv.tb};
+                const double t2 = (tm + iv.tb) / 2;            // edge_open's expression
+                interpolate_state_dev(q2.sk, q2.A + (int64_t)e * S2, q2.B + (int64_t)e * S2, t2, q2.states + (int64_t)ns * S2);
+                ns++;
+              }
+              if (ep) {                                        // the proximal half [ta, tm]
+                q2.iv[ns] = EdgeIv{e, iv.sa, sm, 0, iv.ta, tm};
+                const double t2 = (iv.ta + tm) / 2;
+                interpolate_state_dev(q2.sk, q2.A + (int64_t)e * S2, q2.B + (int64_t)e * S2, t2, q2.states + (int64_t)ns * S2);
+              }
             }
           }
         }
         sub.lap(q2.ctl, EQ_T_F3);
         eq_release();                   // the pushed records, before their ready flags
         for (int g = lane; g < Tnew; g += 64) {
-          const int slot = nb + g;
-          __hip_atomic_store((uint32_t *)q2.sample_edge + slot, (uint32_t)q2.iv[slot].e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          const int ns = nb + g;
+          __hip_atomic_store((uint32_t *)q2.sample_edge + ns, (uint32_t)q2.iv[ns].e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+        eq_wait_vm();                   // the flags are out: the samples may be taken
+        if (lane == 0) __hip_atomic_fetch_add((int *)(q2.ctl + EQ_AVAIL), Tnew, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sub.lap(q2.ctl, EQ_T_F4);
       }
     }
@@ -363,7 +387,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     if (lane == 0) {
       __hip_atomic_fetch_add(q2.ctl + EQ_DONE, (uint32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(q2.ctl + EQ_BATCHES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(q2.ctl + 124 + (cnt == 64 ? 0 : (cnt >= 32 ? 1 : (cnt >= 2 ? 2 : 3))), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(q2.ctl + EQ_SIZES + (cnt == 64 ? 0 : (cnt >= 32 ? 1 : (cnt >= 2 ? 2 : 3))), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     clk.lap(q2.ctl, EQ_T_FOLD);
