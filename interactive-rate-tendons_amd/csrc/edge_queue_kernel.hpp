@@ -225,7 +225,8 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
       bool exact = false;
       sweep_body<false>(q2.fb_in, n_eff, q2.fb_ld, fa.P, fa.CH, fa.NM, K, fa.g, fa.grid, fa.near_grid, 1, fa.debug, nullptr, nullptr, nullptr, &exact);
       __syncthreads();
-      if (lane == 0) __hip_atomic_fetch_add(q2.ctl + EQ_PENDING, (uint32_t)__popcll(__ballot(lv.pending)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t npend = (uint32_t)__popcll(__ballot(lv.pending));
+      if (lane == 0) __hip_atomic_fetch_add(q2.ctl + EQ_PENDING, npend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (lv.pending) lv.valid = exact;
       clk.lap(q2.ctl, EQ_T_EXACT);
     }
