@@ -513,8 +513,45 @@ int tr_profile_read(tr_ctx *ctx, int64_t launches[TR_PROFILE_SLOTS], double tota
 int tr_profile_end(tr_ctx *ctx);
 
 /* debug / A-B switches (tests): bit0 = brute-force O(P^2) self-collision instead of the
- * conservative-skip sweep (verdicts must be identical) */
+ * conservative-skip sweep (verdicts must be identical); bit1 = no milestone proof of "no self collision": every
+ * configuration takes the exact pairwise sweep (the fallback pass of the verdict path, the in-wave sweep of the edge queue);
+ * bit2 = no dilated-grid fast path in the voxel walk.  Verdicts, flags and FK counts are the same under every combination. */
 int tr_set_debug(tr_ctx *ctx, uint32_t bits);
+
+/* How the last tr_validate_edges_indexed* call of this context was scheduled (instrumentation; tests assert on it):
+ *   stats[0]  FK samples the edge queue took (0: the call ran on the level-synchronous lanes)
+ *   stats[1]  rounds: batches of up to 64 samples a persistent wave integrated
+ *   stats[2]  samples whose self-collision test took the exact pairwise sweep inside the queue
+ *   stats[3]  flags the queue ended with: 0 = complete; 1 = sample pool too small, 4 = an edge level of more than 2048 intervals
+ *             (in both cases the lanes then took the call); 2 = a wait made no progress (the call returned TR_ERR_RUNTIME)
+ * The edge queue (csrc/edge_queue_kernel.hpp) is ONE persistent launch over a device work queue with a barrier per edge instead of
+ * one per level of all edges: same verdicts, FK counts and domain-error count as the lanes, bit for bit. */
+int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
+
+/* Environment switches, read ONCE by tr_create (a context keeps what it read).  They exist for A/B measurements and for
+ * tests that must reach a rarely taken path; none of them changes a result, and production code sets none of them.
+ *   TENDON_HIP_FUSED=0|1|2          schedule of tr_validate_batch*: 2 (default) verdict-only kernel, 1 K1 + K2 as one kernel over
+ *                                   stored points, 0 separate launches (the edge queue, the signature hand-over and
+ *                                   tr_sample_valid_vertices* need 2 and report TR_ERR_UNSUPPORTED or fall back otherwise)
+ *   TENDON_HIP_EDGE_QUEUE=0|1       1 (default): indexed edge checks through the edge queue where it applies (no retraction,
+ *                                   schedule 2); 0: always the level-synchronous lanes
+ *   TENDON_HIP_EDGE_QUEUE_WAVES=n   persistent workgroups of the edge queue (default: what the device holds at once)
+ *   TENDON_HIP_EDGE_LANES=1..4      exactly that many lanes of the level-synchronous edge bisection (default: by the edge count)
+ *   TENDON_HIP_EDGE_LANE_GUESS=x    samples per edge assumed when a lane is given its share of the pool (tests: a small value
+ *                                   provokes the overflow path)
+ *   TENDON_HIP_EDGE_POOL=n          upper bound of the FK sample pool (tests: forces chunking / the overflow paths)
+ *   TENDON_HIP_FB_CAP=n             columns of the fallback pass's point workspace (default: one resident round of waves)
+ *   TENDON_HIP_RETRACT_SORT=n       retraction robots: batches of at least n configurations are ordered by backbone length
+ *                                   (0 = never); TENDON_HIP_RETRACT_KBEGIN_OFF: no per-wave loop start in that order
+ *   TENDON_HIP_CH_SCALE=x           milestone spacing of the self-collision proof in robot radii (default 2)
+ * Read per call (the tests switch between two paths inside one process):
+ *   TENDON_HIP_KNN=lanes            neighbour search by the lane-per-query kernel for every k (default: wave per query up to k = 64);
+ *                                   TENDON_HIP_KNN_CELL=x scales its cell width (tuning)
+ *   TENDON_HIP_MERGE=sort           edge voxel sets merged by the segmented sort (default: the per-edge LDS table);
+ *                                   TENDON_HIP_MERGE_MAXLOAD=n bounds that table's load (tests: reaches the overflow fallback)
+ *   TENDON_HIP_LANDMARKS=...        landmark choice of tr_roadmap_prepare (csrc/roadmap.hip; tuning)
+ *   TENDON_HIP_PIPE_LOG2=n          chunk size 2^n of tr_validate_batch's host-buffer pipeline (tuning)
+ * Output on stderr only: TENDON_HIP_EDGE_TIMING, TENDON_HIP_VOX_TIMING, TENDON_HIP_ROADMAP_TIMING. */
 
 #ifdef __cplusplus
 }

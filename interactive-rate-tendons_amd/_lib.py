@@ -33,7 +33,7 @@ ABI_SYMBOLS = (
     "tr_check_cached", "tr_check_cached_dev", "tr_check_cached_subset_dev", "tr_state_layout", "tr_space_weights", "tr_kstar_k",
     "tr_roadmap_create", "tr_roadmap_destroy", "tr_roadmap_last_error", "tr_roadmap_set_caches", "tr_roadmap_set_caches_dev", "tr_roadmap_prepare", "tr_roadmap_clear_validity",
     "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_edges_indexed", "tr_connect_edges_indexed", "tr_voxelize_fetch", "tr_voxelize_fetch_dev", "tr_voxelize_count", "tr_knn", "tr_knn_range", "tr_knn_table_edges", "tr_knn_edges", "tr_knn_edges_dev", "tr_knn_range_dev", "tr_knn_table_edges_dev", "tr_validate_edges_indexed_dev", "tr_signature_words", "tr_validate_candidates_sig_dev", "tr_validate_edges_indexed_sig_dev", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
-    "tr_set_debug",
+    "tr_set_debug", "tr_edge_schedule_last",
     "tr_candidate_states", "tr_candidate_states_dev", "tr_validate_candidates_dev", "tr_compact_rows_dev",
     "tr_sample_valid_vertices", "tr_sample_valid_vertices_dev", "tr_sample_valid_vertices_sig_dev",
 )
@@ -303,6 +303,7 @@ def lib():
     L.tr_profile_read.argtypes = [vp, P(i64), dp]
     L.tr_profile_end.argtypes = [vp]
     L.tr_set_debug.argtypes = [vp, C.c_uint32]
+    L.tr_edge_schedule_last.argtypes = [vp, P(C.c_uint32)]
     _lib = L
     return L
 

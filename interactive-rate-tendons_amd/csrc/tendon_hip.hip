@@ -1054,6 +1054,11 @@ int tr_set_checker(tr_ctx *c, int32_t checker) {
 }
 
 int tr_set_debug(tr_ctx *c, uint32_t bits) { if (!c) return TR_ERR_INVALID_ARG; c->debug = bits; return TR_OK; }
+int tr_edge_schedule_last(const tr_ctx *c, uint32_t stats[4]) {
+  if (!c || !stats) return TR_ERR_INVALID_ARG;
+  for (int q = 0; q < 4; q++) stats[q] = c->edge_queue_last[q];
+  return TR_OK;
+}
 
 int tr_set_grid(tr_ctx *c, uint32_t N, const double lim[6], const uint64_t *blocks, const double inv_rot[9]) {
   if (!c || !lim || !blocks) return fail(c, TR_ERR_INVALID_ARG, "null argument");

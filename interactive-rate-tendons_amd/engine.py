@@ -134,6 +134,13 @@ class Engine:
     def set_debug(self, bits):
         L.check(self._ctx, self.lib.tr_set_debug(self._ctx, int(bits)))
 
+    def edge_schedule_last(self):
+        """How the last indexed edge call was scheduled: dict(samples, rounds, exact_sweep, flags) of the edge queue (samples == 0:
+        the level-synchronous lanes took the call)."""
+        st = (C.c_uint32 * 4)()
+        L.check(self._ctx, self.lib.tr_edge_schedule_last(self._ctx, st))
+        return dict(samples=int(st[0]), rounds=int(st[1]), exact_sweep=int(st[2]), flags=int(st[3]))
+
     # ---- host-buffer calls ---------------------------------------------------------------------
     def _states(self, states):
         st = _f64(states)

@@ -511,3 +511,65 @@ def test_device_resident_entry_points_reject_bad_arguments(irt):
     # zero sizes are no-ops
     assert lib.tr_validate_edges_indexed_dev(ctx, C.byref(sp), None, 0, None, 0, None, None, C.byref(n64)) == 0
     assert lib.tr_knn_range_dev(ctx, p, 10, 4, 0, 3, 1e300, None) == 0
+
+
+def test_edge_queue_equals_the_level_synchronous_lanes(irt, orc, helpers):
+    """The indexed edge check as ONE persistent launch over a device work queue with a barrier per edge (csrc/edge_queue_kernel.hpp, the
+    default) gives the verdicts, the reference's FK counts and the domain-error count of the level-synchronous lanes
+    (TENDON_HIP_EDGE_QUEUE=0), edge by edge: for a 3-tendon and a 4-tendon robot, a rotating robot in a rotated environment, a
+    slender robot under high tension whose samples need the exact pairwise self-collision sweep (taken INSIDE the queue by the wave that
+    finds them), with every sample forced through that sweep (debug bit 1), with a queue of a handful of waves (each wave's rounds
+    then depend on other waves' pushes from the first level on), and when the pool is too small for the queue (it gives up, the lanes
+    take the call).  tr_edge_schedule_last says which schedule ran.  The oracle's checkMotion on a sample of the edges."""
+    W = irt.workloads
+    thin = W.robot_config1()
+    thin.specs.dL = 0.2 / 128
+    thin.r = 0.008
+    for t in thin.tendons:
+        t.max_tension, t.min_length, t.max_length = 100.0, -1.0, 0.12
+    spin = W.robot_config3()
+    spin.enable_rotation = True
+    a = 0.4
+    rot = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1.0]])
+    cases = ((W.robot_config2(), 12.0, None, 0), (W.robot_config3(), 20.0, None, 0), (spin, 20.0, rot, 0), (thin, 100.0, None, 0),
+             (W.robot_config3(), 20.0, None, 2))
+    for robot, tau_max, inv_rot, debug in cases:
+        nv = 1500
+        vox, _ = W.reach_environment(seed=7, n_spheres=48)
+        env = irt.VoxelEnvironment()
+        if inv_rot is not None:
+            env.inv_rotation = inv_rot
+        states = W.random_states(robot, nv, seed=91, tau_max=tau_max)
+        nt = len(robot.tendons)
+        near = np.argsort(np.linalg.norm(states[:, None, :nt] - states[None, :, :nt], axis=2), axis=1)[:, 1:8]
+        edges = np.stack([np.repeat(np.arange(nv), 7), near.reshape(-1)], 1)
+
+        def run():
+            chk = irt.VoxelBackboneValidityChecker(robot, env, vox)
+            if debug:
+                chk.engine.set_debug(debug)
+            out = irt.VoxelBackboneMotionValidator(chk).check_motion_indexed(states, edges)
+            out["schedule"] = chk.engine.edge_schedule_last()
+            return out
+
+        want = _with_env(irt, {"TENDON_HIP_EDGE_QUEUE": "0"}, run)
+        assert want["schedule"]["samples"] == 0
+        own = int(np.asarray(want["n_fk"]).sum()) - 2 * len(edges)
+        for extra in ({}, {"TENDON_HIP_EDGE_QUEUE_WAVES": "5"}, {"TENDON_HIP_EDGE_POOL": "24000"}):
+            got = _with_env(irt, dict({"TENDON_HIP_EDGE_QUEUE": "1"}, **extra), run)
+            for k in ("valid", "n_fk", "n_domain_errors"):
+                assert np.array_equal(got[k], want[k]), (k, extra, debug, np.flatnonzero(np.asarray(got[k]) != np.asarray(want[k]))[:8])
+            sch = got["schedule"]
+            if "TENDON_HIP_EDGE_POOL" in extra and own + nv + 64 > 24000:
+                assert sch["flags"] == 1, sch                     # the pool is too small: the queue says so and the lanes took the call
+            else:
+                assert sch["flags"] == 0 and sch["samples"] == own, (sch, own)
+                if debug & 2:
+                    assert sch["exact_sweep"] > 0.5 * own, sch    # (samples that fail before the self-collision test do not take it)
+        assert 0.2 < want["valid"].mean() < 0.995 and want["n_fk"].max() > 4
+        if not debug:
+            idx = np.random.default_rng(92).choice(len(edges), 300, replace=False)
+            ov, onf, _ = orc.check_motion_batch(helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, vox), states[edges[idx, 0]],
+                                                states[edges[idx, 1]], inv_rot=np.eye(3) if inv_rot is None else inv_rot, nthreads=0, lib=orc.omp_lib())
+            assert np.array_equal(want["valid"][idx], ov)
+            assert np.array_equal(want["n_fk"][idx][ov], onf[ov])
