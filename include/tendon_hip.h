@@ -448,8 +448,8 @@ int tr_knn_edges(tr_ctx *ctx, const double *states, int64_t n, int32_t k, double
  * from tr_validate_edges_indexed_dev the mask words (d_valid_bits: (n_edges + 63) / 64 words; d_n_fk: n_edges counts or NULL),
  * which are device arrays too.  Same results, order and error codes as tr_knn_edges / tr_validate_edges_indexed; both calls
  * synchronise with the device on entry (the inputs may have been written on any stream) and before they return.
- * tr_validate_edges_indexed_dev returns TR_ERR_UNSUPPORTED where the host form would fall back to gathering the
- * end states on the host (more vertices than half the sample pool). */
+ * Where the host form falls back to gathering the end states on the host (more vertices than half the sample pool: beyond 2^23
+ * vertices, or under a bounded pool) tr_validate_edges_indexed_dev brings its inputs over and does the same: correct, not fast. */
 int tr_knn_edges_dev(tr_ctx *ctx, const double *d_states, int64_t n, int32_t k, double max_distance, int32_t *d_edges,
                      int64_t capacity, int64_t *n_edges);
 int tr_validate_edges_indexed_dev(tr_ctx *ctx, const tr_space_params *sp, const double *d_states, int64_t n_states,

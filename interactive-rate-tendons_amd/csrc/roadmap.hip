@@ -80,7 +80,7 @@ struct DevCache {
   std::vector<Buf> idle;
   std::unordered_map<void *, Buf> live;
   size_t idle_bytes = 0;
-  static constexpr size_t kCacheMaxBytes = (size_t)3 << 30, kCacheMaxEntries = 48;
+  static constexpr size_t kCacheMaxBytes = (size_t)1 << 30, kCacheMaxEntries = 32;
   hipError_t alloc(int dev, void **out, size_t bytes) {
     bytes = std::max<size_t>(bytes, 256);
     std::lock_guard<std::mutex> lock(mu);
@@ -109,8 +109,17 @@ struct DevCache {
     *out = p;
     return hipSuccess;
   }
+  // everything parked goes back to the device (an allocation elsewhere in the library ran out of memory: tr_dev_cache_trim)
+  void trim() {
+    std::lock_guard<std::mutex> lock(mu);
+    for (const Buf &b : idle) (void)hipFree(b.p);
+    idle.clear(); idle_bytes = 0;
+  }
   void release(void *p) {
     if (!p) return;
+    // hipFree synchronised with the device; a parked buffer may be handed to its next owner at once, so work that still uses it
+    // (a roadmap destroyed with launches in flight) is waited for here
+    (void)hipDeviceSynchronize();
     std::lock_guard<std::mutex> lock(mu);
     auto it = live.find(p);
     if (it == live.end()) { (void)hipFree(p); return; }
@@ -121,6 +130,9 @@ struct DevCache {
   }
 };
 DevCache &dev_cache() { static DevCache c; return c; }
+}  // namespace
+void tr_dev_cache_trim() { dev_cache().trim(); }
+namespace {
 
 enum : uint8_t { V_UNKNOWN = 0, V_VALID = 1, V_INVALID = 2 };   // VALIDITY_UNKNOWN / VALIDITY_TRUE / removed from the graph
 

@@ -39,6 +39,8 @@
 #include "env_kernel.hpp"
 #include "sample.hpp"
 
+void tr_dev_cache_trim();          // roadmap.hip: frees the idle device buffers of the query objects' cache
+
 namespace {
 
 std::string g_create_error;
@@ -340,7 +342,13 @@ template <typename T>
 int dev_alloc(tr_ctx *ctx, T **p, size_t count) {
   if (*p) { (void)hipFree(*p); *p = nullptr; }
   if (count == 0) count = 1;
-  HIP_TRY(ctx, hipMalloc((void **)p, count * sizeof(T)));
+  hipError_t e = hipMalloc((void **)p, count * sizeof(T));
+  if (e == hipErrorOutOfMemory) {        // the query objects' buffer cache (roadmap.hip) may hold idle memory: give it back, try once more
+    (void)hipGetLastError();
+    tr_dev_cache_trim();
+    e = hipMalloc((void **)p, count * sizeof(T));
+  }
+  HIP_TRY(ctx, e);
   return TR_OK;
 }
 
@@ -1909,6 +1917,7 @@ int tr_knn_table_edges(tr_ctx *c, const int32_t *idx, int64_t n, int32_t k, int3
 int tr_knn_range_dev(tr_ctx *c, const double *d_states, int64_t n, int64_t first_query, int64_t n_queries, int32_t k, double max_distance,
                      int32_t *d_idx) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);         // (before the first fail(): it writes the context's error text)
   if (first_query < 0 || n_queries < 0 || first_query + n_queries > n) return fail(c, TR_ERR_OUT_OF_RANGE, "query range outside the states");
   if (n_queries > 0 && !d_idx) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   if (n_queries == 0) return TR_OK;
@@ -1932,6 +1941,7 @@ int tr_knn_edges(tr_ctx *c, const double *states, int64_t n, int32_t k, double m
 int tr_knn_edges_dev(tr_ctx *c, const double *d_states, int64_t n, int32_t k, double max_distance, int32_t *d_edges, int64_t capacity,
                      int64_t *n_edges) {
   if (!c) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::recursive_mutex> lock_(c->mu);         // (before the first fail(): it writes the context's error text)
   if (!n_edges || capacity < 0 || (capacity > 0 && !d_edges)) return fail(c, TR_ERR_INVALID_ARG, "bad argument");
   *n_edges = 0;
   HIP_TRY(c, hipSetDevice(c->device));

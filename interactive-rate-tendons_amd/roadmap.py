@@ -73,7 +73,9 @@ class RoadmapBuilder:
         (tr_knn_edges_dev; k counts the vertex itself) and checkMotion on every candidate edge (tr_validate_edges_indexed_sig_dev /
         _dev) -- only counts cross PCIe.  Returns torch tensors on the engine's GPU: d_states [n, S], d_edges [n_edges, 2] int32,
         d_valid_bits (int64 words; unpack_bits(words, n_edges)), and n_domain_errors, candidates_tried.  Same vertices, edges and
-        verdicts as sample_valid_vertices -> knn_edges_gpu -> validate_edges."""
+        verdicts as sample_valid_vertices -> knn_edges_gpu -> validate_edges -- except for retraction robots, whose vertices the host
+        builder renumbers by backbone length (sample_valid_vertices) and this call leaves in acceptance order: the same vertex SET and
+        the same edges between them, under different indices."""
         import torch
         t0 = time.perf_counter()
         eng, dev = self.engine, "cuda:%d" % self.engine.device

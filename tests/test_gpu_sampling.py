@@ -87,6 +87,10 @@ def test_accepted_set_does_not_depend_on_the_batching(irt, which):
     d = e.sample_valid_vertices(n_want, seed=17, first_candidate=128, max_candidates=1024, want_index=True)
     k = int((idx < 1024).sum())
     assert d["accepted"] == k and d["tried"] == 1024 and np.array_equal(d["index"], a["index"][:k])
+    # ... also when the bound is not a whole number of waves (round 3 consumed up to 63 candidates beyond it)
+    d = e.sample_valid_vertices(n_want, seed=17, first_candidate=128, max_candidates=1000, want_index=True)
+    k = int((idx < 1000).sum())
+    assert d["accepted"] == k and d["tried"] == 1000 and np.array_equal(d["index"], a["index"][:k])
 
 
 def test_device_form_and_shard_form(irt):
