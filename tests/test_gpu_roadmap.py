@@ -169,7 +169,7 @@ def test_build_on_device_of_a_sparse_roadmap(irt):
     robot = W.robot_config3()
     chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
     rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=31)
-    n, k, dmax = 30000, 6, 0.55
+    n, k, dmax = 30000, 6, 0.45
     out = rb.build_on_device(n, k, max_distance=dmax)
     states, _ = rb.sample_valid_vertices(n)
     edges = rb.knn_edges_gpu(states, k, max_distance=dmax)
