@@ -429,6 +429,133 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
         dist.destroy_process_group()
     return 0
 
+def run_config4_projection(args, torch, dev_index):
+    """`--workload config4 --emulate-world G [G ...]`: the per-rank critical path of the sharded PRM build at world sizes this box
+    cannot run, measured on ONE GPU -- a PROJECTION, not a scaling curve.  The build runs once at world size 1; then, for every world
+    size G and every rank r = 0 .. G-1 in turn, rank r's shard of each phase runs alone on the GPU with the other ranks' gathered
+    inputs taken from the world-1 run (the candidate sequence, the gathered mask, the vertices' signature rows, the neighbour table and
+    the edge list are the same for every world size), its outputs compared with the world-1 run's slice.  Reported per G: each
+    phase's time per rank and its maximum over the ranks, the work every rank repeats (regenerating and compacting the candidates,
+    deriving the edge list from the gathered table), the bytes each rank contributes to each all-gather, and two labelled MODELS of
+    the collectives' time (xGMI: 7 links per GPU; all links at once, and a ring).  What it cannot show: RCCL's real latency, link
+    contention, host jitter across 8 processes."""
+    irt = importlib.import_module("interactive-rate-tendons_amd")
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    checker = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox, device=dev_index)
+    mv = irt.VoxelBackboneMotionValidator(checker)
+    eng = checker.engine
+    M, k, seed = 1 << args.config4_log2, args.config4_k, 3
+    dev = "cuda:%d" % dev_index
+    box = D.sampling_box(robot)
+    sw, S = eng.signature_words(), eng.state_size
+    if sw == 0:
+        raise SystemExit("--emulate-world needs a context that hands vertex signatures over (backbone checker, no retraction)")
+    validate = D.device_candidate_validator(eng, seed, box, signatures=True)
+    compact = D.device_row_compactor(eng)
+    space = (mv.min_tension_change, mv.min_rotation_change, mv.min_retraction_change)
+    reps = max(1, args.steps)
+
+    def timed(fn):
+        """fastest of `reps` runs of fn, in ms, and its last result"""
+        best, out = 1e30, None
+        for _ in range(reps):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = fn()
+            torch.cuda.synchronize(); best = min(best, time.perf_counter() - t0)
+        return 1e3 * best, out
+
+    def vertex_shard(G, r):
+        start, stop, shard = D.shard_bounds(M, G, r)
+        n_real = max(0, min(stop, M) - start)
+        local, rows = validate(start, n_real, shard // 64)
+        return local, compact(local, n_real, rows), shard
+
+    def knn_shard(verts, G, r):
+        n = verts.shape[0]
+        start, stop, shard = D.shard_bounds(n, G, r)
+        n_real = max(0, min(stop, n) - start)
+        rows = torch.full((shard, k + 1), -1, dtype=torch.int32, device=dev)
+        if n_real > 0:
+            eng.knn_range_dev(verts, n, start, n_real, k + 1, rows)
+        return rows, shard
+
+    def edge_shard(verts, vsig, d_edges, ne, G, r):
+        start, stop, shard = D.shard_bounds(ne, G, r)
+        n_real = max(0, min(stop, ne) - start)
+        words = torch.zeros(shard // 64, dtype=torch.int64, device=dev)
+        if n_real > 0:
+            eng.validate_edges_indexed_dev(verts, verts.shape[0], d_edges[start:start + n_real], n_real, words, None, *space, d_vertex_sig=vsig)
+            if n_real % 64:
+                words[n_real // 64] &= (1 << (n_real % 64)) - 1
+        return words, shard
+
+    # ---- world size 1: the reference results and times ----
+    for _ in range(max(1, args.warmup)):
+        vertex_shard(1, 0)
+    t_v1, (mask, vsig, _) = timed(lambda: vertex_shard(1, 0))
+    t_regen, (verts, _) = timed(lambda: D.gather_valid_vertices_dev(eng, seed, M, mask, box=box))
+    nv = verts.shape[0]
+    t_k1, (table, _) = timed(lambda: knn_shard(verts, 1, 0))
+    table = table[:nv].contiguous()
+    d_edges = torch.empty((max(1, nv * (k + 1)), 2), dtype=torch.int32, device=dev)
+    t_list, ne = timed(lambda: eng.edges_from_knn_dev(table.reshape(-1), nv, k + 1, d_edges))
+    eng.reserve_edges(ne)
+    edge_shard(verts, vsig, d_edges, ne, 1, 0)
+    t_e1, (ewords, _) = timed(lambda: edge_shard(verts, vsig, d_edges, ne, 1, 0))
+    base = {"vertices": t_v1, "regenerate_and_compact": t_regen, "knn_rows": t_k1, "edge_list_from_table": t_list, "edges": t_e1}
+    world1 = sum(base.values())
+    worlds = {}
+    link_gbs = 64.0                     # one direction of one xGMI link (MI355X_MICROARCH.md: 7 links x ~153 GB/s bidirectional per GPU)
+    for G in args.emulate_world:
+        per = {"vertices": [], "knn_rows": [], "edges": []}
+        counts = []
+        for r in range(G):
+            t, (local, mine, vshard) = timed(lambda: vertex_shard(G, r))
+            per["vertices"].append(t)
+            lo = r * (vshard // 64)
+            ref = mask[lo:lo + vshard // 64]
+            assert torch.equal(local[: ref.numel()], ref) and not bool(local[ref.numel():].any()), "rank %d of %d: vertex mask differs from the world-1 run" % (r, G)
+            counts.append(int(mine.shape[0]))
+            t, (rows, nshard) = timed(lambda: knn_shard(verts, G, r))
+            per["knn_rows"].append(t)
+            lo = r * nshard
+            n_real = max(0, min(lo + nshard, nv) - lo)
+            assert torch.equal(rows[:n_real], table[lo:lo + n_real]), "rank %d of %d: neighbour rows differ from the world-1 run" % (r, G)
+            t, (w, eshard) = timed(lambda: edge_shard(verts, vsig, d_edges, ne, G, r))
+            per["edges"].append(t)
+            lo = r * (eshard // 64)
+            ref = ewords[lo:lo + eshard // 64]
+            assert torch.equal(w[: ref.numel()], ref), "rank %d of %d: edge verdicts differ from the world-1 run" % (r, G)
+        assert sum(counts) == nv
+        payload = {"vertex_mask": vshard // 8, "vertex_signatures": max(counts) * sw * 4, "knn_rows": nshard * (k + 1) * 4, "edge_mask": eshard // 8}
+        # a rank receives (G - 1) shards: over all its links at once, or one after the other round a ring; 20 us per step of latency
+        model_links = {n: 1e3 * (b / (link_gbs * 1e9) + 20e-6) for n, b in payload.items()}
+        model_ring = {n: 1e3 * (G - 1) * (b / (link_gbs * 1e9) + 20e-6) for n, b in payload.items()}
+        phases = {n: max(v) for n, v in per.items()}
+        replicated = {"regenerate_and_compact": t_regen, "edge_list_from_table": t_list}
+        crit = sum(phases.values()) + sum(replicated.values())
+        worlds[str(G)] = {
+            "phases_ms_max_over_ranks": phases, "phases_ms_per_rank": per, "replicated_ms_on_every_rank": replicated,
+            "compute_critical_path_ms": crit, "replicated_fraction_of_critical_path": sum(replicated.values()) / crit,
+            "allgather_bytes_per_rank": payload, "allgather_model_ms_all_links": model_links, "allgather_model_ms_ring": model_ring,
+            "projected_build_ms": {"all_links": crit + sum(model_links.values()), "ring": crit + sum(model_ring.values())},
+            "projected_speedup_over_world_1": {"compute_only": world1 / crit, "all_links": world1 / (crit + sum(model_links.values())),
+                                               "ring": world1 / (crit + sum(model_ring.values()))},
+            "shard_efficiency": {n: base[n] / (G * phases[n]) for n in phases},
+        }
+    out = {"projection": True,
+           "what": "per-rank critical path of BASELINE configs[3] (2^%d candidates, %d neighbours) at world sizes emulated on ONE GPU: rank r's shard "
+                   "of each phase run alone, in turn, with the gathered inputs of a world-1 run; collectives are MODELLED, not run; this is "
+                   "not a scaling curve" % (args.config4_log2, k),
+           "n_gpus": 1, "candidates": M, "valid_vertices": int(nv), "candidate_edges": int(ne), "repetitions_fastest_of": reps,
+           "edge_schedule": eng.edge_schedule_last(), "world_1_ms": dict(base, total=world1), "emulated_worlds": worlds,
+           "collective_model": "bytes_per_rank / %.0f GB/s + 20 us, once (all 7 links at once) or G - 1 times (ring)" % link_gbs}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -445,6 +572,10 @@ def main():
                          "caches, 10k lazy queries) -- prints that script's JSON object instead of the headline line.  config4: "
                          "BASELINE configs[3], the PRM build at 2^20 candidates with vertices, neighbour rows and edges sharded over "
                          "--gpus N ranks (strong scaling), one JSON line with per-phase and per-collective times")
+    ap.add_argument("--emulate-world", type=int, nargs="+", default=None, metavar="G",
+                    help="--workload config4 on ONE GPU: run every rank's shard of every phase alone, in turn, for each world size G given, and "
+                         "print a PROJECTION of the per-rank critical path (max over ranks per phase, replicated work, all-gather payloads; the "
+                         "collectives are modelled).  Not a scaling curve")
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "traffic_latest.json"),
                     help="per-launch HBM bytes of the dominant kernel from a separate rocprofv3 --pmc pass")
     args = ap.parse_args()
@@ -460,6 +591,10 @@ def main():
         sys.exit(spawn_ranks(args.gpus))
 
     torch, dist, world, rank, local_rank, dev_index, rehearsal, use_dist = setup_ranks(args)
+    if args.workload == "config4" and args.emulate_world:
+        if world != 1:
+            raise SystemExit("--emulate-world runs on one GPU (--gpus 1)")
+        return run_config4_projection(args, torch, dev_index)
     if args.workload == "config4":
         return run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist)
 
