@@ -206,6 +206,8 @@ struct tr_roadmap {
   bool has_caches = false;
   uint32_t *d_ids = nullptr; uint64_t *d_masks = nullptr; int64_t *d_off = nullptr;
   int32_t *d_list = nullptr; uint8_t *d_hit = nullptr; uint64_t *d_bits = nullptr;
+  uint64_t *h_bits = nullptr;          // pinned image of d_bits (tr_roadmap_revalidate)
+  std::vector<uint64_t> absent;        // per word of the combined item index: bit set = the item has no cache (invalid for good)
   int64_t list_cap = 0;
   int64_t nnz = 0;
   // results of the last tr_roadmap_solve
@@ -534,6 +536,7 @@ void free_dev(tr_roadmap *r) {
   void *p[] = {r->d_ids, r->d_masks, r->d_off, r->d_list, r->d_hit, r->d_bits};
   for (void *q : p) if (q) dev_cache().release(q);
   r->d_ids = nullptr; r->d_masks = nullptr; r->d_off = nullptr; r->d_list = nullptr; r->d_hit = nullptr; r->d_bits = nullptr;
+  if (r->h_bits) { (void)hipHostFree(r->h_bits); r->h_bits = nullptr; }
   r->list_cap = 0; r->has_caches = false;
 }
 
@@ -680,6 +683,11 @@ int set_caches_impl(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *v_i
   RM_HIP(r, hipMemcpy(r->d_off, off.data(), off.size() * sizeof(int64_t), hipMemcpyHostToDevice));
   for (int64_t i = 0; i < r->V; i++) r->vpresent[(size_t)i] = v_present_bits ? (uint8_t)((v_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
   for (int64_t i = 0; i < r->E; i++) r->epresent[(size_t)i] = e_present_bits ? (uint8_t)((e_present_bits[i >> 6] >> (i & 63)) & 1) : 1;
+  // what tr_roadmap_revalidate needs on the host: a pinned image of the hit words and, per word, the items without a cache
+  RM_HIP(r, hipHostMalloc((void **)&r->h_bits, ((size_t)items / 64 + 1) * sizeof(uint64_t), hipHostMallocDefault));
+  r->absent.assign((size_t)items / 64 + 1, 0);
+  for (int64_t i = 0; i < r->V; i++) if (!r->vpresent[(size_t)i]) r->absent[(size_t)i >> 6] |= (uint64_t)1 << (i & 63);
+  for (int64_t i = 0; i < r->E; i++) if (!r->epresent[(size_t)i]) { const int64_t q = r->V + i; r->absent[(size_t)q >> 6] |= (uint64_t)1 << (q & 63); }
   r->has_caches = true;
   return TR_OK;
 }
@@ -725,16 +733,27 @@ int tr_roadmap_revalidate(tr_roadmap *r, int64_t *n_invalid_vertices, int64_t *n
   if (items > 0) {
     const int rc = tr_check_cached_dev(r->ctx, r->d_ids, r->d_masks, r->d_off, items, r->d_bits, nullptr);
     if (rc) return rfail(r, rc, tr_last_error(r->ctx));
-    std::vector<uint64_t> bits((size_t)(items + 63) / 64);
-    RM_HIP(r, hipMemcpy(bits.data(), r->d_bits, bits.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    for (int64_t i = 0; i < r->V; i++) {
-      const bool bad = ((bits[(size_t)i >> 6] >> (i & 63)) & 1) || !r->vpresent[(size_t)i];
-      r->vstat[(size_t)i] = bad ? V_INVALID : V_VALID; nv += bad;
-    }
-    for (int64_t i = 0; i < r->E; i++) {
-      const int64_t q = r->V + i;
-      const bool bad = ((bits[(size_t)q >> 6] >> (q & 63)) & 1) || !r->epresent[(size_t)i];
-      r->estat[(size_t)i] = bad ? V_INVALID : V_VALID; ne += bad;
+    // one kernel, one copy of the hit words into pinned memory, and a pass over WORDS, not items: a word without a hit and
+    // without a missing cache -- nearly all of them when the environment changes a little -- marks its 64 items valid at once
+    // (the per-item pass of round 3 was 0.4 of the call's 0.58 ms at 6.8 x 10^5 items, the kernel 0.115)
+    const size_t nw = (size_t)(items + 63) / 64;
+    RM_HIP(r, hipMemcpyAsync(r->h_bits, r->d_bits, nw * sizeof(uint64_t), hipMemcpyDeviceToHost, nullptr));
+    RM_HIP(r, hipStreamSynchronize(nullptr));
+    uint8_t *vs = r->vstat.data(), *es = r->estat.data();
+    const int64_t V = r->V;
+    for (size_t w = 0; w < nw; w++) {
+      const int64_t q0 = (int64_t)w * 64, q1 = std::min<int64_t>(q0 + 64, items);
+      uint64_t bad = r->h_bits[w] | r->absent[w];
+      if (q1 - q0 < 64) bad &= ((uint64_t)1 << (q1 - q0)) - 1;
+      if (bad == 0 && (q1 <= V || q0 >= V)) {
+        std::memset(q1 <= V ? vs + q0 : es + (q0 - V), V_VALID, (size_t)(q1 - q0));
+        continue;
+      }
+      for (int64_t q = q0; q < q1; q++) {
+        const bool b = (bad >> (q - q0)) & 1;
+        if (q < V) { vs[q] = b ? V_INVALID : V_VALID; nv += b; }
+        else { es[q - V] = b ? V_INVALID : V_VALID; ne += b; }
+      }
     }
   }
   if (n_invalid_vertices) *n_invalid_vertices = nv;

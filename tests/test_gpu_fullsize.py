@@ -295,3 +295,76 @@ def test_full_size_config4_stays_in_hbm_and_agrees_with_the_host_forms(irt):
     host = eng.validate_edges_indexed(verts, edges, *space)
     got = irt.unpack_bits(words["handed over"].cpu().numpy().view(np.uint64), ne)
     assert np.array_equal(got, host["valid"]) and 0.98 < got.mean() < 1.0 and host["n_domain_errors"] == 0
+
+
+def test_full_size_config5_query_loop(irt, orc, helpers):
+    """BASELINE configs[4] at full size: a 10^5-vertex roadmap with vertex and edge voxel caches (built and kept on the device), the
+    obstacle grid changed (8 more spheres), 10 000 start / goal queries through the lazy loop (tr_roadmap_solve) and through the
+    eager form (tr_roadmap_revalidate, then search) -- the oracle's sequential query loop on 320 sampled queries (status, path,
+    cost), the revalidation counts against the oracle's cached-set test of EVERY item, and every vertex and edge of every returned
+    path validated from scratch (FK + predicate, checkMotion) in the new environment."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=72)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
+    states, _ = rb.sample_valid_vertices(100000, batch=1 << 17)
+    edges = rb.knn_edges_gpu(states, 11)
+    valid, _ = rb.validate_edges(states, edges)
+    e_ok = edges[valid]                                        # createRoadmap removes invalid edges (:1543-1551)
+    vc, ec = rb.vertex_caches(states), rb.edge_caches(states, e_ok)
+    assert len(e_ok) > 500000 and vc["shape_valid"].all() and ec["fully_valid"].all()
+    vd, ed = rb.vertex_caches(states, device=True), rb.edge_caches(states, e_ok, device=True)
+    prm = irt.VoxelCachedLazyPRM(chk, states, e_ok)
+    prm.set_caches(vd, ed)
+    del vd, ed
+    prm.set_obstacles(new_vox)
+    nq = 10000
+    pairs = np.random.default_rng(17).integers(0, len(states), size=(nq, 2))
+    lazy = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    st_lazy = dict(prm.stats)
+    v_lazy, e_lazy = prm.validity()
+    assert st_lazy["rounds"] >= 2 and 0 < st_lazy["items_checked"] < 0.6 * (len(states) + len(e_ok))     # lazy: most items never looked at
+    solved = lazy["status"] == 0
+    assert 0.8 < solved.mean() < 1.0 and (lazy["status"] >= 2).any()
+    # the oracle: its own query loop on a sample of the queries; the cached-set test of every item
+    orb, og = helpers.oracle_robot(orc, robot, lib="omp"), helpers.oracle_grid(orc, new_vox)
+    hit_v = orc.check_cached(og, vc["block_ids"], vc["masks"], vc["offsets"])
+    hit_e = orc.check_cached(og, ec["block_ids"], ec["masks"], ec["offsets"])
+    assert np.array_equal(v_lazy[v_lazy > 0] == 2, hit_v[v_lazy > 0]) and np.array_equal(e_lazy[e_lazy > 0] == 2, hit_e[e_lazy > 0])
+    orm = orc.Roadmap(orb, states, e_ok, None, vc, ec, lib=orc.omp_lib())
+    code = {-2: 2, -3: 3, 0: 1}
+    sample = np.random.default_rng(18).choice(nq, 320, replace=False)
+    for q in sample:
+        w = orm.query(og, pairs[q, 0], pairs[q, 1])
+        assert lazy["status"][q] == (0 if w["n"] > 0 else code[w["n"]]), (q, w["n"], lazy["status"][q])
+        if w["n"] > 0:
+            assert lazy["cost"][q] == w["cost"] and np.array_equal(lazy["paths"][q], w["path"]), (q, w["cost"], lazy["cost"][q])
+    # eager: one pass over all 6.8 x 10^5 cached sets, then the same answers without a single item check
+    prm.clearValidity()
+    nv, ne = prm.revalidate()
+    assert nv == int(hit_v.sum()) > 0 and ne == int(hit_e.sum()) > 0
+    v_all, e_all = prm.validity()
+    assert np.array_equal(v_all == 2, hit_v) and np.array_equal(e_all == 2, hit_e) and (v_all > 0).all() and (e_all > 0).all()
+    eager = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    assert prm.stats["rounds"] <= 1 and prm.stats["items_checked"] == 0
+    assert np.array_equal(eager["status"], lazy["status"]) and np.array_equal(eager["cost"], lazy["cost"])
+    assert np.array_equal(eager["path_vertices"], lazy["path_vertices"]) and np.array_equal(eager["path_offsets"], lazy["path_offsets"])
+    # every returned path from scratch in the new environment
+    chk2 = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), new_vox)
+    pv = np.unique(lazy["path_vertices"])
+    assert chk2.is_valid(states[pv]).all()
+    po, pvx = lazy["path_offsets"], lazy["path_vertices"]
+    inner = np.ones(len(pvx), dtype=bool)
+    inner[po[1:][po[1:] > po[:-1]] - 1] = False                # the last vertex of every non-empty path starts no edge
+    a, b = pvx[:-1][inner[:-1]], pvx[1:][inner[:-1]]
+    und = np.unique(np.stack([np.minimum(a, b), np.maximum(a, b)], 1), axis=0)
+    assert len(und) > 20000
+    assert irt.VoxelBackboneMotionValidator(chk2).check_motion(states[und[:, 0]], states[und[:, 1]]).all()
+    # a path's ends are the query's, its cost the sum of its edges' state-space distances (tension-only space: Euclidean)
+    for q in np.flatnonzero(solved)[:200]:
+        p = lazy["paths"][q]
+        assert p[0] == pairs[q, 0] and p[-1] == pairs[q, 1]
+        d = sum(np.linalg.norm(states[x] - states[y]) for x, y in zip(p[:-1], p[1:]))
+        assert abs(d - lazy["cost"][q]) <= 1e-12 * max(1.0, d)
