@@ -47,15 +47,16 @@ def algorithmic_flops_per_rk4_step(N):
     as written -- independent of what the compiler emits, so that executing more instructions cannot raise the fraction:
       per tendon and evaluation   128   (pd 10, |pd|^2 5, rsqrt + Newton 7, c / q / sdot 7, A 12 + 1, e / g 8, B 18, H 12,
                                          Q / P 10, w 13, pd.w 5, a_i 12, b 8)
-      tendon-independent          272   (rhat / rhat^2 folds 5, K u / K (v - e3) 7, c 24, d 12, M11 5, its adjugate 18,
-                                         1 / det 10, M11^-1 6, y 15, T = B M11^-1 45, Schur complement 43, rhs 18, adjugate 18,
-                                         1 / det 10, u' 18, v' 18)
+      tendon-independent          241   (rhat / rhat^2 folds 5, K u / K (v - e3) 7, c 24, d 12, M11 5, K_bt + H 7, and the
+                                         6 x 6 solve as an unrolled L D L^T: 35 FMAs + 15 products + 6 reciprocals (5 each) to
+                                         factor, 30 FMAs + 6 products for the two triangular solves = 181; rounds 2 - 3 ran the
+                                         two-adjugate Schur form, 272 in all)
       per stage                   78 + 2 N   (p quadrature 21, L_i 2 N, R' = R u^ 27, accumulators 30), + 30 stage state x 3
-      per step                    4 (128 N + 272 + 78 + 2 N) + 90 + 3
-    = 3 053 (N = 3), 3 573 (N = 4); the gfx950 ISA of the same source executes 3 089 / 3 621 (profiles/isa_counts.json).
+      per step                    4 (128 N + 241 + 78 + 2 N) + 90 + 3
+    = 2 929 (N = 3), 3 449 (N = 4) (rounds 2 - 3: 3 053 / 3 573); what the gfx950 ISA of the same source executes: profiles/isa_counts.json.
     DESIGN.md section 5 carries the derivation; SURVEY 8(d)'s 1.1 Mflop per check is the reference's formulation as written
     (dense 3x3 products, two general inverses), which this kernel does not execute."""
-    return 4 * (128 * N + 272 + 78 + 2 * N) + 93
+    return 4 * (128 * N + 241 + 78 + 2 * N) + 93
 
 
 def host_core_share(omp_max):

@@ -15,9 +15,9 @@
 //    tabulated once on the host for the 3 distinct stage abscissae of every step and read through
 //    wave-uniform scalar loads (SGPR operands) -- no per-lane transcendental in the hot loop;
 //  * the right-hand side exploits structure the reference leaves to Eigen: r has no z component,
-//    A_i is symmetric, G = B^T, H is symmetric, K_se/K_bt are diagonal, and the 6x6 solve is a
-//    symmetric block (Schur) elimination with adjugate 3x3 inverses: [v';u'] = M^-1 [d;c] with
-//    M = [[K_se+A, B^T],[B, K_bt+H]];
+//    A_i is symmetric, G = B^T, H is symmetric, K_se/K_bt are diagonal, and the 6x6 solve
+//    [v';u'] = M^-1 [d;c] with M = [[K_se+A, B^T],[B, K_bt+H]] is an unrolled symmetric L D L^T
+//    factorisation (round 4; before: block elimination with adjugate 3x3 inverses);
 //  * (p, L, L_i) are pure quadratures (nothing depends on them), so they keep no stage copy.
 //  * __launch_bounds__(64, 2): two waves per SIMD (<= 256 registers) measured 16 % faster than the
 //    365-register single-wave allocation the compiler picks when unconstrained.
@@ -137,6 +137,59 @@ __device__ __forceinline__ void strain_rates_routed(const double v[3], const dou
   // M11 = K_se + A - Z I (symmetric); inverse by adjugate
   const double ksz0 = K.ks0 - Z, ksz2 = K.ks2 - Z;
   const double m00 = ksz0 + Axx, m01 = Axy, m02 = Axz, m11 = ksz0 + Ayy, m12 = Ayz, m22 = ksz2 + Azz;
+#ifndef TRK_SOLVE_SCHUR
+  // The symmetric 6 x 6 system [[M11, B^T], [B, K_bt + H]] [v'; u'] = [d; c] by an unrolled L D L^T factorisation without pivoting:
+  // 35 FMAs, 15 products and six reciprocals to factor, 36 operations for the two triangular solves (181 flops, ~105 instructions).
+  // Round 4's A/B against the two-adjugate Schur form below (272 flops with its set-up, ~132 instructions, two reciprocals;
+  // -DTRK_SOLVE_SCHUR): the bare RK4 loop 7.84 -> 7.56 ms per 2^20 (N = 3), 4.75 -> 4.61 ms per 2^19 (N = 4), fk_verdict
+  // 8.27 -> 8.00 / 5.02 -> 4.93 ms (profiles/r04/kbench_ldlt_v1.txt); the six reciprocals' dependent chain is covered by the SIMD's
+  // other wave.  Backbone points stay within 1e-14 m of the Schur form's (tests: 1e-9 m of the oracle).
+  {
+    // (no contraction beyond the FMAs written out: every kernel that holds this body then forms the same bits)
+#pragma clang fp contract(off)
+    const double n00 = (K.kb0 - P3) + Hxx, n01 = Hxy, n02 = Hxz, n11 = (K.kb0 - P1) + Hyy, n12 = Hyz, n22 = ((K.kb2 - P1) - P3) + Hzz;
+    const double p0 = m00;
+    const double r0 = fast_rcp(p0);
+    const double w10 = m01, l10 = w10 * r0;
+    const double w20 = m02, l20 = w20 * r0;
+    const double w30 = B00, l30 = w30 * r0;
+    const double w40 = B10, l40 = w40 * r0;
+    const double w50 = B20, l50 = w50 * r0;
+    const double p1 = TRK_FMA(-l10, w10, m11);
+    const double r1 = fast_rcp(p1);
+    const double w21 = TRK_FMA(-l20, w10, m12), l21 = w21 * r1;
+    const double w31 = TRK_FMA(-l30, w10, B01), l31 = w31 * r1;
+    const double w41 = TRK_FMA(-l40, w10, B11), l41 = w41 * r1;
+    const double w51 = TRK_FMA(-l50, w10, B21), l51 = w51 * r1;
+    const double p2 = TRK_FMA(-l21, w21, TRK_FMA(-l20, w20, m22));
+    const double r2 = fast_rcp(p2);
+    const double w32 = TRK_FMA(-l31, w21, TRK_FMA(-l30, w20, B02)), l32 = w32 * r2;
+    const double w42 = TRK_FMA(-l41, w21, TRK_FMA(-l40, w20, B12)), l42 = w42 * r2;
+    const double w52 = TRK_FMA(-l51, w21, TRK_FMA(-l50, w20, B22)), l52 = w52 * r2;
+    const double p3 = TRK_FMA(-l32, w32, TRK_FMA(-l31, w31, TRK_FMA(-l30, w30, n00)));
+    const double r3 = fast_rcp(p3);
+    const double w43 = TRK_FMA(-l42, w32, TRK_FMA(-l41, w31, TRK_FMA(-l40, w30, n01))), l43 = w43 * r3;
+    const double w53 = TRK_FMA(-l52, w32, TRK_FMA(-l51, w31, TRK_FMA(-l50, w30, n02))), l53 = w53 * r3;
+    const double p4 = TRK_FMA(-l43, w43, TRK_FMA(-l42, w42, TRK_FMA(-l41, w41, TRK_FMA(-l40, w40, n11))));
+    const double r4 = fast_rcp(p4);
+    const double w54 = TRK_FMA(-l53, w43, TRK_FMA(-l52, w42, TRK_FMA(-l51, w41, TRK_FMA(-l50, w40, n12)))), l54 = w54 * r4;
+    const double p5 = TRK_FMA(-l54, w54, TRK_FMA(-l53, w53, TRK_FMA(-l52, w52, TRK_FMA(-l51, w51, TRK_FMA(-l50, w50, n22)))));
+    const double r5 = fast_rcp(p5);
+    const double y0 = dx;
+    const double y1 = TRK_FMA(-l10, y0, dy);
+    const double y2 = TRK_FMA(-l21, y1, TRK_FMA(-l20, y0, dz));
+    const double y3 = TRK_FMA(-l32, y2, TRK_FMA(-l31, y1, TRK_FMA(-l30, y0, cx)));
+    const double y4 = TRK_FMA(-l43, y3, TRK_FMA(-l42, y2, TRK_FMA(-l41, y1, TRK_FMA(-l40, y0, cy))));
+    const double y5 = TRK_FMA(-l54, y4, TRK_FMA(-l53, y3, TRK_FMA(-l52, y2, TRK_FMA(-l51, y1, TRK_FMA(-l50, y0, cz)))));
+    const double x5 = y5 * r5;
+    const double x4 = TRK_FMA(-l54, x5, y4 * r4);
+    const double x3 = TRK_FMA(-l53, x5, TRK_FMA(-l43, x4, y3 * r3));
+    const double x2 = TRK_FMA(-l52, x5, TRK_FMA(-l42, x4, TRK_FMA(-l32, x3, y2 * r2)));
+    const double x1 = TRK_FMA(-l51, x5, TRK_FMA(-l41, x4, TRK_FMA(-l31, x3, TRK_FMA(-l21, x2, y1 * r1))));
+    const double x0 = TRK_FMA(-l50, x5, TRK_FMA(-l40, x4, TRK_FMA(-l30, x3, TRK_FMA(-l20, x2, TRK_FMA(-l10, x1, y0 * r0)))));
+    dv[0] = x0; dv[1] = x1; dv[2] = x2; du[0] = x3; du[1] = x4; du[2] = x5;
+  }
+#else
   const double c00 = TRK_FMA(m11, m22, -(m12 * m12)), c01 = TRK_FMA(m02, m12, -(m01 * m22)), c02 = TRK_FMA(m01, m12, -(m02 * m11));
   const double c11 = TRK_FMA(m00, m22, -(m02 * m02)), c12 = TRK_FMA(m01, m02, -(m00 * m12)), c22 = TRK_FMA(m00, m11, -(m01 * m01));
   const double idet = fast_rcp(TRK_FMA(m00, c00, TRK_FMA(m01, c01, m02 * c02)));
@@ -174,6 +227,7 @@ __device__ __forceinline__ void strain_rates_routed(const double v[3], const dou
   dv[0] = TRK_FMA(-T20, du[2], TRK_FMA(-T10, du[1], TRK_FMA(-T00, du[0], yx)));
   dv[1] = TRK_FMA(-T21, du[2], TRK_FMA(-T11, du[1], TRK_FMA(-T01, du[0], yy_)));
   dv[2] = TRK_FMA(-T22, du[2], TRK_FMA(-T12, du[1], TRK_FMA(-T02, du[0], yz)));
+#endif
 #undef TRK_FMA
 }
 

@@ -1,7 +1,8 @@
 // fused_kernel.hpp -- K1 + K2 in one launch for the verdict path (tr_validate_batch*): every wave
 // integrates its 64 configurations (fk_uniform_body), then sweeps the backbones it has just stored
-// (sweep_body) -- same code, same arithmetic, same memory layout as the two separate kernels, so
-// results are identical bit for bit.  What changes is the schedule: a SIMD holds two waves, and
+// (sweep_body) -- same code, same arithmetic, same memory layout as the two separate kernels: the
+// verdicts and flags are the same; the points agree to rounding (hipcc pairs the multiply-adds of a sum
+// of products per kernel: one ulp in about a hundredth of the backbones).  What changes is the schedule: a SIMD holds two waves, and
 // while one is in its sweep (latency-bound: loads, cell tests) the other is in its RK4 steps
 // (fp64-VALU-bound), so the sweep runs in issue slots and memory latency the FK leaves idle, and
 // there is no second launch with its own ramp and tail.  The points are read back by the lane that
