@@ -190,7 +190,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
     ps.sigst.init(); ps.sig_row_of = -1; ps.sig_first_row = 0; ps.sig_row0 = h; ps.sig_cnt = cnt;
     __syncthreads();                    // (the previous round's LDS scratch is dead)
-    VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
+    VL_U(VLay<true>::HIT + lane) = 0u; VL_U(VLay<true>::INPREV + lane) = 0u; VL_F(VLay<true>::DIST + lane) = 0.0f;
     __syncthreads();
     // fk_uniform_body takes lane l of block b as configuration 64 b + l of `states`, live below n: shift both so that it is slot h + l
     const int S = K.state_size;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     LaneVerdict lv;
     {
       const VerdictArgs a = *va;
-      lv = verdict_decide<N, false>(a, fl_, live);
+      lv = verdict_decide<N, false, true>(a, fl_, live);
     }
     int zero2 = 0;
     asm volatile("" : "+s"(zero2));

@@ -78,25 +78,43 @@ struct alignas(128) VerdictArgs {
   }
 };
 
-constexpr int VQ = 128;           // ring of deferred segments per wave
-
 // Dynamic LDS of one wave.  Everything is addressed as vlds[constant + lane] (never through a stored pointer: hipcc then
 // keeps the accesses in the LDS address space -- ds_read / ds_write -- instead of falling back to flat accesses).
 //   doubles [0, 192)           prev[3][64]     previous point (as produced, before the environment rotation)
 //   doubles [192, 192 + 6 VQ)  qe[6][VQ]       deferred segments: rotated end points a, b
 //   words from 2 * (192 + 6 VQ):  qowner[VQ] | cell[3][64] | inprev[64] | hitflag[64] | dist[64] | delta[64] (SPH) / nearw[64] | milestones float[4][NM][64]
+// VQ, the ring of deferred segments, is flushed 64 at a time as soon as VQ - 64 are queued (a point can queue 64 more): 128 entries and
+// a flush per 64 for the plain kernels.  With signatures (edge samples) the image also holds the signature tile of SigStage
+// (sweep_kernel.hpp) behind the milestones, and at 128 entries it was exactly 20 KiB at 8 milestones -- an eighth of a CU's LDS,
+// with no room for the 2 KiB of the 4-tendon robots' tendon-length quadratures (fk_kernel.hpp: li_in_lds), which stayed in 38
+// spilled registers (104 B of scratch per lane, 2.1x the algorithmic HBM traffic).  Round 4: 88 entries there (a flush per 24
+// deferred segments: ~10 instead of ~4 per backbone, each a DDA walk of the queued lanes, < 0.5 % of the instructions) and the
+// owners as bytes: 18 136 B + 2 048 B of quadratures = 19.7 KiB.
 extern __shared__ double vlds[];
-constexpr int VL_QE = 3 * 64;
-constexpr int VL_W0 = 2 * (VL_QE + 6 * VQ);
-constexpr int VL_QOWNER = VL_W0, VL_CELL = VL_QOWNER + VQ, VL_INPREV = VL_CELL + 3 * 64, VL_HIT = VL_INPREV + 64,
-              VL_DIST = VL_HIT + 64, VL_DELTA = VL_DIST + 64, VL_MS = VL_DELTA + 64;
-// voxel checker: delta[] is unused and holds the requested half of the dilated-grid word of the previous point's block instead
-constexpr int VL_NEARW = VL_DELTA;
-// with signatures (edge samples) the tile of SigStage (sweep_kernel.hpp) follows the milestones: 18 176 + 2 304 B = exactly
-// 20 KiB per wave at NM = 8, eight waves per CU still fit the 160 KiB (the plain 4-tendon kernels add 2 KiB of static LDS for
-// their tendon-length quadratures: 19.75 KiB)
+#ifndef TRK_SIG_VQ
+#define TRK_SIG_VQ 88            // (A/B: 128 = round 3's layout, the quadratures of the signature kernels then stay in registers)
+#endif
+template <bool SIG>
+struct VLay {
+  static constexpr int VQ = SIG ? TRK_SIG_VQ : 128;
+  static constexpr int QE = 3 * 64;                                         // doubles
+  static constexpr int W0 = 2 * (QE + 6 * VQ);                              // words from here on
+  static constexpr int QOWNER = W0, OWNER_WORDS = SIG ? (VQ + 3) / 4 : VQ;  // owner lanes: bytes with signatures, words without
+  static constexpr int CELL = QOWNER + OWNER_WORDS, INPREV = CELL + 3 * 64, HIT = INPREV + 64, DIST = HIT + 64, DELTA = DIST + 64, MS = DELTA + 64;
+  // voxel checker: delta[] is unused and holds the requested half of the dilated-grid word of the previous point's block instead
+  static constexpr int NEARW = DELTA;
+  __device__ static __forceinline__ int wrap(int i) {                       // ring index, i < 2 VQ
+    if constexpr ((VQ & (VQ - 1)) == 0) return i & (VQ - 1); else return i >= VQ ? i - VQ : i;
+  }
+  __device__ static __forceinline__ void set_owner(int slot, int lane) {
+    if constexpr (SIG) ((uint8_t *)vlds)[4 * QOWNER + slot] = (uint8_t)lane; else ((uint32_t *)vlds)[QOWNER + slot] = (uint32_t)lane;
+  }
+  __device__ static __forceinline__ int owner(int slot) {
+    if constexpr (SIG) return (int)((const uint8_t *)vlds)[4 * QOWNER + slot]; else return (int)((const uint32_t *)vlds)[QOWNER + slot];
+  }
+};
 __host__ __device__ inline size_t verdict_lds_bytes(int NM, bool with_sig = false) {
-  return (size_t)VL_MS * 4 + (size_t)4 * NM * 64 * sizeof(float) + (with_sig ? (size_t)SIG_LDS_WORDS * 4 : 0);
+  return (size_t)(with_sig ? VLay<true>::MS : VLay<false>::MS) * 4 + (size_t)4 * NM * 64 * sizeof(float) + (with_sig ? (size_t)SIG_LDS_WORDS * 4 : 0);
 }
 
 // (plain accesses: hipcc does not move `volatile` ones into the LDS address space; the compiler barriers at both ends of
@@ -112,17 +130,17 @@ __host__ __device__ inline size_t verdict_lds_bytes(int NM, bool with_sig = fals
 // verdict kernels carry none of it.
 template <bool SPH, bool SIG = false>
 struct PointSweep {
+  using Lay = VLay<SIG>;
+  static constexpr int VQ = Lay::VQ;
   // fk_uniform_body keeps the 4-tendon robots' tendon-length quadratures in LDS when this hook sits in its loop (fk_kernel.hpp:
-  // li_in_lds).  Not with signatures: that kernel's LDS image is exactly an eighth of the CU's at 8 milestones (below), and a
-  // ninth 2 KB would cost it a wave per CU -- measured -11 % (a ring of 64 deferred segments, emptied BEFORE a push that would
-  // not fit, would make the room, but the second flush site spills 20 more registers in every variant).
-  static constexpr int kLiInLdsFrom = SIG ? (1 << 30) : 4;   // (3 tendons: 2 spilled dwords, nothing to gain)
+  // li_in_lds); with signatures too since round 4 made the room (VLay).  (3 tendons: 2 spilled dwords, nothing to gain)
+  static constexpr int kLiInLdsFrom = (SIG && TRK_SIG_VQ > 88) ? (1 << 30) : 4;
   const VerdictArgs *va;
   float dn_prev;                  // SPH: distance-field value at the previous point's cell (requested one point ahead)
   uint32_t sph_state;             // SPH: bit 0 = the previous point awaits its classification, bit 1 = it lies inside the closed domain
   int qhead, qcount;              // wave-uniform
   int P, CH, NM, Kl, ms_next, ms_k;   // wave-uniform: point count, milestone spacing / count, last milestone, next milestone row / index
-  SigStage sigst;                 // ... through this LDS tile (words [VL_MS + 4 NM 64, + SIG_LDS_WORDS) of the wave's image)
+  SigStage sigst;                 // ... through this LDS tile (words [Lay::MS + 4 NM 64, + SIG_LDS_WORDS) of the wave's image)
   // the sample whose row this lane writes (-1: none) and its first point that goes through the tile: lane-private for the
   // retraction kernel (a permuted batch, the first two points in rows of the lane's own); the shared-grid kernel forms them
   // from sig_n on the fly
@@ -138,14 +156,14 @@ struct PointSweep {
     sig_row0 = (int)r0; sig_cnt = left >= 64 ? 64 : (left > 0 ? (int)left : 0);
   }
   __device__ __forceinline__ void sig_put(const VerdictArgs &a, int row, bool on, uint32_t value, int row_of, int first_row) {
-    const int base = VL_MS + 4 * NM * 64;
+    const int base = Lay::MS + 4 * NM * 64;
     sigst.put([base](int i) -> uint32_t & { return VL_U(base + i); }, a.sig, a.sig_stride, row_of, first_row, row, on, value);
   }
   template <bool RETRACT>
   __device__ __forceinline__ void sig_finish() {
     if constexpr (SIG) {
       const VerdictArgs &a = args();
-      const int base = VL_MS + 4 * NM * 64;
+      const int base = Lay::MS + 4 * NM * 64;
       sigst.flush([base](int i) -> uint32_t & { return VL_U(base + i); }, a.sig, a.sig_stride, RETRACT ? sig_row_of : sig_own_row(),
                   RETRACT ? sig_first_row : 0);
     }
@@ -173,9 +191,9 @@ struct PointSweep {
       const GridK &g = a.g;
       const double radius = a.radius;
       for (int e = 0; e < cnt; e++) {
-        const int slot = (qhead + e) & (VQ - 1);
-        const double sx = VL_D(VL_QE + 0 * VQ + slot), sy = VL_D(VL_QE + 1 * VQ + slot), sz = VL_D(VL_QE + 2 * VQ + slot);
-        const int owner = (int)VL_U(VL_QOWNER + slot);
+        const int slot = Lay::wrap(qhead + e);
+        const double sx = VL_D(Lay::QE + 0 * VQ + slot), sy = VL_D(Lay::QE + 1 * VQ + slot), sz = VL_D(Lay::QE + 2 * VQ + slot);
+        const int owner = Lay::owner(slot);
         bool found = false;
         {
           // add_point (VoxelOctree.cpp:319-323): the point's own cell, if the point is inside the closed domain
@@ -188,23 +206,23 @@ struct PointSweep {
           }
         }
         if (!found) found = sphere_scan_wave(sx, sy, sz, radius, g, a.grid, lane);
-        if (found && lane == 0) atomicOr(&((uint32_t *)vlds)[VL_HIT + owner], 1u);
+        if (found && lane == 0) atomicOr(&((uint32_t *)vlds)[Lay::HIT + owner], 1u);
       }
     } else
     if (lane < cnt) {
-      const int slot = (qhead + lane) & (VQ - 1);
-      const V3 pa = {VL_D(VL_QE + 0 * VQ + slot), VL_D(VL_QE + 1 * VQ + slot), VL_D(VL_QE + 2 * VQ + slot)};
-      const V3 pb = {VL_D(VL_QE + 3 * VQ + slot), VL_D(VL_QE + 4 * VQ + slot), VL_D(VL_QE + 5 * VQ + slot)};
-      const int owner = (int)VL_U(VL_QOWNER + slot);
+      const int slot = Lay::wrap(qhead + lane);
+      const V3 pa = {VL_D(Lay::QE + 0 * VQ + slot), VL_D(Lay::QE + 1 * VQ + slot), VL_D(Lay::QE + 2 * VQ + slot)};
+      const V3 pb = {VL_D(Lay::QE + 3 * VQ + slot), VL_D(Lay::QE + 4 * VQ + slot), VL_D(Lay::QE + 5 * VQ + slot)};
+      const int owner = Lay::owner(slot);
       V3 A, B;
       bool inside, bad = false, h = false;
       if (line_setup(pa, pb, a.g, A, B, inside, bad)) {
         GridCursor wc{a.grid, a.g.Nb, -1, 0ull};
         h = walk_cells(A, B, a.g, [&](int x, int y, int z) { return wc.occupied(x, y, z); });
       }
-      if (h || bad) atomicOr(&((uint32_t *)vlds)[VL_HIT + owner], (h ? 1u : 0u) | (bad ? 2u : 0u));
+      if (h || bad) atomicOr(&((uint32_t *)vlds)[Lay::HIT + owner], (h ? 1u : 0u) | (bad ? 2u : 0u));
     }
-    qhead = (qhead + cnt) & (VQ - 1);
+    qhead = Lay::wrap(qhead + cnt);
     qcount -= cnt;
     __syncthreads();
   }
@@ -231,7 +249,7 @@ struct PointSweep {
     // occupied centre is at least field - delta and -- the nearest one -- at most field + delta away from it
     const float ex = (float)(cx - (g.xmin + g.dx * ((double)ix + 0.5))), ey = (float)(cy - (g.ymin + g.dy * ((double)iy + 0.5))),
                 ez = (float)(cz - (g.zmin + g.dz * ((double)iz + 0.5)));
-    VL_F(VL_DELTA + threadIdx.x) = sqrtf(ex * ex + ey * ey + ez * ez) * 1.000001f;
+    VL_F(Lay::DELTA + threadIdx.x) = sqrtf(ex * ex + ey * ey + ez * ez) * 1.000001f;
   }
 
   // after the RK4 loop.  SPH: the last point's classification (its field value was requested when it was produced)
@@ -244,16 +262,16 @@ struct PointSweep {
       const int lane = threadIdx.x;
       bool need = false;
       V3 pr = {VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)};
-      if (active && !VL_U(VL_HIT + lane) && (sph_state & 1u)) {
+      if (active && !VL_U(Lay::HIT + lane) && (sph_state & 1u)) {
         if (!g.rot_is_identity) {
           const V3 pv = pr;
           pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
           pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
           pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
         }
-        const float dl = VL_F(VL_DELTA + lane);
+        const float dl = VL_F(Lay::DELTA + lane);
         if (dn_prev - dl > a.r_hi) {}
-        else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+        else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(Lay::HIT + lane) = 1u;
         else need = true;
       }
       sph_state = 0;
@@ -261,9 +279,9 @@ struct PointSweep {
       if (wm) {
         if (qcount + __popcll(wm) > VQ) flush();
         if (need) {
-          const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
-          VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
-          VL_U(VL_QOWNER + slot) = (uint32_t)lane;
+          const int slot = Lay::wrap(qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1)));
+          VL_D(Lay::QE + 0 * VQ + slot) = pr.x; VL_D(Lay::QE + 1 * VQ + slot) = pr.y; VL_D(Lay::QE + 2 * VQ + slot) = pr.z;
+          Lay::set_owner(slot, lane);
         }
         qcount += __popcll(wm);
       }
@@ -314,20 +332,20 @@ struct PointSweep {
     const int lane = threadIdx.x;
     const int cqx = c[0], cqy = c[1], cqz = c[2];
     const bool use_near = h.use_near != 0;
-    const uint32_t was_in = VL_U(VL_INPREV + lane);
-    const int cpx = VL_I(VL_CELL + lane), cpy = VL_I(VL_CELL + 64 + lane), cpz = VL_I(VL_CELL + 128 + lane);
+    const uint32_t was_in = VL_U(Lay::INPREV + lane);
+    const int cpx = VL_I(Lay::CELL + lane), cpy = VL_I(Lay::CELL + 64 + lane), cpz = VL_I(Lay::CELL + 128 + lane);
     const uint32_t ex = (uint32_t)(cqx - cpx + 1), ey = (uint32_t)(cqy - cpy + 1), ez = (uint32_t)(cqz - cpz + 1);   // 0, 1, 2: neighbours
     const uint32_t emax = ex > ey ? (ex > ez ? ex : ez) : (ey > ez ? ey : ez);
     // the half of the dilated-grid word of the previous point's block that holds its cell's bit: requested when that point
     // was produced, delivered straight into LDS (no register lives across the RK4 step for it)
     const uint32_t bit = (uint32_t)(((cpx & 1) << 4) | ((cpy & 3) << 2) | (cpz & 3));
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // (the compiler does not order LDS reads after loads into LDS; a whole RK4 step has passed)
-    uint32_t near_bit = (VL_U(VL_NEARW + lane) >> bit) & 1u;
+    uint32_t near_bit = (VL_U(Lay::NEARW + lane) >> bit) & 1u;
     const bool start_free = use_near & (near_bit == 0u);
     // otherwise (also at the domain boundary): the full reference path, in the flush
     const bool need = !first & !((was_in != 0u) & in_q & (emax <= 2u) & start_free);
-    VL_I(VL_CELL + lane) = cqx; VL_I(VL_CELL + 64 + lane) = cqy; VL_I(VL_CELL + 128 + lane) = cqz;
-    VL_U(VL_INPREV + lane) = in_q ? 1u : 0u;
+    VL_I(Lay::CELL + lane) = cqx; VL_I(Lay::CELL + 64 + lane) = cqy; VL_I(Lay::CELL + 128 + lane) = cqz;
+    VL_U(Lay::INPREV + lane) = in_q ? 1u : 0u;
     {
       // request the half word of q's block for the next point: a global load whose destination is LDS word nearw[lane]
       // (global_load_lds_dword; counted by vmcnt, no destination register), half word 0 for lanes outside the box, whose
@@ -338,7 +356,7 @@ struct PointSweep {
       asm volatile("" : "+v"(w) : "v"(near_bit));
       typedef __attribute__((address_space(3))) uint32_t *lds_u32_ptr;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) uint32_t *)h.near_grid + w,
-                                       (lds_u32_ptr)((uint32_t *)vlds + VL_NEARW), 4, 0, 0);
+                                       (lds_u32_ptr)((uint32_t *)vlds + Lay::NEARW), 4, 0, 0);
     }
     return need;
   }
@@ -362,15 +380,15 @@ struct PointSweep {
     const V3 q = {x, y, z};
     V3 pv = q;
     float d = 0.0f;
-    if (j > 0) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(VL_DIST + lane); }
+    if (j > 0) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(Lay::DIST + lane); }
     {
       const float dx = (float)(q.x - pv.x), dy = (float)(q.y - pv.y), dz = (float)(q.z - pv.z);
       d += __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);   // v_sqrt_f32 (1 ulp): the proof keeps 1e-6 m of slack over ~1e-8 m of rounding
-      VL_F(VL_DIST + lane) = d;
+      VL_F(Lay::DIST + lane) = d;
     }
     if (j == ms_next) {                                     // wave-uniform: every CH-th point and the tip (ms_next = min(k CH, P - 1))
       const int CH_ = a.hot.CH, P_ = a.hot.P;               // (from the argument block: they hold no registers between milestones)
-      const int o = VL_MS + ms_k * 64 + lane, pl = a.NM * 64;     // the tip's slot: ceil((P - 1) / CH) = the count of milestones before it
+      const int o = Lay::MS + ms_k * 64 + lane, pl = a.NM * 64;     // the tip's slot: ceil((P - 1) / CH) = the count of milestones before it
       VL_F(o) = (float)q.x; VL_F(o + pl) = (float)q.y; VL_F(o + 2 * pl) = (float)q.z; VL_F(o + 3 * pl) = d;
       ms_next = (ms_next + CH_ < P_ - 1) ? ms_next + CH_ : P_ - 1;
       ms_k++;
@@ -388,7 +406,7 @@ struct PointSweep {
       if constexpr (SIG) sig_put(a, j, true, cell_signature(x, y, z, g), sig_own_row(), 0);
     }
     if constexpr (SPH) {
-      if (active && !VL_U(VL_HIT + lane)) {
+      if (active && !VL_U(Lay::HIT + lane)) {
         // the previous point's field value has arrived: far from every occupied centre, certainly within r of one, or
         // in the shell between -- then the point is queued for the exact scan
         if (sph_state & 1u) {
@@ -397,27 +415,27 @@ struct PointSweep {
             pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
             pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
           }
-          const float dl = VL_F(VL_DELTA + lane);
+          const float dl = VL_F(Lay::DELTA + lane);
           if (dn_prev - dl > a.r_hi) {}
-          else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+          else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(Lay::HIT + lane) = 1u;
           else need = true;
         }
         sph_state = 0;
-        if (!VL_U(VL_HIT + lane)) request(a, q);
+        if (!VL_U(Lay::HIT + lane)) request(a, q);
       }
     } else
-    if (active && !VL_U(VL_HIT + lane)) need = voxel_test(a.hot, j == 0, in_q, cq);
+    if (active && !VL_U(Lay::HIT + lane)) need = voxel_test(a.hot, j == 0, in_q, cq);
     const unsigned long long wm = __ballot(need);
     if (wm) {
       if (need) {
         if constexpr (!SPH) pr = to_voxel_frame(a, pv);
-        const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
-        VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
-        if constexpr (!SPH) { VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z; }
-        VL_U(VL_QOWNER + slot) = (uint32_t)lane;
+        const int slot = Lay::wrap(qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1)));
+        VL_D(Lay::QE + 0 * VQ + slot) = pr.x; VL_D(Lay::QE + 1 * VQ + slot) = pr.y; VL_D(Lay::QE + 2 * VQ + slot) = pr.z;
+        if constexpr (!SPH) { VL_D(Lay::QE + 3 * VQ + slot) = qr.x; VL_D(Lay::QE + 4 * VQ + slot) = qr.y; VL_D(Lay::QE + 5 * VQ + slot) = qr.z; }
+        Lay::set_owner(slot, lane);
       }
       qcount += __popcll(wm);
-      if (qcount >= 64) flush();
+      if (qcount >= VQ - 64) flush();
     }
     VL_BARRIER();
   }
@@ -458,12 +476,12 @@ struct PointSweep {
     }
     if (on) {
       float d = 0.0f;
-      if (!first) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(VL_DIST + lane); }
+      if (!first) { pv = V3{VL_D(lane), VL_D(64 + lane), VL_D(128 + lane)}; d = VL_F(Lay::DIST + lane); }
       pr = pv;
       {
         const float dx = (float)(q.x - pv.x), dy = (float)(q.y - pv.y), dz = (float)(q.z - pv.z);
         d += __builtin_amdgcn_sqrtf(dx * dx + dy * dy + dz * dz);   // v_sqrt_f32 (1 ulp): the proof keeps 1e-6 m of slack over ~1e-8 m of rounding
-        VL_F(VL_DIST + lane) = d;
+        VL_F(Lay::DIST + lane) = d;
       }
       {
         // back = rows to the tip; k = back / CH through a float quotient (back < 2^16, CH <= 48: (back + 1/2) / CH is at
@@ -473,41 +491,41 @@ struct PointSweep {
         const bool ms_row = (back - k * CH) == 0;
         if (first || ms_row) {
           const int slot = (first && !ms_row) ? k + 1 : k;
-          const int o = VL_MS + slot * 64 + lane, pl = NM * 64;
+          const int o = Lay::MS + slot * 64 + lane, pl = NM * 64;
           VL_F(o) = (float)q.x; VL_F(o + pl) = (float)q.y; VL_F(o + 2 * pl) = (float)q.z; VL_F(o + 3 * pl) = -d;
         }
       }
       VL_D(lane) = q.x; VL_D(64 + lane) = q.y; VL_D(128 + lane) = q.z;
       if constexpr (SPH) {
-        if (active && !VL_U(VL_HIT + lane)) {
+        if (active && !VL_U(Lay::HIT + lane)) {
           if (sph_state & 1u) {
             if (!g.rot_is_identity) {
               pr.x = g.inv_rot[0] * pv.x + g.inv_rot[1] * pv.y + g.inv_rot[2] * pv.z;
               pr.y = g.inv_rot[3] * pv.x + g.inv_rot[4] * pv.y + g.inv_rot[5] * pv.z;
               pr.z = g.inv_rot[6] * pv.x + g.inv_rot[7] * pv.y + g.inv_rot[8] * pv.z;
             }
-            const float dl = VL_F(VL_DELTA + lane);
+            const float dl = VL_F(Lay::DELTA + lane);
             if (dn_prev - dl > a.r_hi) {}
-            else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(VL_HIT + lane) = 1u;
+            else if ((sph_state & 2u) && dn_prev + dl < a.r_lo) VL_U(Lay::HIT + lane) = 1u;
             else need = true;
           }
           sph_state = 0;
-          if (!VL_U(VL_HIT + lane)) request(a, q);
+          if (!VL_U(Lay::HIT + lane)) request(a, q);
         }
       } else
-      if (active && !VL_U(VL_HIT + lane)) need = voxel_test(a.hot, first, in_q, cq);
+      if (active && !VL_U(Lay::HIT + lane)) need = voxel_test(a.hot, first, in_q, cq);
     }
     const unsigned long long wm = __ballot(need);
     if (wm) {
       if (need) {
         if constexpr (!SPH) pr = to_voxel_frame(a, pv);
-        const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & (VQ - 1);
-        VL_D(VL_QE + 0 * VQ + slot) = pr.x; VL_D(VL_QE + 1 * VQ + slot) = pr.y; VL_D(VL_QE + 2 * VQ + slot) = pr.z;
-        if constexpr (!SPH) { VL_D(VL_QE + 3 * VQ + slot) = qr.x; VL_D(VL_QE + 4 * VQ + slot) = qr.y; VL_D(VL_QE + 5 * VQ + slot) = qr.z; }
-        VL_U(VL_QOWNER + slot) = (uint32_t)lane;
+        const int slot = Lay::wrap(qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1)));
+        VL_D(Lay::QE + 0 * VQ + slot) = pr.x; VL_D(Lay::QE + 1 * VQ + slot) = pr.y; VL_D(Lay::QE + 2 * VQ + slot) = pr.z;
+        if constexpr (!SPH) { VL_D(Lay::QE + 3 * VQ + slot) = qr.x; VL_D(Lay::QE + 4 * VQ + slot) = qr.y; VL_D(Lay::QE + 5 * VQ + slot) = qr.z; }
+        Lay::set_owner(slot, lane);
       }
       qcount += __popcll(wm);
-      if (qcount >= 64) flush();
+      if (qcount >= VQ - 64) flush();
     }
     VL_BARRIER();
   }
@@ -517,8 +535,9 @@ struct PointSweep {
 // does after its pass 1; comparisons and one subtraction: nothing here can contract).  pending: only the exact pairwise
 // self-collision sweep can decide the configuration (its bit is then left 0 and the fallback pass ORs it in).
 struct LaneVerdict { bool valid, pending; uint32_t fl; };
-template <int N, bool SPH>
+template <int N, bool SPH, bool SIG>
 __device__ __forceinline__ LaneVerdict verdict_decide(const VerdictArgs &a, const FkLane<N> &fl_, bool live) {
+  using Lay = VLay<SIG>;
   const int lane = threadIdx.x;
   const int P = a.P;
   const int Kl = (P - 1 + a.CH - 1) / a.CH;
@@ -534,13 +553,13 @@ __device__ __forceinline__ LaneVerdict verdict_decide(const VerdictArgs &a, cons
     len_ok = ok;
   }
   bool alive = conv_ok && len_ok;
-  const uint32_t hf = VL_U(VL_HIT + lane);
+  const uint32_t hf = VL_U(Lay::HIT + lane);
   const bool hit = (hf & 1u) != 0;
   bool bad = (hf & 2u) != 0;
-  if (alive && !(VL_F(VL_DIST + lane) < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
+  if (alive && !(VL_F(Lay::DIST + lane) < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
   bool need_exact = alive && P > 2;
   if (!(a.debug & 2u) && __any(need_exact)) {
-    const float *mx = (const float *)vlds + VL_MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
+    const float *mx = (const float *)vlds + Lay::MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
     need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)a.radius);
   }
 
@@ -571,13 +590,14 @@ template <int N, bool ROT, bool SPH, bool SIG = false>
 __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict(
     const double *__restrict__ states, int64_t n, RobotK K, const double *__restrict__ tab, const StepK *__restrict__ steps,
     int nsteps, double *__restrict__ tips, const VerdictArgs *__restrict__ va) {
+  using Lay = VLay<SIG>;
   const int lane = threadIdx.x;
   PointSweep<SPH, SIG> ps;
   ps.va = va;
   ps.dn_prev = 0.0f; ps.sph_state = 0u;
   ps.qhead = 0; ps.qcount = 0; ps.active = false;
   ps.P = va->P; ps.CH = va->CH; ps.NM = va->NM; ps.Kl = (ps.P - 1 + ps.CH - 1) / ps.CH; ps.ms_next = 0; ps.ms_k = 0;
-  VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
+  VL_U(Lay::HIT + lane) = 0u; VL_U(Lay::INPREV + lane) = 0u; VL_F(Lay::DIST + lane) = 0.0f;
   {
     const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
     ps.sigst.init(); ps.sig_row_of = -1; ps.sig_first_row = 0; ps.sig_rows_of_launch(n);
@@ -611,7 +631,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
   const VerdictArgs a = *va;
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
   const bool live = i < n;
-  const LaneVerdict lv = verdict_decide<N, SPH>(a, fl_, live);
+  const LaneVerdict lv = verdict_decide<N, SPH, SIG>(a, fl_, live);
   const bool valid = lv.valid, pending = lv.pending;
   const uint32_t fl = lv.fl;
   const uint64_t bits = __ballot(valid && live);
@@ -650,6 +670,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
     const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
     const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
     double *__restrict__ tips, const VerdictArgs *__restrict__ va, RetractHandoff ho) {
+  using Lay = VLay<SIG>;
   const int lane = threadIdx.x;
   PointSweep<SPH, SIG> ps;
   ps.va = va;
@@ -661,7 +682,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
     const int64_t i0 = (int64_t)blockIdx.x * 64 + lane;
     ps.sigst.init(); ps.sig_row_of = i0 < n ? (perm ? perm[i0] : (int)i0) : -1; ps.sig_first_row = 0; ps.sig_row0 = 0; ps.sig_cnt = 0;
   }
-  VL_U(VL_HIT + lane) = 0u; VL_U(VL_INPREV + lane) = 0u; VL_F(VL_DIST + lane) = 0.0f;
+  VL_U(Lay::HIT + lane) = 0u; VL_U(Lay::INPREV + lane) = 0u; VL_F(Lay::DIST + lane) = 0.0f;
   __syncthreads();
 
   FkLaneR<N> fl_;
@@ -692,13 +713,13 @@ __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_ve
     len_ok = ok;
   }
   bool alive = conv_ok && len_ok;
-  const uint32_t hf = VL_U(VL_HIT + lane);
+  const uint32_t hf = VL_U(Lay::HIT + lane);
   const bool hit = (hf & 1u) != 0;
   bool bad = (hf & 2u) != 0;
-  if (alive && !(VL_F(VL_DIST + lane) < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
+  if (alive && !(VL_F(Lay::DIST + lane) < 1e30f)) { alive = false; bad = true; }   // NaN / inf points
   bool need_exact = alive && np > 2;
   if (!(a.debug & 2u) && __any(need_exact)) {
-    const float *mx = (const float *)vlds + VL_MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
+    const float *mx = (const float *)vlds + Lay::MS + lane, *my = mx + (size_t)a.NM * 64, *mz = my + (size_t)a.NM * 64, *ma = mz + (size_t)a.NM * 64;
     need_exact = milestones_unresolved(mx, my, mz, ma, a.NM, Kl, need_exact, (float)a.radius);
   }
 
