@@ -493,4 +493,70 @@ __global__ __launch_bounds__(64) void knn_merge(const int32_t *__restrict__ part
   }
 }
 
+// A range of queries (tr_knn_range*: a rank's rows of the neighbour table): the positions j of the sorted order whose state is one of
+// the queries -- perm[j] in [q0, q0 + nq) -- in ASCENDING j (neighbouring waves then search neighbouring cells), by a count per
+// block of 1024 positions, a one-block scan of the counts and an ordered write.  (Round 3 brought the whole permutation to the
+// host for this: 2.4 MB down and a 6 x 10^5-step loop per rank and build, a constant ~1.3 ms that no number of ranks divides.)
+__device__ __forceinline__ uint32_t range_flags(const int32_t *__restrict__ perm, int64_t n, int64_t q0, int64_t nq, int64_t first, uint32_t (&cnt)[4]) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t mine = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    const int64_t j = first + r * 256 + wave * 64 + lane;
+    const bool on = j < n && (int64_t)perm[j] >= q0 && (int64_t)perm[j] < q0 + nq;
+    const unsigned long long m = __ballot(on);
+    cnt[r] = (uint32_t)__popcll(m);
+    if (on) mine |= 1u << r;
+    mine |= (uint32_t)__popcll(m & (((unsigned long long)1 << lane) - 1)) << (8 + 6 * r);     // the lane's rank inside the wave's 64, per round
+  }
+  return mine;
+}
+__global__ __launch_bounds__(256) void range_positions_count(const int32_t *__restrict__ perm, int64_t n, int64_t q0, int64_t nq, uint32_t *__restrict__ bsum) {
+  __shared__ uint32_t part[16];
+  uint32_t cnt[4];
+  (void)range_flags(perm, n, q0, nq, (int64_t)blockIdx.x * 1024, cnt);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) for (int r = 0; r < 4; r++) part[r * 4 + wave] = cnt[r];
+  __syncthreads();
+  if (threadIdx.x == 0) { uint32_t t = 0; for (int i = 0; i < 16; i++) t += part[i]; bsum[blockIdx.x] = t; }
+}
+__global__ __launch_bounds__(1024) void range_positions_scan(uint32_t *__restrict__ bsum, int64_t nb) {      // exclusive, in place, one block
+  __shared__ uint32_t sh[1024];
+  uint32_t carry = 0;
+  for (int64_t b0 = 0; b0 < nb; b0 += 1024) {
+    const int64_t i = b0 + threadIdx.x;
+    const uint32_t v = i < nb ? bsum[i] : 0u;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (int o = 1; o < 1024; o <<= 1) {
+      const uint32_t a = threadIdx.x >= (unsigned)o ? sh[threadIdx.x - o] : 0u;
+      __syncthreads();
+      sh[threadIdx.x] += a;
+      __syncthreads();
+    }
+    if (i < nb) bsum[i] = carry + sh[threadIdx.x] - v;
+    carry += sh[1023];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(256) void range_positions_write(const int32_t *__restrict__ perm, int64_t n, int64_t q0, int64_t nq, const uint32_t *__restrict__ bsum,
+                                                             int32_t *__restrict__ out) {
+  __shared__ uint32_t part[16];
+  uint32_t cnt[4];
+  const uint32_t mine = range_flags(perm, n, q0, nq, (int64_t)blockIdx.x * 1024, cnt);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) for (int r = 0; r < 4; r++) part[r * 4 + wave] = cnt[r];
+  __syncthreads();
+  const uint32_t base = bsum[blockIdx.x];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    if (!((mine >> r) & 1u)) continue;
+    uint32_t before = 0;
+    for (int i = 0; i < r * 4 + wave; i++) before += part[i];                 // (round-major, wave-minor: ascending positions)
+    const int64_t j = (int64_t)blockIdx.x * 1024 + r * 256 + wave * 64 + lane;
+    const int64_t o = (int64_t)base + before + ((mine >> (8 + 6 * r)) & 63u);
+    if (o < nq) out[o] = (int32_t)j;
+  }
+}
+
 }  // namespace trk

@@ -2038,13 +2038,15 @@ int knn_impl(tr_ctx *c, const double *states, int64_t n, int32_t k, double max_d
       if (e != hipSuccess) { rc = fail(c, TR_ERR_HIP, std::string("knn sort: ") + hipGetErrorString(e)); break; }
     }
     if (nq != n) {
-      // a range of queries: their positions in sorted order, ascending (a wave's 64 queries stay neighbours in the first coordinate)
-      std::vector<int32_t> perm((size_t)n), ql;
-      if (hipMemcpy(perm.data(), d_perm, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "copy back failed"); break; }
-      ql.reserve((size_t)nq);
-      for (int64_t j = 0; j < n; j++) if (perm[(size_t)j] >= q0 && perm[(size_t)j] < q0 + nq) ql.push_back((int32_t)j);
-      if (!scratch(11, (size_t)nq * sizeof(int32_t), &d_ql) ||
-          hipMemcpy(d_ql, ql.data(), (size_t)nq * sizeof(int32_t), hipMemcpyHostToDevice) != hipSuccess) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+      // a range of queries: their positions in sorted order, ascending (neighbouring waves search neighbouring cells), on the device
+      const int64_t nb = (n + 1023) / 1024;
+      uint32_t *d_bs = nullptr;
+      if (!scratch(11, (size_t)nq * sizeof(int32_t), &d_ql) || !scratch(12, (size_t)nb * sizeof(uint32_t), &d_bs)) { rc = fail(c, TR_ERR_HIP, "hipMalloc failed"); break; }
+      ProfScope ps(c, 3, nullptr);
+      hipLaunchKernelGGL(trk::range_positions_count, dim3((unsigned)nb), dim3(256), 0, nullptr, (const int32_t *)d_perm, n, q0, nq, d_bs);
+      hipLaunchKernelGGL(trk::range_positions_scan, dim3(1), dim3(1024), 0, nullptr, d_bs, nb);
+      hipLaunchKernelGGL(trk::range_positions_write, dim3((unsigned)nb), dim3(256), 0, nullptr, (const int32_t *)d_perm, n, q0, nq, (const uint32_t *)d_bs, d_ql);
+      if (hipGetLastError() != hipSuccess) { rc = fail(c, TR_ERR_HIP, "query positions: launch failed"); break; }
     }
     {
       ProfScope ps(c, 3, nullptr);
