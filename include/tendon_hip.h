@@ -533,8 +533,9 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *   TENDON_HIP_FUSED=0|1|2          schedule of tr_validate_batch*: 2 (default) verdict-only kernel, 1 K1 + K2 as one kernel over
  *                                   stored points, 0 separate launches (the edge queue, the signature hand-over and
  *                                   tr_sample_valid_vertices* need 2 and report TR_ERR_UNSUPPORTED or fall back otherwise)
- *   TENDON_HIP_EDGE_QUEUE=0|1       1 (default): indexed edge checks through the edge queue where it applies (no retraction,
- *                                   schedule 2); 0: always the level-synchronous lanes
+ *   TENDON_HIP_EDGE_QUEUE=0|1       unset: the device-resident indexed edge checks (tr_validate_edges_indexed_dev / _sig_dev) go through
+ *                                   the edge queue where it applies (no retraction, schedule 2), the host-array form through the
+ *                                   level-synchronous lanes; 1: both through the queue; 0: both through the lanes
  *   TENDON_HIP_EDGE_QUEUE_WAVES=n   persistent workgroups of the edge queue (default: what the device holds at once)
  *   TENDON_HIP_EDGE_LANES=1..4      exactly that many lanes of the level-synchronous edge bisection (default: by the edge count)
  *   TENDON_HIP_EDGE_LANE_GUESS=x    samples per edge assumed when a lane is given its share of the pool (tests: a small value

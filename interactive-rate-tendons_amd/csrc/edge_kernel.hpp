@@ -199,6 +199,7 @@ enum { EQ_HEAD = 0, EQ_TAIL = 32, EQ_DONE = 64, EQ_FLAGS = 96, EQ_DOMAIN = 97, E
        EQ_SIZES = 124,              // rounds of 64 | 32..63 | 2..31 | 1 samples
        EQ_AVAIL = 128, EQ_WORDS = 160 };
 enum { EQF_OVERFLOW = 1u, EQF_STUCK = 2u, EQF_DEEP = 4u };      // pool too small | a wait made no progress | a level of more than 2048 intervals
+constexpr int EQ_STASH_WORDS = 68;        // LDS words a wave keeps behind the verdict body's image across an integration (edge_queue_kernel.hpp)
 constexpr int EQ_MAX_CAND = 4096;        // candidates (two per interval) of one edge level the finishing wave can hold
 
 struct EdgeQueueArgs {

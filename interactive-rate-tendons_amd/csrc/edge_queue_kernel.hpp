@@ -60,6 +60,11 @@ constexpr int EQ_PRE = 2 * EQ_GROUP_IV / 32, EQ_EOF = EQ_PRE + 64, EQ_BASEOF = E
               EQ_NBASE = EQ_DOM + 64, EQ_FILL = EQ_NBASE + 64, EQ_RELW = EQ_FILL + 64;     // (word offsets)
 #define EQ_REL(i) (((double *)vlds)[EQ_RELW / 2 + (i)])
 
+// What a wave must remember across an integration -- its lanes' edges, the claimed slots, the phase clock -- waits in 272 bytes of
+// LDS behind the verdict body's image (words [base, base + 68), base = the image's size in words): held in registers it cost the RK4
+// loop 28 more scratch loads per step than fk_verdict's own (measured: the queue's rounds 3 - 5 % longer than the kernel's).
+__device__ __forceinline__ int eq_stash_base(int NM) { return VLay<true>::MS + 4 * NM * 64 + SIG_LDS_WORDS; }
+
 // signatures_differ (edge_kernel.hpp) for BOTH halves of one interval by ONE lane: the rows of the interval's ends (ra, rb) and of its
 // midpoint (rm) from the tip down, four points per 16-byte load, 18 loads in flight; for each half the first event in tip-first
 // order decides, a domain error at a point before a difference at that point.  fp: proximal half (ra, rm), fd: distal half (rm, rb).
@@ -196,6 +201,11 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     const int S = K.state_size;
     const double *st_eff = q.states + ((int64_t)h - (int64_t)blockIdx.x * 64) * S;
     const int64_t n_eff = (int64_t)blockIdx.x * 64 + cnt;
+    {
+      const int sb = eq_stash_base(ps.NM);
+      VL_I(sb + lane) = e_lane;
+      if (lane == 0) { VL_I(sb + 64) = h; VL_I(sb + 65) = cnt; VL_U(sb + 66) = (uint32_t)clk.t; VL_U(sb + 67) = (uint32_t)(clk.t >> 32); }
+    }
     FkLane<N> fl_;
     {
       FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -206,10 +216,15 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     while (ps.qcount > 0) ps.flush();
     __syncthreads();
     LaneVerdict lv;
+    int e2, h2, cnt2;                    // (the stash: see eq_stash_base)
     {
       const VerdictArgs a = *va;
-      lv = verdict_decide<N, false, true>(a, fl_, live);
+      const int sb = eq_stash_base(a.NM);
+      e2 = VL_I(sb + lane); h2 = VL_I(sb + 64); cnt2 = VL_I(sb + 65);
+      clk.t = (unsigned long long)VL_U(sb + 66) | ((unsigned long long)VL_U(sb + 67) << 32);
+      lv = verdict_decide<N, false, true>(a, fl_, lane < cnt2);
     }
+    const bool live2 = lane < cnt2;
     int zero2 = 0;
     asm volatile("" : "+s"(zero2));
     const EdgeQueueArgs &q2 = qa[zero2];
@@ -219,11 +234,13 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
       // storing the points in its own columns of the workspace, and takes sweep_body's verdict for the pending lanes
       // (what fk_sweep_fused_list does for the level-synchronous launches; rare: tight curls only)
       __syncthreads();
-      fk_uniform_body<N, ROT, false, false>(st_eff, n_eff, q2.fb_ld, K, tab, steps, nsteps, q2.fb_out, NoPointHook(), nullptr, nullptr);
+      const double *st2 = q2.states + ((int64_t)h2 - (int64_t)blockIdx.x * 64) * K.state_size;
+      const int64_t n2 = (int64_t)blockIdx.x * 64 + cnt2;
+      fk_uniform_body<N, ROT, false, false>(st2, n2, q2.fb_ld, K, tab, steps, nsteps, q2.fb_out, NoPointHook(), nullptr, nullptr);
       __syncthreads();
       const FusedSweepArgs fa = *sa;
       bool exact = false;
-      sweep_body<false>(q2.fb_in, n_eff, q2.fb_ld, fa.P, fa.CH, fa.NM, K, fa.g, fa.grid, fa.near_grid, 1, fa.debug, nullptr, nullptr, nullptr, &exact);
+      sweep_body<false>(q2.fb_in, n2, q2.fb_ld, fa.P, fa.CH, fa.NM, K, fa.g, fa.grid, fa.near_grid, 1, fa.debug, nullptr, nullptr, nullptr, &exact);
       __syncthreads();
       const uint32_t npend = (uint32_t)__popcll(__ballot(lv.pending));
       if (lane == 0) __hip_atomic_fetch_add(q2.ctl + EQ_PENDING, npend, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -232,11 +249,11 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     }
 
     // ---- fold ----
-    if (live && !lv.valid) q2.edge_ok[e_lane] = 0u;
+    if (live2 && !lv.valid) q2.edge_ok[e2] = 0u;
     eq_release();                       // the round's signature rows and edge_ok stores, before the counters say so
     int old = 0;
-    if (live) old = __hip_atomic_fetch_add(q2.remaining + e_lane, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    bool fin = live && old == 1;        // this lane folded the last outstanding sample of its edge's level
+    if (live2) old = __hip_atomic_fetch_add(q2.remaining + e2, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool fin = live2 && old == 1;        // this lane folded the last outstanding sample of its edge's level
     bool stop = false;
     EqClock sub = clk;
     sub.lap(q2.ctl, EQ_T_F0);
@@ -252,8 +269,8 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
       // them out 64 at a time.
       int base_l = 0, ncand_l = 0;
       double rel_l = 0.0;
-      if (fin && q2.edge_ok[e_lane] != 0u) {                  // (an invalid sample decides the edge: nothing to open)
-        base_l = q2.lvl_base[e_lane]; ncand_l = q2.lvl_cnt[e_lane]; rel_l = q2.rel[e_lane];
+      if (fin && q2.edge_ok[e2] != 0u) {                  // (an invalid sample decides the edge: nothing to open)
+        base_l = q2.lvl_base[e2]; ncand_l = q2.lvl_cnt[e2]; rel_l = q2.rel[e2];
         if (2 * ncand_l > EQ_MAX_CAND) {
           __hip_atomic_fetch_or(q2.ctl + EQ_FLAGS, EQF_DEEP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           ncand_l = 0; stop = true;
@@ -280,7 +297,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
         const int T = __shfl(ex, 63, 64);                      // the group's intervals
         ex -= n_g;                                             // exclusive prefix: the lane's first interval
         __syncthreads();
-        EQ_I(EQ_PRE + lane) = ex; EQ_I(EQ_EOF + lane) = e_lane; EQ_I(EQ_BASEOF + lane) = base_l;
+        EQ_I(EQ_PRE + lane) = ex; EQ_I(EQ_EOF + lane) = e2; EQ_I(EQ_BASEOF + lane) = base_l;
         EQ_I(EQ_CNT + lane) = 0; EQ_I(EQ_DOM + lane) = 0; EQ_I(EQ_FILL + lane) = 0;
         EQ_REL(lane) = rel_l;
         __syncthreads();
@@ -321,7 +338,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
         int total_l = 0;
         if (in_group) {
           if (EQ_I(EQ_DOM + lane)) {
-            q2.edge_ok[e_lane] = 0u;
+            q2.edge_ok[e2] = 0u;
             __hip_atomic_fetch_add(q2.ctl + EQ_DOMAIN, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           } else total_l = EQ_I(EQ_CNT + lane);
         }
@@ -340,8 +357,8 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
         }
         EQ_I(EQ_NBASE + lane) = nb + nex;
         if (total_l > 0) {
-          q2.lvl_base[e_lane] = nb + nex; q2.lvl_cnt[e_lane] = total_l; q2.remaining[e_lane] = total_l;
-          q2.nfk[e_lane] += total_l;                           // every sample of an opened level is evaluated
+          q2.lvl_base[e2] = nb + nex; q2.lvl_cnt[e2] = total_l; q2.remaining[e2] = total_l;
+          q2.nfk[e2] += total_l;                           // every sample of an opened level is evaluated
         }
         __syncthreads();
         // pass 2: the survivors' records at their slots
@@ -386,9 +403,9 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     if (stop) break;
     // the round's samples are done -- after its pushes have moved the tail (the adds above have returned)
     if (lane == 0) {
-      __hip_atomic_fetch_add(q2.ctl + EQ_DONE, (uint32_t)cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(q2.ctl + EQ_DONE, (uint32_t)cnt2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       __hip_atomic_fetch_add(q2.ctl + EQ_BATCHES, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(q2.ctl + EQ_SIZES + (cnt == 64 ? 0 : (cnt >= 32 ? 1 : (cnt >= 2 ? 2 : 3))), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(q2.ctl + EQ_SIZES + (cnt2 == 64 ? 0 : (cnt2 >= 32 ? 1 : (cnt2 >= 2 ? 2 : 3))), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     clk.lap(q2.ctl, EQ_T_FOLD);

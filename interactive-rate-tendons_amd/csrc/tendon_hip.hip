@@ -158,6 +158,7 @@ struct tr_ctx {
   // launches on lanes: the default where it applies (backbone checker, no retraction, verdict-only schedule); TENDON_HIP_EDGE_QUEUE=0
   // keeps the lanes (A/B, tests).  edge_queue_waves: workgroups of that launch (0 = what the device holds at once)
   bool edge_queue = true;
+  bool edge_queue_forced = false;                 // TENDON_HIP_EDGE_QUEUE=1: also for the host-array form (default there: the lanes, see validate_edges_indexed_impl)
   int edge_queue_waves = 0;
   uint32_t edge_queue_last[4] = {0, 0, 0, 0};     // the last queue run: samples, rounds (wave batches), samples through the exact sweep, flags
   double edge_rate_seen = 0.0;                    // own samples per edge of this context's last indexed edge call (0 = none yet): sizes
@@ -438,6 +439,27 @@ int upload_staged(tr_ctx *c, void *d_dst, const void *h_src, size_t bytes, hipSt
                      (const uint64_t *)c->h_stage, words);
   HIP_TRY(c, hipGetLastError());
   HIP_TRY(c, hipStreamSynchronize(s));                  // the buffer is free for the next call
+  return TR_OK;
+}
+
+// Device array -> host array through the same pinned buffer: a copy KERNEL writes the mapped pinned memory, then a memcpy into the
+// caller's (pageable) array -- 2.3 MB of FK counts took the runtime's staged copy ~1 ms after the edge queue's launch, this ~0.2.
+// Synchronises the stream.  `bytes` is rounded up to whole words on the device side (the arrays here are allocated with room).
+int download_staged(tr_ctx *c, void *h_dst, const void *d_src, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return TR_OK;
+  const size_t padded = (bytes + 7) / 8 * 8;
+  if (c->h_stage_cap < padded) {
+    if (c->h_stage) { HIP_TRY(c, hipDeviceSynchronize()); (void)hipHostFree(c->h_stage); c->h_stage = nullptr; c->h_stage_cap = 0; }
+    const size_t want = padded + padded / 4;
+    HIP_TRY(c, hipHostMalloc(&c->h_stage, want, hipHostMallocDefault));
+    c->h_stage_cap = want;
+  }
+  const int64_t words = (int64_t)(padded / 8);
+  hipLaunchKernelGGL(trk::copy_words, dim3((unsigned)std::min<int64_t>((words + 255) / 256, 2048)), dim3(256), 0, s, (uint64_t *)c->h_stage,
+                     (const uint64_t *)d_src, words);
+  HIP_TRY(c, hipGetLastError());
+  HIP_TRY(c, hipStreamSynchronize(s));
+  std::memcpy(h_dst, c->h_stage, bytes);
   return TR_OK;
 }
 
@@ -739,7 +761,7 @@ int launch_edge_queue(tr_ctx *ctx, hipStream_t s, uint32_t *sig, int64_t sig_str
   trk::SweepIn in{w.px, w.py, w.pz, nullptr, w.Li, w.conv, nullptr, w.acc};
   const trk::FusedSweepArgs *d_fargs; size_t lds_f; int fslot;
   if ((rc = fused_args_slot(ctx, in, 1, nullptr, nullptr, s, &d_fargs, &lds_f, &fslot))) return rc;
-  const size_t lds_v = std::max(trk::verdict_lds_bytes(a.NM, true), lds_f);
+  const size_t lds_v = std::max(trk::verdict_lds_bytes(a.NM, true) + (size_t)trk::EQ_STASH_WORDS * 4, lds_f);   // (+ the waves' stash: edge_queue_kernel.hpp)
   const trk::FkOut none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   const trk::FkLaunch fl{nullptr, 0, 0, ctx->K, (bool)ctx->K.enable_rotation, false, ctx->d_tab, ctx->d_steps,
                          (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, none, s};
@@ -765,7 +787,7 @@ int edge_queue_waves(tr_ctx *ctx) {
   if (ctx->edge_queue_waves > 0) return ctx->edge_queue_waves;
   int CH, NM; size_t lds_k2;
   sweep_geometry(ctx, CH, NM, lds_k2);
-  const size_t lds_v = std::max(trk::verdict_lds_bytes(NM, true), lds_k2);
+  const size_t lds_v = std::max(trk::verdict_lds_bytes(NM, true) + (size_t)trk::EQ_STASH_WORDS * 4, lds_k2);
   int per_cu = 0;
   switch (ctx->K.n_tendons) {
 #define TRK_CASE(N) case N: per_cu = trk::fk_edge_queue_waves_per_cu<N>((bool)ctx->K.enable_rotation, lds_v); break;
@@ -876,7 +898,7 @@ int tr_create(const tr_robot_desc *rb, int device, tr_ctx **out) {
   if (const char *e = std::getenv("TENDON_HIP_RETRACT_SORT")) c->retract_sort_min = std::atoll(e);
   if (std::getenv("TENDON_HIP_RETRACT_KBEGIN_OFF")) c->retract_wave_start = false;
   if (const char *e = std::getenv("TENDON_HIP_EDGE_LANES")) { c->edge_lanes = std::max(1, std::min(tr_ctx::kMaxLanes, std::atoi(e))); c->edge_lanes_fixed = true; }
-  if (const char *e = std::getenv("TENDON_HIP_EDGE_QUEUE")) c->edge_queue = std::atoi(e) != 0;
+  if (const char *e = std::getenv("TENDON_HIP_EDGE_QUEUE")) { c->edge_queue = std::atoi(e) != 0; c->edge_queue_forced = c->edge_queue; }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_QUEUE_WAVES")) { const int v = std::atoi(e); if (v >= 1 && v <= 8192) c->edge_queue_waves = v; }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_LANE_GUESS")) { const double v = std::atof(e); if (v >= 0.5 && v <= 64.0) { c->edge_lane_guess = v; c->edge_lane_guess_forced = true; } }
   if (const char *e = std::getenv("TENDON_HIP_EDGE_POOL")) {      // testing only: a small pool forces the chunk-halving path

@@ -123,6 +123,20 @@ def main():
     add("fk_verdict<4> +sig", bytes=n_samples * (8 * 4 + 4 * 129 + 0.125), flops=n_samples * fl4, units=n_samples,
         unit="edge samples (up to four lanes' launches share the GPU, so the per-launch durations this row sums overlap: the call as a whole integrates 8.6e7 samples/s, r03/edge_timeline_v2.txt)")
     add("edge_filter", bytes=2.0 * 129 * 4 * (n_samples + len(edges)), units=n_samples + len(edges), unit="interval tests on cell signatures (upper bound: early exit from the tip)")
+    # the same edges through the device-resident form: the edge queue (round 4), ONE persistent launch that integrates the samples,
+    # folds them into their edges and finishes the levels (its vertex pass is one more launch of the +sig kernel)
+    import torch
+    d_states, d_edges = torch.from_numpy(states).cuda(), torch.from_numpy(np.ascontiguousarray(edges, dtype=np.int32)).cuda()
+    d_bits = torch.zeros((len(edges) + 63) // 64, dtype=torch.int64, device="cuda")
+    mvq = rb.mv
+    for _ in range(2):
+        chk.engine.validate_edges_indexed_dev(d_states, V, d_edges, len(edges), d_bits, None, mvq.min_tension_change, mvq.min_rotation_change, mvq.min_retraction_change)
+    sch = chk.engine.edge_schedule_last()
+    assert np.array_equal(irt.unpack_bits(d_bits.cpu().numpy().view(np.uint64), len(edges)), valid) and sch["flags"] == 0
+    add("fk_edge_queue<4>", bytes=2 * sch["samples"] * (8 * 4 + 4 * 129 + 32 + 3 * 4 * 129), flops=2 * sch["samples"] * fl4, units=2 * sch["samples"],
+        unit="edge samples through the edge queue (a sample: its state and interval record in, its signature row out, and the three rows its interval is tested against)")
+    units["fk_verdict<4> +sig"]["bytes"] += 2 * V * (8 * 4 + 4 * 129 + 0.125); units["fk_verdict<4> +sig"]["flops"] += 2 * V * fl4; units["fk_verdict<4> +sig"]["units"] += 2 * V
+    del d_states, d_edges, d_bits
     e_ok = edges[valid]
     vc = rb.vertex_caches(states)
     ec = rb.edge_caches(states, e_ok)
