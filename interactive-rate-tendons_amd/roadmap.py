@@ -9,6 +9,7 @@ import time
 
 import numpy as np
 
+from . import _lib as L
 from . import distributed as D
 from .engine import unpack_bits
 
@@ -27,7 +28,13 @@ class RoadmapBuilder:
         fk_verdict and compacted in candidate order on the GPU; only the accepted states and tips come back.  The accepted set
         is a deterministic prefix-filter of the sequence (independent of the batch sizes; `batch` is accepted and ignored)."""
         t0 = time.perf_counter()
-        out = self.engine.sample_valid_vertices(N, seed=self.seed, box=D.sampling_box(self.robot, self.tau_max))
+        box = D.sampling_box(self.robot, self.tau_max)
+        try:
+            out = self.engine.sample_valid_vertices(N, seed=self.seed, box=box)
+        except L.Unsupported:
+            # a context on another schedule than the verdict-only one (TENDON_HIP_FUSED=0 / 1: A/B runs): the rejection loop over
+            # batches of the SAME candidate sequence through validate_candidates -- the same accepted set, candidate by candidate
+            out = self._sample_valid_vertices_batches(N, box, batch or (1 << 16))
         if out["accepted"] < N:
             raise RuntimeError("only %d of %d valid vertices after %d candidates" % (out["accepted"], N, out["tried"]))
         states, tips, tried = out["states"], out["tips"], out["tried"]
@@ -45,6 +52,20 @@ class RoadmapBuilder:
             states, tips = np.ascontiguousarray(states[order]), np.ascontiguousarray(tips[order])
         self.timing["vertices"] = dict(seconds=time.perf_counter() - t0, candidates=tried, accepted=N)
         return states, tips
+
+    def _sample_valid_vertices_batches(self, N, box, batch):
+        states, tips, pos = [], [], 0
+        have, limit = 0, 64 * N + (1 << 20)
+        while have < N and pos < limit:
+            m = min(batch, limit - pos)
+            cand = D.candidate_states(self.robot, self.seed, pos, m, box=box)
+            det = self.checker.is_valid_detail(cand)
+            idx = np.flatnonzero(det["valid"])[: N - have]
+            states.append(cand[idx]); tips.append(det["tips"][idx])
+            tried = pos + (int(idx[-1]) + 1 if have + len(idx) >= N and len(idx) else m)
+            have += len(idx); pos += m
+        return dict(states=np.concatenate(states) if states else np.zeros((0, len(box[0]))), tips=np.concatenate(tips) if tips else np.zeros((0, 3)),
+                    accepted=have, tried=tried if have >= N else pos)
 
     # ---- phase 3: k nearest neighbours in state space (host) -------------------------------------------
     def state_space_metric_scale(self):

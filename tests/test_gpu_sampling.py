@@ -154,3 +154,31 @@ def test_roadmap_builder_uses_the_device_phase(irt):
     cand = D.candidate_states(robot, 5, 0, t["candidates"])
     ok = chk.is_valid_detail(cand)["valid"]
     assert ok.sum() == 2000 and ok[-1] and np.array_equal(states, cand[ok])
+
+
+def test_builder_samples_the_same_vertices_on_the_other_schedules(irt):
+    """RoadmapBuilder.sample_valid_vertices on a context that runs the stored-point schedules (TENDON_HIP_FUSED=0 / 1, where the device
+    sampler reports TR_ERR_UNSUPPORTED): the host rejection loop over the same candidate sequence accepts the same vertices."""
+    import os
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    got = {}
+    for fused in ("2", "1", "0"):
+        old = os.environ.get("TENDON_HIP_FUSED")
+        os.environ["TENDON_HIP_FUSED"] = fused
+        try:
+            chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+            rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=5)
+            got[fused] = rb.sample_valid_vertices(3000, batch=4096)
+            tried = rb.timing["vertices"]["candidates"]
+            assert fused == "2" or tried == got["tried"], (fused, tried, got["tried"])
+            got["tried"] = tried
+        finally:
+            if old is None:
+                os.environ.pop("TENDON_HIP_FUSED", None)
+            else:
+                os.environ["TENDON_HIP_FUSED"] = old
+    for fused in ("1", "0"):
+        assert np.array_equal(got[fused][0], got["2"][0])
+        assert np.abs(got[fused][1] - got["2"][1]).max() <= 1e-13          # tips: another kernel's rounding
