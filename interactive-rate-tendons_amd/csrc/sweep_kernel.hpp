@@ -501,9 +501,12 @@ __device__ __forceinline__ void sweep_body(
   float *__restrict__ my = mx + (size_t)NM * 64;
   float *__restrict__ mz = my + (size_t)NM * 64;
   float *__restrict__ ma = mz + (size_t)NM * 64;
-  // deferred voxel walks (see pass 1): a ring of (owner lane << 16 | end row) and one hit flag per lane
+  // deferred voxel walks (see pass 1): a ring of owner lanes with the segments' rotated end points (six doubles each: the flush of
+  // rounds 1 - 3 read them back from the point planes, six words from six lines per segment -- 0.03 x 384 B = 11.5 B on top of a
+  // point's 24: 1.49x the algorithmic traffic) and one hit flag per lane
   uint32_t *__restrict__ wq = (uint32_t *)(lds + (size_t)4 * NM * 64);
   uint32_t *__restrict__ wflag = wq + 128;
+  double *__restrict__ wpts = (double *)(wflag + 64);            // [6][128]: a.x, a.y, a.z, b.x, b.y, b.z (8-byte aligned: 4 NM 64 + 192 words)
   wflag[lane] = 0;
 
   const int64_t i = (int64_t)blockIdx.x * 64 + lane;
@@ -557,6 +560,7 @@ __device__ __forceinline__ void sweep_body(
     bool in_prev = false;
     int cpx = 0, cpy = 0, cpz = 0;
     uint64_t near_prev = 0;                               // dilated-grid word of the previous point's block
+    V3 seg_a = {0, 0, 0}, seg_b = {0, 0, 0};              // the deferred segment of the point being visited (rotated end points)
     auto visit = [&](int j, const V3 &q) -> bool {
       bool need = false;
       if (j == 0) prev = q;
@@ -588,6 +592,7 @@ __device__ __forceinline__ void sweep_body(
             // so the answer does not wait for a dependent load here
             const bool start_free = use_near && !((near_prev >> (((cpx & 3) << 4) | ((cpy & 3) << 2) | (cpz & 3))) & 1ull);
             need = !(nearby && start_free);                    // the walk itself is deferred (below)
+            if (need) { seg_a = prevr; seg_b = qr; }
           } else {
             hit = line_hits(prevr, qr, g, gc, near, bad);      // near or outside the domain boundary: full reference path
           }
@@ -607,20 +612,9 @@ __device__ __forceinline__ void sweep_body(
       __syncthreads();
       const int cnt = qcount < 64 ? qcount : 64;
       if (lane < cnt) {
-        const uint32_t e = wq[(qhead + lane) & 127];
-        const int owner = (int)(e >> 16), r = (int)(e & 0xffffu);
-        const int64_t oc = (int64_t)blockIdx.x * 64 + owner;
-        const int64_t oa = (int64_t)(r - 1) * ld + oc, ob = (int64_t)r * ld + oc;
-        V3 a = {in.px[oa], in.py[oa], in.pz[oa]}, b = {in.px[ob], in.py[ob], in.pz[ob]};
-        if (!g.rot_is_identity) {
-          const V3 a0 = a, b0 = b;
-          a.x = g.inv_rot[0] * a0.x + g.inv_rot[1] * a0.y + g.inv_rot[2] * a0.z;
-          a.y = g.inv_rot[3] * a0.x + g.inv_rot[4] * a0.y + g.inv_rot[5] * a0.z;
-          a.z = g.inv_rot[6] * a0.x + g.inv_rot[7] * a0.y + g.inv_rot[8] * a0.z;
-          b.x = g.inv_rot[0] * b0.x + g.inv_rot[1] * b0.y + g.inv_rot[2] * b0.z;
-          b.y = g.inv_rot[3] * b0.x + g.inv_rot[4] * b0.y + g.inv_rot[5] * b0.z;
-          b.z = g.inv_rot[6] * b0.x + g.inv_rot[7] * b0.y + g.inv_rot[8] * b0.z;
-        }
+        const int slot = (qhead + lane) & 127;
+        const int owner = (int)wq[slot];
+        const V3 a = {wpts[slot], wpts[128 + slot], wpts[256 + slot]}, b = {wpts[384 + slot], wpts[512 + slot], wpts[640 + slot]};
         const V3 A = {(a.x - g.xmin) * g.inv_dx, (a.y - g.ymin) * g.inv_dy, (a.z - g.zmin) * g.inv_dz};
         const V3 B = {(b.x - g.xmin) * g.inv_dx, (b.y - g.ymin) * g.inv_dy, (b.z - g.zmin) * g.inv_dz};
         GridCursor wc{grid, g.Nb, -1, 0ull};
@@ -646,7 +640,12 @@ __device__ __forceinline__ void sweep_body(
         if (alive && j >= shift && j < np + shift) need = visit(j - shift, q);
         const unsigned long long wm = __ballot(need);
         if (wm) {
-          if (need) wq[(qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & 127] = ((uint32_t)lane << 16) | (uint32_t)j;
+          if (need) {
+            const int slot = (qhead + qcount + __popcll(wm & (((unsigned long long)1 << lane) - 1))) & 127;
+            wq[slot] = (uint32_t)lane;
+            wpts[slot] = seg_a.x; wpts[128 + slot] = seg_a.y; wpts[256 + slot] = seg_a.z;
+            wpts[384 + slot] = seg_b.x; wpts[512 + slot] = seg_b.y; wpts[640 + slot] = seg_b.z;
+          }
           qcount += __popcll(wm);
           if (qcount >= 64) flush();
         }

@@ -520,7 +520,7 @@ void sweep_geometry(const tr_ctx *ctx, int &CH, int &NM, size_t &lds) {
   if (CH < 1) CH = 1;
   while ((P - 1 + CH - 1) / CH + 1 > 48) CH++;
   NM = (P - 1 + CH - 1) / CH + 1;
-  lds = (size_t)4 * NM * 64 * sizeof(float) + (128 + 64) * sizeof(uint32_t);   // milestones + deferred-walk ring and flags
+  lds = (size_t)4 * NM * 64 * sizeof(float) + (128 + 64) * sizeof(uint32_t) + (size_t)6 * 128 * sizeof(double);   // milestones + deferred-walk ring, flags and the ring's end points
 }
 
 int launch_sweep(tr_ctx *ctx, const trk::SweepIn &in, int64_t n, int64_t ld, int check_voxels,
