@@ -110,11 +110,11 @@ def _units():
     instantiations compile in parallel."""
     fk_deps = ["fk_inst.hip", "fk_launch.hpp", "fk_kernel.hpp", "fk_retract_kernel.hpp", "fused_kernel.hpp", "verdict_kernel.hpp",
                "sweep_kernel.hpp", "sphere_kernel.hpp", "tr_types.hpp"]
-    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip", "sample.hip", "edge_queue_kernel.hpp"]
+    fk_only = ["fk_inst.hip", "fk_kernel.hpp", "fk_retract_kernel.hpp", "cache_merge.hip", "roadmap.hip", "sample.hip", "edge_queue_kernel.hpp", "search_kernel.hpp"]
     main_deps = [f for f in os.listdir(SRC_DIR) if not f.startswith("_") and f not in fk_only]
     u = [("tendon_hip.o", "tendon_hip.hip", [], main_deps + [HEADER]),
          ("cache_merge.o", "cache_merge.hip", [], ["cache_merge.hip", "cache_merge.hpp"]),
-         ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", HEADER]),
+         ("roadmap.o", "roadmap.hip", ["-pthread"], ["roadmap.hip", "search_kernel.hpp", HEADER]),
          ("sample.o", "sample.hip", [], ["sample.hip", "sample.hpp", "tr_types.hpp"])]
     q_deps = fk_deps + ["edge_queue_kernel.hpp", "edge_kernel.hpp"]
     for n in range(1, 9):

@@ -42,6 +42,7 @@
 #include <vector>
 
 #include "../../include/tendon_hip.h"
+#include "search_kernel.hpp"
 
 namespace {
 
@@ -216,6 +217,26 @@ struct tr_roadmap {
   // statistics of the last solve
   int64_t st_rounds = 0, st_items_checked = 0, st_astar_runs = 0, st_expanded = 0;
   std::vector<Scratch> scratch;
+  // the graph searches on the device (search_kernel.hpp): everything below lives in HBM for the life of the roadmap
+  struct DevSearch {
+    int state = 0;                       // 0: not set up yet, 1: ready, -1: not available for this roadmap (reason in `why`)
+    std::string why;
+    int64_t slots = 0, nq_cap = 0;
+    int32_t far_cap = 0;
+    uint32_t pbuf_cap = 0;
+    uint64_t gens_issued = 0;
+    bool lm_current = false;
+    char *arena = nullptr;               // adjacency | states | landmark table | validity bytes | per-slot arrays
+    trk::SNode *nodes = nullptr;
+    char *qarena = nullptr;              // per-round arrays (queries, results, packed paths)
+    int64_t *d_adj_off = nullptr; trk::SArc *d_adj = nullptr; double *d_states = nullptr; float *d_lm = nullptr;
+    uint8_t *d_vstat = nullptr, *d_estat = nullptr;
+    uint32_t *d_gens = nullptr, *d_ctl = nullptr;
+    double *d_far_f = nullptr; int32_t *d_far_v = nullptr, *d_stage = nullptr;
+    int32_t *d_qs = nullptr, *d_qg = nullptr, *d_poff = nullptr, *d_plen = nullptr, *d_pbuf = nullptr;
+    uint8_t *d_found = nullptr;
+    int64_t st_queries = 0, st_fallbacks = 0;
+  } ds;
 };
 
 namespace {
@@ -448,6 +469,7 @@ bool landmark_distances_device(tr_roadmap *r) {
 // pseudo-random directions), one Dijkstra each over ALL edges -- validity plays no part, see the header comment.
 void build_landmarks(tr_roadmap *r, int n, int T) {
   r->lm_d.clear(); r->lm_v.clear(); r->lm_n = 0; r->lm_mismatch = false;
+  r->ds.lm_current = false;
   const int64_t V = r->V;
   const int S = r->S;
   if (n <= 0 || V < 2 || r->E == 0) return;
@@ -538,6 +560,208 @@ void free_dev(tr_roadmap *r) {
   r->d_ids = nullptr; r->d_masks = nullptr; r->d_off = nullptr; r->d_list = nullptr; r->d_hit = nullptr; r->d_bits = nullptr;
   if (r->h_bits) { (void)hipHostFree(r->h_bits); r->h_bits = nullptr; }
   r->list_cap = 0; r->has_caches = false;
+}
+
+void free_search(tr_roadmap *r) {
+  auto &d = r->ds;
+  if (d.arena) dev_cache().release(d.arena);
+  if (d.nodes) dev_cache().release(d.nodes);
+  if (d.qarena) dev_cache().release(d.qarena);
+  d = tr_roadmap::DevSearch{};
+}
+
+// ---- the graph searches on the device (search_kernel.hpp) ----
+static_assert(sizeof(trk::SArc) == sizeof(Arc) && sizeof(trk::SNode) == sizeof(Node), "the device records are the host's");
+
+// 0 = the host threads, 1 = the device for rounds of at least kSearchMinQueries queries, 2 = the device always (tests)
+constexpr int64_t kSearchMinQueries = 512;
+int search_mode() {
+  const char *e = std::getenv("TENDON_HIP_SEARCH");
+  if (!e) return 1;
+  if (std::strcmp(e, "host") == 0 || std::strcmp(e, "0") == 0) return 0;
+  if (std::strcmp(e, "device") == 0 || std::strcmp(e, "force") == 0) return 2;
+  return 1;
+}
+
+// The resident part: adjacency, states, landmark table, validity bytes, and per wave slot a node array (V records), a far list, a
+// path staging area.  The slot count is what the chip holds of this kernel (LDS: 12.4 KiB per wave), cut to a memory budget.
+bool search_setup(tr_roadmap *r) {
+  auto &d = r->ds;
+  if (d.state != 0) return d.state > 0;
+  d.state = -1;
+  const int64_t V = r->V;
+  if (r->S > trk::SR_MAXS) { d.why = "state size above the kernel's"; return false; }
+  if (V < 2 || r->adj.size() == 0) { d.why = "no graph"; return false; }
+  // two arcs between the same pair of vertices would make two lanes relax the same record in one step: such roadmaps stay on the host
+  {
+    std::vector<int32_t> nb;
+    for (int64_t v = 0; v < V; v++) {
+      const int64_t a0 = r->adj_off[(size_t)v], a1 = r->adj_off[(size_t)v + 1];
+      if (a1 - a0 < 2) continue;
+      nb.clear();
+      for (int64_t k = a0; k < a1; k++) nb.push_back(r->adj[(size_t)k].v);
+      std::sort(nb.begin(), nb.end());
+      if (std::adjacent_find(nb.begin(), nb.end()) != nb.end()) { d.why = "parallel edges"; return false; }
+    }
+  }
+  const int dev = tr_device(r->ctx);
+  if (hipSetDevice(dev) != hipSuccess) { d.why = "hipSetDevice"; return false; }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { d.why = "hipGetDeviceProperties"; return false; }
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trk::roadmap_astar, 64, trk::search_lds_bytes()) != hipSuccess || per_cu < 1) {
+    d.why = "occupancy query"; return false;
+  }
+  int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
+  if (const char *e = std::getenv("TENDON_HIP_SEARCH_SLOTS")) slots = std::max<int64_t>(1, std::min<int64_t>(slots, std::atoll(e)));
+  const int64_t budget = (int64_t)12 << 30;                      // node records: 32 B x V per slot
+  slots = std::min<int64_t>(slots, budget / (32 * V));
+  if (slots < 64) { d.why = "roadmap too large for resident node arrays"; return false; }
+  d.slots = slots;
+  d.far_cap = (int32_t)std::min<int64_t>(std::max<int64_t>(4096, (int64_t)r->adj.size()), 32768);
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const int Lmax = trk::SR_MAXL;
+  const size_t b_off = up((size_t)(V + 1) * 8), b_adj = up(r->adj.size() * sizeof(Arc)), b_st = up((size_t)V * r->S * 8),
+               b_lm = up((size_t)V * Lmax * 4),
+               b_vs = up((size_t)V), b_es = up((size_t)std::max<int64_t>(r->E, 1)), b_gen = up((size_t)slots * 4), b_ctl = 256,
+               b_ff = up((size_t)slots * d.far_cap * 8), b_fv = up((size_t)slots * d.far_cap * 4),
+               b_stage = up((size_t)slots * 2 * trk::SR_PATH_MAX * 4);
+  if (dev_cache().alloc(dev, (void **)&d.arena, b_off + b_adj + b_st + b_lm + b_vs + b_es + b_gen + b_ctl + b_ff + b_fv + b_stage) != hipSuccess) {
+    d.why = "out of device memory"; return false;
+  }
+  char *p = d.arena;
+  d.d_adj_off = (int64_t *)p; p += b_off;
+  d.d_adj = (trk::SArc *)p; p += b_adj;
+  d.d_states = (double *)p; p += b_st;
+  d.d_lm = (float *)p; p += b_lm;
+  d.d_vstat = (uint8_t *)p; p += b_vs;
+  d.d_estat = (uint8_t *)p; p += b_es;
+  d.d_gens = (uint32_t *)p; p += b_gen;
+  d.d_ctl = (uint32_t *)p; p += b_ctl;
+  d.d_far_f = (double *)p; p += b_ff;
+  d.d_far_v = (int32_t *)p; p += b_fv;
+  d.d_stage = (int32_t *)p;
+  bool ok = dev_cache().alloc(dev, (void **)&d.nodes, (size_t)slots * V * sizeof(Node)) == hipSuccess;
+  ok = ok && hipMemsetAsync(d.nodes, 0, (size_t)slots * V * sizeof(Node), nullptr) == hipSuccess &&
+       hipMemsetAsync(d.d_gens, 0, b_gen, nullptr) == hipSuccess &&
+       hipMemcpyAsync(d.d_adj_off, r->adj_off.data(), (size_t)(V + 1) * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       hipMemcpyAsync(d.d_adj, r->adj.data(), r->adj.size() * sizeof(Arc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       hipMemcpyAsync(d.d_states, r->states.data(), (size_t)V * r->S * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       hipStreamSynchronize(nullptr) == hipSuccess;
+  if (!ok) { free_search(r); r->ds.state = -1; r->ds.why = "out of device memory"; return false; }
+  d.lm_current = false;
+  d.state = 1;
+  return true;
+}
+
+// One round's searches: found[k] / paths / paths_e as the host loop leaves them.  Returns false when the device cannot take the
+// round (the caller then runs the host loop); queries the kernel gave up on (SR_FALLBACK) are listed in `redo`.
+bool device_search_round(tr_roadmap *r, const int32_t *starts, const int32_t *goals, const std::vector<int64_t> &active,
+                         std::vector<uint8_t> &found, std::vector<std::vector<int32_t>> &paths,
+                         std::vector<std::vector<int32_t>> &paths_e, std::vector<size_t> &redo, int64_t &expanded) {
+  if (!search_setup(r)) return false;
+  auto &d = r->ds;
+  const int dev = tr_device(r->ctx);
+  const int64_t nq = (int64_t)active.size(), V = r->V;
+  const int L = r->lm_n > 0 ? r->lm_n : 0;
+  if (L > trk::SR_MAXL) return false;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  if (nq > d.nq_cap) {
+    if (d.qarena) dev_cache().release(d.qarena);
+    d.qarena = nullptr;
+    d.nq_cap = std::max<int64_t>(nq, 1024);
+    d.pbuf_cap = (uint32_t)std::min<int64_t>((int64_t)d.nq_cap * 256, (int64_t)1 << 28);
+    const size_t bq = up((size_t)d.nq_cap * 4);
+    if (dev_cache().alloc(dev, (void **)&d.qarena, 4 * bq + up((size_t)d.nq_cap) + (size_t)d.pbuf_cap * 4) != hipSuccess) { d.nq_cap = 0; return false; }
+    char *p = d.qarena;
+    d.d_qs = (int32_t *)p; p += bq;
+    d.d_qg = (int32_t *)p; p += bq;
+    d.d_poff = (int32_t *)p; p += bq;
+    d.d_plen = (int32_t *)p; p += bq;
+    d.d_found = (uint8_t *)p; p += up((size_t)d.nq_cap);
+    d.d_pbuf = (int32_t *)p;
+  }
+  if (d.gens_issued + (uint64_t)nq >= ((uint64_t)1 << 32) - 1) {     // (a slot's generation stamp may not wrap)
+    if (hipMemsetAsync(d.nodes, 0, (size_t)d.slots * V * sizeof(Node), nullptr) != hipSuccess ||
+        hipMemsetAsync(d.d_gens, 0, (size_t)d.slots * 4, nullptr) != hipSuccess) return false;
+    d.gens_issued = 0;
+  }
+  d.gens_issued += (uint64_t)nq;
+  std::vector<int32_t> qs((size_t)nq), qg((size_t)nq);
+  for (int64_t k = 0; k < nq; k++) { qs[(size_t)k] = starts[active[(size_t)k]]; qg[(size_t)k] = goals[active[(size_t)k]]; }
+  bool ok = true;
+  std::vector<float> padded;                                      // (rows padded to a multiple of four with zeros: see the kernel's heuristic)
+  if (!d.lm_current) {
+    const int Lp = (L + 3) & ~3;
+    const float *src = r->lm_d.data();
+    if (L && Lp != L) {
+      padded.assign((size_t)V * Lp, 0.0f);
+      for (int64_t v = 0; v < V; v++) std::memcpy(&padded[(size_t)v * Lp], &r->lm_d[(size_t)v * L], (size_t)L * 4);
+      src = padded.data();
+    }
+    if (L) ok = hipMemcpyAsync(d.d_lm, src, (size_t)V * Lp * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess;
+    d.lm_current = true;
+  }
+  ok = ok && hipMemcpyAsync(d.d_vstat, r->vstat.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       (r->E == 0 || hipMemcpyAsync(d.d_estat, r->estat.data(), (size_t)r->E, hipMemcpyHostToDevice, nullptr) == hipSuccess) &&
+       hipMemcpyAsync(d.d_qs, qs.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       hipMemcpyAsync(d.d_qg, qg.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       hipMemsetAsync(d.d_ctl, 0, 256, nullptr) == hipSuccess;
+  if (!ok) return false;
+  trk::SearchArgs a{};
+  a.adj_off = d.d_adj_off; a.adj = d.d_adj; a.states = d.d_states; a.lm = L ? d.d_lm : nullptr;
+  a.S = r->S; a.NT = r->NT; a.rot = r->rot; a.ret = r->ret; a.L = L;
+  a.w_rot = r->w_rot; a.w_ret = r->w_ret; a.lm_slack = kLmSlack;
+  a.vstat = d.d_vstat; a.estat = d.d_estat; a.V = V; a.E = r->E; a.n_arcs = (int64_t)r->adj.size();
+  a.qs = d.d_qs; a.qg = d.d_qg; a.nq = nq;
+  a.next = d.d_ctl; a.pbuf_used = d.d_ctl + 1; a.expanded = (unsigned long long *)(d.d_ctl + 2);
+  a.nodes = d.nodes; a.gens = d.d_gens;
+  a.far_f = d.d_far_f; a.far_v = d.d_far_v; a.far_cap = d.far_cap; a.stage = d.d_stage;
+  a.found = d.d_found; a.poff = d.d_poff; a.plen = d.d_plen; a.pbuf = d.d_pbuf; a.pbuf_cap = d.pbuf_cap;
+  a.max_pops = 16 * V + 1024;                                   // every vertex reopened a few times: far beyond what a search does
+  const unsigned grid = (unsigned)std::min<int64_t>(d.slots, nq);
+  if (std::getenv("TENDON_HIP_SEARCH_STATS"))
+    std::fprintf(stderr, "[tendon_hip] search launch: V %lld E %lld arcs %lld L %d S %d nq %lld grid %u far_cap %d | adj_off %p adj %p states %p lm %p vstat %p estat %p gens %p ctl %p far_f %p far_v %p stage %p | nodes %p (%zu B) | qs %p qg %p poff %p plen %p found %p pbuf %p (%u)\n",
+                 (long long)V, (long long)r->E, (long long)r->adj.size(), L, r->S, (long long)nq, grid, d.far_cap, (void *)d.d_adj_off, (void *)d.d_adj,
+                 (void *)d.d_states, (void *)d.d_lm, (void *)d.d_vstat, (void *)d.d_estat, (void *)d.d_gens, (void *)d.d_ctl, (void *)d.d_far_f,
+                 (void *)d.d_far_v, (void *)d.d_stage, (void *)d.nodes, (size_t)d.slots * V * sizeof(Node), (void *)d.d_qs, (void *)d.d_qg,
+                 (void *)d.d_poff, (void *)d.d_plen, (void *)d.d_found, (void *)d.d_pbuf, d.pbuf_cap);
+  hipLaunchKernelGGL(trk::roadmap_astar, dim3(grid), dim3(64), trk::search_lds_bytes(), nullptr, a);
+  if (hipGetLastError() != hipSuccess) return false;
+  std::vector<uint8_t> res((size_t)nq);
+  std::vector<int32_t> poff((size_t)nq), plen((size_t)nq);
+  uint32_t ctl[16] = {0};
+  ok = hipMemcpy(ctl, d.d_ctl, sizeof(ctl), hipMemcpyDeviceToHost) == hipSuccess &&
+       hipMemcpy(res.data(), d.d_found, (size_t)nq, hipMemcpyDeviceToHost) == hipSuccess &&
+       hipMemcpy(poff.data(), d.d_poff, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+       hipMemcpy(plen.data(), d.d_plen, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess;
+  if (!ok) return false;
+  if (ctl[14]) std::fprintf(stderr, "[tendon_hip] roadmap_astar: loop guard %u tripped (query %u)\n", ctl[14], ctl[15]);
+  if (ctl[8]) {                                                   // (only a -DTRK_SEARCH_CHECKS build writes these)
+    std::fprintf(stderr, "[tendon_hip] roadmap_astar: check %u failed in lane %u, value %lld (query %u, pop %u)\n", ctl[8], ctl[9],
+                 (long long)(((uint64_t)ctl[11] << 32) | ctl[10]), ctl[12], ctl[13]);
+    return false;
+  }
+  const uint32_t used = std::min(ctl[1], d.pbuf_cap);
+  std::vector<int32_t> pbuf((size_t)used);
+  if (used && hipMemcpy(pbuf.data(), d.d_pbuf, (size_t)used * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  unsigned long long ex = 0;
+  std::memcpy(&ex, &ctl[2], sizeof(ex));
+  expanded += (int64_t)ex;
+  redo.clear();
+  for (int64_t k = 0; k < nq; k++) {
+    const int64_t q = active[(size_t)k];
+    found[(size_t)k] = 0;
+    if (res[(size_t)k] == trk::SR_FALLBACK) { redo.push_back((size_t)k); continue; }
+    if (res[(size_t)k] != trk::SR_FOUND) continue;
+    const int32_t n = plen[(size_t)k], o = poff[(size_t)k];
+    if (n < 1 || o < 0 || (uint64_t)o + (uint64_t)(2 * n - 1) > used) { redo.push_back((size_t)k); continue; }
+    paths[(size_t)q].assign(pbuf.begin() + o, pbuf.begin() + o + n);
+    paths_e[(size_t)q].assign(pbuf.begin() + o + n, pbuf.begin() + o + 2 * n - 1);
+    found[(size_t)k] = 1;
+  }
+  d.st_queries += nq; d.st_fallbacks += (int64_t)redo.size();
+  return true;
 }
 
 // validity of the listed combined items (vertex v -> v, edge e -> V + e) against the current obstacle grid: one K4 launch
@@ -645,6 +869,7 @@ void tr_roadmap_destroy(tr_roadmap *r) {
   if (!r) return;
   (void)hipSetDevice(tr_device(r->ctx));
   free_dev(r);
+  free_search(r);
   delete r;
 }
 
@@ -824,28 +1049,57 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   }
 
   std::vector<uint8_t> found;
+  const int smode = search_mode();
   while (!active.empty()) {
     r->st_rounds++;
     // A* for every unresolved query, on the host cores
     found.assign(active.size(), 0);
     std::atomic<int64_t> next{0}, expanded{0};
+    // ... on the device when the round is large enough to fill it (search_kernel.hpp); the host threads take what it hands back
+    std::vector<size_t> todo;
+    bool subset = false;
+    if (smode == 2 || (smode == 1 && (int64_t)active.size() >= kSearchMinQueries)) {
+      int64_t ex = 0;
+      subset = device_search_round(r, starts, goals, active, found, paths, paths_e, todo, ex);
+      expanded += ex;
+    }
+    const int64_t n_host = subset ? (int64_t)todo.size() : (int64_t)active.size();
+    std::vector<int64_t> hist_v;
+    if (std::getenv("TENDON_HIP_SEARCH_HIST")) hist_v.assign(active.size(), 0);
+    int64_t *hist = hist_v.empty() ? nullptr : hist_v.data();
     auto worker = [&](int t) {
       Scratch &sc = r->scratch[(size_t)t];
       int64_t ex = 0;
       for (;;) {
-        const int64_t k = next.fetch_add(1);
-        if (k >= (int64_t)active.size()) break;
-        const int64_t q = active[(size_t)k];
-        found[(size_t)k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+        const int64_t j = next.fetch_add(1);
+        if (j >= n_host) break;
+        const size_t k = subset ? todo[(size_t)j] : (size_t)j;
+        const int64_t q = active[k];
+        const int64_t ex0 = ex;
+        found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+        if (hist) hist[k] = ex - ex0;
       }
       expanded += ex;
     };
-    {
-      const int nt = (int)std::min<int64_t>(T, (int64_t)active.size());
+    if (n_host > 0) {
+      const int nt = (int)std::min<int64_t>(T, n_host);
       std::vector<std::thread> th;
       for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
       worker(0);
       for (auto &x : th) x.join();
+    }
+    if (hist) {
+      std::vector<int64_t> f, nf;
+      for (size_t k = 0; k < active.size(); k++) (found[k] ? f : nf).push_back(hist[k]);
+      auto show = [](const char *name, std::vector<int64_t> &v) {
+        if (v.empty()) { std::fprintf(stderr, "  %s: none\n", name); return; }
+        std::sort(v.begin(), v.end());
+        int64_t sum = 0; for (int64_t x : v) sum += x;
+        std::fprintf(stderr, "  %s: %zu searches, %lld expansions; median %lld, 90%% %lld, 99%% %lld, max %lld\n", name, v.size(), (long long)sum,
+                     (long long)v[v.size() / 2], (long long)v[v.size() * 9 / 10], (long long)v[v.size() * 99 / 100], (long long)v.back());
+      };
+      std::fprintf(stderr, "[tendon_hip] round %lld:\n", (long long)r->st_rounds);
+      show("found", f); show("not found", nf);
     }
     r->st_astar_runs += (int64_t)active.size();
     r->st_expanded += expanded.load();
@@ -890,6 +1144,10 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     path_offsets[q + 1] = r->path_off[(size_t)q + 1];
   }
   if (stats) *stats = tr_roadmap_stats{r->st_rounds, r->st_items_checked, r->st_astar_runs, r->st_expanded};
+  if (std::getenv("TENDON_HIP_SEARCH_STATS"))
+    std::fprintf(stderr, "[tendon_hip] searches: mode %d, device state %d%s%s, %lld slots, %lld searches on the device so far, %lld handed back to the host\n",
+                 smode, r->ds.state, r->ds.why.empty() ? "" : " -- ", r->ds.why.c_str(), (long long)r->ds.slots, (long long)r->ds.st_queries,
+                 (long long)r->ds.st_fallbacks);
   return TR_OK;
 }
 
