@@ -434,6 +434,12 @@ int tr_roadmap_get_validity(tr_roadmap *rm, uint8_t *vertex_status /*[n_vertices
 int tr_roadmap_solve(tr_roadmap *rm, const int32_t *starts, const int32_t *goals, int64_t n_queries, int32_t n_threads,
                      int32_t *status, double *cost, int64_t *path_offsets, tr_roadmap_stats *stats);
 int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capacity);
+/* Where the graph searches of the last tr_roadmap_solve ran (the A* of a round is done by the `roadmap_astar` kernel, one wave
+ * per query, when the round has 512 queries or more -- see TENDON_HIP_SEARCH below -- and by the host threads otherwise; the
+ * answers are the same):  out[0] searches finished by the kernel, out[1] searches the kernel handed back to the host threads
+ * (over its pop budget, or a list full), out[2] searches the host threads took while the kernel ran (the ones expected to be
+ * longest), out[3] times a search's open list moved entries between its LDS part and its HBM part. */
+int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[4]);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
  * of connectionStrategy_(v), `if (!getEdge(v, n)) connectVertices(v, n)`): the undirected edge set of the k-nearest

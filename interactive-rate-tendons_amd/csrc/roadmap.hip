@@ -235,7 +235,10 @@ struct tr_roadmap {
     double *d_far_f = nullptr; int32_t *d_far_v = nullptr, *d_stage = nullptr;
     int32_t *d_qs = nullptr, *d_qg = nullptr, *d_poff = nullptr, *d_plen = nullptr, *d_pbuf = nullptr;
     uint8_t *d_found = nullptr;
-    int64_t st_queries = 0, st_fallbacks = 0;
+    int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0;   // of the last tr_roadmap_solve
+    int64_t in_flight = 0;               // queries of the launch that has not been collected yet
+    std::vector<int32_t> h_qs, h_qg;     // host images of what the pending copies read
+    std::vector<float> h_padded;
   } ds;
 };
 
@@ -583,6 +586,19 @@ int search_mode() {
   return 1;
 }
 
+// the share of a round's searches (the ones expected to be longest) that the host threads take while the kernel runs, and the
+// kernel's pop budget per search; TENDON_HIP_SEARCH_HOST_SHARE (per cent) / TENDON_HIP_SEARCH_BUDGET override
+double search_host_share() {
+  const char *e = std::getenv("TENDON_HIP_SEARCH_HOST_SHARE");
+  const double p = e ? std::atof(e) : 2.0;
+  return std::min(100.0, std::max(0.0, p)) / 100.0;
+}
+int64_t search_budget() {
+  const char *e = std::getenv("TENDON_HIP_SEARCH_BUDGET");
+  const long long b = e ? std::atoll(e) : 10000;
+  return b > 0 ? (int64_t)b : 0;
+}
+
 // The resident part: adjacency, states, landmark table, validity bytes, and per wave slot a node array (V records), a far list, a
 // path staging area.  The slot count is what the chip holds of this kernel (LDS: 12.4 KiB per wave), cut to a memory budget.
 bool search_setup(tr_roadmap *r) {
@@ -654,15 +670,19 @@ bool search_setup(tr_roadmap *r) {
   return true;
 }
 
-// One round's searches: found[k] / paths / paths_e as the host loop leaves them.  Returns false when the device cannot take the
-// round (the caller then runs the host loop); queries the kernel gave up on (SR_FALLBACK) are listed in `redo`.
-bool device_search_round(tr_roadmap *r, const int32_t *starts, const int32_t *goals, const std::vector<int64_t> &active,
-                         std::vector<uint8_t> &found, std::vector<std::vector<int32_t>> &paths,
-                         std::vector<std::vector<int32_t>> &paths_e, std::vector<size_t> &redo, int64_t &expanded) {
+// One round's searches in two halves, so that the host threads can search their share while the kernel runs.
+// device_search_launch: the queries active[klist[.]], in that order (the caller puts the ones it expects to be long first), are sent
+// to the kernel; nothing is waited for.  `budget` caps the pops of one search (0: no cap): a search that reaches it is handed back.
+// Returns false when the device cannot take the round (the caller then searches everything on the host).
+// device_search_collect: waits for the kernel and leaves found[k] / paths / paths_e as the host search would; the queries the
+// kernel gave up on (SR_FALLBACK) are listed in `redo`.
+bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *goals, const std::vector<int64_t> &active,
+                          const std::vector<size_t> &klist, int64_t budget) {
   if (!search_setup(r)) return false;
   auto &d = r->ds;
   const int dev = tr_device(r->ctx);
-  const int64_t nq = (int64_t)active.size(), V = r->V;
+  const int64_t nq = (int64_t)klist.size(), V = r->V;
+  if (nq == 0) return false;
   const int L = r->lm_n > 0 ? r->lm_n : 0;
   if (L > trk::SR_MAXL) return false;
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -687,10 +707,11 @@ bool device_search_round(tr_roadmap *r, const int32_t *starts, const int32_t *go
     d.gens_issued = 0;
   }
   d.gens_issued += (uint64_t)nq;
-  std::vector<int32_t> qs((size_t)nq), qg((size_t)nq);
-  for (int64_t k = 0; k < nq; k++) { qs[(size_t)k] = starts[active[(size_t)k]]; qg[(size_t)k] = goals[active[(size_t)k]]; }
+  std::vector<int32_t> &qs = d.h_qs, &qg = d.h_qg;                  // (members: the copies below may still be reading them when this returns)
+  qs.resize((size_t)nq); qg.resize((size_t)nq);
+  for (int64_t j = 0; j < nq; j++) { qs[(size_t)j] = starts[active[klist[(size_t)j]]]; qg[(size_t)j] = goals[active[klist[(size_t)j]]]; }
   bool ok = true;
-  std::vector<float> padded;                                      // (rows padded to a multiple of four with zeros: see the kernel's heuristic)
+  std::vector<float> &padded = d.h_padded;                        // (rows padded to a multiple of four with zeros: see the kernel's heuristic)
   if (!d.lm_current) {
     const int Lp = (L + 3) & ~3;
     const float *src = r->lm_d.data();
@@ -718,7 +739,7 @@ bool device_search_round(tr_roadmap *r, const int32_t *starts, const int32_t *go
   a.nodes = d.nodes; a.gens = d.d_gens;
   a.far_f = d.d_far_f; a.far_v = d.d_far_v; a.far_cap = d.far_cap; a.stage = d.d_stage;
   a.found = d.d_found; a.poff = d.d_poff; a.plen = d.d_plen; a.pbuf = d.d_pbuf; a.pbuf_cap = d.pbuf_cap;
-  a.max_pops = 16 * V + 1024;                                   // every vertex reopened a few times: far beyond what a search does
+  a.max_pops = budget > 0 ? budget : 16 * V + 1024;             // (uncapped: every vertex reopened a few times, far beyond what a search does)
   const unsigned grid = (unsigned)std::min<int64_t>(d.slots, nq);
   if (std::getenv("TENDON_HIP_SEARCH_STATS"))
     std::fprintf(stderr, "[tendon_hip] search launch: V %lld E %lld arcs %lld L %d S %d nq %lld grid %u far_cap %d | adj_off %p adj %p states %p lm %p vstat %p estat %p gens %p ctl %p far_f %p far_v %p stage %p | nodes %p (%zu B) | qs %p qg %p poff %p plen %p found %p pbuf %p (%u)\n",
@@ -728,40 +749,63 @@ bool device_search_round(tr_roadmap *r, const int32_t *starts, const int32_t *go
                  (void *)d.d_poff, (void *)d.d_plen, (void *)d.d_found, (void *)d.d_pbuf, d.pbuf_cap);
   hipLaunchKernelGGL(trk::roadmap_astar, dim3(grid), dim3(64), trk::search_lds_bytes(), nullptr, a);
   if (hipGetLastError() != hipSuccess) return false;
+  d.in_flight = nq;
+  return true;
+}
+
+void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, const std::vector<size_t> &klist,
+                           std::vector<uint8_t> &found, std::vector<std::vector<int32_t>> &paths,
+                           std::vector<std::vector<int32_t>> &paths_e, std::vector<size_t> &redo, int64_t &expanded) {
+  auto &d = r->ds;
+  const int64_t nq = d.in_flight;
+  d.in_flight = 0;
+  // (any failure: the whole list goes back to the host threads)
+  auto give_back = [&]() { redo = klist; for (size_t k : klist) found[k] = 0; };
+  redo.clear();
+  if (nq != (int64_t)klist.size()) { give_back(); return; }
+  bool ok = true;
   std::vector<uint8_t> res((size_t)nq);
   std::vector<int32_t> poff((size_t)nq), plen((size_t)nq);
-  uint32_t ctl[16] = {0};
+  uint32_t ctl[32] = {0};
   ok = hipMemcpy(ctl, d.d_ctl, sizeof(ctl), hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(res.data(), d.d_found, (size_t)nq, hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(poff.data(), d.d_poff, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(plen.data(), d.d_plen, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess;
-  if (!ok) return false;
+  if (!ok) { give_back(); return; }
+  if (std::getenv("TENDON_HIP_SEARCH_STATS")) {                     // (non-zero only in a -DTRK_SEARCH_CLOCKS build)
+    unsigned long long c[7];
+    std::memcpy(c, &ctl[16], sizeof(c));
+    const double tot = (double)(c[0] + c[1] + c[2] + c[3] + c[4]);
+    if (tot > 0)
+      std::fprintf(stderr, "[tendon_hip] search clocks: %.1f wave-ms in all (longest search %.2f ms): refill %.1f%%, pop %.1f%%, record + offsets %.1f%%, arcs + rows + relax %.1f%%, append %.1f%%\n",
+                   tot * 1e-5, (double)c[6] * 1e-5, 100.0 * c[0] / tot, 100.0 * c[1] / tot, 100.0 * c[2] / tot, 100.0 * c[3] / tot, 100.0 * c[4] / tot);
+  }
   if (ctl[14]) std::fprintf(stderr, "[tendon_hip] roadmap_astar: loop guard %u tripped (query %u)\n", ctl[14], ctl[15]);
   if (ctl[8]) {                                                   // (only a -DTRK_SEARCH_CHECKS build writes these)
     std::fprintf(stderr, "[tendon_hip] roadmap_astar: check %u failed in lane %u, value %lld (query %u, pop %u)\n", ctl[8], ctl[9],
                  (long long)(((uint64_t)ctl[11] << 32) | ctl[10]), ctl[12], ctl[13]);
-    return false;
+    give_back();
+    return;
   }
   const uint32_t used = std::min(ctl[1], d.pbuf_cap);
   std::vector<int32_t> pbuf((size_t)used);
-  if (used && hipMemcpy(pbuf.data(), d.d_pbuf, (size_t)used * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  if (used && hipMemcpy(pbuf.data(), d.d_pbuf, (size_t)used * 4, hipMemcpyDeviceToHost) != hipSuccess) { give_back(); return; }
   unsigned long long ex = 0;
   std::memcpy(&ex, &ctl[2], sizeof(ex));
   expanded += (int64_t)ex;
-  redo.clear();
-  for (int64_t k = 0; k < nq; k++) {
-    const int64_t q = active[(size_t)k];
-    found[(size_t)k] = 0;
-    if (res[(size_t)k] == trk::SR_FALLBACK) { redo.push_back((size_t)k); continue; }
-    if (res[(size_t)k] != trk::SR_FOUND) continue;
-    const int32_t n = plen[(size_t)k], o = poff[(size_t)k];
-    if (n < 1 || o < 0 || (uint64_t)o + (uint64_t)(2 * n - 1) > used) { redo.push_back((size_t)k); continue; }
+  for (int64_t j = 0; j < nq; j++) {
+    const size_t k = klist[(size_t)j];
+    const int64_t q = active[k];
+    found[k] = 0;
+    if (res[(size_t)j] == trk::SR_FALLBACK) { redo.push_back(k); continue; }
+    if (res[(size_t)j] != trk::SR_FOUND) continue;
+    const int32_t n = plen[(size_t)j], o = poff[(size_t)j];
+    if (n < 1 || o < 0 || (uint64_t)o + (uint64_t)(2 * n - 1) > used) { redo.push_back(k); continue; }
     paths[(size_t)q].assign(pbuf.begin() + o, pbuf.begin() + o + n);
     paths_e[(size_t)q].assign(pbuf.begin() + o + n, pbuf.begin() + o + 2 * n - 1);
-    found[(size_t)k] = 1;
+    found[k] = 1;
   }
-  d.st_queries += nq; d.st_fallbacks += (int64_t)redo.size();
-  return true;
+  d.st_queries += nq - (int64_t)redo.size(); d.st_fallbacks += (int64_t)redo.size(); d.st_moves += (int64_t)ctl[4];
 }
 
 // validity of the listed combined items (vertex v -> v, edge e -> V + e) against the current obstacle grid: one K4 launch
@@ -1004,6 +1048,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   if (n_queries < 0 || (n_queries > 0 && (!starts || !goals || !status || !path_offsets))) return rfail(r, TR_ERR_INVALID_ARG, "bad argument");
   r->path_off.assign((size_t)n_queries + 1, 0); r->path_v.clear();
   r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
+  r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = 0;
   if (path_offsets) path_offsets[0] = 0;
   if (n_queries == 0) { if (stats) *stats = tr_roadmap_stats{0, 0, 0, 0}; return TR_OK; }
   for (int64_t q = 0; q < n_queries; q++)
@@ -1054,39 +1099,71 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     r->st_rounds++;
     // A* for every unresolved query, on the host cores
     found.assign(active.size(), 0);
-    std::atomic<int64_t> next{0}, expanded{0};
-    // ... on the device when the round is large enough to fill it (search_kernel.hpp); the host threads take what it hands back
-    std::vector<size_t> todo;
-    bool subset = false;
+    std::atomic<int64_t> expanded{0};
+    // ... on the device when the round is large enough to fill it (search_kernel.hpp).  The searches are ordered by the state-space
+    // distance between their end points, longest first: the host threads take the head of that order (a core expands a vertex in
+    // a fraction of the time a wave does, so the searches expected to be longest are theirs) while the kernel works through the
+    // rest, longest first; what the kernel hands back (over its pop budget, or a list full) the host threads search afterwards.
+    std::vector<size_t> host_list, dev_list, redo;
+    bool on_device = false;
+    const auto t_round = std::chrono::steady_clock::now();
     if (smode == 2 || (smode == 1 && (int64_t)active.size() >= kSearchMinQueries)) {
-      int64_t ex = 0;
-      subset = device_search_round(r, starts, goals, active, found, paths, paths_e, todo, ex);
-      expanded += ex;
+      std::vector<std::pair<double, size_t>> key(active.size());
+      for (size_t k = 0; k < active.size(); k++) {
+        const int64_t q = active[k];
+        key[k] = {state_distance(r, &r->states[(size_t)starts[q] * r->S], &r->states[(size_t)goals[q] * r->S]), k};
+      }
+      std::sort(key.begin(), key.end(), [](const std::pair<double, size_t> &x, const std::pair<double, size_t> &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
+      const size_t n_h = smode == 2 ? 0 : (size_t)((double)active.size() * search_host_share());
+      for (size_t i = 0; i < key.size(); i++) (i < n_h ? host_list : dev_list).push_back(key[i].second);
+      on_device = device_search_launch(r, starts, goals, active, dev_list, smode == 2 ? 0 : search_budget());
+      if (!on_device) { host_list.clear(); dev_list.clear(); }
+      else r->ds.st_host_share += (int64_t)host_list.size();
     }
-    const int64_t n_host = subset ? (int64_t)todo.size() : (int64_t)active.size();
     std::vector<int64_t> hist_v;
     if (std::getenv("TENDON_HIP_SEARCH_HIST")) hist_v.assign(active.size(), 0);
     int64_t *hist = hist_v.empty() ? nullptr : hist_v.data();
-    auto worker = [&](int t) {
-      Scratch &sc = r->scratch[(size_t)t];
-      int64_t ex = 0;
-      for (;;) {
-        const int64_t j = next.fetch_add(1);
-        if (j >= n_host) break;
-        const size_t k = subset ? todo[(size_t)j] : (size_t)j;
-        const int64_t q = active[k];
-        const int64_t ex0 = ex;
-        found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
-        if (hist) hist[k] = ex - ex0;
-      }
-      expanded += ex;
-    };
-    if (n_host > 0) {
+    // the host threads over a list of positions in `active` (null: all of them)
+    auto host_search = [&](const std::vector<size_t> *list) {
+      const int64_t n_host = list ? (int64_t)list->size() : (int64_t)active.size();
+      if (n_host == 0) return;
+      std::atomic<int64_t> next{0};
+      auto worker = [&](int t) {
+        Scratch &sc = r->scratch[(size_t)t];
+        int64_t ex = 0;
+        for (;;) {
+          const int64_t j = next.fetch_add(1);
+          if (j >= n_host) break;
+          const size_t k = list ? (*list)[(size_t)j] : (size_t)j;
+          const int64_t q = active[k];
+          const int64_t ex0 = ex;
+          found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+          if (hist) hist[k] = ex - ex0;
+        }
+        expanded += ex;
+      };
       const int nt = (int)std::min<int64_t>(T, n_host);
       std::vector<std::thread> th;
       for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
       worker(0);
       for (auto &x : th) x.join();
+    };
+    if (!on_device) host_search(nullptr);
+    else {
+      const auto t0 = std::chrono::steady_clock::now();
+      host_search(&host_list);
+      const auto t1 = std::chrono::steady_clock::now();
+      int64_t ex = 0;
+      device_search_collect(r, active, dev_list, found, paths, paths_e, redo, ex);
+      expanded += ex;
+      const auto t2 = std::chrono::steady_clock::now();
+      host_search(&redo);
+      if (std::getenv("TENDON_HIP_SEARCH_STATS")) {
+        const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "[tendon_hip] round %lld: order + launch %.2f ms, %zu searches on the host meanwhile %.2f ms, wait + collect %zu %.2f ms, %zu handed back %.2f ms\n",
+                     (long long)r->st_rounds, ms(t_round, t0), host_list.size(), ms(t0, t1), dev_list.size(), ms(t1, t2), redo.size(),
+                     ms(t2, std::chrono::steady_clock::now()));
+      }
     }
     if (hist) {
       std::vector<int64_t> f, nf;
@@ -1145,9 +1222,16 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   }
   if (stats) *stats = tr_roadmap_stats{r->st_rounds, r->st_items_checked, r->st_astar_runs, r->st_expanded};
   if (std::getenv("TENDON_HIP_SEARCH_STATS"))
-    std::fprintf(stderr, "[tendon_hip] searches: mode %d, device state %d%s%s, %lld slots, %lld searches on the device so far, %lld handed back to the host\n",
+    std::fprintf(stderr, "[tendon_hip] searches: mode %d, device state %d%s%s, %lld slots, %lld searches finished on the device, %lld handed back to the host, %lld on the host meanwhile\n",
                  smode, r->ds.state, r->ds.why.empty() ? "" : " -- ", r->ds.why.c_str(), (long long)r->ds.slots, (long long)r->ds.st_queries,
-                 (long long)r->ds.st_fallbacks);
+                 (long long)r->ds.st_fallbacks, (long long)r->ds.st_host_share);
+  return TR_OK;
+}
+
+int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[4]) {
+  if (!r || !out) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  out[0] = r->ds.st_queries; out[1] = r->ds.st_fallbacks; out[2] = r->ds.st_host_share; out[3] = r->ds.st_moves;
   return TR_OK;
 }
 

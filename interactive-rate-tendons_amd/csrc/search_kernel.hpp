@@ -106,6 +106,13 @@ __device__ __forceinline__ int sr_wave_sum(int c) {
 #define SR_LOOP_GUARD(counter, limit, code)
 #endif
 
+// -DTRK_SEARCH_CLOCKS: the 100 MHz clock read at the phase boundaries of an expansion, summed per phase into control words 16.. (profiling aid)
+#ifdef TRK_SEARCH_CLOCKS
+#define SR_CLK(i) do { const unsigned long long t_ = wall_clock64(); clk[i] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define SR_CLK(i) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ double sr_lds[];
@@ -204,13 +211,18 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
     double T = inf;
     int result = SR_NO_PATH;
     unsigned long long exp_q = 0;
+    unsigned moves = 0;                                         // times the threshold moved (near full / near empty)
     const double h0 = sr_u(heuristic(start));
     if (h0 != inf) {
       if (lane == 0) { node[start] = SNode{0.0, h0, start, -1, gen, 0u}; nf[0] = h0; nv[0] = start; }
       n_near = 1;
       __syncthreads();
+#ifdef TRK_SEARCH_CLOCKS
+      unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+#endif
       for (int64_t pops = 0;; pops++) {
         lane = sr_opaque(lane);
+        SR_CLK(4);
         if (pops >= a.max_pops) { result = SR_FALLBACK; break; }
         if (n_near == 0) {
           if (n_far == 0) break;                               // the open list is empty: no path
@@ -256,15 +268,24 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
           if (n_near > SR_CAP) { result = SR_FALLBACK; break; }
           n_far = keep;
           T = Tn;
+          moves++;
           __syncthreads();
           if (n_near == 0) { result = SR_FALLBACK; break; }    // (cannot happen: the minimum qualifies)
         }
+        SR_CLK(0);
         // ---- pop: the smallest key of near ----
         double best = inf;
         int bi = -1;
         int lg2 = 0;
         (void)lg2;
-        for (int i = lane; i < n_near; i += 64) { SR_LOOP_GUARD(lg2, 32, 24) const double f = nf[i]; if (f < best || bi < 0) { best = f; bi = i; } }
+        for (int i0 = 0; i0 < n_near; i0 += 256) {                // (four reads in flight per lane; the order of the comparisons is the index order)
+          SR_LOOP_GUARD(lg2, 32, 24)
+          double f4[4];
+#pragma unroll
+          for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; f4[j] = i < n_near ? nf[i] : inf; }
+#pragma unroll
+          for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; if (i < n_near && (f4[j] < best || bi < 0)) { best = f4[j]; bi = i; } }
+        }
         const double fmin = sr_wave_min(best);
         const unsigned long long who = __ballot(bi >= 0 && best == fmin);
         pops_dbg = pops;
@@ -276,6 +297,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
         if (lane == 0) { nf[idx] = nf[n_near - 1]; nv[idx] = nv[n_near - 1]; }
         n_near--;
         __syncthreads();
+        SR_CLK(1);
         const SNode nu_ = node[u];
         const int64_t a0_ = a.adj_off[u], a1_ = a.adj_off[u + 1];       // (requested with the record: both hang on u alone)
         const double nu_g = sr_u(nu_.g);
@@ -286,6 +308,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
         const int64_t a0 = sr_u(a0_);
         int64_t a1 = sr_u(a1_);
         SR_CHK(a0 >= 0 && a0 <= a1 && a1 <= a.n_arcs, 4, a1);
+        SR_CLK(2);
         bool failed = false;
         lg2 = 0;
         for (int64_t base = a0; base < a1 && !failed; base += 64) {
@@ -315,6 +338,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
           }
           // ---- append: keys below T to near, the others to far ----
           unsigned long long mn_ = __ballot(push && fp < T);
+          SR_CLK(3);
           int lg3 = 0;
           (void)lg3;
           while (n_near + __popcll(mn_) > SR_CAP) {
@@ -348,6 +372,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
             if (n_far > a.far_cap) { failed = true; break; }
             n_near = keep;
             T = Tn;
+            moves++;
             mn_ = __ballot(push && fp < T);
           }
           if (failed) break;
@@ -361,6 +386,12 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
         }
         if (failed) { result = SR_FALLBACK; break; }
       }
+#ifdef TRK_SEARCH_CLOCKS
+      if (lane == 0) {
+        for (int i = 0; i < 6; i++) atomicAdd((unsigned long long *)(a.next + 16) + i, clk[i]);
+        atomicMax((unsigned long long *)(a.next + 16) + 6, clk[0] + clk[1] + clk[2] + clk[3] + clk[4]);
+      }
+#endif
     }
     // ---- the path, goal ... start, and its edges ----
     int nvert = 0;
@@ -400,6 +431,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
     if (lane == 0) {
       a.found[qi] = (uint8_t)result;
       atomicAdd(a.expanded, exp_q);
+      if (moves) atomicAdd(a.next + 4, moves);
     }
   }
 }

@@ -37,8 +37,11 @@ def main():
         prm.prepare(nl)
         res = {}
         for form in ("eager", "lazy"):
-            for mode in ("host", "device", "host", "device"):
-                os.environ["TENDON_HIP_SEARCH"] = mode
+            for mode in ("host", "device", "auto", "host", "device", "auto"):
+                if mode == "auto":
+                    os.environ.pop("TENDON_HIP_SEARCH", None)      # the default: large rounds shared between the kernel and the host threads
+                else:
+                    os.environ["TENDON_HIP_SEARCH"] = mode
                 prm.clearValidity()
                 if form == "eager":
                     prm.revalidate()
@@ -52,12 +55,11 @@ def main():
                 if mode == "host":
                     ref = r
                 else:
-                    res[form + "_same_status"] = bool(np.array_equal(ref["status"], r["status"]))
-                    res[form + "_same_cost"] = bool(np.array_equal(ref["cost"], r["cost"]))
-                    res[form + "_same_paths"] = bool(np.array_equal(ref["path_vertices"], r["path_vertices"]))
+                    res[form + "_" + mode + "_same"] = bool(np.array_equal(ref["status"], r["status"]) and np.array_equal(ref["cost"], r["cost"])
+                                                            and np.array_equal(ref["path_vertices"], r["path_vertices"]))
         for form in ("eager", "lazy"):
-            h, d = min(res[form + "_host"]), min(res[form + "_device"])
-            res[form + "_queries_per_s"] = {"host": nq / h, "device": nq / d, "ratio": h / d}
+            h, d, a = min(res[form + "_host"]), min(res[form + "_device"]), min(res[form + "_auto"])
+            res[form + "_queries_per_s"] = {"host": nq / h, "device": nq / d, "auto": nq / a, "device_ratio": h / d, "auto_ratio": h / a}
         out[str(nl)] = res
         print(nl, json.dumps(res), flush=True)
     print(json.dumps(out))

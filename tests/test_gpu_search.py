@@ -1,0 +1,120 @@
+"""The graph searches of the query loop on the device (csrc/search_kernel.hpp: roadmap_astar, one wave per query) against the host
+threads' A* -- the statement of astarSearch / constructSolution (motion-planning/VoxelCachedLazyPRM.cpp:2689-2771, 2950-2976) that
+tests/test_gpu_lazy_prm.py pins to the oracle: same statuses, costs, paths, validity bytes, rounds and items checked, whichever side
+searches, and the same number of expansions (the kernel is that search statement for statement, ties between equal keys apart)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _prm(irt, n_vertices, k, seed, n_new_spheres=76):
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=seed)
+    states, _ = rb.sample_valid_vertices(n_vertices, batch=8192)
+    edges = rb.knn_edges_gpu(states, k)
+    valid, _ = rb.validate_edges(states, edges)
+    edges = edges[valid]
+    prm = irt.VoxelCachedLazyPRM(chk, states, edges)
+    prm.set_caches(rb.vertex_caches(states), rb.edge_caches(states, edges))
+    new_vox, _ = W.reach_environment(seed=7, n_spheres=n_new_spheres)
+    prm.set_obstacles(new_vox)
+    return prm, states
+
+
+def _solve(prm, starts, goals, eager):
+    prm.clearValidity()
+    if eager:
+        prm.revalidate()
+    out = prm.solveWithRoadmap(starts, goals)
+    v, e = prm.validity()
+    return out, dict(prm.stats), v, e
+
+
+def _same(a, b, expansions=True):
+    (ra, sa, va, ea), (rb, sb, vb, eb) = a, b
+    assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["cost"], rb["cost"])
+    assert np.array_equal(ra["path_offsets"], rb["path_offsets"]) and np.array_equal(ra["path_vertices"], rb["path_vertices"])
+    assert np.array_equal(va, vb) and np.array_equal(ea, eb)
+    assert sa["rounds"] == sb["rounds"] and sa["items_checked"] == sb["items_checked"] and sa["astar_runs"] == sb["astar_runs"]
+    if expansions:
+        assert sa["expanded"] == sb["expanded"], (sa, sb)
+
+
+@pytest.mark.parametrize("landmarks", [16, 0, 6])
+def test_device_searches_equal_the_host_searches(irt, monkeypatch, landmarks):
+    prm, states = _prm(irt, 2500, 6, seed=21)
+    prm.prepare(landmarks)
+    rng = np.random.default_rng(4)
+    nq = 700
+    starts, goals = rng.integers(0, len(states), nq), rng.integers(0, len(states), nq)
+    goals[:5] = starts[:5]
+    for eager in (False, True):
+        monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+        ref = _solve(prm, starts, goals, eager)
+        assert (ref[0]["status"] == 0).sum() > 0.5 * nq and (ref[0]["status"] != 0).any()
+        monkeypatch.setenv("TENDON_HIP_SEARCH", "device")          # every round on the device, no pop budget
+        _same(ref, _solve(prm, starts, goals, eager))
+        assert prm.search_stats["device"] == ref[1]["astar_runs"] and prm.search_stats["handed_back"] == 0
+        monkeypatch.delenv("TENDON_HIP_SEARCH")                    # the default: large rounds shared with the host threads
+        _same(ref, _solve(prm, starts, goals, eager))
+        assert prm.search_stats["device"] > 500 and prm.search_stats["host_meanwhile"] > 0, prm.search_stats
+        # a budget that most searches exceed (they are handed back to the host threads) and a large host share: the expansions
+        # the kernel spent before giving up count as well, so only the answers are compared
+        monkeypatch.setenv("TENDON_HIP_SEARCH_BUDGET", "40")
+        monkeypatch.setenv("TENDON_HIP_SEARCH_HOST_SHARE", "25")
+        _same(ref, _solve(prm, starts, goals, eager), expansions=False)
+        assert prm.search_stats["handed_back"] > 100 and prm.search_stats["host_meanwhile"] > 100, prm.search_stats
+        monkeypatch.delenv("TENDON_HIP_SEARCH_BUDGET")
+        monkeypatch.delenv("TENDON_HIP_SEARCH_HOST_SHARE")
+
+
+def test_device_searches_with_open_lists_beyond_the_lds_part(irt, monkeypatch):
+    """20 000 vertices, no landmark bounds: the open list of a search outgrows the kernel's LDS part (1024 entries), so the threshold
+    drops (entries move to the list in HBM) and rises again (they come back) many times per search."""
+    prm, states = _prm(irt, 20000, 8, seed=5, n_new_spheres=70)
+    prm.prepare(0)
+    rng = np.random.default_rng(8)
+    nq = 600
+    order = np.argsort(states[:, 0] + states[:, 1])                # end points from opposite corners of the sampled box: long searches
+    starts, goals = rng.choice(order[:2000], nq).astype(np.int64), rng.choice(order[-2000:], nq).astype(np.int64)
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+    ref = _solve(prm, starts, goals, True)
+    assert prm.search_stats["device"] == 0
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "device")
+    _same(ref, _solve(prm, starts, goals, True))
+    ss = prm.search_stats
+    assert ss["device"] == ref[1]["astar_runs"] and ss["handed_back"] == 0 and ss["list_moves"] > nq, ss   # ... and it did happen
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+    ref = _solve(prm, starts, goals, False)
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "device")
+    _same(ref, _solve(prm, starts, goals, False))
+
+
+def test_roadmap_with_parallel_edges_stays_on_the_host(irt, monkeypatch):
+    """Two edges between the same pair of vertices: the kernel relaxes a vertex's arcs in parallel lanes, so such a roadmap is
+    searched on the host whatever the switch says -- and gives the answers it always gave."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=3)
+    states, _ = rb.sample_valid_vertices(300, batch=4096)
+    edges = rb.knn_edges_gpu(states, 5)
+    valid, _ = rb.validate_edges(states, edges)
+    edges = edges[valid]
+    doubled = np.concatenate([edges, edges[:7][:, ::-1]])
+    rng = np.random.default_rng(2)
+    starts, goals = rng.integers(0, len(states), 64), rng.integers(0, len(states), 64)
+    outs = []
+    for ed in (edges, doubled):
+        prm = irt.VoxelCachedLazyPRM(chk, states, ed)
+        prm.set_caches(rb.vertex_caches(states), rb.edge_caches(states, ed))
+        prm.set_obstacles(vox)
+        monkeypatch.setenv("TENDON_HIP_SEARCH", "device")
+        outs.append(prm.solveWithRoadmap(starts, goals))
+    assert np.array_equal(outs[0]["status"], outs[1]["status"]) and np.array_equal(outs[0]["cost"], outs[1]["cost"])
+    assert np.array_equal(outs[0]["path_vertices"], outs[1]["path_vertices"])
