@@ -599,6 +599,13 @@ int64_t search_budget() {
   return b > 0 ? (int64_t)b : 0;
 }
 
+// vertices a step of the kernel takes off a search's open list (1: the host's order of expansions exactly); TENDON_HIP_SEARCH_K overrides
+int search_kbest() {
+  const char *e = std::getenv("TENDON_HIP_SEARCH_K");
+  const int k = e ? std::atoi(e) : trk::SR_K;
+  return std::max(1, std::min(k, (int)trk::SR_K));
+}
+
 // The resident part: adjacency, states, landmark table, validity bytes, and per wave slot a node array (V records), a far list, a
 // path staging area.  The slot count is what the chip holds of this kernel (LDS: 12.4 KiB per wave), cut to a memory budget.
 bool search_setup(tr_roadmap *r) {
@@ -740,6 +747,7 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
   a.far_f = d.d_far_f; a.far_v = d.d_far_v; a.far_cap = d.far_cap; a.stage = d.d_stage;
   a.found = d.d_found; a.poff = d.d_poff; a.plen = d.d_plen; a.pbuf = d.d_pbuf; a.pbuf_cap = d.pbuf_cap;
   a.max_pops = budget > 0 ? budget : 16 * V + 1024;             // (uncapped: every vertex reopened a few times, far beyond what a search does)
+  a.kbest = search_kbest();
   const unsigned grid = (unsigned)std::min<int64_t>(d.slots, nq);
   if (std::getenv("TENDON_HIP_SEARCH_STATS"))
     std::fprintf(stderr, "[tendon_hip] search launch: V %lld E %lld arcs %lld L %d S %d nq %lld grid %u far_cap %d | adj_off %p adj %p states %p lm %p vstat %p estat %p gens %p ctl %p far_f %p far_v %p stage %p | nodes %p (%zu B) | qs %p qg %p poff %p plen %p found %p pbuf %p (%u)\n",

@@ -1,21 +1,27 @@
 // search_kernel.hpp -- `roadmap_astar`: the graph searches of the lazy query loop (VoxelCachedLazyPRM::solveWithRoadmap ->
 // constructSolution -> astarSearch, motion-planning/VoxelCachedLazyPRM.cpp:1977-2096, 2689-2771, 2950-2976) on the device, ONE WAVE PER
-// QUERY, thousands of queries in flight.  It is roadmap.hip's host `astar` statement for statement -- the same heuristic (state-space
-// distance, sharpened by the landmark bounds), the same relaxation rule (a vertex whose cost improves is opened again), the same
-// stopping rule (the goal leaves the open list) -- with the one thing a wave does better than a core: the ~12 arcs of an expanded
-// vertex are relaxed by as many lanes at once, each with its own dependent chain of loads (arc -> validity bytes, node record,
-// state, landmark row), and the chip hides those latencies behind the other waves.
+// QUERY, thousands of queries in flight.  It is roadmap.hip's host `astar` -- the same heuristic (state-space distance, sharpened by the
+// landmark bounds), the same relaxation rule (a vertex whose cost improves is opened again), the same stopping rule (the goal leaves
+// the open list as its minimum) -- shaped for a wave:
+//   * a step takes up to `kbest` vertices off the open list at once (the minimum, and the smallest of the other lanes' minima) and
+//     relaxes all their arcs together, ~12 per vertex, one lane each: the step is a chain of three dependent memory round trips
+//     (record + adjacency offsets -> arcs -> validity bytes, neighbour's record, state and landmark rows, all requested at once)
+//     whatever the number of lanes busy, so four vertices cost little more than one.  Expanding a vertex that is not the minimum is
+//     what any best-first search with re-opening may do: the stopping rule alone makes the returned cost optimal, and with it
+//     the path (the optimum is unique unless two paths' fp64 cost sums agree in every bit).  kbest = 1 is the host's order of
+//     expansions exactly (same count).
+//   * two lanes of a step may reach the same neighbour from different parents; the better one must win, whole: the lanes agree through
+//     three small LDS tables (owner by hash of the vertex, smallest cost, lowest lane among equals) before anyone writes.
 //
 // The open list is what a GPU has no good answer for; here it is split by a threshold T on the key f = g + h:
-//   near  (LDS, SR_CAP entries): every entry with f < T, unsorted; the minimum is a wave-wide scan + reduction (a few hundred cycles);
+//   near  (LDS, SR_CAP entries): every entry with f < T, unsorted; every lane scans its share, a wave reduction finds the minimum;
 //   far   (global, per wave):    every entry with f >= T, unsorted, append-only between refills.
 // near full -> T drops halfway towards near's minimum and the entries above it move to far; near empty -> T rises to a value that
 // lets about half a list's worth of far's entries in (found by counting) and they move to near.  Entries are never updated in place:
 // a vertex reached again with a better cost gets a new entry, the old one is skipped when it surfaces (its vertex is closed), as on
 // the host.
-// Every loop is bounded; a query that exceeds a bound (far list, expansions, path length, path buffer) is flagged SR_FALLBACK and the
-// host search answers it.  Ties between exactly equal keys may be broken differently than on the host (which breaks them by heap
-// order): equal-cost alternative paths, possible only between paths whose fp64 cost sums agree in every bit.
+// Every loop is bounded; a query that exceeds a bound (expansion budget, far list, path length, path buffer) is flagged SR_FALLBACK
+// and the host search answers it.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -24,32 +30,36 @@ namespace trk {
 
 struct SArc { int32_t v, e; double w; };                      // roadmap.hip: Arc
 struct SNode { double g, h; int32_t parent, parent_edge; uint32_t stamp, closed; };   // roadmap.hip: Node
-constexpr int SR_CAP = 1024;                                  // near-list entries per wave (LDS)
+constexpr int SR_CAP = 896;                                   // near-list entries per wave (LDS)
 constexpr int SR_MAXS = 12, SR_MAXL = 64;                     // state coordinates, landmarks
 constexpr int SR_PATH_MAX = 4096;                             // vertices of a path (per-wave staging)
+constexpr int SR_K = 4;                                       // vertices expanded per step, at most
+constexpr int SR_TAB = 128;                                   // slots of the conflict tables
 enum : uint8_t { SR_NO_PATH = 0, SR_FOUND = 1, SR_FALLBACK = 2 };
 constexpr uint8_t SR_INVALID = 2;                             // roadmap.hip: V_INVALID
-__host__ __device__ inline size_t search_lds_bytes() { return (size_t)SR_CAP * 12 + SR_MAXS * 8 + SR_MAXL * 4; }
+// near keys | near vertices | goal state | goal landmark row | conflict tables (owner, cost, lane): 12 waves per CU
+__host__ __device__ inline size_t search_lds_bytes() { return (size_t)SR_CAP * 12 + SR_MAXS * 8 + SR_MAXL * 4 + (size_t)SR_TAB * 16; }
 
 struct SearchArgs {
   const int64_t *adj_off; const SArc *adj;                    // CSR adjacency, both directions
-  const double *states; const float *lm;                      // [V][S]; [V][L] landmark distances or null
+  const double *states; const float *lm;                      // [V][S]; [V][L rounded up to a multiple of 4] landmark distances or null
   int32_t S, NT, rot, ret, L;
   double w_rot, w_ret, lm_slack;
   const uint8_t *vstat, *estat;
   int64_t V, E, n_arcs;
   const int32_t *qs, *qg; int64_t nq;                         // the round's queries
-  uint32_t *next;                                             // query ticket
+  uint32_t *next;                                             // control words: [0] query ticket, [1] path words used, [2..3] expansions, [4] list moves
   SNode *nodes; uint32_t *gens;                               // [slots][V], [slots]
   double *far_f; int32_t *far_v; int32_t far_cap;             // [slots][far_cap]
   int32_t *stage;                                             // [slots][2 SR_PATH_MAX] path staging
   uint8_t *found; int32_t *poff, *plen;                       // [nq]
   int32_t *pbuf; uint32_t pbuf_cap; uint32_t *pbuf_used;      // packed paths: vertices goal .. start, then their edges
   unsigned long long *expanded;
-  int64_t max_pops;
+  int64_t max_pops;                                           // expansions a search may spend before it is handed back
+  int32_t kbest;                                              // 1 .. SR_K
 };
 
-// Values that are the same in every lane are told so to the compiler (readfirstlane): counters, thresholds and the popped vertex
+// Values that are the same in every lane are told so to the compiler (readfirstlane): counters, thresholds and the popped vertices
 // live in scalar registers and the loops around them branch on the scalar unit instead of being predicated lane by lane.
 __device__ __forceinline__ int sr_u(int x) { return __builtin_amdgcn_readfirstlane(x); }
 // The lane index as the loops below see it: re-read through an empty asm once per iteration, so that the optimiser cannot prove the
@@ -83,30 +93,7 @@ __device__ __forceinline__ int sr_wave_sum(int c) {
   return sr_u(c);
 }
 
-// -DTRK_SEARCH_CHECKS: every index is checked before it is used; the first violation is recorded in the control words (code, lane,
-// value) and the wave leaves (debugging aid: the product build carries none of it)
-#ifdef TRK_SEARCH_CHECKS
-#define SR_CHK(cond, code, val)                                                                                          \
-  do {                                                                                                                   \
-    if (!(cond)) { a.next[8] = (uint32_t)(code); a.next[9] = (uint32_t)threadIdx.x; a.next[10] = (uint32_t)(val); a.next[11] = (uint32_t)((int64_t)(val) >> 32); return; } \
-  } while (0)
-#elif defined(TRK_SEARCH_CLAMPS)
-#define SR_CHK(cond, code, val)                                                                                          \
-  do {                                                                                                                   \
-    if (!(cond)) { if (atomicCAS(&a.next[8], 0u, (uint32_t)(code)) == 0u) { a.next[9] = (uint32_t)threadIdx.x; a.next[10] = (uint32_t)(val); a.next[11] = (uint32_t)((int64_t)(val) >> 32); a.next[12] = qi; a.next[13] = (uint32_t)pops_dbg; } val = 0; } \
-  } while (0)
-#else
-#define SR_CHK(cond, code, val) do { } while (0)
-#endif
-// (clamped build only) a loop that runs past any count it can legitimately reach is recorded and left
-#ifdef TRK_SEARCH_CLAMPS
-#define SR_LOOP_GUARD(counter, limit, code)                                                                              \
-  if (++(counter) > (limit)) { atomicCAS(&a.next[14], 0u, (uint32_t)(code)); a.next[15] = qi; break; }
-#else
-#define SR_LOOP_GUARD(counter, limit, code)
-#endif
-
-// -DTRK_SEARCH_CLOCKS: the 100 MHz clock read at the phase boundaries of an expansion, summed per phase into control words 16.. (profiling aid)
+// -DTRK_SEARCH_CLOCKS: the 100 MHz clock read at the phase boundaries of a step, summed per phase into control words 16.. (profiling aid)
 #ifdef TRK_SEARCH_CLOCKS
 #define SR_CLK(i) do { const unsigned long long t_ = wall_clock64(); clk[i] += t_ - t_last; t_last = t_; } while (0)
 #else
@@ -120,6 +107,9 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
   int32_t *nv = (int32_t *)(nf + SR_CAP);                     // [SR_CAP]
   double *gst = (double *)(nv + SR_CAP);                      // [SR_MAXS] the goal's state
   float *glm = (float *)(gst + SR_MAXS);                      // [SR_MAXL] the goal's landmark row
+  unsigned long long *tab_key = (unsigned long long *)(glm + SR_MAXL);   // [SR_TAB] smallest cost offered to the slot's vertex
+  uint32_t *tab_owner = (uint32_t *)(tab_key + SR_TAB);       // [SR_TAB] a lane that claimed the slot
+  uint32_t *tab_low = tab_owner + SR_TAB;                     // [SR_TAB] lowest lane among those offering the smallest cost
   const int lane_id = threadIdx.x;
   const int64_t slot = blockIdx.x;
   SNode *__restrict__ node = a.nodes + slot * a.V;
@@ -128,10 +118,11 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
   int32_t *__restrict__ stage = a.stage + slot * (int64_t)(2 * SR_PATH_MAX);
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
   const int S = a.S, L = a.L;
+  const int kbest = a.kbest < 1 ? 1 : (a.kbest > SR_K ? SR_K : a.kbest);
 
   // roadmap.hip: state_distance + the landmark bounds; every lane for its own vertex.  The loads -- the state row, then the landmark row
   // four float4 at a time (rows are padded to a multiple of four with zeros, which bound nothing) -- are all requested before the
-  // first is used: a lane's expansion is a chain of dependent memory round trips, and this keeps it at one for the heuristic.
+  // first is used: a lane's relaxation is a chain of dependent memory round trips, and this keeps it at one for the heuristic.
   const int NT = a.NT, L4 = (L + 3) >> 2;
   const bool rot = a.rot != 0, ret = a.ret != 0;
   const float slack = (float)a.lm_slack;
@@ -186,22 +177,16 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
     return h;
   };
 
-  int lg_ticket = 0;
-  (void)lg_ticket;
   for (;;) {
     int lane = sr_opaque(lane_id);
+    const unsigned long long below = ((unsigned long long)1 << lane) - 1;
     uint32_t qi = 0, gen = 0;
-    SR_LOOP_GUARD(lg_ticket, 100000, 20)
     if (lane == 0) { qi = atomicAdd(a.next, 1u); }
     qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
     if ((int64_t)qi >= a.nq) break;
     if (lane == 0) { gen = a.gens[slot] + 1u; a.gens[slot] = gen; }
     gen = (uint32_t)__builtin_amdgcn_readfirstlane((int)gen);
-    int32_t start = a.qs[qi];
-    const int32_t goal = a.qg[qi];
-    int64_t pops_dbg = -1;
-    (void)pops_dbg;
-    SR_CHK(start >= 0 && start < a.V && goal >= 0 && goal < a.V, 1, start);
+    const int32_t start = a.qs[qi], goal = a.qg[qi];
     __syncthreads();
     if (lane < S) gst[lane] = a.states[(int64_t)goal * S + lane];
     if (lane < 4 * L4) glm[lane] = a.lm[(int64_t)goal * (4 * L4) + lane];
@@ -220,17 +205,15 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
 #ifdef TRK_SEARCH_CLOCKS
       unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
 #endif
-      for (int64_t pops = 0;; pops++) {
+      for (;;) {
         lane = sr_opaque(lane);
         SR_CLK(4);
-        if (pops >= a.max_pops) { result = SR_FALLBACK; break; }
+        if ((int64_t)exp_q >= a.max_pops) { result = SR_FALLBACK; break; }
         if (n_near == 0) {
           if (n_far == 0) break;                               // the open list is empty: no path
           // ---- refill: raise T so that about half a list's worth of far's entries come in ----
           double mn = inf, mx = -inf;
-          int lg = 0;
-          (void)lg;
-          for (int i = lane; i < n_far; i += 64) { SR_LOOP_GUARD(lg, 2048, 21) const double f = ff[i]; mn = f < mn ? f : mn; mx = f > mx ? f : mx; }
+          for (int i = lane; i < n_far; i += 64) { const double f = ff[i]; mn = f < mn ? f : mn; mx = f > mx ? f : mx; }
           mn = sr_wave_min(mn); mx = sr_wave_max(mx);
           double Tn = inf;
           if (n_far > SR_CAP / 2) {
@@ -239,8 +222,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
             if (!(Tn > mn)) Tn = inf;                          // every key the same: they all qualify (and must fit: checked below)
             for (int tries = 0; tries < 64; tries++) {
               int c = 0;
-              lg = 0;
-              for (int i = lane; i < n_far; i += 64) { SR_LOOP_GUARD(lg, 2048, 22) c += ff[i] < Tn ? 1 : 0; }
+              for (int i = lane; i < n_far; i += 64) c += ff[i] < Tn ? 1 : 0;
               c = sr_wave_sum(c);
               if (c <= SR_CAP) break;
               const double Th = mn + (Tn - mn) * 0.5;
@@ -251,16 +233,13 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
           }
           // partition far in place: keys below Tn to near, the rest compacted to the front
           int keep = 0;
-          lg = 0;
           for (int c0 = 0; c0 < n_far; c0 += 64) {
-            SR_LOOP_GUARD(lg, 2048, 23)
             const int i = c0 + lane;
             const bool on = i < n_far;
             const double f = on ? ff[i] : 0.0;
             const int32_t v = on ? fv[i] : 0;
             const bool in = on && f < Tn, stay = on && !in;
             const unsigned long long mi = __ballot(in), ms = __ballot(stay);
-            const unsigned long long below = ((unsigned long long)1 << lane) - 1;
             if (in) { const int p = n_near + __popcll(mi & below); if (p < SR_CAP) { nf[p] = f; nv[p] = v; } }
             if (stay) { const int p = keep + __popcll(ms & below); ff[p] = f; fv[p] = v; }
             n_near += __popcll(mi); keep += __popcll(ms);
@@ -273,89 +252,158 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
           if (n_near == 0) { result = SR_FALLBACK; break; }    // (cannot happen: the minimum qualifies)
         }
         SR_CLK(0);
-        // ---- pop: the smallest key of near ----
+        // ---- select: every lane the smallest key of its share of near (entries lane, lane + 64, ...; four reads in flight, compared
+        // in index order), then up to kbest rounds of a wave minimum over the lanes not taken yet: the first is near's minimum ----
         double best = inf;
         int bi = -1;
-        int lg2 = 0;
-        (void)lg2;
-        for (int i0 = 0; i0 < n_near; i0 += 256) {                // (four reads in flight per lane; the order of the comparisons is the index order)
-          SR_LOOP_GUARD(lg2, 32, 24)
+        for (int i0 = 0; i0 < n_near; i0 += 256) {
           double f4[4];
 #pragma unroll
           for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; f4[j] = i < n_near ? nf[i] : inf; }
 #pragma unroll
           for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; if (i < n_near && (f4[j] < best || bi < 0)) { best = f4[j]; bi = i; } }
         }
-        const double fmin = sr_wave_min(best);
-        const unsigned long long who = __ballot(bi >= 0 && best == fmin);
-        pops_dbg = pops;
-        int idx = sr_u(__shfl(bi, __ffsll((long long)who) - 1, 64));
-        SR_CHK(idx >= 0 && idx < n_near, 2, idx);
-        int32_t u = sr_u(nv[idx]);
-        SR_CHK(u >= 0 && u < a.V, 3, u);
+        int sel_i[SR_K], sel_u[SR_K];
+        int nsel = 0;
+        bool taken = bi < 0;
+#pragma unroll
+        for (int r = 0; r < SR_K; r++) {
+          sel_i[r] = -1; sel_u[r] = -1;
+          if (r < kbest && nsel == r) {
+            const double fm = sr_wave_min(taken ? inf : best);
+            const unsigned long long who = __ballot(!taken && best == fm);
+            if (who) {
+              const int src = __ffsll((long long)who) - 1;
+              sel_i[r] = sr_u(__shfl(bi, src, 64));
+              sel_u[r] = sr_u(nv[sel_i[r]]);
+              if (lane == src) taken = true;
+              nsel = r + 1;
+            }
+          }
+        }
+        // the goal ends the search when it is the minimum; found further down the batch it stays on the list, with what follows it
+#pragma unroll
+        for (int r = 1; r < SR_K; r++)
+          if (r < nsel && sel_u[r] == goal) nsel = r;
         __syncthreads();
-        if (lane == 0) { nf[idx] = nf[n_near - 1]; nv[idx] = nv[n_near - 1]; }
-        n_near--;
+        // the entries leave the list, the highest index first (the last entry moves into the hole: never one still to be removed)
+        {
+          int idx[SR_K];
+#pragma unroll
+          for (int r = 0; r < SR_K; r++) idx[r] = r < nsel ? sel_i[r] : -1;
+#pragma unroll
+          for (int p = 0; p < SR_K; p++)
+#pragma unroll
+            for (int q = 0; q + 1 < SR_K - p; q++)
+              if (idx[q] < idx[q + 1]) { const int t = idx[q]; idx[q] = idx[q + 1]; idx[q + 1] = t; }
+#pragma unroll
+          for (int r = 0; r < SR_K; r++) {
+            if (idx[r] >= 0) {
+              if (lane == 0) { nf[idx[r]] = nf[n_near - 1]; nv[idx[r]] = nv[n_near - 1]; }
+              n_near--;
+            }
+          }
+        }
         __syncthreads();
         SR_CLK(1);
-        const SNode nu_ = node[u];
-        const int64_t a0_ = a.adj_off[u], a1_ = a.adj_off[u + 1];       // (requested with the record: both hang on u alone)
-        const double nu_g = sr_u(nu_.g);
-        if (sr_u((int)nu_.closed)) continue;                               // a stale entry of a vertex already expanded with a better cost
-        if (lane == 0) node[u].closed = 1u;
-        exp_q++;
-        if (u == goal) { result = SR_FOUND; break; }
-        const int64_t a0 = sr_u(a0_);
-        int64_t a1 = sr_u(a1_);
-        SR_CHK(a0 >= 0 && a0 <= a1 && a1 <= a.n_arcs, 4, a1);
+        // ---- the vertices' records and adjacency offsets, one lane each; closed ones (stale entries) and repeats are dropped ----
+        int my_u = -1;
+#pragma unroll
+        for (int r = 0; r < SR_K; r++) if (lane == r && r < nsel) my_u = sel_u[r];
+        SNode rec = SNode{0.0, 0.0, -1, -1, 0u, 1u};
+        int64_t my_a0 = 0, my_a1 = 0;
+        if (my_u >= 0) { rec = node[my_u]; my_a0 = a.adj_off[my_u]; my_a1 = a.adj_off[my_u + 1]; }
+        bool live = my_u >= 0 && rec.closed == 0u;
+#pragma unroll
+        for (int r = 0; r + 1 < SR_K; r++) if (lane > r && r < nsel && my_u == sel_u[r]) live = false;
+        if (live) node[my_u].closed = 1u;
+        const unsigned long long mlive = __ballot(live);
+        exp_q += (unsigned long long)__popcll(mlive);
+        if ((mlive & 1ull) && sel_u[0] == goal) { result = SR_FOUND; break; }
+        double pg[SR_K];
+        int64_t pa0[SR_K];
+        int cum[SR_K + 1];
+        cum[0] = 0;
+#pragma unroll
+        for (int r = 0; r < SR_K; r++) {
+          const bool on = (mlive >> r) & 1ull;
+          pg[r] = sr_u(__shfl(rec.g, r, 64));
+          pa0[r] = sr_u(__shfl(my_a0, r, 64));
+          const int64_t e1 = sr_u(__shfl(my_a1, r, 64));
+          cum[r + 1] = cum[r] + (on ? (int)(e1 - pa0[r]) : 0);
+        }
+        const int total = cum[SR_K];
         SR_CLK(2);
         bool failed = false;
-        lg2 = 0;
-        for (int64_t base = a0; base < a1 && !failed; base += 64) {
-          SR_LOOP_GUARD(lg2, 4096, 25)
-          const int64_t k = base + lane;
-          bool push = false;
-          double fp = 0.0;
-          int32_t vp = 0;
-          if (k < a1) {
-            SArc arc = a.adj[k];
-            SR_CHK(arc.v >= 0 && arc.v < a.V, 5, arc.v);
-            SR_CHK(arc.e >= 0 && arc.e < a.E, 6, arc.e);
+        for (int base = 0; base < total && !failed; base += 64) {
+          const int t = base + lane;
+          bool cand = false, push = false;
+          double fp = 0.0, gv = 0.0, hh = 0.0;
+          int32_t vp = 0, pu = -1, pe = -1;
+          SNode nn = SNode{0.0, 0.0, -1, -1, 0u, 0u};
+          if (t < total) {
+            int r = 0;
+#pragma unroll
+            for (int q = 1; q < SR_K; q++) r += t >= cum[q] ? 1 : 0;
+            int64_t k = 0;
+            double ug = 0.0;
+#pragma unroll
+            for (int q = 0; q < SR_K; q++) if (r == q) { k = pa0[q] + (t - cum[q]); ug = pg[q]; pu = sel_u[q]; }
+            const SArc arc = a.adj[k];
             // everything the relaxation can need is requested at once, whether or not it turns out to be needed: validity bytes,
             // the neighbour's record, and the rows of its heuristic (one memory round trip instead of three)
             const uint8_t es = a.estat[arc.e], vs = a.vstat[arc.v];
-            const SNode nn = node[arc.v];
+            nn = node[arc.v];
             const double hv = heuristic(arc.v);
             if (es != SR_INVALID && vs != SR_INVALID) {
-              const double gv = nu_g + arc.w;
+              gv = ug + arc.w;
               const bool first = nn.stamp != gen;
               if (first || gv < nn.g) {
-                const double h = first ? hv : nn.h;                  // h(v) is fixed for the query: computed when v is first reached
-                if (h == inf) node[arc.v] = SNode{gv, h, first ? -1 : nn.parent, first ? -1 : nn.parent_edge, gen, 1u};
-                else { node[arc.v] = SNode{gv, h, u, arc.e, gen, 0u}; push = true; fp = gv + h; vp = arc.v; }
+                hh = first ? hv : nn.h;                          // h(v) is fixed for the query: computed when v is first reached
+                if (first) { nn.parent = -1; nn.parent_edge = -1; }
+                cand = true; vp = arc.v; pe = arc.e;
               }
             }
+          }
+          // ---- two lanes with the same neighbour: the smaller cost wins (the lower lane among equals), the others stand down ----
+          if (__popcll(mlive) > 1) {
+            bool open = cand;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(gv);      // (costs are >= 0: ordered as integers)
+            const unsigned hs = ((unsigned)vp * 2654435761u) >> 25;
+            for (int round = 0; round < 16; round++) {
+              if (!__ballot(open)) break;
+              if (open) { tab_owner[hs] = (uint32_t)lane; tab_key[hs] = ~0ull; tab_low[hs] = 64u; }
+              __syncthreads();
+              const int w = open ? (int)tab_owner[hs] : lane;
+              const int32_t vw = __shfl(vp, w, 64);
+              const bool grp = open && vw == vp;                 // the slot is this vertex's for the round (another vertex's lanes wait)
+              if (grp) atomicMin(&tab_key[hs], key);
+              __syncthreads();
+              const bool least = grp && tab_key[hs] == key;
+              if (least) atomicMin(&tab_low[hs], (uint32_t)lane);
+              __syncthreads();
+              if (grp) { open = false; if (!(least && tab_low[hs] == (uint32_t)lane)) cand = false; }
+              __syncthreads();
+            }
+            if (__ballot(open)) { failed = true; break; }
+          }
+          if (cand) {
+            if (hh == inf) node[vp] = SNode{gv, hh, nn.parent, nn.parent_edge, gen, 1u};
+            else { node[vp] = SNode{gv, hh, pu, pe, gen, 0u}; push = true; fp = gv + hh; }
           }
           // ---- append: keys below T to near, the others to far ----
           unsigned long long mn_ = __ballot(push && fp < T);
           SR_CLK(3);
-          int lg3 = 0;
-          (void)lg3;
           while (n_near + __popcll(mn_) > SR_CAP) {
-            SR_LOOP_GUARD(lg3, 4096, 26)
             // near is full: T drops halfway towards its smallest key, what lies above moves to far
             double lo = inf, hi = -inf;
-            int lg4 = 0;
-            (void)lg4;
-            for (int i = lane; i < n_near; i += 64) { SR_LOOP_GUARD(lg4, 32, 27) const double f = nf[i]; lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
+            for (int i = lane; i < n_near; i += 64) { const double f = nf[i]; lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
             lo = sr_wave_min(lo); hi = sr_wave_max(hi);
             const double top = T < inf ? T : hi;
             const double Tn = lo + (top - lo) * 0.5;
             if (!(Tn > lo) || !(Tn < top)) { failed = true; break; }
             int keep = 0;
-            lg4 = 0;
             for (int c0 = 0; c0 < n_near; c0 += 64) {
-              SR_LOOP_GUARD(lg4, 32, 28)
               const int i = c0 + lane;
               const bool on = i < n_near;
               const double f = on ? nf[i] : 0.0;
@@ -363,7 +411,6 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
               __syncthreads();
               const bool stay = on && f < Tn, out = on && !stay;
               const unsigned long long ms = __ballot(stay), mo = __ballot(out);
-              const unsigned long long below = ((unsigned long long)1 << lane) - 1;
               if (stay) { const int p = keep + __popcll(ms & below); nf[p] = f; nv[p] = v; }
               if (out) { const int p = n_far + __popcll(mo & below); if (p < a.far_cap) { ff[p] = f; fv[p] = v; } }
               keep += __popcll(ms); n_far += __popcll(mo);
@@ -378,9 +425,8 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
           if (failed) break;
           const unsigned long long mf_ = __ballot(push && !(fp < T));
           if (n_far + __popcll(mf_) > a.far_cap) { failed = true; break; }
-          const unsigned long long below = ((unsigned long long)1 << lane) - 1;
-          if (push && fp < T) { int p = n_near + __popcll(mn_ & below); SR_CHK(p >= 0 && p < SR_CAP, 9, p); nf[p] = fp; nv[p] = vp; }
-          else if (push) { int p = n_far + __popcll(mf_ & below); SR_CHK(p >= 0 && p < a.far_cap, 8, p); ff[p] = fp; fv[p] = vp; }
+          if (push && fp < T) { const int p = n_near + __popcll(mn_ & below); nf[p] = fp; nv[p] = vp; }
+          else if (push) { const int p = n_far + __popcll(mf_ & below); ff[p] = fp; fv[p] = vp; }
           n_near += __popcll(mn_); n_far += __popcll(mf_);
           __syncthreads();
         }
@@ -400,7 +446,6 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
         int32_t v = goal;
         for (;;) {
           if (nvert >= SR_PATH_MAX) { nvert = -1; break; }
-          SR_CHK(v >= 0 && v < a.V, 7, v);
           stage[nvert] = v;
           if (v == start) { nvert++; break; }
           const SNode nd = node[v];
@@ -420,11 +465,8 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
       if ((uint64_t)off + need > a.pbuf_cap) result = SR_FALLBACK;
       else {
         __threadfence_block();
-        int lg5 = 0;
-        (void)lg5;
-        for (int i = lane; i < nvert; i += 64) { SR_LOOP_GUARD(lg5, 128, 29) a.pbuf[off + i] = stage[i]; }
-        lg5 = 0;
-        for (int i = lane; i < nvert - 1; i += 64) { SR_LOOP_GUARD(lg5, 128, 30) a.pbuf[off + nvert + i] = stage[SR_PATH_MAX + i]; }
+        for (int i = lane; i < nvert; i += 64) a.pbuf[off + i] = stage[i];
+        for (int i = lane; i < nvert - 1; i += 64) a.pbuf[off + nvert + i] = stage[SR_PATH_MAX + i];
         if (lane == 0) { a.poff[qi] = (int32_t)off; a.plen[qi] = nvert; }
       }
     }
