@@ -77,20 +77,46 @@ __device__ __forceinline__ int64_t sr_u(int64_t x) {
   const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32));
   return (int64_t)(((unsigned long long)hi << 32) | lo);
 }
+// Wave reductions on the DPP path (no LDS traffic: a ds_bpermute butterfly is twelve LDS round trips for a double): rotations by
+// 8, 4, 2, 1 inside each row of 16 lanes leave the row's result in all of its lanes, row_bcast15 / row_bcast31 fold the rows into
+// lane 63, which is read back as a scalar.
+#define SR_DPP32(v, ctrl, rmask) __builtin_amdgcn_update_dpp((v), (v), (ctrl), (rmask), 0xf, false)
+#define SR_DPP_STEP64(x, ctrl, rmask, OP)                                                                                \
+  do {                                                                                                                   \
+    const long long b_ = __double_as_longlong(x);                                                                        \
+    const int lo_ = SR_DPP32((int)(unsigned)b_, ctrl, rmask), hi_ = SR_DPP32((int)(unsigned)(b_ >> 32), ctrl, rmask);     \
+    const double y_ = __longlong_as_double((long long)(((unsigned long long)(unsigned)hi_ << 32) | (unsigned)lo_));      \
+    x = (y_ OP x) ? y_ : x;                                                                                              \
+  } while (0)
+__device__ __forceinline__ double sr_lane63(double x) {
+  const long long b = __double_as_longlong(x);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+template <class T> __device__ __forceinline__ T sr_lane(T x, int l) {        // lane l's 64-bit value as a scalar (v_readlane, no LDS)
+  static_assert(sizeof(T) == 8, "two dwords");
+  unsigned long long b;
+  __builtin_memcpy(&b, &x, 8);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), l);
+  b = ((unsigned long long)hi << 32) | lo;
+  T y;
+  __builtin_memcpy(&y, &b, 8);
+  return y;
+}
 __device__ __forceinline__ double sr_wave_min(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = y < x ? y : x; }
-  return sr_u(x);
+  SR_DPP_STEP64(x, 0x128, 0xf, <); SR_DPP_STEP64(x, 0x124, 0xf, <); SR_DPP_STEP64(x, 0x122, 0xf, <); SR_DPP_STEP64(x, 0x121, 0xf, <);
+  SR_DPP_STEP64(x, 0x142, 0xa, <); SR_DPP_STEP64(x, 0x143, 0xc, <);
+  return sr_lane63(x);
 }
 __device__ __forceinline__ double sr_wave_max(double x) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const double y = __shfl_xor(x, o, 64); x = y > x ? y : x; }
-  return sr_u(x);
+  SR_DPP_STEP64(x, 0x128, 0xf, >); SR_DPP_STEP64(x, 0x124, 0xf, >); SR_DPP_STEP64(x, 0x122, 0xf, >); SR_DPP_STEP64(x, 0x121, 0xf, >);
+  SR_DPP_STEP64(x, 0x142, 0xa, >); SR_DPP_STEP64(x, 0x143, 0xc, >);
+  return sr_lane63(x);
 }
 __device__ __forceinline__ int sr_wave_sum(int c) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o, 64);
-  return sr_u(c);
+  c += SR_DPP32(c, 0x128, 0xf); c += SR_DPP32(c, 0x124, 0xf); c += SR_DPP32(c, 0x122, 0xf); c += SR_DPP32(c, 0x121, 0xf);
+  // (the row sums are in every lane of their rows: fold the four rows through scalars)
+  return __builtin_amdgcn_readlane(c, 0) + __builtin_amdgcn_readlane(c, 16) + __builtin_amdgcn_readlane(c, 32) + __builtin_amdgcn_readlane(c, 48);
 }
 
 // -DTRK_SEARCH_CLOCKS: the 100 MHz clock read at the phase boundaries of a step, summed per phase into control words 16.. (profiling aid)
@@ -274,7 +300,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
             const unsigned long long who = __ballot(!taken && best == fm);
             if (who) {
               const int src = __ffsll((long long)who) - 1;
-              sel_i[r] = sr_u(__shfl(bi, src, 64));
+              sel_i[r] = __builtin_amdgcn_readlane(bi, src);
               sel_u[r] = sr_u(nv[sel_i[r]]);
               if (lane == src) taken = true;
               nsel = r + 1;
@@ -327,9 +353,9 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
 #pragma unroll
         for (int r = 0; r < SR_K; r++) {
           const bool on = (mlive >> r) & 1ull;
-          pg[r] = sr_u(__shfl(rec.g, r, 64));
-          pa0[r] = sr_u(__shfl(my_a0, r, 64));
-          const int64_t e1 = sr_u(__shfl(my_a1, r, 64));
+          pg[r] = sr_lane(rec.g, r);
+          pa0[r] = sr_lane(my_a0, r);
+          const int64_t e1 = sr_lane(my_a1, r);
           cum[r + 1] = cum[r] + (on ? (int)(e1 - pa0[r]) : 0);
         }
         const int total = cum[SR_K];
