@@ -242,6 +242,7 @@ def secondary_metrics():
                 "create_roadmap_s": c3["create_roadmap"]["seconds"]},
             "config5_10k_queries": {
                 "queries_per_s_lazy": q["lazy"]["queries_per_s"], "lazy_rounds": q["lazy"]["rounds"], "lazy_items_checked": q["lazy"]["items_checked"],
+                "queries_per_s_lazy_host_threads_only": q["searches_on_host_threads_only"]["lazy_queries_per_s"], "lazy_searches": q["lazy"]["searches"],
                 "queries_per_s_eager_incl_revalidation": q["eager"]["queries_per_s_incl_revalidation"],
                 "revalidate_all_cached_sets_ms": q["eager"]["revalidate_all_ms"], "cached_sets": q["roadmap_vertices"] + q["roadmap_edges"],
                 "vertex_caches_built_per_s": c5["vertex_caches_built_per_s"], "edge_caches_built_per_s": c5["edge_caches_built_per_s"],

@@ -259,7 +259,7 @@ def run(argv=None):
     t0 = time.perf_counter()
     lazy = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
     t_lazy = time.perf_counter() - t0
-    st_lazy = dict(prm.stats)
+    st_lazy = dict(prm.stats, searches=dict(prm.search_stats))
     k4l = chk.engine.profile_read()["cached_blocks_vs_grid"]
     chk.engine.profile_end()
     prm.clearValidity()
@@ -269,7 +269,22 @@ def run(argv=None):
     t0 = time.perf_counter()
     eager = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
     t_eager = time.perf_counter() - t0
-    st_eager = dict(prm.stats)
+    st_eager = dict(prm.stats, searches=dict(prm.search_stats))
+    # the same two calls with every graph search on the host threads (TENDON_HIP_SEARCH=host): the round-3 schedule, timed beside
+    import os
+    os.environ["TENDON_HIP_SEARCH"] = "host"
+    prm.clearValidity()
+    t0 = time.perf_counter()
+    lazy_h = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    t_lazy_host = time.perf_counter() - t0
+    prm.clearValidity()
+    prm.revalidate()
+    t0 = time.perf_counter()
+    prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    t_eager_host = time.perf_counter() - t0
+    del os.environ["TENDON_HIP_SEARCH"]
+    assert np.array_equal(lazy["status"], lazy_h["status"]) and np.array_equal(lazy["cost"], lazy_h["cost"])
+    assert np.array_equal(lazy["path_vertices"], lazy_h["path_vertices"])
     assert np.array_equal(lazy["status"], eager["status"]) and np.array_equal(lazy["cost"], eager["cost"])
     assert np.array_equal(lazy["status"], plain["status"]) and np.array_equal(lazy["cost"], plain["cost"])
     assert np.array_equal(lazy["path_vertices"], plain["path_vertices"])
@@ -283,6 +298,8 @@ def run(argv=None):
           "eager": {"queries_per_s_incl_revalidation": nq / (t_eager + t_reval), "revalidate_all_ms": 1e3 * t_reval,
                     "items_per_s_revalidation": (len(states) + len(e_ok)) / t_reval, "search_seconds": t_eager, **st_eager,
                     "invalid_vertices": n_bad_v, "invalid_edges": n_bad_e},
+          "searches_on_host_threads_only": {"lazy_queries_per_s": nq / t_lazy_host, "eager_search_seconds": t_eager_host,
+                                            "same_statuses_costs_paths": True},
           "solved_fraction": float((lazy["status"] == 0).mean()), "no_path": int((lazy["status"] == 1).sum()),
           "invalid_endpoint": int((lazy["status"] >= 2).sum()),
           "path_vertices": {"mean": float(plen.mean()) if len(plen) else 0.0, "max": int(plen.max()) if len(plen) else 0}}

@@ -557,8 +557,17 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *   TENDON_HIP_MERGE=sort           edge voxel sets merged by the segmented sort (default: the per-edge LDS table);
  *                                   TENDON_HIP_MERGE_MAXLOAD=n bounds that table's load (tests: reaches the overflow fallback)
  *   TENDON_HIP_LANDMARKS=...        landmark choice of tr_roadmap_prepare (csrc/roadmap.hip; tuning)
+ *   TENDON_HIP_SEARCH=host|device   graph searches of tr_roadmap_solve: unset = a round of 512 or more queries is shared between the
+ *                                   roadmap_astar kernel and the host threads (below), a smaller round is the host threads'; host =
+ *                                   the host threads always; device = the kernel always, whole rounds, no budget (tests)
+ *   TENDON_HIP_SEARCH_HOST_SHARE=p  per cent of a shared round's searches (the ones with the most distant end points) that the host
+ *                                   threads take while the kernel runs (default 2)
+ *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default 10000; 0 none)
+ *   TENDON_HIP_SEARCH_K=1..4        vertices the kernel takes off a search's open list per step (default 4; 1 = the host's order)
+ *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds, within 12 GiB of records)
  *   TENDON_HIP_PIPE_LOG2=n          chunk size 2^n of tr_validate_batch's host-buffer pipeline (tuning)
- * Output on stderr only: TENDON_HIP_EDGE_TIMING, TENDON_HIP_VOX_TIMING, TENDON_HIP_ROADMAP_TIMING. */
+ * Output on stderr only: TENDON_HIP_EDGE_TIMING, TENDON_HIP_VOX_TIMING, TENDON_HIP_ROADMAP_TIMING, TENDON_HIP_SEARCH_STATS (where a
+ * round's searches ran and for how long), TENDON_HIP_SEARCH_HIST (expansions per search, host searches only). */
 
 #ifdef __cplusplus
 }

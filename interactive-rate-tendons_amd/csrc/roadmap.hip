@@ -637,7 +637,11 @@ bool search_setup(tr_roadmap *r) {
   }
   int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
   if (const char *e = std::getenv("TENDON_HIP_SEARCH_SLOTS")) slots = std::max<int64_t>(1, std::min<int64_t>(slots, std::atoll(e)));
-  const int64_t budget = (int64_t)12 << 30;                      // node records: 32 B x V per slot
+  int64_t budget = (int64_t)12 << 30;                            // node records: 32 B x V per slot; at most half of what is free
+  {
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<int64_t>(budget, (int64_t)(free_b / 2));
+  }
   slots = std::min<int64_t>(slots, budget / (32 * V));
   if (slots < 64) { d.why = "roadmap too large for resident node arrays"; return false; }
   d.slots = slots;
@@ -749,12 +753,6 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
   a.max_pops = budget > 0 ? budget : 16 * V + 1024;             // (uncapped: every vertex reopened a few times, far beyond what a search does)
   a.kbest = search_kbest();
   const unsigned grid = (unsigned)std::min<int64_t>(d.slots, nq);
-  if (std::getenv("TENDON_HIP_SEARCH_STATS"))
-    std::fprintf(stderr, "[tendon_hip] search launch: V %lld E %lld arcs %lld L %d S %d nq %lld grid %u far_cap %d | adj_off %p adj %p states %p lm %p vstat %p estat %p gens %p ctl %p far_f %p far_v %p stage %p | nodes %p (%zu B) | qs %p qg %p poff %p plen %p found %p pbuf %p (%u)\n",
-                 (long long)V, (long long)r->E, (long long)r->adj.size(), L, r->S, (long long)nq, grid, d.far_cap, (void *)d.d_adj_off, (void *)d.d_adj,
-                 (void *)d.d_states, (void *)d.d_lm, (void *)d.d_vstat, (void *)d.d_estat, (void *)d.d_gens, (void *)d.d_ctl, (void *)d.d_far_f,
-                 (void *)d.d_far_v, (void *)d.d_stage, (void *)d.nodes, (size_t)d.slots * V * sizeof(Node), (void *)d.d_qs, (void *)d.d_qg,
-                 (void *)d.d_poff, (void *)d.d_plen, (void *)d.d_found, (void *)d.d_pbuf, d.pbuf_cap);
   hipLaunchKernelGGL(trk::roadmap_astar, dim3(grid), dim3(64), trk::search_lds_bytes(), nullptr, a);
   if (hipGetLastError() != hipSuccess) return false;
   d.in_flight = nq;
@@ -787,13 +785,6 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
     if (tot > 0)
       std::fprintf(stderr, "[tendon_hip] search clocks: %.1f wave-ms in all (longest search %.2f ms): refill %.1f%%, pop %.1f%%, record + offsets %.1f%%, arcs + rows + relax %.1f%%, append %.1f%%\n",
                    tot * 1e-5, (double)c[6] * 1e-5, 100.0 * c[0] / tot, 100.0 * c[1] / tot, 100.0 * c[2] / tot, 100.0 * c[3] / tot, 100.0 * c[4] / tot);
-  }
-  if (ctl[14]) std::fprintf(stderr, "[tendon_hip] roadmap_astar: loop guard %u tripped (query %u)\n", ctl[14], ctl[15]);
-  if (ctl[8]) {                                                   // (only a -DTRK_SEARCH_CHECKS build writes these)
-    std::fprintf(stderr, "[tendon_hip] roadmap_astar: check %u failed in lane %u, value %lld (query %u, pop %u)\n", ctl[8], ctl[9],
-                 (long long)(((uint64_t)ctl[11] << 32) | ctl[10]), ctl[12], ctl[13]);
-    give_back();
-    return;
   }
   const uint32_t used = std::min(ctl[1], d.pbuf_cap);
   std::vector<int32_t> pbuf((size_t)used);
