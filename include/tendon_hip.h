@@ -438,8 +438,9 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
  * per query, when the round has 512 queries or more -- see TENDON_HIP_SEARCH below -- and by the host threads otherwise; the
  * answers are the same):  out[0] searches finished by the kernel, out[1] searches the kernel handed back to the host threads
  * (over its pop budget, or a list full), out[2] searches the host threads took while the kernel ran (the ones expected to be
- * longest), out[3] times a search's open list moved entries between its LDS part and its HBM part. */
-int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[4]);
+ * longest), out[3] times a search's open list moved entries between its LDS part and its HBM part, out[4] vertex expansions
+ * by the kernel (those of searches it handed back included), out[5] vertex expansions by the host threads. */
+int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[6]);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
  * of connectionStrategy_(v), `if (!getEdge(v, n)) connectVertices(v, n)`): the undirected edge set of the k-nearest

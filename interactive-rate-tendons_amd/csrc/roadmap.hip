@@ -235,7 +235,7 @@ struct tr_roadmap {
     double *d_far_f = nullptr; int32_t *d_far_v = nullptr, *d_stage = nullptr;
     int32_t *d_qs = nullptr, *d_qg = nullptr, *d_poff = nullptr, *d_plen = nullptr, *d_pbuf = nullptr;
     uint8_t *d_found = nullptr;
-    int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0;   // of the last tr_roadmap_solve
+    int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0, st_expanded = 0;   // of the last tr_roadmap_solve
     int64_t in_flight = 0;               // queries of the launch that has not been collected yet
     std::vector<int32_t> h_qs, h_qg;     // host images of what the pending copies read
     std::vector<float> h_padded;
@@ -792,6 +792,7 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
   unsigned long long ex = 0;
   std::memcpy(&ex, &ctl[2], sizeof(ex));
   expanded += (int64_t)ex;
+  d.st_expanded += (int64_t)ex;
   for (int64_t j = 0; j < nq; j++) {
     const size_t k = klist[(size_t)j];
     const int64_t q = active[k];
@@ -1047,7 +1048,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   if (n_queries < 0 || (n_queries > 0 && (!starts || !goals || !status || !path_offsets))) return rfail(r, TR_ERR_INVALID_ARG, "bad argument");
   r->path_off.assign((size_t)n_queries + 1, 0); r->path_v.clear();
   r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
-  r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = 0;
+  r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = r->ds.st_expanded = 0;
   if (path_offsets) path_offsets[0] = 0;
   if (n_queries == 0) { if (stats) *stats = tr_roadmap_stats{0, 0, 0, 0}; return TR_OK; }
   for (int64_t q = 0; q < n_queries; q++)
@@ -1115,7 +1116,8 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       std::sort(key.begin(), key.end(), [](const std::pair<double, size_t> &x, const std::pair<double, size_t> &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
       const size_t n_h = smode == 2 ? 0 : (size_t)((double)active.size() * search_host_share());
       for (size_t i = 0; i < key.size(); i++) (i < n_h ? host_list : dev_list).push_back(key[i].second);
-      on_device = device_search_launch(r, starts, goals, active, dev_list, smode == 2 ? 0 : search_budget());
+      // (TENDON_HIP_SEARCH=device: no budget unless TENDON_HIP_SEARCH_BUDGET asks for one)
+      on_device = device_search_launch(r, starts, goals, active, dev_list, smode == 2 && !std::getenv("TENDON_HIP_SEARCH_BUDGET") ? 0 : search_budget());
       if (!on_device) { host_list.clear(); dev_list.clear(); }
       else r->ds.st_host_share += (int64_t)host_list.size();
     }
@@ -1227,10 +1229,11 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   return TR_OK;
 }
 
-int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[4]) {
+int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[6]) {
   if (!r || !out) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock_(r->mu);
   out[0] = r->ds.st_queries; out[1] = r->ds.st_fallbacks; out[2] = r->ds.st_host_share; out[3] = r->ds.st_moves;
+  out[4] = r->ds.st_expanded; out[5] = r->st_expanded - r->ds.st_expanded;
   return TR_OK;
 }
 

@@ -159,8 +159,22 @@ def main():
     rng = np.random.default_rng(17)
     q = rng.integers(0, V, size=(2000, 2))
     prm.clearValidity()
-    prm.solveWithRoadmap(q[:, 0], q[:, 1])
+    with_env({"TENDON_HIP_SEARCH": "host"}, lambda: prm.solveWithRoadmap(q[:, 0], q[:, 1]))   # (the search kernel has its own section below)
     add("cached_subset_vs_grid", units=prm.stats["items_checked"], unit="cached sets (lazy rounds)")
+    # ---- the graph searches of the query loop on the device: 10 000 queries, validity known, every search on the kernel ------
+    prm.prepare(16)
+    q = rng.integers(0, V, size=(10000, 2))
+    prm.clearValidity()
+    prm.revalidate()
+    sreps, dev_exp = 3, 0
+    for _ in range(sreps):                  # every round on the kernel, with the default budget (a search over it is handed back: its expansions so far count)
+        with_env({"TENDON_HIP_SEARCH": "device", "TENDON_HIP_SEARCH_BUDGET": "10000"}, lambda: prm.solveWithRoadmap(q[:, 0], q[:, 1]))
+        dev_exp += prm.search_stats["expanded_device"]
+    deg = 2.0 * len(e_ok) / V
+    S_, L_ = states.shape[1], 16
+    add("roadmap_astar", bytes=dev_exp * (48 + deg * (16 + 2 + 32 + 8 * S_ + 4 * L_ + 32)), units=dev_exp,
+        unit="vertex expansions (three times 10 000 searches, a wave each; bytes: record + offsets + per arc: arc, validity, neighbour record read and written, state and landmark rows)",
+        searches=prm.search_stats["device"], list_moves=prm.search_stats["list_moves"])
     # ---- sphere checker (K8) and environment edits (K7) ------------------------------------------------------------------
     r2 = W.robot_config2()
     raw = irt.VoxelOctree(256)
