@@ -427,7 +427,8 @@ int tr_roadmap_clear_validity(tr_roadmap *rm);
 int tr_roadmap_revalidate(tr_roadmap *rm, int64_t *n_invalid_vertices, int64_t *n_invalid_edges);
 /* status per item: 0 unknown, 1 valid, 2 invalid (removed) */
 int tr_roadmap_get_validity(tr_roadmap *rm, uint8_t *vertex_status /*[n_vertices]*/, uint8_t *edge_status /*[n_edges]*/);
-/* The batched query loop.  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
+/* The batched query loop (lazy: only the items on candidate paths are tested, round by round -- until so many queries keep coming
+ * back that testing every cached set at once is cheaper, see TENDON_HIP_LAZY_ONLY).  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
  * query q's path (start ... goal) is entries path_offsets[q] .. path_offsets[q+1]-1 of the array
  * tr_roadmap_fetch_paths copies out.  n_threads = host threads for the A* searches (0 = the process's CPU share).
  * Validity discovered by a call is kept for the next one (as the reference's graph keeps it between queries). */
@@ -439,8 +440,10 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
  * answers are the same):  out[0] searches finished by the kernel, out[1] searches the kernel handed back to the host threads
  * (over its pop budget, or a list full), out[2] searches the host threads took while the kernel ran (the ones expected to be
  * longest), out[3] times a search's open list moved entries between its LDS part and its HBM part, out[4] vertex expansions
- * by the kernel (those of searches it handed back included), out[5] vertex expansions by the host threads. */
-int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[6]);
+ * by the kernel (those of searches it handed back included), out[5] vertex expansions by the host threads, out[6] queries answered
+ * "no path" without a search because their end points lie in different components of the roadmap minus the items known invalid
+ * (the reference's solutionComponent test, :2015-2044; labels recomputed on the device per round, see TENDON_HIP_COMPONENTS), out[7] 0. */
+int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[8]);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
  * of connectionStrategy_(v), `if (!getEdge(v, n)) connectVertices(v, n)`): the undirected edge set of the k-nearest
@@ -566,6 +569,13 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default 10000; 0 none)
  *   TENDON_HIP_SEARCH_K=1..4        vertices the kernel takes off a search's open list per step (default 4; 1 = the host's order)
  *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds, within 12 GiB of records)
+ *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when a tenth of the first
+ *                                   round's searches are still open after a round, every cached set is tested in one launch and
+ *                                   the next round is the last -- cheaper than more rounds of searches; same answers)
+ *   TENDON_HIP_COMPONENTS=0|1       component labels of the roadmap minus the invalid items (queries across components are answered "no
+ *                                   path" without a search): unset = from the moment they would have paid on this roadmap (a search
+ *                                   walked 2000 vertices in vain, or the kernel handed searches back), 1 = every round of 64 queries
+ *                                   or more, 0 = never (a query with an unreachable goal is searched to exhaustion)
  *   TENDON_HIP_PIPE_LOG2=n          chunk size 2^n of tr_validate_batch's host-buffer pipeline (tuning)
  * Output on stderr only: TENDON_HIP_EDGE_TIMING, TENDON_HIP_VOX_TIMING, TENDON_HIP_ROADMAP_TIMING, TENDON_HIP_SEARCH_STATS (where a
  * round's searches ran and for how long), TENDON_HIP_SEARCH_HIST (expansions per search, host searches only). */

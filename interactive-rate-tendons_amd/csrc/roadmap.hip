@@ -240,6 +240,17 @@ struct tr_roadmap {
     std::vector<int32_t> h_qs, h_qg;     // host images of what the pending copies read
     std::vector<float> h_padded;
   } ds;
+  // connected components of the roadmap minus what is known invalid (component_labels): the edge list and the labels in HBM
+  struct DevComp {
+    int state = 0;                       // 0: not set up yet, 1: ready, -1: not available
+    char *arena = nullptr;
+    int32_t *d_eu = nullptr, *d_ev = nullptr, *d_parent = nullptr, *d_label = nullptr;
+    uint8_t *d_vstat = nullptr, *d_estat = nullptr;
+    bool status_current = false;         // d_vstat / d_estat hold this round's validity bytes (the search kernel reads them too)
+    bool wanted = false;                 // a search on this roadmap has walked a component in vain: label every large round from now on
+    std::vector<int32_t> label;          // per vertex: the smallest vertex of its component
+    int64_t st_cut = 0;                  // searches of the last solve answered by the labels alone
+  } dc;
 };
 
 namespace {
@@ -565,6 +576,11 @@ void free_dev(tr_roadmap *r) {
   r->list_cap = 0; r->has_caches = false;
 }
 
+void free_comp(tr_roadmap *r) {
+  if (r->dc.arena) dev_cache().release(r->dc.arena);
+  r->dc = tr_roadmap::DevComp{};
+}
+
 void free_search(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.arena) dev_cache().release(d.arena);
@@ -573,11 +589,128 @@ void free_search(tr_roadmap *r) {
   d = tr_roadmap::DevSearch{};
 }
 
+// ---- connected components of the roadmap minus the items known invalid ----
+// The reference gives up on a query whose start and goal lie in different components before it searches (solutionComponent /
+// sameComponent, VoxelCachedLazyPRM.cpp:2015-2044; LazyPRM renumbers the components when it removes items).  Without that a search
+// for an unreachable goal walks the start's whole component before it reports "no path": 10^5 expansions, 37 ms on a core, 250 ms at
+// a wave's pace.  Here the labels are recomputed per round on the device: union-find over the edge list with atomic hooks of the
+// larger root under the smaller, then one pass that points every vertex at its root.  ~0.1 ms of kernels + the validity bytes up and the labels down.
+// (Plain loads and stores except for the hooks: another XCD's L2 may show an older parent, which is an ancestor all the same; a
+// vertex passed on the way is pointed at its grandparent -- path halving.  Only the compare-and-swap that turns a root into a
+// child has to see the truth, and it does: it is an agent-scope atomic, and its return value is where a failed attempt goes on.)
+__device__ __forceinline__ int32_t cc_root(int32_t *parent, int32_t x) {
+  int32_t p = parent[x];
+  for (int guard = 0; p != x && guard < (1 << 24); guard++) {
+    const int32_t gp = parent[p];
+    if (gp != p) parent[x] = gp;
+    x = p; p = gp;
+  }
+  return x;
+}
+__global__ __launch_bounds__(256) void cc_init(int32_t *__restrict__ parent, int64_t V) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v < V) parent[v] = (int32_t)v;
+}
+// first pass: every vertex under its smallest smaller neighbour (one atomicMin per edge on mostly distinct words) -- a forest of
+// short trees whose roots are the local minima, so that the hooks below contend for many words instead of one
+__global__ __launch_bounds__(256) void cc_seed(const int32_t *__restrict__ eu, const int32_t *__restrict__ ev, const uint8_t *__restrict__ estat,
+                                               const uint8_t *__restrict__ vstat, int64_t E, int32_t *parent) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E || estat[e] == V_INVALID) return;
+  const int32_t a = eu[e], b = ev[e];
+  if (a == b || vstat[a] == V_INVALID || vstat[b] == V_INVALID) return;
+  atomicMin(&parent[a > b ? a : b], a > b ? b : a);
+}
+__global__ __launch_bounds__(256) void cc_hook(const int32_t *__restrict__ eu, const int32_t *__restrict__ ev, const uint8_t *__restrict__ estat,
+                                               const uint8_t *__restrict__ vstat, int64_t E, int32_t *parent) {
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= E || estat[e] == V_INVALID) return;
+  const int32_t a = eu[e], b = ev[e];
+  if (vstat[a] == V_INVALID || vstat[b] == V_INVALID) return;
+  int32_t ra = cc_root(parent, a), rb = cc_root(parent, b);
+  for (int guard = 0; ra != rb && guard < (1 << 24); guard++) {
+    if (ra < rb) { const int32_t t = ra; ra = rb; rb = t; }                 // the larger root goes under the smaller
+    const int32_t old = atomicCAS(&parent[ra], ra, rb);
+    if (old == ra) break;                                                   // hooked
+    ra = cc_root(parent, old);                                              // someone else hooked it first: follow and try again
+    rb = cc_root(parent, rb);
+  }
+}
+// (reads only: a halving store of one thread here could replace the root another thread has just written for the same vertex by a
+// mere ancestor -- seen as connected pairs with different labels)
+__global__ __launch_bounds__(256) void cc_flatten(const int32_t *__restrict__ parent, int32_t *__restrict__ label, int64_t V) {
+  const int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (v >= V) return;
+  int32_t x = (int32_t)v, p = parent[x];
+  for (int guard = 0; p != x && guard < (1 << 24); guard++) { x = p; p = parent[x]; }
+  label[v] = x;
+}
+
+// r->dc.label[v] = the smallest vertex of v's component in the graph minus the items known invalid.  false: not available (no
+// edges, out of memory): the caller searches as before.
+bool component_labels(tr_roadmap *r) {
+  auto &c = r->dc;
+  c.status_current = false;
+  if (c.state < 0 || r->E == 0 || r->V < 2) return false;
+  const int dev = tr_device(r->ctx);
+  const int64_t V = r->V, E = r->E;
+  if (hipSetDevice(dev) != hipSuccess) return false;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  if (c.state == 0) {
+    c.state = -1;
+    const size_t b_e = up((size_t)E * 4), b_v = up((size_t)V * 4), b_vs = up((size_t)V), b_es = up((size_t)E);
+    if (dev_cache().alloc(dev, (void **)&c.arena, 2 * b_e + 2 * b_v + b_vs + b_es) != hipSuccess) return false;
+    char *p = c.arena;
+    c.d_eu = (int32_t *)p; p += b_e;
+    c.d_ev = (int32_t *)p; p += b_e;
+    c.d_parent = (int32_t *)p; p += b_v;
+    c.d_label = (int32_t *)p; p += b_v;
+    c.d_vstat = (uint8_t *)p; p += b_vs;
+    c.d_estat = (uint8_t *)p;
+    if (hipMemcpyAsync(c.d_eu, r->eu.data(), (size_t)E * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess ||
+        hipMemcpyAsync(c.d_ev, r->ev.data(), (size_t)E * 4, hipMemcpyHostToDevice, nullptr) != hipSuccess) { free_comp(r); r->dc.state = -1; return false; }
+    c.label.resize((size_t)V);
+    c.state = 1;
+  }
+  bool ok = hipMemcpyAsync(c.d_vstat, r->vstat.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+            hipMemcpyAsync(c.d_estat, r->estat.data(), (size_t)E, hipMemcpyHostToDevice, nullptr) == hipSuccess;
+  if (!ok) return false;
+  const bool timing = std::getenv("TENDON_HIP_SEARCH_STATS") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (timing) (void)hipStreamSynchronize(nullptr);
+  const auto t1 = std::chrono::steady_clock::now();
+  hipLaunchKernelGGL(cc_init, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, nullptr, c.d_parent, V);
+  hipLaunchKernelGGL(cc_seed, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, nullptr, c.d_eu, c.d_ev, c.d_estat, c.d_vstat, E, c.d_parent);
+  hipLaunchKernelGGL(cc_hook, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, nullptr, c.d_eu, c.d_ev, c.d_estat, c.d_vstat, E, c.d_parent);
+  hipLaunchKernelGGL(cc_flatten, dim3((unsigned)((V + 255) / 256)), dim3(256), 0, nullptr, c.d_parent, c.d_label, V);
+  if (hipGetLastError() != hipSuccess) return false;
+  if (timing) (void)hipStreamSynchronize(nullptr);
+  const auto t2 = std::chrono::steady_clock::now();
+  if (hipMemcpy(c.label.data(), c.d_label, (size_t)V * 4, hipMemcpyDeviceToHost) != hipSuccess) return false;
+  if (timing) {
+    const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    std::fprintf(stderr, "[tendon_hip] component labels: validity bytes up %.3f ms, kernels %.3f ms, labels down %.3f ms\n", ms(t0, t1), ms(t1, t2),
+                 ms(t2, std::chrono::steady_clock::now()));
+  }
+  c.status_current = true;
+  return true;
+}
+
 // ---- the graph searches on the device (search_kernel.hpp) ----
 static_assert(sizeof(trk::SArc) == sizeof(Arc) && sizeof(trk::SNode) == sizeof(Node), "the device records are the host's");
 
 // 0 = the host threads, 1 = the device for rounds of at least kSearchMinQueries queries, 2 = the device always (tests)
 constexpr int64_t kSearchMinQueries = 512;
+constexpr int64_t kComponentMinQueries = 64;                     // rounds smaller than this are searched without component labels
+constexpr int64_t kComponentTrigger = 2000;                      // expansions of a search that ends without a path, from which on labels pay
+// 0: never; 1: when they have paid before on this roadmap (a search walked kComponentTrigger vertices and found no path) or the kernel
+// hands searches back (default); 2: every round of kComponentMinQueries or more (TENDON_HIP_COMPONENTS=0 | unset | 1)
+int components_mode() {
+  const char *e = std::getenv("TENDON_HIP_COMPONENTS");
+  if (!e) return 1;
+  if (std::strcmp(e, "0") == 0 || std::strcmp(e, "off") == 0) return 0;
+  return 2;
+}
 int search_mode() {
   const char *e = std::getenv("TENDON_HIP_SEARCH");
   if (!e) return 1;
@@ -734,8 +867,9 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
     if (L) ok = hipMemcpyAsync(d.d_lm, src, (size_t)V * Lp * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess;
     d.lm_current = true;
   }
-  ok = ok && hipMemcpyAsync(d.d_vstat, r->vstat.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
-       (r->E == 0 || hipMemcpyAsync(d.d_estat, r->estat.data(), (size_t)r->E, hipMemcpyHostToDevice, nullptr) == hipSuccess) &&
+  const bool shared_status = r->dc.status_current;               // this round's validity bytes are in HBM already (component_labels)
+  ok = ok && (shared_status || (hipMemcpyAsync(d.d_vstat, r->vstat.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       (r->E == 0 || hipMemcpyAsync(d.d_estat, r->estat.data(), (size_t)r->E, hipMemcpyHostToDevice, nullptr) == hipSuccess))) &&
        hipMemcpyAsync(d.d_qs, qs.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_qg, qg.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemsetAsync(d.d_ctl, 0, 256, nullptr) == hipSuccess;
@@ -744,7 +878,7 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
   a.adj_off = d.d_adj_off; a.adj = d.d_adj; a.states = d.d_states; a.lm = L ? d.d_lm : nullptr;
   a.S = r->S; a.NT = r->NT; a.rot = r->rot; a.ret = r->ret; a.L = L;
   a.w_rot = r->w_rot; a.w_ret = r->w_ret; a.lm_slack = kLmSlack;
-  a.vstat = d.d_vstat; a.estat = d.d_estat; a.V = V; a.E = r->E; a.n_arcs = (int64_t)r->adj.size();
+  a.vstat = shared_status ? r->dc.d_vstat : d.d_vstat; a.estat = shared_status ? r->dc.d_estat : d.d_estat; a.V = V; a.E = r->E; a.n_arcs = (int64_t)r->adj.size();
   a.qs = d.d_qs; a.qg = d.d_qg; a.nq = nq;
   a.next = d.d_ctl; a.pbuf_used = d.d_ctl + 1; a.expanded = (unsigned long long *)(d.d_ctl + 2);
   a.nodes = d.nodes; a.gens = d.d_gens;
@@ -914,6 +1048,7 @@ void tr_roadmap_destroy(tr_roadmap *r) {
   (void)hipSetDevice(tr_device(r->ctx));
   free_dev(r);
   free_search(r);
+  free_comp(r);
   delete r;
 }
 
@@ -992,9 +1127,10 @@ int tr_roadmap_clear_validity(tr_roadmap *r) {
   return TR_OK;
 }
 
-int tr_roadmap_revalidate(tr_roadmap *r, int64_t *n_invalid_vertices, int64_t *n_invalid_edges) {
-  if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+}  // extern "C"
+namespace {
+// (the caller holds r->mu)
+int revalidate_locked(tr_roadmap *r, int64_t *n_invalid_vertices, int64_t *n_invalid_edges) {
   if (!r->has_caches) return rfail(r, TR_ERR_INVALID_ARG, "no voxel caches attached (tr_roadmap_set_caches)");
   RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
   const int64_t items = r->V + r->E;
@@ -1032,6 +1168,14 @@ int tr_roadmap_revalidate(tr_roadmap *r, int64_t *n_invalid_vertices, int64_t *n
   if (n_invalid_edges) *n_invalid_edges = ne;
   return TR_OK;
 }
+}  // namespace
+extern "C" {
+
+int tr_roadmap_revalidate(tr_roadmap *r, int64_t *n_invalid_vertices, int64_t *n_invalid_edges) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  return revalidate_locked(r, n_invalid_vertices, n_invalid_edges);
+}
 
 int tr_roadmap_get_validity(tr_roadmap *r, uint8_t *vertex_status, uint8_t *edge_status) {
   if (!r) return TR_ERR_INVALID_ARG;
@@ -1049,6 +1193,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   r->path_off.assign((size_t)n_queries + 1, 0); r->path_v.clear();
   r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
   r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = r->ds.st_expanded = 0;
+  r->dc.st_cut = 0;
   if (path_offsets) path_offsets[0] = 0;
   if (n_queries == 0) { if (stats) *stats = tr_roadmap_stats{0, 0, 0, 0}; return TR_OK; }
   for (int64_t q = 0; q < n_queries; q++)
@@ -1095,11 +1240,40 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
 
   std::vector<uint8_t> found;
   const int smode = search_mode();
+  bool went_eager = false;
+  int64_t first_round = 0;
   while (!active.empty()) {
     r->st_rounds++;
     // A* for every unresolved query, on the host cores
     found.assign(active.size(), 0);
     std::atomic<int64_t> expanded{0};
+    // queries whose end points lie in different components of what is left of the graph have no path: the labels answer them
+    // (rounds of kComponentMinQueries or more; TENDON_HIP_COMPONENTS=0 searches them as before, to the same answer)
+    r->dc.status_current = false;
+    std::vector<size_t> todo;                                   // positions in `active` that need a search
+    todo.reserve(active.size());
+    const int cmode = components_mode();
+    bool labels_now = false;
+    auto ensure_labels = [&]() {
+      if (labels_now) return true;
+      const auto t_cc = std::chrono::steady_clock::now();
+      if (cmode == 0 || !component_labels(r)) return false;
+      labels_now = true;
+      if (std::getenv("TENDON_HIP_SEARCH_STATS"))
+        std::fprintf(stderr, "[tendon_hip] round %lld: component labels %.3f ms\n", (long long)r->st_rounds,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_cc).count());
+      return true;
+    };
+    if ((int64_t)active.size() >= kComponentMinQueries && (cmode == 2 || (cmode == 1 && r->dc.wanted)) && ensure_labels()) {
+      const int32_t *lab = r->dc.label.data();
+      for (size_t k = 0; k < active.size(); k++) {
+        const int64_t q = active[k];
+        if (lab[starts[q]] == lab[goals[q]]) todo.push_back(k);
+      }
+      r->dc.st_cut += (int64_t)(active.size() - todo.size());
+    } else {
+      for (size_t k = 0; k < active.size(); k++) todo.push_back(k);
+    }
     // ... on the device when the round is large enough to fill it (search_kernel.hpp).  The searches are ordered by the state-space
     // distance between their end points, longest first: the host threads take the head of that order (a core expands a vertex in
     // a fraction of the time a wave does, so the searches expected to be longest are theirs) while the kernel works through the
@@ -1107,14 +1281,15 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     std::vector<size_t> host_list, dev_list, redo;
     bool on_device = false;
     const auto t_round = std::chrono::steady_clock::now();
-    if (smode == 2 || (smode == 1 && (int64_t)active.size() >= kSearchMinQueries)) {
-      std::vector<std::pair<double, size_t>> key(active.size());
-      for (size_t k = 0; k < active.size(); k++) {
+    if (!todo.empty() && (smode == 2 || (smode == 1 && (int64_t)todo.size() >= kSearchMinQueries))) {
+      std::vector<std::pair<double, size_t>> key(todo.size());
+      for (size_t j = 0; j < todo.size(); j++) {
+        const size_t k = todo[j];
         const int64_t q = active[k];
-        key[k] = {state_distance(r, &r->states[(size_t)starts[q] * r->S], &r->states[(size_t)goals[q] * r->S]), k};
+        key[j] = {state_distance(r, &r->states[(size_t)starts[q] * r->S], &r->states[(size_t)goals[q] * r->S]), k};
       }
       std::sort(key.begin(), key.end(), [](const std::pair<double, size_t> &x, const std::pair<double, size_t> &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-      const size_t n_h = smode == 2 ? 0 : (size_t)((double)active.size() * search_host_share());
+      const size_t n_h = smode == 2 ? 0 : (size_t)((double)todo.size() * search_host_share());
       for (size_t i = 0; i < key.size(); i++) (i < n_h ? host_list : dev_list).push_back(key[i].second);
       // (TENDON_HIP_SEARCH=device: no budget unless TENDON_HIP_SEARCH_BUDGET asks for one)
       on_device = device_search_launch(r, starts, goals, active, dev_list, smode == 2 && !std::getenv("TENDON_HIP_SEARCH_BUDGET") ? 0 : search_budget());
@@ -1125,6 +1300,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     if (std::getenv("TENDON_HIP_SEARCH_HIST")) hist_v.assign(active.size(), 0);
     int64_t *hist = hist_v.empty() ? nullptr : hist_v.data();
     // the host threads over a list of positions in `active` (null: all of them)
+    std::atomic<bool> walked_in_vain{false};
     auto host_search = [&](const std::vector<size_t> *list) {
       const int64_t n_host = list ? (int64_t)list->size() : (int64_t)active.size();
       if (n_host == 0) return;
@@ -1139,6 +1315,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
           const int64_t q = active[k];
           const int64_t ex0 = ex;
           found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+          if (!found[k] && ex - ex0 >= kComponentTrigger) walked_in_vain.store(true, std::memory_order_relaxed);
           if (hist) hist[k] = ex - ex0;
         }
         expanded += ex;
@@ -1149,7 +1326,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       worker(0);
       for (auto &x : th) x.join();
     };
-    if (!on_device) host_search(nullptr);
+    if (!on_device) host_search(&todo);
     else {
       const auto t0 = std::chrono::steady_clock::now();
       host_search(&host_list);
@@ -1158,6 +1335,19 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       device_search_collect(r, active, dev_list, found, paths, paths_e, redo, ex);
       expanded += ex;
       const auto t2 = std::chrono::steady_clock::now();
+      // what the kernel handed back is long by definition: the labels (if the round has none yet) weed out the unreachable goals
+      if (!redo.empty() && !labels_now && ensure_labels()) {
+        const int32_t *lab = r->dc.label.data();
+        std::vector<size_t> keep;
+        for (size_t k : redo) {
+          const int64_t q = active[k];
+          if (lab[starts[q]] == lab[goals[q]]) keep.push_back(k);
+          else found[k] = 0;
+        }
+        r->dc.st_cut += (int64_t)(redo.size() - keep.size());
+        if (keep.size() < redo.size()) r->dc.wanted = true;
+        redo.swap(keep);
+      }
       host_search(&redo);
       if (std::getenv("TENDON_HIP_SEARCH_STATS")) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1166,6 +1356,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
                      ms(t2, std::chrono::steady_clock::now()));
       }
     }
+    if (walked_in_vain.load()) r->dc.wanted = true;
     if (hist) {
       std::vector<int64_t> f, nf;
       for (size_t k = 0; k < active.size(); k++) (found[k] ? f : nf).push_back(hist[k]);
@@ -1179,7 +1370,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       std::fprintf(stderr, "[tendon_hip] round %lld:\n", (long long)r->st_rounds);
       show("found", f); show("not found", nf);
     }
-    r->st_astar_runs += (int64_t)active.size();
+    r->st_astar_runs += (int64_t)todo.size();
     r->st_expanded += expanded.load();
     // unknown items on the candidate paths: all interior vertices, and the edges of paths without an unknown vertex
     // are only worth testing once the vertices are clean -- but testing them in the same launch costs nothing, saves
@@ -1213,6 +1404,20 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         if (cost) { double c = 0; for (size_t i = paths_e[(size_t)q].size(); i-- > 0;) c += r->w[(size_t)paths_e[(size_t)q][i]]; cost[q] = c; }
       } else still.push_back(q);
     }
+    // The lazy loop pays off while few queries come back for another round.  When a tenth of the first round's searches are still
+    // open (a cluttered environment: every round finds them new candidate paths through items not looked at yet, hundreds of
+    // rounds in the worst case), looking at EVERY item costs less than one more round of searches -- one K4 launch over all cached
+    // sets, 0.25 ms at 6.8 x 10^5 -- and the next round is the last.  Answers are those of the lazy loop (validity is a function of
+    // the environment); what changes is which items end up known.  TENDON_HIP_LAZY_ONLY=1 keeps the loop lazy to the end (A/B, tests).
+    if (r->st_rounds == 1) first_round = (int64_t)active.size();
+    if (!went_eager && r->has_caches && (int64_t)still.size() >= 64 && (int64_t)still.size() * 10 >= first_round && !std::getenv("TENDON_HIP_LAZY_ONLY")) {
+      int64_t unknown = 0;
+      for (uint8_t x : r->vstat) unknown += x == V_UNKNOWN;
+      for (uint8_t x : r->estat) unknown += x == V_UNKNOWN;
+      if ((rc = revalidate_locked(r, nullptr, nullptr))) return rc;
+      r->st_items_checked += unknown;
+      went_eager = true;
+    }
     active.swap(still);
   }
   for (int64_t q = 0; q < n_queries; q++) {
@@ -1229,11 +1434,12 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   return TR_OK;
 }
 
-int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[6]) {
+int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[8]) {
   if (!r || !out) return TR_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock_(r->mu);
   out[0] = r->ds.st_queries; out[1] = r->ds.st_fallbacks; out[2] = r->ds.st_host_share; out[3] = r->ds.st_moves;
   out[4] = r->ds.st_expanded; out[5] = r->st_expanded - r->ds.st_expanded;
+  out[6] = r->dc.st_cut; out[7] = 0;
   return TR_OK;
 }
 

@@ -448,10 +448,10 @@ class VoxelCachedLazyPRM:
         pv = np.zeros(int(off[-1]), dtype=np.int32)
         self._check(self.lib.tr_roadmap_fetch_paths(self._rm, pv.ctypes.data_as(i32), len(pv)))
         self.stats = dict(rounds=st.rounds, items_checked=st.items_checked, astar_runs=st.astar_runs, expanded=st.expanded)
-        ss = (C.c_int64 * 6)()
+        ss = (C.c_int64 * 8)()
         self._check(self.lib.tr_roadmap_search_stats(self._rm, ss))
         # where the searches ran (tr_roadmap_search_stats): finished by the kernel / handed back by it / on the host threads meanwhile
         self.search_stats = dict(device=int(ss[0]), handed_back=int(ss[1]), host_meanwhile=int(ss[2]), list_moves=int(ss[3]),
-                                 expanded_device=int(ss[4]), expanded_host=int(ss[5]))
+                                 expanded_device=int(ss[4]), expanded_host=int(ss[5]), answered_by_components=int(ss[6]))
         return dict(status=status, cost=cost, path_offsets=off, path_vertices=pv,
                     paths=[pv[off[q]:off[q + 1]] for q in range(n)])

@@ -9,7 +9,7 @@ irt = importlib.import_module("interactive-rate-tendons_amd")
 W = irt.workloads
 robot = W.robot_config3()
 vox, _ = W.reach_environment(seed=7, n_spheres=64)
-new_vox, _ = W.reach_environment(seed=7, n_spheres=72)
+new_vox, _ = W.reach_environment(seed=7, n_spheres=int(os.environ.get("PROBE_SPHERES", "72")))   # (64 when the roadmap was built)
 chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
 rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=11)
 states, _ = rb.sample_valid_vertices(100000, batch=1 << 17)
@@ -34,6 +34,8 @@ for st in settings:
                 prm.revalidate()
             sys.stderr.flush()
             t0 = time.perf_counter()
-            prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+            out = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
             best = min(best, time.perf_counter() - t0)
-        print("share %s%% budget %s %s: %.2f ms, %.0f queries/s" % (share, budget, form, best * 1e3, len(pairs) / best), flush=True)
+            prm.last_status = out["status"]
+        print("share %s%% budget %s %s: %.2f ms, %.0f queries/s   (searches: %s; statuses %s)" % (share, budget, form, best * 1e3, len(pairs) / best, prm.search_stats,
+              np.bincount(prm.last_status, minlength=4).tolist() if hasattr(prm, "last_status") else ""), flush=True)

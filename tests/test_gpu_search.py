@@ -127,3 +127,72 @@ def test_roadmap_with_parallel_edges_stays_on_the_host(irt, monkeypatch):
         outs.append(prm.solveWithRoadmap(starts, goals))
     assert np.array_equal(outs[0]["status"], outs[1]["status"]) and np.array_equal(outs[0]["cost"], outs[1]["cost"])
     assert np.array_equal(outs[0]["path_vertices"], outs[1]["path_vertices"])
+
+
+def test_unreachable_goals_are_answered_by_component_labels(irt, monkeypatch):
+    """A cluttered environment cuts the roadmap into pieces: queries across pieces are answered from the component labels of the
+    round (the reference's solutionComponent test) instead of a search that walks the start's whole component -- same statuses,
+    costs, paths and validity as with the labels switched off, on the host threads and on the device; by default the labels are
+    computed from the first solve on in which a search walked a component in vain."""
+    prm, states = _prm(irt, 6000, 6, seed=9, n_new_spheres=160)
+    prm.prepare(16)
+    rng = np.random.default_rng(12)
+    nq = 800
+    starts, goals = rng.integers(0, len(states), nq), rng.integers(0, len(states), nq)
+
+    def answers_equal(want, out):
+        (ra, sa, va, ea), (rb, sb, vb, eb) = want, out
+        assert np.array_equal(ra["status"], rb["status"]) and np.array_equal(ra["cost"], rb["cost"])
+        assert np.array_equal(ra["path_vertices"], rb["path_vertices"]) and np.array_equal(va, vb) and np.array_equal(ea, eb)
+        assert sa["rounds"] == sb["rounds"] and sa["items_checked"] == sb["items_checked"]
+
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+    monkeypatch.setenv("TENDON_HIP_COMPONENTS", "0")
+    ref = {eager: _solve(prm, starts, goals, eager) for eager in (True, False)}
+    n_nopath = int((ref[True][0]["status"] == 1).sum())
+    assert n_nopath > 20 and (ref[True][0]["status"] == 0).sum() > 100, np.bincount(ref[True][0]["status"])
+    assert prm.search_stats["answered_by_components"] == 0
+    monkeypatch.setenv("TENDON_HIP_COMPONENTS", "1")               # labels in every round
+    for mode in ("host", "device", None):
+        if mode is None:
+            monkeypatch.delenv("TENDON_HIP_SEARCH")
+        else:
+            monkeypatch.setenv("TENDON_HIP_SEARCH", mode)
+        for eager in (True, False):
+            out = _solve(prm, starts, goals, eager)
+            answers_equal(ref[eager], out)
+            if eager:
+                assert prm.search_stats["answered_by_components"] == n_nopath, (prm.search_stats, n_nopath)
+                assert out[1]["expanded"] < ref[eager][1]["expanded"]
+    # the default: the first solve finds out (searches that walk thousands of vertices in vain), the second one uses labels
+    monkeypatch.delenv("TENDON_HIP_COMPONENTS")
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+    prm2, _ = _prm(irt, 6000, 6, seed=9, n_new_spheres=160)
+    prm2.prepare(16)
+    first = _solve(prm2, starts, goals, True)
+    answers_equal(ref[True], first)
+    if first[1]["expanded"] > 2000 * 20:                           # (it did walk in vain)
+        second = _solve(prm2, starts, goals, True)
+        answers_equal(ref[True], second)
+        assert prm2.search_stats["answered_by_components"] == n_nopath and second[1]["expanded"] < first[1]["expanded"]
+
+
+def test_lazy_loop_turns_eager_when_queries_keep_coming_back(irt, monkeypatch):
+    """Cluttered environment, validity unknown: the lazy loop alone needs many rounds (every round finds the open queries new
+    candidate paths through items nobody looked at); by default tr_roadmap_solve tests every cached set in one launch once a tenth
+    of the first round's searches are still open.  Same answers, fewer rounds, and afterwards no item is unknown."""
+    prm, states = _prm(irt, 6000, 6, seed=9, n_new_spheres=160)
+    prm.prepare(16)
+    rng = np.random.default_rng(12)
+    nq = 800
+    starts, goals = rng.integers(0, len(states), nq), rng.integers(0, len(states), nq)
+    monkeypatch.setenv("TENDON_HIP_LAZY_ONLY", "1")
+    lazy = _solve(prm, starts, goals, False)
+    assert (lazy[2] == 0).any() and lazy[1]["rounds"] >= 4, lazy[1]
+    monkeypatch.delenv("TENDON_HIP_LAZY_ONLY")
+    out = _solve(prm, starts, goals, False)
+    assert np.array_equal(lazy[0]["status"], out[0]["status"]) and np.array_equal(lazy[0]["cost"], out[0]["cost"])
+    assert np.array_equal(lazy[0]["path_vertices"], out[0]["path_vertices"])
+    assert out[1]["rounds"] < lazy[1]["rounds"] and not (out[2] == 0).any() and not (out[3] == 0).any(), (lazy[1], out[1])
+    known = lazy[2] > 0
+    assert np.array_equal(lazy[2][known], out[2][known])             # what the lazy loop knew, it knew right
