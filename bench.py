@@ -241,6 +241,7 @@ def secondary_metrics():
                 "fk_samples_per_edge_mean": c3["fk_samples_per_edge"]["mean"], "connect_all_edges_s": q["connect_all_edges_s"],
                 "create_roadmap_s": c3["create_roadmap"]["seconds"]},
             "config5_10k_queries": {
+                "queries_per_s": q["default_schedule"]["queries_per_s"], "rounds": q["default_schedule"]["rounds"],
                 "queries_per_s_lazy": q["lazy"]["queries_per_s"], "lazy_rounds": q["lazy"]["rounds"], "lazy_items_checked": q["lazy"]["items_checked"],
                 "queries_per_s_lazy_host_threads_only": q["searches_on_host_threads_only"]["lazy_queries_per_s"], "lazy_searches": q["lazy"]["searches"],
                 "queries_per_s_eager_incl_revalidation": q["eager"]["queries_per_s_incl_revalidation"],

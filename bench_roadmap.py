@@ -254,7 +254,9 @@ def run(argv=None):
     t0 = time.perf_counter()
     prm.prepare(16)                                             # once per roadmap: 16 landmark distance tables
     t_prepare = time.perf_counter() - t0
+    import os
     prm.clearValidity()
+    os.environ["TENDON_HIP_LAZY_ONLY"] = "1"                    # the reference's loop item by item: only what lies on candidate paths is tested
     chk.engine.profile_begin()
     t0 = time.perf_counter()
     lazy = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
@@ -262,6 +264,14 @@ def run(argv=None):
     st_lazy = dict(prm.stats, searches=dict(prm.search_stats))
     k4l = chk.engine.profile_read()["cached_blocks_vs_grid"]
     chk.engine.profile_end()
+    del os.environ["TENDON_HIP_LAZY_ONLY"]
+    # the default schedule of tr_roadmap_solve from unknown validity: lazy until a test of every cached set is cheaper than another round
+    prm.clearValidity()
+    t0 = time.perf_counter()
+    dflt = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    t_dflt = time.perf_counter() - t0
+    st_dflt = dict(prm.stats, searches=dict(prm.search_stats))
+    assert np.array_equal(lazy["status"], dflt["status"]) and np.array_equal(lazy["cost"], dflt["cost"]) and np.array_equal(lazy["path_vertices"], dflt["path_vertices"])
     prm.clearValidity()
     t0 = time.perf_counter()
     n_bad_v, n_bad_e = prm.revalidate()
@@ -271,8 +281,8 @@ def run(argv=None):
     t_eager = time.perf_counter() - t0
     st_eager = dict(prm.stats, searches=dict(prm.search_stats))
     # the same two calls with every graph search on the host threads (TENDON_HIP_SEARCH=host): the round-3 schedule, timed beside
-    import os
     os.environ["TENDON_HIP_SEARCH"] = "host"
+    os.environ["TENDON_HIP_LAZY_ONLY"] = "1"
     prm.clearValidity()
     t0 = time.perf_counter()
     lazy_h = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
@@ -283,6 +293,7 @@ def run(argv=None):
     prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
     t_eager_host = time.perf_counter() - t0
     del os.environ["TENDON_HIP_SEARCH"]
+    del os.environ["TENDON_HIP_LAZY_ONLY"]
     assert np.array_equal(lazy["status"], lazy_h["status"]) and np.array_equal(lazy["cost"], lazy_h["cost"])
     assert np.array_equal(lazy["path_vertices"], lazy_h["path_vertices"])
     assert np.array_equal(lazy["status"], eager["status"]) and np.array_equal(lazy["cost"], eager["cost"])
@@ -294,7 +305,10 @@ def run(argv=None):
           "connect_all_edges_s": t_connect, "edges_connected_per_s": len(edges) / t_connect, "caches_attached_from_device_s": t_attach_dev,
           "landmark_tables_s": t_prepare,
           "lazy_reference_heuristic_only": {"queries_per_s": nq / t_plain, "seconds": t_plain, **st_plain},
-          "lazy": {"queries_per_s": nq / t_lazy, "seconds": t_lazy, **st_lazy, "k4_launches": k4l["launches"], "k4_ms_total": k4l["total_ms"]},
+          "lazy": {"queries_per_s": nq / t_lazy, "seconds": t_lazy, **st_lazy, "k4_launches": k4l["launches"], "k4_ms_total": k4l["total_ms"],
+                   "note": "TENDON_HIP_LAZY_ONLY=1: only items on candidate paths are ever tested"},
+          "default_schedule": {"queries_per_s": nq / t_dflt, "seconds": t_dflt, **st_dflt,
+                               "note": "tr_roadmap_solve as shipped, from unknown validity: tests every cached set once that is cheaper than another round"},
           "eager": {"queries_per_s_incl_revalidation": nq / (t_eager + t_reval), "revalidate_all_ms": 1e3 * t_reval,
                     "items_per_s_revalidation": (len(states) + len(e_ok)) / t_reval, "search_seconds": t_eager, **st_eager,
                     "invalid_vertices": n_bad_v, "invalid_edges": n_bad_e},

@@ -428,7 +428,7 @@ int tr_roadmap_revalidate(tr_roadmap *rm, int64_t *n_invalid_vertices, int64_t *
 /* status per item: 0 unknown, 1 valid, 2 invalid (removed) */
 int tr_roadmap_get_validity(tr_roadmap *rm, uint8_t *vertex_status /*[n_vertices]*/, uint8_t *edge_status /*[n_edges]*/);
 /* The batched query loop (lazy: only the items on candidate paths are tested, round by round -- until so many queries keep coming
- * back that testing every cached set at once is cheaper, see TENDON_HIP_LAZY_ONLY).  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
+ * back for another round while testing every cached set at once is cheaper than that round, see TENDON_HIP_LAZY_ONLY).  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
  * query q's path (start ... goal) is entries path_offsets[q] .. path_offsets[q+1]-1 of the array
  * tr_roadmap_fetch_paths copies out.  n_threads = host threads for the A* searches (0 = the process's CPU share).
  * Validity discovered by a call is kept for the next one (as the reference's graph keeps it between queries). */
@@ -569,9 +569,9 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default 10000; 0 none)
  *   TENDON_HIP_SEARCH_K=1..4        vertices the kernel takes off a search's open list per step (default 4; 1 = the host's order)
  *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds, within 12 GiB of records)
- *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when a tenth of the first
- *                                   round's searches are still open after a round, every cached set is tested in one launch and
- *                                   the next round is the last -- cheaper than more rounds of searches; same answers)
+ *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when queries are still open
+ *                                   after a round and one launch over every cached set is estimated at less than half of what the
+ *                                   round's searches took, everything is tested and the next round is the last; same answers)
  *   TENDON_HIP_COMPONENTS=0|1       component labels of the roadmap minus the invalid items (queries across components are answered "no
  *                                   path" without a search): unset = from the moment they would have paid on this roadmap (a search
  *                                   walked 2000 vertices in vain, or the kernel handed searches back), 1 = every round of 64 queries

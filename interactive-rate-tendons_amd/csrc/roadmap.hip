@@ -1241,7 +1241,6 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   std::vector<uint8_t> found;
   const int smode = search_mode();
   bool went_eager = false;
-  int64_t first_round = 0;
   while (!active.empty()) {
     r->st_rounds++;
     // A* for every unresolved query, on the host cores
@@ -1376,6 +1375,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     // are only worth testing once the vertices are clean -- but testing them in the same launch costs nothing, saves
     // a round, and removing more invalid items never changes an accepted path (see the header comment)
     list.clear();
+    const auto t_items0 = std::chrono::steady_clock::now();
     for (size_t k = 0; k < active.size(); k++) {
       if (!found[k]) continue;
       const int64_t q = active[k];
@@ -1388,11 +1388,13 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       for (int32_t e : pe)
         if (r->estat[(size_t)e] == V_UNKNOWN && !emark[(size_t)e]) { emark[(size_t)e] = 1; list.push_back((int32_t)(r->V + e)); }
     }
+    const auto t_items1 = std::chrono::steady_clock::now();
     if (!list.empty()) {
       if ((rc = check_items(r, list, hit))) return rc;
       record(list, hit);
       for (int32_t it : list) { if (it < r->V) vmark[(size_t)it] = 0; else emark[(size_t)(it - r->V)] = 0; }
     }
+    const auto t_items2 = std::chrono::steady_clock::now();
     std::vector<int64_t> still;
     for (size_t k = 0; k < active.size(); k++) {
       const int64_t q = active[k];
@@ -1404,13 +1406,16 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         if (cost) { double c = 0; for (size_t i = paths_e[(size_t)q].size(); i-- > 0;) c += r->w[(size_t)paths_e[(size_t)q][i]]; cost[q] = c; }
       } else still.push_back(q);
     }
-    // The lazy loop pays off while few queries come back for another round.  When a tenth of the first round's searches are still
-    // open (a cluttered environment: every round finds them new candidate paths through items not looked at yet, hundreds of
-    // rounds in the worst case), looking at EVERY item costs less than one more round of searches -- one K4 launch over all cached
-    // sets, 0.25 ms at 6.8 x 10^5 -- and the next round is the last.  Answers are those of the lazy loop (validity is a function of
-    // the environment); what changes is which items end up known.  TENDON_HIP_LAZY_ONLY=1 keeps the loop lazy to the end (A/B, tests).
-    if (r->st_rounds == 1) first_round = (int64_t)active.size();
-    if (!went_eager && r->has_caches && (int64_t)still.size() >= 64 && (int64_t)still.size() * 10 >= first_round && !std::getenv("TENDON_HIP_LAZY_ONLY")) {
+    // The lazy loop exists to save validity tests; here a test of EVERY cached set is one K4 launch (0.25 ms at 6.8 x 10^5 sets),
+    // while every further round costs at least its longest search (milliseconds on a core) -- and in a cluttered environment the
+    // open queries find new candidate paths through untested items round after round, hundreds of rounds in the worst case.  So
+    // when queries are still open and testing everything is estimated at less than half of what the round's searches just took,
+    // everything is tested and the next round is the last.  Answers are those of the lazy loop (validity is a function of the
+    // environment); what changes is which items end up known.  TENDON_HIP_LAZY_ONLY=1 keeps the loop lazy to the end (the
+    // reference's behaviour item by item; A/B, tests).
+    const double search_ms = std::chrono::duration<double, std::milli>(t_items0 - t_round).count();
+    const double all_ms = 0.1 + 3.6e-7 * (double)(r->V + r->E);
+    if (!went_eager && r->has_caches && !still.empty() && all_ms < 0.5 * search_ms && !std::getenv("TENDON_HIP_LAZY_ONLY")) {
       int64_t unknown = 0;
       for (uint8_t x : r->vstat) unknown += x == V_UNKNOWN;
       for (uint8_t x : r->estat) unknown += x == V_UNKNOWN;

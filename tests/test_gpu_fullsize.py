@@ -297,7 +297,7 @@ def test_full_size_config4_stays_in_hbm_and_agrees_with_the_host_forms(irt):
     assert np.array_equal(got, host["valid"]) and 0.98 < got.mean() < 1.0 and host["n_domain_errors"] == 0
 
 
-def test_full_size_config5_query_loop(irt, orc, helpers):
+def test_full_size_config5_query_loop(irt, orc, helpers, monkeypatch):
     """BASELINE configs[4] at full size: a 10^5-vertex roadmap with vertex and edge voxel caches (built and kept on the device), the
     obstacle grid changed (8 more spheres), 10 000 start / goal queries through the lazy loop (tr_roadmap_solve) and through the
     eager form (tr_roadmap_revalidate, then search) -- the oracle's sequential query loop on 320 sampled queries (status, path,
@@ -322,10 +322,19 @@ def test_full_size_config5_query_loop(irt, orc, helpers):
     prm.set_obstacles(new_vox)
     nq = 10000
     pairs = np.random.default_rng(17).integers(0, len(states), size=(nq, 2))
+    # default: the loop tests every cached set in one launch once that is cheaper than another round of searches ...
+    dflt = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    st_dflt = dict(prm.stats)
+    prm.clearValidity()
+    # ... strictly lazy (the reference's loop item by item), which is what the oracle restates
+    monkeypatch.setenv("TENDON_HIP_LAZY_ONLY", "1")
     lazy = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+    monkeypatch.delenv("TENDON_HIP_LAZY_ONLY")
     st_lazy = dict(prm.stats)
     v_lazy, e_lazy = prm.validity()
     assert st_lazy["rounds"] >= 2 and 0 < st_lazy["items_checked"] < 0.6 * (len(states) + len(e_ok))     # lazy: most items never looked at
+    assert np.array_equal(dflt["status"], lazy["status"]) and np.array_equal(dflt["cost"], lazy["cost"])
+    assert np.array_equal(dflt["path_vertices"], lazy["path_vertices"]) and st_dflt["rounds"] <= st_lazy["rounds"]
     solved = lazy["status"] == 0
     assert 0.8 < solved.mean() < 1.0 and (lazy["status"] >= 2).any()
     # the oracle: its own query loop on a sample of the queries; the cached-set test of every item

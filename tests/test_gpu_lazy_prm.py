@@ -7,6 +7,14 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _strictly_lazy(monkeypatch):
+    """The tests of this file pin the reference's lazy loop item by item -- which items end up known, how many rounds -- so they run
+    with TENDON_HIP_LAZY_ONLY=1.  By default tr_roadmap_solve tests every cached set in one launch as soon as that is cheaper than
+    another round of searches (same answers: tests/test_gpu_search.py)."""
+    monkeypatch.setenv("TENDON_HIP_LAZY_ONLY", "1")
+
+
 def _roadmap(irt, n_vertices, k, seed):
     W = irt.workloads
     robot = W.robot_config3()

@@ -9,6 +9,13 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _strictly_lazy(monkeypatch):
+    """Rounds, items tested and validity bytes are compared between schedules here, so the loop stays strictly lazy
+    (TENDON_HIP_LAZY_ONLY=1); when it turns eager by default depends on how long a round's searches took.  The last test lifts it."""
+    monkeypatch.setenv("TENDON_HIP_LAZY_ONLY", "1")
+
+
 def _prm(irt, n_vertices, k, seed, n_new_spheres=76):
     W = irt.workloads
     robot = W.robot_config3()
@@ -179,15 +186,14 @@ def test_unreachable_goals_are_answered_by_component_labels(irt, monkeypatch):
 
 def test_lazy_loop_turns_eager_when_queries_keep_coming_back(irt, monkeypatch):
     """Cluttered environment, validity unknown: the lazy loop alone needs many rounds (every round finds the open queries new
-    candidate paths through items nobody looked at); by default tr_roadmap_solve tests every cached set in one launch once a tenth
-    of the first round's searches are still open.  Same answers, fewer rounds, and afterwards no item is unknown."""
+    candidate paths through items nobody looked at); by default tr_roadmap_solve tests every cached set in one launch as soon as
+    that is cheaper than another round of searches.  Same answers, fewer rounds, and afterwards no item is unknown."""
     prm, states = _prm(irt, 6000, 6, seed=9, n_new_spheres=160)
     prm.prepare(16)
     rng = np.random.default_rng(12)
     nq = 800
     starts, goals = rng.integers(0, len(states), nq), rng.integers(0, len(states), nq)
-    monkeypatch.setenv("TENDON_HIP_LAZY_ONLY", "1")
-    lazy = _solve(prm, starts, goals, False)
+    lazy = _solve(prm, starts, goals, False)                       # (strictly lazy: the fixture)
     assert (lazy[2] == 0).any() and lazy[1]["rounds"] >= 4, lazy[1]
     monkeypatch.delenv("TENDON_HIP_LAZY_ONLY")
     out = _solve(prm, starts, goals, False)
