@@ -927,18 +927,24 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
   std::memcpy(&ex, &ctl[2], sizeof(ex));
   expanded += (int64_t)ex;
   d.st_expanded += (int64_t)ex;
-  for (int64_t j = 0; j < nq; j++) {
-    const size_t k = klist[(size_t)j];
-    const int64_t q = active[k];
-    found[k] = 0;
-    if (res[(size_t)j] == trk::SR_FALLBACK) { redo.push_back(k); continue; }
-    if (res[(size_t)j] != trk::SR_FOUND) continue;
-    const int32_t n = plen[(size_t)j], o = poff[(size_t)j];
-    if (n < 1 || o < 0 || (uint64_t)o + (uint64_t)(2 * n - 1) > used) { redo.push_back(k); continue; }
-    paths[(size_t)q].assign(pbuf.begin() + o, pbuf.begin() + o + n);
-    paths_e[(size_t)q].assign(pbuf.begin() + o + n, pbuf.begin() + o + 2 * n - 1);
-    found[k] = 1;
-  }
+  const int Tb = nq >= 2048 ? std::min(host_threads(0), 16) : 1;          // (ten thousand small vectors: by ranges on the host threads)
+  std::vector<std::vector<size_t>> part((size_t)Tb);
+  on_threads(Tb, [&](int t) {
+    const int64_t j0 = nq * t / Tb, j1 = nq * (t + 1) / Tb;
+    for (int64_t j = j0; j < j1; j++) {
+      const size_t k = klist[(size_t)j];
+      const int64_t q = active[k];
+      found[k] = 0;
+      if (res[(size_t)j] == trk::SR_FALLBACK) { part[(size_t)t].push_back(k); continue; }
+      if (res[(size_t)j] != trk::SR_FOUND) continue;
+      const int32_t n = plen[(size_t)j], o = poff[(size_t)j];
+      if (n < 1 || o < 0 || (uint64_t)o + (uint64_t)(2 * n - 1) > used) { part[(size_t)t].push_back(k); continue; }
+      paths[(size_t)q].assign(pbuf.begin() + o, pbuf.begin() + o + n);
+      paths_e[(size_t)q].assign(pbuf.begin() + o + n, pbuf.begin() + o + 2 * n - 1);
+      found[k] = 1;
+    }
+  });
+  for (const auto &p : part) redo.insert(redo.end(), p.begin(), p.end());
   d.st_queries += nq - (int64_t)redo.size(); d.st_fallbacks += (int64_t)redo.size(); d.st_moves += (int64_t)ctl[4];
 }
 
@@ -1376,17 +1382,28 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     // a round, and removing more invalid items never changes an accepted path (see the header comment)
     list.clear();
     const auto t_items0 = std::chrono::steady_clock::now();
-    for (size_t k = 0; k < active.size(); k++) {
-      if (!found[k]) continue;
-      const int64_t q = active[k];
-      const auto &pv = paths[(size_t)q];
-      const auto &pe = paths_e[(size_t)q];
-      for (size_t i = 1; i + 1 < pv.size(); i++) {
-        const int32_t v = pv[i];
-        if (r->vstat[(size_t)v] == V_UNKNOWN && !vmark[(size_t)v]) { vmark[(size_t)v] = 1; list.push_back(v); }
-      }
-      for (int32_t e : pe)
-        if (r->estat[(size_t)e] == V_UNKNOWN && !emark[(size_t)e]) { emark[(size_t)e] = 1; list.push_back((int32_t)(r->V + e)); }
+    // (large rounds: by ranges of queries on the host threads; an item goes to the list of the thread that marks it first -- the set
+    // is the same whoever that is, and the order of the list decides nothing)
+    const int Tb = active.size() >= 2048 ? std::min(T, 16) : 1;
+    {
+      std::vector<std::vector<int32_t>> part((size_t)Tb);
+      on_threads(Tb, [&](int t) {
+        std::vector<int32_t> &mine = part[(size_t)t];
+        const size_t k0 = active.size() * (size_t)t / (size_t)Tb, k1 = active.size() * (size_t)(t + 1) / (size_t)Tb;
+        for (size_t k = k0; k < k1; k++) {
+          if (!found[k]) continue;
+          const int64_t q = active[k];
+          const auto &pv = paths[(size_t)q];
+          const auto &pe = paths_e[(size_t)q];
+          for (size_t i = 1; i + 1 < pv.size(); i++) {
+            const int32_t v = pv[i];
+            if (r->vstat[(size_t)v] == V_UNKNOWN && !__atomic_exchange_n(&vmark[(size_t)v], (uint8_t)1, __ATOMIC_RELAXED)) mine.push_back(v);
+          }
+          for (int32_t e : pe)
+            if (r->estat[(size_t)e] == V_UNKNOWN && !__atomic_exchange_n(&emark[(size_t)e], (uint8_t)1, __ATOMIC_RELAXED)) mine.push_back((int32_t)(r->V + e));
+        }
+      });
+      for (const auto &p : part) list.insert(list.end(), p.begin(), p.end());
     }
     const auto t_items1 = std::chrono::steady_clock::now();
     if (!list.empty()) {
@@ -1396,15 +1413,22 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     }
     const auto t_items2 = std::chrono::steady_clock::now();
     std::vector<int64_t> still;
-    for (size_t k = 0; k < active.size(); k++) {
-      const int64_t q = active[k];
-      if (!found[k]) { status[q] = TR_QUERY_NO_PATH; paths[(size_t)q].clear(); continue; }   // different components (:2026-2036)
-      bool ok = true;
-      for (size_t i = 1; i + 1 < paths[(size_t)q].size() && ok; i++) ok = r->vstat[(size_t)paths[(size_t)q][i]] == V_VALID;
-      for (size_t i = 0; i < paths_e[(size_t)q].size() && ok; i++) ok = r->estat[(size_t)paths_e[(size_t)q][i]] == V_VALID;
-      if (ok) {
-        if (cost) { double c = 0; for (size_t i = paths_e[(size_t)q].size(); i-- > 0;) c += r->w[(size_t)paths_e[(size_t)q][i]]; cost[q] = c; }
-      } else still.push_back(q);
+    {
+      std::vector<std::vector<int64_t>> part((size_t)Tb);
+      on_threads(Tb, [&](int t) {
+        const size_t k0 = active.size() * (size_t)t / (size_t)Tb, k1 = active.size() * (size_t)(t + 1) / (size_t)Tb;
+        for (size_t k = k0; k < k1; k++) {
+          const int64_t q = active[k];
+          if (!found[k]) { status[q] = TR_QUERY_NO_PATH; paths[(size_t)q].clear(); continue; }   // different components (:2026-2036)
+          bool ok = true;
+          for (size_t i = 1; i + 1 < paths[(size_t)q].size() && ok; i++) ok = r->vstat[(size_t)paths[(size_t)q][i]] == V_VALID;
+          for (size_t i = 0; i < paths_e[(size_t)q].size() && ok; i++) ok = r->estat[(size_t)paths_e[(size_t)q][i]] == V_VALID;
+          if (ok) {
+            if (cost) { double c = 0; for (size_t i = paths_e[(size_t)q].size(); i-- > 0;) c += r->w[(size_t)paths_e[(size_t)q][i]]; cost[q] = c; }
+          } else part[(size_t)t].push_back(q);
+        }
+      });
+      for (const auto &p : part) still.insert(still.end(), p.begin(), p.end());    // (ranges in order: the queries keep their order)
     }
     // The lazy loop exists to save validity tests; here a test of EVERY cached set is one K4 launch (0.25 ms at 6.8 x 10^5 sets),
     // while every further round costs at least its longest search (milliseconds on a core) -- and in a cluttered environment the

@@ -300,6 +300,30 @@ def gathered_vertex_mask(robot, validate_bits_dev, M, seed, tau_max, device):
     return unpack_bits(v.run(M), M)
 
 
+class _Paths:
+    """The paths of a batch of queries as a sequence: paths[q] is query q's vertex indices, start ... goal (empty when it has none).
+    A view on the packed arrays -- ten thousand slices are only made when someone asks for them."""
+
+    def __init__(self, vertices, offsets):
+        self._v, self._o = vertices, offsets
+
+    def __len__(self):
+        return len(self._o) - 1
+
+    def __getitem__(self, q):
+        if isinstance(q, slice):
+            return [self[i] for i in range(*q.indices(len(self)))]
+        q = int(q)
+        if q < 0:
+            q += len(self)
+        if not 0 <= q < len(self):
+            raise IndexError(q)
+        return self._v[self._o[q]:self._o[q + 1]]
+
+    def __iter__(self):
+        return (self[q] for q in range(len(self)))
+
+
 class VoxelCachedLazyPRM:
     """The query side of motion_planning::VoxelCachedLazyPRM on a roadmap with voxel caches (BASELINE config 5):
     `solveWithRoadmap` (motion-planning/VoxelCachedLazyPRM.cpp:1977-2096 -> constructSolution :2689-2771) for a batch
@@ -453,5 +477,4 @@ class VoxelCachedLazyPRM:
         # where the searches ran (tr_roadmap_search_stats): finished by the kernel / handed back by it / on the host threads meanwhile
         self.search_stats = dict(device=int(ss[0]), handed_back=int(ss[1]), host_meanwhile=int(ss[2]), list_moves=int(ss[3]),
                                  expanded_device=int(ss[4]), expanded_host=int(ss[5]), answered_by_components=int(ss[6]))
-        return dict(status=status, cost=cost, path_offsets=off, path_vertices=pv,
-                    paths=[pv[off[q]:off[q + 1]] for q in range(n)])
+        return dict(status=status, cost=cost, path_offsets=off, path_vertices=pv, paths=_Paths(pv, off))
