@@ -8,10 +8,15 @@
 // tested from the goal side and the FIRST invalid one is removed; repeat until a path survives or start and goal fall
 // into different components.  Each test is a tiny octree intersection -- latency-bound on the CPU and far too small for a
 // GPU launch of its own.  Here a whole batch of queries advances in rounds:
-//   round = [A* for every unresolved query, in parallel on the host cores, on the graph minus what is known invalid]
+//   round = [A* for every unresolved query on the graph minus what is known invalid: large rounds on the device, one wave per
+//            query (search_kernel.hpp: roadmap_astar), shared with the host threads; small rounds on the host threads alone]
 //           -> the union of the still-unknown vertices and edges on all candidate paths -> ONE K4 launch on that subset
 //              (cached_subset_vs_grid; the caches live in HBM as one CSR) -> validity recorded, invalid items leave the graph
 //   queries whose candidate path turned out all valid are done; the others search again next round.
+//   Two shortcuts that change no answer (round 4): queries whose end points lie in different components of what is left of the
+//   graph are answered from component labels computed on the device (component_labels; the reference's solutionComponent test),
+//   and when queries are still open while ONE launch over every cached set is cheaper than another round of searches, everything
+//   is tested and the next round is the last (the loop turns eager; TENDON_HIP_LAZY_ONLY=1 forbids it).
 // tr_roadmap_revalidate is the eager form: one K4 pass over every cached set (well under a millisecond for 10^5..10^6
 // items), after which every query resolves in its first round.
 // Returned paths are the reference's: a path is accepted only when all its items are valid, and it is the shortest path
@@ -19,8 +24,8 @@
 // shortest path of the graph minus ALL invalid items, whatever subset has been discovered (equal costs; equal vertex
 // sequences unless two paths tie exactly).  What differs is bookkeeping only: every unknown edge of a vertex-clean path
 // is tested in the round (the reference stops at the first invalid one), so the set of DISCOVERED invalid edges is a superset.
-// The searches are the host's share of the loop (latency-bound pointer chasing over a graph that fits the host caches;
-// the device's share is the voxel work).  Their heuristic is the reference's state-space distance, sharpened by landmark
+// A search is latency-bound pointer chasing: one search is ~8x faster on a host core than on a wave, but the device runs three
+// thousand of them at once -- hence the shared schedule.  The heuristic is the reference's state-space distance, sharpened by landmark
 // lower bounds (tr_roadmap_prepare): distances from a few extremal vertices over the FULL graph; |d(l, v) - d(l, goal)| never
 // exceeds the distance from v to the goal, and stays a lower bound when invalid items leave the graph (distances only
 // grow).  The path A* returns is still the shortest one -- an admissible heuristic only changes how few vertices are expanded.
