@@ -242,6 +242,9 @@ struct tr_roadmap {
     uint8_t *d_found = nullptr;
     int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0, st_expanded = 0;   // of the last tr_roadmap_solve
     int64_t in_flight = 0;               // queries of the launch that has not been collected yet
+    bool budget_from_env = false;
+    int64_t budget = 0;                  // expansions per search before the kernel hands it back (0: not chosen yet); doubles when
+                                         // more than a twentieth of a round came back -- a larger roadmap has longer searches
     std::vector<int32_t> h_qs, h_qg;     // host images of what the pending copies read
     std::vector<float> h_padded;
   } ds;
@@ -1302,7 +1305,12 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       const size_t n_h = smode == 2 ? 0 : (size_t)((double)todo.size() * search_host_share());
       for (size_t i = 0; i < key.size(); i++) (i < n_h ? host_list : dev_list).push_back(key[i].second);
       // (TENDON_HIP_SEARCH=device: no budget unless TENDON_HIP_SEARCH_BUDGET asks for one)
-      on_device = device_search_launch(r, starts, goals, active, dev_list, smode == 2 && !std::getenv("TENDON_HIP_SEARCH_BUDGET") ? 0 : search_budget());
+      {
+        const bool from_env = std::getenv("TENDON_HIP_SEARCH_BUDGET") != nullptr;
+        if (r->ds.budget == 0 || from_env || r->ds.budget_from_env) r->ds.budget = search_budget();
+        r->ds.budget_from_env = from_env;
+      }
+      on_device = device_search_launch(r, starts, goals, active, dev_list, smode == 2 && !std::getenv("TENDON_HIP_SEARCH_BUDGET") ? 0 : r->ds.budget);
       if (!on_device) { host_list.clear(); dev_list.clear(); }
       else r->ds.st_host_share += (int64_t)host_list.size();
     }
@@ -1344,6 +1352,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       int64_t ex = 0;
       device_search_collect(r, active, dev_list, found, paths, paths_e, redo, ex);
       expanded += ex;
+
       const auto t2 = std::chrono::steady_clock::now();
       // what the kernel handed back is long by definition: the labels (if the round has none yet) weed out the unreachable goals
       if (!redo.empty() && !labels_now && ensure_labels()) {
@@ -1358,6 +1367,9 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         if (keep.size() < redo.size()) r->dc.wanted = true;
         redo.swap(keep);
       }
+      // (what is left of the handed-back searches has a path to find: when that is more than a twentieth of the round, the budget
+      // is too small for this roadmap's searches)
+      if (smode != 2 && !r->ds.budget_from_env && redo.size() * 20 > dev_list.size() && r->ds.budget > 0 && r->ds.budget < 16 * r->V) r->ds.budget *= 2;
       host_search(&redo);
       if (std::getenv("TENDON_HIP_SEARCH_STATS")) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
