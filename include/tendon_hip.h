@@ -565,8 +565,9 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *                                   roadmap_astar kernel and the host threads (below), a smaller round is the host threads'; host =
  *                                   the host threads always; device = the kernel always, whole rounds, no budget (tests)
  *   TENDON_HIP_SEARCH_HOST_SHARE=p  per cent of a shared round's searches (the ones with the most distant end points) that the host
- *                                   threads take while the kernel runs (default 2)
- *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default 10000; 0 none)
+ *                                   threads take while the kernel runs (default: starts at 2 and follows the two sides' times per roadmap)
+ *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default: starts at
+ *                                   10000 and doubles per roadmap while more than 1 in 200 searches come back; 0 none)
  *   TENDON_HIP_SEARCH_K=1..4        vertices the kernel takes off a search's open list per step (default 4; 1 = the host's order)
  *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds, within 12 GiB of records)
  *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when queries are still open

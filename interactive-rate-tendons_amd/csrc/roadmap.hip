@@ -243,6 +243,7 @@ struct tr_roadmap {
     int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0, st_expanded = 0;   // of the last tr_roadmap_solve
     int64_t in_flight = 0;               // queries of the launch that has not been collected yet
     bool budget_from_env = false;
+    double share = -1.0;                 // the host threads' share of a shared round (< 0: not chosen yet); follows the two sides' times
     int64_t budget = 0;                  // expansions per search before the kernel hands it back (0: not chosen yet); doubles when
                                          // more than a twentieth of a round came back -- a larger roadmap has longer searches
     std::vector<int32_t> h_qs, h_qg;     // host images of what the pending copies read
@@ -1302,7 +1303,9 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         key[j] = {state_distance(r, &r->states[(size_t)starts[q] * r->S], &r->states[(size_t)goals[q] * r->S]), k};
       }
       std::sort(key.begin(), key.end(), [](const std::pair<double, size_t> &x, const std::pair<double, size_t> &y) { return x.first > y.first || (x.first == y.first && x.second < y.second); });
-      const size_t n_h = smode == 2 ? 0 : (size_t)((double)todo.size() * search_host_share());
+      const bool share_from_env = std::getenv("TENDON_HIP_SEARCH_HOST_SHARE") != nullptr;
+      if (r->ds.share < 0 || share_from_env) r->ds.share = search_host_share();
+      const size_t n_h = smode == 2 ? 0 : (size_t)((double)todo.size() * r->ds.share);
       for (size_t i = 0; i < key.size(); i++) (i < n_h ? host_list : dev_list).push_back(key[i].second);
       // (TENDON_HIP_SEARCH=device: no budget unless TENDON_HIP_SEARCH_BUDGET asks for one)
       {
@@ -1367,9 +1370,15 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         if (keep.size() < redo.size()) r->dc.wanted = true;
         redo.swap(keep);
       }
-      // (what is left of the handed-back searches has a path to find: when that is more than a twentieth of the round, the budget
-      // is too small for this roadmap's searches)
-      if (smode != 2 && !r->ds.budget_from_env && redo.size() * 20 > dev_list.size() && r->ds.budget > 0 && r->ds.budget < 16 * r->V) r->ds.budget *= 2;
+      // (what is left of the handed-back searches has a path to find, and a core needs milliseconds for each: when they are more
+      // than one in two hundred of the round, the budget is too small for this roadmap's searches.  The host's share follows the
+      // clock: halved when the kernel had finished long before the host threads, raised when they waited for it longer than they worked.)
+      if (smode != 2 && !r->ds.budget_from_env && redo.size() * 200 > dev_list.size() && r->ds.budget > 0 && r->ds.budget < 16 * r->V) r->ds.budget *= 2;
+      if (smode != 2 && !std::getenv("TENDON_HIP_SEARCH_HOST_SHARE") && !host_list.empty()) {
+        const double t_host = std::chrono::duration<double, std::milli>(t1 - t0).count(), t_wait = std::chrono::duration<double, std::milli>(t2 - t1).count();
+        if (t_wait < 0.1 * t_host) r->ds.share = std::max(0.0025, r->ds.share * 0.5);
+        else if (t_wait > t_host) r->ds.share = std::min(0.08, r->ds.share * 1.5);
+      }
       host_search(&redo);
       if (std::getenv("TENDON_HIP_SEARCH_STATS")) {
         const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
