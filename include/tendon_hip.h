@@ -568,7 +568,7 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *                                   threads take while the kernel runs (default: starts at 2 and follows the two sides' times per roadmap)
  *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default: starts at
  *                                   10000 and doubles per roadmap while more than 1 in 200 searches come back; 0 none)
- *   TENDON_HIP_SEARCH_K=1..4        vertices the kernel takes off a search's open list per step (default 4; 1 = the host's order)
+ *   TENDON_HIP_SEARCH_K=1..6        vertices the kernel takes off a search's open list per step (default 6; 1 = the host's order)
  *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds, within 12 GiB of records)
  *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when queries are still open
  *                                   after a round and one launch over every cached set is estimated at less than half of what the

@@ -6,7 +6,7 @@
 //   * a step takes up to `kbest` vertices off the open list at once (the minimum, and the smallest of the other lanes' minima) and
 //     relaxes all their arcs together, ~12 per vertex, one lane each: the step is a chain of three dependent memory round trips
 //     (record + adjacency offsets -> arcs -> validity bytes, neighbour's record, state and landmark rows, all requested at once)
-//     whatever the number of lanes busy, so four vertices cost little more than one.  Expanding a vertex that is not the minimum is
+//     whatever the number of lanes busy, so six vertices cost little more than one (their ~70 arcs: one pass of the wave, sometimes two).  Expanding a vertex that is not the minimum is
 //     what any best-first search with re-opening may do: the stopping rule alone makes the returned cost optimal, and with it
 //     the path (the optimum is unique unless two paths' fp64 cost sums agree in every bit).  kbest = 1 is the host's order of
 //     expansions exactly (same count).
@@ -33,7 +33,7 @@ struct SNode { double g, h; int32_t parent, parent_edge; uint32_t stamp, closed;
 constexpr int SR_CAP = 896;                                   // near-list entries per wave (LDS)
 constexpr int SR_MAXS = 12, SR_MAXL = 64;                     // state coordinates, landmarks
 constexpr int SR_PATH_MAX = 4096;                             // vertices of a path (per-wave staging)
-constexpr int SR_K = 4;                                       // vertices expanded per step, at most
+constexpr int SR_K = 6;                                       // vertices expanded per step, at most
 constexpr int SR_TAB = 128;                                   // slots of the conflict tables
 enum : uint8_t { SR_NO_PATH = 0, SR_FOUND = 1, SR_FALLBACK = 2 };
 constexpr uint8_t SR_INVALID = 2;                             // roadmap.hip: V_INVALID

@@ -2,7 +2,7 @@
 threads' A* -- the statement of astarSearch / constructSolution (motion-planning/VoxelCachedLazyPRM.cpp:2689-2771, 2950-2976) that
 tests/test_gpu_lazy_prm.py pins to the oracle: same statuses, costs, paths, validity bytes, rounds and items checked, whichever side
 searches.  With one vertex per step (TENDON_HIP_SEARCH_K=1) the kernel is that search statement for statement and the expansions are
-counted equal too; with its default of four per step it expands a few vertices the host would not have (the answers do not move)."""
+counted equal too; with its default of six per step it expands a few vertices the host would not have (the answers do not move)."""
 import numpy as np
 import pytest
 
@@ -70,11 +70,14 @@ def test_device_searches_equal_the_host_searches(irt, monkeypatch, landmarks):
         monkeypatch.delenv("TENDON_HIP_SEARCH_K")
         out = _solve(prm, starts, goals, eager)
         _same(ref, out, expansions=False)
-        assert ref[1]["expanded"] <= out[1]["expanded"] < 1.5 * ref[1]["expanded"], (ref[1], out[1])
+        # (searches of ~50 expansions on this small roadmap: taking six vertices per step, the last steps expand vertices the host
+        # never reaches; on the 10^5-vertex roadmap, searches of ~1000 expansions, the excess is 1 - 2 %)
+        assert ref[1]["expanded"] <= out[1]["expanded"] < 3 * ref[1]["expanded"], (ref[1], out[1])
         assert prm.search_stats["device"] == ref[1]["astar_runs"] and prm.search_stats["handed_back"] == 0
         monkeypatch.delenv("TENDON_HIP_SEARCH")                    # the default: large rounds shared with the host threads
         _same(ref, _solve(prm, starts, goals, eager), expansions=False)
-        assert prm.search_stats["device"] > 500 and prm.search_stats["host_meanwhile"] > 0, prm.search_stats
+        ss = prm.search_stats                                      # (the host's share follows the clock: anything up to 8 %)
+        assert ss["device"] > 0.8 * (ref[1]["astar_runs"] - ss["answered_by_components"]) - 50 and ss["host_meanwhile"] > 0, ss
         # a budget that most searches exceed (they are handed back to the host threads) and a large host share: the expansions
         # the kernel spent before giving up count as well, so only the answers are compared
         monkeypatch.setenv("TENDON_HIP_SEARCH_BUDGET", "40")
