@@ -754,6 +754,7 @@ bool search_setup(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.state != 0) return d.state > 0;
   d.state = -1;
+  Laps laps("search_setup");
   const int64_t V = r->V;
   if (r->S > trk::SR_MAXS) { d.why = "state size above the kernel's"; return false; }
   if (V < 2 || r->adj.size() == 0) { d.why = "no graph"; return false; }
@@ -769,6 +770,7 @@ bool search_setup(tr_roadmap *r) {
       if (std::adjacent_find(nb.begin(), nb.end()) != nb.end()) { d.why = "parallel edges"; return false; }
     }
   }
+  laps.lap("parallel-edge check");
   const int dev = tr_device(r->ctx);
   if (hipSetDevice(dev) != hipSuccess) { d.why = "hipSetDevice"; return false; }
   hipDeviceProp_t prop;
@@ -810,13 +812,16 @@ bool search_setup(tr_roadmap *r) {
   d.d_far_f = (double *)p; p += b_ff;
   d.d_far_v = (int32_t *)p; p += b_fv;
   d.d_stage = (int32_t *)p;
+  laps.lap("device properties + arena");
   bool ok = dev_cache().alloc(dev, (void **)&d.nodes, (size_t)slots * V * sizeof(Node)) == hipSuccess;
+  laps.lap("node records allocated");
   ok = ok && hipMemsetAsync(d.nodes, 0, (size_t)slots * V * sizeof(Node), nullptr) == hipSuccess &&
        hipMemsetAsync(d.d_gens, 0, b_gen, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_adj_off, r->adj_off.data(), (size_t)(V + 1) * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_adj, r->adj.data(), r->adj.size() * sizeof(Arc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_states, r->states.data(), (size_t)V * r->S * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipStreamSynchronize(nullptr) == hipSuccess;
+  laps.lap("records cleared + graph uploaded");
   if (!ok) { free_search(r); r->ds.state = -1; r->ds.why = "out of device memory"; return false; }
   d.lm_current = false;
   d.state = 1;
