@@ -3,7 +3,7 @@
 caches of which a random share collides, lazy and eager solving with several landmark counts -- statuses and costs against
 scipy's Dijkstra on the valid sub-graph (an independent implementation), returned paths checked edge by edge.
 
-    python tests/fuzz_queries.py [n_cases] [seed]
+    python tests/fuzz_queries.py [n_cases] [seed]          (FUZZ_QUERIES_NQ=n queries per case, default 300)
 """
 import importlib
 import os
@@ -55,7 +55,7 @@ def main():
         v_ok, e_ok = blocks[vid] == 0, blocks[eid] == 0
         keep = e_ok & v_ok[e[:, 0]] & v_ok[e[:, 1]]
         G = coo_matrix((np.r_[w[keep], w[keep]], (np.r_[e[keep, 0], e[keep, 1]], np.r_[e[keep, 1], e[keep, 0]])), shape=(V, V)).tocsr()
-        nq = 300
+        nq = int(os.environ.get("FUZZ_QUERIES_NQ", "300"))      # (512 or more: the default switches share the rounds with the device search)
         q = rng.integers(0, V, (nq, 2))
         D = dijkstra(G, directed=False, indices=np.unique(q[:, 0]))
         row = {s: i for i, s in enumerate(np.unique(q[:, 0]))}
