@@ -909,7 +909,7 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
 
 void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, const std::vector<size_t> &klist,
                            std::vector<uint8_t> &found, std::vector<std::vector<int32_t>> &paths,
-                           std::vector<std::vector<int32_t>> &paths_e, std::vector<size_t> &redo, int64_t &expanded) {
+                           std::vector<std::vector<int32_t>> &paths_e, std::vector<size_t> &redo, int64_t &expanded, int T) {
   auto &d = r->ds;
   const int64_t nq = d.in_flight;
   d.in_flight = 0;
@@ -941,7 +941,7 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
   std::memcpy(&ex, &ctl[2], sizeof(ex));
   expanded += (int64_t)ex;
   d.st_expanded += (int64_t)ex;
-  const int Tb = nq >= 2048 ? std::min(host_threads(0), 16) : 1;          // (ten thousand small vectors: by ranges on the host threads)
+  const int Tb = nq >= 2048 ? std::max(1, std::min(T, 16)) : 1;            // (ten thousand small vectors: by ranges on the host threads)
   std::vector<std::vector<size_t>> part((size_t)Tb);
   on_threads(Tb, [&](int t) {
     const int64_t j0 = nq * t / Tb, j1 = nq * (t + 1) / Tb;
@@ -1358,7 +1358,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       host_search(&host_list);
       const auto t1 = std::chrono::steady_clock::now();
       int64_t ex = 0;
-      device_search_collect(r, active, dev_list, found, paths, paths_e, redo, ex);
+      device_search_collect(r, active, dev_list, found, paths, paths_e, redo, ex, T);
       expanded += ex;
 
       const auto t2 = std::chrono::steady_clock::now();
