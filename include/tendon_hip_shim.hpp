@@ -520,6 +520,13 @@ class VoxelCachedLazyPRM {
     for (size_t q = 0; q < n; q++) s.paths[q].assign(pv.begin() + off[q], pv.begin() + off[q + 1]);
     return s;
   }
+  // Where the graph searches of the last solveWithRoadmap ran (tr_roadmap_search_stats): the kernel, the host threads, the component labels.
+  struct SearchStats { int64_t on_device, handed_back, on_host_meanwhile, list_moves, expanded_on_device, expanded_on_host, answered_by_components; };
+  SearchStats searchStats() const {
+    int64_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    rcheck(tr_roadmap_search_stats(rm_, o));
+    return SearchStats{o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+  }
 
  private:
   void rcheck(int st) const {

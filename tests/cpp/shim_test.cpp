@@ -113,6 +113,10 @@ int main(int argc, char **argv) {
       for (int32_t v : sol.paths[q]) std::printf(" %d", v);
       std::printf("\n");
     }
+    {
+      const auto ss = prm.searchStats();                  // three queries: the host threads' round (the kernel takes rounds of 512 or more)
+      if (ss.on_device != 0 || ss.handed_back != 0 || ss.expanded_on_host <= 0) { std::printf("searchStats wrong\n"); return 3; }
+    }
     auto inv = prm.revalidate();
     std::printf("revalidate %lld %lld\n", (long long)inv.first, (long long)inv.second);
     vc3.add_capsules({0.0, 0.0, 0.3, 0.05, 0.0, 0.3, 0.01});
