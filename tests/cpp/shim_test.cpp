@@ -115,7 +115,7 @@ int main(int argc, char **argv) {
     }
     {
       const auto ss = prm.searchStats();                  // three queries: the host threads' round (the kernel takes rounds of 512 or more)
-      if (ss.on_device != 0 || ss.handed_back != 0 || ss.expanded_on_host <= 0) { std::printf("searchStats wrong\n"); return 3; }
+      if (ss.on_device != 0 || ss.handed_back != 0 || ss.expanded_on_host < 0 || ss.answered_by_components != 0) { std::printf("searchStats wrong\n"); return 3; }
     }
     auto inv = prm.revalidate();
     std::printf("revalidate %lld %lld\n", (long long)inv.first, (long long)inv.second);
