@@ -150,3 +150,19 @@ def test_config4_workload_world1_rccl_and_world2_rehearsal_agree():
         for key in ("valid_vertices", "candidate_edges", "valid_edges", "vertex_mask_crc32", "edge_list_crc32"):
             assert one["config"][key] == other["config"][key], key
     assert all(v > 0 for v in two["config"]["phases_ms"].values()) and two["value"] > 0
+
+
+def test_config4_per_shard_projection_on_one_gpu():
+    """`bench.py --workload config4 --emulate-world 2 4`: every rank's shard of every phase run alone on this GPU, its outputs
+    compared with the world-1 run's slice inside the workload (it aborts on a difference); the report must carry the per-rank
+    times, the replicated work, the all-gather payloads and the projection label."""
+    out = _bench(["--workload", "config4", "--config4-log2", "15", "--config4-k", "6", "--steps", "1", "--warmup", "0",
+                  "--emulate-world", "2", "4"])
+    assert "projection" in out and out["n_gpus"] == 1 and set(out["emulated_worlds"]) == {"2", "4"}
+    w1 = out["world_1_ms"]
+    assert all(w1[k] > 0 for k in ("vertices", "knn_rows", "edges", "total"))
+    for g, w in out["emulated_worlds"].items():
+        assert len(w["phases_ms_per_rank"]["edges"]) == int(g) and all(t > 0 for t in w["phases_ms_per_rank"]["edges"])
+        assert w["compute_critical_path_ms"] > 0 and 0 <= w["replicated_fraction_of_critical_path"] < 1
+        assert set(w["allgather_bytes_per_rank"]) == {"vertex_mask", "vertex_signatures", "knn_rows", "edge_mask"}
+    assert 0 < out["valid_vertices"] < 1 << 15 and out["candidate_edges"] > 0
