@@ -427,6 +427,10 @@ int tr_roadmap_clear_validity(tr_roadmap *rm);
 int tr_roadmap_revalidate(tr_roadmap *rm, int64_t *n_invalid_vertices, int64_t *n_invalid_edges);
 /* status per item: 0 unknown, 1 valid, 2 invalid (removed) */
 int tr_roadmap_get_validity(tr_roadmap *rm, uint8_t *vertex_status /*[n_vertices]*/, uint8_t *edge_status /*[n_edges]*/);
+/* The inverse of tr_roadmap_get_validity: what a builder already knows goes in (either array may be NULL = leave as it is).
+ * createRoadmap with ValidateVertices / ValidateEdges leaves the items it accepted VALIDITY_TRUE
+ * (vertexValidityProperty_ :1476, computeEdgeValidity :2621-2631), so the first query on such a roadmap tests nothing again. */
+int tr_roadmap_set_validity(tr_roadmap *rm, const uint8_t *vertex_status /*[n_vertices]*/, const uint8_t *edge_status /*[n_edges]*/);
 /* The batched query loop (lazy: only the items on candidate paths are tested, round by round -- until so many queries keep coming
  * back for another round while testing every cached set at once is cheaper than that round, see TENDON_HIP_LAZY_ONLY).  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
  * query q's path (start ... goal) is entries path_offsets[q] .. path_offsets[q+1]-1 of the array

@@ -10,12 +10,14 @@
 //   motion_planning::VoxelBackboneMotionValidator                       motion-planning/VoxelBackboneMotionValidator.h
 //   motion_planning::VoxelBackboneDiscreteMotionValidator               motion-planning/VoxelBackboneDiscreteMotionValidator.h
 //   motion_planning::VoxelCaches, voxelize_states, caches_collide       the cache loops of VoxelCachedLazyPRM.cpp
-//   motion_planning::VoxelCachedLazyPRM                                  solveWithRoadmap for a batch of queries on a cached roadmap
+//   motion_planning::VoxelCachedLazyPRM                                  createRoadmap / precompute* (the build) and solveWithRoadmap
+//                                                                        for a batch of queries (motion-planning/VoxelCachedLazyPRM.h:469-514)
 //
 // Error behaviour: every tr_status is rethrown as the C++ exception type the reference throws at
 // the same condition (std::invalid_argument, std::out_of_range, std::domain_error,
 // std::length_error, std::runtime_error).
 #pragma once
+#include <algorithm>
 #include <array>
 #include <cmath>
 #include <cstdint>
@@ -466,49 +468,351 @@ class VoxelBackboneDiscreteMotionValidator : public VoxelBackboneMotionValidator
   }
 };
 
-/// The query side of motion_planning::VoxelCachedLazyPRM on a roadmap with voxel caches: solveWithRoadmap
-/// (motion-planning/VoxelCachedLazyPRM.cpp:1977-2096 -> constructSolution :2689-2771) for a batch of (start, goal)
-/// roadmap vertices, clearValidity (:1656-1663), and the eager re-validation of every cached set.
+namespace detail {
+inline std::vector<uint64_t> pack(const std::vector<bool> &b) {
+  std::vector<uint64_t> w((b.size() + 63) / 64, 0);
+  for (size_t i = 0; i < b.size(); i++) if (b[i]) w[i >> 6] |= (uint64_t)1 << (i & 63);
+  return w;
+}
+/// n items without a cache
+inline VoxelCaches empty_items(size_t n) {
+  VoxelCaches c;
+  c.offsets.assign(n + 1, 0);
+  c.usable.assign(n, false);
+  return c;
+}
+/// out item i = item keep[i] of c
+inline VoxelCaches select_items(const VoxelCaches &c, const std::vector<size_t> &keep) {
+  VoxelCaches out;
+  out.offsets.assign(keep.size() + 1, 0);
+  out.usable.resize(keep.size());
+  for (size_t i = 0; i < keep.size(); i++) out.offsets[i + 1] = out.offsets[i] + (c.offsets[keep[i] + 1] - c.offsets[keep[i]]);
+  out.block_ids.resize((size_t)out.offsets.back()); out.masks.resize((size_t)out.offsets.back());
+  for (size_t i = 0; i < keep.size(); i++) {
+    const size_t a = (size_t)c.offsets[keep[i]], b = (size_t)c.offsets[keep[i] + 1], o = (size_t)out.offsets[i];
+    std::copy(c.block_ids.begin() + a, c.block_ids.begin() + b, out.block_ids.begin() + o);
+    std::copy(c.masks.begin() + a, c.masks.begin() + b, out.masks.begin() + o);
+    out.usable[i] = c.usable[keep[i]];
+  }
+  return out;
+}
+/// b's items after a's
+inline void append_items(VoxelCaches &a, const VoxelCaches &b) {
+  const int64_t base = a.offsets.back();
+  for (size_t i = 0; i < b.items(); i++) a.offsets.push_back(base + b.offsets[i + 1]);
+  a.block_ids.insert(a.block_ids.end(), b.block_ids.begin(), b.block_ids.begin() + b.offsets.back());
+  a.masks.insert(a.masks.end(), b.masks.begin(), b.masks.begin() + b.offsets.back());
+  a.usable.insert(a.usable.end(), b.usable.begin(), b.usable.end());
+}
+/// item idx[i] of dst becomes item i of src (idx ascending)
+inline void replace_items(VoxelCaches &dst, const std::vector<size_t> &idx, const VoxelCaches &src) {
+  if (idx.empty()) return;
+  VoxelCaches out;
+  out.offsets.assign(dst.items() + 1, 0);
+  out.usable = dst.usable;
+  std::vector<int64_t> from(dst.items(), -1);
+  for (size_t i = 0; i < idx.size(); i++) from[idx[i]] = (int64_t)i;
+  for (size_t v = 0; v < dst.items(); v++) {
+    const VoxelCaches &c = from[v] < 0 ? dst : src;
+    const size_t it = from[v] < 0 ? v : (size_t)from[v];
+    out.offsets[v + 1] = out.offsets[v] + (c.offsets[it + 1] - c.offsets[it]);
+    out.block_ids.insert(out.block_ids.end(), c.block_ids.begin() + c.offsets[it], c.block_ids.begin() + c.offsets[it + 1]);
+    out.masks.insert(out.masks.end(), c.masks.begin() + c.offsets[it], c.masks.begin() + c.offsets[it + 1]);
+    if (from[v] >= 0) out.usable[v] = src.usable[it];
+  }
+  dst = std::move(out);
+}
+}  // namespace detail
+
+/// motion_planning::VoxelCachedLazyPRM (motion-planning/VoxelCachedLazyPRM.h:195-830) on the batched engine: the roadmap BUILD --
+/// createRoadmap with its CreateRoadmapOption flags (.h:469-497, .cpp:1380-1561), precompute{Vertex,Edge}Validity (:1563-1648),
+/// precompute{Vertex,Edge}VoxelCache (:1692-1789), clear*VoxelCache, clearDisconnectedVertices (:1665-1690), the connection
+/// strategies (:1327-1364) -- as apps/create_roadmap.cpp:252-331 drives it, and the QUERY side: solveWithRoadmap (:1977-2096 ->
+/// constructSolution :2689-2771) for a batch of (start, goal) roadmap vertices, clearValidity (:1656-1663), the eager
+/// re-validation of every cached set.  The graph (states, edges, voxel sets, validity) lives in this object on the host and in
+/// a tr_roadmap in HBM that is rebuilt when the graph was edited; every loop over vertices or edges is one batched call.
+///
+/// Differences a caller sees: vertices are numbered 0 .. milestoneCount() - 1 in creation order (the reference's indexProperty_);
+/// new milestones come from ONE reproducible candidate sequence (seed, candidate index), not from thread-local OMPL samplers;
+/// items found invalid by a query stay in the arrays with status 2 instead of leaving the graph (the searches skip them), and
+/// clearValidity() makes them unknown again; queries name roadmap vertices (the reference adds start / goal states first).
 class VoxelCachedLazyPRM {
  public:
+  enum CreateRoadmapOption {             // VoxelCachedLazyPRM.h:469-482
+    LazyRoadmap = 0x0, VoxelizeVertices = 0x1, ValidateVertices = 0x2, VoxelizeEdges = 0x4, ValidateEdges = 0x8
+  };
   struct Solution { std::vector<int32_t> status; std::vector<double> cost; std::vector<std::vector<int32_t>> paths; tr_roadmap_stats stats; };
+  /// what the last createRoadmap did: the candidate edges of the connection loop with checkMotion's verdict (or is_fully_valid)
+  /// and the reference's count of FK evaluations per edge, the candidates consumed by the vertex phase
+  struct BuildReport {
+    std::vector<int32_t> candidate_edges; std::vector<bool> accepted; std::vector<int32_t> n_fk;
+    int64_t candidates_tried = 0; std::vector<int64_t> candidate_index; int32_t k = 0; double max_distance = 0;
+  };
 
+  /// a planner with an empty roadmap: createRoadmap / precompute* build it (`mv` supplies checkMotion and the space resolution)
+  VoxelCachedLazyPRM(const VoxelBackboneValidityChecker &vc, const VoxelBackboneMotionValidator &mv, uint64_t seed = 0)
+      : vc_(vc), mv_(&mv), S_(vc.robot().state_size()), seed_(seed) {
+    vcache_ = detail::empty_items(0); ecache_ = detail::empty_items(0);
+  }
+  /// a loaded roadmap (fromRoadmapParser :2357-2580): states, edge index pairs, optional weights (NULL = state-space distance)
   VoxelCachedLazyPRM(const VoxelBackboneValidityChecker &vc, const std::vector<double> &states, size_t n_states,
-                     const std::vector<int32_t> &edges, const std::vector<double> *weights = nullptr)
-      : vc_(vc) {
-    if (states.size() != n_states * vc.robot().state_size()) throw std::invalid_argument("State is not the right size");
-    const int st = tr_roadmap_create(vc.context(), states.data(), (int64_t)n_states, edges.data(), weights ? weights->data() : nullptr,
-                                     (int64_t)(edges.size() / 2), &rm_);
-    if (st == TR_ERR_OUT_OF_RANGE) throw std::out_of_range("edge refers to a state outside the roadmap");
-    if (st != TR_OK) throw std::invalid_argument("tr_roadmap_create failed");
+                     const std::vector<int32_t> &edges, const std::vector<double> *weights = nullptr,
+                     const VoxelBackboneMotionValidator *mv = nullptr)
+      : vc_(vc), mv_(mv), S_(vc.robot().state_size()) {
+    if (states.size() != n_states * S_) throw std::invalid_argument("State is not the right size");
+    if (weights && weights->size() != edges.size() / 2) throw std::invalid_argument("one weight per edge");
+    states_ = states; edges_ = edges;
+    if (weights) weights_ = *weights;
+    tips_.assign(3 * n_states, std::nan("")); has_tip_.assign(n_states, 0);
+    vstat_.assign(n_states, 0); estat_.assign(edges.size() / 2, 0);
+    vcache_ = detail::empty_items(n_states); ecache_ = detail::empty_items(edges.size() / 2);
+    create_device_graph();                               // (an edge outside the roadmap throws here, as before)
   }
   ~VoxelCachedLazyPRM() { tr_roadmap_destroy(rm_); }
   VoxelCachedLazyPRM(const VoxelCachedLazyPRM &) = delete;
   VoxelCachedLazyPRM &operator=(const VoxelCachedLazyPRM &) = delete;
 
-  /// vertexVoxelsProperty_ / edgeVoxelsProperty_ as CSR; `usable` = which items have a cache at all
+  // ---- the graph ----
+  size_t milestoneCount() const { return vstat_.size(); }                       // .h:449
+  size_t edgeCount() const { return estat_.size(); }                            // .h:452
+  const std::vector<double> &states() const { return states_; }                 // milestoneCount() x state_size
+  const std::vector<double> &tipPositions() const { return tips_; }             // x 3; NaN where tipPositionProperty_ is empty
+  const std::vector<int32_t> &edges() const { return edges_; }                  // edgeCount() x 2
+  const VoxelCaches &vertexVoxels() const { return vcache_; }                   // vertexVoxelsProperty_; usable[v] = has a cache
+  const VoxelCaches &edgeVoxels() const { return ecache_; }
+  const BuildReport &lastBuild() const { return report_; }
+  /// 0 unknown, 1 VALIDITY_TRUE, 2 found invalid
+  void validity(std::vector<uint8_t> &vertex_status, std::vector<uint8_t> &edge_status) { absorb(); vertex_status = vstat_; edge_status = estat_; }
+
+  // ---- connection strategy (:1316-1364) ----
+  void setMaxNearestNeighbors(size_t k) {                                        // KBoundedStrategy(k, maxDistance_) :1327-1344
+    if (star_) throw std::runtime_error("Cannot set the maximum nearest neighbors for VoxelCachedLazyPRM");
+    k_ = k;
+  }
+  void setStarConnectionStrategy() { star_ = true; }                             // KStarStrategy :1346-1356
+  void setRange(double distance) { max_distance_ = distance; }                   // :1319-1326
+  /// maxDistance_: 0.2 of the space's maximum extent unless set (SelfConfig::configurePlannerRange, :1242)
+  double getRange() const {
+    if (max_distance_ > 0) return max_distance_;
+    double w_rot = 0, w_ret = 0, ext2 = 0;
+    tr_space_weights(vc_.context(), &w_rot, &w_ret);
+    const auto &rb = vc_.robot();
+    for (auto &t : rb.tendons) ext2 += t.max_tension * t.max_tension;
+    return 0.2 * (std::sqrt(ext2) + (rb.enable_rotation ? w_rot * 3.14159265358979323846 : 0.0) + (rb.enable_retraction ? w_ret * rb.specs.L : 0.0));
+  }
+  /// the box new milestones are drawn from (default: the planner's state-space bounds, Problem.cpp:101-163)
+  void setSamplingBounds(const std::vector<double> &lo, const std::vector<double> &hi) {
+    if (lo.size() != S_ || hi.size() != S_) throw std::invalid_argument("State is not the right size");
+    lo_ = lo; hi_ = hi;
+  }
+
+  // ---- createRoadmap (:1380-1561) ----
+  /// Brings the roadmap up to N milestones.  New milestones: the next candidates of the sequence that pass what `opt` asks of a
+  /// vertex (nothing | is_valid_shape | is_valid_shape and no collision, :1412-1440); every new milestone is connected to its
+  /// connection-strategy neighbours among ALL milestones (:1491-1502: nearestK on a structure that already holds the milestone, so
+  /// k counts the milestone itself); with VoxelizeEdges / ValidateEdges the new edges are voxelised / checked (voxelizeEdge :2879 /
+  /// computeEdgeValidity :2621) in one batched pass and the failing ones removed (:1508-1551).
+  void createRoadmap(size_t N, int opt = LazyRoadmap) {
+    const size_t Nv = milestoneCount();
+    if (N <= Nv) return;                                                         // :1387-1391
+    need_validators("createRoadmap");
+    absorb();
+    tr_ctx *c = vc_.context();
+    const bool validate_verts = opt & ValidateVertices, validate_edges = opt & ValidateEdges;
+    const bool voxelize_verts = validate_verts || (opt & VoxelizeVertices), voxelize_edges = validate_edges || (opt & VoxelizeEdges);
+    const size_t add = N - Nv;
+    const double *lo = lo_.empty() ? nullptr : lo_.data(), *hi = hi_.empty() ? nullptr : hi_.data();
+    report_ = BuildReport{};
+    std::vector<double> st(add * S_), tips(3 * add, std::nan(""));
+    report_.candidate_index.resize(add);
+    const uint64_t first = next_candidate_;
+    if (!voxelize_verts) {                                                       // sampleUniform, accepted as it is (:1417-1419)
+      check(c, tr_candidate_states(c, seed_, first, (int64_t)add, lo, hi, st.data()));
+      for (size_t i = 0; i < add; i++) report_.candidate_index[i] = (int64_t)(first + i);
+      next_candidate_ += add;
+    } else if (validate_verts) {                                                 // ... until valid shape and no collision (:1421-1436)
+      int64_t acc = 0, tried = 0;
+      check(c, tr_sample_valid_vertices(c, seed_, first, lo, hi, (int64_t)add, 0, st.data(), tips.data(), report_.candidate_index.data(), &acc, &tried));
+      if ((size_t)acc < add) throw std::runtime_error("createRoadmap: only " + std::to_string(acc) + " valid milestones in " + std::to_string(tried) + " candidates");
+      next_candidate_ += (uint64_t)tried;
+    } else {                                                                     // ... until valid shape (:1421-1426)
+      size_t have = 0;
+      while (have < add) {
+        const size_t m = std::max<size_t>(4096, (add - have) + (add - have) / 2);
+        std::vector<double> cand(m * S_);
+        std::vector<uint64_t> bits((m + 63) / 64);
+        std::vector<uint8_t> flags(m);
+        check(c, tr_candidate_states(c, seed_, next_candidate_, (int64_t)m, lo, hi, cand.data()));
+        check(c, tr_validate_batch(c, cand.data(), (int64_t)m, bits.data(), nullptr, flags.data()));
+        const unsigned shape_ok = TR_FLAG_CONVERGED | TR_FLAG_LENGTH_OK | TR_FLAG_NO_SELFCOL;
+        size_t used = m;
+        for (size_t i = 0; i < m; i++) {
+          if ((flags[i] & (shape_ok | TR_FLAG_DOMAIN)) != shape_ok) continue;
+          std::copy(cand.begin() + i * S_, cand.begin() + (i + 1) * S_, st.begin() + have * S_);
+          report_.candidate_index[have] = (int64_t)(next_candidate_ + i);
+          if (++have == add) { used = i + 1; break; }
+        }
+        next_candidate_ += used;
+        if (next_candidate_ - first > 64 * (uint64_t)add + (1u << 20)) throw std::runtime_error("createRoadmap: too few shape-valid candidates");
+      }
+    }
+    report_.candidates_tried = (int64_t)(next_candidate_ - first);
+    // the milestones join the graph before any of them is connected (:1463-1483)
+    VoxelCaches vnew = detail::empty_items(add);
+    if (voxelize_verts) {
+      vnew = voxelize_states(vc_, st, add, &tips);
+      for (size_t i = 0; i < add; i++) if (!vnew.usable[i]) throw std::runtime_error("createRoadmap: an accepted milestone has no valid shape");
+    }
+    states_.insert(states_.end(), st.begin(), st.end());
+    tips_.insert(tips_.end(), tips.begin(), tips.end());
+    has_tip_.insert(has_tip_.end(), add, voxelize_verts ? 1 : 0);
+    vstat_.insert(vstat_.end(), add, validate_verts ? 1 : 0);
+    detail::append_items(vcache_, vnew);
+    dirty_ = true;
+    // connectionStrategy_(v) for every new v; an edge exists once (:1491-1502)
+    const int64_t kk = std::min<int64_t>((int64_t)N, star_ ? (int64_t)tr_kstar_k(c, (int64_t)N) : (int64_t)k_);
+    const double maxd = star_ ? HUGE_VAL : getRange();
+    report_.k = (int32_t)kk; report_.max_distance = maxd;
+    std::vector<int32_t> cand((size_t)(2 * (int64_t)N * kk));
+    int64_t ne = 0;
+    if (kk >= 1 && Nv == 0) {
+      check(c, tr_knn_edges(c, states_.data(), (int64_t)N, (int32_t)kk, maxd, cand.data(), (int64_t)N * kk, &ne));
+    } else if (kk >= 1) {
+      std::vector<int32_t> table((size_t)((int64_t)N * kk), -1);                  // rows of the old milestones stay empty: they do not connect again
+      std::vector<double> dist((size_t)((int64_t)add * kk));
+      check(c, tr_knn_range(c, states_.data(), (int64_t)N, (int64_t)Nv, (int64_t)add, (int32_t)kk, maxd, table.data() + Nv * (size_t)kk, dist.data()));
+      check(c, tr_knn_table_edges(c, table.data(), (int64_t)N, (int32_t)kk, cand.data(), (int64_t)N * kk, &ne));
+    }
+    cand.resize((size_t)(2 * ne));
+    report_.candidate_edges = cand;
+    report_.accepted.assign((size_t)ne, true);
+    VoxelCaches enew = detail::empty_items((size_t)ne);
+    std::vector<size_t> keep;
+    if (voxelize_edges && ne > 0) {
+      enew.offsets.assign((size_t)ne + 1, 0);
+      std::vector<uint64_t> bits((size_t)(ne + 63) / 64);
+      report_.n_fk.resize((size_t)ne);
+      check(c, (validate_edges ? tr_connect_edges_indexed : tr_voxelize_edges_indexed)(
+                   c, &mv_->space, states_.data(), (int64_t)N, cand.data(), ne, enew.offsets.data(), bits.data(), report_.n_fk.data()));
+      enew.usable = detail::unpack(bits, (size_t)ne);
+      detail::fetch(c, enew);
+      report_.accepted = enew.usable;
+      for (size_t e = 0; e < (size_t)ne; e++) if (enew.usable[e]) keep.push_back(e);
+      enew = detail::select_items(enew, keep);
+    } else {
+      for (size_t e = 0; e < (size_t)ne; e++) keep.push_back(e);
+    }
+    for (size_t e : keep) {
+      edges_.push_back(cand[2 * e]); edges_.push_back(cand[2 * e + 1]);
+      if (!weights_.empty()) weights_.push_back(distance(&states_[(size_t)cand[2 * e] * S_], &states_[(size_t)cand[2 * e + 1] * S_]));
+    }
+    estat_.insert(estat_.end(), keep.size(), validate_edges ? 1 : 0);
+    detail::append_items(ecache_, enew);
+  }
+
+  // ---- precompute* (:1563-1648, :1692-1789) ----
+  /// voxelizeVertex for every vertex without a cache or a tip; vertices without a valid shape leave the roadmap
+  void precomputeVertexVoxelCache() {
+    need_validators("precomputeVertexVoxelCache");
+    absorb();
+    remove_vertices(voxelize_missing_vertices(nullptr));
+  }
+  /// voxelizeEdge for every edge without a cache; edges that are not fully valid leave the roadmap
+  void precomputeEdgeVoxelCache() {
+    need_validators("precomputeEdgeVoxelCache");
+    absorb();
+    std::vector<size_t> miss;
+    for (size_t e = 0; e < edgeCount(); e++) if (!ecache_.usable[e]) miss.push_back(e);
+    remove_edges(edge_pass(miss, false));
+  }
+  void precomputeVoxelCache() { precomputeVertexVoxelCache(); precomputeEdgeVoxelCache(); }
+  /// computeVertexValidity for every vertex not known valid (voxelise if needed, then against the obstacles); the others leave
+  void precomputeVertexValidity() {
+    need_validators("precomputeVertexValidity");
+    absorb();
+    std::vector<bool> todo(milestoneCount());
+    for (size_t v = 0; v < milestoneCount(); v++) todo[v] = vstat_[v] != 1;
+    std::vector<size_t> gone = voxelize_missing_vertices(&todo);
+    const std::vector<bool> hit = caches_collide(vc_, vcache_);
+    std::vector<bool> out(milestoneCount(), false);
+    for (size_t v : gone) out[v] = true;
+    for (size_t v = 0; v < milestoneCount(); v++) {
+      if (!todo[v] || out[v]) continue;
+      if (hit[v]) out[v] = true; else vstat_[v] = 1;
+    }
+    gone.clear();
+    for (size_t v = 0; v < milestoneCount(); v++) if (out[v]) gone.push_back(v);
+    remove_vertices(gone);
+  }
+  /// computeEdgeValidity for every edge not known valid; the others leave
+  void precomputeEdgeValidity() {
+    need_validators("precomputeEdgeValidity");
+    absorb();
+    std::vector<size_t> miss, have;
+    for (size_t e = 0; e < edgeCount(); e++) if (estat_[e] != 1) (ecache_.usable[e] ? have : miss).push_back(e);
+    std::vector<size_t> gone = edge_pass(miss, true);                            // voxelise + collide in one traversal of the samples
+    std::vector<bool> out(edgeCount(), false);
+    for (size_t e : gone) out[e] = true;
+    for (size_t e : miss) if (!out[e]) estat_[e] = 1;
+    if (!have.empty()) {
+      const std::vector<bool> hit = caches_collide(vc_, ecache_);
+      for (size_t e : have) { if (hit[e]) out[e] = true; else estat_[e] = 1; }
+    }
+    gone.clear();
+    for (size_t e = 0; e < edgeCount(); e++) if (out[e]) gone.push_back(e);
+    remove_edges(gone);
+  }
+  void precomputeValidity() { precomputeVertexValidity(); precomputeEdgeValidity(); }
+  void clearVertexVoxelCache() { absorb(); vcache_ = detail::empty_items(milestoneCount()); dirty_ = true; }    // :1791-1795
+  void clearEdgeVoxelCache() { absorb(); ecache_ = detail::empty_items(edgeCount()); dirty_ = true; }           // :1797-1801
+  void clearVoxelCache() { clearVertexVoxelCache(); clearEdgeVoxelCache(); }
+  /// vertices outside the largest connected component leave the roadmap (:1665-1690)
+  void clearDisconnectedVertices() {
+    absorb();
+    const size_t V = milestoneCount();
+    std::vector<int32_t> parent(V);
+    for (size_t v = 0; v < V; v++) parent[v] = (int32_t)v;
+    auto find = [&](int32_t x) { while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; } return x; };
+    for (size_t e = 0; e < edgeCount(); e++) {
+      const int32_t a = find(edges_[2 * e]), b = find(edges_[2 * e + 1]);
+      if (a != b) parent[std::max(a, b)] = std::min(a, b);
+    }
+    std::vector<size_t> size(V, 0);
+    for (size_t v = 0; v < V; v++) size[(size_t)find((int32_t)v)]++;
+    size_t best = 0;
+    for (size_t v = 0; v < V; v++) if (size[v] > size[best]) best = v;
+    std::vector<size_t> gone;
+    for (size_t v = 0; v < V; v++) if ((size_t)find((int32_t)v) != best) gone.push_back(v);
+    remove_vertices(gone);
+  }
+
+  // ---- queries ----
+  /// vertexVoxelsProperty_ / edgeVoxelsProperty_ as CSR; `usable` = which items have a cache at all (empty = all of them)
   void setCaches(const VoxelCaches &vertices, const VoxelCaches &edges) {
-    auto pack = [](const std::vector<bool> &b) {
-      std::vector<uint64_t> w((b.size() + 63) / 64, 0);
-      for (size_t i = 0; i < b.size(); i++) if (b[i]) w[i >> 6] |= (uint64_t)1 << (i & 63);
-      return w;
-    };
-    const auto vp = pack(vertices.usable), ep = pack(edges.usable);
-    rcheck(tr_roadmap_set_caches(rm_, vertices.offsets.data(), vertices.block_ids.data(), vertices.masks.data(),
-                                 vertices.usable.empty() ? nullptr : vp.data(), edges.offsets.data(), edges.block_ids.data(),
-                                 edges.masks.data(), edges.usable.empty() ? nullptr : ep.data()));
+    if (vertices.items() != milestoneCount() || edges.items() != edgeCount()) throw std::invalid_argument("cache offsets do not match the roadmap");
+    absorb();
+    vcache_ = vertices; ecache_ = edges;
+    if (vcache_.usable.empty()) vcache_.usable.assign(milestoneCount(), true);
+    if (ecache_.usable.empty()) ecache_.usable.assign(edgeCount(), true);
+    caches_given_ = true;
+    dirty_ = true;
   }
   /// landmark lower bounds for the searches (0 = the reference's heuristic alone); paths and costs do not depend on it
-  void prepare(int n_landmarks = 16, int n_threads = 0) { rcheck(tr_roadmap_prepare(rm_, n_landmarks, n_threads)); }
-  void clearValidity() { rcheck(tr_roadmap_clear_validity(rm_)); }
+  void prepare(int n_landmarks = 16, int n_threads = 0) { lm_ = n_landmarks; lm_threads_ = n_threads; sync(); }
+  void clearValidity() {                                                         // :1656-1663
+    std::fill(vstat_.begin(), vstat_.end(), 0); std::fill(estat_.begin(), estat_.end(), 0);
+    if (rm_ && !dirty_) rcheck(tr_roadmap_clear_validity(rm_));
+  }
   /// every cached set against the checker's current obstacle grid -> (#invalid vertices, #invalid edges)
   std::pair<int64_t, int64_t> revalidate() {
+    sync();
     int64_t nv = 0, ne = 0;
     rcheck(tr_roadmap_revalidate(rm_, &nv, &ne));
     return {nv, ne};
   }
   Solution solveWithRoadmap(const std::vector<int32_t> &starts, const std::vector<int32_t> &goals, int n_threads = 0) {
     if (starts.size() != goals.size()) throw std::invalid_argument("starts and goals differ in length");
+    sync();
     const size_t n = starts.size();
     Solution s;
     s.status.resize(n); s.cost.resize(n);
@@ -524,8 +828,21 @@ class VoxelCachedLazyPRM {
   struct SearchStats { int64_t on_device, handed_back, on_host_meanwhile, list_moves, expanded_on_device, expanded_on_host, answered_by_components; };
   SearchStats searchStats() const {
     int64_t o[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    rcheck(tr_roadmap_search_stats(rm_, o));
+    if (rm_) rcheck(tr_roadmap_search_stats(rm_, o));
     return SearchStats{o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
+  }
+  /// CompoundStateSpace::distance with the weights of Problem.cpp:112-152 (the edge cost connectVertices stores, :2857-2861)
+  double distance(const double *a, const double *b) const {
+    const auto &rb = vc_.robot();
+    const size_t N = rb.tendons.size();
+    double w_rot = 0, w_ret = 0, s = 0;
+    tr_space_weights(vc_.context(), &w_rot, &w_ret);
+    for (size_t i = 0; i < N; i++) s += (a[i] - b[i]) * (a[i] - b[i]);
+    double d = std::sqrt(s);
+    size_t k = N;
+    if (rb.enable_rotation) { double r = std::fabs(a[k] - b[k]); if (r > 3.14159265358979323846) r = 2 * 3.14159265358979323846 - r; d += w_rot * r; k++; }
+    if (rb.enable_retraction) d += w_ret * std::fabs(a[k] - b[k]);
+    return d;
   }
 
  private:
@@ -536,8 +853,136 @@ class VoxelCachedLazyPRM {
     if (st == TR_ERR_INVALID_ARG) throw std::invalid_argument(m);
     throw std::runtime_error(m);
   }
+  void need_validators(const char *what) const {
+    if (!mv_) throw std::runtime_error(std::string(what) + ": missing voxel motion validator");      // the reference's setup_ == false (:1286-1298)
+  }
+  void create_device_graph() {
+    tr_roadmap_destroy(rm_); rm_ = nullptr;
+    const int st = tr_roadmap_create(vc_.context(), states_.data(), (int64_t)milestoneCount(), edges_.data(),
+                                     weights_.empty() ? nullptr : weights_.data(), (int64_t)edgeCount(), &rm_);
+    if (st == TR_ERR_OUT_OF_RANGE) throw std::out_of_range("edge refers to a state outside the roadmap");
+    if (st != TR_OK) throw std::invalid_argument("tr_roadmap_create failed");
+    dirty_ = false;
+  }
+  /// validity the query loop discovered since the last edit comes back into this object
+  void absorb() {
+    if (rm_ && !dirty_ && milestoneCount()) rcheck(tr_roadmap_get_validity(rm_, vstat_.data(), estat_.empty() ? nullptr : estat_.data()));
+  }
+  /// the device image follows the host graph: graph, caches (computed where a builder left them out: the reference voxelises such
+  /// items when a query first meets them, computeVertexValidity :2607-2618), known validity, landmark tables
+  void sync() {
+    if (rm_ && !dirty_) return;
+    if (mv_ && !caches_given_) {
+      std::vector<size_t> gone = voxelize_missing_vertices(nullptr);
+      for (size_t v : gone) vstat_[v] = 2;                                       // no valid shape: invalid in every environment
+      std::vector<size_t> miss;
+      for (size_t e = 0; e < edgeCount(); e++) if (!ecache_.usable[e] && estat_[e] != 2) miss.push_back(e);
+      for (size_t e : edge_pass(miss, false)) estat_[e] = 2;
+    }
+    create_device_graph();
+    const auto vp = detail::pack(vcache_.usable), ep = detail::pack(ecache_.usable);
+    rcheck(tr_roadmap_set_caches(rm_, vcache_.offsets.data(), vcache_.block_ids.data(), vcache_.masks.data(), vp.data(),
+                                 ecache_.offsets.data(), ecache_.block_ids.data(), ecache_.masks.data(), ep.data()));
+    if (milestoneCount()) rcheck(tr_roadmap_set_validity(rm_, vstat_.data(), estat_.empty() ? nullptr : estat_.data()));
+    if (lm_ >= 0) rcheck(tr_roadmap_prepare(rm_, lm_, lm_threads_));
+  }
+  /// voxelizeVertex (:2803-2837) for the vertices (of `only`, if given) without a cache or a tip -> those without a valid shape
+  std::vector<size_t> voxelize_missing_vertices(const std::vector<bool> *only) {
+    std::vector<size_t> miss, gone;
+    for (size_t v = 0; v < milestoneCount(); v++)
+      if ((!vcache_.usable[v] || !has_tip_[v]) && vstat_[v] != 2 && (!only || (*only)[v])) miss.push_back(v);
+    if (miss.empty()) return gone;
+    std::vector<double> st(miss.size() * S_), tips;
+    for (size_t i = 0; i < miss.size(); i++) std::copy(states_.begin() + miss[i] * S_, states_.begin() + (miss[i] + 1) * S_, st.begin() + i * S_);
+    VoxelCaches got = voxelize_states(vc_, st, miss.size(), &tips);
+    detail::replace_items(vcache_, miss, got);
+    for (size_t i = 0; i < miss.size(); i++) {
+      if (!got.usable[i]) { gone.push_back(miss[i]); continue; }
+      std::copy(tips.begin() + 3 * i, tips.begin() + 3 * i + 3, tips_.begin() + 3 * miss[i]);
+      has_tip_[miss[i]] = 1;
+    }
+    dirty_ = true;
+    return gone;
+  }
+  /// voxelizeEdge (collide = false, :2879-2902) or computeEdgeValidity (collide = true, :2621-2631) for the listed edges, which have
+  /// no cache yet -> the ones that fail; the others own their voxel set afterwards
+  std::vector<size_t> edge_pass(const std::vector<size_t> &list, bool collide) {
+    std::vector<size_t> gone;
+    if (list.empty()) return gone;
+    tr_ctx *c = vc_.context();
+    std::vector<int32_t> sub(2 * list.size());
+    for (size_t i = 0; i < list.size(); i++) { sub[2 * i] = edges_[2 * list[i]]; sub[2 * i + 1] = edges_[2 * list[i] + 1]; }
+    VoxelCaches got;
+    got.offsets.assign(list.size() + 1, 0);
+    std::vector<uint64_t> bits((list.size() + 63) / 64);
+    check(c, (collide ? tr_connect_edges_indexed : tr_voxelize_edges_indexed)(c, &mv_->space, states_.data(), (int64_t)milestoneCount(), sub.data(),
+                                                                              (int64_t)list.size(), got.offsets.data(), bits.data(), nullptr));
+    got.usable = detail::unpack(bits, list.size());
+    detail::fetch(c, got);
+    detail::replace_items(ecache_, list, got);
+    for (size_t i = 0; i < list.size(); i++) if (!got.usable[i]) gone.push_back(list[i]);
+    dirty_ = true;
+    return gone;
+  }
+  /// removeVertices (:2904-2948): the vertices and every edge at them leave; the others are renumbered in order
+  void remove_vertices(const std::vector<size_t> &gone) {
+    if (gone.empty()) return;
+    const size_t V = milestoneCount();
+    std::vector<int32_t> renum(V, 0);
+    for (size_t v : gone) renum[v] = -1;
+    std::vector<size_t> keep;
+    for (size_t v = 0; v < V; v++) if (renum[v] == 0) { renum[v] = (int32_t)keep.size(); keep.push_back(v); }
+    std::vector<size_t> egone;
+    for (size_t e = 0; e < edgeCount(); e++) if (renum[(size_t)edges_[2 * e]] < 0 || renum[(size_t)edges_[2 * e + 1]] < 0) egone.push_back(e);
+    remove_edges(egone);
+    for (int32_t &x : edges_) x = renum[(size_t)x];
+    std::vector<double> st(keep.size() * S_), tp(keep.size() * 3);
+    std::vector<uint8_t> ht(keep.size()), vs(keep.size());
+    for (size_t i = 0; i < keep.size(); i++) {
+      std::copy(states_.begin() + keep[i] * S_, states_.begin() + (keep[i] + 1) * S_, st.begin() + i * S_);
+      std::copy(tips_.begin() + keep[i] * 3, tips_.begin() + keep[i] * 3 + 3, tp.begin() + i * 3);
+      ht[i] = has_tip_[keep[i]]; vs[i] = vstat_[keep[i]];
+    }
+    states_.swap(st); tips_.swap(tp); has_tip_.swap(ht); vstat_.swap(vs);
+    vcache_ = detail::select_items(vcache_, keep);
+    dirty_ = true;
+  }
+  void remove_edges(const std::vector<size_t> &gone) {
+    if (gone.empty()) return;
+    std::vector<bool> out(edgeCount(), false);
+    for (size_t e : gone) out[e] = true;
+    std::vector<size_t> keep;
+    for (size_t e = 0; e < edgeCount(); e++) if (!out[e]) keep.push_back(e);
+    std::vector<int32_t> ed(2 * keep.size());
+    std::vector<double> w(weights_.empty() ? 0 : keep.size());
+    std::vector<uint8_t> es(keep.size());
+    for (size_t i = 0; i < keep.size(); i++) {
+      ed[2 * i] = edges_[2 * keep[i]]; ed[2 * i + 1] = edges_[2 * keep[i] + 1];
+      if (!weights_.empty()) w[i] = weights_[keep[i]];
+      es[i] = estat_[keep[i]];
+    }
+    edges_.swap(ed); weights_.swap(w); estat_.swap(es);
+    ecache_ = detail::select_items(ecache_, keep);
+    dirty_ = true;
+  }
+
   const VoxelBackboneValidityChecker &vc_;
+  const VoxelBackboneMotionValidator *mv_ = nullptr;
+  size_t S_ = 0;
+  uint64_t seed_ = 0, next_candidate_ = 0;
+  std::vector<double> lo_, hi_;
+  std::vector<double> states_, tips_, weights_;
+  std::vector<uint8_t> has_tip_, vstat_, estat_;
+  std::vector<int32_t> edges_;
+  VoxelCaches vcache_, ecache_;
+  bool caches_given_ = false;
+  bool star_ = false;
+  size_t k_ = 5;                       // magic::DEFAULT_NEAREST_NEIGHBORS_LAZY (:125)
+  double max_distance_ = 0.0;
+  int lm_ = -1, lm_threads_ = 0;
+  BuildReport report_;
   tr_roadmap *rm_ = nullptr;
+  bool dirty_ = true;
 };
 
 }  // namespace motion_planning

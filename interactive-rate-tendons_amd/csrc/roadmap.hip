@@ -1205,6 +1205,16 @@ int tr_roadmap_get_validity(tr_roadmap *r, uint8_t *vertex_status, uint8_t *edge
   return TR_OK;
 }
 
+int tr_roadmap_set_validity(tr_roadmap *r, const uint8_t *vertex_status, const uint8_t *edge_status) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  for (int64_t i = 0; vertex_status && i < r->V; i++) if (vertex_status[i] > V_INVALID) return rfail(r, TR_ERR_INVALID_ARG, "vertex status must be 0, 1 or 2");
+  for (int64_t i = 0; edge_status && i < r->E; i++) if (edge_status[i] > V_INVALID) return rfail(r, TR_ERR_INVALID_ARG, "edge status must be 0, 1 or 2");
+  if (vertex_status) std::memcpy(r->vstat.data(), vertex_status, r->vstat.size());
+  if (edge_status) std::memcpy(r->estat.data(), edge_status, r->estat.size());
+  return TR_OK;
+}
+
 int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals, int64_t n_queries, int32_t n_threads,
                      int32_t *status, double *cost, int64_t *path_offsets, tr_roadmap_stats *stats) {
   if (!r) return TR_ERR_INVALID_ARG;

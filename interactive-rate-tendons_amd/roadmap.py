@@ -55,7 +55,7 @@ class RoadmapBuilder:
 
     def _sample_valid_vertices_batches(self, N, box, batch):
         states, tips, pos = [], [], 0
-        have, limit = 0, 64 * N + (1 << 20)
+        have, tried, limit = 0, 0, 64 * N + (1 << 20)
         while have < N and pos < limit:
             m = min(batch, limit - pos)
             cand = D.candidate_states(self.robot, self.seed, pos, m, box=box)
@@ -452,6 +452,18 @@ class VoxelCachedLazyPRM:
         v, e = np.zeros(len(self.states), dtype=np.uint8), np.zeros(len(self.edges), dtype=np.uint8)
         self._check(self.lib.tr_roadmap_get_validity(self._rm, v.ctypes.data_as(C.POINTER(C.c_uint8)), e.ctypes.data_as(C.POINTER(C.c_uint8))))
         return v, e
+
+    def set_validity(self, vertex_status=None, edge_status=None):
+        """What a builder already knows (tr_roadmap_set_validity): createRoadmap with ValidateVertices / ValidateEdges leaves its
+        items VALIDITY_TRUE (motion-planning/VoxelCachedLazyPRM.cpp:1476, :2621-2631).  None = leave as it is."""
+        C = self._C
+        u8 = C.POINTER(C.c_uint8)
+        v = None if vertex_status is None else np.ascontiguousarray(vertex_status, dtype=np.uint8)
+        e = None if edge_status is None else np.ascontiguousarray(edge_status, dtype=np.uint8)
+        if (v is not None and len(v) != len(self.states)) or (e is not None and len(e) != len(self.edges)):
+            raise self._L.InvalidArgument("status arrays do not match the roadmap")
+        self._check(self.lib.tr_roadmap_set_validity(self._rm, v.ctypes.data_as(u8) if v is not None else None,
+                                                     e.ctypes.data_as(u8) if e is not None else None))
 
     def solveWithRoadmap(self, starts, goals, n_threads=0):
         """Batch of queries -> dict(status, cost, paths): paths[q] = vertex indices start ... goal (empty unless solved)."""
