@@ -431,8 +431,8 @@ int tr_roadmap_get_validity(tr_roadmap *rm, uint8_t *vertex_status /*[n_vertices
  * createRoadmap with ValidateVertices / ValidateEdges leaves the items it accepted VALIDITY_TRUE
  * (vertexValidityProperty_ :1476, computeEdgeValidity :2621-2631), so the first query on such a roadmap tests nothing again. */
 int tr_roadmap_set_validity(tr_roadmap *rm, const uint8_t *vertex_status /*[n_vertices]*/, const uint8_t *edge_status /*[n_edges]*/);
-/* The batched query loop (lazy: only the items on candidate paths are tested, round by round -- until so many queries keep coming
- * back for another round while testing every cached set at once is cheaper than that round, see TENDON_HIP_LAZY_ONLY).  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
+/* The batched query loop (lazy: only the items on candidate paths are tested, round by round -- until so many queries are still
+ * open after a round that testing every cached set at once is cheaper than another round, see TENDON_HIP_LAZY_ONLY).  status[q] = TR_QUERY_*; cost[q] (optional) = path cost; path_offsets[n_queries + 1]:
  * query q's path (start ... goal) is entries path_offsets[q] .. path_offsets[q+1]-1 of the array
  * tr_roadmap_fetch_paths copies out.  n_threads = host threads for the A* searches (0 = the process's CPU share).
  * Validity discovered by a call is kept for the next one (as the reference's graph keeps it between queries). */
@@ -446,7 +446,8 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
  * longest), out[3] times a search's open list moved entries between its LDS part and its HBM part, out[4] vertex expansions
  * by the kernel (those of searches it handed back included), out[5] vertex expansions by the host threads, out[6] queries answered
  * "no path" without a search because their end points lie in different components of the roadmap minus the items known invalid
- * (the reference's solutionComponent test, :2015-2044; labels recomputed on the device per round, see TENDON_HIP_COMPONENTS), out[7] 0. */
+ * (the reference's solutionComponent test, :2015-2044; labels recomputed on the device per round, see TENDON_HIP_COMPONENTS), out[7] times
+ * a search on the device outgrew its table of per-vertex records and moved into a larger one from the shared pool. */
 int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[8]);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
@@ -573,10 +574,17 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default: starts at
  *                                   10000 and doubles per roadmap while more than 1 in 200 searches come back; 0 none)
  *   TENDON_HIP_SEARCH_K=1..6        vertices the kernel takes off a search's open list per step (default 6; 1 = the host's order)
- *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds, within 12 GiB of records)
- *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when queries are still open
- *                                   after a round and one launch over every cached set is estimated at less than half of what the
- *                                   round's searches took, everything is tested and the next round is the last; same answers)
+ *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds: 16 waves per CU)
+ *   TENDON_HIP_SEARCH_LC0=8..14     log2 of the per-vertex records a search in flight owns (default 12: 176 KiB per slot with its far list;
+ *                                   the searches' state does not depend on the roadmap's size); TENDON_HIP_SEARCH_POOL=a,b,c: shared tables of
+ *                                   4 / 16 / 64 times that size for the searches that outgrow it (default slots / 2, slots / 16, 8; a search
+ *                                   that finds none free is handed back to the host threads).  Both read when a roadmap's first large
+ *                                   round sets the searches up (tests reach the growth and hand-back paths with small values)
+ *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when at least
+ *                                   max(4, cached sets / 2^17) queries are still open after a round, every cached set is tested in one
+ *                                   launch and the next round is the last; same answers; the rule reads counts, not clocks, so
+ *                                   rounds / items_checked / the validity left behind are reproducible; `expanded` depends on which
+ *                                   side -- kernel or host threads -- ran a search)
  *   TENDON_HIP_COMPONENTS=0|1       component labels of the roadmap minus the invalid items (queries across components are answered "no
  *                                   path" without a search): unset = from the moment they would have paid on this roadmap (a search
  *                                   walked 2000 vertices in vain, or the kernel handed searches back), 1 = every round of 64 queries

@@ -227,20 +227,22 @@ struct tr_roadmap {
     int state = 0;                       // 0: not set up yet, 1: ready, -1: not available for this roadmap (reason in `why`)
     std::string why;
     int64_t slots = 0, nq_cap = 0;
-    int32_t far_cap = 0;
+    int32_t lc0 = 12;                    // log2 of the records of a slot's own table
+    int32_t pool_n[trk::SR_CLASSES] = {0, 0, 0, 0}, pool_word[trk::SR_CLASSES] = {0, 0, 0, 0};
+    size_t ctl_bytes = 0, table_bytes = 0;
     uint32_t pbuf_cap = 0;
     uint64_t gens_issued = 0;
     bool lm_current = false;
-    char *arena = nullptr;               // adjacency | states | landmark table | validity bytes | per-slot arrays
-    trk::SNode *nodes = nullptr;
+    char *arena = nullptr;               // adjacency rows | states | landmark table | validity bytes | control words + pool bitmaps
+    char *tables = nullptr;              // the slots' tables, then the pool's, class by class
+    char *pool[trk::SR_CLASSES] = {nullptr, nullptr, nullptr, nullptr};
     char *qarena = nullptr;              // per-round arrays (queries, results, packed paths)
-    int64_t *d_adj_off = nullptr; trk::SArc *d_adj = nullptr; double *d_states = nullptr; float *d_lm = nullptr;
+    trk::SArc *d_rows = nullptr; double *d_states = nullptr; float *d_lm = nullptr;
     uint8_t *d_vstat = nullptr, *d_estat = nullptr;
-    uint32_t *d_gens = nullptr, *d_ctl = nullptr;
-    double *d_far_f = nullptr; int32_t *d_far_v = nullptr, *d_stage = nullptr;
+    uint32_t *d_ctl = nullptr;
     int32_t *d_qs = nullptr, *d_qg = nullptr, *d_poff = nullptr, *d_plen = nullptr, *d_pbuf = nullptr;
     uint8_t *d_found = nullptr;
-    int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0, st_expanded = 0;   // of the last tr_roadmap_solve
+    int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0, st_expanded = 0, st_grows = 0, st_max_records = 0;   // of the last tr_roadmap_solve
     int64_t in_flight = 0;               // queries of the launch that has not been collected yet
     bool budget_from_env = false;
     double share = -1.0;                 // the host threads' share of a shared round (< 0: not chosen yet); follows the two sides' times
@@ -593,7 +595,7 @@ void free_comp(tr_roadmap *r) {
 void free_search(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.arena) dev_cache().release(d.arena);
-  if (d.nodes) dev_cache().release(d.nodes);
+  if (d.tables) dev_cache().release(d.tables);
   if (d.qarena) dev_cache().release(d.qarena);
   d = tr_roadmap::DevSearch{};
 }
@@ -706,7 +708,7 @@ bool component_labels(tr_roadmap *r) {
 }
 
 // ---- the graph searches on the device (search_kernel.hpp) ----
-static_assert(sizeof(trk::SArc) == sizeof(Arc) && sizeof(trk::SNode) == sizeof(Node), "the device records are the host's");
+static_assert(sizeof(trk::SArc) == sizeof(Arc) && sizeof(trk::SRec) == 32, "the device's arcs are the host's; two records to a 64-byte line");
 
 // 0 = the host threads, 1 = the device for rounds of at least kSearchMinQueries queries, 2 = the device always (tests)
 constexpr int64_t kSearchMinQueries = 512;
@@ -748,8 +750,17 @@ int search_kbest() {
   return std::max(1, std::min(k, (int)trk::SR_K));
 }
 
-// The resident part: adjacency, states, landmark table, validity bytes, and per wave slot a node array (V records), a far list, a
-// path staging area.  The slot count is what the chip holds of this kernel (LDS: 12.4 KiB per wave), cut to a memory budget.
+// The kernel for the roadmap's state size (the heuristic keeps SX coordinates in registers)
+using SearchKernel = void (*)(trk::SearchArgs);
+SearchKernel search_kernel_for(int S) { return S <= 4 ? trk::roadmap_astar<4> : S <= 8 ? trk::roadmap_astar<8> : trk::roadmap_astar<trk::SR_MAXS>; }
+
+// The resident part: adjacency rows, states, landmark table, validity bytes -- what depends on the roadmap -- and the searches' own state,
+// which does not: per wave slot a table of 2^lc0 records with its far list (44 B per record: 176 KiB at lc0 = 12), and a pool of larger
+// tables (x 4 per class) that long searches move into.  The slot count is what the chip holds of this kernel (LDS: 9.8 KiB per wave).
+//   TENDON_HIP_SEARCH_SLOTS=n     searches in flight (default: what the device holds)
+//   TENDON_HIP_SEARCH_LC0=8..14   log2 of a slot's own table (default 12; tests: a small value makes every search grow)
+//   TENDON_HIP_SEARCH_POOL=a,b,c  tables of the three larger classes (default slots / 2, slots / 16, 8; 0,0,0: every search that outgrows
+//                                 its table is handed back to the host threads)
 bool search_setup(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.state != 0) return d.state > 0;
@@ -771,58 +782,101 @@ bool search_setup(tr_roadmap *r) {
     }
   }
   laps.lap("parallel-edge check");
+  // adjacency at a fixed stride: row v holds v's arcs (at most SR_D; unused slots marked); a vertex with more keeps SR_D - 1 in a
+  // row whose last slot names its next row (rows V, V + 1, ... in vertex order)
+  constexpr int D = trk::SR_D;
+  int64_t n_rows = V;
+  for (int64_t v = 0; v < V; v++) {
+    int64_t deg = r->adj_off[(size_t)v + 1] - r->adj_off[(size_t)v];
+    while (deg > D) { deg -= D - 1; n_rows++; }
+  }
+  if (n_rows > std::numeric_limits<int32_t>::max() / D) { d.why = "roadmap too large for the row index"; return false; }
+  RawArray<trk::SArc> rows;
+  rows.resize_uninit((size_t)n_rows * D);
+  {
+    int64_t next_row = V;
+    for (int64_t v = 0; v < V; v++) {
+      const Arc *arc = r->adj.data() + r->adj_off[(size_t)v];
+      int64_t deg = r->adj_off[(size_t)v + 1] - r->adj_off[(size_t)v], row = v;
+      for (;;) {
+        trk::SArc *out = rows.data() + (size_t)row * D;
+        const int take = deg > D ? D - 1 : (int)deg;
+        for (int j = 0; j < take; j++) out[j] = trk::SArc{arc[j].v, arc[j].e, arc[j].w};
+        for (int j = take; j < D; j++) out[j] = trk::SArc{trk::SR_ARC_NONE, -1, 0.0};
+        arc += take; deg -= take;
+        if (deg == 0) break;
+        out[D - 1] = trk::SArc{trk::SR_ARC_MORE, (int32_t)next_row, 0.0};
+        row = next_row++;
+      }
+    }
+  }
+  laps.lap("adjacency rows");
   const int dev = tr_device(r->ctx);
   if (hipSetDevice(dev) != hipSuccess) { d.why = "hipSetDevice"; return false; }
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { d.why = "hipGetDeviceProperties"; return false; }
   int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, trk::roadmap_astar, 64, trk::search_lds_bytes()) != hipSuccess || per_cu < 1) {
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, search_kernel_for(r->S), 64, trk::search_lds_bytes()) != hipSuccess || per_cu < 1) {
     d.why = "occupancy query"; return false;
   }
   int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
   if (const char *e = std::getenv("TENDON_HIP_SEARCH_SLOTS")) slots = std::max<int64_t>(1, std::min<int64_t>(slots, std::atoll(e)));
-  int64_t budget = (int64_t)12 << 30;                            // node records: 32 B x V per slot; at most half of what is free
-  {
-    size_t free_b = 0, total_b = 0;
-    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<int64_t>(budget, (int64_t)(free_b / 2));
+  d.lc0 = 12;
+  if (const char *e = std::getenv("TENDON_HIP_SEARCH_LC0")) d.lc0 = std::max(8, std::min(14, std::atoi(e)));
+  int64_t pn[trk::SR_CLASSES] = {0, std::max<int64_t>(64, slots / 2), std::max<int64_t>(16, slots / 16), 8};
+  if (const char *e = std::getenv("TENDON_HIP_SEARCH_POOL")) {
+    long long x1 = 0, x2 = 0, x3 = 0;
+    if (std::sscanf(e, "%lld,%lld,%lld", &x1, &x2, &x3) >= 1) { pn[1] = std::max(0ll, x1); pn[2] = std::max(0ll, x2); pn[3] = std::max(0ll, x3); }
   }
-  slots = std::min<int64_t>(slots, budget / (32 * V));
-  if (slots < 64) { d.why = "roadmap too large for resident node arrays"; return false; }
+  // the searches' state within a third of what is free: the pool shrinks first, then the slots
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { d.why = "hipMemGetInfo"; return false; }
+  auto tables_bytes = [&](int64_t s_) {
+    size_t b = (size_t)s_ * trk::search_chunk_bytes(d.lc0);
+    for (int c = 1; c < trk::SR_CLASSES; c++) b += (size_t)pn[c] * trk::search_chunk_bytes(d.lc0 + 2 * c);
+    return b;
+  };
+  for (int c = trk::SR_CLASSES - 1; c >= 1; c--)
+    while (pn[c] > 0 && tables_bytes(slots) > free_b / 3) pn[c] /= 2;
+  while (slots > 64 && tables_bytes(slots) > free_b / 3) slots /= 2;
+  if (tables_bytes(slots) > free_b / 3) { d.why = "out of device memory"; return false; }
   d.slots = slots;
-  d.far_cap = (int32_t)std::min<int64_t>(std::max<int64_t>(4096, (int64_t)r->adj.size()), 32768);
+  int word = trk::SR_CTL_WORDS;
+  for (int c = 0; c < trk::SR_CLASSES; c++) { d.pool_n[c] = (int32_t)pn[c]; d.pool_word[c] = word; word += (int)((pn[c] + 31) / 32); }
+  d.ctl_bytes = ((size_t)word * 4 + 255) & ~(size_t)255;
+  d.table_bytes = tables_bytes(slots);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int Lmax = trk::SR_MAXL;
-  const size_t b_off = up((size_t)(V + 1) * 8), b_adj = up(r->adj.size() * sizeof(Arc)), b_st = up((size_t)V * r->S * 8),
-               b_lm = up((size_t)V * Lmax * 4),
-               b_vs = up((size_t)V), b_es = up((size_t)std::max<int64_t>(r->E, 1)), b_gen = up((size_t)slots * 4), b_ctl = 256,
-               b_ff = up((size_t)slots * d.far_cap * 8), b_fv = up((size_t)slots * d.far_cap * 4),
-               b_stage = up((size_t)slots * 2 * trk::SR_PATH_MAX * 4);
-  if (dev_cache().alloc(dev, (void **)&d.arena, b_off + b_adj + b_st + b_lm + b_vs + b_es + b_gen + b_ctl + b_ff + b_fv + b_stage) != hipSuccess) {
+  const size_t b_rows = up((size_t)n_rows * D * sizeof(trk::SArc)), b_st = up((size_t)V * r->S * 8), b_lm = up((size_t)V * Lmax * 4),
+               b_vs = up((size_t)V), b_es = up((size_t)std::max<int64_t>(r->E, 1));
+  if (dev_cache().alloc(dev, (void **)&d.arena, b_rows + b_st + b_lm + b_vs + b_es + d.ctl_bytes) != hipSuccess) {
     d.why = "out of device memory"; return false;
   }
   char *p = d.arena;
-  d.d_adj_off = (int64_t *)p; p += b_off;
-  d.d_adj = (trk::SArc *)p; p += b_adj;
+  d.d_rows = (trk::SArc *)p; p += b_rows;
   d.d_states = (double *)p; p += b_st;
   d.d_lm = (float *)p; p += b_lm;
   d.d_vstat = (uint8_t *)p; p += b_vs;
   d.d_estat = (uint8_t *)p; p += b_es;
-  d.d_gens = (uint32_t *)p; p += b_gen;
-  d.d_ctl = (uint32_t *)p; p += b_ctl;
-  d.d_far_f = (double *)p; p += b_ff;
-  d.d_far_v = (int32_t *)p; p += b_fv;
-  d.d_stage = (int32_t *)p;
+  d.d_ctl = (uint32_t *)p;
   laps.lap("device properties + arena");
-  bool ok = dev_cache().alloc(dev, (void **)&d.nodes, (size_t)slots * V * sizeof(Node)) == hipSuccess;
-  laps.lap("node records allocated");
-  ok = ok && hipMemsetAsync(d.nodes, 0, (size_t)slots * V * sizeof(Node), nullptr) == hipSuccess &&
-       hipMemsetAsync(d.d_gens, 0, b_gen, nullptr) == hipSuccess &&
-       hipMemcpyAsync(d.d_adj_off, r->adj_off.data(), (size_t)(V + 1) * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
-       hipMemcpyAsync(d.d_adj, r->adj.data(), r->adj.size() * sizeof(Arc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+  bool ok = dev_cache().alloc(dev, (void **)&d.tables, d.table_bytes) == hipSuccess;
+  if (ok) {
+    char *q = d.tables + (size_t)slots * trk::search_chunk_bytes(d.lc0);
+    for (int c = 1; c < trk::SR_CLASSES; c++) { d.pool[c] = q; q += (size_t)pn[c] * trk::search_chunk_bytes(d.lc0 + 2 * c); }
+  }
+  laps.lap("tables allocated");
+  // (generation 0 is nobody's: cleared once, never again until the generation counter would wrap)
+  ok = ok && hipMemsetAsync(d.tables, 0, d.table_bytes, nullptr) == hipSuccess &&
+       hipMemcpyAsync(d.d_rows, rows.data(), (size_t)n_rows * D * sizeof(trk::SArc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_states, r->states.data(), (size_t)V * r->S * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipStreamSynchronize(nullptr) == hipSuccess;
-  laps.lap("records cleared + graph uploaded");
+  laps.lap("tables cleared + graph uploaded");
   if (!ok) { free_search(r); r->ds.state = -1; r->ds.why = "out of device memory"; return false; }
+  if (std::getenv("TENDON_HIP_SEARCH_STATS"))
+    std::fprintf(stderr, "[tendon_hip] search state: %lld slots x %zu KiB + pool %d / %d / %d tables = %.1f MiB (whatever the roadmap's size); roadmap: %lld rows of %d arcs (%lld continued), %.1f MiB\n",
+                 (long long)slots, trk::search_chunk_bytes(d.lc0) >> 10, d.pool_n[1], d.pool_n[2], d.pool_n[3], (double)d.table_bytes / 1048576.0,
+                 (long long)n_rows, D, (long long)(n_rows - V), (double)(b_rows + b_st + b_lm + b_vs + b_es) / 1048576.0);
   d.lm_current = false;
   d.state = 1;
   return true;
@@ -859,11 +913,11 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
     d.d_found = (uint8_t *)p; p += up((size_t)d.nq_cap);
     d.d_pbuf = (int32_t *)p;
   }
-  if (d.gens_issued + (uint64_t)nq >= ((uint64_t)1 << 32) - 1) {     // (a slot's generation stamp may not wrap)
-    if (hipMemsetAsync(d.nodes, 0, (size_t)d.slots * V * sizeof(Node), nullptr) != hipSuccess ||
-        hipMemsetAsync(d.d_gens, 0, (size_t)d.slots * 4, nullptr) != hipSuccess) return false;
+  if (d.gens_issued + (uint64_t)nq >= ((uint64_t)1 << 31) - 2) {     // (a generation may not come round again while its records could be met)
+    if (hipMemsetAsync(d.tables, 0, d.table_bytes, nullptr) != hipSuccess) return false;
     d.gens_issued = 0;
   }
+  const uint32_t gen_base = (uint32_t)d.gens_issued;
   d.gens_issued += (uint64_t)nq;
   std::vector<int32_t> &qs = d.h_qs, &qg = d.h_qg;                  // (members: the copies below may still be reading them when this returns)
   qs.resize((size_t)nq); qg.resize((size_t)nq);
@@ -886,22 +940,22 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
        (r->E == 0 || hipMemcpyAsync(d.d_estat, r->estat.data(), (size_t)r->E, hipMemcpyHostToDevice, nullptr) == hipSuccess))) &&
        hipMemcpyAsync(d.d_qs, qs.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_qg, qg.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
-       hipMemsetAsync(d.d_ctl, 0, 256, nullptr) == hipSuccess;
+       hipMemsetAsync(d.d_ctl, 0, d.ctl_bytes, nullptr) == hipSuccess;
   if (!ok) return false;
   trk::SearchArgs a{};
-  a.adj_off = d.d_adj_off; a.adj = d.d_adj; a.states = d.d_states; a.lm = L ? d.d_lm : nullptr;
+  a.rows = d.d_rows; a.states = d.d_states; a.lm = L ? d.d_lm : nullptr;
   a.S = r->S; a.NT = r->NT; a.rot = r->rot; a.ret = r->ret; a.L = L;
   a.w_rot = r->w_rot; a.w_ret = r->w_ret; a.lm_slack = kLmSlack;
-  a.vstat = shared_status ? r->dc.d_vstat : d.d_vstat; a.estat = shared_status ? r->dc.d_estat : d.d_estat; a.V = V; a.E = r->E; a.n_arcs = (int64_t)r->adj.size();
+  a.vstat = shared_status ? r->dc.d_vstat : d.d_vstat; a.estat = shared_status ? r->dc.d_estat : d.d_estat; a.V = V; a.E = r->E;
   a.qs = d.d_qs; a.qg = d.d_qg; a.nq = nq;
   a.next = d.d_ctl; a.pbuf_used = d.d_ctl + 1; a.expanded = (unsigned long long *)(d.d_ctl + 2);
-  a.nodes = d.nodes; a.gens = d.d_gens;
-  a.far_f = d.d_far_f; a.far_v = d.d_far_v; a.far_cap = d.far_cap; a.stage = d.d_stage;
+  a.base = d.tables; a.lc0 = d.lc0; a.gen_base = gen_base;
+  for (int c = 0; c < trk::SR_CLASSES; c++) { a.pool[c] = d.pool[c]; a.pool_n[c] = d.pool_n[c]; a.pool_word[c] = d.pool_word[c]; }
   a.found = d.d_found; a.poff = d.d_poff; a.plen = d.d_plen; a.pbuf = d.d_pbuf; a.pbuf_cap = d.pbuf_cap;
   a.max_pops = budget > 0 ? budget : 16 * V + 1024;             // (uncapped: every vertex reopened a few times, far beyond what a search does)
   a.kbest = search_kbest();
   const unsigned grid = (unsigned)std::min<int64_t>(d.slots, nq);
-  hipLaunchKernelGGL(trk::roadmap_astar, dim3(grid), dim3(64), trk::search_lds_bytes(), nullptr, a);
+  hipLaunchKernelGGL(search_kernel_for(r->S), dim3(grid), dim3(64), trk::search_lds_bytes(), nullptr, a);
   if (hipGetLastError() != hipSuccess) return false;
   d.in_flight = nq;
   return true;
@@ -960,6 +1014,7 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
   });
   for (const auto &p : part) redo.insert(redo.end(), p.begin(), p.end());
   d.st_queries += nq - (int64_t)redo.size(); d.st_fallbacks += (int64_t)redo.size(); d.st_moves += (int64_t)ctl[4];
+  d.st_grows += (int64_t)ctl[5]; d.st_max_records = std::max<int64_t>(d.st_max_records, (int64_t)ctl[6]);
 }
 
 // validity of the listed combined items (vertex v -> v, edge e -> V + e) against the current obstacle grid: one K4 launch
@@ -1222,7 +1277,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   if (n_queries < 0 || (n_queries > 0 && (!starts || !goals || !status || !path_offsets))) return rfail(r, TR_ERR_INVALID_ARG, "bad argument");
   r->path_off.assign((size_t)n_queries + 1, 0); r->path_v.clear();
   r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
-  r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = r->ds.st_expanded = 0;
+  r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = r->ds.st_expanded = r->ds.st_grows = r->ds.st_max_records = 0;
   r->dc.st_cut = 0;
   if (path_offsets) path_offsets[0] = 0;
   if (n_queries == 0) { if (stats) *stats = tr_roadmap_stats{0, 0, 0, 0}; return TR_OK; }
@@ -1474,13 +1529,14 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     // The lazy loop exists to save validity tests; here a test of EVERY cached set is one K4 launch (0.25 ms at 6.8 x 10^5 sets),
     // while every further round costs at least its longest search (milliseconds on a core) -- and in a cluttered environment the
     // open queries find new candidate paths through untested items round after round, hundreds of rounds in the worst case.  So
-    // when queries are still open and testing everything is estimated at less than half of what the round's searches just took,
-    // everything is tested and the next round is the last.  Answers are those of the lazy loop (validity is a function of the
-    // environment); what changes is which items end up known.  TENDON_HIP_LAZY_ONLY=1 keeps the loop lazy to the end (the
-    // reference's behaviour item by item; A/B, tests).
-    const double search_ms = std::chrono::duration<double, std::milli>(t_items0 - t_round).count();
-    const double all_ms = 0.1 + 3.6e-7 * (double)(r->V + r->E);
-    if (!went_eager && r->has_caches && !still.empty() && all_ms < 0.5 * search_ms && !std::getenv("TENDON_HIP_LAZY_ONLY")) {
+    // when enough queries are still open for another round to cost more than that launch, everything is tested and the next round
+    // is the last.  The rule is a function of the round's counts alone (open queries against the number of cached sets: one open
+    // query per 2^17 sets, four at least) -- not of clocks: rounds, items_checked and the validity a call leaves behind are the same
+    // run after run (tests/test_gpu_search.py).  Answers are those of the lazy loop (validity is a function of the environment);
+    // what changes is which items end up known.  TENDON_HIP_LAZY_ONLY=1 keeps the loop lazy to the end (the reference's
+    // behaviour item by item; A/B, tests).
+    const int64_t eager_from = std::max<int64_t>(4, (r->V + r->E) >> 17);
+    if (!went_eager && r->has_caches && (int64_t)still.size() >= eager_from && !std::getenv("TENDON_HIP_LAZY_ONLY")) {
       int64_t unknown = 0;
       for (uint8_t x : r->vstat) unknown += x == V_UNKNOWN;
       for (uint8_t x : r->estat) unknown += x == V_UNKNOWN;
@@ -1509,7 +1565,7 @@ int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[8]) {
   std::lock_guard<std::mutex> lock_(r->mu);
   out[0] = r->ds.st_queries; out[1] = r->ds.st_fallbacks; out[2] = r->ds.st_host_share; out[3] = r->ds.st_moves;
   out[4] = r->ds.st_expanded; out[5] = r->st_expanded - r->ds.st_expanded;
-  out[6] = r->dc.st_cut; out[7] = 0;
+  out[6] = r->dc.st_cut; out[7] = r->ds.st_grows;
   return TR_OK;
 }
 

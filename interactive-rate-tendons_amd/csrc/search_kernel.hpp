@@ -3,55 +3,79 @@
 // QUERY, thousands of queries in flight.  It is roadmap.hip's host `astar` -- the same heuristic (state-space distance, sharpened by the
 // landmark bounds), the same relaxation rule (a vertex whose cost improves is opened again), the same stopping rule (the goal leaves
 // the open list as its minimum) -- shaped for a wave:
-//   * a step takes up to `kbest` vertices off the open list at once (the minimum, and the smallest of the other lanes' minima) and
-//     relaxes all their arcs together, ~12 per vertex, one lane each: the step is a chain of three dependent memory round trips
-//     (record + adjacency offsets -> arcs -> validity bytes, neighbour's record, state and landmark rows, all requested at once)
-//     whatever the number of lanes busy, so six vertices cost little more than one (their ~70 arcs: one pass of the wave, sometimes two).  Expanding a vertex that is not the minimum is
-//     what any best-first search with re-opening may do: the stopping rule alone makes the returned cost optimal, and with it
-//     the path (the optimum is unique unless two paths' fp64 cost sums agree in every bit).  kbest = 1 is the host's order of
-//     expansions exactly (same count).
+//   * a step takes up to SR_K = 4 vertices off the open list at once (the minimum, and the smallest of the other lanes' minima); each
+//     gets a group of SR_D = 16 lanes, one per slot of its ADJACENCY ROW: arcs live at a fixed stride of 16 per vertex (unused slots
+//     marked; a vertex with more arcs chains further rows through its last slot, 1 - 3 % of a k-nearest roadmap's vertices), so the
+//     arcs' address follows from the vertex alone and their load leaves together with the vertex's own record.  A step is then a chain
+//     of TWO dependent memory round trips -- record + arcs of the popped vertices; per arc the validity bytes, the neighbour's record
+//     and the rows of its heuristic, all requested at once -- whatever the number of lanes busy (round 4: three, through CSR offsets).
+//     Expanding a vertex that is not the minimum is what any best-first search with re-opening may do: the stopping rule alone makes
+//     the returned cost optimal, and with it the path (the optimum is unique unless two paths' fp64 cost sums agree in every bit).
+//     One vertex per step (kbest = 1) is the host's order of expansions exactly (same count).
 //   * two lanes of a step may reach the same neighbour from different parents; the better one must win, whole: the lanes agree through
 //     three small LDS tables (owner by hash of the vertex, smallest cost, lowest lane among equals) before anyone writes.
+//   * the search's per-vertex state (g, h, parent, closed) lives in a HASH TABLE sized to the search, not to the roadmap: 32-byte
+//     records {g, h, parent, parent edge, vertex, generation << 1 | closed}, two to a 64-byte line, linear probing from the vertex's
+//     line; a record of another generation is free, so nothing is ever cleared.  Every wave slot owns a table of 2^lc0 records (4 096:
+//     a search of ~1 000 expansions touches ~3 000 vertices); a search that fills three quarters of its table moves -- rehashing what it
+//     has -- into one four times the size claimed from a shared pool (bitmaps, one atomic), and returns it when it ends; no free table:
+//     the search is handed back to the host.  Two lanes wanting the same free record in one step settle it through an LDS word (the
+//     loser probes on): plain loads and stores only, as for the dense arrays this replaces (round 4: 32 B x V per slot, 9.8 GB at 10^5
+//     vertices; now ~0.2 MB per slot + the pool, whatever V is).
 //
 // The open list is what a GPU has no good answer for; here it is split by a threshold T on the key f = g + h:
 //   near  (LDS, SR_CAP entries): every entry with f < T, unsorted; every lane scans its share, a wave reduction finds the minimum;
-//   far   (global, per wave):    every entry with f >= T, unsorted, append-only between refills.
+//   far   (global, beside the table): every entry with f >= T, unsorted, append-only between refills.
 // near full -> T drops halfway towards near's minimum and the entries above it move to far; near empty -> T rises to a value that
 // lets about half a list's worth of far's entries in (found by counting) and they move to near.  Entries are never updated in place:
 // a vertex reached again with a better cost gets a new entry, the old one is skipped when it surfaces (its vertex is closed), as on
 // the host.
-// Every loop is bounded; a query that exceeds a bound (expansion budget, far list, path length, path buffer) is flagged SR_FALLBACK
-// and the host search answers it.
+// Every loop is bounded; a query that exceeds a bound (expansion budget, no larger table free, path length, path buffer) is flagged
+// SR_FALLBACK and the host search answers it.
+//
+// The query loop draws its ticket with an atomic EVERY lane executes (lane 0 adds one, the others zero): no `if (lane == 0)` stands
+// between the loop head and the cross-lane operations, so there is no lane-dependent branch for the optimiser to thread the back edge
+// through (hipcc 7.2 did that to round 4's `if (lane == 0) ticket = atomicAdd(..)`: the 63 other lanes got an inner copy of the loop
+// that lane 0 was not part of, and the kernel faulted; tests/test_kernel_resources.py checks the listing for a single ticket site).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace trk {
 
-struct SArc { int32_t v, e; double w; };                      // roadmap.hip: Arc
-struct SNode { double g, h; int32_t parent, parent_edge; uint32_t stamp, closed; };   // roadmap.hip: Node
-constexpr int SR_CAP = 896;                                   // near-list entries per wave (LDS)
+struct SArc { int32_t v, e; double w; };                      // roadmap.hip: Arc; v = SR_ARC_NONE: unused slot, SR_ARC_MORE: e = the next row
+struct SRec { double g, h; int32_t parent, parent_edge; uint32_t key, tag; };   // tag = generation << 1 | closed
+constexpr int SR_CAP = 640;                                   // near-list entries per wave (LDS)
 constexpr int SR_MAXS = 12, SR_MAXL = 64;                     // state coordinates, landmarks
-constexpr int SR_PATH_MAX = 4096;                             // vertices of a path (per-wave staging)
-constexpr int SR_K = 6;                                       // vertices expanded per step, at most
+constexpr int SR_K = 4;                                       // vertices expanded per step, at most
+constexpr int SR_D = 16;                                      // arcs per adjacency row = lanes per expanded vertex
 constexpr int SR_TAB = 128;                                   // slots of the conflict tables
+constexpr int SR_CLASSES = 4;                                 // table sizes: 2^lc0 records, then x 4 per class
+constexpr int SR_CTL_WORDS = 64;                              // control words ahead of the pool bitmaps
+constexpr int32_t SR_ARC_NONE = -1, SR_ARC_MORE = -2;
 enum : uint8_t { SR_NO_PATH = 0, SR_FOUND = 1, SR_FALLBACK = 2 };
 constexpr uint8_t SR_INVALID = 2;                             // roadmap.hip: V_INVALID
-// near keys | near vertices | goal state | goal landmark row | conflict tables (owner, cost, lane): 12 waves per CU
+// near keys | near vertices | goal state | goal landmark row | conflict tables (owner, cost, lane): 16 waves per CU
 __host__ __device__ inline size_t search_lds_bytes() { return (size_t)SR_CAP * 12 + SR_MAXS * 8 + SR_MAXL * 4 + (size_t)SR_TAB * 16; }
+// a table of C records with its far list beside it: records | far keys | far vertices
+__host__ __device__ inline size_t search_chunk_bytes(int lc) { return ((size_t)1 << lc) * 44; }
 
 struct SearchArgs {
-  const int64_t *adj_off; const SArc *adj;                    // CSR adjacency, both directions
+  const SArc *rows;                                           // [V + continuation rows][SR_D]
   const double *states; const float *lm;                      // [V][S]; [V][L rounded up to a multiple of 4] landmark distances or null
   int32_t S, NT, rot, ret, L;
   double w_rot, w_ret, lm_slack;
   const uint8_t *vstat, *estat;
-  int64_t V, E, n_arcs;
+  int64_t V, E;
   const int32_t *qs, *qg; int64_t nq;                         // the round's queries
-  uint32_t *next;                                             // control words: [0] query ticket, [1] path words used, [2..3] expansions, [4] list moves
-  SNode *nodes; uint32_t *gens;                               // [slots][V], [slots]
-  double *far_f; int32_t *far_v; int32_t far_cap;             // [slots][far_cap]
-  int32_t *stage;                                             // [slots][2 SR_PATH_MAX] path staging
+  uint32_t *next;                                             // control words: [0] query ticket, [1] path words used, [2..3] expansions, [4] list
+                                                              // moves, [5] table growths, [6] most records a search held, [16..] clocks;
+                                                              // from SR_CTL_WORDS on the pool bitmaps (bit set = table taken)
+  char *base;                                                 // [slots] tables of class 0
+  char *pool[SR_CLASSES];                                     // [pool_n[c]] tables of class c >= 1
+  int32_t pool_n[SR_CLASSES], pool_word[SR_CLASSES];          // tables per class; first bitmap word of the class (index into next)
+  int32_t lc0;                                                // log2 of the records of a class-0 table
+  uint32_t gen_base;                                          // query i of the launch searches under generation gen_base + i + 1 (< 2^31)
   uint8_t *found; int32_t *poff, *plen;                       // [nq]
   int32_t *pbuf; uint32_t pbuf_cap; uint32_t *pbuf_used;      // packed paths: vertices goal .. start, then their edges
   unsigned long long *expanded;
@@ -119,6 +143,7 @@ __device__ __forceinline__ int sr_wave_sum(int c) {
   return __builtin_amdgcn_readlane(c, 0) + __builtin_amdgcn_readlane(c, 16) + __builtin_amdgcn_readlane(c, 32) + __builtin_amdgcn_readlane(c, 48);
 }
 
+
 // -DTRK_SEARCH_CLOCKS: the 100 MHz clock read at the phase boundaries of a step, summed per phase into control words 16.. (profiling aid)
 #ifdef TRK_SEARCH_CLOCKS
 #define SR_CLK(i) do { const unsigned long long t_ = wall_clock64(); clk[i] += t_ - t_last; t_last = t_; } while (0)
@@ -126,7 +151,31 @@ __device__ __forceinline__ int sr_wave_sum(int c) {
 #define SR_CLK(i) do { } while (0)
 #endif
 
-__global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
+// a free table of class c from the shared pool (one lane): -1 when none is free
+__device__ inline int sr_pool_claim(const SearchArgs &a, int c) {
+  const int n = a.pool_n[c];
+  uint32_t *bits = a.next + a.pool_word[c];
+  for (int w = 0; w * 32 < n; w++) {
+    const int left = n - w * 32;
+    const uint32_t all = left >= 32 ? 0xffffffffu : ((1u << left) - 1u);
+    for (int tries = 0; tries < 32; tries++) {
+      const uint32_t cur = __hip_atomic_load(&bits[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const uint32_t fr = ~cur & all;
+      if (!fr) break;
+      const uint32_t bit = fr & (0u - fr);
+      if (!(atomicOr(&bits[w], bit) & bit)) return w * 32 + (__ffs((int)bit) - 1);
+    }
+  }
+  return -1;
+}
+// A pooled table passes between waves on different XCDs inside one launch.  What its next user reads of the previous one's records is
+// harmless whatever it sees (a record of another generation is free, stale or not); what must not happen is the previous user's dirty
+// lines leaving ITS XCD's L2 after the next user has written the same lines through another L2.  So the wave that returns a table
+// first writes its XCD's dirty lines back (agent-scope release: the caller's fence), and only then clears the bit.
+__device__ inline void sr_pool_release(const SearchArgs &a, int c, int idx) { atomicAnd(a.next + a.pool_word[c] + (idx >> 5), ~(1u << (idx & 31))); }
+
+// SX: the state coordinates the heuristic keeps in registers (4, 8 or SR_MAXS; S <= SX)
+template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
 #pragma clang fp contract(off)
   extern __shared__ double sr_lds[];
   double *nf = sr_lds;                                        // [SR_CAP]
@@ -136,15 +185,14 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
   unsigned long long *tab_key = (unsigned long long *)(glm + SR_MAXL);   // [SR_TAB] smallest cost offered to the slot's vertex
   uint32_t *tab_owner = (uint32_t *)(tab_key + SR_TAB);       // [SR_TAB] a lane that claimed the slot
   uint32_t *tab_low = tab_owner + SR_TAB;                     // [SR_TAB] lowest lane among those offering the smallest cost
-  const int lane_id = threadIdx.x;
+  const int lane = threadIdx.x;
+  const int grp = lane >> 4, sub = lane & (SR_D - 1);         // the expanded vertex this lane works for, its slot of the adjacency row
   const int64_t slot = blockIdx.x;
-  SNode *__restrict__ node = a.nodes + slot * a.V;
-  double *__restrict__ ff = a.far_f + slot * (int64_t)a.far_cap;
-  int32_t *__restrict__ fv = a.far_v + slot * (int64_t)a.far_cap;
-  int32_t *__restrict__ stage = a.stage + slot * (int64_t)(2 * SR_PATH_MAX);
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
   const int S = a.S, L = a.L;
   const int kbest = a.kbest < 1 ? 1 : (a.kbest > SR_K ? SR_K : a.kbest);
+  const unsigned long long below = ((unsigned long long)1 << lane) - 1;
+  const SArc no_arc = SArc{SR_ARC_NONE, -1, 0.0};
 
   // roadmap.hip: state_distance + the landmark bounds; every lane for its own vertex.  The loads -- the state row, then the landmark row
   // four float4 at a time (rows are padded to a multiple of four with zeros, which bound nothing) -- are all requested before the
@@ -154,16 +202,16 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
   const float slack = (float)a.lm_slack;
   auto heuristic = [&](int32_t v) -> double {
     const double *sv = a.states + (int64_t)v * S;
-    double x[SR_MAXS];
+    double x[SX];
 #pragma unroll
-    for (int i = 0; i < SR_MAXS; i++) x[i] = i < S ? sv[i] : 0.0;
+    for (int i = 0; i < SX; i++) x[i] = i < S ? sv[i] : 0.0;
     const float4 *lv = (const float4 *)(a.lm + (int64_t)v * (4 * L4));
     float4 y[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) y[j] = j < L4 ? lv[j] : float4{0.f, 0.f, 0.f, 0.f};
     double s = 0, t_rot = 0, t_ret = 0;
 #pragma unroll
-    for (int i = 0; i < SR_MAXS; i++) {
+    for (int i = 0; i < SX; i++) {
       if (i < S) {
         const double d = x[i] - gst[i];
         if (i < NT) s += d * d;
@@ -204,35 +252,114 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
   };
 
   for (;;) {
-    int lane = sr_opaque(lane_id);
-    const unsigned long long below = ((unsigned long long)1 << lane) - 1;
-    uint32_t qi = 0, gen = 0;
-    if (lane == 0) { qi = atomicAdd(a.next, 1u); }
-    qi = (uint32_t)__builtin_amdgcn_readfirstlane((int)qi);
+    // the ticket: one atomic that every lane executes (see the header)
+    uint32_t qi = atomicAdd(a.next, lane == 0 ? 1u : 0u);
+    qi = (uint32_t)__builtin_amdgcn_readlane((int)qi, 0);
     if ((int64_t)qi >= a.nq) break;
-    if (lane == 0) { gen = a.gens[slot] + 1u; a.gens[slot] = gen; }
-    gen = (uint32_t)__builtin_amdgcn_readfirstlane((int)gen);
+    const uint32_t gen = a.gen_base + qi + 1u;
     const int32_t start = a.qs[qi], goal = a.qg[qi];
     __syncthreads();
     if (lane < S) gst[lane] = a.states[(int64_t)goal * S + lane];
     if (lane < 4 * L4) glm[lane] = a.lm[(int64_t)goal * (4 * L4) + lane];
     __syncthreads();
 
-    int n_near = 0, n_far = 0;
+    // ---- the search's table: class, index in the class, records, far list; all wave-uniform ----
+    int cls = 0, chunk = (int)slot, lc = a.lc0;
+    char *cb = a.base + slot * (int64_t)search_chunk_bytes(lc);
+    SRec *tb = (SRec *)cb;
+    double *ff = (double *)(cb + ((size_t)32 << lc));
+    int32_t *fv = (int32_t *)(cb + ((size_t)40 << lc));
+    int count = 0, n_near = 0, n_far = 0;
+    unsigned grows = 0;
+
+    // v's record: linear probing from the first record of v's line; a record of another generation ends the probe (free).
+    // found: rec / p are the record and its index; not found: p is the free record the probe stopped at.
+    auto lookup = [&](int32_t v, bool on, SRec &rec, uint32_t &p) -> bool {
+      const uint32_t m = (1u << lc) - 1u;
+      p = (((uint32_t)v * 2654435761u) >> (33 - lc)) << 1;
+      bool hit = false;
+      if (on) {
+        for (uint32_t t = 0; t <= m; t += 2) {
+          const SRec r0 = tb[p], r1 = tb[p + 1];
+          if ((r0.tag >> 1) != gen) break;
+          if (r0.key == (uint32_t)v) { rec = r0; hit = true; break; }
+          if ((r1.tag >> 1) != gen) { p = p + 1; break; }
+          if (r1.key == (uint32_t)v) { rec = r1; p = p + 1; hit = true; break; }
+          p = (p + 2) & m;
+        }
+      }
+      return hit;
+    };
+    // a free record of table `t` (2^tlc records) for vertex v, on its probe path from p on: lanes that want the same record in the
+    // same call settle it through an LDS word (last writer wins; the others probe on).  Wave-uniform call; the winner marks the
+    // record taken (key, generation) at once, the caller fills in the rest.
+    auto claim = [&](SRec *t, int tlc, bool want, int32_t v, uint32_t p) -> uint32_t {
+      const uint32_t m = (1u << tlc) - 1u;
+      bool pending = want;
+      for (int round = 0; round < 1024; round++) {
+        if (!__ballot(pending)) break;
+        if (pending) {
+          for (uint32_t k = 0; k <= m; k++) { if ((t[p].tag >> 1) != gen) break; p = (p + 1) & m; }
+          tab_owner[p & (SR_TAB - 1)] = (uint32_t)lane;
+        }
+        __syncthreads();
+        const bool won = pending && tab_owner[p & (SR_TAB - 1)] == (uint32_t)lane;
+        if (won) { t[p].key = (uint32_t)v; t[p].tag = gen << 1; pending = false; }
+        __syncthreads();
+      }
+      return p;
+    };
+    // into a table four times the size (or the next size that has one free): what the search has is rehashed, the far list copied,
+    // the old table returned to the pool.  false: no table free (the search is handed back).
+    auto grow = [&]() -> bool {
+      int nc = cls, idx = -1;
+      while (idx < 0 && nc + 1 < SR_CLASSES) {
+        nc++;
+        if (lane == 0) idx = sr_pool_claim(a, nc);
+        idx = __builtin_amdgcn_readfirstlane(idx);
+      }
+      if (idx < 0) return false;
+      const int nlc = a.lc0 + 2 * nc;
+      char *nb = a.pool[nc] + (int64_t)idx * (int64_t)search_chunk_bytes(nlc);
+      SRec *nt = (SRec *)nb;
+      double *nff = (double *)(nb + ((size_t)32 << nlc));
+      int32_t *nfv = (int32_t *)(nb + ((size_t)40 << nlc));
+      for (int i0 = 0; i0 < (1 << lc); i0 += 64) {
+        const SRec rc = tb[i0 + lane];
+        const bool mine = (rc.tag >> 1) == gen;
+        const uint32_t p0 = (((uint32_t)rc.key * 2654435761u) >> (33 - nlc)) << 1;
+        const uint32_t p = claim(nt, nlc, mine, (int32_t)rc.key, p0);
+        if (mine) { nt[p].g = rc.g; nt[p].h = rc.h; nt[p].parent = rc.parent; nt[p].parent_edge = rc.parent_edge; nt[p].tag = rc.tag; }
+      }
+      for (int i = lane; i < n_far; i += 64) { nff[i] = ff[i]; nfv[i] = fv[i]; }
+      __syncthreads();
+      if (cls > 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // (see sr_pool_release)
+        if (lane == 0) sr_pool_release(a, cls, chunk);
+      }
+      cls = nc; chunk = idx; lc = nlc; tb = nt; ff = nff; fv = nfv;
+      grows++;
+      return true;
+    };
+
     double T = inf;
     int result = SR_NO_PATH;
     unsigned long long exp_q = 0;
     unsigned moves = 0;                                         // times the threshold moved (near full / near empty)
     const double h0 = sr_u(heuristic(start));
     if (h0 != inf) {
-      if (lane == 0) { node[start] = SNode{0.0, h0, start, -1, gen, 0u}; nf[0] = h0; nv[0] = start; }
-      n_near = 1;
+      {
+        SRec none;
+        uint32_t p0 = 0;
+        (void)lookup(start, lane == 0, none, p0);
+        if (lane == 0) { tb[p0] = SRec{0.0, h0, start, -1, (uint32_t)start, gen << 1}; nf[0] = h0; nv[0] = start; }
+      }
+      n_near = 1; count = 1;
       __syncthreads();
 #ifdef TRK_SEARCH_CLOCKS
       unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
 #endif
       for (;;) {
-        lane = sr_opaque(lane);
         SR_CLK(4);
         if ((int64_t)exp_q >= a.max_pops) { result = SR_FALLBACK; break; }
         if (n_near == 0) {
@@ -332,67 +459,52 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
         }
         __syncthreads();
         SR_CLK(1);
-        // ---- the vertices' records and adjacency offsets, one lane each; closed ones (stale entries) and repeats are dropped ----
+        // ---- the popped vertices' records and first adjacency rows, a group of 16 lanes each: one round trip; closed ones (stale
+        // entries) and repeats are dropped ----
         int my_u = -1;
 #pragma unroll
-        for (int r = 0; r < SR_K; r++) if (lane == r && r < nsel) my_u = sel_u[r];
-        SNode rec = SNode{0.0, 0.0, -1, -1, 0u, 1u};
-        int64_t my_a0 = 0, my_a1 = 0;
-        if (my_u >= 0) { rec = node[my_u]; my_a0 = a.adj_off[my_u]; my_a1 = a.adj_off[my_u + 1]; }
-        bool live = my_u >= 0 && rec.closed == 0u;
+        for (int r = 0; r < SR_K; r++) if (grp == r && r < nsel) my_u = sel_u[r];
+        SArc arc = my_u >= 0 ? a.rows[(int64_t)my_u * SR_D + sub] : no_arc;
+        SRec urec = SRec{0.0, 0.0, -1, -1, 0u, 1u};
+        uint32_t pu = 0;
+        bool live = lookup(my_u, my_u >= 0, urec, pu) && (urec.tag & 1u) == 0u;
 #pragma unroll
-        for (int r = 0; r + 1 < SR_K; r++) if (lane > r && r < nsel && my_u == sel_u[r]) live = false;
-        if (live) node[my_u].closed = 1u;
+        for (int r = 0; r + 1 < SR_K; r++) if (grp > r && r < nsel && my_u == sel_u[r]) live = false;
+        if (live && sub == 0) tb[pu].tag = (gen << 1) | 1u;
         const unsigned long long mlive = __ballot(live);
-        exp_q += (unsigned long long)__popcll(mlive);
+        const int n_live = __popcll(mlive & 0x0001000100010001ull);
+        exp_q += (unsigned long long)n_live;
         if ((mlive & 1ull) && sel_u[0] == goal) { result = SR_FOUND; break; }
-        double pg[SR_K];
-        int64_t pa0[SR_K];
-        int cum[SR_K + 1];
-        cum[0] = 0;
-#pragma unroll
-        for (int r = 0; r < SR_K; r++) {
-          const bool on = (mlive >> r) & 1ull;
-          pg[r] = sr_lane(rec.g, r);
-          pa0[r] = sr_lane(my_a0, r);
-          const int64_t e1 = sr_lane(my_a1, r);
-          cum[r + 1] = cum[r] + (on ? (int)(e1 - pa0[r]) : 0);
-        }
-        const int total = cum[SR_K];
+        const double ug = urec.g;
         SR_CLK(2);
         bool failed = false;
-        for (int base = 0; base < total && !failed; base += 64) {
-          const int t = base + lane;
-          bool cand = false, push = false;
+        bool act = live;
+        for (int pass = 0; pass < (1 << 20) && !failed; pass++) {
+          // a step may add a record per lane: the table moves before it could pass three quarters (no lane holds a position here)
+          if (count + 64 > (3 << lc) / 4 && !grow()) { failed = true; break; }
+          const bool has = act && arc.v >= 0;
+          const bool more = act && arc.v == SR_ARC_MORE;
+          bool cand = false, push = false, fresh = false;
           double fp = 0.0, gv = 0.0, hh = 0.0;
-          int32_t vp = 0, pu = -1, pe = -1;
-          SNode nn = SNode{0.0, 0.0, -1, -1, 0u, 0u};
-          if (t < total) {
-            int r = 0;
-#pragma unroll
-            for (int q = 1; q < SR_K; q++) r += t >= cum[q] ? 1 : 0;
-            int64_t k = 0;
-            double ug = 0.0;
-#pragma unroll
-            for (int q = 0; q < SR_K; q++) if (r == q) { k = pa0[q] + (t - cum[q]); ug = pg[q]; pu = sel_u[q]; }
-            const SArc arc = a.adj[k];
+          int32_t vp = 0, pe = -1;
+          uint32_t pv = 0;
+          if (has) {
             // everything the relaxation can need is requested at once, whether or not it turns out to be needed: validity bytes,
-            // the neighbour's record, and the rows of its heuristic (one memory round trip instead of three)
+            // the neighbour's record (the line its probe starts at), and the rows of its heuristic
             const uint8_t es = a.estat[arc.e], vs = a.vstat[arc.v];
-            nn = node[arc.v];
             const double hv = heuristic(arc.v);
+            SRec nn = SRec{0.0, 0.0, -1, -1, 0u, 0u};
+            const bool seen = lookup(arc.v, true, nn, pv);
             if (es != SR_INVALID && vs != SR_INVALID) {
               gv = ug + arc.w;
-              const bool first = nn.stamp != gen;
-              if (first || gv < nn.g) {
-                hh = first ? hv : nn.h;                          // h(v) is fixed for the query: computed when v is first reached
-                if (first) { nn.parent = -1; nn.parent_edge = -1; }
-                cand = true; vp = arc.v; pe = arc.e;
+              if (!seen || gv < nn.g) {
+                hh = seen ? nn.h : hv;                           // h(v) is fixed for the query: computed when v is first reached
+                cand = true; fresh = !seen; vp = arc.v; pe = arc.e;
               }
             }
           }
           // ---- two lanes with the same neighbour: the smaller cost wins (the lower lane among equals), the others stand down ----
-          if (__popcll(mlive) > 1) {
+          if (n_live > 1) {
             bool open = cand;
             const unsigned long long key = (unsigned long long)__double_as_longlong(gv);      // (costs are >= 0: ordered as integers)
             const unsigned hs = ((unsigned)vp * 2654435761u) >> 25;
@@ -402,20 +514,28 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
               __syncthreads();
               const int w = open ? (int)tab_owner[hs] : lane;
               const int32_t vw = __shfl(vp, w, 64);
-              const bool grp = open && vw == vp;                 // the slot is this vertex's for the round (another vertex's lanes wait)
-              if (grp) atomicMin(&tab_key[hs], key);
+              const bool same = open && vw == vp;                // the slot is this vertex's for the round (another vertex's lanes wait)
+              if (same) atomicMin(&tab_key[hs], key);
               __syncthreads();
-              const bool least = grp && tab_key[hs] == key;
+              const bool least = same && tab_key[hs] == key;
               if (least) atomicMin(&tab_low[hs], (uint32_t)lane);
               __syncthreads();
-              if (grp) { open = false; if (!(least && tab_low[hs] == (uint32_t)lane)) cand = false; }
+              if (same) { open = false; if (!(least && tab_low[hs] == (uint32_t)lane)) cand = false; }
               __syncthreads();
             }
             if (__ballot(open)) { failed = true; break; }
           }
-          if (cand) {
-            if (hh == inf) node[vp] = SNode{gv, hh, nn.parent, nn.parent_edge, gen, 1u};
-            else { node[vp] = SNode{gv, hh, pu, pe, gen, 0u}; push = true; fp = gv + hh; }
+          // ---- the winners write: a vertex reached before in place, a new one into a free record of its probe path ----
+          {
+            const unsigned long long mnew = __ballot(cand && fresh);
+            if (mnew) pv = claim(tb, lc, cand && fresh, vp, pv);
+            count += __popcll(mnew);
+            if (cand) {
+              SRec *rp = tb + pv;
+              rp->g = gv; rp->h = hh; rp->parent = my_u; rp->parent_edge = pe; rp->key = (uint32_t)vp;
+              rp->tag = (gen << 1) | (hh == inf ? 1u : 0u);
+              if (hh != inf) { push = true; fp = gv + hh; }
+            }
           }
           // ---- append: keys below T to near, the others to far ----
           unsigned long long mn_ = __ballot(push && fp < T);
@@ -428,6 +548,7 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
             const double top = T < inf ? T : hi;
             const double Tn = lo + (top - lo) * 0.5;
             if (!(Tn > lo) || !(Tn < top)) { failed = true; break; }
+            if (n_far + n_near > (1 << lc) && !grow()) { failed = true; break; }
             int keep = 0;
             for (int c0 = 0; c0 < n_near; c0 += 64) {
               const int i = c0 + lane;
@@ -438,11 +559,10 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
               const bool stay = on && f < Tn, out = on && !stay;
               const unsigned long long ms = __ballot(stay), mo = __ballot(out);
               if (stay) { const int p = keep + __popcll(ms & below); nf[p] = f; nv[p] = v; }
-              if (out) { const int p = n_far + __popcll(mo & below); if (p < a.far_cap) { ff[p] = f; fv[p] = v; } }
+              if (out) { const int p = n_far + __popcll(mo & below); ff[p] = f; fv[p] = v; }
               keep += __popcll(ms); n_far += __popcll(mo);
               __syncthreads();
             }
-            if (n_far > a.far_cap) { failed = true; break; }
             n_near = keep;
             T = Tn;
             moves++;
@@ -450,11 +570,16 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
           }
           if (failed) break;
           const unsigned long long mf_ = __ballot(push && !(fp < T));
-          if (n_far + __popcll(mf_) > a.far_cap) { failed = true; break; }
+          if (n_far + __popcll(mf_) > (1 << lc) && !grow()) { failed = true; break; }
           if (push && fp < T) { const int p = n_near + __popcll(mn_ & below); nf[p] = fp; nv[p] = vp; }
           else if (push) { const int p = n_far + __popcll(mf_ & below); ff[p] = fp; fv[p] = vp; }
           n_near += __popcll(mn_); n_far += __popcll(mf_);
           __syncthreads();
+          // ---- a vertex with more arcs than a row holds: its group goes on to the row its last slot names ----
+          if (!__ballot(more)) break;
+          const int nrow = __shfl(more ? arc.e : -1, (lane & 48) | (SR_D - 1), 64);
+          act = act && nrow >= 0;
+          arc = act ? a.rows[(int64_t)nrow * SR_D + sub] : no_arc;
         }
         if (failed) { result = SR_FALLBACK; break; }
       }
@@ -465,17 +590,22 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
       }
 #endif
     }
-    // ---- the path, goal ... start, and its edges ----
+    // ---- the path, goal ... start, and its edges, staged in the far list's place (the open list is dead) ----
     int nvert = 0;
+    const int path_max = 1 << (lc - 1);
+    int32_t *stage = fv;
+    __syncthreads();
     if (result == SR_FOUND) {
       if (lane == 0) {
         int32_t v = goal;
         for (;;) {
-          if (nvert >= SR_PATH_MAX) { nvert = -1; break; }
+          if (nvert >= path_max) { nvert = -1; break; }
           stage[nvert] = v;
           if (v == start) { nvert++; break; }
-          const SNode nd = node[v];
-          stage[SR_PATH_MAX + nvert] = nd.parent_edge;
+          SRec nd = SRec{0.0, 0.0, -1, -1, 0u, 0u};
+          uint32_t p = 0;
+          if (!lookup(v, true, nd, p)) { nvert = -1; break; }
+          stage[path_max + nvert] = nd.parent_edge;
           v = nd.parent;
           nvert++;
         }
@@ -484,22 +614,26 @@ __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
       if (nvert <= 0) result = SR_FALLBACK;
     }
     if (result == SR_FOUND) {
-      uint32_t off = 0;
+      uint32_t off = atomicAdd(a.pbuf_used, lane == 0 ? (uint32_t)(2 * nvert - 1) : 0u);
+      off = (uint32_t)__builtin_amdgcn_readlane((int)off, 0);
       const uint32_t need = (uint32_t)(2 * nvert - 1);
-      if (lane == 0) off = atomicAdd(a.pbuf_used, need);
-      off = (uint32_t)__builtin_amdgcn_readfirstlane((int)off);
       if ((uint64_t)off + need > a.pbuf_cap) result = SR_FALLBACK;
       else {
-        __threadfence_block();
+        __syncthreads();
         for (int i = lane; i < nvert; i += 64) a.pbuf[off + i] = stage[i];
-        for (int i = lane; i < nvert - 1; i += 64) a.pbuf[off + nvert + i] = stage[SR_PATH_MAX + i];
+        for (int i = lane; i < nvert - 1; i += 64) a.pbuf[off + nvert + i] = stage[path_max + i];
         if (lane == 0) { a.poff[qi] = (int32_t)off; a.plen[qi] = nvert; }
       }
     }
+    __syncthreads();
+    if (cls > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
       a.found[qi] = (uint8_t)result;
       atomicAdd(a.expanded, exp_q);
       if (moves) atomicAdd(a.next + 4, moves);
+      if (grows) atomicAdd(a.next + 5, grows);
+      atomicMax(a.next + 6, (uint32_t)count);
+      if (cls > 0) sr_pool_release(a, cls, chunk);
     }
   }
 }

@@ -488,5 +488,5 @@ class VoxelCachedLazyPRM:
         self._check(self.lib.tr_roadmap_search_stats(self._rm, ss))
         # where the searches ran (tr_roadmap_search_stats): finished by the kernel / handed back by it / on the host threads meanwhile
         self.search_stats = dict(device=int(ss[0]), handed_back=int(ss[1]), host_meanwhile=int(ss[2]), list_moves=int(ss[3]),
-                                 expanded_device=int(ss[4]), expanded_host=int(ss[5]), answered_by_components=int(ss[6]))
+                                 expanded_device=int(ss[4]), expanded_host=int(ss[5]), answered_by_components=int(ss[6]), table_growths=int(ss[7]))
         return dict(status=status, cost=cost, path_offsets=off, path_vertices=pv, paths=_Paths(pv, off))

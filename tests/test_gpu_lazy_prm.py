@@ -31,7 +31,11 @@ def _roadmap(irt, n_vertices, k, seed):
     return robot, vox, chk, states, edges, vc, ec
 
 
-def test_query_loop_matches_oracle_and_paths_are_valid_from_scratch(irt, orc, helpers):
+@pytest.mark.parametrize("search", ["host", "device"])
+def test_query_loop_matches_oracle_and_paths_are_valid_from_scratch(irt, orc, helpers, monkeypatch, search):
+    """`search`: every graph search of the loop on the host threads, or every one in the roadmap_astar kernel (a round of 400
+    queries would otherwise stay on the host: the kernel takes rounds of 512 or more) -- the oracle pins both."""
+    monkeypatch.setenv("TENDON_HIP_SEARCH", search)
     W = irt.workloads
     robot, vox, chk, states, edges, vc, ec = _roadmap(irt, 2500, 6, seed=21)
     new_vox, _ = W.reach_environment(seed=7, n_spheres=76)            # 12 more obstacles than the roadmap was built in
@@ -108,8 +112,11 @@ def test_query_loop_matches_oracle_and_paths_are_valid_from_scratch(irt, orc, he
         assert abs(d - lazy["cost"][q]) <= 1e-12 * max(1.0, d)
 
 
-def test_query_loop_small_graph_semantics(irt, orc):
-    """The hand-traced graph of tests/test_oracle.py::test_lazy_prm_query_loop_hand_traced through the product."""
+@pytest.mark.parametrize("search", ["host", "device"])
+def test_query_loop_small_graph_semantics(irt, orc, monkeypatch, search):
+    """The hand-traced graph of tests/test_oracle.py::test_lazy_prm_query_loop_hand_traced through the product, its searches on
+    the host threads and in the kernel."""
+    monkeypatch.setenv("TENDON_HIP_SEARCH", search)
     from importlib import import_module
     T = import_module("interactive-rate-tendons_amd").tendon
     robot = T.TendonRobot(tendons=[T.TendonSpecs(C=[0.0], D=[0.01]), T.TendonSpecs(C=[2.0], D=[0.01])], specs=T.BackboneSpecs())

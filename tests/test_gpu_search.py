@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _strictly_lazy(monkeypatch):
     """Rounds, items tested and validity bytes are compared between schedules here, so the loop stays strictly lazy
-    (TENDON_HIP_LAZY_ONLY=1); when it turns eager by default depends on how long a round's searches took.  The last test lifts it."""
+    (TENDON_HIP_LAZY_ONLY=1); the last test lifts it: by default the loop turns eager once enough queries are still open after a
+    round (a rule on counts, so that path is reproducible too)."""
     monkeypatch.setenv("TENDON_HIP_LAZY_ONLY", "1")
 
 
@@ -113,6 +114,42 @@ def test_device_searches_with_open_lists_beyond_the_lds_part(irt, monkeypatch):
     _same(ref, _solve(prm, starts, goals, False), expansions=False)
 
 
+@pytest.mark.parametrize("lc0,pool", [("8", None), ("8", "6,1,0"), (None, None)])
+def test_device_searches_on_wide_vertices_small_tables_and_an_exhausted_pool(irt, monkeypatch, lc0, pool):
+    """14 neighbours per vertex: a third of the vertices have more arcs than one adjacency row of the kernel holds (16) and chain a
+    second row.  With tables of 256 records per search every search outgrows its own table and moves -- rehashing -- into the shared
+    pool's larger ones, some of them twice; with a pool of 6 + 1 tables most find none free and are handed back to the host threads.
+    Same statuses, costs, paths, validity, rounds as the host searches every time; with one vertex per step the same expansions."""
+    if lc0 is not None:
+        monkeypatch.setenv("TENDON_HIP_SEARCH_LC0", lc0)
+    if pool is not None:
+        monkeypatch.setenv("TENDON_HIP_SEARCH_POOL", pool)
+    prm, states = _prm(irt, 8000, 15, seed=13, n_new_spheres=72)
+    deg = np.bincount(prm.edges.ravel(), minlength=len(states))
+    assert (deg > 16).mean() > 0.1 and deg.max() > 20
+    prm.prepare(4)                                                 # weak bounds: searches of a few hundred expansions
+    rng = np.random.default_rng(3)
+    nq = 600
+    starts, goals = rng.integers(0, len(states), nq), rng.integers(0, len(states), nq)
+    for eager in (True, False):
+        monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+        ref = _solve(prm, starts, goals, eager)
+        monkeypatch.setenv("TENDON_HIP_SEARCH", "device")
+        if pool is None:
+            monkeypatch.setenv("TENDON_HIP_SEARCH_K", "1")
+            _same(ref, _solve(prm, starts, goals, eager))
+            monkeypatch.delenv("TENDON_HIP_SEARCH_K")
+        out = _solve(prm, starts, goals, eager)
+        _same(ref, out, expansions=False)
+        ss = prm.search_stats
+        if lc0 is None:
+            assert ss["handed_back"] == 0 and ss["table_growths"] == 0, ss
+        elif pool is None:
+            assert ss["handed_back"] == 0 and ss["table_growths"] > nq // 2, ss
+        else:
+            assert ss["handed_back"] > nq // 4 and ss["table_growths"] > 0 and ss["device"] > 0, ss
+
+
 def test_roadmap_with_parallel_edges_stays_on_the_host(irt, monkeypatch):
     """Two edges between the same pair of vertices: the kernel relaxes a vertex's arcs in parallel lanes, so such a roadmap is
     searched on the host whatever the switch says -- and gives the answers it always gave."""
@@ -205,3 +242,15 @@ def test_lazy_loop_turns_eager_when_queries_keep_coming_back(irt, monkeypatch):
     assert out[1]["rounds"] < lazy[1]["rounds"] and not (out[2] == 0).any() and not (out[3] == 0).any(), (lazy[1], out[1])
     known = lazy[2] > 0
     assert np.array_equal(lazy[2][known], out[2][known])             # what the lazy loop knew, it knew right
+    # the switch reads counts, not clocks: the default path leaves the same rounds, items tested and validity bytes run after run
+    # and whichever side -- host threads, kernel, both -- runs the searches
+    assert out[1]["rounds"] == 2
+    for mode in ("host", "device", None, None):
+        if mode is None:
+            monkeypatch.delenv("TENDON_HIP_SEARCH", raising=False)
+        else:
+            monkeypatch.setenv("TENDON_HIP_SEARCH", mode)
+        again = _solve(prm, starts, goals, False)
+        assert np.array_equal(again[0]["status"], out[0]["status"]) and np.array_equal(again[0]["path_vertices"], out[0]["path_vertices"])
+        assert again[1]["rounds"] == out[1]["rounds"] and again[1]["items_checked"] == out[1]["items_checked"], (again[1], out[1])
+        assert np.array_equal(again[2], out[2]) and np.array_equal(again[3], out[3])
