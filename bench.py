@@ -325,6 +325,7 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
     vv = D.ShardedVertexValidator(robot, seed=seed, device=dev, box=box,
                                   validate_candidates=D.device_candidate_validator(eng, seed, box, signatures=hand_over))
     compact = D.device_row_compactor(eng)
+    codec = D.signature_wire_codec(eng) if hand_over else None    # the rows travel delta-coded (TENDON_HIP_SIG_WIRE=raw: as they are)
     space = (mv.min_tension_change, mv.min_rotation_change, mv.min_retraction_change)
 
     def fence():
@@ -336,7 +337,7 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
         t = [time.perf_counter()]
         vsig = None
         if hand_over:
-            mask, vsig = vv.run_with_rows(M, compact)
+            mask, vsig = vv.run_with_rows(M, compact, codec=codec)
         else:
             mask = vv.run(M, keep_on_device=True)
         torch.cuda.synchronize(); t.append(time.perf_counter())
@@ -395,7 +396,8 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
                 "knn_rows": torch.zeros(nshard * (k + 1), dtype=torch.int32, device=dev),
                 "edge_mask": torch.zeros(eshard // 64, dtype=torch.int64, device=dev)}
         if hand_over:                   # (padded to the largest shard's accepted count; about the same on every rank)
-            bufs["vertex_signatures"] = torch.zeros((len(verts) + world - 1) // world * eng.signature_words(), dtype=torch.int32, device=dev)
+            bufs["vertex_signatures"] = torch.zeros((len(verts) + world - 1) // world * (eng.signature_packed_words() if codec is not None else eng.signature_words()),
+                                                    dtype=torch.int32, device=dev)
         for name, b in bufs.items():
             D.allgather_mask(b)
             fence()
@@ -418,6 +420,7 @@ def run_config4(args, torch, dist, world, rank, dev_index, rehearsal, use_dist):
                        "ranks_seen": dist.get_world_size() if use_dist else 1, "rehearsal_shared_gpu": rehearsal,
                        "collective": ("gloo(host)" if rehearsal else "rccl") if use_dist else None,
                        "device_resident_between_phases": bool(resident), "vertex_signatures_handed_over": bool(hand_over),
+                       "signature_rows_on_the_wire": (getattr(vv, "rows_on_the_wire", "raw") if hand_over else None),
                        "candidates": M, "valid_vertices": int(len(verts)), "candidate_edges": int(len(edges)), "valid_edges": int(ev.sum()),
                        "vertex_mask_crc32": int(sums[0]), "edge_list_crc32": int(sums[4]),
                        "phases_ms": {"vertices_incl_allgather": 1e3 * phase[0], "regenerate_compact_download": 1e3 * phase[1],
@@ -507,6 +510,16 @@ def run_config4_projection(args, torch, dev_index):
     eng.reserve_edges(ne)
     edge_shard(verts, vsig, d_edges, ne, 1, 0)
     t_e1, (ewords, _) = timed(lambda: edge_shard(verts, vsig, d_edges, ne, 1, 0))
+    codec = D.signature_wire_codec(eng)
+    t_unpack = 0.0
+    if codec is not None:
+        packed, bad = codec.pack(vsig)
+        assert bad == 0, "%d signature rows of valid vertices could not be delta-coded" % bad
+        back = codec.unpack(packed)
+        P_ = eng.num_points
+        assert torch.equal(back[:, :P_], vsig[:, :P_]), "signature rows differ after pack + unpack"
+        t_pack1 = timed(lambda: codec.pack(vsig))[0]
+        t_unpack = timed(lambda: codec.unpack(packed))[0]
     base = {"vertices": t_v1, "regenerate_and_compact": t_regen, "knn_rows": t_k1, "edge_list_from_table": t_list, "edges": t_e1}
     world1 = sum(base.values())
     worlds = {}
@@ -532,12 +545,18 @@ def run_config4_projection(args, torch, dev_index):
             ref = ewords[lo:lo + eshard // 64]
             assert torch.equal(w[: ref.numel()], ref), "rank %d of %d: edge verdicts differ from the world-1 run" % (r, G)
         assert sum(counts) == nv
-        payload = {"vertex_mask": vshard // 8, "vertex_signatures": max(counts) * sw * 4, "knn_rows": nshard * (k + 1) * 4, "edge_mask": eshard // 8}
+        # the signature rows travel delta-coded (tr_pack_signatures_dev on the rank's rows before the all-gather, tr_unpack_signatures_dev
+        # on all rows after it: both on every rank's critical path); TENDON_HIP_SIG_WIRE=raw: as they are
+        row_bytes = (eng.signature_packed_words() if codec is not None else sw) * 4
+        payload = {"vertex_mask": vshard // 8, "vertex_signatures": max(counts) * row_bytes, "knn_rows": nshard * (k + 1) * 4, "edge_mask": eshard // 8}
         # a rank receives (G - 1) shards: over all its links at once, or one after the other round a ring; 20 us per step of latency
         model_links = {n: 1e3 * (b / (link_gbs * 1e9) + 20e-6) for n, b in payload.items()}
         model_ring = {n: 1e3 * (G - 1) * (b / (link_gbs * 1e9) + 20e-6) for n, b in payload.items()}
         phases = {n: max(v) for n, v in per.items()}
         replicated = {"regenerate_and_compact": t_regen, "edge_list_from_table": t_list}
+        if codec is not None:
+            phases["signature_pack"] = timed(lambda: codec.pack(vsig[: max(counts)]))[0]
+            replicated["signature_unpack"] = t_unpack
         crit = sum(phases.values()) + sum(replicated.values())
         worlds[str(G)] = {
             "phases_ms_max_over_ranks": phases, "phases_ms_per_rank": per, "replicated_ms_on_every_rank": replicated,
@@ -546,7 +565,8 @@ def run_config4_projection(args, torch, dev_index):
             "projected_build_ms": {"all_links": crit + sum(model_links.values()), "ring": crit + sum(model_ring.values())},
             "projected_speedup_over_world_1": {"compute_only": world1 / crit, "all_links": world1 / (crit + sum(model_links.values())),
                                                "ring": world1 / (crit + sum(model_ring.values()))},
-            "shard_efficiency": {n: base[n] / (G * phases[n]) for n in phases},
+            "shard_efficiency": {n: base[n] / (G * phases[n]) for n in phases if n in base},
+            "signature_row_bytes_on_the_wire": row_bytes,
         }
     out = {"projection": True,
            "what": "per-rank critical path of BASELINE configs[3] (2^%d candidates, %d neighbours) at world sizes emulated on ONE GPU: rank r's shard "
@@ -554,6 +574,8 @@ def run_config4_projection(args, torch, dev_index):
                    "not a scaling curve" % (args.config4_log2, k),
            "n_gpus": 1, "candidates": M, "valid_vertices": int(nv), "candidate_edges": int(ne), "repetitions_fastest_of": reps,
            "edge_schedule": eng.edge_schedule_last(), "world_1_ms": dict(base, total=world1), "emulated_worlds": worlds,
+           "signature_wire": None if codec is None else {"raw_row_bytes": sw * 4, "packed_row_bytes": eng.signature_packed_words() * 4,
+                                                         "pack_all_rows_ms": t_pack1, "unpack_all_rows_ms": t_unpack, "rows": int(nv)},
            "collective_model": "bytes_per_rank / %.0f GB/s + 20 us, once (all 7 links at once) or G - 1 times (ring)" % link_gbs}
     print(json.dumps(out), flush=True)
     return 0

@@ -490,6 +490,18 @@ int tr_validate_edges_indexed_sig_dev(tr_ctx *ctx, const tr_space_params *sp, co
                                       const uint32_t *d_vertex_sig, const int32_t *d_edges, int64_t n_edges,
                                       uint64_t *d_valid_bits, int32_t *d_n_fk, int64_t *n_domain_errors);
 
+/* The signature rows on the wire.  They are the one large collective of a sharded roadmap build (576 B per vertex at 129 backbone
+ * points: 346 MB per build of 6 x 10^5 vertices), and they are redundant: consecutive backbone points lie at most dL <= one voxel edge
+ * apart (the checker's constructor enforces it), so consecutive cells of a row differ by -1, 0 or +1 per axis.  A packed row =
+ * the first point's word, then 6 bits per further point, padded to tr_signature_packed_words(ctx) uint32 (an even number: 26 = 104 B
+ * at 129 points).  tr_pack_signatures_dev packs n_rows rows (d_sig: n_rows x tr_signature_words) and reports in *n_uncodable the rows
+ * it could not code (a point outside the voxel domain, or a larger step: never for vertices that passed the vertex phase) -- the
+ * caller then sends the rows as they are; it synchronises `stream` (one counter read-back).  tr_unpack_signatures_dev restores the rows
+ * word for word (the padding words of a row beyond the backbone's points are not written; nothing reads them). */
+int tr_signature_packed_words(const tr_ctx *ctx);
+int tr_pack_signatures_dev(tr_ctx *ctx, const uint32_t *d_sig, int64_t n_rows, uint32_t *d_packed, int64_t *n_uncodable, void *stream);
+int tr_unpack_signatures_dev(tr_ctx *ctx, const uint32_t *d_packed, int64_t n_rows, uint32_t *d_sig, void *stream);
+
 /* The same neighbour lists for a RANGE of the states as queries (all n states remain the candidates): rows
  * first_query .. first_query + n_queries - 1 of tr_knn's tables, whatever the range -- one rank's share when the connection
  * loop of a large roadmap is spread over several GPUs.  idx / dist: n_queries x k. */
@@ -570,10 +582,13 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *                                   roadmap_astar kernel and the host threads (below), a smaller round is the host threads'; host =
  *                                   the host threads always; device = the kernel always, whole rounds, no budget (tests)
  *   TENDON_HIP_SEARCH_HOST_SHARE=p  per cent of a shared round's searches (the ones with the most distant end points) that the host
- *                                   threads take while the kernel runs (default: starts at 2 and follows the two sides' times per roadmap)
- *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back to the host threads (default: starts at
- *                                   10000 and doubles per roadmap while more than 1 in 200 searches come back; 0 none)
- *   TENDON_HIP_SEARCH_K=1..6        vertices the kernel takes off a search's open list per step (default 6; 1 = the host's order)
+ *                                   threads take while the kernel runs (default: starts at 1 and follows the two sides' times per roadmap)
+ *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back: the host threads start on it at once, while
+ *                                   the kernel is still running (a word per query in pinned memory tells them) (default: starts at 6500
+ *                                   and follows the clock per roadmap: up when the host threads were still busy long after the kernel
+ *                                   had ended, down when they ran dry; 0 none)
+ *   TENDON_HIP_SEARCH_K=1..8        vertices the kernel takes off a search's open list per step, at most (default 8: as many as their
+ *                                   arcs fill the wave's 64 lanes; 1 = the host's order)
  *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds: 16 waves per CU)
  *   TENDON_HIP_SEARCH_LC0=8..14     log2 of the per-vertex records a search in flight owns (default 12: 176 KiB per slot with its far list;
  *                                   the searches' state does not depend on the roadmap's size); TENDON_HIP_SEARCH_POOL=a,b,c: shared tables of

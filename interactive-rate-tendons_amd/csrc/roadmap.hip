@@ -238,10 +238,13 @@ struct tr_roadmap {
     char *pool[trk::SR_CLASSES] = {nullptr, nullptr, nullptr, nullptr};
     char *qarena = nullptr;              // per-round arrays (queries, results, packed paths)
     trk::SArc *d_rows = nullptr; double *d_states = nullptr; float *d_lm = nullptr;
-    uint8_t *d_vstat = nullptr, *d_estat = nullptr;
+    uint8_t *d_vstat = nullptr, *d_estat = nullptr, *d_deg = nullptr;
     uint32_t *d_ctl = nullptr;
     int32_t *d_qs = nullptr, *d_qg = nullptr, *d_poff = nullptr, *d_plen = nullptr, *d_pbuf = nullptr;
     uint8_t *d_found = nullptr;
+    uint32_t *h_handback = nullptr, *d_handback = nullptr;   // pinned: the kernel marks a search here the moment it hands it back
+    int64_t handback_cap = 0;
+    double kernel_ms = 0, host_after_ms = 0;                   // of the last shared round: the kernel's span, the host threads' work after it
     int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0, st_expanded = 0, st_grows = 0, st_max_records = 0;   // of the last tr_roadmap_solve
     int64_t in_flight = 0;               // queries of the launch that has not been collected yet
     bool budget_from_env = false;
@@ -597,6 +600,7 @@ void free_search(tr_roadmap *r) {
   if (d.arena) dev_cache().release(d.arena);
   if (d.tables) dev_cache().release(d.tables);
   if (d.qarena) dev_cache().release(d.qarena);
+  if (d.h_handback) (void)hipHostFree(d.h_handback);
   d = tr_roadmap::DevSearch{};
 }
 
@@ -655,6 +659,24 @@ __global__ __launch_bounds__(256) void cc_flatten(const int32_t *__restrict__ pa
   int32_t x = (int32_t)v, p = parent[x];
   for (int guard = 0; p != x && guard < (1 << 24); guard++) { x = p; p = parent[x]; }
   label[v] = x;
+}
+
+// The same labels by union-find on one host thread (a few ms at 6 x 10^5 edges): for the searches the kernel hands back WHILE it runs,
+// when the device cannot be asked (its stream is busy with the searches).  Only equality of two labels is ever used.
+void host_component_labels(tr_roadmap *r) {
+  const int64_t V = r->V, E = r->E;
+  std::vector<int32_t> &parent = r->dc.label;
+  parent.resize((size_t)V);
+  for (int64_t v = 0; v < V; v++) parent[(size_t)v] = (int32_t)v;
+  auto find = [&](int32_t x) { while (parent[(size_t)x] != x) { parent[(size_t)x] = parent[(size_t)parent[(size_t)x]]; x = parent[(size_t)x]; } return x; };
+  for (int64_t e = 0; e < E; e++) {
+    if (r->estat[(size_t)e] == V_INVALID) continue;
+    const int32_t a = r->eu[(size_t)e], b = r->ev[(size_t)e];
+    if (r->vstat[(size_t)a] == V_INVALID || r->vstat[(size_t)b] == V_INVALID) continue;
+    const int32_t ra = find(a), rb = find(b);
+    if (ra != rb) parent[(size_t)std::max(ra, rb)] = std::min(ra, rb);
+  }
+  for (int64_t v = 0; v < V; v++) parent[(size_t)v] = find((int32_t)v);
 }
 
 // r->dc.label[v] = the smallest vertex of v's component in the graph minus the items known invalid.  false: not available (no
@@ -734,12 +756,12 @@ int search_mode() {
 // kernel's pop budget per search; TENDON_HIP_SEARCH_HOST_SHARE (per cent) / TENDON_HIP_SEARCH_BUDGET override
 double search_host_share() {
   const char *e = std::getenv("TENDON_HIP_SEARCH_HOST_SHARE");
-  const double p = e ? std::atof(e) : 2.0;
+  const double p = e ? std::atof(e) : 1.0;
   return std::min(100.0, std::max(0.0, p)) / 100.0;
 }
 int64_t search_budget() {
   const char *e = std::getenv("TENDON_HIP_SEARCH_BUDGET");
-  const long long b = e ? std::atoll(e) : 10000;
+  const long long b = e ? std::atoll(e) : 6500;
   return b > 0 ? (int64_t)b : 0;
 }
 
@@ -769,6 +791,7 @@ bool search_setup(tr_roadmap *r) {
   const int64_t V = r->V;
   if (r->S > trk::SR_MAXS) { d.why = "state size above the kernel's"; return false; }
   if (V < 2 || r->adj.size() == 0) { d.why = "no graph"; return false; }
+  if (V >= ((int64_t)1 << trk::SR_VBITS)) { d.why = "more vertices than an open-list word names"; return false; }
   // two arcs between the same pair of vertices would make two lanes relax the same record in one step: such roadmaps stay on the host
   {
     std::vector<int32_t> nb;
@@ -793,11 +816,13 @@ bool search_setup(tr_roadmap *r) {
   if (n_rows > std::numeric_limits<int32_t>::max() / D) { d.why = "roadmap too large for the row index"; return false; }
   RawArray<trk::SArc> rows;
   rows.resize_uninit((size_t)n_rows * D);
+  std::vector<uint8_t> lanes((size_t)V);                          // lanes a vertex's first row needs (an open-list word carries it)
   {
     int64_t next_row = V;
     for (int64_t v = 0; v < V; v++) {
       const Arc *arc = r->adj.data() + r->adj_off[(size_t)v];
       int64_t deg = r->adj_off[(size_t)v + 1] - r->adj_off[(size_t)v], row = v;
+      lanes[(size_t)v] = (uint8_t)std::max<int64_t>(1, std::min<int64_t>(deg, D));
       for (;;) {
         trk::SArc *out = rows.data() + (size_t)row * D;
         const int take = deg > D ? D - 1 : (int)deg;
@@ -849,7 +874,7 @@ bool search_setup(tr_roadmap *r) {
   const int Lmax = trk::SR_MAXL;
   const size_t b_rows = up((size_t)n_rows * D * sizeof(trk::SArc)), b_st = up((size_t)V * r->S * 8), b_lm = up((size_t)V * Lmax * 4),
                b_vs = up((size_t)V), b_es = up((size_t)std::max<int64_t>(r->E, 1));
-  if (dev_cache().alloc(dev, (void **)&d.arena, b_rows + b_st + b_lm + b_vs + b_es + d.ctl_bytes) != hipSuccess) {
+  if (dev_cache().alloc(dev, (void **)&d.arena, b_rows + b_st + b_lm + 2 * b_vs + b_es + d.ctl_bytes) != hipSuccess) {
     d.why = "out of device memory"; return false;
   }
   char *p = d.arena;
@@ -858,6 +883,7 @@ bool search_setup(tr_roadmap *r) {
   d.d_lm = (float *)p; p += b_lm;
   d.d_vstat = (uint8_t *)p; p += b_vs;
   d.d_estat = (uint8_t *)p; p += b_es;
+  d.d_deg = (uint8_t *)p; p += b_vs;
   d.d_ctl = (uint32_t *)p;
   laps.lap("device properties + arena");
   bool ok = dev_cache().alloc(dev, (void **)&d.tables, d.table_bytes) == hipSuccess;
@@ -870,6 +896,7 @@ bool search_setup(tr_roadmap *r) {
   ok = ok && hipMemsetAsync(d.tables, 0, d.table_bytes, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_rows, rows.data(), (size_t)n_rows * D * sizeof(trk::SArc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_states, r->states.data(), (size_t)V * r->S * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+       hipMemcpyAsync(d.d_deg, lanes.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipStreamSynchronize(nullptr) == hipSuccess;
   laps.lap("tables cleared + graph uploaded");
   if (!ok) { free_search(r); r->ds.state = -1; r->ds.why = "out of device memory"; return false; }
@@ -913,6 +940,15 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
     d.d_found = (uint8_t *)p; p += up((size_t)d.nq_cap);
     d.d_pbuf = (int32_t *)p;
   }
+  if (nq > d.handback_cap) {
+    if (d.h_handback) (void)hipHostFree(d.h_handback);
+    d.h_handback = nullptr; d.d_handback = nullptr; d.handback_cap = 0;
+    const int64_t cap = std::max<int64_t>(nq, 4096);
+    if (hipHostMalloc((void **)&d.h_handback, (size_t)cap * sizeof(uint32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess &&
+        hipHostGetDevicePointer((void **)&d.d_handback, d.h_handback, 0) == hipSuccess) d.handback_cap = cap;
+    else { if (d.h_handback) (void)hipHostFree(d.h_handback); d.h_handback = nullptr; d.d_handback = nullptr; }
+  }
+  if (d.h_handback) std::memset(d.h_handback, 0, (size_t)nq * sizeof(uint32_t));
   if (d.gens_issued + (uint64_t)nq >= ((uint64_t)1 << 31) - 2) {     // (a generation may not come round again while its records could be met)
     if (hipMemsetAsync(d.tables, 0, d.table_bytes, nullptr) != hipSuccess) return false;
     d.gens_issued = 0;
@@ -940,18 +976,20 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
        (r->E == 0 || hipMemcpyAsync(d.d_estat, r->estat.data(), (size_t)r->E, hipMemcpyHostToDevice, nullptr) == hipSuccess))) &&
        hipMemcpyAsync(d.d_qs, qs.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_qg, qg.data(), (size_t)nq * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
-       hipMemsetAsync(d.d_ctl, 0, d.ctl_bytes, nullptr) == hipSuccess;
+       hipMemsetAsync(d.d_ctl, 0, d.ctl_bytes, nullptr) == hipSuccess &&
+       hipMemsetAsync(d.d_ctl + 40, 0xff, 8, nullptr) == hipSuccess;       // (a -DTRK_SEARCH_CLOCKS build keeps the first wave's start there)
   if (!ok) return false;
   trk::SearchArgs a{};
   a.rows = d.d_rows; a.states = d.d_states; a.lm = L ? d.d_lm : nullptr;
   a.S = r->S; a.NT = r->NT; a.rot = r->rot; a.ret = r->ret; a.L = L;
   a.w_rot = r->w_rot; a.w_ret = r->w_ret; a.lm_slack = kLmSlack;
-  a.vstat = shared_status ? r->dc.d_vstat : d.d_vstat; a.estat = shared_status ? r->dc.d_estat : d.d_estat; a.V = V; a.E = r->E;
+  a.vstat = shared_status ? r->dc.d_vstat : d.d_vstat; a.estat = shared_status ? r->dc.d_estat : d.d_estat; a.deg = d.d_deg; a.V = V; a.E = r->E;
   a.qs = d.d_qs; a.qg = d.d_qg; a.nq = nq;
   a.next = d.d_ctl; a.pbuf_used = d.d_ctl + 1; a.expanded = (unsigned long long *)(d.d_ctl + 2);
   a.base = d.tables; a.lc0 = d.lc0; a.gen_base = gen_base;
   for (int c = 0; c < trk::SR_CLASSES; c++) { a.pool[c] = d.pool[c]; a.pool_n[c] = d.pool_n[c]; a.pool_word[c] = d.pool_word[c]; }
   a.found = d.d_found; a.poff = d.d_poff; a.plen = d.d_plen; a.pbuf = d.d_pbuf; a.pbuf_cap = d.pbuf_cap;
+  a.handback = d.handback_cap >= nq ? d.d_handback : nullptr;
   a.max_pops = budget > 0 ? budget : 16 * V + 1024;             // (uncapped: every vertex reopened a few times, far beyond what a search does)
   a.kbest = search_kbest();
   const unsigned grid = (unsigned)std::min<int64_t>(d.slots, nq);
@@ -963,18 +1001,20 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
 
 void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, const std::vector<size_t> &klist,
                            std::vector<uint8_t> &found, std::vector<std::vector<int32_t>> &paths,
-                           std::vector<std::vector<int32_t>> &paths_e, std::vector<size_t> &redo, int64_t &expanded, int T) {
+                           std::vector<std::vector<int32_t>> &paths_e, std::vector<size_t> &redo, int64_t &expanded, int T,
+                           const std::vector<uint8_t> *handled = nullptr) {
   auto &d = r->ds;
   const int64_t nq = d.in_flight;
   d.in_flight = 0;
   // (any failure: the whole list goes back to the host threads)
-  auto give_back = [&]() { redo = klist; for (size_t k : klist) found[k] = 0; };
+  // (`handled`: positions the host threads have searched already -- handed back while the kernel ran: their answers stand)
+  auto give_back = [&]() { redo.clear(); for (size_t k : klist) if (!handled || !(*handled)[k]) { redo.push_back(k); found[k] = 0; } };
   redo.clear();
   if (nq != (int64_t)klist.size()) { give_back(); return; }
   bool ok = true;
   std::vector<uint8_t> res((size_t)nq);
   std::vector<int32_t> poff((size_t)nq), plen((size_t)nq);
-  uint32_t ctl[32] = {0};
+  uint32_t ctl[128] = {0};
   ok = hipMemcpy(ctl, d.d_ctl, sizeof(ctl), hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(res.data(), d.d_found, (size_t)nq, hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(poff.data(), d.d_poff, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess &&
@@ -984,6 +1024,14 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
     unsigned long long c[7];
     std::memcpy(c, &ctl[16], sizeof(c));
     const double tot = (double)(c[0] + c[1] + c[2] + c[3] + c[4]);
+    unsigned long long sp[2];
+    std::memcpy(sp, &ctl[32], sizeof(sp));
+    if (tot > 0) std::fprintf(stderr, "[tendon_hip] search steps: %llu steps, %llu passes, %.2f us per step\n", sp[0], sp[1], sp[0] ? tot * 1e-2 / (double)sp[0] : 0.0);
+    if (tot > 0) {
+      std::fprintf(stderr, "[tendon_hip] searches ended per 2 ms (count/expansions):");
+      for (int b = 0; b < 40; b++) if (ctl[44 + b]) std::fprintf(stderr, " %d:%u/%u", 2 * b, ctl[44 + b], ctl[84 + b]);
+      std::fprintf(stderr, "\n");
+    }
     if (tot > 0)
       std::fprintf(stderr, "[tendon_hip] search clocks: %.1f wave-ms in all (longest search %.2f ms): refill %.1f%%, pop %.1f%%, record + offsets %.1f%%, arcs + rows + relax %.1f%%, append %.1f%%\n",
                    tot * 1e-5, (double)c[6] * 1e-5, 100.0 * c[0] / tot, 100.0 * c[1] / tot, 100.0 * c[2] / tot, 100.0 * c[3] / tot, 100.0 * c[4] / tot);
@@ -997,11 +1045,14 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
   d.st_expanded += (int64_t)ex;
   const int Tb = nq >= 2048 ? std::max(1, std::min(T, 16)) : 1;            // (ten thousand small vectors: by ranges on the host threads)
   std::vector<std::vector<size_t>> part((size_t)Tb);
+  std::vector<int64_t> nfb((size_t)Tb, 0);
   on_threads(Tb, [&](int t) {
     const int64_t j0 = nq * t / Tb, j1 = nq * (t + 1) / Tb;
     for (int64_t j = j0; j < j1; j++) {
       const size_t k = klist[(size_t)j];
       const int64_t q = active[k];
+      if (res[(size_t)j] == trk::SR_FALLBACK) nfb[(size_t)t]++;
+      if (handled && (*handled)[k]) continue;
       found[k] = 0;
       if (res[(size_t)j] == trk::SR_FALLBACK) { part[(size_t)t].push_back(k); continue; }
       if (res[(size_t)j] != trk::SR_FOUND) continue;
@@ -1013,7 +1064,10 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
     }
   });
   for (const auto &p : part) redo.insert(redo.end(), p.begin(), p.end());
-  d.st_queries += nq - (int64_t)redo.size(); d.st_fallbacks += (int64_t)redo.size(); d.st_moves += (int64_t)ctl[4];
+  int64_t n_fb = 0;
+  for (int64_t x : nfb) n_fb += x;
+  n_fb = std::max<int64_t>(n_fb, (int64_t)redo.size());          // (a path that did not fit its buffer comes back too)
+  d.st_queries += nq - n_fb; d.st_fallbacks += n_fb; d.st_moves += (int64_t)ctl[4];
   d.st_grows += (int64_t)ctl[5]; d.st_max_records = std::max<int64_t>(d.st_max_records, (int64_t)ctl[6]);
 }
 
@@ -1419,16 +1473,95 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     };
     if (!on_device) host_search(&todo);
     else {
+      // One team of host threads for the whole shared round: first the host's own share (the searches expected to be longest), then --
+      // while the kernel is still running -- whatever it hands back, the MOMENT it does: the kernel sets a word per query in pinned
+      // memory when a search exceeds its budget (or finds no larger table, ...), a thread with nothing else to do polls those
+      // words and the stream, and feeds the others.  The longest searches of a round -- which bound the launch when a wave has to
+      // finish them at a tenth of a core's pace -- are thus finished by cores while the waves work through the rest, and the budget
+      // can be small.  Unreachable goals among them are weeded out by component labels computed here on the host (the device's
+      // stream is busy), once, when the first search comes back.
       const auto t0 = std::chrono::steady_clock::now();
-      host_search(&host_list);
+      const int dev_id = tr_device(r->ctx);
+      const uint32_t *flags = (r->ds.handback_cap >= (int64_t)dev_list.size()) ? r->ds.h_handback : nullptr;
+      const int64_t n_dev = (int64_t)dev_list.size(), n_share = (int64_t)host_list.size();
+      std::vector<uint8_t> handled(active.size(), 0), seen((size_t)n_dev, 0);
+      std::vector<size_t> feed((size_t)n_dev);
+      std::atomic<int64_t> feed_tail{0}, feed_head{0}, next_share{0}, share_left{n_share};
+      std::atomic<bool> closed{flags == nullptr};
+      std::mutex poll_mu;
+      bool labels_host = labels_now;                              // (poller only)
+      int64_t n_streamed = 0, n_cut_host = 0;                     // (poller only)
+      std::chrono::steady_clock::time_point t_share_done = t0, t_kernel_done = t0;
+      std::atomic<bool> kernel_done{false};
+      auto process = [&](int t, size_t k, int64_t &ex) {
+        Scratch &sc = r->scratch[(size_t)t];
+        const int64_t q = active[k];
+        const int64_t ex0 = ex;
+        found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+        if (!found[k] && ex - ex0 >= kComponentTrigger) walked_in_vain.store(true, std::memory_order_relaxed);
+        if (hist) hist[k] = ex - ex0;
+      };
+      auto poll = [&]() {                                          // (under poll_mu)
+        const bool done = hipStreamQuery(nullptr) == hipSuccess;   // read BEFORE the words: one set before the kernel ended is then seen below
+        if (done && !kernel_done.load()) { t_kernel_done = std::chrono::steady_clock::now(); kernel_done.store(true); }
+        int64_t t = feed_tail.load(std::memory_order_relaxed);
+        for (int64_t j = 0; j < n_dev; j++) {
+          if (seen[(size_t)j] || !__atomic_load_n(&flags[j], __ATOMIC_ACQUIRE)) continue;
+          seen[(size_t)j] = 1;
+          const size_t k = dev_list[(size_t)j];
+          handled[k] = 1;
+          n_streamed++;
+          if (!labels_host && cmode != 0) { host_component_labels(r); labels_host = true; }
+          if (labels_host) {
+            const int64_t q = active[k];
+            if (r->dc.label[(size_t)starts[q]] != r->dc.label[(size_t)goals[q]]) { found[k] = 0; n_cut_host++; continue; }
+          }
+          feed[(size_t)t++] = k;
+        }
+        feed_tail.store(t, std::memory_order_release);
+        if (done) closed.store(true, std::memory_order_release);
+      };
+      auto member = [&](int t) {
+        (void)hipSetDevice(dev_id);
+        int64_t ex = 0;
+        for (;;) {
+          const int64_t j = next_share.load(std::memory_order_relaxed) < n_share ? next_share.fetch_add(1) : n_share;
+          if (j < n_share) {
+            process(t, host_list[(size_t)j], ex);
+            if (share_left.fetch_sub(1) == 1) t_share_done = std::chrono::steady_clock::now();
+            continue;
+          }
+          int64_t h = feed_head.load(std::memory_order_relaxed);
+          if (h < feed_tail.load(std::memory_order_acquire)) {
+            if (feed_head.compare_exchange_weak(h, h + 1)) process(t, feed[(size_t)h], ex);
+            continue;
+          }
+          if (closed.load(std::memory_order_acquire)) {
+            if (feed_head.load() < feed_tail.load(std::memory_order_acquire)) continue;
+            break;
+          }
+          if (poll_mu.try_lock()) { poll(); poll_mu.unlock(); }
+          std::this_thread::sleep_for(std::chrono::microseconds(25));
+        }
+        expanded += ex;
+      };
+      {
+        const int nt = std::max(1, T);
+        std::vector<std::thread> th;
+        for (int t = 1; t < nt; t++) th.emplace_back(member, t);
+        member(0);
+        for (auto &x : th) x.join();
+      }
+      if (n_cut_host) { r->dc.st_cut += n_cut_host; r->dc.wanted = true; }
       const auto t1 = std::chrono::steady_clock::now();
       int64_t ex = 0;
-      device_search_collect(r, active, dev_list, found, paths, paths_e, redo, ex, T);
+      device_search_collect(r, active, dev_list, found, paths, paths_e, redo, ex, T, &handled);
       expanded += ex;
-
+      if (!kernel_done.load()) t_kernel_done = std::chrono::steady_clock::now();     // (no flags to poll: collect waited for it)
       const auto t2 = std::chrono::steady_clock::now();
-      // what the kernel handed back is long by definition: the labels (if the round has none yet) weed out the unreachable goals
-      if (!redo.empty() && !labels_now && ensure_labels()) {
+      // what is left (a path that did not fit its buffer; everything, without the pinned words): as before, after the kernel
+      if (!redo.empty() && !labels_now && !labels_host && ensure_labels()) labels_host = true;
+      if (!redo.empty() && (labels_now || labels_host)) {
         const int32_t *lab = r->dc.label.data();
         std::vector<size_t> keep;
         for (size_t k : redo) {
@@ -1440,22 +1573,26 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         if (keep.size() < redo.size()) r->dc.wanted = true;
         redo.swap(keep);
       }
-      // (what is left of the handed-back searches has a path to find, and a core needs milliseconds for each: when they are more
-      // than one in two hundred of the round, the budget is too small for this roadmap's searches.  The host's share follows the
-      // clock: halved when the kernel had finished long before the host threads, raised when they waited for it longer than they worked.)
-      if (smode != 2 && !r->ds.budget_from_env && redo.size() * 200 > dev_list.size() && r->ds.budget > 0 && r->ds.budget < 16 * r->V) r->ds.budget *= 2;
-      if (smode != 2 && !std::getenv("TENDON_HIP_SEARCH_HOST_SHARE") && !host_list.empty()) {
-        const double t_host = std::chrono::duration<double, std::milli>(t1 - t0).count(), t_wait = std::chrono::duration<double, std::milli>(t2 - t1).count();
-        if (t_wait < 0.1 * t_host) r->ds.share = std::max(0.0025, r->ds.share * 0.5);
-        else if (t_wait > t_host) r->ds.share = std::min(0.08, r->ds.share * 1.5);
-      }
       host_search(&redo);
-      if (std::getenv("TENDON_HIP_SEARCH_STATS")) {
-        const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "[tendon_hip] round %lld: order + launch %.2f ms, %zu searches on the host meanwhile %.2f ms, wait + collect %zu %.2f ms, %zu handed back %.2f ms\n",
-                     (long long)r->st_rounds, ms(t_round, t0), host_list.size(), ms(t0, t1), dev_list.size(), ms(t1, t2), redo.size(),
-                     ms(t2, std::chrono::steady_clock::now()));
+      const auto t3 = std::chrono::steady_clock::now();
+      const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      // The two knobs follow the clock (answers do not depend on them).  Budget: the host threads were still searching long after the
+      // kernel had ended -> the kernel keeps more (x 1.5); they ran dry early and little came back -> it hands back sooner (x 0.75).
+      // Share: halved when the host's own share outlasted the kernel, raised when it was done in a fraction of the kernel's span.
+      const double t_kernel = ms(t_round, t_kernel_done), t_after = std::max(0.0, ms(t_kernel_done, t3)), t_share = n_share ? ms(t0, t_share_done) : 0.0;
+      r->ds.kernel_ms = t_kernel; r->ds.host_after_ms = t_after;
+      if (smode != 2 && !r->ds.budget_from_env && r->ds.budget > 0) {
+        if (t_after > 0.25 * t_kernel) r->ds.budget = std::min<int64_t>(16 * r->V, r->ds.budget + r->ds.budget / 2);
+        else if (t_after < 0.05 * t_kernel && (n_streamed + (int64_t)redo.size()) * 100 < n_dev) r->ds.budget = std::max<int64_t>(1000, r->ds.budget - r->ds.budget / 4);
       }
+      if (smode != 2 && !std::getenv("TENDON_HIP_SEARCH_HOST_SHARE") && n_share > 0) {
+        if (t_share > t_kernel) r->ds.share = std::max(0.0025, r->ds.share * 0.5);
+        else if (t_share < 0.4 * t_kernel && t_after < 0.1 * t_kernel) r->ds.share = std::min(0.08, r->ds.share * 1.5);
+      }
+      if (std::getenv("TENDON_HIP_SEARCH_STATS"))
+        std::fprintf(stderr, "[tendon_hip] round %lld: order + launch %.2f ms; kernel done at %.2f ms (%zu searches); host threads: own share %zu done at %.2f ms, %lld handed back meanwhile (%lld answered by labels), all done at %.2f ms; collect %.2f ms, %zu afterwards %.2f ms; next budget %lld, share %.4f\n",
+                     (long long)r->st_rounds, ms(t_round, t0), t_kernel, dev_list.size(), host_list.size(), ms(t_round, t_share_done), (long long)n_streamed,
+                     (long long)n_cut_host, ms(t_round, t1), ms(t1, t2), redo.size(), ms(t2, t3), (long long)r->ds.budget, r->ds.share);
     }
     if (walked_in_vain.load()) r->dc.wanted = true;
     if (hist) {

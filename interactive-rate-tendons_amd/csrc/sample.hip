@@ -1,5 +1,6 @@
 // sample.hip -- candidate generator and accepted-set compaction of createRoadmap's vertex phase (see sample.hpp).
 #include "sample.hpp"
+#include <algorithm>
 
 namespace trk {
 
@@ -123,7 +124,90 @@ __global__ void compact_finish(SampleCounters *ctr, int64_t capacity, uint64_t i
   else ctr->have = (unsigned long long)capacity;         // ->tried was written by the row that filled the last position
 }
 
+// one thread per (row, group of 16 points): points 16 g + 1 .. 16 g + 16 against their predecessors
+__global__ __launch_bounds__(256) void pack_signatures_kernel(const uint32_t *__restrict__ sig, int64_t n_rows, int P, int64_t stride, int G, int PW,
+                                                              uint32_t *__restrict__ packed, unsigned long long *__restrict__ bad) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_rows * G) return;
+  const int64_t row = t / G;
+  const int g = (int)(t - row * G);
+  const uint32_t *in = sig + row * stride;
+  uint32_t prev = in[16 * g];
+  bool ok = !(prev & (1u << 30));
+  // three words: five 6-bit codes each (bits 0 .. 29), the sixteenth code's three 2-bit fields in their top bits
+  uint32_t w3[3] = {0u, 0u, 0u};
+  for (int j = 0; j < 16; j++) {
+    const int pt = 16 * g + 1 + j;
+    uint32_t code = 0x15u;                                     // (padding past the last point: no movement)
+    if (pt < P) {
+      const uint32_t cur = in[pt];
+      const uint32_t dx = (cur & 1023u) + 1u - (prev & 1023u), dy = ((cur >> 10) & 1023u) + 1u - ((prev >> 10) & 1023u),
+                     dz = ((cur >> 20) & 1023u) + 1u - ((prev >> 20) & 1023u);
+      ok = ok && !(cur & (1u << 30)) && dx <= 2u && dy <= 2u && dz <= 2u;
+      code = (dx & 3u) | ((dy & 3u) << 2) | ((dz & 3u) << 4);
+      prev = cur;
+    }
+    if (j < 15) w3[j / 5] |= code << (6 * (j % 5));
+    else { w3[0] |= (code & 3u) << 30; w3[1] |= ((code >> 2) & 3u) << 30; w3[2] |= ((code >> 4) & 3u) << 30; }
+  }
+  uint32_t *out = packed + row * PW;
+  if (g == 0) out[0] = in[0];
+  out[1 + 3 * g] = w3[0]; out[2 + 3 * g] = w3[1]; out[3 + 3 * g] = w3[2];
+  if (g == G - 1 && ((1 + 3 * G) & 1)) out[1 + 3 * G] = 0u;    // the pad word
+  if (!ok) atomicAdd(bad, 1ull);
+}
+
+__device__ __forceinline__ uint32_t sig_code_at(const uint32_t *w3, int j) {
+  if (j < 15) return (w3[j / 5] >> (6 * (j % 5))) & 63u;
+  return (w3[0] >> 30) | ((w3[1] >> 30) << 2) | ((w3[2] >> 30) << 4);
+}
+
+// one thread per (row, group): the cell its group starts from = the first cell + the steps of the groups before it
+__global__ __launch_bounds__(256) void unpack_signatures_kernel(const uint32_t *__restrict__ packed, int64_t n_rows, int P, int64_t stride, int G, int PW,
+                                                                uint32_t *__restrict__ sig) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_rows * G) return;
+  const int64_t row = t / G;
+  const int g = (int)(t - row * G);
+  const uint32_t *in = packed + row * PW;
+  const uint32_t first = in[0];
+  int cx = (int)(first & 1023u), cy = (int)((first >> 10) & 1023u), cz = (int)((first >> 20) & 1023u);
+  for (int q = 0; q < g; q++) {
+    const uint32_t w3[3] = {in[1 + 3 * q], in[2 + 3 * q], in[3 + 3 * q]};
+    for (int j = 0; j < 16; j++) {
+      const uint32_t c = sig_code_at(w3, j);
+      cx += (int)(c & 3u) - 1; cy += (int)((c >> 2) & 3u) - 1; cz += (int)((c >> 4) & 3u) - 1;
+    }
+  }
+  uint32_t *out = sig + row * stride;
+  if (g == 0) out[0] = first;
+  const uint32_t w3[3] = {in[1 + 3 * g], in[2 + 3 * g], in[3 + 3 * g]};
+  for (int j = 0; j < 16; j++) {
+    const int pt = 16 * g + 1 + j;
+    if (pt >= P) break;
+    const uint32_t c = sig_code_at(w3, j);
+    cx += (int)(c & 3u) - 1; cy += (int)((c >> 2) & 3u) - 1; cz += (int)((c >> 4) & 3u) - 1;
+    out[pt] = ((uint32_t)cx & 1023u) | (((uint32_t)cy & 1023u) << 10) | (((uint32_t)cz & 1023u) << 20);
+  }
+}
+
 }  // namespace
+
+void launch_pack_signatures(const uint32_t *d_sig, int64_t n_rows, int n_points, int64_t sig_stride, uint32_t *d_packed, unsigned long long *d_bad,
+                            hipStream_t s) {
+  if (n_rows <= 0) return;
+  const int G = (n_points - 1 + 15) / 16;
+  const int64_t threads = n_rows * std::max(G, 1);
+  hipLaunchKernelGGL(pack_signatures_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_sig, n_rows, n_points, sig_stride, std::max(G, 1),
+                     sig_packed_words(n_points), d_packed, d_bad);
+}
+void launch_unpack_signatures(const uint32_t *d_packed, int64_t n_rows, int n_points, int64_t sig_stride, uint32_t *d_sig, hipStream_t s) {
+  if (n_rows <= 0) return;
+  const int G = (n_points - 1 + 15) / 16;
+  const int64_t threads = n_rows * std::max(G, 1);
+  hipLaunchKernelGGL(unpack_signatures_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_packed, n_rows, n_points, sig_stride, std::max(G, 1),
+                     sig_packed_words(n_points), d_sig);
+}
 
 void launch_candidate_states(uint64_t seed, uint64_t first, int64_t count, const SampleBox &box, double *d_states, hipStream_t s) {
   if (count <= 0) return;

@@ -43,4 +43,13 @@ void launch_compact_rows(const uint64_t *d_mask, int64_t count, uint64_t index_b
                          const double *d_tips, int64_t capacity, double *d_rows_out, double *d_tips_out, int64_t *d_index_out,
                          SampleCounters *d_counters, uint32_t *d_wprefix, hipStream_t s);
 
+// Signature rows on the wire (the sharded build's one large all-gather): consecutive backbone points lie at most dL <= one voxel edge
+// apart, so consecutive cells of a row differ by -1, 0 or +1 per axis.  A packed row = the first point's signature word, then 6
+// bits per further point (2 per axis: difference + 1), 16 points to three words; padded to an even number of words.  A row with a
+// SIG_BAD word or a larger step cannot be coded: it is counted in *d_bad (the caller then sends the rows as they are).
+__host__ __device__ inline int sig_packed_words(int n_points) { const int w = 1 + 3 * ((n_points - 1 + 15) / 16); return (w + 1) & ~1; }
+void launch_pack_signatures(const uint32_t *d_sig, int64_t n_rows, int n_points, int64_t sig_stride, uint32_t *d_packed, unsigned long long *d_bad,
+                            hipStream_t s);
+void launch_unpack_signatures(const uint32_t *d_packed, int64_t n_rows, int n_points, int64_t sig_stride, uint32_t *d_sig, hipStream_t s);
+
 }  // namespace trk

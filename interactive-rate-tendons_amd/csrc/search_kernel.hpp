@@ -3,12 +3,14 @@
 // QUERY, thousands of queries in flight.  It is roadmap.hip's host `astar` -- the same heuristic (state-space distance, sharpened by the
 // landmark bounds), the same relaxation rule (a vertex whose cost improves is opened again), the same stopping rule (the goal leaves
 // the open list as its minimum) -- shaped for a wave:
-//   * a step takes up to SR_K = 4 vertices off the open list at once (the minimum, and the smallest of the other lanes' minima); each
-//     gets a group of SR_D = 16 lanes, one per slot of its ADJACENCY ROW: arcs live at a fixed stride of 16 per vertex (unused slots
-//     marked; a vertex with more arcs chains further rows through its last slot, 1 - 3 % of a k-nearest roadmap's vertices), so the
-//     arcs' address follows from the vertex alone and their load leaves together with the vertex's own record.  A step is then a chain
-//     of TWO dependent memory round trips -- record + arcs of the popped vertices; per arc the validity bytes, the neighbour's record
-//     and the rows of its heuristic, all requested at once -- whatever the number of lanes busy (round 4: three, through CSR offsets).
+//   * a step takes up to SR_K = 6 vertices off the open list at once (the minimum, and the smallest of the other lanes' minima) -- as
+//     many as their arcs fill the wave's 64 lanes, one arc per lane: an open-list entry carries its vertex's arc count next to the
+//     vertex (5 bits of the word), so the lanes are dealt out before anything is loaded (~5 vertices of a 10-nearest roadmap).  Arcs
+//     live in ADJACENCY ROWS at a fixed stride of SR_D = 16 per vertex (a vertex with more chains further rows through its last slot,
+//     1 - 3 % of a k-nearest roadmap's vertices), so their address follows from the vertex alone and their load leaves together with
+//     the vertex's own record.  A step is then a chain of TWO dependent memory round trips -- record + arcs of the popped vertices;
+//     per arc the validity bytes, the neighbour's record and arc count and the rows of its heuristic, all requested at once --
+//     whatever the number of lanes busy (round 4: three, through CSR offsets).
 //     Expanding a vertex that is not the minimum is what any best-first search with re-opening may do: the stopping rule alone makes
 //     the returned cost optimal, and with it the path (the optimum is unique unless two paths' fp64 cost sums agree in every bit).
 //     One vertex per step (kbest = 1) is the host's order of expansions exactly (same count).
@@ -47,11 +49,12 @@ struct SArc { int32_t v, e; double w; };                      // roadmap.hip: Ar
 struct SRec { double g, h; int32_t parent, parent_edge; uint32_t key, tag; };   // tag = generation << 1 | closed
 constexpr int SR_CAP = 640;                                   // near-list entries per wave (LDS)
 constexpr int SR_MAXS = 12, SR_MAXL = 64;                     // state coordinates, landmarks
-constexpr int SR_K = 4;                                       // vertices expanded per step, at most
+constexpr int SR_K = 6;                                       // vertices expanded per step, at most (as many as their arcs fill 64 lanes: ~5)
+constexpr int SR_VBITS = 26;                                  // an open-list word: vertex | lanes its first row needs << SR_VBITS
 constexpr int SR_D = 16;                                      // arcs per adjacency row = lanes per expanded vertex
 constexpr int SR_TAB = 128;                                   // slots of the conflict tables
 constexpr int SR_CLASSES = 4;                                 // table sizes: 2^lc0 records, then x 4 per class
-constexpr int SR_CTL_WORDS = 64;                              // control words ahead of the pool bitmaps
+constexpr int SR_CTL_WORDS = 128;                              // control words ahead of the pool bitmaps
 constexpr int32_t SR_ARC_NONE = -1, SR_ARC_MORE = -2;
 enum : uint8_t { SR_NO_PATH = 0, SR_FOUND = 1, SR_FALLBACK = 2 };
 constexpr uint8_t SR_INVALID = 2;                             // roadmap.hip: V_INVALID
@@ -66,6 +69,7 @@ struct SearchArgs {
   int32_t S, NT, rot, ret, L;
   double w_rot, w_ret, lm_slack;
   const uint8_t *vstat, *estat;
+  const uint8_t *deg;                                         // [V] lanes a vertex's first row needs: its arcs, 1 at least, SR_D at most
   int64_t V, E;
   const int32_t *qs, *qg; int64_t nq;                         // the round's queries
   uint32_t *next;                                             // control words: [0] query ticket, [1] path words used, [2..3] expansions, [4] list
@@ -77,6 +81,8 @@ struct SearchArgs {
   int32_t lc0;                                                // log2 of the records of a class-0 table
   uint32_t gen_base;                                          // query i of the launch searches under generation gen_base + i + 1 (< 2^31)
   uint8_t *found; int32_t *poff, *plen;                       // [nq]
+  uint32_t *handback;                                         // [nq] in pinned host memory, or null: set the moment a search is handed back, so
+                                                              // that the host threads start on it while the kernel still runs
   int32_t *pbuf; uint32_t pbuf_cap; uint32_t *pbuf_used;      // packed paths: vertices goal .. start, then their edges
   unsigned long long *expanded;
   int64_t max_pops;                                           // expansions a search may spend before it is handed back
@@ -137,6 +143,16 @@ __device__ __forceinline__ double sr_wave_max(double x) {
   SR_DPP_STEP64(x, 0x142, 0xa, >); SR_DPP_STEP64(x, 0x143, 0xc, >);
   return sr_lane63(x);
 }
+// ... of a 32-bit key: one v_min_u32 with a DPP operand per stage.  The minimum of 64 non-negative doubles, exactly, is two of these
+// (the high words, then the low words among the lanes that hold the smallest high word): ~20 instructions where the 64-bit
+// compare-and-select chain takes ~100, and a step runs it once per vertex it takes.
+__device__ __forceinline__ uint32_t sr_wave_min_u32(uint32_t x) {
+#define SR_MIN_STEP(ctrl, rmask) do { const uint32_t y_ = (uint32_t)SR_DPP32((int)x, ctrl, rmask); x = y_ < x ? y_ : x; } while (0)
+  SR_MIN_STEP(0x128, 0xf); SR_MIN_STEP(0x124, 0xf); SR_MIN_STEP(0x122, 0xf); SR_MIN_STEP(0x121, 0xf);
+  SR_MIN_STEP(0x142, 0xa); SR_MIN_STEP(0x143, 0xc);
+#undef SR_MIN_STEP
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
 __device__ __forceinline__ int sr_wave_sum(int c) {
   c += SR_DPP32(c, 0x128, 0xf); c += SR_DPP32(c, 0x124, 0xf); c += SR_DPP32(c, 0x122, 0xf); c += SR_DPP32(c, 0x121, 0xf);
   // (the row sums are in every lane of their rows: fold the four rows through scalars)
@@ -186,7 +202,6 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
   uint32_t *tab_owner = (uint32_t *)(tab_key + SR_TAB);       // [SR_TAB] a lane that claimed the slot
   uint32_t *tab_low = tab_owner + SR_TAB;                     // [SR_TAB] lowest lane among those offering the smallest cost
   const int lane = threadIdx.x;
-  const int grp = lane >> 4, sub = lane & (SR_D - 1);         // the expanded vertex this lane works for, its slot of the adjacency row
   const int64_t slot = blockIdx.x;
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
   const int S = a.S, L = a.L;
@@ -251,6 +266,9 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     return h;
   };
 
+#ifdef TRK_SEARCH_CLOCKS
+  if (lane == 0) atomicMin((unsigned long long *)(a.next + 40), wall_clock64());
+#endif
   for (;;) {
     // the ticket: one atomic that every lane executes (see the header)
     uint32_t qi = atomicAdd(a.next, lane == 0 ? 1u : 0u);
@@ -269,37 +287,44 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     SRec *tb = (SRec *)cb;
     double *ff = (double *)(cb + ((size_t)32 << lc));
     int32_t *fv = (int32_t *)(cb + ((size_t)40 << lc));
-    int count = 0, n_near = 0, n_far = 0;
+    int count = 0, n_near = 0, n_far = 0, n_dead = 0;
     unsigned grows = 0;
 
-    // v's record: linear probing from the first record of v's line; a record of another generation ends the probe (free).
+    // v's record: linear probing from the first record of v's line; a record of another generation ends the probe (free).  The
+    // first line is loaded by the CALLER (slot0 -> r0, r1) together with whatever else it needs of v, so that a lookup adds no
+    // round trip of its own; resolve() goes on from there -- to further lines only when both records belong to other vertices.
     // found: rec / p are the record and its index; not found: p is the free record the probe stopped at.
-    auto lookup = [&](int32_t v, bool on, SRec &rec, uint32_t &p) -> bool {
+    auto slot0 = [&](int32_t v) -> uint32_t { return (((uint32_t)v * 2654435761u) >> (33 - lc)) << 1; };
+    auto resolve = [&](int32_t v, SRec r0, SRec r1, SRec &rec, uint32_t &p) -> bool {
       const uint32_t m = (1u << lc) - 1u;
-      p = (((uint32_t)v * 2654435761u) >> (33 - lc)) << 1;
-      bool hit = false;
-      if (on) {
-        for (uint32_t t = 0; t <= m; t += 2) {
-          const SRec r0 = tb[p], r1 = tb[p + 1];
-          if ((r0.tag >> 1) != gen) break;
-          if (r0.key == (uint32_t)v) { rec = r0; hit = true; break; }
-          if ((r1.tag >> 1) != gen) { p = p + 1; break; }
-          if (r1.key == (uint32_t)v) { rec = r1; p = p + 1; hit = true; break; }
-          p = (p + 2) & m;
-        }
+      for (uint32_t t = 0; t <= m; t += 2) {
+        if ((r0.tag >> 1) != gen) return false;
+        if (r0.key == (uint32_t)v) { rec = r0; return true; }
+        if ((r1.tag >> 1) != gen) { p = p + 1; return false; }
+        if (r1.key == (uint32_t)v) { rec = r1; p = p + 1; return true; }
+        p = (p + 2) & m;
+        r0 = tb[p]; r1 = tb[p + 1];
       }
-      return hit;
+      return false;
+    };
+    auto lookup = [&](int32_t v, bool on, SRec &rec, uint32_t &p) -> bool {
+      p = slot0(v);
+      if (!on) return false;
+      const SRec r0 = tb[p], r1 = tb[p + 1];
+      return resolve(v, r0, r1, rec, p);
     };
     // a free record of table `t` (2^tlc records) for vertex v, on its probe path from p on: lanes that want the same record in the
     // same call settle it through an LDS word (last writer wins; the others probe on).  Wave-uniform call; the winner marks the
-    // record taken (key, generation) at once, the caller fills in the rest.
-    auto claim = [&](SRec *t, int tlc, bool want, int32_t v, uint32_t p) -> uint32_t {
+    // record taken (key, generation) at once, the caller fills in the rest.  known_free: p is where a lookup of this step ended, so
+    // the first round need not look at it again (a dependent load saved per pass).
+    auto claim = [&](SRec *t, int tlc, bool want, int32_t v, uint32_t p, bool known_free) -> uint32_t {
       const uint32_t m = (1u << tlc) - 1u;
       bool pending = want;
       for (int round = 0; round < 1024; round++) {
         if (!__ballot(pending)) break;
         if (pending) {
-          for (uint32_t k = 0; k <= m; k++) { if ((t[p].tag >> 1) != gen) break; p = (p + 1) & m; }
+          if (round > 0 || !known_free)
+            for (uint32_t k = 0; k <= m; k++) { if ((t[p].tag >> 1) != gen) break; p = (p + 1) & m; }
           tab_owner[p & (SR_TAB - 1)] = (uint32_t)lane;
         }
         __syncthreads();
@@ -328,7 +353,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
         const SRec rc = tb[i0 + lane];
         const bool mine = (rc.tag >> 1) == gen;
         const uint32_t p0 = (((uint32_t)rc.key * 2654435761u) >> (33 - nlc)) << 1;
-        const uint32_t p = claim(nt, nlc, mine, (int32_t)rc.key, p0);
+        const uint32_t p = claim(nt, nlc, mine, (int32_t)rc.key, p0, false);
         if (mine) { nt[p].g = rc.g; nt[p].h = rc.h; nt[p].parent = rc.parent; nt[p].parent_edge = rc.parent_edge; nt[p].tag = rc.tag; }
       }
       for (int i = lane; i < n_far; i += 64) { nff[i] = ff[i]; nfv[i] = fv[i]; }
@@ -352,17 +377,21 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
         SRec none;
         uint32_t p0 = 0;
         (void)lookup(start, lane == 0, none, p0);
-        if (lane == 0) { tb[p0] = SRec{0.0, h0, start, -1, (uint32_t)start, gen << 1}; nf[0] = h0; nv[0] = start; }
+        if (lane == 0) { tb[p0] = SRec{0.0, h0, start, -1, (uint32_t)start, gen << 1}; nf[0] = h0; nv[0] = start | ((int32_t)a.deg[start] << SR_VBITS); }
       }
       n_near = 1; count = 1;
       __syncthreads();
 #ifdef TRK_SEARCH_CLOCKS
-      unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, t_last = wall_clock64();
+      unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, t_last = wall_clock64(), n_steps = 0, n_passes = 0;
 #endif
       for (;;) {
         SR_CLK(4);
+#ifdef TRK_SEARCH_CLOCKS
+        n_steps++;
+#endif
         if ((int64_t)exp_q >= a.max_pops) { result = SR_FALLBACK; break; }
-        if (n_near == 0) {
+        if (n_near == n_dead) {                                // (entries taken off the list stay as dead slots until the list is next rewritten)
+          n_near = 0; n_dead = 0;
           if (n_far == 0) break;                               // the open list is empty: no path
           // ---- refill: raise T so that about half a list's worth of far's entries come in ----
           double mn = inf, mx = -inf;
@@ -414,65 +443,60 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
 #pragma unroll
           for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; f4[j] = i < n_near ? nf[i] : inf; }
 #pragma unroll
-          for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; if (i < n_near && (f4[j] < best || bi < 0)) { best = f4[j]; bi = i; } }
+          for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; if (f4[j] < best) { best = f4[j]; bi = i; } }      // (a dead slot holds +inf)
         }
-        int sel_i[SR_K], sel_u[SR_K];
+        int sel_i[SR_K], sel_u[SR_K], cum[SR_K + 1];
         int nsel = 0;
         bool taken = bi < 0;
+        cum[0] = 0;
+        const int bw = bi >= 0 ? nv[bi] : 0;                    // the lane's candidate word, read once for all rounds
+        const unsigned long long bbits = (unsigned long long)__double_as_longlong(best);   // (keys are >= 0: ordered as integers)
+        const uint32_t bhi = (uint32_t)(bbits >> 32), blo = (uint32_t)bbits;
 #pragma unroll
         for (int r = 0; r < SR_K; r++) {
-          sel_i[r] = -1; sel_u[r] = -1;
+          sel_i[r] = -1; sel_u[r] = -1; cum[r + 1] = cum[r];
           if (r < kbest && nsel == r) {
-            const double fm = sr_wave_min(taken ? inf : best);
-            const unsigned long long who = __ballot(!taken && best == fm);
+            const uint32_t mh = sr_wave_min_u32(taken ? 0xffffffffu : bhi);
+            const bool top = !taken && bhi == mh;
+            const uint32_t ml = sr_wave_min_u32(top ? blo : 0xffffffffu);
+            const unsigned long long who = __ballot(top && blo == ml);
             if (who) {
               const int src = __ffsll((long long)who) - 1;
-              sel_i[r] = __builtin_amdgcn_readlane(bi, src);
-              sel_u[r] = sr_u(nv[sel_i[r]]);
-              if (lane == src) taken = true;
-              nsel = r + 1;
+              const int i = __builtin_amdgcn_readlane(bi, src);
+              const int w = __builtin_amdgcn_readlane(bw, src);
+              const int u = w & ((1 << SR_VBITS) - 1), d = (int)((unsigned)w >> SR_VBITS);
+              // the goal ends the search when it is the minimum; further down the batch it stays on the list, with what follows it --
+              // and so does a vertex whose arcs the wave has no lanes left for
+              if (r == 0 || (u != goal && cum[r] + d <= 64)) {
+                sel_i[r] = i; sel_u[r] = u; cum[r + 1] = cum[r] + d;
+                if (lane == src) taken = true;
+                nsel = r + 1;
+              }
             }
           }
         }
-        // the goal ends the search when it is the minimum; found further down the batch it stays on the list, with what follows it
-#pragma unroll
-        for (int r = 1; r < SR_K; r++)
-          if (r < nsel && sel_u[r] == goal) nsel = r;
         __syncthreads();
-        // the entries leave the list, the highest index first (the last entry moves into the hole: never one still to be removed)
-        {
-          int idx[SR_K];
+        // the entries leave the list: their slots are marked dead (+inf) where they are -- no entry moves, no step depends on the one
+        // before -- and are dropped when the list is next rewritten (near full: see the append)
 #pragma unroll
-          for (int r = 0; r < SR_K; r++) idx[r] = r < nsel ? sel_i[r] : -1;
-#pragma unroll
-          for (int p = 0; p < SR_K; p++)
-#pragma unroll
-            for (int q = 0; q + 1 < SR_K - p; q++)
-              if (idx[q] < idx[q + 1]) { const int t = idx[q]; idx[q] = idx[q + 1]; idx[q + 1] = t; }
-#pragma unroll
-          for (int r = 0; r < SR_K; r++) {
-            if (idx[r] >= 0) {
-              if (lane == 0) { nf[idx[r]] = nf[n_near - 1]; nv[idx[r]] = nv[n_near - 1]; }
-              n_near--;
-            }
-          }
-        }
+        for (int r = 0; r < SR_K; r++) if (lane == r && r < nsel) nf[sel_i[r]] = inf;
+        n_dead += nsel;
         __syncthreads();
         SR_CLK(1);
-        // ---- the popped vertices' records and first adjacency rows, a group of 16 lanes each: one round trip; closed ones (stale
-        // entries) and repeats are dropped ----
-        int my_u = -1;
+        // ---- the popped vertices' records and first adjacency rows, a group of lanes each (as many as the row has arcs): one round
+        // trip; closed ones (stale entries) and repeats are dropped ----
+        int my_u = -1, grp = -1, sub = 0, gbase = 0;
 #pragma unroll
-        for (int r = 0; r < SR_K; r++) if (grp == r && r < nsel) my_u = sel_u[r];
+        for (int r = 0; r < SR_K; r++) if (r < nsel && lane >= cum[r] && lane < cum[r + 1]) { my_u = sel_u[r]; grp = r; sub = lane - cum[r]; gbase = cum[r]; }
         SArc arc = my_u >= 0 ? a.rows[(int64_t)my_u * SR_D + sub] : no_arc;
         SRec urec = SRec{0.0, 0.0, -1, -1, 0u, 1u};
         uint32_t pu = 0;
         bool live = lookup(my_u, my_u >= 0, urec, pu) && (urec.tag & 1u) == 0u;
 #pragma unroll
-        for (int r = 0; r + 1 < SR_K; r++) if (grp > r && r < nsel && my_u == sel_u[r]) live = false;
+        for (int r = 0; r + 1 < SR_K; r++) if (grp > r && my_u == sel_u[r]) live = false;
         if (live && sub == 0) tb[pu].tag = (gen << 1) | 1u;
         const unsigned long long mlive = __ballot(live);
-        const int n_live = __popcll(mlive & 0x0001000100010001ull);
+        const int n_live = __popcll(__ballot(live && sub == 0));
         exp_q += (unsigned long long)n_live;
         if ((mlive & 1ull) && sel_u[0] == goal) { result = SR_FOUND; break; }
         const double ug = urec.g;
@@ -482,19 +506,25 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
         for (int pass = 0; pass < (1 << 20) && !failed; pass++) {
           // a step may add a record per lane: the table moves before it could pass three quarters (no lane holds a position here)
           if (count + 64 > (3 << lc) / 4 && !grow()) { failed = true; break; }
+#ifdef TRK_SEARCH_CLOCKS
+          n_passes++;
+#endif
           const bool has = act && arc.v >= 0;
           const bool more = act && arc.v == SR_ARC_MORE;
           bool cand = false, push = false, fresh = false;
           double fp = 0.0, gv = 0.0, hh = 0.0;
           int32_t vp = 0, pe = -1;
-          uint32_t pv = 0;
+          uint32_t pv = 0, vd = 0;
           if (has) {
             // everything the relaxation can need is requested at once, whether or not it turns out to be needed: validity bytes,
             // the neighbour's record (the line its probe starts at), and the rows of its heuristic
+            pv = slot0(arc.v);
+            const SRec r0 = tb[pv], r1 = tb[pv + 1];
             const uint8_t es = a.estat[arc.e], vs = a.vstat[arc.v];
+            vd = a.deg[arc.v];
             const double hv = heuristic(arc.v);
             SRec nn = SRec{0.0, 0.0, -1, -1, 0u, 0u};
-            const bool seen = lookup(arc.v, true, nn, pv);
+            const bool seen = resolve(arc.v, r0, r1, nn, pv);
             if (es != SR_INVALID && vs != SR_INVALID) {
               gv = ug + arc.w;
               if (!seen || gv < nn.g) {
@@ -504,7 +534,20 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
             }
           }
           // ---- two lanes with the same neighbour: the smaller cost wins (the lower lane among equals), the others stand down ----
+          // (first the cheap question "do any two of them name the same neighbour at all?": every candidate lane leaves its number in a
+          // byte slot of its neighbour's hash -- 1 024 slots in the cost table's place -- and looks whether it is still there; two lanes
+          // with one neighbour share the slot, so one of them finds the other's number.  Four times in five nobody does, and the
+          // protocol below -- four barriers a round -- is skipped.)
+          bool contested = false;
           if (n_live > 1) {
+            uint8_t *quick = (uint8_t *)tab_key;
+            const unsigned hq = ((unsigned)vp * 2654435761u) >> 22;
+            if (cand) quick[hq] = (uint8_t)lane;
+            __syncthreads();
+            contested = __ballot(cand && quick[hq] != (uint8_t)lane) != 0ull;
+            __syncthreads();
+          }
+          if (contested) {
             bool open = cand;
             const unsigned long long key = (unsigned long long)__double_as_longlong(gv);      // (costs are >= 0: ordered as integers)
             const unsigned hs = ((unsigned)vp * 2654435761u) >> 25;
@@ -528,7 +571,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           // ---- the winners write: a vertex reached before in place, a new one into a free record of its probe path ----
           {
             const unsigned long long mnew = __ballot(cand && fresh);
-            if (mnew) pv = claim(tb, lc, cand && fresh, vp, pv);
+            if (mnew) pv = claim(tb, lc, cand && fresh, vp, pv, true);
             count += __popcll(mnew);
             if (cand) {
               SRec *rp = tb + pv;
@@ -541,43 +584,51 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           unsigned long long mn_ = __ballot(push && fp < T);
           SR_CLK(3);
           while (n_near + __popcll(mn_) > SR_CAP) {
-            // near is full: T drops halfway towards its smallest key, what lies above moves to far
-            double lo = inf, hi = -inf;
-            for (int i = lane; i < n_near; i += 64) { const double f = nf[i]; lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
-            lo = sr_wave_min(lo); hi = sr_wave_max(hi);
-            const double top = T < inf ? T : hi;
-            const double Tn = lo + (top - lo) * 0.5;
-            if (!(Tn > lo) || !(Tn < top)) { failed = true; break; }
-            if (n_far + n_near > (1 << lc) && !grow()) { failed = true; break; }
+            // near is full.  With dead slots in it: they are squeezed out, nothing else changes.  Without: T drops halfway towards
+            // its smallest key, what lies above moves to far
+            const bool spill = n_dead == 0;
+            double Tn = inf;
+            if (spill) {
+              double lo = inf, hi = -inf;
+              for (int i = lane; i < n_near; i += 64) { const double f = nf[i]; lo = f < lo ? f : lo; hi = f > hi ? f : hi; }
+              lo = sr_wave_min(lo); hi = sr_wave_max(hi);
+              const double top = T < inf ? T : hi;
+              Tn = lo + (top - lo) * 0.5;
+              if (!(Tn > lo) || !(Tn < top)) { failed = true; break; }
+              if (n_far + n_near > (1 << lc) && !grow()) { failed = true; break; }
+            }
             int keep = 0;
             for (int c0 = 0; c0 < n_near; c0 += 64) {
               const int i = c0 + lane;
               const bool on = i < n_near;
-              const double f = on ? nf[i] : 0.0;
+              const double f = on ? nf[i] : inf;
               const int32_t v = on ? nv[i] : 0;
               __syncthreads();
-              const bool stay = on && f < Tn, out = on && !stay;
+              const bool stay = f < Tn, out = !stay && f < inf;
               const unsigned long long ms = __ballot(stay), mo = __ballot(out);
               if (stay) { const int p = keep + __popcll(ms & below); nf[p] = f; nv[p] = v; }
               if (out) { const int p = n_far + __popcll(mo & below); ff[p] = f; fv[p] = v; }
               keep += __popcll(ms); n_far += __popcll(mo);
               __syncthreads();
             }
-            n_near = keep;
-            T = Tn;
-            moves++;
-            mn_ = __ballot(push && fp < T);
+            n_near = keep; n_dead = 0;
+            if (spill) {
+              T = Tn;
+              moves++;
+              mn_ = __ballot(push && fp < T);
+            }
           }
           if (failed) break;
           const unsigned long long mf_ = __ballot(push && !(fp < T));
           if (n_far + __popcll(mf_) > (1 << lc) && !grow()) { failed = true; break; }
-          if (push && fp < T) { const int p = n_near + __popcll(mn_ & below); nf[p] = fp; nv[p] = vp; }
-          else if (push) { const int p = n_far + __popcll(mf_ & below); ff[p] = fp; fv[p] = vp; }
+          const int32_t wp = vp | (int32_t)(vd << SR_VBITS);
+          if (push && fp < T) { const int p = n_near + __popcll(mn_ & below); nf[p] = fp; nv[p] = wp; }
+          else if (push) { const int p = n_far + __popcll(mf_ & below); ff[p] = fp; fv[p] = wp; }
           n_near += __popcll(mn_); n_far += __popcll(mf_);
           __syncthreads();
           // ---- a vertex with more arcs than a row holds: its group goes on to the row its last slot names ----
           if (!__ballot(more)) break;
-          const int nrow = __shfl(more ? arc.e : -1, (lane & 48) | (SR_D - 1), 64);
+          const int nrow = __shfl(more ? arc.e : -1, gbase + (SR_D - 1), 64);
           act = act && nrow >= 0;
           arc = act ? a.rows[(int64_t)nrow * SR_D + sub] : no_arc;
         }
@@ -587,6 +638,10 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
       if (lane == 0) {
         for (int i = 0; i < 6; i++) atomicAdd((unsigned long long *)(a.next + 16) + i, clk[i]);
         atomicMax((unsigned long long *)(a.next + 16) + 6, clk[0] + clk[1] + clk[2] + clk[3] + clk[4]);
+        // when searches end, in 2 ms buckets since the first wave's start (words 40 .. 41: that start; 44 .. : 40 buckets of counts,
+        // 84 .. : 40 buckets of the expansions of the searches that ended there)
+        atomicAdd((unsigned long long *)(a.next + 32), n_steps);
+        atomicAdd((unsigned long long *)(a.next + 32) + 1, n_passes);
       }
 #endif
     }
@@ -629,11 +684,21 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     if (cls > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
       a.found[qi] = (uint8_t)result;
+      if (result == SR_FALLBACK && a.handback) __hip_atomic_store(a.handback + qi, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicAdd(a.expanded, exp_q);
       if (moves) atomicAdd(a.next + 4, moves);
       if (grows) atomicAdd(a.next + 5, grows);
       atomicMax(a.next + 6, (uint32_t)count);
       if (cls > 0) sr_pool_release(a, cls, chunk);
+#ifdef TRK_SEARCH_CLOCKS
+      {
+        const unsigned long long t0_ = __hip_atomic_load((unsigned long long *)(a.next + 40), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned b_ = (unsigned)((wall_clock64() - t0_) / 200000ull);
+        if (b_ > 39u) b_ = 39u;
+        atomicAdd(a.next + 44 + b_, 1u);
+        atomicAdd(a.next + 84 + b_, (uint32_t)exp_q);
+      }
+#endif
     }
   }
 }

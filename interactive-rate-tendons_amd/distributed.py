@@ -151,7 +151,7 @@ class ShardedVertexValidator:
         # world_size * shard/64 words; bits of items >= M are zero.  unpack_bits(words, M) is the mask.
         return full if keep_on_device else full.cpu().numpy().view(np.uint64)
 
-    def run_with_rows(self, M, compact, rank=None, world_size=None):
+    def run_with_rows(self, M, compact, rank=None, world_size=None, codec=None):
         """run(), and a row of data per ACCEPTED candidate gathered with the mask: validate_candidates(first, count, n_words) returns
         (mask words, rows [count, w]) here -- device_candidate_validator(..., signatures=True): the candidates' backbone signatures,
         which tr_validate_edges_indexed_sig_dev takes instead of integrating the vertices again on every rank -- and
@@ -169,6 +169,18 @@ class ShardedVertexValidator:
         words = full.cpu().numpy().view(np.uint64).reshape(world_size, shard // WORD)
         counts = [int(np.unpackbits(words[r].view(np.uint8)).sum()) for r in range(world_size)]
         mine = compact(local, n_real, rows)
+        if codec is not None:
+            # the rows travel packed (signature_wire_codec: 104 instead of 576 bytes per vertex at 129 backbone points) unless some
+            # rank holds a row it cannot code -- then every rank sends its rows as they are (one small all-reduce decides)
+            packed, bad = codec.pack(mine)
+            if dist.is_available() and dist.is_initialized() and world_size > 1:
+                import torch
+                flag = torch.tensor([bad], dtype=torch.int64, device=mine.device if dist.get_backend() != "gloo" else "cpu")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                bad = int(flag.item())
+            self.rows_on_the_wire = "raw" if bad else "packed"
+            if not bad:
+                return full, codec.unpack(allgather_rows(packed, counts))
         return full, allgather_rows(mine, counts)
 
 
@@ -192,6 +204,28 @@ def device_candidate_validator(engine, seed, box=None, tips=None, signatures=Fal
                 tips["tips"] = d_tips.view(count, 3)
         return bits
     return validate
+
+
+def signature_wire_codec(engine):
+    """codec for ShardedVertexValidator.run_with_rows on `engine`'s GPU: the accepted candidates' signature rows are delta-coded
+    before the all-gather and restored after it (tr_pack_signatures_dev / tr_unpack_signatures_dev).  None when the context has
+    no signatures to hand over or TENDON_HIP_SIG_WIRE=raw asks for the rows as they are (A/B)."""
+    import os
+    if os.environ.get("TENDON_HIP_SIG_WIRE", "") == "raw" or engine.signature_words() == 0:
+        return None
+
+    class Codec:
+        @staticmethod
+        def pack(rows):
+            if rows.shape[0] == 0:
+                import torch
+                return torch.empty((0, engine.signature_packed_words()), dtype=torch.int32, device=rows.device), 0
+            return engine.pack_signatures_dev(rows.contiguous())
+
+        @staticmethod
+        def unpack(packed):
+            return engine.unpack_signatures_dev(packed.contiguous())
+    return Codec
 
 
 def device_row_compactor(engine):

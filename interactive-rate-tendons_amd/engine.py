@@ -447,6 +447,31 @@ class Engine:
         """uint32 words per row of the vertex signature arrays (tr_signature_words); 0: this context cannot hand signatures over."""
         return int(self.lib.tr_signature_words(self._ctx))
 
+    def signature_packed_words(self):
+        """uint32 words of a signature row as it travels between ranks (tr_signature_packed_words: first cell + 6 bits per further point)."""
+        return int(self.lib.tr_signature_packed_words(self._ctx))
+
+    def pack_signatures_dev(self, d_sig, stream=None):
+        """Signature rows [n, signature_words()] (int32, on this GPU) -> (packed rows [n, signature_packed_words()], rows that could not
+        be coded: the caller sends the rows as they are if there is one).  tr_pack_signatures_dev; synchronises the stream."""
+        torch = _torch()
+        n = int(d_sig.shape[0])
+        out = torch.empty((n, self.signature_packed_words()), dtype=torch.int32, device=d_sig.device)
+        bad = C.c_int64(0)
+        L.check(self._ctx, self.lib.tr_pack_signatures_dev(self._ctx, C.c_void_p(d_sig.data_ptr()), n, C.c_void_p(out.data_ptr()), C.byref(bad),
+                                                           self._stream_ptr(stream)))
+        return out, int(bad.value)
+
+    def unpack_signatures_dev(self, d_packed, stream=None):
+        """The inverse: packed rows [n, signature_packed_words()] -> signature rows [n, signature_words()] (tr_unpack_signatures_dev; the
+        padding words of a row beyond the backbone's points are left as allocated: nothing reads them)."""
+        torch = _torch()
+        n = int(d_packed.shape[0])
+        out = torch.empty((n, self.signature_words()), dtype=torch.int32, device=d_packed.device)
+        L.check(self._ctx, self.lib.tr_unpack_signatures_dev(self._ctx, C.c_void_p(d_packed.data_ptr()), n, C.c_void_p(out.data_ptr()),
+                                                             self._stream_ptr(stream)))
+        return out
+
     def validate_candidates_sig_dev(self, seed, first, count, d_bits, d_sig, d_tips=None, box=None, stream=None):
         """validate_candidates_dev that also writes every candidate's backbone cell signature (d_sig: int32 tensor, count x
         signature_words()): compacted like the accepted states, the rows spare validate_edges_indexed_dev its vertex pass."""

@@ -52,6 +52,7 @@ def main():
                 res.setdefault(key, []).append(dt)
                 res[key + "_expanded"] = prm.stats["expanded"]
                 res[key + "_rounds"] = prm.stats["rounds"]
+                res[key + "_where"] = dict(prm.search_stats)
                 if mode == "host":
                     ref = r
                 else:

@@ -140,6 +140,11 @@ def test_config4_workload_world1_rccl_and_world2_rehearsal_agree():
     assert 0 < one["config"]["valid_vertices"] < 1 << 15 and 0 < one["config"]["valid_edges"] <= one["config"]["candidate_edges"]
     assert set(two["config"]["collectives_alone"]) == {"vertex_mask", "knn_rows", "edge_mask", "vertex_signatures"}
     assert one["config"]["vertex_signatures_handed_over"] and two["config"]["vertex_signatures_handed_over"]
+    assert one["config"]["signature_rows_on_the_wire"] == "packed" and two["config"]["signature_rows_on_the_wire"] == "packed"
+    raw = _bench(["--gpus", "1"] + common, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TENDON_HIP_SIG_WIRE="raw")
+    assert raw["config"]["signature_rows_on_the_wire"] == "raw"
+    for key in ("valid_vertices", "candidate_edges", "valid_edges", "vertex_mask_crc32", "edge_list_crc32"):
+        assert one["config"][key] == raw["config"][key], key
     # ... and without the signature hand-over (every rank's edge call integrates the vertices itself): the same build
     # ... and through the host-array forms of every phase (tr_knn_range / tr_knn_table_edges / tr_validate_edges_indexed): the same build
     plain = _bench(["--gpus", "1"] + common, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", TENDON_BENCH_NO_SIGNATURES="1")
@@ -166,3 +171,6 @@ def test_config4_per_shard_projection_on_one_gpu():
         assert w["compute_critical_path_ms"] > 0 and 0 <= w["replicated_fraction_of_critical_path"] < 1
         assert set(w["allgather_bytes_per_rank"]) == {"vertex_mask", "vertex_signatures", "knn_rows", "edge_mask"}
     assert 0 < out["valid_vertices"] < 1 << 15 and out["candidate_edges"] > 0
+    sw = out["signature_wire"]
+    assert sw["raw_row_bytes"] == 576 and sw["packed_row_bytes"] == 104 and sw["pack_all_rows_ms"] > 0 and sw["unpack_all_rows_ms"] > 0
+    assert out["emulated_worlds"]["4"]["signature_row_bytes_on_the_wire"] == 104

@@ -143,6 +143,56 @@ def test_device_form_and_shard_form(irt):
     assert torch.equal(out[:100], rows[:100]) and int(out[100:].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("which", ["config3", "config2_rotating"])
+def test_signature_rows_survive_the_wire_coding(irt, which):
+    """tr_pack_signatures_dev / tr_unpack_signatures_dev: the accepted candidates' signature rows delta-coded for the all-gather of a
+    sharded build (first cell + 6 bits per further point: 104 instead of 576 bytes at 129 points) come back word for word; rows that
+    cannot be coded -- an invalid candidate whose backbone leaves the voxel domain (SIG_BAD), a row with a jump of two cells -- are
+    counted, so that the caller sends them as they are.  Through distributed.signature_wire_codec + run_with_rows: same rows."""
+    import torch
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3() if which == "config3" else W.robot_config2()
+    if which != "config3":
+        robot.enable_rotation = True
+    chk = _setup(irt, robot)
+    e = chk.engine
+    sw, pw, P = e.signature_words(), e.signature_packed_words(), e.num_points
+    assert sw == 144 and P == 129 and pw == 26 and pw % 2 == 0
+    M = 30000 + 13
+    validate = D.device_candidate_validator(e, 31, signatures=True)
+    bits, sig = validate(0, M, (M + 63) // 64)
+    mine = D.device_row_compactor(e)(bits, M, sig)
+    n = mine.shape[0]
+    assert 0.3 * M < n < M
+    packed, bad = e.pack_signatures_dev(mine)
+    assert bad == 0 and packed.shape == (n, pw)
+    back = e.unpack_signatures_dev(packed)
+    assert torch.equal(back[:, :P], mine[:, :P])
+    # the coding itself, on the host: first word, then (d + 1) per axis in 2-bit fields, five points to a word, the sixteenth in the top bits
+    row = mine[7, :P].cpu().numpy().astype(np.int64)
+    cell = np.stack([row & 1023, (row >> 10) & 1023, (row >> 20) & 1023], 1)
+    code = ((np.diff(cell, axis=0) + 1) * np.array([1, 4, 16])).sum(1)
+    pk = packed[7].cpu().numpy().view(np.uint32).astype(np.uint64)
+    assert pk[0] == row[0]
+    for j, c in enumerate(code):
+        g, q = divmod(j, 16)
+        w3 = pk[1 + 3 * g: 4 + 3 * g]
+        got = (int(w3[q // 5]) >> (6 * (q % 5))) & 63 if q < 15 else (int(w3[0]) >> 30) | ((int(w3[1]) >> 30) << 2) | ((int(w3[2]) >> 30) << 4)
+        assert got == c, (j, got, c)
+    # rows that cannot be coded are reported: a two-cell jump, a point outside the domain
+    broken = mine[:64].clone()
+    broken[3, 40] = (broken[3, 40] + 2) & 0x3FFFFFFF if int(broken[3, 40] & 1023) < 1000 else broken[3, 40] - 2
+    broken[9, 100] = broken[9, 100] | (1 << 30)
+    _, bad = e.pack_signatures_dev(broken)
+    assert bad >= 2
+    # through the sharded validator: world size 1 packs and unpacks on the way (what every rank does around the all-gather)
+    v = D.ShardedVertexValidator(robot, seed=31, device="cuda", validate_candidates=validate)
+    full, rows = v.run_with_rows(M, D.device_row_compactor(e), rank=0, world_size=1, codec=D.signature_wire_codec(e))
+    assert v.rows_on_the_wire == "packed" and torch.equal(rows[:, :P], mine[:, :P]) and torch.equal(full[: bits.numel()], bits)
+    empty, bad = D.signature_wire_codec(e).pack(mine[:0])
+    assert empty.shape == (0, pw) and bad == 0
+
+
 def test_roadmap_builder_uses_the_device_phase(irt):
     W, D = irt.workloads, irt.distributed
     robot = W.robot_config3()

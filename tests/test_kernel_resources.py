@@ -122,6 +122,59 @@ def test_verdict_retract_kernel_occupancy_and_lds_address_space(tmp_path, n_tend
     assert asm.count("ds_read") + asm.count("ds_write") >= 30
 
 
+SEARCH_TU = r'''
+#include <hip/hip_runtime.h>
+#include "search_kernel.hpp"
+template __global__ void trk::roadmap_astar<%d>(trk::SearchArgs);
+'''
+
+
+@pytest.mark.parametrize("sx", [4, 12])
+def test_search_kernel_occupancy_and_single_ticket_site(tmp_path, sx):
+    """roadmap_astar: 16 waves per CU (<= 128 VGPRs; its LDS image is sized for that), no register spilled to scratch beyond a few
+    dwords, and ONE query loop: hipcc 7.2 once jump-threaded the back edge of that loop for the 63 lanes that did not draw the
+    ticket (`if (lane == 0) ticket = atomicAdd(..)`) into a copy of the loop that lane 0 was not part of -- cross-lane operations
+    without the lane that writes the list heads, a GPU memory fault.  The ticket is now an atomic every lane executes; a threaded
+    or duplicated loop would show as a second ticket site.  Returning dword adds in the listing: the ticket and the path buffer's."""
+    src = tmp_path / "ks.hip"
+    src.write_text(SEARCH_TU % sx)
+    base = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-I", CSRC, str(src)]
+    out = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "ks.o")], capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-2000:]
+    get = lambda key: int(re.search(key + r"[^:]*: (\d+)", out.stderr).group(1))
+    # (up to 4 state coordinates -- BASELINE's robots -- 16 waves per CU; the 12-coordinate form keeps more of a state row in registers)
+    assert get("Occupancy") >= (4 if sx == 4 else 3) and get("VGPRs") <= (128 if sx == 4 else 160) and get("AGPRs") == 0 and get("VGPRs Spill") == 0
+    assert get("ScratchSize") <= 64
+    asm = subprocess.run(base + ["-S", "-o", "-"], capture_output=True, text=True).stdout
+    returning_adds = re.findall(r"^\s*(?:global|flat)_atomic_add v\d+, .*\bsc0\b", asm, flags=re.M)
+    assert len(returning_adds) == 2, returning_adds
+
+
+EDGE_QUEUE_TU = r'''
+#include <hip/hip_runtime.h>
+#include "tr_types.hpp"
+#include "verdict_kernel.hpp"
+#include "edge_kernel.hpp"
+#include "edge_queue_kernel.hpp"
+template __global__ void trk::fk_edge_queue<4, false>(RobotK, const double*, const StepK*, int, const trk::VerdictArgs*, const trk::EdgeQueueArgs*,
+                                                      const trk::FusedSweepArgs*);
+'''
+
+
+def test_edge_queue_claim_sites_are_not_duplicated(tmp_path):
+    """fk_edge_queue holds the same loop shape (`if (lane == 0) { atomics }` -> broadcast -> loop back, eq_claim and the main
+    loop): its returning atomic adds appear once each in the listing -- the AVAIL and HEAD claims of eq_claim, the fold's
+    `remaining` decrement, the tail allocation of an edge's next level, and the counter of the verdict body's list of
+    configurations for the exact sweep.  A jump-threaded copy of one of those loops would duplicate its site."""
+    src = tmp_path / "kq.hip"
+    src.write_text(EDGE_QUEUE_TU)
+    asm = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "--cuda-device-only", "-I", CSRC,
+                          str(src), "-S", "-o", "-"], capture_output=True, text=True)
+    assert asm.returncode == 0, asm.stderr[-2000:]
+    returning_adds = re.findall(r"^\s*(?:global|flat)_atomic_add v\d+, .*\bsc0\b", asm.stdout, flags=re.M)
+    assert len(returning_adds) == 5, returning_adds
+
+
 def test_isa_counts_are_current():
     """profiles/isa_counts.json -- the flops per RK4 step bench.py prices the fp64-VALU roofline with -- must be the
     count of THIS source tree's gfx950 assembly (profiles/count_isa.py rewrites it)."""
