@@ -239,7 +239,8 @@ def secondary_metrics():
                 "edges": c3["edges"], "edges_validated_per_s": c3["edges_per_s"], "edges_validated_per_s_repeat_call": c3["edges_per_s_repeat"],
                 "edges_validated_per_s_vertex_signatures_handed_over": c3["edges_per_s_device_resident_signatures_handed_over"], "edge_fk_samples_per_s": c3["edge_fk_samples_per_s"],
                 "fk_samples_per_edge_mean": c3["fk_samples_per_edge"]["mean"], "connect_all_edges_s": q["connect_all_edges_s"],
-                "create_roadmap_s": c3["create_roadmap"]["seconds"]},
+                "create_roadmap_s": c3["create_roadmap"]["seconds"],
+                "edge_kernel_roofline": c3.get("edge_kernel_roofline")},
             "config5_10k_queries": {
                 "queries_per_s": q["default_schedule"]["queries_per_s"], "rounds": q["default_schedule"]["rounds"],
                 "queries_per_s_lazy": q["lazy"]["queries_per_s"], "lazy_rounds": q["lazy"]["rounds"], "lazy_items_checked": q["lazy"]["items_checked"],
@@ -247,7 +248,7 @@ def secondary_metrics():
                 "queries_per_s_eager_incl_revalidation": q["eager"]["queries_per_s_incl_revalidation"],
                 "revalidate_all_cached_sets_ms": q["eager"]["revalidate_all_ms"], "cached_sets": q["roadmap_vertices"] + q["roadmap_edges"],
                 "vertex_caches_built_per_s": c5["vertex_caches_built_per_s"], "edge_caches_built_per_s": c5["edge_caches_built_per_s"],
-                "solved_fraction": q["solved_fraction"]},
+                "rooflines": q.get("rooflines"), "solved_fraction": q["solved_fraction"]},
             "config4_on_one_gpu": config4_one_gpu_extras(),
             "config1_fk_only": r["config1"], "sphere_checker_checks_per_s": r["sphere_checker"]["checks_per_s"],
             "rotation_retraction_robot": {k: r["rotation_retraction_robot"][k] for k in ("robot", "checks_per_s", "edges", "edges_per_s",

@@ -107,6 +107,7 @@ def run(argv=None):
     import torch
     eng = chk.engine
     t_edges_sig = None
+    edge_roofline = None
     if eng.signature_words():
         nv, S, sw = len(states), eng.state_size, eng.signature_words()
         d_st = torch.empty(nv * S, dtype=torch.float64, device="cuda")
@@ -123,6 +124,23 @@ def run(argv=None):
                                            rb.mv.min_retraction_change, d_vertex_sig=d_sig)
             torch.cuda.synchronize(); t_edges_sig = min(t_edges_sig, time.perf_counter() - t0)
         assert ne == len(edges) and np.array_equal(irt.unpack_bits(d_bits.cpu().numpy().view(np.uint64), ne), valid)
+        # the edge kernel's roofline: one more such call under tr_profile_* (HIP events on its stream): every sample is one FK + sweep lane of
+        # the persistent fk_edge_queue launch (fp64-VALU bound: the hand-counted flops of an RK4 step x the steps of a backbone)
+        eng.profile_begin()
+        eng.validate_edges_indexed_dev(d_st, nv, d_ed, ne, d_bits, None, rb.mv.min_tension_change, rb.mv.min_rotation_change,
+                                       rb.mv.min_retraction_change, d_vertex_sig=d_sig)
+        torch.cuda.synchronize()
+        prof = eng.profile_read()["fk_verdict"]
+        sched = eng.edge_schedule_last()
+        eng.profile_end()
+        if sched["samples"] and prof["total_ms"] > 0:
+            import bench as _bench
+            fl = _bench.algorithmic_flops_per_rk4_step(len(robot.tendons)) * (eng.num_points - 1)
+            tf = sched["samples"] * fl / (prof["total_ms"] * 1e-3) / 1e12
+            edge_roofline = {"kernel": "fk_edge_queue<%d>" % len(robot.tendons), "bound": "fp64_valu", "samples": sched["samples"],
+                             "rounds_of_up_to_64": sched["rounds"], "algorithmic_flops_per_sample": fl, "kernel_ms": prof["total_ms"],
+                             "launches": prof["launches"], "achieved": tf, "peak": _bench.FP64_VALU_PEAK_TF, "unit": "TFLOP/s",
+                             "frac": tf / _bench.FP64_VALU_PEAK_TF}
         del d_st, d_sig, d_ed, d_bits
     # the host's exact search as the check of the edge list (0.8 s of cKDTree: after the timed calls, so that the edge phase follows the
     # neighbour search as it does in a build and not a second of GPU idle)
@@ -140,6 +158,7 @@ def run(argv=None):
             "edges_per_s": len(edges) / t["edges"]["seconds"], "edges_per_s_repeat": len(edges) / t_edges_repeat,
             "edges_per_s_device_resident_signatures_handed_over": (len(edges) / t_edges_sig) if t_edges_sig else None,
             "edge_fk_samples_per_s": t["edges"]["fk_samples"] / t["edges"]["seconds"],
+            "edge_kernel_roofline": edge_roofline,
             "edge_valid_fraction": float(valid.mean()),
             "fk_samples_per_edge": {"mean": float(nfk.mean()), "p50": float(np.median(nfk)), "max": int(nfk.max()),
                                     "histogram": {str(k_): int(c_) for k_, c_ in enumerate(np.bincount(nfk)) if c_}},
@@ -273,13 +292,31 @@ def run(argv=None):
     st_dflt = dict(prm.stats, searches=dict(prm.search_stats))
     assert np.array_equal(lazy["status"], dflt["status"]) and np.array_equal(lazy["cost"], dflt["cost"]) and np.array_equal(lazy["path_vertices"], dflt["path_vertices"])
     prm.clearValidity()
+    chk.engine.profile_begin()
     t0 = time.perf_counter()
     n_bad_v, n_bad_e = prm.revalidate()
     t_reval = time.perf_counter() - t0
+    k4e = chk.engine.profile_read()["cached_blocks_vs_grid"]
+    chk.engine.profile_end()
     t0 = time.perf_counter()
     eager = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
     t_eager = time.perf_counter() - t0
     st_eager = dict(prm.stats, searches=dict(prm.search_stats))
+    # the two HBM-side kernels of the loop against the 8 TB/s roofline, from events on their streams: K4 streams every cached set's
+    # block list (12 B per block + its offsets) past the L2-resident grid; K9's byte count per vertex expansion is tr_roadmap_profile's
+    HBM_PEAK = 8.0e12
+    nblk_all = int(vc_all["offsets"][-1] + ec_all["offsets"][-1])
+    k4_bytes = 12.0 * nblk_all + 8.0 * (len(states) + len(e_ok))
+    k4_roof = {"kernel": "cached_blocks_vs_grid", "bound": "hbm", "cached_sets": len(states) + int(len(e_ok)), "algorithmic_bytes": k4_bytes,
+               "kernel_ms": k4e["total_ms"], "launches": k4e["launches"],
+               "achieved": k4_bytes / (k4e["total_ms"] * 1e-3) / 1e9 if k4e["total_ms"] > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+    k4_roof["frac"] = k4_roof["achieved"] / k4_roof["peak"] if k4_roof["achieved"] else None
+    sp = dict(prm.search_profile)
+    k9_bytes = sp["expansions"] * sp["bytes_per_expansion"]
+    k9_roof = {"kernel": "roadmap_astar", "bound": "hbm (latency: one wave per search)", "expansions": sp["expansions"],
+               "algorithmic_bytes_per_expansion": sp["bytes_per_expansion"], "kernel_ms": sp["kernel_ms"], "launches": sp["launches"],
+               "achieved": k9_bytes / (sp["kernel_ms"] * 1e-3) / 1e9 if sp["kernel_ms"] > 0 else None, "peak": HBM_PEAK / 1e9, "unit": "GB/s"}
+    k9_roof["frac"] = k9_roof["achieved"] / k9_roof["peak"] if k9_roof["achieved"] else None
     # the same two calls with every graph search on the host threads (TENDON_HIP_SEARCH=host): the round-3 schedule, timed beside
     os.environ["TENDON_HIP_SEARCH"] = "host"
     os.environ["TENDON_HIP_LAZY_ONLY"] = "1"
@@ -314,6 +351,7 @@ def run(argv=None):
                     "invalid_vertices": n_bad_v, "invalid_edges": n_bad_e},
           "searches_on_host_threads_only": {"lazy_queries_per_s": nq / t_lazy_host, "eager_search_seconds": t_eager_host,
                                             "same_statuses_costs_paths": True},
+          "rooflines": {"cached_blocks_vs_grid": k4_roof, "roadmap_astar": k9_roof},
           "solved_fraction": float((lazy["status"] == 0).mean()), "no_path": int((lazy["status"] == 1).sum()),
           "invalid_endpoint": int((lazy["status"] >= 2).sum()),
           "path_vertices": {"mean": float(plen.mean()) if len(plen) else 0.0, "max": int(plen.max()) if len(plen) else 0}}

@@ -449,6 +449,11 @@ int tr_roadmap_fetch_paths(tr_roadmap *rm, int32_t *path_vertices, int64_t capac
  * (the reference's solutionComponent test, :2015-2044; labels recomputed on the device per round, see TENDON_HIP_COMPONENTS), out[7] times
  * a search on the device outgrew its table of per-vertex records and moved into a larger one from the shared pool. */
 int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[8]);
+/* The roadmap_astar launches of the last tr_roadmap_solve, timed with HIP events on the stream they ran on: out[0] their total
+ * milliseconds, out[1] their number, out[2] the vertex expansions they did, out[3] the ALGORITHMIC bytes of one expansion on this
+ * roadmap (the vertex's record and row header, and per arc: the arc, two validity bytes, the arc count, the neighbour's record read
+ * and written, its state and landmark rows) -- bench.py turns them into the kernel's HBM roofline fraction. */
+int tr_roadmap_profile(tr_roadmap *rm, double out[4]);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
  * of connectionStrategy_(v), `if (!getEdge(v, n)) connectVertices(v, n)`): the undirected edge set of the k-nearest
@@ -497,7 +502,7 @@ int tr_validate_edges_indexed_sig_dev(tr_ctx *ctx, const tr_space_params *sp, co
  * at 129 points).  tr_pack_signatures_dev packs n_rows rows (d_sig: n_rows x tr_signature_words) and reports in *n_uncodable the rows
  * it could not code (a point outside the voxel domain, or a larger step: never for vertices that passed the vertex phase) -- the
  * caller then sends the rows as they are; it synchronises `stream` (one counter read-back).  tr_unpack_signatures_dev restores the rows
- * word for word (the padding words of a row beyond the backbone's points are not written; nothing reads them). */
+ * word for word (the padding words of a row beyond the backbone's points come back as zeros; nothing reads them). */
 int tr_signature_packed_words(const tr_ctx *ctx);
 int tr_pack_signatures_dev(tr_ctx *ctx, const uint32_t *d_sig, int64_t n_rows, uint32_t *d_packed, int64_t *n_uncodable, void *stream);
 int tr_unpack_signatures_dev(tr_ctx *ctx, const uint32_t *d_packed, int64_t n_rows, uint32_t *d_sig, void *stream);

@@ -237,7 +237,9 @@ struct tr_roadmap {
     char *tables = nullptr;              // the slots' tables, then the pool's, class by class
     char *pool[trk::SR_CLASSES] = {nullptr, nullptr, nullptr, nullptr};
     char *qarena = nullptr;              // per-round arrays (queries, results, packed paths)
-    trk::SArc *d_rows = nullptr; double *d_states = nullptr; float *d_lm = nullptr;
+    trk::SArc *d_rows = nullptr; char *d_vrows = nullptr;        // adjacency rows; per vertex: state | landmark distances
+    int32_t row_bytes = 0;
+    char *d_fat = nullptr; size_t fat_bytes = 0; int32_t arc_bytes = 0; int64_t n_rows = 0;   // the rows the kernel reads (search_fat_rows)
     uint8_t *d_vstat = nullptr, *d_estat = nullptr, *d_deg = nullptr;
     uint32_t *d_ctl = nullptr;
     int32_t *d_qs = nullptr, *d_qg = nullptr, *d_poff = nullptr, *d_plen = nullptr, *d_pbuf = nullptr;
@@ -245,6 +247,9 @@ struct tr_roadmap {
     uint32_t *h_handback = nullptr, *d_handback = nullptr;   // pinned: the kernel marks a search here the moment it hands it back
     int64_t handback_cap = 0;
     double kernel_ms = 0, host_after_ms = 0;                   // of the last shared round: the kernel's span, the host threads' work after it
+    hipEvent_t ev[2] = {nullptr, nullptr};                     // around every roadmap_astar launch (tr_roadmap_profile)
+    bool ev_pending = false;
+    double st_kernel_ms = 0; int64_t st_launches = 0;          // of the last tr_roadmap_solve
     int64_t st_queries = 0, st_fallbacks = 0, st_host_share = 0, st_moves = 0, st_expanded = 0, st_grows = 0, st_max_records = 0;   // of the last tr_roadmap_solve
     int64_t in_flight = 0;               // queries of the launch that has not been collected yet
     bool budget_from_env = false;
@@ -252,7 +257,7 @@ struct tr_roadmap {
     int64_t budget = 0;                  // expansions per search before the kernel hands it back (0: not chosen yet); doubles when
                                          // more than a twentieth of a round came back -- a larger roadmap has longer searches
     std::vector<int32_t> h_qs, h_qg;     // host images of what the pending copies read
-    std::vector<float> h_padded;
+    std::vector<char> h_vrows;
   } ds;
   // connected components of the roadmap minus what is known invalid (component_labels): the edge list and the labels in HBM
   struct DevComp {
@@ -599,8 +604,10 @@ void free_search(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.arena) dev_cache().release(d.arena);
   if (d.tables) dev_cache().release(d.tables);
+  if (d.d_fat) dev_cache().release(d.d_fat);
   if (d.qarena) dev_cache().release(d.qarena);
   if (d.h_handback) (void)hipHostFree(d.h_handback);
+  for (hipEvent_t e : d.ev) if (e) (void)hipEventDestroy(e);
   d = tr_roadmap::DevSearch{};
 }
 
@@ -872,15 +879,14 @@ bool search_setup(tr_roadmap *r) {
   d.table_bytes = tables_bytes(slots);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int Lmax = trk::SR_MAXL;
-  const size_t b_rows = up((size_t)n_rows * D * sizeof(trk::SArc)), b_st = up((size_t)V * r->S * 8), b_lm = up((size_t)V * Lmax * 4),
+  const size_t b_rows = up((size_t)n_rows * D * sizeof(trk::SArc)), b_vr = up((size_t)V * trk::search_row_bytes(r->S, Lmax)),
                b_vs = up((size_t)V), b_es = up((size_t)std::max<int64_t>(r->E, 1));
-  if (dev_cache().alloc(dev, (void **)&d.arena, b_rows + b_st + b_lm + 2 * b_vs + b_es + d.ctl_bytes) != hipSuccess) {
+  if (dev_cache().alloc(dev, (void **)&d.arena, b_rows + b_vr + 2 * b_vs + b_es + d.ctl_bytes) != hipSuccess) {
     d.why = "out of device memory"; return false;
   }
   char *p = d.arena;
   d.d_rows = (trk::SArc *)p; p += b_rows;
-  d.d_states = (double *)p; p += b_st;
-  d.d_lm = (float *)p; p += b_lm;
+  d.d_vrows = p; p += b_vr;
   d.d_vstat = (uint8_t *)p; p += b_vs;
   d.d_estat = (uint8_t *)p; p += b_es;
   d.d_deg = (uint8_t *)p; p += b_vs;
@@ -895,7 +901,6 @@ bool search_setup(tr_roadmap *r) {
   // (generation 0 is nobody's: cleared once, never again until the generation counter would wrap)
   ok = ok && hipMemsetAsync(d.tables, 0, d.table_bytes, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_rows, rows.data(), (size_t)n_rows * D * sizeof(trk::SArc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
-       hipMemcpyAsync(d.d_states, r->states.data(), (size_t)V * r->S * 8, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipMemcpyAsync(d.d_deg, lanes.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
        hipStreamSynchronize(nullptr) == hipSuccess;
   laps.lap("tables cleared + graph uploaded");
@@ -903,8 +908,9 @@ bool search_setup(tr_roadmap *r) {
   if (std::getenv("TENDON_HIP_SEARCH_STATS"))
     std::fprintf(stderr, "[tendon_hip] search state: %lld slots x %zu KiB + pool %d / %d / %d tables = %.1f MiB (whatever the roadmap's size); roadmap: %lld rows of %d arcs (%lld continued), %.1f MiB\n",
                  (long long)slots, trk::search_chunk_bytes(d.lc0) >> 10, d.pool_n[1], d.pool_n[2], d.pool_n[3], (double)d.table_bytes / 1048576.0,
-                 (long long)n_rows, D, (long long)(n_rows - V), (double)(b_rows + b_st + b_lm + b_vs + b_es) / 1048576.0);
+                 (long long)n_rows, D, (long long)(n_rows - V), (double)(b_rows + b_vr + 2 * b_vs + b_es) / 1048576.0);
   d.lm_current = false;
+  d.n_rows = n_rows;
   d.state = 1;
   return true;
 }
@@ -959,16 +965,34 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
   qs.resize((size_t)nq); qg.resize((size_t)nq);
   for (int64_t j = 0; j < nq; j++) { qs[(size_t)j] = starts[active[klist[(size_t)j]]]; qg[(size_t)j] = goals[active[klist[(size_t)j]]]; }
   bool ok = true;
-  std::vector<float> &padded = d.h_padded;                        // (rows padded to a multiple of four with zeros: see the kernel's heuristic)
   if (!d.lm_current) {
-    const int Lp = (L + 3) & ~3;
-    const float *src = r->lm_d.data();
-    if (L && Lp != L) {
-      padded.assign((size_t)V * Lp, 0.0f);
-      for (int64_t v = 0; v < V; v++) std::memcpy(&padded[(size_t)v * Lp], &r->lm_d[(size_t)v * L], (size_t)L * 4);
-      src = padded.data();
+    // the vertices' rows: state | landmark distances (padded to a multiple of four floats with zeros, which bound nothing)
+    d.row_bytes = trk::search_row_bytes(r->S, L);
+    const int lm_off = trk::search_lm_offset(r->S);
+    std::vector<char> &rows = d.h_vrows;                          // (a member: the copy below may still be reading it when this returns)
+    rows.assign((size_t)V * d.row_bytes, 0);
+    for (int64_t v = 0; v < V; v++) {
+      char *row = rows.data() + (size_t)v * d.row_bytes;
+      std::memcpy(row, &r->states[(size_t)v * r->S], (size_t)r->S * 8);
+      if (L) std::memcpy(row + lm_off, &r->lm_d[(size_t)v * L], (size_t)L * 4);
     }
-    if (L) ok = hipMemcpyAsync(d.d_lm, src, (size_t)V * Lp * 4, hipMemcpyHostToDevice, nullptr) == hipSuccess;
+    ok = hipMemcpyAsync(d.d_vrows, rows.data(), rows.size(), hipMemcpyHostToDevice, nullptr) == hipSuccess;
+    // ... and the rows the kernel reads: every arc with a copy of its neighbour's row behind it (built on the device)
+    d.arc_bytes = trk::search_arc_bytes(r->S, L);
+    const size_t need = (size_t)d.n_rows * trk::SR_D * d.arc_bytes;
+    if (ok && need > d.fat_bytes) {
+      if (d.d_fat) dev_cache().release(d.d_fat);
+      d.d_fat = nullptr; d.fat_bytes = 0;
+      ok = dev_cache().alloc(dev, (void **)&d.d_fat, need) == hipSuccess;
+      if (ok) d.fat_bytes = need;
+    }
+    if (ok) {
+      const int64_t n_slots = d.n_rows * trk::SR_D;
+      hipLaunchKernelGGL(trk::search_fat_rows, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, nullptr, d.d_rows, n_slots, d.d_vrows, d.row_bytes,
+                         d.arc_bytes - (int)sizeof(trk::SArc), d.d_deg, d.d_fat, d.arc_bytes);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    if (!ok) return false;
     d.lm_current = true;
   }
   const bool shared_status = r->dc.status_current;               // this round's validity bytes are in HBM already (component_labels)
@@ -980,7 +1004,8 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
        hipMemsetAsync(d.d_ctl + 40, 0xff, 8, nullptr) == hipSuccess;       // (a -DTRK_SEARCH_CLOCKS build keeps the first wave's start there)
   if (!ok) return false;
   trk::SearchArgs a{};
-  a.rows = d.d_rows; a.states = d.d_states; a.lm = L ? d.d_lm : nullptr;
+  a.fat = d.d_fat; a.arc_bytes = d.arc_bytes; a.states = (const double *)d.d_vrows; a.lm = L ? (const float *)(d.d_vrows + trk::search_lm_offset(r->S)) : nullptr;
+  a.row_bytes = d.row_bytes;
   a.S = r->S; a.NT = r->NT; a.rot = r->rot; a.ret = r->ret; a.L = L;
   a.w_rot = r->w_rot; a.w_ret = r->w_ret; a.lm_slack = kLmSlack;
   a.vstat = shared_status ? r->dc.d_vstat : d.d_vstat; a.estat = shared_status ? r->dc.d_estat : d.d_estat; a.deg = d.d_deg; a.V = V; a.E = r->E;
@@ -993,8 +1018,11 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
   a.max_pops = budget > 0 ? budget : 16 * V + 1024;             // (uncapped: every vertex reopened a few times, far beyond what a search does)
   a.kbest = search_kbest();
   const unsigned grid = (unsigned)std::min<int64_t>(d.slots, nq);
+  if (!d.ev[0] && (hipEventCreate(&d.ev[0]) != hipSuccess || hipEventCreate(&d.ev[1]) != hipSuccess)) { d.ev[0] = d.ev[1] = nullptr; }
+  if (d.ev[0]) (void)hipEventRecord(d.ev[0], nullptr);
   hipLaunchKernelGGL(search_kernel_for(r->S), dim3(grid), dim3(64), trk::search_lds_bytes(), nullptr, a);
   if (hipGetLastError() != hipSuccess) return false;
+  if (d.ev[0]) { (void)hipEventRecord(d.ev[1], nullptr); d.ev_pending = true; }
   d.in_flight = nq;
   return true;
 }
@@ -1014,12 +1042,17 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
   bool ok = true;
   std::vector<uint8_t> res((size_t)nq);
   std::vector<int32_t> poff((size_t)nq), plen((size_t)nq);
-  uint32_t ctl[128] = {0};
+  uint32_t ctl[136] = {0};
   ok = hipMemcpy(ctl, d.d_ctl, sizeof(ctl), hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(res.data(), d.d_found, (size_t)nq, hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(poff.data(), d.d_poff, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess &&
        hipMemcpy(plen.data(), d.d_plen, (size_t)nq * 4, hipMemcpyDeviceToHost) == hipSuccess;
   if (!ok) { give_back(); return; }
+  if (d.ev_pending) {
+    float ms_ = 0.0f;
+    if (hipEventElapsedTime(&ms_, d.ev[0], d.ev[1]) == hipSuccess) { d.st_kernel_ms += (double)ms_; d.st_launches++; }
+    d.ev_pending = false;
+  }
   if (std::getenv("TENDON_HIP_SEARCH_STATS")) {                     // (non-zero only in a -DTRK_SEARCH_CLOCKS build)
     unsigned long long c[7];
     std::memcpy(c, &ctl[16], sizeof(c));
@@ -1028,6 +1061,10 @@ void device_search_collect(tr_roadmap *r, const std::vector<int64_t> &active, co
     std::memcpy(sp, &ctl[32], sizeof(sp));
     if (tot > 0) std::fprintf(stderr, "[tendon_hip] search steps: %llu steps, %llu passes, %.2f us per step\n", sp[0], sp[1], sp[0] ? tot * 1e-2 / (double)sp[0] : 0.0);
     if (tot > 0) {
+      unsigned long long rx[3];
+      std::memcpy(rx, &ctl[124], sizeof(rx));
+      std::fprintf(stderr, "[tendon_hip] inside arcs + rows + relax: loads + heuristic + lookup %.1f%%, conflicts %.1f%%, claims + writes %.1f%% (of all)\n",
+                   100.0 * rx[0] / tot, 100.0 * rx[1] / tot, 100.0 * rx[2] / tot);
       std::fprintf(stderr, "[tendon_hip] searches ended per 2 ms (count/expansions):");
       for (int b = 0; b < 40; b++) if (ctl[44 + b]) std::fprintf(stderr, " %d:%u/%u", 2 * b, ctl[44 + b], ctl[84 + b]);
       std::fprintf(stderr, "\n");
@@ -1332,6 +1369,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   r->path_off.assign((size_t)n_queries + 1, 0); r->path_v.clear();
   r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
   r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = r->ds.st_expanded = r->ds.st_grows = r->ds.st_max_records = 0;
+  r->ds.st_kernel_ms = 0; r->ds.st_launches = 0;
   r->dc.st_cut = 0;
   if (path_offsets) path_offsets[0] = 0;
   if (n_queries == 0) { if (stats) *stats = tr_roadmap_stats{0, 0, 0, 0}; return TR_OK; }
@@ -1576,15 +1614,10 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       host_search(&redo);
       const auto t3 = std::chrono::steady_clock::now();
       const auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-      // The two knobs follow the clock (answers do not depend on them).  Budget: the host threads were still searching long after the
-      // kernel had ended -> the kernel keeps more (x 1.5); they ran dry early and little came back -> it hands back sooner (x 0.75).
-      // Share: halved when the host's own share outlasted the kernel, raised when it was done in a fraction of the kernel's span.
+      // The host's share follows the clock (answers do not depend on it): halved when the host's own share outlasted the kernel,
+      // raised when it was done in a fraction of the kernel's span and nothing was left to do after it.
       const double t_kernel = ms(t_round, t_kernel_done), t_after = std::max(0.0, ms(t_kernel_done, t3)), t_share = n_share ? ms(t0, t_share_done) : 0.0;
       r->ds.kernel_ms = t_kernel; r->ds.host_after_ms = t_after;
-      if (smode != 2 && !r->ds.budget_from_env && r->ds.budget > 0) {
-        if (t_after > 0.25 * t_kernel) r->ds.budget = std::min<int64_t>(16 * r->V, r->ds.budget + r->ds.budget / 2);
-        else if (t_after < 0.05 * t_kernel && (n_streamed + (int64_t)redo.size()) * 100 < n_dev) r->ds.budget = std::max<int64_t>(1000, r->ds.budget - r->ds.budget / 4);
-      }
       if (smode != 2 && !std::getenv("TENDON_HIP_SEARCH_HOST_SHARE") && n_share > 0) {
         if (t_share > t_kernel) r->ds.share = std::max(0.0025, r->ds.share * 0.5);
         else if (t_share < 0.4 * t_kernel && t_after < 0.1 * t_kernel) r->ds.share = std::min(0.08, r->ds.share * 1.5);
@@ -1703,6 +1736,18 @@ int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[8]) {
   out[0] = r->ds.st_queries; out[1] = r->ds.st_fallbacks; out[2] = r->ds.st_host_share; out[3] = r->ds.st_moves;
   out[4] = r->ds.st_expanded; out[5] = r->st_expanded - r->ds.st_expanded;
   out[6] = r->dc.st_cut; out[7] = r->ds.st_grows;
+  return TR_OK;
+}
+
+int tr_roadmap_profile(tr_roadmap *r, double out[4]) {
+  if (!r || !out) return TR_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock_(r->mu);
+  const double deg = r->V > 0 ? (double)r->adj.size() / (double)r->V : 0.0;
+  const int L = r->lm_n > 0 ? r->lm_n : 0;
+  out[0] = r->ds.st_kernel_ms; out[1] = (double)r->ds.st_launches; out[2] = (double)r->ds.st_expanded;
+  // per expansion: the vertex's record and row header, per arc the arc, two validity bytes, the arc count, the neighbour's record read
+  // and written, its state and landmark rows
+  out[3] = 48.0 + deg * (16.0 + 2.0 + 1.0 + 32.0 + 8.0 * r->S + 4.0 * L + 32.0);
   return TR_OK;
 }
 

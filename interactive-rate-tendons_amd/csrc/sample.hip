@@ -124,7 +124,8 @@ __global__ void compact_finish(SampleCounters *ctr, int64_t capacity, uint64_t i
   else ctr->have = (unsigned long long)capacity;         // ->tried was written by the row that filled the last position
 }
 
-// one thread per (row, group of 16 points): points 16 g + 1 .. 16 g + 16 against their predecessors
+// one thread per (row, group of 16 points): points 16 g + 1 .. 16 g + 16 against their predecessors; the row's words 16 g .. 16 g + 15
+// come in as four 16-byte loads (rows start on 64-byte boundaries), word 16 g + 16 as one more
 __global__ __launch_bounds__(256) void pack_signatures_kernel(const uint32_t *__restrict__ sig, int64_t n_rows, int P, int64_t stride, int G, int PW,
                                                               uint32_t *__restrict__ packed, unsigned long long *__restrict__ bad) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -132,26 +133,32 @@ __global__ __launch_bounds__(256) void pack_signatures_kernel(const uint32_t *__
   const int64_t row = t / G;
   const int g = (int)(t - row * G);
   const uint32_t *in = sig + row * stride;
-  uint32_t prev = in[16 * g];
-  bool ok = !(prev & (1u << 30));
+  uint32_t w[17];
+  {
+    const uint4 *in4 = reinterpret_cast<const uint4 *>(in + 16 * g);
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const uint4 v = in4[q]; w[4 * q] = v.x; w[4 * q + 1] = v.y; w[4 * q + 2] = v.z; w[4 * q + 3] = v.w; }
+    w[16] = 16 * g + 16 < P ? in[16 * g + 16] : 0u;
+  }
+  bool ok = !(w[0] & (1u << 30));
   // three words: five 6-bit codes each (bits 0 .. 29), the sixteenth code's three 2-bit fields in their top bits
   uint32_t w3[3] = {0u, 0u, 0u};
+#pragma unroll
   for (int j = 0; j < 16; j++) {
     const int pt = 16 * g + 1 + j;
     uint32_t code = 0x15u;                                     // (padding past the last point: no movement)
     if (pt < P) {
-      const uint32_t cur = in[pt];
+      const uint32_t cur = w[j + 1], prev = w[j];
       const uint32_t dx = (cur & 1023u) + 1u - (prev & 1023u), dy = ((cur >> 10) & 1023u) + 1u - ((prev >> 10) & 1023u),
                      dz = ((cur >> 20) & 1023u) + 1u - ((prev >> 20) & 1023u);
       ok = ok && !(cur & (1u << 30)) && dx <= 2u && dy <= 2u && dz <= 2u;
       code = (dx & 3u) | ((dy & 3u) << 2) | ((dz & 3u) << 4);
-      prev = cur;
     }
     if (j < 15) w3[j / 5] |= code << (6 * (j % 5));
     else { w3[0] |= (code & 3u) << 30; w3[1] |= ((code >> 2) & 3u) << 30; w3[2] |= ((code >> 4) & 3u) << 30; }
   }
   uint32_t *out = packed + row * PW;
-  if (g == 0) out[0] = in[0];
+  if (g == 0) out[0] = w[0];
   out[1 + 3 * g] = w3[0]; out[2 + 3 * g] = w3[1]; out[3 + 3 * g] = w3[2];
   if (g == G - 1 && ((1 + 3 * G) & 1)) out[1 + 3 * G] = 0u;    // the pad word
   if (!ok) atomicAdd(bad, 1ull);
@@ -162,33 +169,38 @@ __device__ __forceinline__ uint32_t sig_code_at(const uint32_t *w3, int j) {
   return (w3[0] >> 30) | ((w3[1] >> 30) << 2) | ((w3[2] >> 30) << 4);
 }
 
-// one thread per (row, group): the cell its group starts from = the first cell + the steps of the groups before it
+// one thread per (row, 16 words of the row): words 16 g .. 16 g + 15 = points 16 g .. 16 g + 15 leave as four 16-byte stores.  Point 16 g
+// = the first cell + every step of the code groups before g; the points after it take the first fifteen steps of code group g.
 __global__ __launch_bounds__(256) void unpack_signatures_kernel(const uint32_t *__restrict__ packed, int64_t n_rows, int P, int64_t stride, int G, int PW,
                                                                 uint32_t *__restrict__ sig) {
+  const int TPR = (P + 15) / 16;                               // threads per row
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_rows * G) return;
-  const int64_t row = t / G;
-  const int g = (int)(t - row * G);
+  if (t >= n_rows * TPR) return;
+  const int64_t row = t / TPR;
+  const int g = (int)(t - row * TPR);
   const uint32_t *in = packed + row * PW;
   const uint32_t first = in[0];
   int cx = (int)(first & 1023u), cy = (int)((first >> 10) & 1023u), cz = (int)((first >> 20) & 1023u);
   for (int q = 0; q < g; q++) {
     const uint32_t w3[3] = {in[1 + 3 * q], in[2 + 3 * q], in[3 + 3 * q]};
-    for (int j = 0; j < 16; j++) {
-      const uint32_t c = sig_code_at(w3, j);
-      cx += (int)(c & 3u) - 1; cy += (int)((c >> 2) & 3u) - 1; cz += (int)((c >> 4) & 3u) - 1;
-    }
+    // the sum of sixteen 2-bit fields per axis, minus sixteen: fields of one axis sit 6 bits apart
+    int sx = 0, sy = 0, sz = 0;
+#pragma unroll
+    for (int j = 0; j < 16; j++) { const uint32_t c = sig_code_at(w3, j); sx += (int)(c & 3u); sy += (int)((c >> 2) & 3u); sz += (int)((c >> 4) & 3u); }
+    cx += sx - 16; cy += sy - 16; cz += sz - 16;
   }
-  uint32_t *out = sig + row * stride;
-  if (g == 0) out[0] = first;
-  const uint32_t w3[3] = {in[1 + 3 * g], in[2 + 3 * g], in[3 + 3 * g]};
+  uint32_t w[16];
+  uint32_t w3[3] = {0x15555555u, 0x15555555u, 0x15555555u};
+  if (g < G) { w3[0] = in[1 + 3 * g]; w3[1] = in[2 + 3 * g]; w3[2] = in[3 + 3 * g]; }
+#pragma unroll
   for (int j = 0; j < 16; j++) {
-    const int pt = 16 * g + 1 + j;
-    if (pt >= P) break;
-    const uint32_t c = sig_code_at(w3, j);
-    cx += (int)(c & 3u) - 1; cy += (int)((c >> 2) & 3u) - 1; cz += (int)((c >> 4) & 3u) - 1;
-    out[pt] = ((uint32_t)cx & 1023u) | (((uint32_t)cy & 1023u) << 10) | (((uint32_t)cz & 1023u) << 20);
+    const int pt = 16 * g + j;
+    w[j] = pt < P ? (((uint32_t)cx & 1023u) | (((uint32_t)cy & 1023u) << 10) | (((uint32_t)cz & 1023u) << 20)) : 0u;
+    if (j < 15) { const uint32_t c = sig_code_at(w3, j); cx += (int)(c & 3u) - 1; cy += (int)((c >> 2) & 3u) - 1; cz += (int)((c >> 4) & 3u) - 1; }
   }
+  uint4 *out4 = reinterpret_cast<uint4 *>(sig + row * stride + 16 * g);
+#pragma unroll
+  for (int q = 0; q < 4; q++) out4[q] = uint4{w[4 * q], w[4 * q + 1], w[4 * q + 2], w[4 * q + 3]};
 }
 
 }  // namespace
@@ -204,7 +216,7 @@ void launch_pack_signatures(const uint32_t *d_sig, int64_t n_rows, int n_points,
 void launch_unpack_signatures(const uint32_t *d_packed, int64_t n_rows, int n_points, int64_t sig_stride, uint32_t *d_sig, hipStream_t s) {
   if (n_rows <= 0) return;
   const int G = (n_points - 1 + 15) / 16;
-  const int64_t threads = n_rows * std::max(G, 1);
+  const int64_t threads = n_rows * ((n_points + 15) / 16);
   hipLaunchKernelGGL(unpack_signatures_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, d_packed, n_rows, n_points, sig_stride, std::max(G, 1),
                      sig_packed_words(n_points), d_sig);
 }

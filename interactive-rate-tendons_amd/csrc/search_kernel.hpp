@@ -54,7 +54,7 @@ constexpr int SR_VBITS = 26;                                  // an open-list wo
 constexpr int SR_D = 16;                                      // arcs per adjacency row = lanes per expanded vertex
 constexpr int SR_TAB = 128;                                   // slots of the conflict tables
 constexpr int SR_CLASSES = 4;                                 // table sizes: 2^lc0 records, then x 4 per class
-constexpr int SR_CTL_WORDS = 128;                              // control words ahead of the pool bitmaps
+constexpr int SR_CTL_WORDS = 136;                              // control words ahead of the pool bitmaps
 constexpr int32_t SR_ARC_NONE = -1, SR_ARC_MORE = -2;
 enum : uint8_t { SR_NO_PATH = 0, SR_FOUND = 1, SR_FALLBACK = 2 };
 constexpr uint8_t SR_INVALID = 2;                             // roadmap.hip: V_INVALID
@@ -62,10 +62,21 @@ constexpr uint8_t SR_INVALID = 2;                             // roadmap.hip: V_
 __host__ __device__ inline size_t search_lds_bytes() { return (size_t)SR_CAP * 12 + SR_MAXS * 8 + SR_MAXL * 4 + (size_t)SR_TAB * 16; }
 // a table of C records with its far list beside it: records | far keys | far vertices
 __host__ __device__ inline size_t search_chunk_bytes(int lc) { return ((size_t)1 << lc) * 44; }
+// a vertex's row: state, then landmark distances from a 16-byte boundary; rows never straddle a 128-byte line they could share
+__host__ __device__ inline int search_lm_offset(int S) { return (8 * S + 15) & ~15; }
+__host__ __device__ inline int search_row_bytes(int S, int L) {
+  const int size = search_lm_offset(S) + 16 * ((L + 3) >> 2);
+  return size <= 32 ? 32 : (size <= 64 ? 64 : ((size + 127) & ~127));
+}
 
 struct SearchArgs {
-  const SArc *rows;                                           // [V + continuation rows][SR_D]
-  const double *states; const float *lm;                      // [V][S]; [V][L rounded up to a multiple of 4] landmark distances or null
+  const char *fat;                                            // [V + continuation rows][SR_D] slots of arc_bytes bytes: the arc (its vertex word
+  int32_t arc_bytes;                                          // carries the lanes the neighbour's own row needs, as an open-list word does),
+                                                              // then a COPY of the neighbour's state | landmark row: what the heuristic of a
+                                                              // relaxation reads arrives with the arcs, in one contiguous fetch per lane
+  const double *states; const float *lm;                      // a vertex's state (S doubles) and its landmark distances (L rounded up to a
+  int32_t row_bytes;                                          // multiple of 4 floats; null: none) sit in ONE row of row_bytes bytes (a 128-byte
+                                                              // line at 4 coordinates + 16 landmarks): `lm` = `states` + the row's landmark offset
   int32_t S, NT, rot, ret, L;
   double w_rot, w_ret, lm_slack;
   const uint8_t *vstat, *estat;
@@ -190,6 +201,26 @@ __device__ inline int sr_pool_claim(const SearchArgs &a, int c) {
 // first writes its XCD's dirty lines back (agent-scope release: the caller's fence), and only then clears the bit.
 __device__ inline void sr_pool_release(const SearchArgs &a, int c, int idx) { atomicAnd(a.next + a.pool_word[c] + (idx >> 5), ~(1u << (idx & 31))); }
 
+// bytes of a slot of the fat rows: the arc, the neighbour's state (to a 16-byte boundary), its landmark distances
+__host__ __device__ inline int search_arc_bytes(int S, int L) { return (int)sizeof(SArc) + search_lm_offset(S) + 16 * ((L + 3) >> 2); }
+
+// The fat rows from the thin ones (host-built: SArc per slot) and the vertices' rows: slot t = arc t with the lanes of its neighbour's
+// own row in the vertex word's top bits, then a copy of the neighbour's state | landmark row.
+__global__ __launch_bounds__(256) void search_fat_rows(const SArc *__restrict__ rows, int64_t n_slots, const char *__restrict__ vrows, int row_bytes,
+                                                       int inner /* bytes of a vertex row that mean something: a multiple of 16 */,
+                                                       const uint8_t *__restrict__ deg, char *__restrict__ fat, int arc_bytes) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= n_slots) return;
+  SArc arc = rows[t];
+  const int32_t v = arc.v;
+  if (v >= 0) arc.v = v | ((int32_t)deg[v] << SR_VBITS);
+  char *out = fat + t * arc_bytes;
+  *(SArc *)out = arc;
+  const uint4 *src = (const uint4 *)(vrows + (int64_t)(v >= 0 ? v : 0) * row_bytes);
+  uint4 *dst = (uint4 *)(out + sizeof(SArc));
+  for (int q = 0; q < inner / 16; q++) dst[q] = v >= 0 ? src[q] : uint4{0u, 0u, 0u, 0u};
+}
+
 // SX: the state coordinates the heuristic keeps in registers (4, 8 or SR_MAXS; S <= SX)
 template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
 #pragma clang fp contract(off)
@@ -215,12 +246,13 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
   const int NT = a.NT, L4 = (L + 3) >> 2;
   const bool rot = a.rot != 0, ret = a.ret != 0;
   const float slack = (float)a.lm_slack;
-  auto heuristic = [&](int32_t v) -> double {
-    const double *sv = a.states + (int64_t)v * S;
+  const int lm_off = search_lm_offset(S);
+  auto heuristic_at = [&](const char *rowp) -> double {
+    const double *sv = (const double *)rowp;
     double x[SX];
 #pragma unroll
     for (int i = 0; i < SX; i++) x[i] = i < S ? sv[i] : 0.0;
-    const float4 *lv = (const float4 *)(a.lm + (int64_t)v * (4 * L4));
+    const float4 *lv = (const float4 *)(rowp + lm_off);
     float4 y[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) y[j] = j < L4 ? lv[j] : float4{0.f, 0.f, 0.f, 0.f};
@@ -277,8 +309,8 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     const uint32_t gen = a.gen_base + qi + 1u;
     const int32_t start = a.qs[qi], goal = a.qg[qi];
     __syncthreads();
-    if (lane < S) gst[lane] = a.states[(int64_t)goal * S + lane];
-    if (lane < 4 * L4) glm[lane] = a.lm[(int64_t)goal * (4 * L4) + lane];
+    if (lane < S) gst[lane] = ((const double *)((const char *)a.states + (int64_t)goal * a.row_bytes))[lane];
+    if (lane < 4 * L4) glm[lane] = ((const float *)((const char *)a.lm + (int64_t)goal * a.row_bytes))[lane];
     __syncthreads();
 
     // ---- the search's table: class, index in the class, records, far list; all wave-uniform ----
@@ -371,7 +403,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     int result = SR_NO_PATH;
     unsigned long long exp_q = 0;
     unsigned moves = 0;                                         // times the threshold moved (near full / near empty)
-    const double h0 = sr_u(heuristic(start));
+    const double h0 = sr_u(heuristic_at((const char *)a.states + (int64_t)start * a.row_bytes));
     if (h0 != inf) {
       {
         SRec none;
@@ -382,7 +414,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
       n_near = 1; count = 1;
       __syncthreads();
 #ifdef TRK_SEARCH_CLOCKS
-      unsigned long long clk[6] = {0, 0, 0, 0, 0, 0}, t_last = wall_clock64(), n_steps = 0, n_passes = 0;
+      unsigned long long clk[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_last = wall_clock64(), n_steps = 0, n_passes = 0;
 #endif
       for (;;) {
         SR_CLK(4);
@@ -488,7 +520,11 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
         int my_u = -1, grp = -1, sub = 0, gbase = 0;
 #pragma unroll
         for (int r = 0; r < SR_K; r++) if (r < nsel && lane >= cum[r] && lane < cum[r + 1]) { my_u = sel_u[r]; grp = r; sub = lane - cum[r]; gbase = cum[r]; }
-        SArc arc = my_u >= 0 ? a.rows[(int64_t)my_u * SR_D + sub] : no_arc;
+        // (the lane's slot of the row: the arc and, behind it, the neighbour's rows -- its heuristic is formed here, from bytes that came
+        // with the arcs, while the neighbours' records are still to be asked for)
+        const char *slotp = a.fat + ((int64_t)(my_u >= 0 ? my_u : 0) * SR_D + sub) * a.arc_bytes;
+        SArc arc = my_u >= 0 ? *(const SArc *)slotp : no_arc;
+        double hv = my_u >= 0 ? heuristic_at(slotp + sizeof(SArc)) : 0.0;
         SRec urec = SRec{0.0, 0.0, -1, -1, 0u, 1u};
         uint32_t pu = 0;
         bool live = lookup(my_u, my_u >= 0, urec, pu) && (urec.tag & 1u) == 0u;
@@ -511,6 +547,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
 #endif
           const bool has = act && arc.v >= 0;
           const bool more = act && arc.v == SR_ARC_MORE;
+          const int32_t av = arc.v & ((1 << SR_VBITS) - 1);           // the neighbour; the bits above: lanes its own row needs
           bool cand = false, push = false, fresh = false;
           double fp = 0.0, gv = 0.0, hh = 0.0;
           int32_t vp = 0, pe = -1;
@@ -518,22 +555,22 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           if (has) {
             // everything the relaxation can need is requested at once, whether or not it turns out to be needed: validity bytes,
             // the neighbour's record (the line its probe starts at), and the rows of its heuristic
-            pv = slot0(arc.v);
+            pv = slot0(av);
             const SRec r0 = tb[pv], r1 = tb[pv + 1];
-            const uint8_t es = a.estat[arc.e], vs = a.vstat[arc.v];
-            vd = a.deg[arc.v];
-            const double hv = heuristic(arc.v);
+            const uint8_t es = a.estat[arc.e], vs = a.vstat[av];
+            vd = (uint32_t)arc.v >> SR_VBITS;
             SRec nn = SRec{0.0, 0.0, -1, -1, 0u, 0u};
-            const bool seen = resolve(arc.v, r0, r1, nn, pv);
+            const bool seen = resolve(av, r0, r1, nn, pv);
             if (es != SR_INVALID && vs != SR_INVALID) {
               gv = ug + arc.w;
               if (!seen || gv < nn.g) {
                 hh = seen ? nn.h : hv;                           // h(v) is fixed for the query: computed when v is first reached
-                cand = true; fresh = !seen; vp = arc.v; pe = arc.e;
+                cand = true; fresh = !seen; vp = av; pe = arc.e;
               }
             }
           }
           // ---- two lanes with the same neighbour: the smaller cost wins (the lower lane among equals), the others stand down ----
+          SR_CLK(5);
           // (first the cheap question "do any two of them name the same neighbour at all?": every candidate lane leaves its number in a
           // byte slot of its neighbour's hash -- 1 024 slots in the cost table's place -- and looks whether it is still there; two lanes
           // with one neighbour share the slot, so one of them finds the other's number.  Four times in five nobody does, and the
@@ -568,6 +605,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
             }
             if (__ballot(open)) { failed = true; break; }
           }
+          SR_CLK(6);
           // ---- the winners write: a vertex reached before in place, a new one into a free record of its probe path ----
           {
             const unsigned long long mnew = __ballot(cand && fresh);
@@ -582,7 +620,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           }
           // ---- append: keys below T to near, the others to far ----
           unsigned long long mn_ = __ballot(push && fp < T);
-          SR_CLK(3);
+          SR_CLK(7);
           while (n_near + __popcll(mn_) > SR_CAP) {
             // near is full.  With dead slots in it: they are squeezed out, nothing else changes.  Without: T drops halfway towards
             // its smallest key, what lies above moves to far
@@ -630,14 +668,18 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           if (!__ballot(more)) break;
           const int nrow = __shfl(more ? arc.e : -1, gbase + (SR_D - 1), 64);
           act = act && nrow >= 0;
-          arc = act ? a.rows[(int64_t)nrow * SR_D + sub] : no_arc;
+          const char *np_ = a.fat + ((int64_t)(act ? nrow : 0) * SR_D + sub) * a.arc_bytes;
+          arc = act ? *(const SArc *)np_ : no_arc;
+          if (act) hv = heuristic_at(np_ + sizeof(SArc));
         }
         if (failed) { result = SR_FALLBACK; break; }
       }
 #ifdef TRK_SEARCH_CLOCKS
       if (lane == 0) {
+        clk[3] = clk[5] + clk[6] + clk[7];                         // "arcs + rows + relax" = loads / heuristic / lookup + conflicts + writes
         for (int i = 0; i < 6; i++) atomicAdd((unsigned long long *)(a.next + 16) + i, clk[i]);
         atomicMax((unsigned long long *)(a.next + 16) + 6, clk[0] + clk[1] + clk[2] + clk[3] + clk[4]);
+        for (int i = 5; i < 8; i++) atomicAdd((unsigned long long *)(a.next + 124 - 2 * 5) + i, clk[i]);   // words 124 .. 129
         // when searches end, in 2 ms buckets since the first wave's start (words 40 .. 41: that start; 44 .. : 40 buckets of counts,
         // 84 .. : 40 buckets of the expansions of the searches that ended there)
         atomicAdd((unsigned long long *)(a.next + 32), n_steps);

@@ -351,6 +351,7 @@ class VoxelCachedLazyPRM:
         self._rm = rm
         self.stats = None
         self.search_stats = None
+        self.search_profile = None
 
     @classmethod
     def from_rmp(cls, checker, path, n_landmarks=16):
@@ -489,4 +490,8 @@ class VoxelCachedLazyPRM:
         # where the searches ran (tr_roadmap_search_stats): finished by the kernel / handed back by it / on the host threads meanwhile
         self.search_stats = dict(device=int(ss[0]), handed_back=int(ss[1]), host_meanwhile=int(ss[2]), list_moves=int(ss[3]),
                                  expanded_device=int(ss[4]), expanded_host=int(ss[5]), answered_by_components=int(ss[6]), table_growths=int(ss[7]))
+        pr = (C.c_double * 4)()
+        self._check(self.lib.tr_roadmap_profile(self._rm, pr))
+        # the roadmap_astar launches of this solve (HIP events): ms, launches, expansions, algorithmic bytes per expansion
+        self.search_profile = dict(kernel_ms=float(pr[0]), launches=int(pr[1]), expansions=int(pr[2]), bytes_per_expansion=float(pr[3]))
         return dict(status=status, cost=cost, path_offsets=off, path_vertices=pv, paths=_Paths(pv, off))
