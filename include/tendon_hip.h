@@ -589,15 +589,15 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *   TENDON_HIP_SEARCH_HOST_SHARE=p  per cent of a shared round's searches (the ones with the most distant end points) that the host
  *                                   threads take while the kernel runs (default: starts at 1 and follows the two sides' times per roadmap)
  *   TENDON_HIP_SEARCH_BUDGET=n      expansions after which the kernel hands a search back: the host threads start on it at once, while
- *                                   the kernel is still running (a word per query in pinned memory tells them) (default: starts at 6500
- *                                   and follows the clock per roadmap: up when the host threads were still busy long after the kernel
- *                                   had ended, down when they ran dry; 0 none)
+ *                                   the kernel is still running (a word per query in pinned memory tells them) (default: starts at 6500,
+ *                                   or a sixteenth of the roadmap's vertices if that is more, and doubles per roadmap while more than
+ *                                   one search in fifty comes back; 0 none)
  *   TENDON_HIP_SEARCH_K=1..8        vertices the kernel takes off a search's open list per step, at most (default 8: as many as their
  *                                   arcs fill the wave's 64 lanes; 1 = the host's order)
  *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds: 16 waves per CU)
  *   TENDON_HIP_SEARCH_LC0=8..14     log2 of the per-vertex records a search in flight owns (default 12: 176 KiB per slot with its far list;
  *                                   the searches' state does not depend on the roadmap's size); TENDON_HIP_SEARCH_POOL=a,b,c: shared tables of
- *                                   4 / 16 / 64 times that size for the searches that outgrow it (default slots / 2, slots / 16, 8; a search
+ *                                   4 / 16 / 64 times that size for the searches that outgrow it (default slots, slots / 4, slots / 64: 7.3 GB in all at 4 096 slots; a search
  *                                   that finds none free is handed back to the host threads).  Both read when a roadmap's first large
  *                                   round sets the searches up (tests reach the growth and hand-back paths with small values)
  *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when at least

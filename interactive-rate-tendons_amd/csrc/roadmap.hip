@@ -239,7 +239,6 @@ struct tr_roadmap {
     char *qarena = nullptr;              // per-round arrays (queries, results, packed paths)
     trk::SArc *d_rows = nullptr; char *d_vrows = nullptr;        // adjacency rows; per vertex: state | landmark distances
     int32_t row_bytes = 0;
-    char *d_fat = nullptr; size_t fat_bytes = 0; int32_t arc_bytes = 0; int64_t n_rows = 0;   // the rows the kernel reads (search_fat_rows)
     uint8_t *d_vstat = nullptr, *d_estat = nullptr, *d_deg = nullptr;
     uint32_t *d_ctl = nullptr;
     int32_t *d_qs = nullptr, *d_qg = nullptr, *d_poff = nullptr, *d_plen = nullptr, *d_pbuf = nullptr;
@@ -604,7 +603,6 @@ void free_search(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.arena) dev_cache().release(d.arena);
   if (d.tables) dev_cache().release(d.tables);
-  if (d.d_fat) dev_cache().release(d.d_fat);
   if (d.qarena) dev_cache().release(d.qarena);
   if (d.h_handback) (void)hipHostFree(d.h_handback);
   for (hipEvent_t e : d.ev) if (e) (void)hipEventDestroy(e);
@@ -788,7 +786,8 @@ SearchKernel search_kernel_for(int S) { return S <= 4 ? trk::roadmap_astar<4> : 
 // tables (x 4 per class) that long searches move into.  The slot count is what the chip holds of this kernel (LDS: 9.8 KiB per wave).
 //   TENDON_HIP_SEARCH_SLOTS=n     searches in flight (default: what the device holds)
 //   TENDON_HIP_SEARCH_LC0=8..14   log2 of a slot's own table (default 12; tests: a small value makes every search grow)
-//   TENDON_HIP_SEARCH_POOL=a,b,c  tables of the three larger classes (default slots / 2, slots / 16, 8; 0,0,0: every search that outgrows
+//   TENDON_HIP_SEARCH_POOL=a,b,c  tables of the three larger classes (default slots, slots / 4, slots / 64 -- 7.3 GB with the slots' own at
+//                                 4 096 slots: a 6 x 10^5-vertex roadmap's searches touch 10^4 - 10^5 vertices each; 0,0,0: every search that outgrows
 //                                 its table is handed back to the host threads)
 bool search_setup(tr_roadmap *r) {
   auto &d = r->ds;
@@ -855,7 +854,7 @@ bool search_setup(tr_roadmap *r) {
   if (const char *e = std::getenv("TENDON_HIP_SEARCH_SLOTS")) slots = std::max<int64_t>(1, std::min<int64_t>(slots, std::atoll(e)));
   d.lc0 = 12;
   if (const char *e = std::getenv("TENDON_HIP_SEARCH_LC0")) d.lc0 = std::max(8, std::min(14, std::atoi(e)));
-  int64_t pn[trk::SR_CLASSES] = {0, std::max<int64_t>(64, slots / 2), std::max<int64_t>(16, slots / 16), 8};
+  int64_t pn[trk::SR_CLASSES] = {0, std::max<int64_t>(64, slots), std::max<int64_t>(16, slots / 4), std::max<int64_t>(8, slots / 64)};
   if (const char *e = std::getenv("TENDON_HIP_SEARCH_POOL")) {
     long long x1 = 0, x2 = 0, x3 = 0;
     if (std::sscanf(e, "%lld,%lld,%lld", &x1, &x2, &x3) >= 1) { pn[1] = std::max(0ll, x1); pn[2] = std::max(0ll, x2); pn[3] = std::max(0ll, x3); }
@@ -910,7 +909,6 @@ bool search_setup(tr_roadmap *r) {
                  (long long)slots, trk::search_chunk_bytes(d.lc0) >> 10, d.pool_n[1], d.pool_n[2], d.pool_n[3], (double)d.table_bytes / 1048576.0,
                  (long long)n_rows, D, (long long)(n_rows - V), (double)(b_rows + b_vr + 2 * b_vs + b_es) / 1048576.0);
   d.lm_current = false;
-  d.n_rows = n_rows;
   d.state = 1;
   return true;
 }
@@ -977,21 +975,6 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
       if (L) std::memcpy(row + lm_off, &r->lm_d[(size_t)v * L], (size_t)L * 4);
     }
     ok = hipMemcpyAsync(d.d_vrows, rows.data(), rows.size(), hipMemcpyHostToDevice, nullptr) == hipSuccess;
-    // ... and the rows the kernel reads: every arc with a copy of its neighbour's row behind it (built on the device)
-    d.arc_bytes = trk::search_arc_bytes(r->S, L);
-    const size_t need = (size_t)d.n_rows * trk::SR_D * d.arc_bytes;
-    if (ok && need > d.fat_bytes) {
-      if (d.d_fat) dev_cache().release(d.d_fat);
-      d.d_fat = nullptr; d.fat_bytes = 0;
-      ok = dev_cache().alloc(dev, (void **)&d.d_fat, need) == hipSuccess;
-      if (ok) d.fat_bytes = need;
-    }
-    if (ok) {
-      const int64_t n_slots = d.n_rows * trk::SR_D;
-      hipLaunchKernelGGL(trk::search_fat_rows, dim3((unsigned)((n_slots + 255) / 256)), dim3(256), 0, nullptr, d.d_rows, n_slots, d.d_vrows, d.row_bytes,
-                         d.arc_bytes - (int)sizeof(trk::SArc), d.d_deg, d.d_fat, d.arc_bytes);
-      ok = hipGetLastError() == hipSuccess;
-    }
     if (!ok) return false;
     d.lm_current = true;
   }
@@ -1004,7 +987,7 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
        hipMemsetAsync(d.d_ctl + 40, 0xff, 8, nullptr) == hipSuccess;       // (a -DTRK_SEARCH_CLOCKS build keeps the first wave's start there)
   if (!ok) return false;
   trk::SearchArgs a{};
-  a.fat = d.d_fat; a.arc_bytes = d.arc_bytes; a.states = (const double *)d.d_vrows; a.lm = L ? (const float *)(d.d_vrows + trk::search_lm_offset(r->S)) : nullptr;
+  a.rows = d.d_rows; a.states = (const double *)d.d_vrows; a.lm = L ? (const float *)(d.d_vrows + trk::search_lm_offset(r->S)) : nullptr;
   a.row_bytes = d.row_bytes;
   a.S = r->S; a.NT = r->NT; a.rot = r->rot; a.ret = r->ret; a.L = L;
   a.w_rot = r->w_rot; a.w_ret = r->w_ret; a.lm_slack = kLmSlack;
@@ -1472,7 +1455,9 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       // (TENDON_HIP_SEARCH=device: no budget unless TENDON_HIP_SEARCH_BUDGET asks for one)
       {
         const bool from_env = std::getenv("TENDON_HIP_SEARCH_BUDGET") != nullptr;
-        if (r->ds.budget == 0 || from_env || r->ds.budget_from_env) r->ds.budget = search_budget();
+        // (a roadmap's first shared round: 6 500 expansions, or a sixteenth of its vertices if that is more -- searches grow with the
+        // graph; afterwards the budget doubles whenever more than one search in fifty came back: see below)
+        if (r->ds.budget == 0 || from_env || r->ds.budget_from_env) r->ds.budget = from_env ? search_budget() : std::max<int64_t>(search_budget(), r->V / 16);
         r->ds.budget_from_env = from_env;
       }
       on_device = device_search_launch(r, starts, goals, active, dev_list, smode == 2 && !std::getenv("TENDON_HIP_SEARCH_BUDGET") ? 0 : r->ds.budget);
@@ -1618,6 +1603,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       // raised when it was done in a fraction of the kernel's span and nothing was left to do after it.
       const double t_kernel = ms(t_round, t_kernel_done), t_after = std::max(0.0, ms(t_kernel_done, t3)), t_share = n_share ? ms(t0, t_share_done) : 0.0;
       r->ds.kernel_ms = t_kernel; r->ds.host_after_ms = t_after;
+      if (smode != 2 && !r->ds.budget_from_env && r->ds.budget > 0 && (n_streamed + (int64_t)redo.size()) * 50 > n_dev && r->ds.budget < 16 * r->V) r->ds.budget *= 2;
       if (smode != 2 && !std::getenv("TENDON_HIP_SEARCH_HOST_SHARE") && n_share > 0) {
         if (t_share > t_kernel) r->ds.share = std::max(0.0025, r->ds.share * 0.5);
         else if (t_share < 0.4 * t_kernel && t_after < 0.1 * t_kernel) r->ds.share = std::min(0.08, r->ds.share * 1.5);

@@ -70,10 +70,7 @@ __host__ __device__ inline int search_row_bytes(int S, int L) {
 }
 
 struct SearchArgs {
-  const char *fat;                                            // [V + continuation rows][SR_D] slots of arc_bytes bytes: the arc (its vertex word
-  int32_t arc_bytes;                                          // carries the lanes the neighbour's own row needs, as an open-list word does),
-                                                              // then a COPY of the neighbour's state | landmark row: what the heuristic of a
-                                                              // relaxation reads arrives with the arcs, in one contiguous fetch per lane
+  const SArc *rows;                                           // [V + continuation rows][SR_D]
   const double *states; const float *lm;                      // a vertex's state (S doubles) and its landmark distances (L rounded up to a
   int32_t row_bytes;                                          // multiple of 4 floats; null: none) sit in ONE row of row_bytes bytes (a 128-byte
                                                               // line at 4 coordinates + 16 landmarks): `lm` = `states` + the row's landmark offset
@@ -201,26 +198,6 @@ __device__ inline int sr_pool_claim(const SearchArgs &a, int c) {
 // first writes its XCD's dirty lines back (agent-scope release: the caller's fence), and only then clears the bit.
 __device__ inline void sr_pool_release(const SearchArgs &a, int c, int idx) { atomicAnd(a.next + a.pool_word[c] + (idx >> 5), ~(1u << (idx & 31))); }
 
-// bytes of a slot of the fat rows: the arc, the neighbour's state (to a 16-byte boundary), its landmark distances
-__host__ __device__ inline int search_arc_bytes(int S, int L) { return (int)sizeof(SArc) + search_lm_offset(S) + 16 * ((L + 3) >> 2); }
-
-// The fat rows from the thin ones (host-built: SArc per slot) and the vertices' rows: slot t = arc t with the lanes of its neighbour's
-// own row in the vertex word's top bits, then a copy of the neighbour's state | landmark row.
-__global__ __launch_bounds__(256) void search_fat_rows(const SArc *__restrict__ rows, int64_t n_slots, const char *__restrict__ vrows, int row_bytes,
-                                                       int inner /* bytes of a vertex row that mean something: a multiple of 16 */,
-                                                       const uint8_t *__restrict__ deg, char *__restrict__ fat, int arc_bytes) {
-  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (t >= n_slots) return;
-  SArc arc = rows[t];
-  const int32_t v = arc.v;
-  if (v >= 0) arc.v = v | ((int32_t)deg[v] << SR_VBITS);
-  char *out = fat + t * arc_bytes;
-  *(SArc *)out = arc;
-  const uint4 *src = (const uint4 *)(vrows + (int64_t)(v >= 0 ? v : 0) * row_bytes);
-  uint4 *dst = (uint4 *)(out + sizeof(SArc));
-  for (int q = 0; q < inner / 16; q++) dst[q] = v >= 0 ? src[q] : uint4{0u, 0u, 0u, 0u};
-}
-
 // SX: the state coordinates the heuristic keeps in registers (4, 8 or SR_MAXS; S <= SX)
 template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs a) {
 #pragma clang fp contract(off)
@@ -246,13 +223,12 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
   const int NT = a.NT, L4 = (L + 3) >> 2;
   const bool rot = a.rot != 0, ret = a.ret != 0;
   const float slack = (float)a.lm_slack;
-  const int lm_off = search_lm_offset(S);
-  auto heuristic_at = [&](const char *rowp) -> double {
-    const double *sv = (const double *)rowp;
+  auto heuristic = [&](int32_t v) -> double {
+    const double *sv = (const double *)((const char *)a.states + (int64_t)v * a.row_bytes);
     double x[SX];
 #pragma unroll
     for (int i = 0; i < SX; i++) x[i] = i < S ? sv[i] : 0.0;
-    const float4 *lv = (const float4 *)(rowp + lm_off);
+    const float4 *lv = (const float4 *)((const char *)a.lm + (int64_t)v * a.row_bytes);
     float4 y[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) y[j] = j < L4 ? lv[j] : float4{0.f, 0.f, 0.f, 0.f};
@@ -403,7 +379,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     int result = SR_NO_PATH;
     unsigned long long exp_q = 0;
     unsigned moves = 0;                                         // times the threshold moved (near full / near empty)
-    const double h0 = sr_u(heuristic_at((const char *)a.states + (int64_t)start * a.row_bytes));
+    const double h0 = sr_u(heuristic(start));
     if (h0 != inf) {
       {
         SRec none;
@@ -520,11 +496,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
         int my_u = -1, grp = -1, sub = 0, gbase = 0;
 #pragma unroll
         for (int r = 0; r < SR_K; r++) if (r < nsel && lane >= cum[r] && lane < cum[r + 1]) { my_u = sel_u[r]; grp = r; sub = lane - cum[r]; gbase = cum[r]; }
-        // (the lane's slot of the row: the arc and, behind it, the neighbour's rows -- its heuristic is formed here, from bytes that came
-        // with the arcs, while the neighbours' records are still to be asked for)
-        const char *slotp = a.fat + ((int64_t)(my_u >= 0 ? my_u : 0) * SR_D + sub) * a.arc_bytes;
-        SArc arc = my_u >= 0 ? *(const SArc *)slotp : no_arc;
-        double hv = my_u >= 0 ? heuristic_at(slotp + sizeof(SArc)) : 0.0;
+        SArc arc = my_u >= 0 ? a.rows[(int64_t)my_u * SR_D + sub] : no_arc;
         SRec urec = SRec{0.0, 0.0, -1, -1, 0u, 1u};
         uint32_t pu = 0;
         bool live = lookup(my_u, my_u >= 0, urec, pu) && (urec.tag & 1u) == 0u;
@@ -547,7 +519,6 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
 #endif
           const bool has = act && arc.v >= 0;
           const bool more = act && arc.v == SR_ARC_MORE;
-          const int32_t av = arc.v & ((1 << SR_VBITS) - 1);           // the neighbour; the bits above: lanes its own row needs
           bool cand = false, push = false, fresh = false;
           double fp = 0.0, gv = 0.0, hh = 0.0;
           int32_t vp = 0, pe = -1;
@@ -555,17 +526,18 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           if (has) {
             // everything the relaxation can need is requested at once, whether or not it turns out to be needed: validity bytes,
             // the neighbour's record (the line its probe starts at), and the rows of its heuristic
-            pv = slot0(av);
+            pv = slot0(arc.v);
             const SRec r0 = tb[pv], r1 = tb[pv + 1];
-            const uint8_t es = a.estat[arc.e], vs = a.vstat[av];
-            vd = (uint32_t)arc.v >> SR_VBITS;
+            const uint8_t es = a.estat[arc.e], vs = a.vstat[arc.v];
+            vd = a.deg[arc.v];
+            const double hv = heuristic(arc.v);
             SRec nn = SRec{0.0, 0.0, -1, -1, 0u, 0u};
-            const bool seen = resolve(av, r0, r1, nn, pv);
+            const bool seen = resolve(arc.v, r0, r1, nn, pv);
             if (es != SR_INVALID && vs != SR_INVALID) {
               gv = ug + arc.w;
               if (!seen || gv < nn.g) {
                 hh = seen ? nn.h : hv;                           // h(v) is fixed for the query: computed when v is first reached
-                cand = true; fresh = !seen; vp = av; pe = arc.e;
+                cand = true; fresh = !seen; vp = arc.v; pe = arc.e;
               }
             }
           }
@@ -668,9 +640,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           if (!__ballot(more)) break;
           const int nrow = __shfl(more ? arc.e : -1, gbase + (SR_D - 1), 64);
           act = act && nrow >= 0;
-          const char *np_ = a.fat + ((int64_t)(act ? nrow : 0) * SR_D + sub) * a.arc_bytes;
-          arc = act ? *(const SArc *)np_ : no_arc;
-          if (act) hv = heuristic_at(np_ + sizeof(SArc));
+          arc = act ? a.rows[(int64_t)nrow * SR_D + sub] : no_arc;
         }
         if (failed) { result = SR_FALLBACK; break; }
       }

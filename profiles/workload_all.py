@@ -172,8 +172,8 @@ def main():
         dev_exp += prm.search_stats["expanded_device"]
     deg = 2.0 * len(e_ok) / V
     S_, L_ = states.shape[1], 16
-    add("roadmap_astar", bytes=dev_exp * (48 + deg * (16 + 2 + 32 + 8 * S_ + 4 * L_ + 32)), units=dev_exp,
-        unit="vertex expansions (three times 10 000 searches, a wave each; bytes: record + offsets + per arc: arc, validity, neighbour record read and written, state and landmark rows)",
+    add("roadmap_astar", bytes=dev_exp * (48 + deg * (16 + 2 + 1 + 32 + 8 * S_ + 4 * L_ + 32)), units=dev_exp,
+        unit="vertex expansions (three times 10 000 searches, a wave each; bytes as tr_roadmap_profile counts them: record + row header + per arc: arc, validity, arc count, neighbour record read and written, state and landmark rows)",
         searches=prm.search_stats["device"], list_moves=prm.search_stats["list_moves"])
     # ---- sphere checker (K8) and environment edits (K7) ------------------------------------------------------------------
     r2 = W.robot_config2()

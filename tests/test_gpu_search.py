@@ -150,6 +150,45 @@ def test_device_searches_on_wide_vertices_small_tables_and_an_exhausted_pool(irt
             assert ss["handed_back"] > nq // 4 and ss["table_growths"] > 0 and ss["device"] > 0, ss
 
 
+def test_device_searches_on_a_600k_vertex_roadmap(irt, monkeypatch):
+    """Config 4's roadmap size (6 x 10^5 vertices, 3.4 x 10^6 candidate edges of the 10-nearest connection loop, taken as valid: the
+    searches need the graph and validity bytes only -- tr_roadmap_set_validity): the searches' state on the device is what it is
+    at any size (a table per search in flight + the shared pool; round 4's 32 B x V per slot left 671 of 3 072 slots here), every
+    slot is resident, and 3 000 queries come back with the host threads' statuses, costs and paths -- all on the device, and through
+    the default shared schedule."""
+    W = irt.workloads
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+    rb = irt.RoadmapBuilder(chk, irt.VoxelBackboneMotionValidator(chk), seed=3)
+    states, _ = rb.sample_valid_vertices(600000)
+    edges = rb.knn_edges_gpu(states, 11)
+    assert len(edges) > 3000000
+    prm = irt.VoxelCachedLazyPRM(chk, states, edges)
+    prm.set_validity(np.ones(len(states), np.uint8), np.ones(len(edges), np.uint8))
+    prm.prepare(16)
+    rng = np.random.default_rng(6)
+    nq = 3000
+    starts, goals = rng.integers(0, len(states), nq), rng.integers(0, len(states), nq)
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+    ref = prm.solveWithRoadmap(starts, goals)
+    assert (ref["status"] == 0).mean() > 0.99 and prm.stats["items_checked"] == 0
+    for mode in ("device", None):
+        if mode is None:
+            monkeypatch.delenv("TENDON_HIP_SEARCH")
+        else:
+            monkeypatch.setenv("TENDON_HIP_SEARCH", mode)
+        out = prm.solveWithRoadmap(starts, goals)
+        assert np.array_equal(ref["status"], out["status"]) and np.array_equal(ref["cost"], out["cost"])
+        assert np.array_equal(ref["path_offsets"], out["path_offsets"]) and np.array_equal(ref["path_vertices"], out["path_vertices"])
+        ss = prm.search_stats
+        if mode == "device":
+            assert ss["device"] + ss["handed_back"] == nq - int((starts == goals).sum()) and ss["handed_back"] < nq // 10 and ss["table_growths"] > 0, ss
+        else:
+            assert ss["device"] > 0.8 * nq, ss
+        assert prm.search_profile["launches"] >= 1 and prm.search_profile["kernel_ms"] > 0
+
+
 def test_roadmap_with_parallel_edges_stays_on_the_host(irt, monkeypatch):
     """Two edges between the same pair of vertices: the kernel relaxes a vertex's arcs in parallel lanes, so such a roadmap is
     searched on the host whatever the switch says -- and gives the answers it always gave."""
