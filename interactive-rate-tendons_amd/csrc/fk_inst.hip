@@ -105,7 +105,7 @@ template <bool ROT, bool WR>
 static void go(const FkLaunch &a) {
   const unsigned grid = (unsigned)((a.n + 63) / 64);
   hipLaunchKernelGGL((fk_rk4_batch_retract<TRK_INST_N, ROT, WR>), dim3(grid), dim3(64), 0, a.stream, a.d_states, a.n, a.ld, a.K,
-                     a.d_poly, a.d_tab, a.d_steps, a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.out);
+                     a.d_poly, a.d_tab, a.d_steps, a.n_steps, a.k_first, a.d_tgrid, a.d_hl, a.out, a.d_perm, a.d_wave_k_begin);
 }
 template <> void launch_fk_retract<TRK_INST_N>(const FkLaunch &a) {
 #else

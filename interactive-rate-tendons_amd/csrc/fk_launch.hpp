@@ -19,6 +19,7 @@ struct FkLaunch {
   hipStream_t stream;
   // retraction robots' verdict path: the prologue kernel's hand-over planes ([19 + N][handoff_ld] doubles) and the batch order
   double *d_handoff = nullptr; int64_t handoff_ld = 0; const int32_t *d_perm = nullptr;
+  const int32_t *d_wave_k_begin = nullptr;      // stored-point retraction kernel: per wave of the order d_perm, the first step of its loop
 };
 
 struct FusedSweepArgs;

@@ -112,7 +112,7 @@ struct FkLaneR {
 // the end of the lane's own first interval, plane by plane, [field][ld] with ld = the launch's lane count rounded to 64 -- lane i
 // of both launches is the same configuration, so both sides are coalesced.  Fields: R 0-8, v 9-11, u 12-14, p 15-17, L_i 18 ..
 // 18 + N - 1, converged (as 0.0 / 1.0), then the configuration's S state coordinates (so that the second kernel does not gather
-// them once more through the batch order: 40 scattered bytes cost a 128-byte line each).
+// them once more through the batch order: 40 scattered bytes cost a 128-byte line each), then the backbone-length quadrature so far.
 struct RetractHandoff {
   double *data;
   int64_t ld;
@@ -135,12 +135,16 @@ __device__ __forceinline__ void fk_retract_body(
     const double *__restrict__ hl /* [P][N] home-length integrand at the shared abscissae */, const FkOut &out,
     OnPoint &&on_point = NoPointHook(), const int32_t *__restrict__ row_map = nullptr, FkLaneR<N> *lane_out = nullptr,
     int k_begin = 0 /* wave-uniform: no lane of this wave has a point in a row that a step before k_begin ends in (0 = unknown) */,
-    const RetractHandoff *ho = nullptr) {
+    const RetractHandoff *ho = nullptr,
+    bool by_config = false /* with row_map: the stored outputs (points, R, L, L_i, converged, n_points, home L_i) go to the
+                              CONFIGURATION's column -- scattered 8-byte stores, 1 % of the kernel's instructions -- so that a batch
+                              integrated in the order of its backbone lengths lands in the caller's order */) {
 #pragma clang fp contract(fast)
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   const bool live = i < n;
   const int64_t il = live ? i : (n - 1);
   const int64_t ic = row_map ? (int64_t)row_map[il] : il;
+  const int64_t oc = by_config ? ic : i;              // the column this lane's stored outputs go to
   const int S = K.state_size, Pmax = K.n_points;
   const double L = K.L, dL = K.dL;
   // the state: from the caller's array (through the batch order), or -- PHASE 2 -- from the hand-over planes, coalesced
@@ -202,16 +206,18 @@ __device__ __forceinline__ void fk_retract_body(
 #pragma unroll
   for (int j = 0; j < N; j++) Li[j] = 0;
   double p1[3] = {0, 0, 0};                          // PHASE 2: the lane's point 1 (the end of its own first interval)
+  double R1[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};        // ... and the frame there (point 0 keeps the identity: the stored-point form writes R)
   if constexpr (PHASE == 2) {
     const double *__restrict__ h = ho->data + (live ? i : n - 1);
     const int64_t hl = ho->ld;
 #pragma unroll
-    for (int q = 0; q < 9; q++) R[q] = h[q * hl];
+    for (int q = 0; q < 9; q++) R1[q] = h[q * hl];
 #pragma unroll
     for (int q = 0; q < 3; q++) { v[q] = h[(9 + q) * hl]; u[q] = h[(12 + q) * hl]; p1[q] = h[(15 + q) * hl]; }
 #pragma unroll
     for (int j = 0; j < N; j++) Li[j] = h[(18 + j) * hl];
     conv = h[(18 + N) * hl] != 0.0;
+    if (out.L) Lb = h[(19 + N + S) * hl];
   }
 
   if constexpr (PHASE != 1) on_point.begin(conv && live);
@@ -223,7 +229,7 @@ __device__ __forceinline__ void fk_retract_body(
     if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
     on_point.tip_point(row, on, is_first, x, y, z, wave_row);
     if (!(on && live)) return;
-    const int64_t o = (int64_t)row * ld + i;
+    const int64_t o = (int64_t)row * ld + oc;
     if (out.px) { out.px[o] = x; out.py[o] = y; out.pz[o] = z; }
     if (WRITE_R) {
       const int64_t PS = (int64_t)Pmax * ld;
@@ -258,6 +264,8 @@ __device__ __forceinline__ void fk_retract_body(
       }
     } else {
       p[0] = p1[0]; p[1] = p1[1]; p[2] = p1[2];
+#pragma unroll
+      for (int q = 0; q < 9; q++) R[q] = R1[q];
     }
     if constexpr (PHASE != 1) store_point(shift + 1, first, false);
   }
@@ -277,6 +285,7 @@ __device__ __forceinline__ void fk_retract_body(
       for (int j = 0; j < N; j++) h[(19 + N + j) * hl] = tau[j];
       if (ROT) h[(19 + N + N) * hl] = states[ic * S + N];
       h[(19 + N + S - 1) * hl] = s_raw;
+      h[(19 + N + S) * hl] = Lb;                           // (the stored-point form returns the backbone length; the verdict forms never read it)
     }
     return;
   }
@@ -406,13 +415,13 @@ __device__ __forceinline__ void fk_retract_body(
     }
   }
   if (live) {
-    if (out.L) out.L[i] = Lb;
+    if (out.L) out.L[oc] = Lb;
     if (out.Li) {
 #pragma unroll
-      for (int j = 0; j < N; j++) out.Li[(int64_t)j * ld + i] = Li[j];
+      for (int j = 0; j < N; j++) out.Li[(int64_t)j * ld + oc] = Li[j];
     }
-    if (out.converged) out.converged[i] = conv ? 1 : 0;
-    if (out.n_points) out.n_points[i] = P_lane;
+    if (out.converged) out.converged[oc] = conv ? 1 : 0;
+    if (out.n_points) out.n_points[oc] = P_lane;
     if (out.tips) {
       double x = p[0], y = p[1], z = p[2];
       if (ROT) { const double x2 = __builtin_fma(rc, x, -(rs * y)), y2 = __builtin_fma(rs, x, rc * y); x = x2; y = y2; z = r22 * z; }
@@ -420,7 +429,7 @@ __device__ __forceinline__ void fk_retract_body(
     }
     if (out.home_Li) {
 #pragma unroll
-      for (int j = 0; j < N; j++) out.home_Li[(int64_t)j * ld + i] = home[j];
+      for (int j = 0; j < N; j++) out.home_Li[(int64_t)j * ld + oc] = home[j];
     }
   }
   if (lane_out) {
@@ -435,8 +444,27 @@ template <int N, bool ROT, bool WRITE_R>
 __global__ __launch_bounds__(64, (N <= TRK_K1R_TWO_WAVE_MAXN ? 2 : 1)) void fk_rk4_batch_retract(
     const double *__restrict__ states, int64_t n, int64_t ld, RobotK K, const PolyK *__restrict__ pk,
     const double *__restrict__ tab, const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid,
-    const double *__restrict__ hl, FkOut out) {
-  fk_retract_body<N, ROT, WRITE_R>(states, n, ld, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out);
+    const double *__restrict__ hl, FkOut out,
+    const int32_t *__restrict__ order /* null, or: lane i integrates configuration order[i] -- the batch by backbone length, so that a
+                                         wave holds backbones of one length (retraction_order); the outputs land in the caller's order */,
+    const int32_t *__restrict__ wave_k_begin /* null, or per wave of that order: the step its tip-aligned loop may start at */) {
+  const int kb = wave_k_begin ? wave_k_begin[blockIdx.x] : 0;
+  fk_retract_body<N, ROT, WRITE_R>(states, n, ld, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, NoPointHook(), order, nullptr, kb, nullptr,
+                                   order != nullptr);
+}
+
+// The verdict form's first launch: every lane's own first interval (base strains by the fixed-point solve, routing polynomials
+// evaluated per lane and stage, up to two RK4 steps) needs more than the 256 registers of a two-wave kernel, so it runs HERE, one
+// wave per SIMD with the whole register file, and hands the integrator's state over in coalesced planes.  (The stored-point form
+// was tried in the same two launches in round 5: 3.97 against 3.52 ms per 2^19 for the one kernel in length order -- the planes
+// cost it more than the spills.)
+template <int N, bool ROT>
+__global__ __launch_bounds__(64, 1) void fk_retract_prologue(
+    const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
+    const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
+    const int32_t *__restrict__ perm, RetractHandoff ho) {
+  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  fk_retract_body<N, ROT, false, NoPointHook, 1>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, NoPointHook(), perm, nullptr, 0, &ho);
 }
 
 }  // namespace trk

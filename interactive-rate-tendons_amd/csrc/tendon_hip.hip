@@ -496,12 +496,35 @@ int note_dev_work(tr_ctx *ctx, hipStream_t s) {
 }
 
 // ---- K1 launch (instantiations live in fk_inst.hip objects) ------------------------------------
-int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s) {
+int launch_fk(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, const trk::FkOut &out, hipStream_t s, int lane = 0) {
   if (n <= 0) return TR_OK;
   ProfScope ps(ctx, 0, s);
   const bool ret = ctx->K.enable_retraction;
-  const trk::FkLaunch a{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, out.R != nullptr, ctx->d_tab, ctx->d_steps,
-                        (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, out, s};
+  trk::FkLaunch a{d_states, n, ld, ctx->K, (bool)ctx->K.enable_rotation, out.R != nullptr, ctx->d_tab, ctx->d_steps,
+                  (int)ctx->steps.size(), ctx->d_poly, ctx->k_first, ctx->d_tgrid, ctx->d_hl, out, s};
+  if (ret && ctx->retract_sort_min > 0 && n >= ctx->retract_sort_min) {
+    // A large batch of a retraction robot is integrated in the order of its backbone lengths, as the verdict-only kernels do
+    // (a wave runs from its LONGEST backbone's base to the tip, the shorter ones idle: in arrival order half of the lane-steps
+    // are masked), and every stored output goes to its configuration's own column: same planes, bit for bit.
+    tr_ctx::RetractOrder &ro = ctx->ro[lane];           // (a lane of the edge bisection: its own buffers and sort scratch, as launch_verdict's)
+    int rc;
+    if (ro.cap < n) {
+      HIP_TRY(ctx, hipDeviceSynchronize());
+      const int64_t want = round_up(n, 64);
+      for (int q = 0; q < 2; q++) {
+        if ((rc = dev_alloc(ctx, &ro.keys[q], (size_t)want))) return rc;
+        if ((rc = dev_alloc(ctx, &ro.vals[q], (size_t)want))) return rc;
+      }
+      if ((rc = dev_alloc(ctx, &ro.kbegin, (size_t)want / 64))) return rc;
+      ro.cap = want;
+    }
+    const int32_t *perm = nullptr;
+    const hipError_t e = trk::retraction_order(lane ? ro.ms : ctx->merge, d_states, n, ctx->K.state_size, ctx->K.L, ro.keys, ro.vals, &perm, s,
+                                               ctx->K.dL, ctx->k_first, ctx->rows_one_step, ro.kbegin);
+    if (e != hipSuccess) return fail(ctx, TR_ERR_HIP, std::string("retraction order: ") + hipGetErrorString(e));
+    a.d_perm = perm;
+    a.d_wave_k_begin = ctx->retract_wave_start ? ro.kbegin : nullptr;
+  }
   switch (ctx->K.n_tendons) {
 #define TRK_CASE(N) case N: if (ret) trk::launch_fk_retract<N>(a); else trk::launch_fk_uniform<N>(a); break;
     TRK_CASE(1) TRK_CASE(2) TRK_CASE(3) TRK_CASE(4) TRK_CASE(5) TRK_CASE(6) TRK_CASE(7) TRK_CASE(8)
@@ -685,7 +708,7 @@ int launch_verdict(tr_ctx *ctx, const double *d_states, int64_t n, uint64_t *d_b
     if (ro.handoff_cap < hld) {
       HIP_TRY(ctx, hipDeviceSynchronize());
       const int64_t want = hld + hld / 8;
-      if ((rc = dev_alloc(ctx, &ro.handoff, (size_t)want * (19 + 2 * TRK_MAX_TENDONS + 2)))) return rc;     // R, v, u, p | L_i | converged | state
+      if ((rc = dev_alloc(ctx, &ro.handoff, (size_t)want * (19 + 2 * TRK_MAX_TENDONS + 3)))) return rc;     // R, v, u, p | L_i | converged | state | L
       ro.handoff_cap = want;
     }
     vl.d_handoff = ro.handoff; vl.handoff_ld = hld; vl.d_perm = a.perm;
@@ -854,7 +877,7 @@ int launch_fk_sweep(tr_ctx *ctx, const double *d_states, int64_t n, int64_t ld, 
   if (ctx->fuse != 0 && !ctx->K.enable_retraction && !out.R && !out.L) {      // the fused kernel integrates neither R output nor L
     if ((rc = launch_fused(ctx, d_states, n, ld, out, in, check_voxels, d_bits, d_flags, s, sig, sig_stride))) return rc;
   } else {
-    if ((rc = launch_fk(ctx, d_states, n, ld, out, s))) return rc;
+    if ((rc = launch_fk(ctx, d_states, n, ld, out, s, lane))) return rc;
     if ((rc = launch_sweep(ctx, in, n, ld, check_voxels, d_bits, d_flags, s))) return rc;
   }
   if (voxel_test == 2) {

@@ -656,15 +656,7 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
 // the 4 MiB L2 (1.3 - 2.5 KB of HBM traffic per check for 68 algorithmic bytes, profiles/r03/traffic_split_v2.json).  So it runs
 // here, ONE wave per SIMD with the whole register file, and hands the integrator's state over (18 + N + 1 doubles per
 // configuration, written and read coalesced).
-template <int N, bool ROT>
-__global__ __launch_bounds__(64, 1) void fk_retract_prologue(
-    const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,
-    const StepK *__restrict__ steps, int nsteps, int k_first, const double *__restrict__ tgrid, const double *__restrict__ hl,
-    const int32_t *__restrict__ perm, RetractHandoff ho) {
-  FkOut out{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  fk_retract_body<N, ROT, false, NoPointHook, 1>(states, n, 0, K, pk, tab, steps, nsteps, k_first, tgrid, hl, out, NoPointHook(), perm, nullptr, 0, &ho);
-}
-
+// (fk_retract_prologue: fk_retract_kernel.hpp -- the stored-point form of large batches takes the same two launches)
 template <int N, bool ROT, bool SPH, bool SIG = false>
 __global__ __launch_bounds__(64, (N <= TRK_VR_TWO_WAVE_MAXN ? 2 : 1)) void fk_verdict_retract(
     const double *__restrict__ states, int64_t n, RobotK K, const PolyK *__restrict__ pk, const double *__restrict__ tab,

@@ -304,3 +304,41 @@ def test_edges_with_retraction_where_samples_need_the_fallback_pass(irt, orc, he
     assert np.array_equal(got["valid"], want), np.flatnonzero(got["valid"] != want)[:10]
     assert np.array_equal(got["n_fk"][want], nfk[want]), np.flatnonzero((got["n_fk"] != nfk) & want)[:10]
     assert 0.3 < want.mean() < 0.95
+
+
+@pytest.mark.parametrize("kind,rot", [("quad", True), ("helix", False)])
+def test_stored_point_fk_in_length_order_equals_arrival_order(irt, orc, helpers, kind, rot):
+    """tr_fk_batch / tr_voxelize_batch for a retraction robot integrate a batch of 8 192 or more in the order of its backbone lengths
+    (fk_rk4_batch_retract with the order of retraction_order: a wave then holds backbones of one length) and scatter every stored
+    output to its configuration's own column: points, R, L, L_i, converged, point counts -- bit for bit those of the arrival-order
+    launch (TENDON_HIP_RETRACT_SORT=0), and the oracle's on a sample; the voxel sets built from those planes are the same too."""
+    robot = _robot(irt, kind)
+    robot.enable_rotation = rot
+    n = 20000 + 37
+    st = _states(irt, robot, n, seed=41)
+    W = irt.workloads
+    vox, _ = W.reach_environment(seed=3, n_spheres=48)
+
+    def run():
+        chk = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox)
+        fk = chk.engine.fk_batch(st, want_R=True)
+        vc = chk.engine.voxelize_batch(st)
+        return fk, vc
+
+    fk0, vc0 = _with_env({"TENDON_HIP_RETRACT_SORT": "0"}, run)
+    fk1, vc1 = run()                                                # the default: ordered from 8 192 configurations on
+    for k in ("p", "R", "L", "L_i", "converged", "n_points"):
+        a, b = fk0[k], fk1[k]
+        assert a.shape == b.shape and np.array_equal(a, b, equal_nan=True), k
+    for k in ("offsets", "block_ids", "masks", "shape_valid"):
+        assert np.array_equal(vc0[k], vc1[k]), k
+    assert len(set(fk1["n_points"].tolist())) > 100                 # every backbone length is there
+    orb = helpers.oracle_robot(orc, robot)
+    for i in list(range(16)) + list(np.random.default_rng(2).choice(n, 60, replace=False)):
+        want = orb.shape(st[i])
+        m = len(want["p"])
+        if st[i, -1] < 0:
+            continue
+        assert fk1["n_points"][i] == m and bool(fk1["converged"][i]) == bool(want["converged"])
+        if want["converged"]:
+            assert np.abs(fk1["p"][i, :m] - want["p"]).max() <= TIP_TOL and np.abs(fk1["L_i"][i] - want["L_i"]).max() <= 1e-10
