@@ -134,7 +134,7 @@ __device__ __forceinline__ void strain_rates_routed(const double v[3], const dou
   const double dx = TRK_FMA(u[2], svy, TRK_FMA(-u[1], svz, -ax));
   const double dy = TRK_FMA(u[0], svz, TRK_FMA(-u[2], svx, -ay));
   const double dz = TRK_FMA(u[1], svx, TRK_FMA(-u[0], svy, -az));
-  // M11 = K_se + A - Z I (symmetric); inverse by adjugate
+  // M11 = K_se + A - Z I (symmetric): the leading block of the 6 x 6 system solved below
   const double ksz0 = K.ks0 - Z, ksz2 = K.ks2 - Z;
   const double m00 = ksz0 + Axx, m01 = Axy, m02 = Axz, m11 = ksz0 + Ayy, m12 = Ayz, m22 = ksz2 + Azz;
 #ifndef TRK_SOLVE_SCHUR

@@ -832,7 +832,7 @@ bool search_setup(tr_roadmap *r) {
       for (;;) {
         trk::SArc *out = rows.data() + (size_t)row * D;
         const int take = deg > D ? D - 1 : (int)deg;
-        for (int j = 0; j < take; j++) out[j] = trk::SArc{arc[j].v, arc[j].e, arc[j].w};
+        for (int j = 0; j < take; j++) out[j] = trk::SArc{arc[j].v, arc[j].e, arc[j].w};        // (the neighbours' lane counts: second pass below)
         for (int j = take; j < D; j++) out[j] = trk::SArc{trk::SR_ARC_NONE, -1, 0.0};
         arc += take; deg -= take;
         if (deg == 0) break;
@@ -840,6 +840,10 @@ bool search_setup(tr_roadmap *r) {
         row = next_row++;
       }
     }
+  }
+  for (size_t t = 0; t < (size_t)n_rows * D; t++) {                 // an arc's vertex word carries the lanes its neighbour's own row needs
+    trk::SArc &x = rows[t];
+    if (x.v >= 0) x.v |= (int32_t)lanes[(size_t)x.v] << trk::SR_VBITS;
   }
   laps.lap("adjacency rows");
   const int dev = tr_device(r->ctx);
@@ -972,7 +976,10 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
     for (int64_t v = 0; v < V; v++) {
       char *row = rows.data() + (size_t)v * d.row_bytes;
       std::memcpy(row, &r->states[(size_t)v * r->S], (size_t)r->S * 8);
-      if (L) std::memcpy(row + lm_off, &r->lm_d[(size_t)v * L], (size_t)L * 4);
+      if (L) {
+        float *lm = (float *)(row + lm_off);
+        for (int l = 0; l < L; l++) { const float x = r->lm_d[(size_t)v * L + l]; lm[l] = x < trk::SR_LM_FAR ? x : trk::SR_LM_FAR; }   // (+inf: see the kernel's heuristic)
+      }
     }
     ok = hipMemcpyAsync(d.d_vrows, rows.data(), rows.size(), hipMemcpyHostToDevice, nullptr) == hipSuccess;
     if (!ok) return false;

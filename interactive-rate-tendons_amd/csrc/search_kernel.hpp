@@ -45,21 +45,24 @@
 
 namespace trk {
 
-struct SArc { int32_t v, e; double w; };                      // roadmap.hip: Arc; v = SR_ARC_NONE: unused slot, SR_ARC_MORE: e = the next row
+struct SArc { int32_t v, e; double w; };                      // roadmap.hip: Arc; v = SR_ARC_NONE: unused slot, SR_ARC_MORE: e = the next row;
+                                                              // in the kernel's rows v carries, above SR_VBITS, the lanes the neighbour's own row needs
 struct SRec { double g, h; int32_t parent, parent_edge; uint32_t key, tag; };   // tag = generation << 1 | closed
 constexpr int SR_CAP = 640;                                   // near-list entries per wave (LDS)
 constexpr int SR_MAXS = 12, SR_MAXL = 64;                     // state coordinates, landmarks
-constexpr int SR_K = 6;                                       // vertices expanded per step, at most (as many as their arcs fill 64 lanes: ~5)
+constexpr int SR_K = 12;                                      // vertices expanded per step, at most (as many as their arcs fill two passes of 64 lanes: ~8)
 constexpr int SR_VBITS = 26;                                  // an open-list word: vertex | lanes its first row needs << SR_VBITS
 constexpr int SR_D = 16;                                      // arcs per adjacency row = lanes per expanded vertex
 constexpr int SR_TAB = 128;                                   // slots of the conflict tables
 constexpr int SR_CLASSES = 4;                                 // table sizes: 2^lc0 records, then x 4 per class
 constexpr int SR_CTL_WORDS = 136;                              // control words ahead of the pool bitmaps
 constexpr int32_t SR_ARC_NONE = -1, SR_ARC_MORE = -2;
+constexpr float SR_LM_FAR = 1e30f;                            // a landmark distance of +inf as the vertices' rows store it
 enum : uint8_t { SR_NO_PATH = 0, SR_FOUND = 1, SR_FALLBACK = 2 };
 constexpr uint8_t SR_INVALID = 2;                             // roadmap.hip: V_INVALID
 // near keys | near vertices | goal state | goal landmark row | conflict tables (owner, cost, lane): 16 waves per CU
-__host__ __device__ inline size_t search_lds_bytes() { return (size_t)SR_CAP * 12 + SR_MAXS * 8 + SR_MAXL * 4 + (size_t)SR_TAB * 16; }
+// ... | the step's lane owners (a byte per lane of its two passes)
+__host__ __device__ inline size_t search_lds_bytes() { return (size_t)SR_CAP * 12 + SR_MAXS * 8 + SR_MAXL * 4 + (size_t)SR_TAB * 16 + 128; }
 // a table of C records with its far list beside it: records | far keys | far vertices
 __host__ __device__ inline size_t search_chunk_bytes(int lc) { return ((size_t)1 << lc) * 44; }
 // a vertex's row: state, then landmark distances from a 16-byte boundary; rows never straddle a 128-byte line they could share
@@ -161,6 +164,22 @@ __device__ __forceinline__ uint32_t sr_wave_min_u32(uint32_t x) {
 #undef SR_MIN_STEP
   return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
+// Inclusive prefix sum / running maximum over the wave's lanes (rows of 16 by row_shr 1, 2, 4, 8 -- a lane without a source keeps the
+// identity --, then the row ends broadcast into the following rows).
+__device__ __forceinline__ int sr_wave_scan_add(int x) {
+#define SR_SCAN_STEP(ctrl, rmask) x += __builtin_amdgcn_update_dpp(0, x, ctrl, rmask, 0xf, false)
+  SR_SCAN_STEP(0x111, 0xf); SR_SCAN_STEP(0x112, 0xf); SR_SCAN_STEP(0x114, 0xf); SR_SCAN_STEP(0x118, 0xf);
+  SR_SCAN_STEP(0x142, 0xa); SR_SCAN_STEP(0x143, 0xc);
+#undef SR_SCAN_STEP
+  return x;
+}
+__device__ __forceinline__ uint32_t sr_wave_scan_max(uint32_t x) {
+#define SR_SCAN_STEP(ctrl, rmask) do { const uint32_t y_ = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, ctrl, rmask, 0xf, false); x = y_ > x ? y_ : x; } while (0)
+  SR_SCAN_STEP(0x111, 0xf); SR_SCAN_STEP(0x112, 0xf); SR_SCAN_STEP(0x114, 0xf); SR_SCAN_STEP(0x118, 0xf);
+  SR_SCAN_STEP(0x142, 0xa); SR_SCAN_STEP(0x143, 0xc);
+#undef SR_SCAN_STEP
+  return x;
+}
 __device__ __forceinline__ int sr_wave_sum(int c) {
   c += SR_DPP32(c, 0x128, 0xf); c += SR_DPP32(c, 0x124, 0xf); c += SR_DPP32(c, 0x122, 0xf); c += SR_DPP32(c, 0x121, 0xf);
   // (the row sums are in every lane of their rows: fold the four rows through scalars)
@@ -209,6 +228,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
   unsigned long long *tab_key = (unsigned long long *)(glm + SR_MAXL);   // [SR_TAB] smallest cost offered to the slot's vertex
   uint32_t *tab_owner = (uint32_t *)(tab_key + SR_TAB);       // [SR_TAB] a lane that claimed the slot
   uint32_t *tab_low = tab_owner + SR_TAB;                     // [SR_TAB] lowest lane among those offering the smallest cost
+  uint8_t *own8 = (uint8_t *)(tab_low + SR_TAB);              // [128] per lane of a step's two passes: the candidate lane (+ 1) whose group starts here
   const int lane = threadIdx.x;
   const int64_t slot = blockIdx.x;
   const double inf = __longlong_as_double(0x7ff0000000000000ll);
@@ -246,14 +266,14 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     if (rot) h += t_rot;
     if (ret) h += t_ret;
     if (L4) {
-      const float finf = __int_as_float(0x7f800000);
+      // (the rows hold SR_LM_FAR where the host's table holds +inf: "not connected to this landmark".  Two far entries bound nothing --
+      // their term is hugely negative --, one far entry makes the term huge: the vertex and the goal lie in different components, as
+      // the host's explicit test says; no comparison with infinity per landmark)
       float best = 0.0f;
-      bool cut = false;
       auto bound = [&](float xv, float yv) {
-        const float hi = xv > yv ? xv : yv, lo = xv > yv ? yv : xv;
-        if (hi == finf) { cut |= lo != hi; return; }
+        const float hi = fmaxf(xv, yv), lo = fminf(xv, yv);
         const float t = (hi - lo) - slack * hi;
-        best = t > best ? t : best;
+        best = fmaxf(best, t);
       };
       for (int c = 0; c < L4; c += 4) {
         if (c) {
@@ -268,7 +288,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           }
         }
       }
-      if (cut) return inf;
+      if (best >= 0.5f * SR_LM_FAR) return inf;
       if ((double)best > h) h = (double)best;
     }
     return h;
@@ -376,10 +396,12 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     };
 
     double T = inf;
+    double slack = 0.0;                                         // how far above the minimum a step's other vertices may lie (follows the lanes' use)
     int result = SR_NO_PATH;
     unsigned long long exp_q = 0;
     unsigned moves = 0;                                         // times the threshold moved (near full / near empty)
     const double h0 = sr_u(heuristic(start));
+    slack = 0.01 * h0;
     if (h0 != inf) {
       {
         SRec none;
@@ -453,64 +475,107 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
 #pragma unroll
           for (int j = 0; j < 4; j++) { const int i = i0 + 64 * j + lane; if (f4[j] < best) { best = f4[j]; bi = i; } }      // (a dead slot holds +inf)
         }
-        int sel_i[SR_K], sel_u[SR_K], cum[SR_K + 1];
-        int nsel = 0;
-        bool taken = bi < 0;
-        cum[0] = 0;
-        const int bw = bi >= 0 ? nv[bi] : 0;                    // the lane's candidate word, read once for all rounds
+        // A step takes the minimum and, with it, every other lane's candidate within `slack` of it -- expanding a vertex that is not
+        // the minimum is what any best-first search with re-opening may do -- as many as their arcs fill two passes of the wave's 64
+        // lanes.  All of it in lane-parallel steps: no loop over the taken vertices (round 5's first version ran one selection round
+        // per vertex: 35 instructions each).  The goal is only ever taken as the minimum.
+        const bool has_c = bi >= 0;
+        const int bw = has_c ? nv[bi] : 0;                      // the lane's candidate word: vertex | lanes its row needs
+        const int bu = bw & ((1 << SR_VBITS) - 1), bd = (int)((unsigned)bw >> SR_VBITS);
         const unsigned long long bbits = (unsigned long long)__double_as_longlong(best);   // (keys are >= 0: ordered as integers)
         const uint32_t bhi = (uint32_t)(bbits >> 32), blo = (uint32_t)bbits;
-#pragma unroll
-        for (int r = 0; r < SR_K; r++) {
-          sel_i[r] = -1; sel_u[r] = -1; cum[r + 1] = cum[r];
-          if (r < kbest && nsel == r) {
-            const uint32_t mh = sr_wave_min_u32(taken ? 0xffffffffu : bhi);
-            const bool top = !taken && bhi == mh;
-            const uint32_t ml = sr_wave_min_u32(top ? blo : 0xffffffffu);
-            const unsigned long long who = __ballot(top && blo == ml);
-            if (who) {
-              const int src = __ffsll((long long)who) - 1;
-              const int i = __builtin_amdgcn_readlane(bi, src);
-              const int w = __builtin_amdgcn_readlane(bw, src);
-              const int u = w & ((1 << SR_VBITS) - 1), d = (int)((unsigned)w >> SR_VBITS);
-              // the goal ends the search when it is the minimum; further down the batch it stays on the list, with what follows it --
-              // and so does a vertex whose arcs the wave has no lanes left for
-              if (r == 0 || (u != goal && cum[r] + d <= 64)) {
-                sel_i[r] = i; sel_u[r] = u; cum[r + 1] = cum[r] + d;
-                if (lane == src) taken = true;
-                nsel = r + 1;
-              }
-            }
+        const uint32_t mh = sr_wave_min_u32(has_c ? bhi : 0xffffffffu);
+        const bool top = has_c && bhi == mh;
+        const uint32_t ml = sr_wave_min_u32(top ? blo : 0xffffffffu);
+        const int src0 = __ffsll((long long)__ballot(top && blo == ml)) - 1;     // (the list holds a live entry: n_near > n_dead)
+        const double fmin = sr_lane(best, src0);
+        const int d0 = __builtin_amdgcn_readlane(bd, src0);
+        // (a search widens its steps as it goes -- one more vertex per eight expansions so far -- so that a search of a few dozen
+        // expansions does not spend most of them beside the path: on a 2 500-vertex roadmap full-width steps from the start expanded
+        // four times what the host does; a search of a thousand is at full width after its first tenth)
+        const int kcap = (int)(exp_q >> 3) + 1 < kbest ? (int)(exp_q >> 3) + 1 : kbest;
+        bool cnd = has_c && (lane == src0 || (kcap > 1 && best <= fmin + slack && bu != goal));
+        {
+          const int rko = __popcll(__ballot(cnd) & below) - (lane > src0 ? 1 : 0);       // rank among the others
+          cnd = cnd && (lane == src0 || rko < kcap - 1);
+        }
+        // lanes: the minimum's arcs first, the others' behind them in lane order; no group straddles the two passes
+        const int x_ = (cnd && lane != src0) ? bd : 0;
+        const int incl = sr_wave_scan_add(x_);
+        int cstart = lane == src0 ? 0 : d0 + incl - x_;
+        {
+          const unsigned long long mstr = __ballot(cnd && cstart < 64 && cstart + bd > 64);
+          if (mstr) {
+            const int ss = __builtin_amdgcn_readlane(cstart, __ffsll((long long)mstr) - 1);
+            if (cstart >= ss) cstart += 64 - ss;
           }
         }
+        const unsigned long long mc_all = __ballot(cnd);
+        cnd = cnd && cstart + bd <= 128;
+        const unsigned long long mc = __ballot(cnd);
+        // (the slack follows the lanes: widened while a step leaves a quarter of them idle, narrowed when candidates had to stay)
+        if (mc != mc_all) slack *= 0.75;
+        else if (d0 + __builtin_amdgcn_readlane(incl, 63) < 96 && __popcll(mc) < kcap) slack = slack * 1.4 + 1e-6 * fmin;
+        own8[lane] = 0; own8[64 + lane] = 0;
         __syncthreads();
-        // the entries leave the list: their slots are marked dead (+inf) where they are -- no entry moves, no step depends on the one
-        // before -- and are dropped when the list is next rewritten (near full: see the append)
-#pragma unroll
-        for (int r = 0; r < SR_K; r++) if (lane == r && r < nsel) nf[sel_i[r]] = inf;
-        n_dead += nsel;
+        // the entries leave the list: their slots are marked dead (+inf) where they are -- no entry moves -- and are dropped when the
+        // list is next rewritten (near full: see the append)
+        if (cnd) { own8[cstart] = (uint8_t)(lane + 1); nf[bi] = inf; }
+        n_dead += __popcll(mc);
         __syncthreads();
         SR_CLK(1);
-        // ---- the popped vertices' records and first adjacency rows, a group of lanes each (as many as the row has arcs): one round
-        // trip; closed ones (stale entries) and repeats are dropped ----
-        int my_u = -1, grp = -1, sub = 0, gbase = 0;
+        // ---- the popped vertices' records and first adjacency rows, for both passes at once: a group of lanes per vertex (as many as
+        // its row has arcs) finds its owner by a running maximum over the markers; one round trip; closed ones (stale entries) drop out ----
+        int u_[2], sub_[2], gb_[2];
+        bool on_[2];
 #pragma unroll
-        for (int r = 0; r < SR_K; r++) if (r < nsel && lane >= cum[r] && lane < cum[r + 1]) { my_u = sel_u[r]; grp = r; sub = lane - cum[r]; gbase = cum[r]; }
-        SArc arc = my_u >= 0 ? a.rows[(int64_t)my_u * SR_D + sub] : no_arc;
-        SRec urec = SRec{0.0, 0.0, -1, -1, 0u, 1u};
-        uint32_t pu = 0;
-        bool live = lookup(my_u, my_u >= 0, urec, pu) && (urec.tag & 1u) == 0u;
+        for (int q = 0; q < 2; q++) {
+          const uint32_t mk = own8[64 * q + lane];
+          const uint32_t v_ = sr_wave_scan_max(mk ? (((uint32_t)lane << 8) | mk) : 0u);
+          const int s_ = (int)(v_ & 0xffu) - 1;
+          const int cs = __shfl(cstart, s_ >= 0 ? s_ : 0, 64), w_ = __shfl(bw, s_ >= 0 ? s_ : 0, 64);
+          const int t_ = 64 * q + lane;
+          on_[q] = s_ >= 0 && t_ < cs + (int)((unsigned)w_ >> SR_VBITS);
+          u_[q] = on_[q] ? (w_ & ((1 << SR_VBITS) - 1)) : -1;
+          sub_[q] = t_ - cs; gb_[q] = cs - 64 * q;
+        }
+        SArc arc_[2];
+        SRec urec_[2];
+        uint32_t pu_[2];
+        bool live_[2];
+        {
+          SRec r0_[2], r1_[2];
 #pragma unroll
-        for (int r = 0; r + 1 < SR_K; r++) if (grp > r && my_u == sel_u[r]) live = false;
-        if (live && sub == 0) tb[pu].tag = (gen << 1) | 1u;
-        const unsigned long long mlive = __ballot(live);
-        const int n_live = __popcll(__ballot(live && sub == 0));
+          for (int q = 0; q < 2; q++) {
+            arc_[q] = on_[q] ? a.rows[(int64_t)u_[q] * SR_D + sub_[q]] : no_arc;
+            pu_[q] = slot0(on_[q] ? u_[q] : 0);
+            if (on_[q]) { r0_[q] = tb[pu_[q]]; r1_[q] = tb[pu_[q] + 1]; }
+          }
+#pragma unroll
+          for (int q = 0; q < 2; q++) {
+            urec_[q] = SRec{0.0, 0.0, -1, -1, 0u, 1u};
+            live_[q] = on_[q] && resolve(u_[q], r0_[q], r1_[q], urec_[q], pu_[q]) && (urec_[q].tag & 1u) == 0u;
+          }
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++) if (live_[q] && sub_[q] == 0) tb[pu_[q]].tag = (gen << 1) | 1u;
+        const unsigned long long mlive0 = __ballot(live_[0]);
+        const int n_live = __popcll(__ballot(live_[0] && sub_[0] == 0)) + __popcll(__ballot(live_[1] && sub_[1] == 0));
         exp_q += (unsigned long long)n_live;
-        if ((mlive & 1ull) && sel_u[0] == goal) { result = SR_FOUND; break; }
-        const double ug = urec.g;
+        if ((mlive0 & 1ull) && __builtin_amdgcn_readfirstlane(u_[0]) == goal) { result = SR_FOUND; break; }   // (lane 0 works for the minimum)
+        // the heuristics of BOTH passes' neighbours now (read-only rows: nothing a pass writes can change them), so that the second
+        // pass's rows travel while the first pass works; the neighbours' RECORDS are fetched pass by pass, after the previous pass's writes
+        double hv_[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) hv_[q] = (live_[q] && arc_[q].v >= 0) ? heuristic(arc_[q].v & ((1 << SR_VBITS) - 1)) : 0.0;
         SR_CLK(2);
         bool failed = false;
-        bool act = live;
+        for (int q = 0; q < 2 && !failed; q++) {
+        SArc arc = q ? arc_[1] : arc_[0];
+        bool act = q ? live_[1] : live_[0];
+        if (!__ballot(act)) continue;
+        const int my_u = q ? u_[1] : u_[0], sub = q ? sub_[1] : sub_[0], gbase = q ? gb_[1] : gb_[0];
+        const double ug = q ? urec_[1].g : urec_[0].g;
         for (int pass = 0; pass < (1 << 20) && !failed; pass++) {
           // a step may add a record per lane: the table moves before it could pass three quarters (no lane holds a position here)
           if (count + 64 > (3 << lc) / 4 && !grow()) { failed = true; break; }
@@ -519,6 +584,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
 #endif
           const bool has = act && arc.v >= 0;
           const bool more = act && arc.v == SR_ARC_MORE;
+          const int32_t av = arc.v & ((1 << SR_VBITS) - 1);           // the neighbour; above it: the lanes ITS row needs (an open-list word's top bits)
           bool cand = false, push = false, fresh = false;
           double fp = 0.0, gv = 0.0, hh = 0.0;
           int32_t vp = 0, pe = -1;
@@ -526,18 +592,18 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           if (has) {
             // everything the relaxation can need is requested at once, whether or not it turns out to be needed: validity bytes,
             // the neighbour's record (the line its probe starts at), and the rows of its heuristic
-            pv = slot0(arc.v);
+            pv = slot0(av);
             const SRec r0 = tb[pv], r1 = tb[pv + 1];
-            const uint8_t es = a.estat[arc.e], vs = a.vstat[arc.v];
-            vd = a.deg[arc.v];
-            const double hv = heuristic(arc.v);
+            const uint8_t es = a.estat[arc.e], vs = a.vstat[av];
+            vd = (uint32_t)arc.v >> SR_VBITS;
+            const double hv = pass == 0 ? (q ? hv_[1] : hv_[0]) : heuristic(av);     // (a continued row's neighbours: here)
             SRec nn = SRec{0.0, 0.0, -1, -1, 0u, 0u};
-            const bool seen = resolve(arc.v, r0, r1, nn, pv);
+            const bool seen = resolve(av, r0, r1, nn, pv);
             if (es != SR_INVALID && vs != SR_INVALID) {
               gv = ug + arc.w;
               if (!seen || gv < nn.g) {
                 hh = seen ? nn.h : hv;                           // h(v) is fixed for the query: computed when v is first reached
-                cand = true; fresh = !seen; vp = arc.v; pe = arc.e;
+                cand = true; fresh = !seen; vp = av; pe = arc.e;
               }
             }
           }
@@ -641,6 +707,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
           const int nrow = __shfl(more ? arc.e : -1, gbase + (SR_D - 1), 64);
           act = act && nrow >= 0;
           arc = act ? a.rows[(int64_t)nrow * SR_D + sub] : no_arc;
+        }
         }
         if (failed) { result = SR_FALLBACK; break; }
       }
