@@ -601,8 +601,10 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *                                   that finds none free is handed back to the host threads).  Both read when a roadmap's first large
  *                                   round sets the searches up (tests reach the growth and hand-back paths with small values)
  *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when at least
- *                                   max(4, cached sets / 2^17) queries are still open after a round, every cached set is tested in one
- *                                   launch and the next round is the last; same answers; the rule reads counts, not clocks, so
+ *                                   max(4, cached sets / 2^17) queries are still open after a round -- or a round's candidate paths hold a
+ *                                   quarter as many items as there are cached sets, or the batch has a 256th as many queries as there
+ *                                   are cached sets to begin with --, every cached set is tested in one
+ *                                   launch and the next round is the last; same answers; the rules read counts, not clocks, so
  *                                   rounds / items_checked / the validity left behind are reproducible; `expanded` depends on which
  *                                   side -- kernel or host threads -- ran a search)
  *   TENDON_HIP_COMPONENTS=0|1       component labels of the roadmap minus the invalid items (queries across components are answered "no

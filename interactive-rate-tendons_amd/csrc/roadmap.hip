@@ -219,6 +219,7 @@ struct tr_roadmap {
   // results of the last tr_roadmap_solve
   std::vector<int64_t> path_off;
   std::vector<int32_t> path_v;
+  std::vector<std::vector<int32_t>> paths_buf, paths_e_buf;   // per query of the last solve: vertices goal ... start, their edges (capacity kept)
   // statistics of the last solve
   int64_t st_rounds = 0, st_items_checked = 0, st_astar_runs = 0, st_expanded = 0;
   std::vector<Scratch> scratch;
@@ -1366,10 +1367,14 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   for (int64_t q = 0; q < n_queries; q++)
     if (starts[q] < 0 || starts[q] >= r->V || goals[q] < 0 || goals[q] >= r->V) return rfail(r, TR_ERR_OUT_OF_RANGE, "query vertex outside the roadmap");
   RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
+  Laps laps("tr_roadmap_solve");
   const int T = host_threads(n_threads);
   if ((int)r->scratch.size() < T) r->scratch.resize((size_t)T);
   if (r->lm_n < 0 && n_queries >= 64) build_landmarks(r, 16, T);         // a handful of queries does not repay 16 graph sweeps
-  std::vector<std::vector<int32_t>> paths((size_t)n_queries), paths_e((size_t)n_queries);
+  // (the queries' path vectors live with the roadmap: ten thousand small vectors cost 1 - 2 ms to allocate and to free per call otherwise)
+  std::vector<std::vector<int32_t>> &paths = r->paths_buf, &paths_e = r->paths_e_buf;
+  if ((int64_t)paths.size() < n_queries) { paths.resize((size_t)n_queries); paths_e.resize((size_t)n_queries); }
+  for (int64_t q = 0; q < n_queries; q++) { paths[(size_t)q].clear(); paths_e[(size_t)q].clear(); }
   std::vector<int32_t> list;
   std::vector<uint8_t> hit;
   std::vector<uint8_t> vmark((size_t)r->V, 0), emark((size_t)r->E, 0);
@@ -1408,6 +1413,28 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   std::vector<uint8_t> found;
   const int smode = search_mode();
   bool went_eager = false;
+  // A batch so large that its candidate paths would hold a quarter of the cached sets anyway (at ~64 items a path) does not start
+  // lazily: one launch tests every cached set (0.25 ms at 6.8 x 10^5 sets) and the searches run on known validity -- one round
+  // instead of two or more.  A count, not a clock; TENDON_HIP_LAZY_ONLY=1: never (the reference's loop item by item).
+  if (r->has_caches && (int64_t)active.size() * 256 >= r->V + r->E && !std::getenv("TENDON_HIP_LAZY_ONLY")) {
+    int64_t unknown = 0;
+    for (uint8_t x : r->vstat) unknown += x == V_UNKNOWN;
+    for (uint8_t x : r->estat) unknown += x == V_UNKNOWN;
+    if (unknown > 0) {
+      if ((rc = revalidate_locked(r, nullptr, nullptr))) return rc;
+      r->st_items_checked += unknown;
+      went_eager = true;
+      // (end points found invalid by that test: their queries end here, as they would have before the first search)
+      std::vector<int64_t> keep;
+      for (int64_t q : active) {
+        if (r->vstat[(size_t)starts[q]] == V_INVALID) status[q] = TR_QUERY_INVALID_START;
+        else if (r->vstat[(size_t)goals[q]] == V_INVALID) status[q] = TR_QUERY_INVALID_GOAL;
+        else keep.push_back(q);
+      }
+      active.swap(keep);
+    }
+  }
+  laps.lap("end points + set-up");
   while (!active.empty()) {
     r->st_rounds++;
     // A* for every unresolved query, on the host cores
@@ -1634,17 +1661,35 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       std::fprintf(stderr, "[tendon_hip] round %lld:\n", (long long)r->st_rounds);
       show("found", f); show("not found", nf);
     }
+    laps.lap("searches");
     r->st_astar_runs += (int64_t)todo.size();
     r->st_expanded += expanded.load();
     // unknown items on the candidate paths: all interior vertices, and the edges of paths without an unknown vertex
     // are only worth testing once the vertices are clean -- but testing them in the same launch costs nothing, saves
     // a round, and removing more invalid items never changes an accepted path (see the header comment)
     list.clear();
+    // (a large round from unknown validity: when the candidate paths hold a quarter as many items as there are cached sets, listing
+    // the unknown ones, sending the list and fetching the verdicts costs several times the one launch that tests EVERY cached set
+    // -- 0.25 ms at 6.8 x 10^5 sets -- so everything is tested at once; a count again, not a clock.  TENDON_HIP_LAZY_ONLY=1: never)
+    bool all_tested = false;
+    if (!went_eager && r->has_caches && !std::getenv("TENDON_HIP_LAZY_ONLY")) {
+      int64_t on_paths = 0;
+      for (size_t k = 0; k < active.size(); k++)
+        if (found[k]) on_paths += (int64_t)(paths[(size_t)active[k]].size() + paths_e[(size_t)active[k]].size());
+      if (on_paths * 4 >= r->V + r->E) {
+        int64_t unknown = 0;
+        for (uint8_t x : r->vstat) unknown += x == V_UNKNOWN;
+        for (uint8_t x : r->estat) unknown += x == V_UNKNOWN;
+        if ((rc = revalidate_locked(r, nullptr, nullptr))) return rc;
+        r->st_items_checked += unknown;
+        went_eager = true; all_tested = true;
+      }
+    }
     const auto t_items0 = std::chrono::steady_clock::now();
     // (large rounds: by ranges of queries on the host threads; an item goes to the list of the thread that marks it first -- the set
     // is the same whoever that is, and the order of the list decides nothing)
     const int Tb = active.size() >= 2048 ? std::min(T, 16) : 1;
-    {
+    if (!all_tested) {
       std::vector<std::vector<int32_t>> part((size_t)Tb);
       on_threads(Tb, [&](int t) {
         std::vector<int32_t> &mine = part[(size_t)t];
@@ -1708,6 +1753,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       went_eager = true;
     }
     active.swap(still);
+    laps.lap("items + verdicts");
   }
   for (int64_t q = 0; q < n_queries; q++) {
     const auto &pv = paths[(size_t)q];
@@ -1715,6 +1761,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     r->path_off[(size_t)q + 1] = (int64_t)r->path_v.size();
     path_offsets[q + 1] = r->path_off[(size_t)q + 1];
   }
+  laps.lap("paths out");
   if (stats) *stats = tr_roadmap_stats{r->st_rounds, r->st_items_checked, r->st_astar_runs, r->st_expanded};
   if (std::getenv("TENDON_HIP_SEARCH_STATS"))
     std::fprintf(stderr, "[tendon_hip] searches: mode %d, device state %d%s%s, %lld slots, %lld searches finished on the device, %lld handed back to the host, %lld on the host meanwhile\n",
