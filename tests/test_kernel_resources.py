@@ -131,8 +131,7 @@ template __global__ void trk::roadmap_astar<%d>(trk::SearchArgs);
 
 @pytest.mark.parametrize("sx", [4, 12])
 def test_search_kernel_occupancy_and_single_ticket_site(tmp_path, sx):
-    """roadmap_astar: 16 waves per CU (<= 128 VGPRs; its LDS image is sized for that), no register spilled to scratch beyond a few
-    dwords, and ONE query loop: hipcc 7.2 once jump-threaded the back edge of that loop for the 63 lanes that did not draw the
+    """roadmap_astar: 12 waves per CU (<= 168 VGPRs), no register spilled to scratch beyond a few dwords, and ONE query loop: hipcc 7.2 once jump-threaded the back edge of that loop for the 63 lanes that did not draw the
     ticket (`if (lane == 0) ticket = atomicAdd(..)`) into a copy of the loop that lane 0 was not part of -- cross-lane operations
     without the lane that writes the list heads, a GPU memory fault.  The ticket is now an atomic every lane executes; a threaded
     or duplicated loop would show as a second ticket site.  Returning dword adds in the listing: the ticket and the path buffer's."""
@@ -142,8 +141,9 @@ def test_search_kernel_occupancy_and_single_ticket_site(tmp_path, sx):
     out = subprocess.run(base + ["-c", "-Rpass-analysis=kernel-resource-usage", "-o", str(tmp_path / "ks.o")], capture_output=True, text=True)
     assert out.returncode == 0, out.stderr[-2000:]
     get = lambda key: int(re.search(key + r"[^:]*: (\d+)", out.stderr).group(1))
-    # (up to 4 state coordinates -- BASELINE's robots -- 16 waves per CU; the 12-coordinate form keeps more of a state row in registers)
-    assert get("Occupancy") >= (4 if sx == 4 else 3) and get("VGPRs") <= (128 if sx == 4 else 160) and get("AGPRs") == 0 and get("VGPRs Spill") == 0
+    # (12 waves per CU: a step holds two passes' arcs, records and heuristics at once; 168 registers is where a wave per SIMD would be lost)
+    # (the 12-coordinate form keeps a whole state row in registers: two waves per SIMD there)
+    assert get("Occupancy") >= (3 if sx == 4 else 2) and get("VGPRs") <= (168 if sx == 4 else 192) and get("AGPRs") == 0 and get("VGPRs Spill") == 0
     assert get("ScratchSize") <= 64
     asm = subprocess.run(base + ["-S", "-o", "-"], capture_output=True, text=True).stdout
     returning_adds = re.findall(r"^\s*(?:global|flat)_atomic_add v\d+, .*\bsc0\b", asm, flags=re.M)
