@@ -48,7 +48,10 @@ namespace trk {
 struct SArc { int32_t v, e; double w; };                      // roadmap.hip: Arc; v = SR_ARC_NONE: unused slot, SR_ARC_MORE: e = the next row;
                                                               // in the kernel's rows v carries, above SR_VBITS, the lanes the neighbour's own row needs
 struct SRec { double g, h; int32_t parent, parent_edge; uint32_t key, tag; };   // tag = generation << 1 | closed
-constexpr int SR_CAP = 640;                                   // near-list entries per wave (LDS)
+#ifndef TRK_SR_CAP
+#define TRK_SR_CAP 640
+#endif
+constexpr int SR_CAP = TRK_SR_CAP;                            // near-list entries per wave (LDS)
 constexpr int SR_MAXS = 12, SR_MAXL = 64;                     // state coordinates, landmarks
 constexpr int SR_K = 12;                                      // vertices expanded per step, at most (as many as their arcs fill two passes of 64 lanes: ~8)
 constexpr int SR_VBITS = 26;                                  // an open-list word: vertex | lanes its first row needs << SR_VBITS
