@@ -454,6 +454,14 @@ int tr_roadmap_search_stats(tr_roadmap *rm, int64_t out[8]);
  * roadmap (the vertex's record and row header, and per arc: the arc, two validity bytes, the arc count, the neighbour's record read
  * and written, its state and landmark rows) -- bench.py turns them into the kernel's HBM roofline fraction. */
 int tr_roadmap_profile(tr_roadmap *rm, double out[4]);
+/* The device searches' state -- a table of per-vertex records per search in flight, a pool of larger ones, the per-round arrays: sized
+ * by the largest round so far (a 512-query round ~0.9 GB, 3 072 searches in flight ~5.3 GB, whatever the roadmap's size), it stays with the
+ * roadmap between calls.  tr_roadmap_release_search_state hands it back to the device (the adjacency rows stay; the next round of 512
+ * queries or more allocates tables again, ~2 ms) and reports the bytes; tr_roadmap_search_state_bytes says what is held now.  When an
+ * allocation anywhere in the library runs out of device memory, the tables of every roadmap that is not inside a call are released
+ * the same way before the allocation is tried again. */
+int tr_roadmap_release_search_state(tr_roadmap *rm, int64_t *bytes_released);
+int tr_roadmap_search_state_bytes(tr_roadmap *rm, int64_t *bytes);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
  * of connectionStrategy_(v), `if (!getEdge(v, n)) connectVertices(v, n)`): the undirected edge set of the k-nearest
@@ -592,12 +600,13 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *                                   the kernel is still running (a word per query in pinned memory tells them) (default: starts at 6500,
  *                                   or a sixteenth of the roadmap's vertices if that is more, and doubles per roadmap while more than
  *                                   one search in fifty comes back; 0 none)
- *   TENDON_HIP_SEARCH_K=1..8        vertices the kernel takes off a search's open list per step, at most (default 8: as many as their
- *                                   arcs fill the wave's 64 lanes; 1 = the host's order)
- *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device (default: what it holds: 16 waves per CU)
+ *   TENDON_HIP_SEARCH_K=1..12       vertices the kernel takes off a search's open list per step, at most (default 12: as many as their
+ *                                   arcs fill the 64 lanes of the step's two passes; 1 = the host's order)
+ *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device, at most (default: what it holds: 12 waves per CU; a round of
+ *                                   fewer queries allocates tables for that many only)
  *   TENDON_HIP_SEARCH_LC0=8..14     log2 of the per-vertex records a search in flight owns (default 12: 176 KiB per slot with its far list;
  *                                   the searches' state does not depend on the roadmap's size); TENDON_HIP_SEARCH_POOL=a,b,c: shared tables of
- *                                   4 / 16 / 64 times that size for the searches that outgrow it (default slots, slots / 4, slots / 64: 7.3 GB in all at 4 096 slots; a search
+ *                                   4 / 16 / 64 times that size for the searches that outgrow it (default slots, slots / 4, slots / 64: 5.3 GB in all at 3 072 slots; a search
  *                                   that finds none free is handed back to the host threads).  Both read when a roadmap's first large
  *                                   round sets the searches up (tests reach the growth and hand-back paths with small values)
  *   TENDON_HIP_LAZY_ONLY=1          tr_roadmap_solve never looks at items off the candidate paths (default: when at least

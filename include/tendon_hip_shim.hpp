@@ -831,6 +831,10 @@ class VoxelCachedLazyPRM {
     if (rm_) rcheck(tr_roadmap_search_stats(rm_, o));
     return SearchStats{o[0], o[1], o[2], o[3], o[4], o[5], o[6]};
   }
+  /// Device memory the graph searches hold for this planner between calls, and handing it back (tr_roadmap_release_search_state;
+  /// the next large batch of queries allocates it again).
+  int64_t searchStateBytes() const { int64_t b = 0; if (rm_) rcheck(tr_roadmap_search_state_bytes(rm_, &b)); return b; }
+  int64_t releaseSearchState() { int64_t b = 0; if (rm_) rcheck(tr_roadmap_release_search_state(rm_, &b)); return b; }
   /// CompoundStateSpace::distance with the weights of Problem.cpp:112-152 (the edge cost connectVertices stores, :2857-2861)
   double distance(const double *a, const double *b) const {
     const auto &rb = vc_.robot();

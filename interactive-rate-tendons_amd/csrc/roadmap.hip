@@ -137,7 +137,8 @@ struct DevCache {
 };
 DevCache &dev_cache() { static DevCache c; return c; }
 }  // namespace
-void tr_dev_cache_trim() { dev_cache().trim(); }
+void release_idle_search_tables();   // (below: the search tables of the roadmaps that are not in a call right now)
+void tr_dev_cache_trim() { release_idle_search_tables(); dev_cache().trim(); }
 namespace {
 
 enum : uint8_t { V_UNKNOWN = 0, V_VALID = 1, V_INVALID = 2 };   // VALIDITY_UNKNOWN / VALIDITY_TRUE / removed from the graph
@@ -189,6 +190,7 @@ template <class T> struct RawArray {
 
 struct tr_roadmap {
   std::mutex mu;
+  std::atomic<bool> busy{false};       // a call holds `mu` (RmLock): the out-of-memory trim leaves this roadmap alone
   tr_ctx *ctx = nullptr;
   std::string err;
   int S = 0, NT = 0;
@@ -228,6 +230,7 @@ struct tr_roadmap {
     int state = 0;                       // 0: not set up yet, 1: ready, -1: not available for this roadmap (reason in `why`)
     std::string why;
     int64_t slots = 0, nq_cap = 0;
+    int64_t max_slots = 0;               // what the device holds at once (or TENDON_HIP_SEARCH_SLOTS); `slots` follows the rounds' sizes up to it
     int32_t lc0 = 12;                    // log2 of the records of a slot's own table
     int32_t pool_n[trk::SR_CLASSES] = {0, 0, 0, 0}, pool_word[trk::SR_CLASSES] = {0, 0, 0, 0};
     size_t ctl_bytes = 0, table_bytes = 0;
@@ -273,6 +276,19 @@ struct tr_roadmap {
 };
 
 namespace {
+
+// Every entry point that works on a roadmap holds its mutex through this; `busy` lets the trim path (which may run on the very
+// thread that holds the mutex: an allocation inside a call ran out of memory) tell without touching the mutex.
+struct RmLock {
+  tr_roadmap *r;
+  explicit RmLock(tr_roadmap *r_) : r(r_) { r->mu.lock(); r->busy.store(true, std::memory_order_release); }
+  ~RmLock() { r->busy.store(false, std::memory_order_release); r->mu.unlock(); }
+  RmLock(const RmLock &) = delete;
+  RmLock &operator=(const RmLock &) = delete;
+};
+// the live roadmaps (tr_roadmap_create .. tr_roadmap_destroy), for release_idle_search_tables
+std::mutex g_roadmaps_mu;
+std::vector<tr_roadmap *> g_roadmaps;
 
 int rfail(tr_roadmap *r, int code, const std::string &m) { if (r) r->err = m; return code; }
 
@@ -600,6 +616,26 @@ void free_comp(tr_roadmap *r) {
   r->dc = tr_roadmap::DevComp{};
 }
 
+// The searches' tables and per-round arrays -- all of the search state that does not depend on the roadmap -- go back to the buffer
+// cache; the adjacency rows stay, and the next large round allocates tables again (search_tables).  Caller holds r->mu.
+size_t release_search_tables(tr_roadmap *r) {
+  auto &d = r->ds;
+  if (d.in_flight) return 0;
+  size_t b = 0;
+  if (d.tables) {
+    dev_cache().release(d.tables);
+    b += d.table_bytes;
+    d.tables = nullptr; d.table_bytes = 0; d.slots = 0; d.gens_issued = 0;
+    for (int c = 0; c < trk::SR_CLASSES; c++) { d.pool[c] = nullptr; d.pool_n[c] = 0; }
+  }
+  if (d.qarena) {
+    dev_cache().release(d.qarena);
+    b += (size_t)d.nq_cap * 17 + (size_t)d.pbuf_cap * 4;
+    d.qarena = nullptr; d.nq_cap = 0; d.pbuf_cap = 0;
+  }
+  return b;
+}
+
 void free_search(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.arena) dev_cache().release(d.arena);
@@ -787,9 +823,21 @@ SearchKernel search_kernel_for(int S) { return S <= 4 ? trk::roadmap_astar<4> : 
 // tables (x 4 per class) that long searches move into.  The slot count is what the chip holds of this kernel (LDS: 9.8 KiB per wave).
 //   TENDON_HIP_SEARCH_SLOTS=n     searches in flight (default: what the device holds)
 //   TENDON_HIP_SEARCH_LC0=8..14   log2 of a slot's own table (default 12; tests: a small value makes every search grow)
-//   TENDON_HIP_SEARCH_POOL=a,b,c  tables of the three larger classes (default slots, slots / 4, slots / 64 -- 7.3 GB with the slots' own at
-//                                 4 096 slots: a 6 x 10^5-vertex roadmap's searches touch 10^4 - 10^5 vertices each; 0,0,0: every search that outgrows
+//   TENDON_HIP_SEARCH_POOL=a,b,c  tables of the three larger classes (default slots, slots / 4, slots / 64 -- 5.3 GB with the slots' own at
+//                                 3 072 slots: a 6 x 10^5-vertex roadmap's searches touch 10^4 - 10^5 vertices each; 0,0,0: every search that outgrows
 //                                 its table is handed back to the host threads)
+// pool tables per class for `slots` searches in flight (class 0: the slots' own)
+void search_pool_counts(int64_t slots, int64_t pn[trk::SR_CLASSES]) {
+  pn[0] = 0; pn[1] = std::max<int64_t>(64, slots); pn[2] = std::max<int64_t>(16, slots / 4); pn[3] = std::max<int64_t>(8, slots / 64);
+  if (const char *e = std::getenv("TENDON_HIP_SEARCH_POOL")) {
+    long long x1 = 0, x2 = 0, x3 = 0;
+    if (std::sscanf(e, "%lld,%lld,%lld", &x1, &x2, &x3) >= 1) {
+      int64_t most[trk::SR_CLASSES];
+      for (int c = 0; c < trk::SR_CLASSES; c++) most[c] = std::max<int64_t>(pn[c], (int64_t)1 << 16);
+      pn[1] = std::min<int64_t>(most[1], std::max(0ll, x1)); pn[2] = std::min<int64_t>(most[2], std::max(0ll, x2)); pn[3] = std::min<int64_t>(most[3], std::max(0ll, x3));
+    }
+  }
+}
 bool search_setup(tr_roadmap *r) {
   auto &d = r->ds;
   if (d.state != 0) return d.state > 0;
@@ -857,30 +905,17 @@ bool search_setup(tr_roadmap *r) {
   }
   int64_t slots = (int64_t)per_cu * prop.multiProcessorCount;
   if (const char *e = std::getenv("TENDON_HIP_SEARCH_SLOTS")) slots = std::max<int64_t>(1, std::min<int64_t>(slots, std::atoll(e)));
+  d.max_slots = slots;
   d.lc0 = 12;
   if (const char *e = std::getenv("TENDON_HIP_SEARCH_LC0")) d.lc0 = std::max(8, std::min(14, std::atoi(e)));
-  int64_t pn[trk::SR_CLASSES] = {0, std::max<int64_t>(64, slots), std::max<int64_t>(16, slots / 4), std::max<int64_t>(8, slots / 64)};
-  if (const char *e = std::getenv("TENDON_HIP_SEARCH_POOL")) {
-    long long x1 = 0, x2 = 0, x3 = 0;
-    if (std::sscanf(e, "%lld,%lld,%lld", &x1, &x2, &x3) >= 1) { pn[1] = std::max(0ll, x1); pn[2] = std::max(0ll, x2); pn[3] = std::max(0ll, x3); }
+  {
+    // control words: the counters, then the pool's claim bitmaps at their largest (search_tables lays them out per table set)
+    int64_t pn[trk::SR_CLASSES];
+    search_pool_counts(slots, pn);
+    int64_t word = trk::SR_CTL_WORDS;
+    for (int c = 0; c < trk::SR_CLASSES; c++) word += (pn[c] + 31) / 32;
+    d.ctl_bytes = ((size_t)word * 4 + 255) & ~(size_t)255;
   }
-  // the searches' state within a third of what is free: the pool shrinks first, then the slots
-  size_t free_b = 0, total_b = 0;
-  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { d.why = "hipMemGetInfo"; return false; }
-  auto tables_bytes = [&](int64_t s_) {
-    size_t b = (size_t)s_ * trk::search_chunk_bytes(d.lc0);
-    for (int c = 1; c < trk::SR_CLASSES; c++) b += (size_t)pn[c] * trk::search_chunk_bytes(d.lc0 + 2 * c);
-    return b;
-  };
-  for (int c = trk::SR_CLASSES - 1; c >= 1; c--)
-    while (pn[c] > 0 && tables_bytes(slots) > free_b / 3) pn[c] /= 2;
-  while (slots > 64 && tables_bytes(slots) > free_b / 3) slots /= 2;
-  if (tables_bytes(slots) > free_b / 3) { d.why = "out of device memory"; return false; }
-  d.slots = slots;
-  int word = trk::SR_CTL_WORDS;
-  for (int c = 0; c < trk::SR_CLASSES; c++) { d.pool_n[c] = (int32_t)pn[c]; d.pool_word[c] = word; word += (int)((pn[c] + 31) / 32); }
-  d.ctl_bytes = ((size_t)word * 4 + 255) & ~(size_t)255;
-  d.table_bytes = tables_bytes(slots);
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
   const int Lmax = trk::SR_MAXL;
   const size_t b_rows = up((size_t)n_rows * D * sizeof(trk::SArc)), b_vr = up((size_t)V * trk::search_row_bytes(r->S, Lmax)),
@@ -896,25 +931,63 @@ bool search_setup(tr_roadmap *r) {
   d.d_deg = (uint8_t *)p; p += b_vs;
   d.d_ctl = (uint32_t *)p;
   laps.lap("device properties + arena");
-  bool ok = dev_cache().alloc(dev, (void **)&d.tables, d.table_bytes) == hipSuccess;
-  if (ok) {
-    char *q = d.tables + (size_t)slots * trk::search_chunk_bytes(d.lc0);
-    for (int c = 1; c < trk::SR_CLASSES; c++) { d.pool[c] = q; q += (size_t)pn[c] * trk::search_chunk_bytes(d.lc0 + 2 * c); }
-  }
-  laps.lap("tables allocated");
-  // (generation 0 is nobody's: cleared once, never again until the generation counter would wrap)
-  ok = ok && hipMemsetAsync(d.tables, 0, d.table_bytes, nullptr) == hipSuccess &&
-       hipMemcpyAsync(d.d_rows, rows.data(), (size_t)n_rows * D * sizeof(trk::SArc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
-       hipMemcpyAsync(d.d_deg, lanes.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
-       hipStreamSynchronize(nullptr) == hipSuccess;
-  laps.lap("tables cleared + graph uploaded");
+  const bool ok = hipMemcpyAsync(d.d_rows, rows.data(), (size_t)n_rows * D * sizeof(trk::SArc), hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+                  hipMemcpyAsync(d.d_deg, lanes.data(), (size_t)V, hipMemcpyHostToDevice, nullptr) == hipSuccess &&
+                  hipStreamSynchronize(nullptr) == hipSuccess;
+  laps.lap("graph uploaded");
   if (!ok) { free_search(r); r->ds.state = -1; r->ds.why = "out of device memory"; return false; }
   if (std::getenv("TENDON_HIP_SEARCH_STATS"))
-    std::fprintf(stderr, "[tendon_hip] search state: %lld slots x %zu KiB + pool %d / %d / %d tables = %.1f MiB (whatever the roadmap's size); roadmap: %lld rows of %d arcs (%lld continued), %.1f MiB\n",
-                 (long long)slots, trk::search_chunk_bytes(d.lc0) >> 10, d.pool_n[1], d.pool_n[2], d.pool_n[3], (double)d.table_bytes / 1048576.0,
-                 (long long)n_rows, D, (long long)(n_rows - V), (double)(b_rows + b_vr + 2 * b_vs + b_es) / 1048576.0);
+    std::fprintf(stderr, "[tendon_hip] search graph: %lld rows of %d arcs (%lld continued), %.1f MiB\n", (long long)n_rows, D, (long long)(n_rows - V),
+                 (double)(b_rows + b_vr + 2 * b_vs + b_es) / 1048576.0);
   d.lm_current = false;
   d.state = 1;
+  return true;
+}
+
+// The tables of the searches in flight, sized by the round: `want` queries need min(want, max_slots) slots (in steps of 256, and at
+// least twice what a smaller round left, so a caller whose rounds grow re-allocates a handful of times) and a pool in proportion.
+// A 512-query round on a fresh roadmap holds ~0.9 GB, a 10 000-query round the device's full 3 072 slots (~5.3 GB); the state stays
+// with the roadmap until tr_roadmap_release_search_state, the out-of-memory trim (release_idle_search_tables) or tr_roadmap_destroy.
+bool search_tables(tr_roadmap *r, int64_t want) {
+  auto &d = r->ds;
+  int64_t slots = std::min<int64_t>(d.max_slots, std::max<int64_t>(256, (want + 255) & ~(int64_t)255));
+  if (d.tables && d.slots >= slots) return true;
+  if (d.tables) slots = std::max(slots, std::min<int64_t>(d.max_slots, 2 * d.slots));
+  Laps laps("search_tables");
+  const int dev = tr_device(r->ctx);
+  if (d.tables) { dev_cache().release(d.tables); d.tables = nullptr; d.slots = 0; }
+  int64_t pn[trk::SR_CLASSES];
+  search_pool_counts(slots, pn);
+  // within a third of what is free: the pool shrinks first, then the slots
+  size_t free_b = 0, total_b = 0;
+  if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { d.why = "hipMemGetInfo"; return false; }
+  auto tables_bytes = [&](int64_t s_) {
+    size_t b = (size_t)s_ * trk::search_chunk_bytes(d.lc0);
+    for (int c = 1; c < trk::SR_CLASSES; c++) b += (size_t)pn[c] * trk::search_chunk_bytes(d.lc0 + 2 * c);
+    return b;
+  };
+  for (int c = trk::SR_CLASSES - 1; c >= 1; c--)
+    while (pn[c] > 0 && tables_bytes(slots) > free_b / 3) pn[c] /= 2;
+  while (slots > 64 && tables_bytes(slots) > free_b / 3) slots /= 2;
+  if (tables_bytes(slots) > free_b / 3) { d.why = "out of device memory"; return false; }
+  int64_t word = trk::SR_CTL_WORDS;
+  for (int c = 0; c < trk::SR_CLASSES; c++) { d.pool_n[c] = (int32_t)pn[c]; d.pool_word[c] = (int32_t)word; word += (pn[c] + 31) / 32; }
+  if ((size_t)word * 4 > d.ctl_bytes) { d.why = "pool larger than the control words"; return false; }
+  d.table_bytes = tables_bytes(slots);
+  if (dev_cache().alloc(dev, (void **)&d.tables, d.table_bytes) != hipSuccess) { d.tables = nullptr; d.table_bytes = 0; d.why = "out of device memory"; return false; }
+  char *q = d.tables + (size_t)slots * trk::search_chunk_bytes(d.lc0);
+  for (int c = 1; c < trk::SR_CLASSES; c++) { d.pool[c] = q; q += (size_t)pn[c] * trk::search_chunk_bytes(d.lc0 + 2 * c); }
+  laps.lap("tables allocated");
+  // (generation 0 is nobody's: cleared once, never again until the generation counter would wrap)
+  if (hipMemsetAsync(d.tables, 0, d.table_bytes, nullptr) != hipSuccess) {
+    dev_cache().release(d.tables); d.tables = nullptr; d.table_bytes = 0; d.why = "hipMemsetAsync"; return false;
+  }
+  d.gens_issued = 0;
+  d.slots = slots;
+  laps.lap("tables cleared");
+  if (std::getenv("TENDON_HIP_SEARCH_STATS"))
+    std::fprintf(stderr, "[tendon_hip] search state: %lld slots x %zu KiB + pool %d / %d / %d tables = %.1f MiB (whatever the roadmap's size)\n",
+                 (long long)slots, trk::search_chunk_bytes(d.lc0) >> 10, d.pool_n[1], d.pool_n[2], d.pool_n[3], (double)d.table_bytes / 1048576.0);
   return true;
 }
 
@@ -931,6 +1004,7 @@ bool device_search_launch(tr_roadmap *r, const int32_t *starts, const int32_t *g
   const int dev = tr_device(r->ctx);
   const int64_t nq = (int64_t)klist.size(), V = r->V;
   if (nq == 0) return false;
+  if (!search_tables(r, nq)) return false;
   const int L = r->lm_n > 0 ? r->lm_n : 0;
   if (L > trk::SR_MAXL) return false;
   auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
@@ -1196,12 +1270,14 @@ int tr_roadmap_create(tr_ctx *ctx, const double *states, int64_t n_vertices, con
   laps.lap("edges + degrees + adjacency");
   r->vstat.assign((size_t)n_vertices, V_UNKNOWN); r->estat.assign((size_t)n_edges, V_UNKNOWN);
   r->vpresent.assign((size_t)n_vertices, 1); r->epresent.assign((size_t)n_edges, 1);
+  { std::lock_guard<std::mutex> g(g_roadmaps_mu); g_roadmaps.push_back(r); }
   *out = r;
   return TR_OK;
 }
 
 void tr_roadmap_destroy(tr_roadmap *r) {
   if (!r) return;
+  { std::lock_guard<std::mutex> g(g_roadmaps_mu); g_roadmaps.erase(std::remove(g_roadmaps.begin(), g_roadmaps.end(), r), g_roadmaps.end()); }
   (void)hipSetDevice(tr_device(r->ctx));
   free_dev(r);
   free_search(r);
@@ -1215,7 +1291,7 @@ int set_caches_impl(tr_roadmap *r, const int64_t *v_offsets, const uint32_t *v_i
                     const uint64_t *v_present_bits, const int64_t *e_offsets, const uint32_t *e_ids,
                     const uint64_t *e_masks, const uint64_t *e_present_bits, hipMemcpyKind kind) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   if (!v_offsets || !e_offsets) return rfail(r, TR_ERR_INVALID_ARG, "null offsets");
   const int64_t nv = v_offsets[r->V], ne = e_offsets[r->E];
   if (nv < 0 || ne < 0 || (nv > 0 && (!v_ids || !v_masks)) || (ne > 0 && (!e_ids || !e_masks))) return rfail(r, TR_ERR_INVALID_ARG, "bad CSR arrays");
@@ -1269,7 +1345,7 @@ int tr_roadmap_set_caches_dev(tr_roadmap *r, const int64_t *v_offsets, const uin
 
 int tr_roadmap_prepare(tr_roadmap *r, int32_t n_landmarks, int32_t n_threads) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   if (n_landmarks < 0 || n_landmarks > 64) return rfail(r, TR_ERR_INVALID_ARG, "landmark count must be in [0, 64]");
   build_landmarks(r, n_landmarks, host_threads(n_threads));
   if (r->lm_mismatch) return rfail(r, TR_ERR_RUNTIME, "landmark distances: the device's table differs from the host's (TENDON_HIP_LANDMARKS=check)");
@@ -1278,7 +1354,7 @@ int tr_roadmap_prepare(tr_roadmap *r, int32_t n_landmarks, int32_t n_threads) {
 
 int tr_roadmap_clear_validity(tr_roadmap *r) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   std::fill(r->vstat.begin(), r->vstat.end(), (uint8_t)V_UNKNOWN);
   std::fill(r->estat.begin(), r->estat.end(), (uint8_t)V_UNKNOWN);
   return TR_OK;
@@ -1330,13 +1406,13 @@ extern "C" {
 
 int tr_roadmap_revalidate(tr_roadmap *r, int64_t *n_invalid_vertices, int64_t *n_invalid_edges) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   return revalidate_locked(r, n_invalid_vertices, n_invalid_edges);
 }
 
 int tr_roadmap_get_validity(tr_roadmap *r, uint8_t *vertex_status, uint8_t *edge_status) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   if (vertex_status) std::memcpy(vertex_status, r->vstat.data(), r->vstat.size());
   if (edge_status) std::memcpy(edge_status, r->estat.data(), r->estat.size());
   return TR_OK;
@@ -1344,7 +1420,7 @@ int tr_roadmap_get_validity(tr_roadmap *r, uint8_t *vertex_status, uint8_t *edge
 
 int tr_roadmap_set_validity(tr_roadmap *r, const uint8_t *vertex_status, const uint8_t *edge_status) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   for (int64_t i = 0; vertex_status && i < r->V; i++) if (vertex_status[i] > V_INVALID) return rfail(r, TR_ERR_INVALID_ARG, "vertex status must be 0, 1 or 2");
   for (int64_t i = 0; edge_status && i < r->E; i++) if (edge_status[i] > V_INVALID) return rfail(r, TR_ERR_INVALID_ARG, "edge status must be 0, 1 or 2");
   if (vertex_status) std::memcpy(r->vstat.data(), vertex_status, r->vstat.size());
@@ -1355,7 +1431,7 @@ int tr_roadmap_set_validity(tr_roadmap *r, const uint8_t *vertex_status, const u
 int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals, int64_t n_queries, int32_t n_threads,
                      int32_t *status, double *cost, int64_t *path_offsets, tr_roadmap_stats *stats) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   if (n_queries < 0 || (n_queries > 0 && (!starts || !goals || !status || !path_offsets))) return rfail(r, TR_ERR_INVALID_ARG, "bad argument");
   r->path_off.assign((size_t)n_queries + 1, 0); r->path_v.clear();
   r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
@@ -1772,7 +1848,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
 
 int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[8]) {
   if (!r || !out) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   out[0] = r->ds.st_queries; out[1] = r->ds.st_fallbacks; out[2] = r->ds.st_host_share; out[3] = r->ds.st_moves;
   out[4] = r->ds.st_expanded; out[5] = r->st_expanded - r->ds.st_expanded;
   out[6] = r->dc.st_cut; out[7] = r->ds.st_grows;
@@ -1781,7 +1857,7 @@ int tr_roadmap_search_stats(tr_roadmap *r, int64_t out[8]) {
 
 int tr_roadmap_profile(tr_roadmap *r, double out[4]) {
   if (!r || !out) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   const double deg = r->V > 0 ? (double)r->adj.size() / (double)r->V : 0.0;
   const int L = r->lm_n > 0 ? r->lm_n : 0;
   out[0] = r->ds.st_kernel_ms; out[1] = (double)r->ds.st_launches; out[2] = (double)r->ds.st_expanded;
@@ -1791,9 +1867,27 @@ int tr_roadmap_profile(tr_roadmap *r, double out[4]) {
   return TR_OK;
 }
 
+int tr_roadmap_release_search_state(tr_roadmap *r, int64_t *bytes_released) {
+  if (!r) return TR_ERR_INVALID_ARG;
+  RmLock lock_(r);
+  RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
+  const size_t b = release_search_tables(r);
+  dev_cache().trim();                                       // (not parked for the next owner: back to the device)
+  if (bytes_released) *bytes_released = (int64_t)b;
+  return TR_OK;
+}
+
+int tr_roadmap_search_state_bytes(tr_roadmap *r, int64_t *bytes) {
+  if (!r || !bytes) return TR_ERR_INVALID_ARG;
+  RmLock lock_(r);
+  const auto &d = r->ds;
+  *bytes = (int64_t)((d.tables ? d.table_bytes : 0) + (d.qarena ? (size_t)d.nq_cap * 17 + (size_t)d.pbuf_cap * 4 : 0));
+  return TR_OK;
+}
+
 int tr_roadmap_fetch_paths(tr_roadmap *r, int32_t *path_vertices, int64_t capacity) {
   if (!r) return TR_ERR_INVALID_ARG;
-  std::lock_guard<std::mutex> lock_(r->mu);
+  RmLock lock_(r);
   const int64_t n = (int64_t)r->path_v.size();
   if (capacity < n) return rfail(r, TR_ERR_INVALID_ARG, "capacity smaller than the stored paths");
   if (n > 0) {
@@ -1804,3 +1898,15 @@ int tr_roadmap_fetch_paths(tr_roadmap *r, int32_t *path_vertices, int64_t capaci
 }
 
 }  // extern "C"
+
+// An allocation somewhere in the library ran out of memory (tr_dev_cache_trim): the search tables of every roadmap that is not inside
+// a call right now go back to the device; their next large round allocates them again.
+void release_idle_search_tables() {
+  std::lock_guard<std::mutex> g(g_roadmaps_mu);
+  for (tr_roadmap *r : g_roadmaps) {
+    if (r->busy.load(std::memory_order_acquire)) continue;  // (possibly by this very thread: the mutex is not asked)
+    if (!r->mu.try_lock()) continue;
+    (void)release_search_tables(r);
+    r->mu.unlock();
+  }
+}

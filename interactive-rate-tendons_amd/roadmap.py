@@ -495,3 +495,15 @@ class VoxelCachedLazyPRM:
         # the roadmap_astar launches of this solve (HIP events): ms, launches, expansions, algorithmic bytes per expansion
         self.search_profile = dict(kernel_ms=float(pr[0]), launches=int(pr[1]), expansions=int(pr[2]), bytes_per_expansion=float(pr[3]))
         return dict(status=status, cost=cost, path_offsets=off, path_vertices=pv, paths=_Paths(pv, off))
+
+    def search_state_bytes(self):
+        """Device memory the graph searches hold for this roadmap between calls (tr_roadmap_search_state_bytes)."""
+        b = self._C.c_int64(0)
+        self._check(self.lib.tr_roadmap_search_state_bytes(self._rm, self._C.byref(b)))
+        return int(b.value)
+
+    def release_search_state(self):
+        """Hands the searches' tables back to the device (tr_roadmap_release_search_state); the next large round allocates them again."""
+        b = self._C.c_int64(0)
+        self._check(self.lib.tr_roadmap_release_search_state(self._rm, self._C.byref(b)))
+        return int(b.value)

@@ -436,6 +436,38 @@ def test_vertex_signatures_handed_over_from_the_vertex_phase(irt):
         e2.validate_candidates_sig_dev(1, 0, 64, torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(64 * 160, dtype=torch.int32, device="cuda"))
 
 
+def test_signature_rows_equal_the_cells_of_the_stored_points(irt):
+    """The FK kernels agree on tips to rounding only (test_fused_and_separate_kernels_give_identical_bits), and the edge verdicts
+    hang on the signature rows: the rows fk_verdict<SIG> writes for a batch of candidates are, word for word, the cells
+    (collision/VoxelOctree.cpp:309-317: closed domain check, truncated quotient) of the points the stored-point kernel fk_rk4_batch
+    returns for the same states -- a one-ulp difference between the kernels moves no point across a cell wall on this batch."""
+    import torch
+    W, D = irt.workloads, irt.distributed
+    robot = W.robot_config3()
+    vox, _ = W.reach_environment(seed=7, n_spheres=64)
+    eng = irt.VoxelBackboneValidityChecker(robot, irt.VoxelEnvironment(), vox).engine
+    sw, S, P, box, seed, M = eng.signature_words(), eng.state_size, eng.num_points, D.sampling_box(robot), 29, 8192
+    d_bits = torch.zeros(M // 64, dtype=torch.int64, device="cuda")
+    d_sig = torch.full((M, sw), -1, dtype=torch.int32, device="cuda")
+    eng.validate_candidates_sig_dev(seed, 0, M, d_bits, d_sig, box=box)
+    cand = torch.empty(M * S, dtype=torch.float64, device="cuda")
+    eng.candidate_states_dev(seed, 0, M, cand, box=box)
+    torch.cuda.synchronize()
+    pts = eng.fk_batch(cand.cpu().numpy().reshape(M, S))["p"]                       # [M][P][3] from the stored-point kernel
+    lims = (vox.xlim(), vox.ylim(), vox.zlim())
+    inside = np.ones((M, P), dtype=bool)
+    word = np.zeros((M, P), dtype=np.int64)
+    for a, ((lo, hi), d) in enumerate(zip(lims, (vox.dx(), vox.dy(), vox.dz()))):
+        x = pts[:, :, a]
+        with np.errstate(invalid="ignore"):
+            inside &= ~((x < lo) | (hi < x)) & (np.abs(x) < 1e300)
+        with np.errstate(invalid="ignore"):
+            word |= (((x - lo) / d).astype(np.int64) & 1023) << (10 * a)
+    word[~inside] = 1 << 30
+    got = d_sig[:, :P].cpu().numpy().view(np.uint32).astype(np.int64)
+    assert inside.mean() > 0.99 and np.array_equal(got, word)
+
+
 def test_sampler_returns_the_signature_rows_of_its_vertices(irt):
     """tr_sample_valid_vertices_sig_dev: the rejection loop's accepted vertices come with their signature rows -- the rows
     tr_validate_candidates_sig_dev writes for those candidates, whatever the batch sizes and whether or not the caller keeps the

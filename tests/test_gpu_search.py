@@ -293,3 +293,38 @@ def test_lazy_loop_turns_eager_when_queries_keep_coming_back(irt, monkeypatch):
         assert np.array_equal(again[0]["status"], out[0]["status"]) and np.array_equal(again[0]["path_vertices"], out[0]["path_vertices"])
         assert again[1]["rounds"] == out[1]["rounds"] and again[1]["items_checked"] == out[1]["items_checked"], (again[1], out[1])
         assert np.array_equal(again[2], out[2]) and np.array_equal(again[3], out[3])
+
+
+def test_search_state_follows_the_round_size_and_can_be_released(irt, monkeypatch):
+    """The searches' tables are sized by the largest round so far, not by what the device could hold: a 600-query round holds tables
+    for 768 searches in flight, a 3 000-query round the device's full set; tr_roadmap_release_search_state hands them back and the
+    next round allocates them again -- the answers are the host's every time."""
+    import torch
+
+    def _same(a, b, expansions=False):          # (the searches run differ: the component labels answer a few queries on one side only)
+        for k in ("status", "cost", "path_offsets", "path_vertices"):
+            assert np.array_equal(a[0][k], b[0][k]), k
+        assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3])
+
+    prm, states = _prm(irt, 2500, 6, seed=21)
+    prm.prepare(8)
+    rng = np.random.default_rng(9)
+    pairs = rng.integers(0, len(states), size=(3000, 2)).astype(np.int32)
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+    want_small, want_all = _solve(prm, pairs[:600, 0], pairs[:600, 1], True), _solve(prm, pairs[:, 0], pairs[:, 1], True)
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "device")
+    assert prm.search_state_bytes() == 0
+    got = _solve(prm, pairs[:600, 0], pairs[:600, 1], True)
+    _same(got, want_small, expansions=False)
+    small = prm.search_state_bytes()
+    assert prm.search_stats["device"] > 0 and 100e6 < small < 1.5e9                    # 768 slots x 176 KiB + a pool in proportion
+    got = _solve(prm, pairs[:, 0], pairs[:, 1], True)
+    _same(got, want_all, expansions=False)
+    full = prm.search_state_bytes()
+    assert full > 2.5 * small
+    free0 = torch.cuda.mem_get_info()[0]
+    assert prm.release_search_state() == full and prm.search_state_bytes() == 0
+    assert torch.cuda.mem_get_info()[0] - free0 > 0.9 * full                             # back with the device, not parked
+    got = _solve(prm, pairs[:600, 0], pairs[:600, 1], True)
+    _same(got, want_small, expansions=False)
+    assert prm.search_stats["device"] > 0 and prm.search_state_bytes() == small
