@@ -197,7 +197,13 @@ enum { EQ_HEAD = 0, EQ_TAIL = 32, EQ_DONE = 64, EQ_FLAGS = 96, EQ_DOMAIN = 97, E
        // ... and inside "folding": release + decrement | acquire + level records | candidates' verdicts | allocation + records | release + publish
        EQ_T_F0 = 114, EQ_T_F1 = 116, EQ_T_F2 = 118, EQ_T_F3 = 120, EQ_T_F4 = 122,
        EQ_SIZES = 124,              // rounds of 64 | 32..63 | 2..31 | 1 samples
-       EQ_AVAIL = 128, EQ_WORDS = 160 };
+       EQ_AVAIL = 128,
+#ifdef TRK_EQ_TRACE
+       EQ_TRACE = 160, EQ_WORDS = 160 + 8 * 64 * 4 };   // (a tuning build, profiles/build_ab.py fk_q4,tendon_hip -DTRK_EQ_TRACE: eight waves write start / end of
+                                                        // integration / end of fold and the shader clock of their first 64 rounds; TENDON_HIP_EDGE_TIMING prints them)
+#else
+       EQ_WORDS = 160 };
+#endif
 enum { EQF_OVERFLOW = 1u, EQF_STUCK = 2u, EQF_DEEP = 4u };      // pool too small | a wait made no progress | a level of more than 2048 intervals
 constexpr int EQ_STASH_WORDS = 68;        // LDS words a wave keeps behind the verdict body's image across an integration (edge_queue_kernel.hpp)
 constexpr int EQ_MAX_CAND = 4096;        // candidates (two per interval) of one edge level the finishing wave can hold

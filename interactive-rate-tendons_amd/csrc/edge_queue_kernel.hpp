@@ -157,6 +157,9 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
   const int lane = threadIdx.x;
   EqClock clk;
   clk.start();
+#ifdef TRK_EQ_TRACE
+  int tr_round = 0;
+#endif
   for (;;) {
     int zero = 0;
     asm volatile("" : "+s"(zero));      // (as PointSweep::args: the queue's arguments are re-read when needed, not held across the RK4 loop)
@@ -228,7 +231,18 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     int zero2 = 0;
     asm volatile("" : "+s"(zero2));
     const EdgeQueueArgs &q2 = qa[zero2];
+#ifdef TRK_EQ_TRACE
+    const uint32_t tr_start = (uint32_t)clk.t;
+    const unsigned long long tr_w0 = wall_clock64(), tr_c0 = (unsigned long long)clock64();
+    // (the shader clock against the 100 MHz wall clock over a fixed stretch of ALU work: the frequency the chip runs at right now)
+    { float x = (float)lane; for (int i = 0; i < 2000; i++) x = __builtin_fmaf(x, 1.0000001f, 0.5f); if (x == 12345.678f) asm volatile("s_nop 0"); }
+    const unsigned long long tr_w1 = wall_clock64(), tr_c1 = (unsigned long long)clock64();
+    const uint32_t tr_mhz = tr_w1 > tr_w0 ? (uint32_t)((tr_c1 - tr_c0) * 100ull / (tr_w1 - tr_w0)) : 0u;
+#endif
     clk.lap(q2.ctl, EQ_T_FK);
+#ifdef TRK_EQ_TRACE
+    const uint32_t tr_fk = (uint32_t)clk.t;
+#endif
     if (__any(lv.pending)) {
       // the exact pairwise self-collision sweep needs every backbone point at once: this wave integrates its round again,
       // storing the points in its own columns of the workspace, and takes sweep_body's verdict for the pending lanes
@@ -409,6 +423,13 @@ __global__ __launch_bounds__(64, (N <= TRK_VERDICT_TWO_WAVE_MAXN ? 2 : 1)) void 
     }
     __syncthreads();
     clk.lap(q2.ctl, EQ_T_FOLD);
+#ifdef TRK_EQ_TRACE
+    if (lane == 0 && (blockIdx.x & 255u) == 0u && (blockIdx.x >> 8) < 8u && tr_round < 64) {
+      uint32_t *w = q2.ctl + EQ_TRACE + ((blockIdx.x >> 8) * 64 + tr_round) * 4;
+      w[0] = tr_start; w[1] = tr_fk; w[2] = (uint32_t)clk.t; w[3] = tr_mhz ? tr_mhz : 1u;
+    }
+    tr_round++;
+#endif
   }
 }
 

@@ -1736,6 +1736,25 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       };
       std::fprintf(stderr, "[tendon_hip] round %lld:\n", (long long)r->st_rounds);
       show("found", f); show("not found", nf);
+      const char *hp = std::getenv("TENDON_HIP_SEARCH_HIST");
+      if (hp && hp[0] == '/') {                               // (a path: one line per search -- expansions against what could predict them)
+        if (FILE *fh = std::fopen(hp, "a")) {
+          const int L = r->lm_n > 0 ? r->lm_n : 0;
+          for (size_t k = 0; k < active.size(); k++) {
+            const int64_t q = active[k];
+            const int32_t s_ = starts[q], g_ = goals[q];
+            double lb = 0.0, sum_s = 1e300;
+            for (int l = 0; l < L; l++) {
+              const double a_ = r->lm_d[(size_t)s_ * L + l], b_ = r->lm_d[(size_t)g_ * L + l];
+              lb = std::max(lb, std::fabs(a_ - b_)); sum_s = std::min(sum_s, a_ + b_);
+            }
+            std::fprintf(fh, "%lld %lld %d %lld %.6g %.6g %.6g %d %d\n", (long long)r->st_rounds, (long long)q, (int)found[k], (long long)hist[k],
+                         state_distance(r, &r->states[(size_t)s_ * r->S], &r->states[(size_t)g_ * r->S]), lb, sum_s,
+                         (int)(r->adj_off[(size_t)s_ + 1] - r->adj_off[(size_t)s_]), (int)(r->adj_off[(size_t)g_ + 1] - r->adj_off[(size_t)g_]));
+          }
+          std::fclose(fh);
+        }
+      }
     }
     laps.lap("searches");
     r->st_astar_runs += (int64_t)todo.size();

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""An A/B build of libtendon_hip.so: one translation unit recompiled with extra flags, the others as built.
+"""An A/B build of libtendon_hip.so: one translation unit (or several, comma-separated) recompiled with extra flags, the others as built.
     python profiles/build_ab.py roadmap -DTRK_SEARCH_CLOCKS -o profiles/_ab/libtendon_hip_clocks.so
 then  TENDON_HIP_LIB=profiles/_ab/libtendon_hip_clocks.so python profiles/probe_search.py"""
 import importlib
@@ -25,7 +25,7 @@ def main():
     objs = []
     for obj, src, flags, _ in L._units():
         o = os.path.join(L.OBJ_DIR, obj)
-        if obj == unit + ".o":
+        if obj[:-2] in unit.split(","):
             o = os.path.join(os.path.dirname(out), "ab_" + obj)
             subprocess.check_call(["hipcc"] + L.HIPCC_FLAGS + flags + extra + ["-c", os.path.join(L.SRC_DIR, src), "-o", o])
         objs.append(o)
