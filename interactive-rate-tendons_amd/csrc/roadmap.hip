@@ -360,16 +360,34 @@ bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::v
   if (node[start].h == inf) return false;
   heap.emplace_back(node[start].h, start);
   bool found = false;
+  constexpr bool node_is_new_hint = true;       // (the state / landmark rows are only read for a vertex met for the first time; most are)
   while (!heap.empty()) {
     std::pop_heap(heap.begin(), heap.end(), cmp);
     const int32_t u = heap.back().second;
     heap.pop_back();
+    if (!heap.empty()) {                        // the likely next vertex: its record and its arcs on their way while this one is expanded
+      const int32_t nx = heap.front().second;   // (the top's two children as well: measured, no gain)
+      __builtin_prefetch(&node[nx]);
+      __builtin_prefetch(r->adj.data() + r->adj_off[nx]);
+    }
     if (node[u].closed) continue;               // a stale entry of a vertex already expanded with a better cost
     node[u].closed = 1u;
     expanded++;
     if (u == goal) { found = true; break; }
     const double gu = node[u].g;
     const Arc *arc = r->adj.data() + r->adj_off[u], *end = r->adj.data() + r->adj_off[u + 1];
+    // (every neighbour is four lines somewhere in a few hundred megabytes -- its record, its validity byte, its state, its landmark
+    // row: asked for together before the first is used, the misses overlap instead of queueing behind one another)
+    for (const Arc *a = arc; a != end; ++a) {
+      const int32_t v = a->v;
+      __builtin_prefetch(&node[v], 1);
+      __builtin_prefetch(&r->vstat[v]);
+      __builtin_prefetch(&r->estat[a->e]);
+      if (node_is_new_hint) {
+        __builtin_prefetch(&r->states[(size_t)v * r->S]);
+        if (L) __builtin_prefetch(&r->lm_d[(size_t)v * L]);
+      }
+    }
     for (; arc != end; ++arc) {
       const int32_t e = arc->e, v = arc->v;
       if (r->estat[e] == V_INVALID || r->vstat[v] == V_INVALID) continue;
