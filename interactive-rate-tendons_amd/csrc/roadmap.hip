@@ -169,6 +169,7 @@ struct Scratch {                       // per host thread, reused across queries
   std::vector<Node> node;
   std::vector<std::pair<double, int32_t>> heap;
   uint32_t gen = 0;
+  double trace_f[4] = {0, 0, 0, 0};    // (TENDON_HIP_SEARCH_HIST=<file>: h(start), and the key taken off the list at the 2 000th / 3 000th / 4 000th expansion)
 };
 
 struct Arc { int32_t v, e; double w; };   // one adjacency entry: neighbour, edge id, edge weight (16 B: four per cache line)
@@ -358,6 +359,9 @@ bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::v
   auto cmp = [](const std::pair<double, int32_t> &a, const std::pair<double, int32_t> &b) { return a.first > b.first; };
   node[start] = Node{0.0, heuristic(start), start, -1, gen, 0u};
   if (node[start].h == inf) return false;
+  static const bool trace = [] { const char *e = std::getenv("TENDON_HIP_SEARCH_HIST"); return e && e[0] == '/'; }();
+  const int64_t expanded0 = expanded;
+  if (trace) { sc.trace_f[0] = node[start].h; sc.trace_f[1] = sc.trace_f[2] = sc.trace_f[3] = 0.0; }
   heap.emplace_back(node[start].h, start);
   bool found = false;
   constexpr bool node_is_new_hint = true;       // (the state / landmark rows are only read for a vertex met for the first time; most are)
@@ -373,6 +377,12 @@ bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::v
     if (node[u].closed) continue;               // a stale entry of a vertex already expanded with a better cost
     node[u].closed = 1u;
     expanded++;
+    if (trace) {
+      const int64_t n_ = expanded - expanded0;
+      if (n_ == 2000) sc.trace_f[1] = node[u].g + node[u].h;
+      else if (n_ == 3000) sc.trace_f[2] = node[u].g + node[u].h;
+      else if (n_ == 4000) sc.trace_f[3] = node[u].g + node[u].h;
+    }
     if (u == goal) { found = true; break; }
     const double gu = node[u].g;
     const Arc *arc = r->adj.data() + r->adj_off[u], *end = r->adj.data() + r->adj_off[u + 1];
@@ -1595,6 +1605,8 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     std::vector<int64_t> hist_v;
     if (std::getenv("TENDON_HIP_SEARCH_HIST")) hist_v.assign(active.size(), 0);
     int64_t *hist = hist_v.empty() ? nullptr : hist_v.data();
+    std::vector<double> hist_f;                                   // (per search: Scratch::trace_f)
+    if (hist) hist_f.assign(active.size() * 4, 0.0);
     // the host threads over a list of positions in `active` (null: all of them)
     std::atomic<bool> walked_in_vain{false};
     auto host_search = [&](const std::vector<size_t> *list) {
@@ -1612,7 +1624,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
           const int64_t ex0 = ex;
           found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
           if (!found[k] && ex - ex0 >= kComponentTrigger) walked_in_vain.store(true, std::memory_order_relaxed);
-          if (hist) hist[k] = ex - ex0;
+          if (hist) { hist[k] = ex - ex0; for (int i_ = 0; i_ < 4; i_++) hist_f[k * 4 + i_] = sc.trace_f[i_]; }
         }
         expanded += ex;
       };
@@ -1650,7 +1662,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         const int64_t ex0 = ex;
         found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
         if (!found[k] && ex - ex0 >= kComponentTrigger) walked_in_vain.store(true, std::memory_order_relaxed);
-        if (hist) hist[k] = ex - ex0;
+        if (hist) { hist[k] = ex - ex0; for (int i_ = 0; i_ < 4; i_++) hist_f[k * 4 + i_] = sc.trace_f[i_]; }
       };
       auto poll = [&]() {                                          // (under poll_mu)
         const bool done = hipStreamQuery(nullptr) == hipSuccess;   // read BEFORE the words: one set before the kernel ended is then seen below
@@ -1766,9 +1778,10 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
               const double a_ = r->lm_d[(size_t)s_ * L + l], b_ = r->lm_d[(size_t)g_ * L + l];
               lb = std::max(lb, std::fabs(a_ - b_)); sum_s = std::min(sum_s, a_ + b_);
             }
-            std::fprintf(fh, "%lld %lld %d %lld %.6g %.6g %.6g %d %d\n", (long long)r->st_rounds, (long long)q, (int)found[k], (long long)hist[k],
+            std::fprintf(fh, "%lld %lld %d %lld %.6g %.6g %.6g %d %d %.6g %.6g %.6g %.6g\n", (long long)r->st_rounds, (long long)q, (int)found[k], (long long)hist[k],
                          state_distance(r, &r->states[(size_t)s_ * r->S], &r->states[(size_t)g_ * r->S]), lb, sum_s,
-                         (int)(r->adj_off[(size_t)s_ + 1] - r->adj_off[(size_t)s_]), (int)(r->adj_off[(size_t)g_ + 1] - r->adj_off[(size_t)g_]));
+                         (int)(r->adj_off[(size_t)s_ + 1] - r->adj_off[(size_t)s_]), (int)(r->adj_off[(size_t)g_ + 1] - r->adj_off[(size_t)g_]),
+                         hist_f[k * 4], hist_f[k * 4 + 1], hist_f[k * 4 + 2], hist_f[k * 4 + 3]);
           }
           std::fclose(fh);
         }

@@ -44,3 +44,20 @@ for top in (100, 200, 400):
                                                                     int((ex > 6500).sum()), int(ex[idx].sum())))
 for name, p in cands.items():
     print("rank correlation with expansions: %-26s %.3f" % (name, np.corrcoef(np.argsort(np.argsort(p)), np.argsort(np.argsort(ex)))[0, 1]))
+# ... and what is known DURING a search: the key at the head of the list after 2 000 / 3 000 / 4 000 expansions against h(start) and the landmark upper bound
+if d.shape[1] >= 13:
+    h0, f2, f3, f4 = d[:, 9], d[:, 10], d[:, 11], d[:, 12]
+    for n_at, f_at in ((2000, f2), (3000, f3), (4000, f4)):
+        alive = ex > n_at
+        long_ = ex > 6500
+        print("-- searches still running after %d expansions: %d, of them above 6 500 in the end: %d" % (n_at, int(alive.sum()), int((alive & long_).sum())))
+        feats = {"progress (f - h0) / (upper - h0)": (f_at - h0) / np.maximum(ub - h0, 1e-12), "progress (f - h0) / (cost - h0) [not known to the search]": (f_at - h0) / np.maximum(cost - h0, 1e-12),
+                 "f - h0": f_at - h0, "upper - f": ub - f_at, "h0": h0, "distance": dist}
+        for name, p in feats.items():
+            p = np.where(alive, p, np.nan)
+            pa, la = p[alive], long_[alive]
+            order = np.argsort(pa)          # small progress first
+            for frac in (0.1, 0.2, 0.3):
+                n_take = int(frac * len(pa))
+                lo = la[order[:n_take]].sum(); hi = la[order[::-1][:n_take]].sum()
+                print("   %-58s lowest %2d %%: %3d of %3d long ones; highest %2d %%: %3d" % (name, int(100 * frac), int(lo), int(la.sum()), int(100 * frac), int(hi)))
