@@ -461,6 +461,10 @@ int tr_roadmap_profile(tr_roadmap *rm, double out[4]);
  * allocation anywhere in the library runs out of device memory, the tables of every roadmap that is not inside a call are released
  * the same way before the allocation is tried again. */
 int tr_roadmap_release_search_state(tr_roadmap *rm, int64_t *bytes_released);
+/* ... and setting it up ahead of the first batch (the adjacency rows and the tables for rounds of up to n_queries queries: a process's first
+ * allocation of the full 5.3 GB takes ~0.15 s, which otherwise falls into the first tr_roadmap_solve of 512 queries or more).
+ * TR_ERR_UNSUPPORTED when this roadmap's searches stay on the host threads (parallel edges, state size above the kernel's, no memory). */
+int tr_roadmap_reserve_search_state(tr_roadmap *rm, int64_t n_queries);
 int tr_roadmap_search_state_bytes(tr_roadmap *rm, int64_t *bytes);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n

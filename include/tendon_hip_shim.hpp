@@ -834,6 +834,7 @@ class VoxelCachedLazyPRM {
   /// Device memory the graph searches hold for this planner between calls, and handing it back (tr_roadmap_release_search_state;
   /// the next large batch of queries allocates it again).
   int64_t searchStateBytes() const { int64_t b = 0; if (rm_) rcheck(tr_roadmap_search_state_bytes(rm_, &b)); return b; }
+  void reserveSearchState(int64_t n_queries) { sync(); rcheck(tr_roadmap_reserve_search_state(rm_, n_queries)); }
   int64_t releaseSearchState() { int64_t b = 0; if (rm_) rcheck(tr_roadmap_release_search_state(rm_, &b)); return b; }
   /// CompoundStateSpace::distance with the weights of Problem.cpp:112-152 (the edge cost connectVertices stores, :2857-2861)
   double distance(const double *a, const double *b) const {

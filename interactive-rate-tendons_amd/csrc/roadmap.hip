@@ -1927,6 +1927,16 @@ int tr_roadmap_release_search_state(tr_roadmap *r, int64_t *bytes_released) {
   return TR_OK;
 }
 
+int tr_roadmap_reserve_search_state(tr_roadmap *r, int64_t n_queries) {
+  if (!r || n_queries < 0) return TR_ERR_INVALID_ARG;
+  RmLock lock_(r);
+  RM_HIP(r, hipSetDevice(tr_device(r->ctx)));
+  if (n_queries == 0) return TR_OK;
+  if (!search_setup(r) || !search_tables(r, n_queries)) return rfail(r, TR_ERR_UNSUPPORTED, "device searches not available for this roadmap: " + r->ds.why);
+  RM_HIP(r, hipStreamSynchronize(nullptr));
+  return TR_OK;
+}
+
 int tr_roadmap_search_state_bytes(tr_roadmap *r, int64_t *bytes) {
   if (!r || !bytes) return TR_ERR_INVALID_ARG;
   RmLock lock_(r);

@@ -502,6 +502,10 @@ class VoxelCachedLazyPRM:
         self._check(self.lib.tr_roadmap_search_state_bytes(self._rm, self._C.byref(b)))
         return int(b.value)
 
+    def reserve_search_state(self, n_queries):
+        """Sets the device searches up for rounds of up to n_queries queries now (tr_roadmap_reserve_search_state) instead of inside the first solve."""
+        self._check(self.lib.tr_roadmap_reserve_search_state(self._rm, int(n_queries)))
+
     def release_search_state(self):
         """Hands the searches' tables back to the device (tr_roadmap_release_search_state); the next large round allocates them again."""
         b = self._C.c_int64(0)

@@ -324,6 +324,8 @@ def test_search_state_follows_the_round_size_and_can_be_released(irt, monkeypatc
     assert full > 2.5 * small
     free0 = torch.cuda.mem_get_info()[0]
     assert prm.release_search_state() == full and prm.search_state_bytes() == 0
+    prm.reserve_search_state(600)                                                        # ahead of a batch: the same tables as the 600-query round left
+    assert prm.search_state_bytes() > 0.9 * small - 64e3 and prm.release_search_state() > 0
     assert torch.cuda.mem_get_info()[0] - free0 > 0.9 * full                             # back with the device, not parked
     got = _solve(prm, pairs[:600, 0], pairs[:600, 1], True)
     _same(got, want_small, expansions=False)
