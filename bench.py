@@ -248,7 +248,8 @@ def secondary_metrics():
                 "queries_per_s_eager_incl_revalidation": q["eager"]["queries_per_s_incl_revalidation"],
                 "revalidate_all_cached_sets_ms": q["eager"]["revalidate_all_ms"], "cached_sets": q["roadmap_vertices"] + q["roadmap_edges"],
                 "vertex_caches_built_per_s": c5["vertex_caches_built_per_s"], "edge_caches_built_per_s": c5["edge_caches_built_per_s"],
-                "rooflines": q.get("rooflines"), "solved_fraction": q["solved_fraction"]},
+                "rooflines": q.get("rooflines"), "solved_fraction": q["solved_fraction"],
+                "with_64_landmark_tables": q.get("landmarks_64")},
             "config4_on_one_gpu": config4_one_gpu_extras(),
             "config1_fk_only": r["config1"], "sphere_checker_checks_per_s": r["sphere_checker"]["checks_per_s"],
             "rotation_retraction_robot": {k: r["rotation_retraction_robot"][k] for k in ("robot", "checks_per_s", "edges", "edges_per_s",

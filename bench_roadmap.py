@@ -333,6 +333,28 @@ def run(argv=None):
     del os.environ["TENDON_HIP_LAZY_ONLY"]
     assert np.array_equal(lazy["status"], lazy_h["status"]) and np.array_equal(lazy["cost"], lazy_h["cost"])
     assert np.array_equal(lazy["path_vertices"], lazy_h["path_vertices"])
+    # the same batch with 64 landmark tables instead of 16 (256 B per vertex instead of 64): the device searches expand 43 % fewer vertices;
+    # timed twice each (the first call after tr_roadmap_prepare uploads the new rows), costs compared with the 16-landmark answers
+    t0 = time.perf_counter()
+    prm.prepare(64)
+    t_prepare64 = time.perf_counter() - t0
+    t_e64, t_d64 = [], []
+    for _ in range(2):
+        prm.clearValidity()
+        prm.revalidate()
+        t0 = time.perf_counter()
+        e64 = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+        t_e64.append(time.perf_counter() - t0)
+        st_e64 = dict(prm.stats, searches=dict(prm.search_stats))
+        prm.clearValidity()
+        t0 = time.perf_counter()
+        d64 = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
+        t_d64.append(time.perf_counter() - t0)
+    assert np.array_equal(lazy["status"], e64["status"]) and np.array_equal(lazy["cost"], e64["cost"])
+    assert np.array_equal(lazy["status"], d64["status"]) and np.array_equal(lazy["cost"], d64["cost"])
+    lm64 = {"landmark_tables_s": t_prepare64, "queries_per_s_validity_known": nq / min(t_e64), "seconds_validity_known": min(t_e64),
+            "queries_per_s_default_schedule": nq / min(t_d64), "seconds_default_schedule": min(t_d64), "expanded": st_e64["expanded"],
+            "searches": st_e64["searches"], "same_statuses_and_costs": True}
     assert np.array_equal(lazy["status"], eager["status"]) and np.array_equal(lazy["cost"], eager["cost"])
     assert np.array_equal(lazy["status"], plain["status"]) and np.array_equal(lazy["cost"], plain["cost"])
     assert np.array_equal(lazy["path_vertices"], plain["path_vertices"])
@@ -352,6 +374,7 @@ def run(argv=None):
           "searches_on_host_threads_only": {"lazy_queries_per_s": nq / t_lazy_host, "eager_search_seconds": t_eager_host,
                                             "same_statuses_costs_paths": True},
           "rooflines": {"cached_blocks_vs_grid": k4_roof, "roadmap_astar": k9_roof},
+          "landmarks_64": lm64,
           "solved_fraction": float((lazy["status"] == 0).mean()), "no_path": int((lazy["status"] == 1).sum()),
           "invalid_endpoint": int((lazy["status"] >= 2).sum()),
           "path_vertices": {"mean": float(plen.mean()) if len(plen) else 0.0, "max": int(plen.max()) if len(plen) else 0}}

@@ -35,9 +35,11 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <functional>
 #include <limits>
 #include <memory>
 #include <mutex>
@@ -66,9 +68,62 @@ struct Laps {
   ~Laps() { if (on) std::fprintf(stderr, "\n"); }
 };
 
+// The library's host threads: started once per process and parked on a condition variable between jobs -- a tr_roadmap_solve runs six
+// or seven parallel sections, and starting fifteen threads for each was 0.3 - 0.5 ms a time (2 - 3 ms of a 25 ms batch of queries).
+// One job at a time; a caller that finds the team busy (another roadmap's call on another host thread) starts threads of its own as
+// before.  Never destroyed: its threads wait inside it when the process ends.
+class HostTeam {
+  std::mutex mu_, job_mu_;
+  std::condition_variable work_, done_;
+  std::vector<std::thread> th_;
+  const std::function<void(int)> *fn_ = nullptr;
+  int T_ = 0, running_ = 0;
+  uint64_t epoch_ = 0;
+  void worker(int t) {
+    uint64_t seen = 0;
+    for (;;) {
+      const std::function<void(int)> *f = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        work_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (t < T_) f = fn_;
+      }
+      if (f) {
+        (*f)(t);
+        std::lock_guard<std::mutex> lk(mu_);
+        if (--running_ == 0) done_.notify_all();
+      }
+    }
+  }
+ public:
+  static HostTeam &get() { static HostTeam *team = new HostTeam(); return *team; }
+  // fn(1) .. fn(T - 1) on the team's threads, fn(0) on the caller's; false (nothing run) when the team is busy
+  bool run(int T, const std::function<void(int)> &fn) {
+    std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
+    if (!job.owns_lock()) return false;
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      while ((int)th_.size() < T - 1) { const int t = (int)th_.size() + 1; th_.emplace_back([this, t] { worker(t); }); th_.back().detach(); }
+      fn_ = &fn; T_ = T; running_ = T - 1; epoch_++;
+    }
+    work_.notify_all();
+    fn(0);
+    std::unique_lock<std::mutex> lk(mu_);
+    done_.wait(lk, [&] { return running_ == 0; });
+    fn_ = nullptr; T_ = 0;
+    return true;
+  }
+};
+
 // fn(t) for t = 0 .. T-1 on T host threads (the caller's included)
 template <class F> void on_threads(int T, F &&fn) {
   if (T <= 1) { fn(0); return; }
+  static const bool pooled = !(std::getenv("TENDON_HIP_HOST_TEAM") && std::atoi(std::getenv("TENDON_HIP_HOST_TEAM")) == 0);   // (A/B: 0 = threads per section)
+  if (pooled) {
+    const std::function<void(int)> f = [&fn](int t) { fn(t); };
+    if (HostTeam::get().run(T, f)) return;
+  }
   std::vector<std::thread> th;
   th.reserve((size_t)T - 1);
   for (int t = 1; t < T; t++) th.emplace_back([&fn, t] { fn(t); });
@@ -453,11 +508,7 @@ void landmark_distances_host(tr_roadmap *r, int T) {
       for (int64_t v = 0; v < V; v++) r->lm_d[(size_t)v * L + l] = (float)dist[(size_t)v];
     }
   };
-  const int nt = std::max(1, std::min(T, L));
-  std::vector<std::thread> th;
-  for (int t = 1; t < nt; t++) th.emplace_back(worker);
-  worker();
-  for (auto &x : th) x.join();
+  on_threads(std::max(1, std::min(T, L)), [&](int) { worker(); });
 }
 
 // The same distances on the device: every sweep relaxes all arcs for all landmarks at once -- thread (u, l) offers dist[u][l] + w(u, v)
@@ -1628,11 +1679,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         }
         expanded += ex;
       };
-      const int nt = (int)std::min<int64_t>(T, n_host);
-      std::vector<std::thread> th;
-      for (int t = 1; t < nt; t++) th.emplace_back(worker, t);
-      worker(0);
-      for (auto &x : th) x.join();
+      on_threads((int)std::min<int64_t>(T, n_host), worker);
     };
     if (!on_device) host_search(&todo);
     else {
@@ -1708,13 +1755,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         }
         expanded += ex;
       };
-      {
-        const int nt = std::max(1, T);
-        std::vector<std::thread> th;
-        for (int t = 1; t < nt; t++) th.emplace_back(member, t);
-        member(0);
-        for (auto &x : th) x.join();
-      }
+      on_threads(std::max(1, T), member);
       if (n_cut_host) { r->dc.st_cut += n_cut_host; r->dc.wanted = true; }
       const auto t1 = std::chrono::steady_clock::now();
       int64_t ex = 0;

@@ -32,7 +32,7 @@ def main():
     prm.set_obstacles(new_vox)
     nq = int(os.environ.get("PROBE_QUERIES", "10000"))
     pairs = np.random.default_rng(17).integers(0, len(states), size=(nq, 2))
-    prm.prepare(16)
+    prm.prepare(int(os.environ.get("PROBE_LANDMARKS", "16")))
     out = {"vertices": nv, "edges": int(len(e_ok)), "queries": nq}
     for mode in os.environ.get("PROBE_MODES", "device,auto,device,auto,auto").split(","):
         if mode == "auto":
