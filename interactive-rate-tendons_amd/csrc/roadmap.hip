@@ -258,7 +258,8 @@ struct tr_roadmap {
   RawArray<double> w;
   std::vector<int64_t> adj_off;        // CSR adjacency, both directions
   RawArray<Arc> adj;
-  // landmark lower bounds (tr_roadmap_prepare): lm_d[v * lm_n + l] = graph distance landmark l -> v over all edges, as float
+  // landmark lower bounds (tr_roadmap_prepare): lm_d[v * lm_n + l] = graph distance landmark l -> v over all edges, as float; SR_LM_FAR
+  // (not +inf) where v is not connected to l: what the branch-free bounds of the host A* and of the kernel's rows read
   // (+inf = not connected); lm_n = 0: none, -1: not built yet (built with the default count by the first solve)
   int lm_n = -1;
   std::vector<float> lm_d;
@@ -396,17 +397,29 @@ bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::v
   auto heuristic = [&](int32_t v) -> double {
     double h = state_distance(r, &r->states[(size_t)v * r->S], sg);
     if (L) {
+      // (SR_LM_FAR where a vertex is not connected to the landmark: two far entries bound nothing -- their term is hugely negative --, one
+      // makes the term huge: different components; no comparison with infinity, no branch: the loop vectorises, and every term is the
+      // kernel's (search_kernel.hpp: heuristic), float operation for float operation)
       const float *lv = &r->lm_d[(size_t)v * L];
+      const float slack = (float)kLmSlack;
+      float b8[8] = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};   // (eight running maxima side by side: element-wise work the compiler turns into vector code)
+      int l = 0;
+      for (; l + 8 <= L; l += 8)
+        for (int j = 0; j < 8; j++) {
+          const float a = lv[l + j], b = lg[l + j];
+          const float hi = a > b ? a : b, lo = a > b ? b : a;
+          const float t = (hi - lo) - slack * hi;                // float subtraction of nearby values: error <= 2^-24 hi, inside the slack
+          b8[j] = t > b8[j] ? t : b8[j];
+        }
       float best = 0.0f;
-      bool cut = false;
-      for (int l = 0; l < L; l++) {
+      for (; l < L; l++) {
         const float a = lv[l], b = lg[l];
         const float hi = a > b ? a : b, lo = a > b ? b : a;
-        if (hi == std::numeric_limits<float>::infinity()) { cut |= lo != hi; continue; }   // one side unreachable from l: different components
-        const float t = (hi - lo) - (float)kLmSlack * hi;          // float subtraction of nearby values: error <= 2^-24 hi, inside the slack
+        const float t = (hi - lo) - slack * hi;
         best = t > best ? t : best;
       }
-      if (cut) return inf;
+      for (int j = 0; j < 8; j++) best = b8[j] > best ? b8[j] : best;
+      if (best >= 0.5f * trk::SR_LM_FAR) return inf;
       if ((double)best > h) h = (double)best;
     }
     return h;
@@ -679,6 +692,7 @@ void build_landmarks(tr_roadmap *r, int n, int T) {
     landmark_distances_host(r, T);
     if (done && check && std::memcmp(dev.data(), r->lm_d.data(), dev.size() * sizeof(float)) != 0) r->lm_mismatch = true;
   }
+  for (float &x_ : r->lm_d) if (!(x_ < trk::SR_LM_FAR)) x_ = trk::SR_LM_FAR;
   r->lm_n = L;
 }
 
