@@ -42,6 +42,16 @@ def main():
         full_vc = rb.vertex_caches(st, device=bool(it % 2))
         prm.set_caches(full_vc, ec)
         out = prm.solveWithRoadmap(np.arange(0, 200), np.arange(200, 400))
+        if it % 4 == 0:
+            # a round large enough for the device searches (their tables come from and go back to the library's buffer cache; every other time
+            # they are handed back explicitly): the same answers as the host threads' for the queries both have seen
+            os.environ["TENDON_HIP_SEARCH"] = "device"          # (whatever the number of queries left to search)
+            big = prm.solveWithRoadmap(np.arange(0, 800) % 3000, (np.arange(0, 800) * 7 + 200) % 3000)
+            del os.environ["TENDON_HIP_SEARCH"]
+            assert prm.search_state_bytes() > 0, dict(prm.search_stats)
+            assert np.array_equal(big["status"][:1], out["status"][:1]) and (big["status"][0] != 0 or big["cost"][0] == out["cost"][0])
+            if it % 8 == 0:
+                assert prm.release_search_state() > 0
         sig = (int(v.sum()), int(ev.sum()), int(lv.sum()), float(lt.sum()), int(len(e_ok)), int((out["status"] == 0).sum()), float(np.nansum(out["cost"][out["status"] == 0])))
         key = (it % 2, it % 3 == 0, it % 5 == 0)
         if ref is None:
