@@ -1714,7 +1714,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       std::atomic<bool> closed{flags == nullptr};
       std::mutex poll_mu;
       bool labels_host = labels_now;                              // (poller only)
-      int64_t n_streamed = 0, n_cut_host = 0;                     // (poller only)
+      int64_t n_streamed = 0, n_cut_host = 0, n_over_budget = 0;   // (poller only)
       std::chrono::steady_clock::time_point t_share_done = t0, t_kernel_done = t0;
       std::atomic<bool> kernel_done{false};
       auto process = [&](int t, size_t k, int64_t &ex) {
@@ -1730,8 +1730,10 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         if (done && !kernel_done.load()) { t_kernel_done = std::chrono::steady_clock::now(); kernel_done.store(true); }
         int64_t t = feed_tail.load(std::memory_order_relaxed);
         for (int64_t j = 0; j < n_dev; j++) {
-          if (seen[(size_t)j] || !__atomic_load_n(&flags[j], __ATOMIC_ACQUIRE)) continue;
+          const uint32_t why_ = seen[(size_t)j] ? 0u : __atomic_load_n(&flags[j], __ATOMIC_ACQUIRE);
+          if (!why_) continue;
           seen[(size_t)j] = 1;
+          if (why_ == 1u) n_over_budget++;
           const size_t k = dev_list[(size_t)j];
           handled[k] = 1;
           n_streamed++;
@@ -1798,7 +1800,9 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
       // raised when it was done in a fraction of the kernel's span and nothing was left to do after it.
       const double t_kernel = ms(t_round, t_kernel_done), t_after = std::max(0.0, ms(t_kernel_done, t3)), t_share = n_share ? ms(t0, t_share_done) : 0.0;
       r->ds.kernel_ms = t_kernel; r->ds.host_after_ms = t_after;
-      if (smode != 2 && !r->ds.budget_from_env && r->ds.budget > 0 && (n_streamed + (int64_t)redo.size()) * 50 > n_dev && r->ds.budget < 16 * r->V) r->ds.budget *= 2;
+      // (only the searches that came back OVER THE BUDGET count: one that found no table left for its records says nothing about the budget --
+      // at 6 x 10^5 vertices those alone are 2 % of a round, and doubling on them let single searches run 600 ms on their wave)
+      if (smode != 2 && !r->ds.budget_from_env && r->ds.budget > 0 && (flags ? n_over_budget : n_streamed + (int64_t)redo.size()) * 50 > n_dev && r->ds.budget < 16 * r->V) r->ds.budget *= 2;
       if (smode != 2 && !std::getenv("TENDON_HIP_SEARCH_HOST_SHARE") && n_share > 0) {
         if (t_share > t_kernel) r->ds.share = std::max(0.0025, r->ds.share * 0.5);
         else if (t_share < 0.4 * t_kernel && t_after < 0.1 * t_kernel) r->ds.share = std::min(0.08, r->ds.share * 1.5);

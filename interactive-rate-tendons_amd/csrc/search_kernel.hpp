@@ -401,6 +401,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     double T = inf;
     double slack = 0.0;                                         // how far above the minimum a step's other vertices may lie (follows the lanes' use)
     int result = SR_NO_PATH;
+    bool over_budget = false;
     unsigned long long exp_q = 0;
     unsigned moves = 0;                                         // times the threshold moved (near full / near empty)
     const double h0 = sr_u(heuristic(start));
@@ -422,7 +423,7 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
 #ifdef TRK_SEARCH_CLOCKS
         n_steps++;
 #endif
-        if ((int64_t)exp_q >= a.max_pops) { result = SR_FALLBACK; break; }
+        if ((int64_t)exp_q >= a.max_pops) { result = SR_FALLBACK; over_budget = true; break; }
         if (n_near == n_dead) {                                // (entries taken off the list stay as dead slots until the list is next rewritten)
           n_near = 0; n_dead = 0;
           if (n_far == 0) break;                               // the open list is empty: no path
@@ -766,7 +767,8 @@ template <int SX> __global__ __launch_bounds__(64) void roadmap_astar(SearchArgs
     if (cls > 0) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
     if (lane == 0) {
       a.found[qi] = (uint8_t)result;
-      if (result == SR_FALLBACK && a.handback) __hip_atomic_store(a.handback + qi, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      // (1: over its budget of expansions -- the host's budget rule counts these --, 3: no table, list or path buffer left for it)
+      if (result == SR_FALLBACK && a.handback) __hip_atomic_store(a.handback + qi, over_budget ? 1u : 3u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
       atomicAdd(a.expanded, exp_q);
       if (moves) atomicAdd(a.next + 4, moves);
       if (grows) atomicAdd(a.next + 5, grows);
