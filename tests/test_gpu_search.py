@@ -330,3 +330,38 @@ def test_search_state_follows_the_round_size_and_can_be_released(irt, monkeypatc
     got = _solve(prm, pairs[:600, 0], pairs[:600, 1], True)
     _same(got, want_small, expansions=False)
     assert prm.search_stats["device"] > 0 and prm.search_state_bytes() == small
+
+
+def test_two_roadmaps_queried_from_two_host_threads_at_once(irt, monkeypatch):
+    """Two planners, each queried from its own Python thread at the same time (the C calls run without the GIL): the library's team of
+    host threads serves one call, the other starts threads of its own, both launch their searches on the device -- and each gets the
+    answers it gets alone."""
+    import threading
+    monkeypatch.delenv("TENDON_HIP_LAZY_ONLY", raising=False)
+    a, sa = _prm(irt, 2500, 6, seed=21)
+    b, sb = _prm(irt, 3000, 7, seed=22)
+    for p in (a, b):
+        p.prepare(8)
+    rng = np.random.default_rng(31)
+    qa = rng.integers(0, len(sa), size=(1500, 2)).astype(np.int32)
+    qb = rng.integers(0, len(sb), size=(1500, 2)).astype(np.int32)
+    alone = [p.solveWithRoadmap(q[:, 0], q[:, 1]) for p, q in ((a, qa), (b, qb))]
+    for rep in range(3):
+        got, errs = [None, None], []
+
+        def run(i, p, q):
+            try:
+                p.clearValidity()
+                got[i] = p.solveWithRoadmap(q[:, 0], q[:, 1])
+            except Exception as e:                      # noqa: BLE001
+                errs.append(e)
+
+        th = [threading.Thread(target=run, args=(0, a, qa)), threading.Thread(target=run, args=(1, b, qb))]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not errs, errs
+        for w, g in zip(alone, got):
+            for k in ("status", "cost", "path_offsets", "path_vertices"):
+                assert np.array_equal(w[k], g[k]), (rep, k)
