@@ -465,6 +465,12 @@ int tr_roadmap_release_search_state(tr_roadmap *rm, int64_t *bytes_released);
  * allocation of the full 5.3 GB takes ~0.15 s, which otherwise falls into the first tr_roadmap_solve of 512 queries or more).
  * TR_ERR_UNSUPPORTED when this roadmap's searches stay on the host threads (parallel edges, state size above the kernel's, no memory). */
 int tr_roadmap_reserve_search_state(tr_roadmap *rm, int64_t n_queries);
+/* Searches of the last tr_roadmap_solve that were answered by a parallel SWEEP on the device instead of A*: a host search that passes a
+ * sixth of the graph in expansions (50 000 at least; TENDON_HIP_SEARCH_SWEEP=n overrides, 0 = never) is abandoned and its source's
+ * distances are relaxed over all valid arcs at once until nothing changes -- the same cost bit for bit, the path walked back along
+ * arcs that meet it exactly.  Only on roadmaps whose searches are set up on the device (a round of 512 queries or more has run, or
+ * tr_roadmap_reserve_search_state). */
+int tr_roadmap_search_sweeps(tr_roadmap *rm, int64_t *n);
 int tr_roadmap_search_state_bytes(tr_roadmap *rm, int64_t *bytes);
 
 /* The connection loop itself (motion-planning/VoxelCachedLazyPRM.cpp:1491-1502: for every vertex v and every neighbour n
@@ -606,6 +612,7 @@ int tr_edge_schedule_last(const tr_ctx *ctx, uint32_t stats[4]);
  *                                   one search in fifty comes back; 0 none)
  *   TENDON_HIP_SEARCH_K=1..12       vertices the kernel takes off a search's open list per step, at most (default 12: as many as their
  *                                   arcs fill the 64 lanes of the step's two passes; 1 = the host's order)
+ *   TENDON_HIP_SEARCH_SWEEP=n       expansions after which a host search is handed to the device sweep (tr_roadmap_search_sweeps; 0 never)
  *   TENDON_HIP_SEARCH_SLOTS=n       searches in flight on the device, at most (default: what it holds: 12 waves per CU; a round of
  *                                   fewer queries allocates tables for that many only)
  *   TENDON_HIP_SEARCH_LC0=8..14     log2 of the per-vertex records a search in flight owns (default 12: 176 KiB per slot with its far list;

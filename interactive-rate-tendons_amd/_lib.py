@@ -32,7 +32,7 @@ ABI_SYMBOLS = (
     "tr_validate_edges_discrete",
     "tr_check_cached", "tr_check_cached_dev", "tr_check_cached_subset_dev", "tr_state_layout", "tr_space_weights", "tr_kstar_k",
     "tr_roadmap_create", "tr_roadmap_destroy", "tr_roadmap_last_error", "tr_roadmap_set_caches", "tr_roadmap_set_caches_dev", "tr_roadmap_prepare", "tr_roadmap_clear_validity",
-    "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_set_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_roadmap_search_stats", "tr_roadmap_profile", "tr_roadmap_release_search_state", "tr_roadmap_reserve_search_state", "tr_roadmap_search_state_bytes", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_edges_indexed", "tr_connect_edges_indexed", "tr_voxelize_fetch", "tr_voxelize_fetch_dev", "tr_voxelize_count", "tr_knn", "tr_knn_range", "tr_knn_table_edges", "tr_knn_edges", "tr_knn_edges_dev", "tr_knn_range_dev", "tr_knn_table_edges_dev", "tr_validate_edges_indexed_dev", "tr_signature_words", "tr_signature_packed_words", "tr_pack_signatures_dev", "tr_unpack_signatures_dev", "tr_validate_candidates_sig_dev", "tr_validate_edges_indexed_sig_dev", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
+    "tr_roadmap_revalidate", "tr_roadmap_get_validity", "tr_roadmap_set_validity", "tr_roadmap_solve", "tr_roadmap_fetch_paths", "tr_roadmap_search_stats", "tr_roadmap_profile", "tr_roadmap_release_search_state", "tr_roadmap_reserve_search_state", "tr_roadmap_search_state_bytes", "tr_roadmap_search_sweeps", "tr_voxelize_batch", "tr_voxelize_edges", "tr_voxelize_edges_indexed", "tr_connect_edges_indexed", "tr_voxelize_fetch", "tr_voxelize_fetch_dev", "tr_voxelize_count", "tr_knn", "tr_knn_range", "tr_knn_table_edges", "tr_knn_edges", "tr_knn_edges_dev", "tr_knn_range_dev", "tr_knn_table_edges_dev", "tr_validate_edges_indexed_dev", "tr_signature_words", "tr_signature_packed_words", "tr_pack_signatures_dev", "tr_unpack_signatures_dev", "tr_validate_candidates_sig_dev", "tr_validate_edges_indexed_sig_dev", "tr_profile_begin", "tr_profile_read", "tr_profile_end",
     "tr_set_debug", "tr_edge_schedule_last",
     "tr_candidate_states", "tr_candidate_states_dev", "tr_validate_candidates_dev", "tr_compact_rows_dev",
     "tr_sample_valid_vertices", "tr_sample_valid_vertices_dev", "tr_sample_valid_vertices_sig_dev",
@@ -278,6 +278,7 @@ def lib():
     L.tr_roadmap_release_search_state.argtypes = [vp, P(i64)]
     L.tr_roadmap_search_state_bytes.argtypes = [vp, P(i64)]
     L.tr_roadmap_reserve_search_state.argtypes = [vp, i64]
+    L.tr_roadmap_search_sweeps.argtypes = [vp, P(i64)]
     L.tr_voxelize_batch.argtypes = [vp, dp, i64, P(i64), P(C.c_uint64), dp]
     L.tr_voxelize_edges.argtypes = [vp, P(TrSpaceParams), dp, dp, i64, P(i64), P(C.c_uint64), P(C.c_int32)]
     L.tr_voxelize_edges_indexed.argtypes = [vp, P(TrSpaceParams), dp, i64, P(C.c_int32), i64, P(i64), P(C.c_uint64), P(C.c_int32)]

@@ -43,6 +43,7 @@
 #include <limits>
 #include <memory>
 #include <mutex>
+#include <new>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -316,6 +317,13 @@ struct tr_roadmap {
     double share = -1.0;                 // the host threads' share of a shared round (< 0: not chosen yet); follows the two sides' times
     int64_t budget = 0;                  // expansions per search before the kernel hands it back (0: not chosen yet); doubles when
                                          // more than a twentieth of a round came back -- a larger roadmap has longer searches
+    // sweep_search: a single-source sweep over the valid arcs for the few searches that expand a large part of the graph
+    std::mutex sweep_mu;
+    hipStream_t sweep_stream = nullptr;
+    char *sweep_arena = nullptr;         // distances (ordered bit patterns) | validity bytes of this round | flags
+    unsigned long long *sweep_h_dist = nullptr;   // pinned: the distances come back here
+    int64_t sweep_round = -1;            // the round whose validity bytes the arena holds
+    int64_t st_sweeps = 0;               // searches answered this way in the last tr_roadmap_solve
     std::vector<int32_t> h_qs, h_qg;     // host images of what the pending copies read
     std::vector<char> h_vrows;
   } ds;
@@ -382,8 +390,10 @@ constexpr double kLmSlack = 1.0 / (1 << 21);
 // With landmark tables the heuristic is the larger of that distance and the landmark bounds: admissible, so the goal
 // leaves the open list with the same (optimal) cost and, ties apart, the same parents; a vertex whose cost improves after
 // it was expanded is opened again (with the consistent state-space distance alone that never happens).
+// `cap` > 0: the search gives up after that many expansions (*abandoned = true, false returned): tr_roadmap_solve then answers it with a
+// parallel sweep on the device (sweep_search below) -- a search that expands a large part of the graph is a poor fit for one core.
 bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::vector<int32_t> &path, std::vector<int32_t> &path_e,
-           int64_t &expanded) {
+           int64_t &expanded, int64_t cap = 0, bool *abandoned = nullptr) {
   if (sc.node.size() != (size_t)r->V) { sc.node.assign((size_t)r->V, Node{0.0, 0.0, -1, -1, 0u, 0u}); sc.gen = 0; }
   if (++sc.gen == 0) { for (Node &nd : sc.node) nd.stamp = 0u; sc.gen = 1; }
   Node *node = sc.node.data();
@@ -451,6 +461,7 @@ bool astar(const tr_roadmap *r, Scratch &sc, int32_t start, int32_t goal, std::v
       else if (n_ == 3000) sc.trace_f[2] = node[u].g + node[u].h;
       else if (n_ == 4000) sc.trace_f[3] = node[u].g + node[u].h;
     }
+    if (cap > 0 && expanded - expanded0 > cap) { if (abandoned) *abandoned = true; return false; }
     if (u == goal) { found = true; break; }
     const double gu = node[u].g;
     const Arc *arc = r->adj.data() + r->adj_off[u], *end = r->adj.data() + r->adj_off[u + 1];
@@ -735,8 +746,12 @@ void free_search(tr_roadmap *r) {
   if (d.tables) dev_cache().release(d.tables);
   if (d.qarena) dev_cache().release(d.qarena);
   if (d.h_handback) (void)hipHostFree(d.h_handback);
+  if (d.sweep_arena) dev_cache().release(d.sweep_arena);
+  if (d.sweep_h_dist) (void)hipHostFree(d.sweep_h_dist);
+  if (d.sweep_stream) (void)hipStreamDestroy(d.sweep_stream);
   for (hipEvent_t e : d.ev) if (e) (void)hipEventDestroy(e);
-  d = tr_roadmap::DevSearch{};
+  d.~DevSearch();
+  new (&d) tr_roadmap::DevSearch();
 }
 
 // ---- connected components of the roadmap minus the items known invalid ----
@@ -1082,6 +1097,119 @@ bool search_tables(tr_roadmap *r, int64_t want) {
     std::fprintf(stderr, "[tendon_hip] search state: %lld slots x %zu KiB + pool %d / %d / %d tables = %.1f MiB (whatever the roadmap's size)\n",
                  (long long)slots, trk::search_chunk_bytes(d.lc0) >> 10, d.pool_n[1], d.pool_n[2], d.pool_n[3], (double)d.table_bytes / 1048576.0);
   return true;
+}
+
+// ---- a search as a parallel sweep ----
+// A query whose path detours far round new obstacles makes A* expand a large part of the graph (on a 6 x 10^5-vertex roadmap: two of
+// 10 000 queries with 3 - 4 x 10^5 expansions each, 200 ms on a core, ten times that on a wave -- they WERE the round).  Such a search
+// is answered by relaxing every reached vertex's valid arcs at once, sweep after sweep (the scheme of landmark_relax: atomicMin on the
+// bit patterns of the non-negative distances), until a sweep changes nothing; vertices at or beyond the goal's distance are not
+// relaxed (weights are non-negative: nothing through them improves the goal).  The fixed point is Dijkstra's -- and A*'s -- cost bit for
+// bit: the minimum over all paths of the left-to-right rounded sums of their weights.  The path is walked back on the host from the
+// goal along arcs with dist[u] + w == dist[v] exactly (the first such arc of a row: A* keeps the first parent that reaches the
+// final cost, so the two can differ only where two routes tie to the last bit).
+__global__ __launch_bounds__(256) void sweep_relax(const trk::SArc *__restrict__ rows, int D, const uint8_t *__restrict__ vstat,
+                                                   const uint8_t *__restrict__ estat, int64_t V, int32_t goal,
+                                                   unsigned long long *__restrict__ dist, uint32_t *__restrict__ changed) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u >= V) return;
+  const unsigned long long bu = dist[u], bg = dist[goal];
+  if (!(bu < bg)) return;                                      // not reached yet (+inf), or no closer than the goal is already
+  const double du = __longlong_as_double((long long)bu);
+  bool any = false;
+  int64_t row = u;
+  for (int guard = 0; guard < 4096; guard++) {                 // (a vertex's rows: 16 arcs each, chained through the last slot)
+    int64_t next = -1;
+    for (int j = 0; j < D; j++) {
+      const trk::SArc a = rows[row * D + j];
+      if (a.v == trk::SR_ARC_NONE) continue;
+      if (a.v == trk::SR_ARC_MORE) { next = a.e; break; }
+      const int32_t v = a.v & (int32_t)((1u << trk::SR_VBITS) - 1u);
+      if (estat[a.e] == V_INVALID || vstat[v] == V_INVALID) continue;
+      const unsigned long long cb = (unsigned long long)__double_as_longlong(du + a.w);
+      if (cb < dist[v]) { if (atomicMin(&dist[v], cb) > cb) any = true; }
+    }
+    if (next < 0) break;
+    row = next;
+  }
+  if (any) *changed = 1u;
+}
+__global__ __launch_bounds__(256) void sweep_init(unsigned long long *__restrict__ dist, int64_t V, int32_t start) {
+  const int64_t u = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (u < V) dist[u] = u == start ? 0ull : 0x7FF0000000000000ull;
+}
+
+// 1: path found (path: goal ... start, path_e: the edges between them, as astar leaves them), 0: no path, -1: not available (the caller
+// searches on).  Serialised per roadmap (one arena); runs on a stream of its own beside the searches' kernel.
+int sweep_search(tr_roadmap *r, int32_t start, int32_t goal, std::vector<int32_t> &path, std::vector<int32_t> &path_e) {
+  auto &d = r->ds;
+  std::lock_guard<std::mutex> lk(d.sweep_mu);
+  if (d.state != 1 || !d.d_rows) return -1;
+  const int64_t V = r->V, E = r->E;
+  if (hipSetDevice(tr_device(r->ctx)) != hipSuccess) return -1;
+  constexpr int BATCH = 8;
+  auto up = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t b_dist = up((size_t)V * 8), b_vs = up((size_t)V), b_es = up((size_t)std::max<int64_t>(E, 1));
+  if (!d.sweep_stream && hipStreamCreateWithFlags(&d.sweep_stream, hipStreamNonBlocking) != hipSuccess) { d.sweep_stream = nullptr; return -1; }
+  if (!d.sweep_arena && dev_cache().alloc(tr_device(r->ctx), (void **)&d.sweep_arena, b_dist + b_vs + b_es + 256) != hipSuccess) { d.sweep_arena = nullptr; return -1; }
+  if (!d.sweep_h_dist && hipHostMalloc((void **)&d.sweep_h_dist, (size_t)V * 8, hipHostMallocDefault) != hipSuccess) { d.sweep_h_dist = nullptr; return -1; }
+  unsigned long long *d_dist = (unsigned long long *)d.sweep_arena;
+  uint8_t *d_vs = (uint8_t *)(d.sweep_arena + b_dist), *d_es = d_vs + b_vs;
+  uint32_t *d_changed = (uint32_t *)(d.sweep_arena + b_dist + b_vs + b_es);
+  hipStream_t st = d.sweep_stream;
+  bool ok = true;
+  if (d.sweep_round != r->st_rounds) {                          // the round's validity bytes (they do not change inside a round)
+    ok = hipMemcpyAsync(d_vs, r->vstat.data(), (size_t)V, hipMemcpyHostToDevice, st) == hipSuccess &&
+         (E == 0 || hipMemcpyAsync(d_es, r->estat.data(), (size_t)E, hipMemcpyHostToDevice, st) == hipSuccess);
+    if (ok) d.sweep_round = r->st_rounds;
+  }
+  const unsigned grid = (unsigned)((V + 255) / 256);
+  if (ok) { hipLaunchKernelGGL(sweep_init, dim3(grid), dim3(256), 0, st, d_dist, V, start); ok = hipGetLastError() == hipSuccess; }
+  bool converged = false;
+  for (int64_t sweeps = 0; ok && !converged && sweeps < V + BATCH; sweeps += BATCH) {
+    uint32_t flags[BATCH];
+    ok = hipMemsetAsync(d_changed, 0, BATCH * sizeof(uint32_t), st) == hipSuccess;
+    for (int b = 0; ok && b < BATCH; b++) {
+      hipLaunchKernelGGL(sweep_relax, dim3(grid), dim3(256), 0, st, (const trk::SArc *)d.d_rows, (int)trk::SR_D, (const uint8_t *)d_vs, (const uint8_t *)d_es, V, goal,
+                         d_dist, d_changed + b);
+      ok = hipGetLastError() == hipSuccess;
+    }
+    ok = ok && hipMemcpyAsync(flags, d_changed, sizeof(flags), hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+    for (int b = 0; ok && b < BATCH; b++) if (!flags[b]) converged = true;
+  }
+  ok = ok && converged && hipMemcpyAsync(d.sweep_h_dist, d_dist, (size_t)V * 8, hipMemcpyDeviceToHost, st) == hipSuccess && hipStreamSynchronize(st) == hipSuccess;
+  if (!ok) { d.sweep_round = -1; return -1; }
+  const unsigned long long *dist = d.sweep_h_dist;
+  const unsigned long long inf_b = 0x7FF0000000000000ull;
+  if (dist[goal] >= inf_b) return 0;
+  path.clear(); path_e.clear();
+  int32_t v = goal;
+  for (int64_t guard = 0; guard <= V; guard++) {
+    path.push_back(v);
+    if (v == start) { d.st_sweeps++; return 1; }
+    const double dv = __builtin_bit_cast(double, dist[v]);
+    const Arc *arc = r->adj.data() + r->adj_off[(size_t)v], *end = r->adj.data() + r->adj_off[(size_t)v + 1];
+    const Arc *pick = nullptr;
+    for (; arc != end; ++arc) {
+      if (r->estat[(size_t)arc->e] == V_INVALID || r->vstat[(size_t)arc->v] == V_INVALID) continue;
+      const unsigned long long bu = dist[arc->v];
+      if (bu >= inf_b) continue;
+      if (__builtin_bit_cast(double, bu) + arc->w == dv && bu < dist[v]) { pick = arc; break; }
+    }
+    if (!pick) break;                                           // (cannot happen at a fixed point; the caller searches on)
+    path_e.push_back(pick->e);
+    v = pick->v;
+  }
+  path.clear(); path_e.clear();
+  return -1;
+}
+
+// expansions after which a host search is given to sweep_search (0: never): a sixth of the graph, 50 000 at least (well above the kernel's
+// budget: what comes back over that is still a core's work); TENDON_HIP_SEARCH_SWEEP=n
+// overrides (tests: a small n sends most searches that way), =0 switches it off
+int64_t sweep_cap(const tr_roadmap *r) {
+  if (const char *e = std::getenv("TENDON_HIP_SEARCH_SWEEP")) return std::max<long long>(0, std::atoll(e));
+  return r->ds.state == 1 ? std::max<int64_t>(50000, r->V / 6) : 0;
 }
 
 // One round's searches in two halves, so that the host threads can search their share while the kernel runs.
@@ -1530,6 +1658,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   r->st_rounds = r->st_items_checked = r->st_astar_runs = r->st_expanded = 0;
   r->ds.st_queries = r->ds.st_fallbacks = r->ds.st_host_share = r->ds.st_moves = r->ds.st_expanded = r->ds.st_grows = r->ds.st_max_records = 0;
   r->ds.st_kernel_ms = 0; r->ds.st_launches = 0;
+  r->ds.st_sweeps = 0; r->ds.sweep_round = -1;
   r->dc.st_cut = 0;
   if (path_offsets) path_offsets[0] = 0;
   if (n_queries == 0) { if (stats) *stats = tr_roadmap_stats{0, 0, 0, 0}; return TR_OK; }
@@ -1674,6 +1803,17 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
     if (hist) hist_f.assign(active.size() * 4, 0.0);
     // the host threads over a list of positions in `active` (null: all of them)
     std::atomic<bool> walked_in_vain{false};
+    // one query on a host thread: A*, and past sweep_cap expansions the parallel sweep on the device (which failing, A* to the end)
+    const int64_t cap_sweep = sweep_cap(r);
+    auto one_search = [&](Scratch &sc, int64_t q, int64_t &ex) -> bool {
+      bool abandoned = false;
+      bool f = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex, cap_sweep, &abandoned);
+      if (abandoned) {
+        const int m = sweep_search(r, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q]);
+        f = m >= 0 ? m == 1 : astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex);
+      }
+      return f;
+    };
     auto host_search = [&](const std::vector<size_t> *list) {
       const int64_t n_host = list ? (int64_t)list->size() : (int64_t)active.size();
       if (n_host == 0) return;
@@ -1687,7 +1827,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
           const size_t k = list ? (*list)[(size_t)j] : (size_t)j;
           const int64_t q = active[k];
           const int64_t ex0 = ex;
-          found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+          found[k] = one_search(sc, q, ex) ? 1 : 0;
           if (!found[k] && ex - ex0 >= kComponentTrigger) walked_in_vain.store(true, std::memory_order_relaxed);
           if (hist) { hist[k] = ex - ex0; for (int i_ = 0; i_ < 4; i_++) hist_f[k * 4 + i_] = sc.trace_f[i_]; }
         }
@@ -1721,7 +1861,7 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
         Scratch &sc = r->scratch[(size_t)t];
         const int64_t q = active[k];
         const int64_t ex0 = ex;
-        found[k] = astar(r, sc, starts[q], goals[q], paths[(size_t)q], paths_e[(size_t)q], ex) ? 1 : 0;
+        found[k] = one_search(sc, q, ex) ? 1 : 0;
         if (!found[k] && ex - ex0 >= kComponentTrigger) walked_in_vain.store(true, std::memory_order_relaxed);
         if (hist) { hist[k] = ex - ex0; for (int i_ = 0; i_ < 4; i_++) hist_f[k * 4 + i_] = sc.trace_f[i_]; }
       };
@@ -1949,9 +2089,9 @@ int tr_roadmap_solve(tr_roadmap *r, const int32_t *starts, const int32_t *goals,
   laps.lap("paths out");
   if (stats) *stats = tr_roadmap_stats{r->st_rounds, r->st_items_checked, r->st_astar_runs, r->st_expanded};
   if (std::getenv("TENDON_HIP_SEARCH_STATS"))
-    std::fprintf(stderr, "[tendon_hip] searches: mode %d, device state %d%s%s, %lld slots, %lld searches finished on the device, %lld handed back to the host, %lld on the host meanwhile\n",
+    std::fprintf(stderr, "[tendon_hip] searches: mode %d, device state %d%s%s, %lld slots, %lld searches finished on the device, %lld handed back to the host, %lld on the host meanwhile, %lld answered by a sweep\n",
                  smode, r->ds.state, r->ds.why.empty() ? "" : " -- ", r->ds.why.c_str(), (long long)r->ds.slots, (long long)r->ds.st_queries,
-                 (long long)r->ds.st_fallbacks, (long long)r->ds.st_host_share);
+                 (long long)r->ds.st_fallbacks, (long long)r->ds.st_host_share, (long long)r->ds.st_sweeps);
   return TR_OK;
 }
 
@@ -1983,6 +2123,13 @@ int tr_roadmap_release_search_state(tr_roadmap *r, int64_t *bytes_released) {
   const size_t b = release_search_tables(r);
   dev_cache().trim();                                       // (not parked for the next owner: back to the device)
   if (bytes_released) *bytes_released = (int64_t)b;
+  return TR_OK;
+}
+
+int tr_roadmap_search_sweeps(tr_roadmap *r, int64_t *n) {
+  if (!r || !n) return TR_ERR_INVALID_ARG;
+  RmLock lock_(r);
+  *n = r->ds.st_sweeps;
   return TR_OK;
 }
 

@@ -502,6 +502,12 @@ class VoxelCachedLazyPRM:
         self._check(self.lib.tr_roadmap_search_state_bytes(self._rm, self._C.byref(b)))
         return int(b.value)
 
+    def search_sweeps(self):
+        """Searches of the last solve answered by the device sweep instead of A* (tr_roadmap_search_sweeps)."""
+        b = self._C.c_int64(0)
+        self._check(self.lib.tr_roadmap_search_sweeps(self._rm, self._C.byref(b)))
+        return int(b.value)
+
     def reserve_search_state(self, n_queries):
         """Sets the device searches up for rounds of up to n_queries queries now (tr_roadmap_reserve_search_state) instead of inside the first solve."""
         self._check(self.lib.tr_roadmap_reserve_search_state(self._rm, int(n_queries)))

@@ -365,3 +365,36 @@ def test_two_roadmaps_queried_from_two_host_threads_at_once(irt, monkeypatch):
         for w, g in zip(alone, got):
             for k in ("status", "cost", "path_offsets", "path_vertices"):
                 assert np.array_equal(w[k], g[k]), (rep, k)
+
+
+@pytest.mark.parametrize("form", ["eager", "lazy"])
+def test_searches_answered_by_the_device_sweep_equal_the_host_searches(irt, monkeypatch, form):
+    """A host search that passes TENDON_HIP_SEARCH_SWEEP expansions is abandoned and answered by relaxing its source's distances over all
+    valid arcs at once on the device (tr_roadmap_search_sweeps).  With the bar at 40 expansions most searches of this roadmap go that way
+    -- hand-backs of the kernel (a budget of 60) and the host's own share alike: statuses, costs, PATHS, validity and rounds are those of
+    plain A* on the host threads, unreachable goals included."""
+    prm, states = _prm(irt, 3000, 6, seed=23, n_new_spheres=90)
+    prm.prepare(8)
+    rng = np.random.default_rng(6)
+    pairs = rng.integers(0, len(states), size=(1200, 2)).astype(np.int32)
+    eager = form == "eager"
+    monkeypatch.setenv("TENDON_HIP_SEARCH", "host")
+    monkeypatch.setenv("TENDON_HIP_SEARCH_SWEEP", "0")
+    want = _solve(prm, pairs[:, 0], pairs[:, 1], eager)
+    assert prm.search_sweeps() == 0 and (want[0]["status"] == 0).sum() > 300 and (want[0]["status"] == 1).sum() > 0
+    prm.reserve_search_state(1200)                                       # the rows the sweep reads (a round on the device does the same)
+    monkeypatch.setenv("TENDON_HIP_SEARCH_SWEEP", "40")
+    def same_answers(got):                   # (the count of searches run differs: once a search has walked a component in vain, labels answer such queries)
+        for k in ("status", "cost", "path_offsets", "path_vertices"):
+            assert np.array_equal(got[0][k], want[0][k]), k
+        assert np.array_equal(got[2], want[2]) and np.array_equal(got[3], want[3])
+        assert got[1]["rounds"] == want[1]["rounds"] and got[1]["items_checked"] == want[1]["items_checked"]
+
+    got = _solve(prm, pairs[:, 0], pairs[:, 1], eager)
+    assert prm.search_sweeps() > 200
+    same_answers(got)
+    monkeypatch.delenv("TENDON_HIP_SEARCH")                              # the shared schedule: hand-backs over a budget of 60 meet the bar too
+    monkeypatch.setenv("TENDON_HIP_SEARCH_BUDGET", "60")
+    got = _solve(prm, pairs[:, 0], pairs[:, 1], eager)
+    assert prm.search_sweeps() > 50 and prm.search_stats["handed_back"] > 50
+    same_answers(got)
