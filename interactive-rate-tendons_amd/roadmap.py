@@ -323,6 +323,18 @@ class _Paths:
     def __iter__(self):
         return (self[q] for q in range(len(self)))
 
+    def tolist(self):
+        """The paths as a list of int32 arrays (what solve() returned before round 4)."""
+        return [self[q] for q in range(len(self))]
+
+    def __eq__(self, other):
+        try:
+            return len(self) == len(other) and all(np.array_equal(a, b) for a, b in zip(self, other))
+        except TypeError:
+            return NotImplemented
+
+    __hash__ = None
+
 
 class VoxelCachedLazyPRM:
     """The query side of motion_planning::VoxelCachedLazyPRM on a roadmap with voxel caches (BASELINE config 5):
