@@ -91,18 +91,23 @@ class HostTeam {
         if (t < T_) f = fn_;
       }
       if (f) {
+        inside() = true;
         (*f)(t);
+        inside() = false;
         std::lock_guard<std::mutex> lk(mu_);
         if (--running_ == 0) done_.notify_all();
       }
     }
   }
+  static bool &inside() { static thread_local bool in = false; return in; }   // this thread is running a section of the team's job
  public:
   static HostTeam &get() { static HostTeam *team = new HostTeam(); return *team; }
   // fn(1) .. fn(T - 1) on the team's threads, fn(0) on the caller's; false (nothing run) when the team is busy
   bool run(int T, const std::function<void(int)> &fn) {
+    if (inside()) return false;                 // (a section started from inside a section: threads of its own, as when the team is busy)
     std::unique_lock<std::mutex> job(job_mu_, std::try_to_lock);
     if (!job.owns_lock()) return false;
+    struct Mark { Mark() { inside() = true; } ~Mark() { inside() = false; } } mark;
     {
       std::lock_guard<std::mutex> lk(mu_);
       while ((int)th_.size() < T - 1) { const int t = (int)th_.size() + 1; th_.emplace_back([this, t] { worker(t); }); th_.back().detach(); }
