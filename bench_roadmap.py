@@ -350,11 +350,11 @@ def run(argv=None):
         t0 = time.perf_counter()
         d64 = prm.solveWithRoadmap(pairs[:, 0], pairs[:, 1])
         t_d64.append(time.perf_counter() - t0)
-    assert np.array_equal(lazy["status"], e64["status"]) and np.array_equal(lazy["cost"], e64["cost"])
-    assert np.array_equal(lazy["status"], d64["status"]) and np.array_equal(lazy["cost"], d64["cost"])
+    same64 = bool(np.array_equal(lazy["status"], e64["status"]) and np.array_equal(lazy["cost"], e64["cost"]) and
+                  np.array_equal(lazy["status"], d64["status"]) and np.array_equal(lazy["cost"], d64["cost"]))   # (reported, not asserted: this is the bench)
     lm64 = {"landmark_tables_s": t_prepare64, "queries_per_s_validity_known": nq / min(t_e64), "seconds_validity_known": min(t_e64),
             "queries_per_s_default_schedule": nq / min(t_d64), "seconds_default_schedule": min(t_d64), "expanded": st_e64["expanded"],
-            "searches": st_e64["searches"], "same_statuses_and_costs": True}
+            "searches": st_e64["searches"], "same_statuses_and_costs": same64}
     assert np.array_equal(lazy["status"], eager["status"]) and np.array_equal(lazy["cost"], eager["cost"])
     assert np.array_equal(lazy["status"], plain["status"]) and np.array_equal(lazy["cost"], plain["cost"])
     assert np.array_equal(lazy["path_vertices"], plain["path_vertices"])
